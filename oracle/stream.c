@@ -1,0 +1,489 @@
+/* TEST INFRASTRUCTURE ONLY (see knz_oracle.h).
+ * Stream framing restated with jobs=1 semantics (output is independent of the job count):
+ *   header        io/CompressedOutputStream.cpp:277-342, io/CompressedInputStream.cpp:511-663
+ *   block encode  io/CompressedOutputStream.cpp:651-898 (EncodingTask::run)
+ *   block decode  io/CompressedInputStream.cpp:790-1041 (DecodingTask::run)
+ *   sequencing    transform/TransformSequence.hpp:88-162 (forward), :165-247 (inverse), :250-265
+ *   buffers       io/CompressedOutputStream.cpp:140-145,447-473,720-739 ; CompressedInputStream.cpp:273-282
+ *   type ids      transform/TransformFactory.hpp:49-73,100-137 ; entropy/EntropyEncoderFactory.hpp:37-52
+ *   checksums     util/XXHash.hpp:61-115,153-230 (kanzi's XXHash64 merge step uses 32-bit style shifts)
+ */
+#include "knz_oracle.h"
+#include <ctype.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define KNZ_MAGIC 0x4B414E5Au
+#define KNZ_VERSION 6
+#define DEFAULT_BUFFER_SIZE (256 * 1024)
+/* src/Error.hpp:26-48 */
+#define ERR_BLOCK_SIZE 2
+#define ERR_INVALID_CODEC 3
+#define ERR_READ_FILE 11
+#define ERR_WRITE_FILE 12
+#define ERR_PROCESS_BLOCK 13
+#define ERR_INVALID_FILE 15
+#define ERR_STREAM_VERSION 16
+#define ERR_INVALID_PARAM 18
+#define ERR_CRC_CHECK 19
+
+static int ilog2_64(uint64_t x) { return 63 ^ __builtin_clzll(x); }
+static int ilog2(uint32_t x) { return 31 ^ __builtin_clz(x); }
+
+static uint32_t rd32le(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+static uint64_t rd64le(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
+
+uint32_t knzo_xxhash32(const uint8_t* data, size_t len, uint32_t seed)
+{
+    const uint32_t P1 = 2654435761u, P2 = 2246822519u, P3 = 3266489917u, P4 = 668265263u, P5 = 374761393u;
+    const int length = (int)len;
+    uint32_t h32;
+    int idx = 0;
+    if (length >= 16) {
+        const int end16 = length - 16;
+        uint32_t v1 = seed + P1 + P2, v2 = seed + P2, v3 = seed, v4 = seed - P1;
+        do {
+            v1 += rd32le(&data[idx]) * P2;      v1 = ((v1 << 13) | (v1 >> 19)) * P1;
+            v2 += rd32le(&data[idx + 4]) * P2;  v2 = ((v2 << 13) | (v2 >> 19)) * P1;
+            v3 += rd32le(&data[idx + 8]) * P2;  v3 = ((v3 << 13) | (v3 >> 19)) * P1;
+            v4 += rd32le(&data[idx + 12]) * P2; v4 = ((v4 << 13) | (v4 >> 19)) * P1;
+            idx += 16;
+        } while (idx <= end16);
+        h32 = ((v1 << 1) | (v1 >> 31)) + ((v2 << 7) | (v2 >> 25)) + ((v3 << 12) | (v3 >> 20)) + ((v4 << 18) | (v4 >> 14));
+    } else {
+        h32 = seed + P5;
+    }
+    h32 += (uint32_t)length;
+    while (idx <= length - 4) {
+        h32 += rd32le(&data[idx]) * P3;
+        h32 = ((h32 << 17) | (h32 >> 15)) * P4;
+        idx += 4;
+    }
+    while (idx < length) {
+        h32 += (uint32_t)data[idx] * P5;
+        h32 = ((h32 << 11) | (h32 >> 21)) * P1;
+        idx++;
+    }
+    h32 ^= h32 >> 15; h32 *= P2; h32 ^= h32 >> 13; h32 *= P3;
+    return h32 ^ (h32 >> 16);
+}
+
+static uint64_t xx64_round(uint64_t acc, uint64_t val)
+{
+    acc += val * 0xC2B2AE3D27D4EB4Full;
+    return ((acc << 31) | (acc >> 33)) * 0x9E3779B185EBCA87ull;
+}
+
+uint64_t knzo_xxhash64(const uint8_t* data, size_t len, uint64_t seed)
+{
+    const uint64_t P1 = 0x9E3779B185EBCA87ull, P2 = 0xC2B2AE3D27D4EB4Full, P3 = 0x165667B19E3779F9ull,
+                   P4 = 0x85EBCA77C2B2AE63ull, P5 = 0x27D4EB2F165667C5ull;
+    const int length = (int)len;
+    uint64_t h64;
+    int idx = 0;
+    if (length >= 32) {
+        const int length32 = length - 32;
+        uint64_t v1 = seed + P1 + P2, v2 = seed + P2, v3 = seed, v4 = seed - P1;
+        do {
+            v1 = xx64_round(v1, rd64le(&data[idx]));
+            v2 = xx64_round(v2, rd64le(&data[idx + 8]));
+            v3 = xx64_round(v3, rd64le(&data[idx + 16]));
+            v4 = xx64_round(v4, rd64le(&data[idx + 24]));
+            idx += 32;
+        } while (idx <= length32);
+        /* XXHash.hpp:186-187: shifts as written in the reference (not 64-bit rotations) */
+        h64 = ((v1 << 1) | (v1 >> 31)) + ((v2 << 7) | (v2 >> 25)) + ((v3 << 12) | (v3 >> 20)) + ((v4 << 18) | (v4 >> 14));
+        h64 = (h64 ^ xx64_round(0, v1)) * P1 + P4;
+        h64 = (h64 ^ xx64_round(0, v2)) * P1 + P4;
+        h64 = (h64 ^ xx64_round(0, v3)) * P1 + P4;
+        h64 = (h64 ^ xx64_round(0, v4)) * P1 + P4;
+    } else {
+        h64 = seed + P5;
+    }
+    h64 += (uint64_t)(int64_t)length;
+    while (idx + 8 <= length) {
+        h64 ^= xx64_round(0, rd64le(&data[idx]));
+        h64 = ((h64 << 27) | (h64 >> 37)) * P1 + P4;
+        idx += 8;
+    }
+    while (idx + 4 <= length) {
+        h64 ^= (uint64_t)rd32le(&data[idx]) * P1;
+        h64 = ((h64 << 23) | (h64 >> 41)) * P2 + P3;
+        idx += 4;
+    }
+    while (idx < length) {
+        h64 ^= (uint64_t)data[idx] * P5;
+        h64 = ((h64 << 11) | (h64 >> 53)) * P1;
+        idx++;
+    }
+    h64 ^= h64 >> 33; h64 *= P2; h64 ^= h64 >> 29; h64 *= P3;
+    return h64 ^ (h64 >> 32);
+}
+
+static int token_type(const char* s, size_t len)
+{
+    static const struct { const char* n; int t; } T[] = {
+        {"NONE", 0}, {"BWT", 1}, {"BWTS", 2}, {"LZ", 3}, {"RLT", 5}, {"ZRLT", 6}, {"MTFT", 7}, {"RANK", 8},
+        {"EXE", 9}, {"TEXT", 10}, {"ROLZ", 11}, {"ROLZX", 12}, {"SRT", 13}, {"LZP", 14}, {"MM", 15},
+        {"LZX", 16}, {"UTF", 17}, {"PACK", 18}, {"DNA", 19} };
+    char up[16];
+    if (len >= sizeof(up)) return -1;
+    for (size_t i = 0; i < len; i++) up[i] = (char)toupper((unsigned char)s[i]);
+    up[len] = 0;
+    for (size_t i = 0; i < sizeof(T) / sizeof(T[0]); i++)
+        if (strcmp(T[i].n, up) == 0) return T[i].t;
+    return -1;
+}
+
+/* TransformFactory.hpp:100-137. Returns ~0 on error. */
+uint64_t knzo_transform_type(const char* names)
+{
+    uint64_t res = 0;
+    int shift = 42, n = 0;
+    const char* p = names;
+    if (strchr(names, '+') == NULL) {
+        const int t = token_type(names, strlen(names));
+        return t < 0 ? ~0ull : ((uint64_t)t << 42);
+    }
+    while (1) {
+        const char* q = strchr(p, '+');
+        const size_t len = q ? (size_t)(q - p) : strlen(p);
+        if (++n > 8) return ~0ull;
+        const int t = token_type(p, len);
+        if (t < 0) return ~0ull;
+        if (t != 0) { res |= ((uint64_t)t << shift); shift -= 6; }
+        if (!q) break;
+        p = q + 1;
+    }
+    return res;
+}
+
+int knzo_entropy_type(const char* name)
+{
+    static const struct { const char* n; int t; } T[] = {
+        {"NONE", 0}, {"HUFFMAN", 1}, {"FPAQ", 2}, {"RANGE", 4}, {"ANS0", 5}, {"CM", 6}, {"TPAQ", 7}, {"ANS1", 8}, {"TPAQX", 9} };
+    char up[16];
+    const size_t len = strlen(name);
+    if (len >= sizeof(up)) return -1;
+    for (size_t i = 0; i < len; i++) up[i] = (char)toupper((unsigned char)name[i]);
+    up[len] = 0;
+    for (size_t i = 0; i < sizeof(T) / sizeof(T[0]); i++)
+        if (strcmp(T[i].n, up) == 0) return T[i].t;
+    return -1;
+}
+
+/* Sequence of transform ids as TransformFactory::newTransform builds it (:208-222). */
+static int seq_tokens(uint64_t ttype, int* tok)
+{
+    int nb = 0;
+    for (int i = 0; i < 8; i++) {
+        const int t = (int)((ttype >> (42 - 6 * i)) & 63);
+        if (t != 0 || i == 0) tok[nb++] = t;
+    }
+    return nb;
+}
+
+static int max_encoded_len(int t, int n)
+{
+    switch (t) {
+    case 1: return n + 33;
+    case 13: return n + 1024;
+    case 5: return (n <= 512) ? n + 32 : n;
+    default: return n;
+    }
+}
+
+static int seq_required(const int* tok, int nb, int n)
+{
+    int req = n;
+    for (int i = 0; i < nb; i++) {
+        const int nx = max_encoded_len(tok[i], req);
+        if (nx > req) req = nx;
+    }
+    return req;
+}
+
+static int supported_transform(int t) { return t == 0 || t == 1 || t == 5 || t == 6 || t == 7 || t == 13; }
+static int supported_entropy(int e) { return e == 0 || e == 1 || e == 2 || e == 5 || e == 8; }
+
+/* TransformSequence::forward with explicit capacities. data = block input (capacity dataCap),
+ * result written to 'outbuf' (capacity bufCap). Returns post-transform length. */
+static int seq_forward(const uint8_t* in, int count, const int* tok, int nb, int etype,
+                       int dataCap, int bufCap, uint8_t* outbuf, int* skipFlagsOut)
+{
+    const int blockSize = count;
+    const int requiredSize = seq_required(tok, nb, blockSize);
+    int skip = 0xFF;
+    /* physical buffers: 0 = input(data), 1 = output(buffer), 2 = temp */
+    int capA = dataCap, capB = bufCap;
+    uint8_t* A = (uint8_t*)malloc((size_t)(capA > requiredSize ? capA : requiredSize) + 16);
+    uint8_t* B = (uint8_t*)malloc((size_t)(capB > requiredSize ? capB : requiredSize) + 16);
+    memcpy(A, in, (size_t)count);
+    uint8_t* pin = A; uint8_t* pout = B;
+    int capIn = capA, capOut = capB;
+    int swaps = 0;
+    for (int i = 0; i < nb; i++) {
+        if (capOut < requiredSize) capOut = requiredSize;   /* reallocation path, :104-115 */
+        int outLen = 0;
+        if (!knzo_transform_forward(tok[i], pin, count, pout, capOut, etype, &outLen)) continue;
+        skip &= ~(1 << (7 - i));
+        count = outLen;
+        { uint8_t* tp = pin; pin = pout; pout = tp; const int tc = capIn; capIn = capOut; capOut = tc; }
+        swaps++;
+    }
+    if ((swaps & 1) == 0) {
+        if (count > bufCap || count > capIn) skip = 0xFF;
+        else memcpy(outbuf, pin, (size_t)count);
+    } else {
+        memcpy(outbuf, pin, (size_t)count);   /* pin is the 'output' physical buffer after an odd swap count */
+    }
+    free(A); free(B);
+    *skipFlagsOut = skip;
+    return count;
+}
+
+int64_t knzo_encode_block(const uint8_t* in, int n, uint64_t ttype, int etype, int checksumBits,
+                          int dataCap, int bufCap, uint8_t* out, size_t cap, int* skipFlagsOut, int* postLenOut)
+{
+    int mode = 0;
+    uint64_t checksum = 0;
+    if (checksumBits == 32) checksum = knzo_xxhash32(in, (size_t)n, KNZ_MAGIC);
+    else if (checksumBits == 64) checksum = knzo_xxhash64(in, (size_t)n, KNZ_MAGIC);
+    if (n <= 15) { ttype = 0; etype = 0; mode |= 0x80; }
+    int tok[8];
+    const int nb = seq_tokens(ttype, tok);
+    for (int i = 0; i < nb; i++) if (!supported_transform(tok[i])) return -2;
+    if (!supported_entropy(etype)) return -2;
+    const int requiredSize = seq_required(tok, nb, n);
+    if (bufCap < requiredSize) bufCap = requiredSize;
+    if (dataCap < n) dataCap = n;
+    uint8_t* buffer = (uint8_t*)malloc((size_t)bufCap + 16);
+    int skipFlags = 0xFF;
+    const int postLen = seq_forward(in, n, tok, nb, etype, dataCap, bufCap, buffer, &skipFlags);
+    const int dataSize = (postLen < 256) ? 1 : (ilog2((uint32_t)postLen) >> 3) + 1;
+    if (dataSize > 4) { free(buffer); return -1; }
+    mode |= ((dataSize - 1) & 3) << 5;
+    knzo_bw w;
+    knzo_bw_init(&w, out, cap);
+    if ((mode & 0x80) || nb <= 4) {
+        mode |= (skipFlags >> 4);
+        knzo_bw_bits(&w, (uint64_t)mode, 8);
+    } else {
+        mode |= 0x10;
+        knzo_bw_bits(&w, (uint64_t)mode, 8);
+        knzo_bw_bits(&w, (uint64_t)skipFlags, 8);
+    }
+    knzo_bw_bits(&w, (uint64_t)postLen, 8u * (unsigned)dataSize);
+    if (checksumBits == 32) knzo_bw_bits(&w, checksum & 0xFFFFFFFFull, 32);
+    else if (checksumBits == 64) knzo_bw_bits(&w, checksum, 64);
+    int r;
+    switch (etype) {
+    case 0: r = knzo_none_encode_bw(&w, buffer, (uint32_t)postLen); break;
+    case 1: r = knzo_huffman_encode_bw(&w, buffer, (uint32_t)postLen); break;
+    case 2: r = knzo_fpaq_encode_bw(&w, buffer, (uint32_t)postLen); break;
+    case 5: r = knzo_ans_encode_bw(&w, buffer, (uint32_t)postLen, 0); break;
+    default: r = knzo_ans_encode_bw(&w, buffer, (uint32_t)postLen, 1); break;
+    }
+    free(buffer);
+    if (r != postLen || w.overflow) return -1;
+    if (skipFlagsOut) *skipFlagsOut = skipFlags;
+    if (postLenOut) *postLenOut = postLen;
+    return (int64_t)w.bits;
+}
+
+/* DecodingTask::run for one block's private bits. Returns 0 or an Error code. */
+int knzo_decode_block(const uint8_t* in, uint64_t nbits, uint64_t ttype, int etype, int checksumBits,
+                      int blockSize, uint8_t* out, int outCap, int* outLen)
+{
+    *outLen = 0;
+    knzo_br r;
+    knzo_br_init(&r, in, nbits);
+    const int mode = (int)knzo_br_bits(&r, 8);
+    int skipFlags = 0;
+    if (mode & 0x80) { ttype = 0; etype = 0; }
+    else if (mode & 0x10) skipFlags = (int)knzo_br_bits(&r, 8);
+    else skipFlags = ((mode << 4) | 0x0F) & 0xFF;
+    const int dataSize = 1 + ((mode >> 5) & 3);
+    const int pre = (int)knzo_br_bits(&r, 8u * (unsigned)dataSize);
+    const uint32_t blkLen = (uint32_t)((blockSize + 512 > blockSize + (blockSize >> 4)) ? blockSize + 512 : blockSize + (blockSize >> 4));
+    uint32_t mts = blkLen + blkLen / 2;
+    if (mts < 2048) mts = 2048;
+    if (mts > (1u << 30)) mts = 1u << 30;
+    if (r.error || pre <= 0 || (uint32_t)pre > mts) return ERR_READ_FILE;
+    uint64_t checksum1 = 0;
+    if (checksumBits == 32) checksum1 = knzo_br_bits(&r, 32);
+    else if (checksumBits == 64) checksum1 = knzo_br_bits(&r, 64);
+    int tok[8];
+    const int nb = seq_tokens(ttype, tok);
+    for (int i = 0; i < nb; i++) if (!supported_transform(tok[i])) return ERR_INVALID_CODEC;
+    if (!supported_entropy(etype)) return ERR_INVALID_CODEC;
+    const int rbytes = (int)((nbits + 7) >> 3);
+    int dataCap = (int)blkLen > rbytes ? (int)blkLen : rbytes;
+    int bufCap = (int)blkLen > pre + 512 ? (int)blkLen : pre + 512;
+    const int big = dataCap > bufCap ? dataCap : bufCap;
+    uint8_t* A = (uint8_t*)malloc((size_t)big + 16);
+    uint8_t* B = (uint8_t*)malloc((size_t)big + 16);
+    int d;
+    switch (etype) {
+    case 0: d = knzo_none_decode_br(&r, A, (uint32_t)pre); break;
+    case 1: d = knzo_huffman_decode_br(&r, A, (uint32_t)pre); break;
+    case 2: d = knzo_fpaq_decode_br(&r, A, (uint32_t)pre); break;
+    case 5: d = knzo_ans_decode_br(&r, A, (uint32_t)pre, 0); break;
+    default: d = knzo_ans_decode_br(&r, A, (uint32_t)pre, 1); break;
+    }
+    if (d != pre) { free(A); free(B); return ERR_PROCESS_BLOCK; }
+    /* TransformSequence::inverse :165-247 */
+    int count = pre;
+    int res = 1;
+    uint8_t* pin = A; uint8_t* pout = B;
+    if (count > dataCap) res = 0;
+    if (res && skipFlags != 0xFF) {
+        for (int i = nb - 1; i >= 0; i--) {
+            if (skipFlags & (1 << (7 - i))) continue;
+            int ol = 0;
+            res = knzo_transform_inverse(tok[i], pin, count, pout, dataCap, &ol);
+            if (!res) break;
+            count = ol;
+            { uint8_t* tp = pin; pin = pout; pout = tp; }
+        }
+    }
+    if (!res) { free(A); free(B); return ERR_PROCESS_BLOCK; }
+    if (count > outCap) { free(A); free(B); return ERR_PROCESS_BLOCK; }
+    memcpy(out, pin, (size_t)count);
+    free(A); free(B);
+    if (checksumBits == 32) {
+        if (knzo_xxhash32(out, (size_t)count, KNZ_MAGIC) != (uint32_t)checksum1) return ERR_CRC_CHECK;
+    } else if (checksumBits == 64) {
+        if (knzo_xxhash64(out, (size_t)count, KNZ_MAGIC) != checksum1) return ERR_CRC_CHECK;
+    }
+    *outLen = count;
+    return 0;
+}
+
+static uint32_t header_checksum(uint32_t ckSize, uint32_t etype, uint64_t ttype, uint32_t blockSize, int szMask, uint64_t size)
+{
+    const uint32_t HASH = 0x1E35A7BDu;
+    uint32_t c = HASH * (0x01030507u * KNZ_VERSION);
+    c ^= HASH * (uint32_t)~ckSize;
+    c ^= HASH * (uint32_t)~etype;
+    c ^= HASH * (uint32_t)((~ttype) >> 32);
+    c ^= HASH * (uint32_t)~ttype;
+    c ^= HASH * (uint32_t)~blockSize;
+    if (szMask != 0) {
+        c ^= HASH * (uint32_t)((~size) >> 32);
+        c ^= HASH * (uint32_t)~size;
+    }
+    return ((c >> 23) ^ (c >> 3)) & 0xFFFFFFu;
+}
+
+int knzo_compress(const uint8_t* in, size_t n, const char* transform, const char* entropy,
+                  int blockSize, int checksum, uint64_t origSize, int headerless,
+                  uint8_t* out, size_t cap, size_t* outLen)
+{
+    *outLen = 0;
+    const uint64_t ttype = knzo_transform_type(transform);
+    const int etype = knzo_entropy_type(entropy);
+    if (ttype == ~0ull || etype < 0) return ERR_INVALID_PARAM;
+    if (blockSize < 1024 || blockSize > (1 << 30) || (blockSize & -16) != blockSize) return ERR_INVALID_PARAM;
+    if (checksum != 0 && checksum != 32 && checksum != 64) return ERR_INVALID_PARAM;
+    knzo_bw w;
+    knzo_bw_init(&w, out, cap);
+    if (!headerless) {
+        const uint32_t ckSize = checksum == 32 ? 1 : (checksum == 64 ? 2 : 0);
+        knzo_bw_bits(&w, KNZ_MAGIC, 32);
+        knzo_bw_bits(&w, KNZ_VERSION, 4);
+        knzo_bw_bits(&w, ckSize, 2);
+        knzo_bw_bits(&w, (uint64_t)etype, 5);
+        knzo_bw_bits(&w, ttype, 48);
+        knzo_bw_bits(&w, (uint64_t)(blockSize >> 4), 28);
+        const int szMask = (origSize == 0 || origSize >= (1ull << 48)) ? 0 : (ilog2_64(origSize) >> 4) + 1;
+        knzo_bw_bits(&w, (uint64_t)szMask, 2);
+        if (szMask) knzo_bw_bits(&w, origSize, 16u * (unsigned)szMask);
+        knzo_bw_bits(&w, 0, 15);
+        knzo_bw_bits(&w, header_checksum(ckSize, (uint32_t)etype, ttype, (uint32_t)blockSize, szMask, origSize), 24);
+    }
+    int dataCap = blockSize + (blockSize >> 3);
+    if (dataCap < DEFAULT_BUFFER_SIZE) dataCap = DEFAULT_BUFFER_SIZE;
+    int bufCap = 0;
+    const size_t tmpCap = (size_t)blockSize + ((size_t)blockSize >> 1) + 65536;
+    uint8_t* tmp = (uint8_t*)malloc(tmpCap);
+    size_t off = 0;
+    while (off < n) {
+        const int len = (n - off < (size_t)blockSize) ? (int)(n - off) : blockSize;
+        int tok[8];
+        const int nb = seq_tokens(len <= 15 ? 0 : ttype, tok);
+        const int req = seq_required(tok, nb, len);
+        if (bufCap < req) bufCap = req;
+        int skipFlags, postLen;
+        const int64_t bits = knzo_encode_block(in + off, len, ttype, etype, checksum, dataCap, bufCap, tmp, tmpCap, &skipFlags, &postLen);
+        if (bits < 0) { free(tmp); return ERR_PROCESS_BLOCK; }
+        /* _data may grow after the transform: CompressedOutputStream.cpp:774-783 */
+        {
+            int bs2 = len + (len >> 3);
+            if (bs2 < postLen) bs2 = postLen;
+            if (bs2 < DEFAULT_BUFFER_SIZE) bs2 = DEFAULT_BUFFER_SIZE;
+            if (dataCap < bs2) dataCap = bs2;
+        }
+        const uint64_t written = (uint64_t)bits;
+        const unsigned lw = (written < 8) ? 3u : (unsigned)ilog2((uint32_t)(written >> 3)) + 4u;
+        knzo_bw_bits(&w, lw - 3, 5);
+        knzo_bw_bits(&w, written, lw);
+        knzo_bw_bytes(&w, tmp, written);
+        off += (size_t)len;
+    }
+    free(tmp);
+    knzo_bw_bits(&w, 0, 5);
+    knzo_bw_bits(&w, 0, 3);
+    if (w.overflow) return ERR_WRITE_FILE;
+    *outLen = (size_t)((w.bits + 7) >> 3);
+    return 0;
+}
+
+int knzo_decompress(const uint8_t* in, size_t inLen, uint8_t* out, size_t cap, size_t* outLen)
+{
+    *outLen = 0;
+    knzo_br r;
+    knzo_br_init(&r, in, 8ull * inLen);
+    if ((uint32_t)knzo_br_bits(&r, 32) != KNZ_MAGIC) return ERR_INVALID_FILE;
+    const int ver = (int)knzo_br_bits(&r, 4);
+    if (ver != KNZ_VERSION) return ERR_STREAM_VERSION;   /* older versions: out of scope */
+    const uint32_t ckSize = (uint32_t)knzo_br_bits(&r, 2);
+    if (ckSize == 3) return ERR_INVALID_FILE;
+    const int etype = (int)knzo_br_bits(&r, 5);
+    const uint64_t ttype = knzo_br_bits(&r, 48);
+    const int blockSize = (int)(knzo_br_bits(&r, 28) << 4);
+    if (blockSize < 1024 || blockSize > (1 << 30)) return ERR_BLOCK_SIZE;
+    const int szMask = (int)knzo_br_bits(&r, 2);
+    uint64_t size = 0;
+    if (szMask) size = knzo_br_bits(&r, 16u * (unsigned)szMask);
+    knzo_br_bits(&r, 15);
+    const uint32_t ck1 = (uint32_t)knzo_br_bits(&r, 24);
+    if (r.error) return ERR_INVALID_FILE;
+    if (ck1 != header_checksum(ckSize, (uint32_t)etype, ttype, (uint32_t)blockSize, szMask, size)) return ERR_CRC_CHECK;
+    const int checksumBits = ckSize == 1 ? 32 : (ckSize == 2 ? 64 : 0);
+    uint8_t* tmp = NULL;
+    size_t tmpCap = 0;
+    size_t off = 0;
+    int err = 0;
+    while (1) {
+        const unsigned lr = 3 + (unsigned)knzo_br_bits(&r, 5);
+        const uint64_t bits = knzo_br_bits(&r, lr);
+        if (r.error) { err = ERR_READ_FILE; break; }
+        if (bits == 0) break;
+        if (bits > (1ull << 34)) { err = ERR_BLOCK_SIZE; break; }
+        const size_t nb = (size_t)((bits + 7) >> 3);
+        if (tmpCap < nb + 8) { free(tmp); tmpCap = nb + 8; tmp = (uint8_t*)malloc(tmpCap); }
+        memset(tmp, 0, nb + 8);
+        knzo_br_bytes(&r, tmp, bits);
+        if (r.error) { err = ERR_READ_FILE; break; }
+        int ol = 0;
+        const size_t room = cap - off;
+        const int outCap = room > (size_t)0x7FFFFFFF ? 0x7FFFFFFF : (int)room;
+        err = knzo_decode_block(tmp, bits, ttype, etype, checksumBits, blockSize, out + off, outCap, &ol);
+        if (err) break;
+        off += (size_t)ol;
+    }
+    free(tmp);
+    *outLen = off;
+    return err;
+}

@@ -1,0 +1,579 @@
+/* TEST INFRASTRUCTURE ONLY (see knz_oracle.h).
+ * Byte transforms restated from the reference:
+ *   ZRLT  transform/ZRLT.cpp:27-117 (forward), :119-215 (inverse)
+ *   MTFT  transform/SBRT.cpp:46-97, :99-145 with MODE_MTF masks (:28-31) == classic move-to-front
+ *   SRT   transform/SRT.cpp:22-109, :111-204, :206-244 (preprocess), :246-308 (header)
+ *   RLT   transform/RLT.cpp:39-221, :223-245, :247-369 ; Global.cpp:354-397 (detectSimpleType)
+ * Control flow is intentionally kept close to the reference where results depend on it
+ * (capacity checks, RLT's 4-byte stride scan).
+ */
+#include "knz_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+
+static int ilog2(uint32_t x) { return 31 ^ __builtin_clz(x); }
+
+/* ------------------------------------------------------------------ ZRLT */
+static int zrlt_forward(const uint8_t* src, int length, uint8_t* dst, int dstCap, int* outLen)
+{
+    *outLen = 0;
+    if (length == 0) return 1;
+    if (dstCap < length) return 0;                       /* getMaxEncodedLength(n) == n, ZRLT.hpp:43 */
+    uint32_t srcIdx = 0, dstIdx = 0;
+    const uint32_t srcEnd = (uint32_t)length;
+    const uint32_t dstEnd = (uint32_t)dstCap;
+    int res = 1;
+    while (srcIdx < srcEnd) {
+        if (src[srcIdx] == 0) {
+            uint32_t runLength = 1;
+            while ((srcIdx + runLength < srcEnd) && src[srcIdx + runLength] == 0) runLength++;
+            srcIdx += runLength;
+            runLength++;
+            const uint32_t needed = (uint32_t)ilog2(runLength);
+            if (needed > dstEnd - dstIdx) { res = 0; break; }
+            int log = (int)needed;
+            while (log > 0) {
+                log--;
+                dst[dstIdx++] = (uint8_t)((runLength >> log) & 1);
+            }
+            continue;
+        }
+        const int val = src[srcIdx];
+        const uint32_t needed = (val >= 0xFE) ? 2u : 1u;
+        if (needed > dstEnd - dstIdx) { res = 0; break; }
+        if (val >= 0xFE) {
+            dst[dstIdx] = 0xFF;
+            dst[dstIdx + 1] = (uint8_t)(val - 0xFE);
+            dstIdx++;
+        } else {
+            dst[dstIdx] = (uint8_t)(val + 1);
+        }
+        srcIdx++;
+        dstIdx++;
+    }
+    *outLen = (int)dstIdx;
+    return res && (srcIdx == srcEnd);
+}
+
+static int zrlt_inverse(const uint8_t* src, int length, uint8_t* dst, int dstCap, int* outLen)
+{
+    *outLen = 0;
+    if (length < 0) return 0;
+    if (length == 0) return 1;
+    uint32_t srcIdx = 0, dstIdx = 0;
+    const uint32_t srcEnd = (uint32_t)length;
+    const uint32_t dstEnd = (uint32_t)dstCap;
+    uint32_t runLength = 0;
+
+    while (1) {
+        uint32_t val = src[srcIdx];
+        if (val <= 1) {
+            runLength = 1;
+            do {
+                runLength += (runLength + val);
+                srcIdx++;
+                if (srcIdx >= srcEnd) goto End;
+                val = src[srcIdx];
+            } while (val <= 1);
+            runLength--;
+            if (runLength > 0) {
+                if (runLength >= dstEnd - dstIdx) goto End;
+                memset(&dst[dstIdx], 0, runLength);
+                dstIdx += runLength;
+                runLength = 0;
+                continue;
+            }
+        }
+        if (dstIdx >= dstEnd) return 0;
+        if (val == 0xFF) {
+            srcIdx++;
+            if (srcIdx >= srcEnd) return 0;
+            dst[dstIdx] = (uint8_t)(0xFE + src[srcIdx]);
+        } else {
+            dst[dstIdx] = (uint8_t)(val - 1);
+        }
+        srcIdx++;
+        dstIdx++;
+        if ((srcIdx >= srcEnd) || (dstIdx >= dstEnd)) break;
+    }
+End:
+    if (runLength > 0) {
+        runLength--;
+        if (runLength > dstEnd - dstIdx) return 0;
+        if (runLength > 0) {
+            memset(&dst[dstIdx], 0, runLength);
+            dstIdx += runLength;
+        }
+    }
+    *outLen = (int)dstIdx;
+    return srcIdx == srcEnd;
+}
+
+/* ------------------------------------------------------------------ MTFT */
+static int mtft_forward(const uint8_t* src, int count, uint8_t* dst, int dstCap, int* outLen)
+{
+    *outLen = 0;
+    if (count == 0) return 1;
+    if (count < 0 || count > dstCap) return 0;
+    uint8_t r2s[256];
+    for (int i = 0; i < 256; i++) r2s[i] = (uint8_t)i;
+    for (int i = 0; i < count; i++) {
+        const uint8_t c = src[i];
+        int r = 0;
+        while (r2s[r] != c) r++;
+        dst[i] = (uint8_t)r;
+        for (; r > 0; r--) r2s[r] = r2s[r - 1];
+        r2s[0] = c;
+    }
+    *outLen = count;
+    return 1;
+}
+
+static int mtft_inverse(const uint8_t* src, int count, uint8_t* dst, int dstCap, int* outLen)
+{
+    *outLen = 0;
+    if (count == 0) return 1;
+    if (count < 0 || count > dstCap) return 0;
+    uint8_t r2s[256];
+    for (int i = 0; i < 256; i++) r2s[i] = (uint8_t)i;
+    for (int i = 0; i < count; i++) {
+        int r = src[i];
+        const uint8_t c = r2s[r];
+        dst[i] = c;
+        for (; r > 0; r--) r2s[r] = r2s[r - 1];
+        r2s[0] = c;
+    }
+    *outLen = count;
+    return 1;
+}
+
+/* ------------------------------------------------------------------ SRT */
+static int srt_preprocess(const uint32_t* freqs, uint8_t* symbols)
+{
+    int nbSymbols = 0;
+    for (int i = 0; i < 256; i++) {
+        if (freqs[i] == 0) continue;
+        symbols[nbSymbols++] = (uint8_t)i;
+    }
+    int h = 4;
+    while (h < nbSymbols) h = h * 3 + 1;
+    do {
+        h /= 3;
+        for (int i = h; i < nbSymbols; i++) {
+            const uint8_t t = symbols[i];
+            int b;
+            for (b = i - h; b >= 0; b -= h) {
+                const int val = (int)(freqs[symbols[b]] - freqs[t]);
+                if ((val >= 0) && ((val != 0) || (t >= symbols[b]))) break;
+                symbols[b + h] = symbols[b];
+            }
+            symbols[b + h] = t;
+        }
+    } while (h != 1);
+    return nbSymbols;
+}
+
+static int srt_forward(const uint8_t* src, int length, uint8_t* out, int dstCap, int* outLen)
+{
+    *outLen = 0;
+    if (length == 0) return 1;
+    if (dstCap < length + 1024) return 0;            /* getMaxEncodedLength = n + MAX_HEADER_SIZE, SRT.hpp:38 */
+    uint32_t freqs[256];
+    uint8_t s2r[256], r2s[256];
+    memset(freqs, 0, sizeof(freqs)); memset(s2r, 0, 256); memset(r2s, 0, 256);
+    for (int i = 0, b = 0; i < length;) {
+        const uint8_t c = src[i];
+        int j = i + 1;
+        while ((j < length) && (src[j] == c)) j++;
+        if (freqs[c] == 0) { r2s[b] = c; s2r[c] = (uint8_t)b; b++; }
+        freqs[c] += (uint32_t)(j - i);
+        i = j;
+    }
+    uint8_t symbols[256];
+    int buckets[256];
+    memset(buckets, 0, sizeof(buckets));
+    const int nbSymbols = srt_preprocess(freqs, symbols);
+    for (int i = 0, bucketPos = 0; i < nbSymbols; i++) {
+        const uint8_t c = symbols[i];
+        buckets[c] = bucketPos;
+        bucketPos += (int)freqs[c];
+    }
+    /* encodeHeader :246-277 */
+    int hdr = 0;
+    for (int i = 0; i < 256; i++) {
+        uint32_t f = freqs[i];
+        for (int k = 0; k < 4 && f >= 128; k++) { out[hdr++] = (uint8_t)(0x80 | f); f >>= 7; }
+        out[hdr++] = (uint8_t)f;
+    }
+    uint8_t* dst = out + hdr;
+    for (int i = 0; i < length;) {
+        const uint8_t c = src[i];
+        int r = s2r[c];
+        int p = buckets[c];
+        dst[p++] = (uint8_t)r;
+        if (r != 0) {
+            do {
+                const uint8_t t = r2s[r - 1];
+                r2s[r] = t;
+                s2r[t] = (uint8_t)r;
+                r--;
+            } while (r != 0);
+            r2s[0] = c;
+            s2r[c] = 0;
+        }
+        i++;
+        while ((i < length) && (src[i] == c)) { dst[p++] = 0; i++; }
+        buckets[c] = p;
+    }
+    *outLen = hdr + length;
+    return 1;
+}
+
+static int srt_inverse(const uint8_t* in, int length, uint8_t* dst, int dstCap, int* outLen)
+{
+    *outLen = 0;
+    if (length == 0) return 1;
+    if (length < 256) return 0;
+    uint32_t freqs[256];
+    /* decodeHeader :279-308 */
+    int srcIdx = 0;
+    for (int i = 0; i < 256; i++) {
+        uint32_t res = 0;
+        int shift = 0;
+        for (int j = 0; j < 5; j++) {
+            if (srcIdx >= length) return 0;
+            const uint32_t val = in[srcIdx++];
+            res |= ((val & 0x7F) << shift);
+            if ((val & 0x80) == 0) break;
+            if (j == 4) return 0;
+            shift += 7;
+        }
+        freqs[i] = res;
+    }
+    length -= srcIdx;
+    if (length < 0 || length > dstCap) return 0;
+    const uint8_t* src = in + srcIdx;
+    uint8_t symbols[256];
+    memset(symbols, 0, 256);
+    int nbSymbols = srt_preprocess(freqs, symbols);
+    int buckets[256], bucketEnds[256];
+    uint8_t r2s[256];
+    memset(buckets, 0, sizeof(buckets)); memset(bucketEnds, 0, sizeof(bucketEnds)); memset(r2s, 0, 256);
+    for (int i = 0, bucketPos = 0; i < nbSymbols; i++) {
+        const uint8_t c = symbols[i];
+        if ((bucketPos < 0) || (bucketPos >= length)) return 0;
+        r2s[src[bucketPos]] = c;
+        buckets[c] = bucketPos + 1;
+        bucketPos += (int)freqs[c];
+        bucketEnds[c] = bucketPos;
+    }
+    uint8_t c = r2s[0];
+    for (int i = 0; i < length; i++) {
+        dst[i] = c;
+        if (buckets[c] < bucketEnds[c]) {
+            const uint8_t r = src[buckets[c]];
+            buckets[c]++;
+            if (r == 0) continue;
+            memmove(&r2s[0], &r2s[1], r);
+            r2s[r] = c;
+            c = r2s[0];
+        } else {
+            if (nbSymbols == 1) continue;
+            nbSymbols--;
+            memmove(&r2s[0], &r2s[1], (size_t)nbSymbols);
+            c = r2s[0];
+        }
+    }
+    *outLen = length;
+    return 1;
+}
+
+/* ------------------------------------------------------------------ RLT */
+#define RLT_ENC1 224
+#define RLT_ENC2 ((255 - RLT_ENC1) << 8)
+#define RLT_THRESHOLD 3
+#define RLT_MAX_RUN (0xFFFF + RLT_ENC2 + RLT_THRESHOLD - 1)
+#define RLT_MAX_RUN4 (RLT_MAX_RUN - 4)
+
+enum { DT_UNDEFINED, DT_TEXT, DT_MULTIMEDIA, DT_EXE, DT_NUMERIC, DT_BASE64, DT_DNA, DT_BIN, DT_UTF8, DT_SMALL };
+
+/* Global.cpp:354-397 */
+static int detect_simple_type(int count, const uint32_t* f)
+{
+    static const char DNA[] = "acgntuACGNTU";
+    static const char NUM[] = "0123456789+-*/=,.:; ";
+    static const char B64[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+    int sum = 0;
+    for (int i = 0; i < 12; i++) sum += (int)f[(uint8_t)DNA[i]];
+    if (sum > (count - count / 12)) return DT_DNA;
+    sum = 0;
+    for (int i = 0; i < 20; i++) sum += (int)f[(uint8_t)NUM[i]];
+    if (sum == count) return DT_NUMERIC;
+    sum = (f[0x3D] == 1) ? 1 : 0;
+    for (int i = 0; i < 64; i++) sum += (int)f[(uint8_t)B64[i]];
+    if (sum == count) return DT_BASE64;
+    sum = 0;
+    for (int i = 0; i < 256; i++) sum += (f[i] > 0) ? 1 : 0;
+    if (sum == 256) return DT_BIN;
+    return (sum <= 4) ? DT_SMALL : DT_UNDEFINED;
+}
+
+static int rlt_emit_run(uint8_t* dst, int run, uint8_t escape, uint8_t val)
+{
+    dst[0] = val;
+    dst[1] = 0;
+    int dstIdx = (val == escape) ? 2 : 1;
+    dst[dstIdx++] = escape;
+    run -= RLT_THRESHOLD;
+    if (run >= RLT_ENC1) {
+        if (run < RLT_ENC2) {
+            run -= RLT_ENC1;
+            dst[dstIdx++] = (uint8_t)(RLT_ENC1 + (run >> 8));
+        } else {
+            run -= RLT_ENC2;
+            dst[dstIdx++] = 0xFF;
+            dst[dstIdx++] = (uint8_t)(run >> 8);
+        }
+    }
+    dst[dstIdx] = (uint8_t)run;
+    return dstIdx + 1;
+}
+
+/* etype: stream entropy id, or -1 when the context has no "entropy" (then, like the reference,
+ * an empty name is not one of the fast coders => best-escape search). */
+static int rlt_forward(const uint8_t* src, int count, uint8_t* dst, int dstCap, int etype, int* outLen)
+{
+    *outLen = 0;
+    if (count == 0) return 1;
+    if (count < 16) return 0;
+    const int maxEnc = (count <= 512) ? count + 32 : count;
+    if (dstCap < maxEnc) return 0;
+    int findBestEscape = 1;
+    if (etype == 0 || etype == 5 || etype == 1 || etype == 4) findBestEscape = 0;
+    uint8_t escape = 0xFB;
+    if (findBestEscape) {
+        uint32_t freqs[256];
+        memset(freqs, 0, sizeof(freqs));
+        for (int i = 0; i < count; i++) freqs[src[i]]++;
+        const int dt = detect_simple_type(count, freqs);
+        if (dt == DT_DNA || dt == DT_BASE64 || dt == DT_UTF8) return 0;
+        int minIdx = 0;
+        if (freqs[minIdx] > 0) {
+            for (int i = 1; i < 256; i++) {
+                if (freqs[i] < freqs[minIdx]) {
+                    minIdx = i;
+                    if (freqs[i] == 0) break;
+                }
+            }
+        }
+        escape = (uint8_t)minIdx;
+    }
+    int srcIdx = 0, dstIdx = 0;
+    const int srcEnd = count, srcEnd4 = srcEnd - 4, dstEnd = dstCap;
+    int res = 1, run = 0;
+    uint8_t prev = src[srcIdx++];
+    dst[dstIdx++] = escape;
+    dst[dstIdx++] = prev;
+    if (prev == escape) dst[dstIdx++] = 0;
+
+    while (1) {
+        if (prev == src[srcIdx]) {
+            const uint32_t v = 0x01010101u * (uint32_t)prev;
+            uint32_t w;
+            memcpy(&w, &src[srcIdx], 4);              /* little-endian host, as LittleEndian::readInt32 */
+            const uint32_t diff = w ^ v;
+            if (diff == 0) {
+                srcIdx += 4; run += 4;
+                if ((run < RLT_MAX_RUN4) && (srcIdx < srcEnd4)) continue;
+            } else {
+                const int n = __builtin_ctz(diff) >> 3;
+                srcIdx += n;
+                run += n;
+            }
+        }
+        if (run > RLT_THRESHOLD) {
+            if (dstIdx + 6 >= dstEnd) { res = 0; break; }
+            dstIdx += rlt_emit_run(&dst[dstIdx], run, escape, prev);
+        } else if (prev != escape) {
+            if (dstIdx + run >= dstEnd) { res = 0; break; }
+            if (run-- > 0) dst[dstIdx++] = prev;
+            while (run-- > 0) dst[dstIdx++] = prev;
+        } else {
+            if (dstIdx + (2 * run) >= dstEnd) { res = 0; break; }
+            while (run-- > 0) { dst[dstIdx++] = escape; dst[dstIdx++] = 0; }
+        }
+        prev = src[srcIdx];
+        srcIdx++;
+        run = 1;
+        if (srcIdx >= srcEnd4) break;
+    }
+
+    if (res) {
+        if (prev != escape) {
+            if (dstIdx + run < dstEnd) while (run-- > 0) dst[dstIdx++] = prev;
+        } else {
+            if (dstIdx + (2 * run) < dstEnd)
+                while (run-- > 0) { dst[dstIdx++] = escape; dst[dstIdx++] = 0; }
+        }
+        while ((srcIdx < srcEnd) && (dstIdx < dstEnd)) {
+            if (src[srcIdx] == escape) {
+                if (dstIdx + 2 >= dstEnd) { res = 0; break; }
+                dst[dstIdx++] = escape;
+                dst[dstIdx++] = 0;
+                srcIdx++;
+                continue;
+            }
+            dst[dstIdx++] = src[srcIdx++];
+        }
+        res &= (srcIdx == srcEnd);
+    }
+    *outLen = dstIdx;
+    return res && (dstIdx < srcIdx);
+}
+
+static int rlt_inverse(const uint8_t* src, int count, uint8_t* dst, int dstCap, int* outLen)
+{
+    *outLen = 0;
+    if (count == 0) return 1;
+    int srcIdx = 0, dstIdx = 0;
+    const int srcEnd = count, dstEnd = dstCap;
+    int res = 1;
+    const uint8_t escape = src[srcIdx++];
+    if ((srcIdx < srcEnd) && (src[srcIdx] == escape)) {
+        srcIdx++;
+        if ((srcIdx < srcEnd) && (src[srcIdx] != 0)) return 0;
+        if (dstIdx >= dstEnd) return 0;
+        dst[dstIdx++] = escape;
+        srcIdx++;
+    }
+    while (srcIdx < srcEnd) {
+        const uint8_t* esc = (const uint8_t*)memchr(&src[srcIdx], escape, (size_t)(srcEnd - srcIdx));
+        const int literalLen = (esc == NULL) ? (srcEnd - srcIdx) : (int)(esc - &src[srcIdx]);
+        if (literalLen > 0) {
+            if (literalLen > dstEnd - dstIdx) { res = 0; break; }
+            memcpy(&dst[dstIdx], &src[srcIdx], (size_t)literalLen);
+            srcIdx += literalLen;
+            dstIdx += literalLen;
+        }
+        if (srcIdx >= srcEnd) break;
+        srcIdx++;
+        if (srcIdx >= srcEnd) { res = 0; break; }
+        int run = src[srcIdx++];
+        if (run == 0) {
+            if (dstIdx >= dstEnd) { res = 0; break; }
+            dst[dstIdx++] = escape;
+            continue;
+        }
+        if (run == 0xFF) {
+            if (srcIdx + 1 >= srcEnd) { res = 0; break; }
+            run = (src[srcIdx] << 8) | src[srcIdx + 1];
+            srcIdx += 2;
+            run += RLT_ENC2;
+        } else if (run >= RLT_ENC1) {
+            if (srcIdx >= srcEnd) { res = 0; break; }
+            run = ((run - RLT_ENC1) << 8) | src[srcIdx];
+            srcIdx++;
+            run += RLT_ENC1;
+        }
+        run += (RLT_THRESHOLD - 1);
+        if ((dstIdx + run > dstEnd) || (run > RLT_MAX_RUN)) { res = 0; break; }
+        if (dstIdx == 0) { res = 0; break; }
+        memset(&dst[dstIdx], dst[dstIdx - 1], (size_t)run);
+        dstIdx += run;
+    }
+    *outLen = dstIdx;
+    return res && (srcIdx == srcEnd);
+}
+
+/* ------------------------------------------------------------------ BWT block codec
+ * transform/BWTBlockCodec.cpp:32-87 (forward), :89-168 (inverse, bsVersion 6 branch) */
+static int bwtblock_forward(const uint8_t* src, int blockSize, uint8_t* dst, int dstCap, int* outLen)
+{
+    *outLen = 0;
+    if (blockSize == 0) return 1;
+    if (dstCap < blockSize + 33) return 0;          /* BWTBlockCodec.hpp:47-50 */
+    int logBlockSize = ilog2((uint32_t)blockSize);
+    if ((blockSize & (blockSize - 1)) != 0) logBlockSize++;
+    const int pIndexSize = (logBlockSize + 7) >> 3;
+    if ((pIndexSize <= 0) || (pIndexSize >= 5)) return 0;
+    const int chunks = knzo_bwt_chunks(blockSize);
+    const int logNbChunks = ilog2((uint32_t)chunks);
+    const int hdr = 1 + chunks * pIndexSize;
+    int primary[8];
+    if (!knzo_bwt_forward_raw(src, blockSize, dst + hdr, primary)) return 0;
+    for (int i = 0, idx = 1; i < chunks; i++) {
+        const int p = primary[i] - 1;
+        int shift = (pIndexSize - 1) << 3;
+        while (shift >= 0) { dst[idx++] = (uint8_t)(p >> shift); shift -= 8; }
+    }
+    dst[0] = (uint8_t)((logNbChunks << 2) | (pIndexSize - 1));
+    *outLen = hdr + blockSize;
+    return 1;
+}
+
+static int bwtblock_inverse(const uint8_t* src, int blockSize, uint8_t* dst, int dstCap, int* outLen)
+{
+    *outLen = 0;
+    if (blockSize <= 1) return blockSize == 0;
+    const uint8_t mode = src[0];
+    const unsigned logNbChunks = (unsigned)(mode >> 2) & 0x07;
+    const int pIndexSize = (mode & 0x03) + 1;
+    const int chunks = 1 << logNbChunks;
+    const int headerSize = 1 + chunks * pIndexSize;
+    if (blockSize - 1 < headerSize) return 0;       /* input._length - input._index < headerSize */
+    if (blockSize < headerSize) return 0;
+    if (chunks != knzo_bwt_chunks(blockSize - headerSize)) return 0;
+    int primary[8];
+    memset(primary, 0, sizeof(primary));
+    int idx = 1;
+    for (int i = 0; i < chunks; i++) {
+        int shift = (pIndexSize - 1) << 3;
+        uint32_t p = 0;
+        while (shift >= 0) { p = (p << 8) | src[idx++]; shift -= 8; }
+        if (p >= 0x7FFFFFFFu) return 0;
+        if (i >= 8) return 0;
+        primary[i] = (int)p + 1;
+    }
+    /* header bytes were consumed by input._index++ : idx == headerSize + ... (mode byte included) */
+    blockSize -= headerSize;
+    if (blockSize > dstCap) return 0;
+    if (!knzo_bwt_inverse_raw(src + idx, blockSize, dst, primary)) return 0;
+    *outLen = blockSize;
+    return 1;
+}
+
+static int null_copy(const uint8_t* src, int n, uint8_t* dst, int dstCap, int* outLen)
+{
+    *outLen = 0;
+    if (n == 0) return 1;
+    if (n > dstCap) return 0;
+    memmove(dst, src, (size_t)n);
+    *outLen = n;
+    return 1;
+}
+
+int knzo_transform_forward(int ttype, const uint8_t* src, int n, uint8_t* dst, int dstCap, int etype, int* outLen)
+{
+    switch (ttype) {
+    case 0:  return null_copy(src, n, dst, dstCap, outLen);
+    case 1:  return bwtblock_forward(src, n, dst, dstCap, outLen);
+    case 5:  return rlt_forward(src, n, dst, dstCap, etype, outLen);
+    case 6:  return zrlt_forward(src, n, dst, dstCap, outLen);
+    case 7:  return mtft_forward(src, n, dst, dstCap, outLen);
+    case 13: return srt_forward(src, n, dst, dstCap, outLen);
+    default: *outLen = 0; return 0;
+    }
+}
+
+int knzo_transform_inverse(int ttype, const uint8_t* src, int n, uint8_t* dst, int dstCap, int* outLen)
+{
+    switch (ttype) {
+    case 0:  return null_copy(src, n, dst, dstCap, outLen);
+    case 1:  return bwtblock_inverse(src, n, dst, dstCap, outLen);
+    case 5:  return rlt_inverse(src, n, dst, dstCap, outLen);
+    case 6:  return zrlt_inverse(src, n, dst, dstCap, outLen);
+    case 7:  return mtft_inverse(src, n, dst, dstCap, outLen);
+    case 13: return srt_inverse(src, n, dst, dstCap, outLen);
+    default: *outLen = 0; return 0;
+    }
+}

@@ -1,0 +1,200 @@
+"""Shared test helpers: ctypes bindings for the oracle (oracle/libknz_oracle.so), the compiled
+reference (oracle/_ref/libkanzi_ref.so, only when built) and the product C-ABI libraries.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch the oracle.
+"""
+import ctypes as C
+import importlib.util
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "kanzi-cpp_amd")
+ORACLE_SO = os.path.join(ROOT, "oracle", "libknz_oracle.so")
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libkanzi_ref.so")
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "kanzi")
+
+u8p = C.POINTER(C.c_uint8)
+
+
+def load_pkg():
+    """Import the package directory 'kanzi-cpp_amd' under the module name kanzi_amd."""
+    if "kanzi_amd" in sys.modules:
+        return sys.modules["kanzi_amd"]
+    spec = importlib.util.spec_from_file_location(
+        "kanzi_amd", os.path.join(PKG, "__init__.py"), submodule_search_locations=[PKG])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["kanzi_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def corpus():
+    load_pkg()
+    import importlib
+    return importlib.import_module("kanzi_amd.corpus")
+
+
+def _buf(b):
+    return (C.c_uint8 * max(1, len(b))).from_buffer_copy(b if len(b) else b"\0")
+
+
+def ensure_oracle():
+    if not os.path.exists(ORACLE_SO) or any(
+            os.path.getmtime(os.path.join(ROOT, "oracle", f)) > os.path.getmtime(ORACLE_SO)
+            for f in os.listdir(os.path.join(ROOT, "oracle")) if f.endswith((".c", ".h"))):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    return ORACLE_SO
+
+
+def ensure_ref():
+    """Build the reference only where its sources exist; otherwise use the prebuilt .so if present."""
+    if not os.path.exists(REF_SO) and os.path.isdir("/root/reference/src"):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref", "-j8"], stdout=subprocess.DEVNULL)
+    return REF_SO if os.path.exists(REF_SO) else None
+
+
+ETYPE = {"NONE": 0, "HUFFMAN": 1, "FPAQ": 2, "ANS0": 5, "ANS1": 8}
+TTYPE = {"NONE": 0, "BWT": 1, "RLT": 5, "ZRLT": 6, "MTFT": 7, "SRT": 13}
+
+
+class Oracle:
+    def __init__(self):
+        L = self.L = C.CDLL(ensure_oracle())
+        L.knzo_entropy_encode.restype = C.c_int64
+        L.knzo_entropy_encode.argtypes = [C.c_int, u8p, C.c_uint32, u8p, C.c_size_t]
+        L.knzo_entropy_decode.restype = C.c_int
+        L.knzo_entropy_decode.argtypes = [C.c_int, u8p, C.c_size_t, u8p, C.c_uint32]
+        L.knzo_transform_forward.restype = C.c_int
+        L.knzo_transform_forward.argtypes = [C.c_int, u8p, C.c_int, u8p, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        L.knzo_transform_inverse.restype = C.c_int
+        L.knzo_transform_inverse.argtypes = [C.c_int, u8p, C.c_int, u8p, C.c_int, C.POINTER(C.c_int)]
+        L.knzo_compress.restype = C.c_int
+        L.knzo_compress.argtypes = [u8p, C.c_size_t, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_uint64,
+                                    C.c_int, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.knzo_decompress.restype = C.c_int
+        L.knzo_decompress.argtypes = [u8p, C.c_size_t, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.knzo_transform_type.restype = C.c_uint64
+        L.knzo_transform_type.argtypes = [C.c_char_p]
+        L.knzo_entropy_type.restype = C.c_int
+        L.knzo_entropy_type.argtypes = [C.c_char_p]
+        L.knzo_xxhash32.restype = C.c_uint32
+        L.knzo_xxhash32.argtypes = [u8p, C.c_size_t, C.c_uint32]
+        L.knzo_xxhash64.restype = C.c_uint64
+        L.knzo_xxhash64.argtypes = [u8p, C.c_size_t, C.c_uint64]
+        L.knzo_bwt_forward_raw.restype = C.c_int
+        L.knzo_bwt_forward_raw.argtypes = [u8p, C.c_int, u8p, C.POINTER(C.c_int)]
+
+    def entropy_encode(self, name, data):
+        cap = len(data) * 2 + 65536
+        out = (C.c_uint8 * cap)()
+        bits = self.L.knzo_entropy_encode(ETYPE[name], _buf(data), len(data), out, cap)
+        if bits < 0:
+            return None, bits
+        return bytes(out[:(bits + 7) // 8]), bits
+
+    def entropy_decode(self, name, enc, n):
+        out = (C.c_uint8 * max(1, n))()
+        r = self.L.knzo_entropy_decode(ETYPE[name], _buf(enc), len(enc), out, n)
+        return r, bytes(out[:n])
+
+    def forward(self, name, data, dst_cap=None, entropy=None):
+        cap = dst_cap if dst_cap is not None else len(data) + 2048
+        out = (C.c_uint8 * (max(cap, len(data)) + 2048))()
+        ol = C.c_int(0)
+        e = ETYPE[entropy] if entropy else -1
+        ok = self.L.knzo_transform_forward(TTYPE[name], _buf(data), len(data), out, cap, e, C.byref(ol))
+        return ok, bytes(out[:ol.value])
+
+    def inverse(self, name, data, dst_cap):
+        out = (C.c_uint8 * (dst_cap + 64))()
+        ol = C.c_int(0)
+        ok = self.L.knzo_transform_inverse(TTYPE[name], _buf(data), len(data), out, dst_cap, C.byref(ol))
+        return ok, bytes(out[:ol.value])
+
+    def bwt_raw(self, data):
+        out = (C.c_uint8 * max(1, len(data)))()
+        prim = (C.c_int * 8)()
+        ok = self.L.knzo_bwt_forward_raw(_buf(data), len(data), out, prim)
+        return ok, bytes(out[:len(data)]), list(prim)
+
+    def compress(self, data, transform, entropy, block_size, checksum=0, orig_size=0, headerless=0):
+        cap = len(data) + len(data) // 2 + (1 << 20)
+        out = (C.c_uint8 * cap)()
+        ol = C.c_size_t(0)
+        rc = self.L.knzo_compress(_buf(data), len(data), transform.encode(), entropy.encode(), block_size,
+                                  checksum, orig_size, headerless, out, cap, C.byref(ol))
+        return rc, bytes(out[:ol.value])
+
+    def decompress(self, enc, cap):
+        out = (C.c_uint8 * max(1, cap))()
+        ol = C.c_size_t(0)
+        rc = self.L.knzo_decompress(_buf(enc), len(enc), out, cap, C.byref(ol))
+        return rc, bytes(out[:ol.value])
+
+
+class Ref:
+    """The unmodified reference (oracle/_ref/libkanzi_ref.so)."""
+
+    def __init__(self):
+        so = ensure_ref()
+        if so is None:
+            raise RuntimeError("reference build not available")
+        L = self.L = C.CDLL(so)
+        L.ref_transform.restype = C.c_int
+        L.ref_transform.argtypes = [C.c_char_p, C.c_int, u8p, C.c_int, C.c_int, u8p, C.c_int, C.c_char_p,
+                                    C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.ref_entropy_encode.restype = C.c_longlong
+        L.ref_entropy_encode.argtypes = [C.c_char_p, u8p, C.c_int, u8p, C.c_size_t]
+        L.ref_entropy_decode.restype = C.c_int
+        L.ref_entropy_decode.argtypes = [C.c_char_p, u8p, C.c_size_t, u8p, C.c_int]
+        L.ref_compress_stream.restype = C.c_int
+        L.ref_compress_stream.argtypes = [u8p, C.c_size_t, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
+                                          C.c_ulonglong, C.c_int, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.ref_decompress_stream.restype = C.c_int
+        L.ref_decompress_stream.argtypes = [u8p, C.c_size_t, C.c_int, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+
+    def entropy_encode(self, name, data):
+        cap = len(data) * 2 + 65536
+        out = (C.c_uint8 * cap)()
+        bits = self.L.ref_entropy_encode(name.encode(), _buf(data), len(data), out, cap)
+        if bits < 0:
+            return None, bits
+        return bytes(out[:(bits + 7) // 8]), bits
+
+    def entropy_decode(self, name, enc, n):
+        out = (C.c_uint8 * max(1, n))()
+        r = self.L.ref_entropy_decode(name.encode(), _buf(enc), len(enc), out, n)
+        return r, bytes(out[:n])
+
+    def forward(self, name, data, dst_cap=None, entropy=None, src_cap=0):
+        cap = dst_cap if dst_cap is not None else len(data) + 2048
+        out = (C.c_uint8 * (max(cap, len(data)) + 2048))()
+        ol = C.c_int(0)
+        sk = C.c_int(0)
+        ok = self.L.ref_transform(name.encode(), 1, _buf(data), len(data), src_cap, out, cap,
+                                  (entropy or "").encode(), C.byref(ol), C.byref(sk))
+        return ok, bytes(out[:ol.value]), sk.value
+
+    def inverse(self, name, data, dst_cap, skip=0):
+        out = (C.c_uint8 * (dst_cap + 64))()
+        ol = C.c_int(0)
+        sk = C.c_int(skip)
+        ok = self.L.ref_transform(name.encode(), 0, _buf(data), len(data), 0, out, dst_cap, b"",
+                                  C.byref(ol), C.byref(sk))
+        return ok, bytes(out[:ol.value])
+
+    def compress(self, data, transform, entropy, block_size, jobs=1, checksum=0, orig_size=0, headerless=0):
+        cap = len(data) + len(data) // 2 + (1 << 20)
+        out = (C.c_uint8 * cap)()
+        ol = C.c_size_t(0)
+        rc = self.L.ref_compress_stream(_buf(data), len(data), transform.encode(), entropy.encode(), block_size,
+                                        jobs, checksum, orig_size, headerless, out, cap, C.byref(ol))
+        return rc, bytes(out[:ol.value])
+
+    def decompress(self, enc, cap, jobs=1):
+        out = (C.c_uint8 * max(1, cap))()
+        ol = C.c_size_t(0)
+        rc = self.L.ref_decompress_stream(_buf(enc), len(enc), jobs, out, cap, C.byref(ol))
+        return rc, bytes(out[:ol.value])
