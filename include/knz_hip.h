@@ -1,0 +1,131 @@
+/*
+ * knz_hip.h -- C ABI of the MI355X (gfx950) kanzi block pipeline.
+ *
+ * This is the thin device layer SURVEY.md section 8(b) calls "New thin C-ABI to HIP": one call
+ * processes a batch of independent blocks that are already resident in HBM and returns the block
+ * payloads exactly as the reference's EncodingTask would have put them in its private bitstream
+ * (io/CompressedOutputStream.cpp:651-898), assembled MSB-first at bit granularity
+ * (bitstream/DefaultOutputBitStream.hpp:97-131). Plain pointers and sizes only; all pointers
+ * named d_* are device pointers, everything else is host memory. Every function returns 0 on
+ * success, a negative value for a device/runtime failure (see knz_hip_last_error) or a positive
+ * kanzi Error code (src/Error.hpp:26-48) for data errors.
+ *
+ * The C++ host mirror of the reference interfaces (Transform<byte>, EntropyEncoder/Decoder,
+ * CompressedOutputStream/InputStream, include/kanzi_amd/) and the reference C API replacement
+ * (include/kanzi_api.h) are built on top of these entry points.
+ */
+#ifndef KNZ_HIP_H
+#define KNZ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KNZ_API __attribute__((visibility("default")))
+
+/* kanzi ids: entropy (entropy/EntropyEncoderFactory.hpp:37-52) and transforms (transform/TransformFactory.hpp:49-73) */
+enum { KNZ_E_NONE = 0, KNZ_E_HUFFMAN = 1, KNZ_E_FPAQ = 2, KNZ_E_ANS0 = 5, KNZ_E_ANS1 = 8 };
+enum { KNZ_T_NONE = 0, KNZ_T_BWT = 1, KNZ_T_RLT = 5, KNZ_T_ZRLT = 6, KNZ_T_MTFT = 7, KNZ_T_SRT = 13 };
+
+/* kanzi error codes surfaced for data errors (src/Error.hpp:26-48) */
+enum { KNZ_ERR_BLOCK_SIZE = 2, KNZ_ERR_INVALID_CODEC = 3, KNZ_ERR_READ_FILE = 11, KNZ_ERR_WRITE_FILE = 12,
+       KNZ_ERR_PROCESS_BLOCK = 13, KNZ_ERR_INVALID_FILE = 15, KNZ_ERR_STREAM_VERSION = 16,
+       KNZ_ERR_INVALID_PARAM = 18, KNZ_ERR_CRC_CHECK = 19 };
+
+typedef struct knz_ctx knz_ctx;
+
+/* Number of visible HIP devices. */
+KNZ_API int knz_hip_device_count(int* count);
+
+/* Create a context on `device`. `stream` is a hipStream_t (as void*) to enqueue on, or NULL to
+ * let the context create its own. Workspaces are grown on demand and reused across calls. */
+KNZ_API int knz_hip_create(int device, void* stream, knz_ctx** out);
+KNZ_API void knz_hip_destroy(knz_ctx* ctx);
+KNZ_API const char* knz_hip_last_error(knz_ctx* ctx);
+
+/* Parameters of one batch of blocks: what CompressedOutputStream puts in the per-task Context
+ * (io/CompressedOutputStream.cpp:491-496): transform ids (48 bits, 6 per stage, first stage in
+ * bits 47..42), entropy id, block size, checksum width (0/32/64). */
+typedef struct {
+    uint64_t transform_type;
+    int32_t entropy_type;
+    int32_t block_size;
+    int32_t checksum_bits;
+    int32_t reserved;
+} knz_params;
+
+/* Upper bound, in bytes, of the bit-packed output of knz_hip_encode_blocks for n input bytes. */
+KNZ_API size_t knz_hip_encode_bound(const knz_params* p, size_t n);
+
+/*
+ * Encode n bytes at d_in, cut into blocks of p->block_size (the last one may be short), each block
+ * through TransformSequence::forward + block header + EntropyEncoder::encode, and append the
+ * results in block order as CompressedOutputStream does (5-bit lw-3, lw-bit length, payload bits;
+ * io/CompressedOutputStream.cpp:852-864).
+ *
+ *   prologue/prologue_bits : host bytes placed first (the stream header, or NULL/0)
+ *   first_block_id         : 0-based id of the first block in this batch (only for buffer-capacity
+ *                            modelling of the reference)
+ *   finish                 : append the end-of-stream marker (5+3 zero bits, :415-417)
+ *   d_out/out_cap          : device output, zero-filled by the call, out_cap >= knz_hip_encode_bound
+ *   out_bits               : total bits written (host). Output bytes = (out_bits+7)/8.
+ *
+ * The call is synchronous with respect to the host when out_bits != NULL (it has to read the
+ * length back); all device work is enqueued on the context's stream.
+ */
+KNZ_API int knz_hip_encode_blocks(knz_ctx* ctx, const knz_params* p, const uint8_t* d_in, size_t n,
+                                  const uint8_t* prologue, uint32_t prologue_bits, int64_t first_block_id,
+                                  int finish, uint8_t* d_out, size_t out_cap, uint64_t* out_bits);
+
+/*
+ * Decode a run of blocks: d_in holds the bit stream, the first block's 5-bit length prefix is at
+ * bit `start_bit`. Blocks are decoded until the end marker, `max_blocks` blocks or `in_bits` is
+ * exhausted. Decoded blocks are written back to back at d_out.
+ *   out_bytes  : decoded byte count (host)
+ *   end_bit    : bit position after the last consumed block / end marker (host, may be NULL)
+ * Mirrors DecodingTask::run (io/CompressedInputStream.cpp:790-1041) incl. its accept/reject rules.
+ */
+KNZ_API int knz_hip_decode_blocks(knz_ctx* ctx, const knz_params* p, const uint8_t* d_in, uint64_t in_bits,
+                                  uint64_t start_bit, int64_t max_blocks, uint8_t* d_out, size_t out_cap,
+                                  uint64_t* out_bytes, uint64_t* end_bit, int64_t* blocks_done);
+
+/* ---- per-stage entry points (host buffers in/out; used by the host mirror classes and tests) ---- */
+
+/* EntropyEncoder::encode for one buffer (entropy/EntropyEncoder.hpp:30-37). out receives the bits
+ * MSB-first from bit 0; *out_bits the exact bit count (dispose() bits included for FPAQ). */
+KNZ_API int knz_hip_entropy_encode(knz_ctx* ctx, int entropy_type, const uint8_t* in, uint32_t n,
+                                   uint8_t* out, size_t out_cap, uint64_t* out_bits);
+/* EntropyDecoder::decode: reads from bit `start_bit` of `in`; *used_bits = bits consumed.
+ * Returns 0 and *decoded == n on success; *decoded mirrors the reference's return value otherwise. */
+KNZ_API int knz_hip_entropy_decode(knz_ctx* ctx, int entropy_type, const uint8_t* in, uint64_t in_bits,
+                                   uint64_t start_bit, uint8_t* out, uint32_t n, int32_t* decoded,
+                                   uint64_t* used_bits);
+
+/* Transform<byte>::forward / inverse for one buffer (src/Transform.hpp:38-45). dst_cap mirrors
+ * SliceArray::_length - _index of the destination (it changes results for ZRLT/RLT). *ok = 1 when the
+ * reference would return true. entropy_type: the stream's entropy id (RLT escape choice), -1 if unset. */
+KNZ_API int knz_hip_transform_forward(knz_ctx* ctx, int transform_type, const uint8_t* in, int32_t n,
+                                      uint8_t* out, int32_t dst_cap, int entropy_type, int32_t* out_len, int32_t* ok);
+KNZ_API int knz_hip_transform_inverse(knz_ctx* ctx, int transform_type, const uint8_t* in, int32_t n,
+                                      uint8_t* out, int32_t dst_cap, int32_t* out_len, int32_t* ok);
+
+/* Device-memory helpers so that non-HIP hosts (ctypes, cgo, JNI) can stage data. */
+KNZ_API int knz_hip_malloc(knz_ctx* ctx, size_t bytes, void** d_ptr);
+KNZ_API int knz_hip_free(knz_ctx* ctx, void* d_ptr);
+KNZ_API int knz_hip_memcpy_h2d(knz_ctx* ctx, void* d_dst, const void* src, size_t bytes);
+KNZ_API int knz_hip_memcpy_d2h(knz_ctx* ctx, void* dst, const void* d_src, size_t bytes);
+KNZ_API int knz_hip_sync(knz_ctx* ctx);
+
+/* Timing of the kernels of the last encode/decode call, measured with HIP events on the context's
+ * stream: name/ms pairs. Returns the number of entries written (<= cap). */
+typedef struct { char name[48]; float ms; uint64_t launches; } knz_kernel_time;
+KNZ_API int knz_hip_set_profiling(knz_ctx* ctx, int enabled);
+KNZ_API int knz_hip_get_kernel_times(knz_ctx* ctx, knz_kernel_time* out, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,504 @@
+// C-ABI layer (include/knz_hip.h): context, workspaces, and the batch drivers that chain the
+// transform / entropy / bit-assembly kernels on one HIP stream.
+#include "common.hpp"
+#include "stages.hpp"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace knz;
+
+namespace knz {
+
+const char* hipErrStr(hipError_t e) { return hipGetErrorString(e); }
+
+struct WsBuf { void* p = nullptr; size_t cap = 0; };
+
+struct ProfEntry { std::string name; hipEvent_t a, b; };
+
+struct Ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    char err[512] = { 0 };
+    std::map<std::string, WsBuf> ws;
+    bool profiling = false;
+    std::vector<ProfEntry> prof;
+    void* pinned = nullptr;      // small pinned host scratch
+    size_t pinnedCap = 0;
+};
+
+static int fail(Ctx* c, int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(c->err, sizeof(c->err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(c, -1, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+static int ws_get(Ctx* c, const char* name, size_t bytes, void** out)
+{
+    WsBuf& w = c->ws[name];
+    if (w.cap < bytes) {
+        if (w.p) HIPCHK(c, hipFree(w.p));
+        w.p = nullptr; w.cap = 0;
+        const size_t want = bytes + (bytes >> 3) + 4096;
+        HIPCHK(c, hipMalloc(&w.p, want));
+        w.cap = want;
+    }
+    *out = w.p;
+    return 0;
+}
+
+struct ProfScope {
+    Ctx* c; int idx = -1;
+    ProfScope(Ctx* ctx, const char* name) : c(ctx) {
+        if (!c->profiling) return;
+        ProfEntry e; e.name = name;
+        hipEventCreate(&e.a); hipEventCreate(&e.b);
+        hipEventRecord(e.a, c->stream);
+        c->prof.push_back(e);
+        idx = (int)c->prof.size() - 1;
+    }
+    ~ProfScope() { if (idx >= 0) hipEventRecord(c->prof[idx].b, c->stream); }
+};
+
+static int count_transforms(uint64_t t, int* tok)
+{
+    int nb = 0;
+    for (int i = 0; i < 8; i++) {
+        const int v = (int)((t >> (42 - 6 * i)) & 63);
+        if (v != 0 || i == 0) tok[nb++] = v;
+    }
+    return nb;
+}
+
+static bool transform_supported(int t) { return t == KNZ_T_NONE; }
+static bool entropy_supported(int e) { return e == KNZ_E_NONE || e == KNZ_E_ANS0; }
+
+static int max_encoded_len(int t, int n)
+{
+    switch (t) {
+    case KNZ_T_BWT: return n + 33;
+    case KNZ_T_SRT: return n + 1024;
+    case KNZ_T_RLT: return (n <= 512) ? n + 32 : n;
+    default: return n;
+    }
+}
+
+}  // namespace knz
+
+extern "C" {
+
+int knz_hip_device_count(int* count)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    *count = (e == hipSuccess) ? n : 0;
+    return e == hipSuccess ? 0 : -1;
+}
+
+int knz_hip_create(int device, void* stream, knz_ctx** out)
+{
+    *out = nullptr;
+    Ctx* c = new Ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete c; return -1; }
+    if (stream) { c->stream = (hipStream_t)stream; c->ownStream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return -1; }
+        c->ownStream = true;
+    }
+    c->pinnedCap = 1 << 20;
+    if (hipHostMalloc(&c->pinned, c->pinnedCap, hipHostMallocDefault) != hipSuccess) { delete c; return -1; }
+    *out = reinterpret_cast<knz_ctx*>(c);
+    return 0;
+}
+
+void knz_hip_destroy(knz_ctx* ctx)
+{
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (auto& kv : c->ws) if (kv.second.p) hipFree(kv.second.p);
+    for (auto& e : c->prof) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    if (c->pinned) hipHostFree(c->pinned);
+    if (c->ownStream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* knz_hip_last_error(knz_ctx* ctx) { return ctx ? reinterpret_cast<Ctx*>(ctx)->err : "null context"; }
+
+size_t knz_hip_encode_bound(const knz_params* p, size_t n)
+{
+    const size_t bs = (size_t)p->block_size;
+    const size_t nb = (n + bs - 1) / bs + 1;
+    // worst case: every symbol emits 16 bits (ANS) or 12 bits (Huffman) plus per-chunk headers
+    return 2 * n + nb * 64 + ((n / ENT_CHUNK) + nb) * (HDR_BYTES + 32) + 4096;
+}
+
+int knz_hip_set_profiling(knz_ctx* ctx, int enabled)
+{
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    c->profiling = enabled != 0;
+    for (auto& e : c->prof) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    c->prof.clear();
+    return 0;
+}
+
+int knz_hip_get_kernel_times(knz_ctx* ctx, knz_kernel_time* out, int cap)
+{
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    hipStreamSynchronize(c->stream);
+    std::vector<std::string> order;
+    std::map<std::string, std::pair<float, uint64_t>> agg;
+    for (auto& e : c->prof) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e.a, e.b) != hipSuccess) ms = 0;
+        if (!agg.count(e.name)) order.push_back(e.name);
+        agg[e.name].first += ms;
+        agg[e.name].second += 1;
+    }
+    int n = 0;
+    for (auto& nm : order) {
+        if (n >= cap) break;
+        memset(&out[n], 0, sizeof(out[n]));
+        snprintf(out[n].name, sizeof(out[n].name), "%s", nm.c_str());
+        out[n].ms = agg[nm].first;
+        out[n].launches = agg[nm].second;
+        n++;
+    }
+    for (auto& e : c->prof) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    c->prof.clear();
+    return n;
+}
+
+int knz_hip_malloc(knz_ctx* ctx, size_t bytes, void** d_ptr)
+{
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMalloc(d_ptr, bytes ? bytes : 1));
+    return 0;
+}
+
+int knz_hip_free(knz_ctx* ctx, void* d_ptr)
+{
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    HIPCHK(c, hipFree(d_ptr));
+    return 0;
+}
+
+int knz_hip_memcpy_h2d(knz_ctx* ctx, void* d_dst, const void* src, size_t bytes)
+{
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    HIPCHK(c, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int knz_hip_memcpy_d2h(knz_ctx* ctx, void* dst, const void* d_src, size_t bytes)
+{
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    HIPCHK(c, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int knz_hip_sync(knz_ctx* ctx)
+{
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// encode
+// ------------------------------------------------------------------------------------------------
+static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t n, const uint8_t* prologue,
+                       uint32_t prologueBits, int framing, int finish, uint8_t* d_out, size_t outCap, uint64_t* outBits)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    if ((reinterpret_cast<uintptr_t>(d_in) & 15) || (reinterpret_cast<uintptr_t>(d_out) & 15))
+        return fail(c, KNZ_ERR_INVALID_PARAM, "device buffers must be 16-byte aligned");
+    const u32 bs = (u32)p->block_size;
+    if (framing && (bs < 1024 || bs > (1u << 30) || (bs & 15))) return fail(c, KNZ_ERR_INVALID_PARAM, "invalid block size %u", bs);
+    int tok[8];
+    const int nTok = count_transforms(p->transform_type, tok);
+    for (int i = 0; i < nTok; i++)
+        if (!transform_supported(tok[i])) return fail(c, KNZ_ERR_INVALID_CODEC, "transform id %d not implemented on device", tok[i]);
+    if (!entropy_supported(p->entropy_type)) return fail(c, KNZ_ERR_INVALID_CODEC, "entropy id %d not implemented on device", p->entropy_type);
+    if (nTok > 4) return fail(c, KNZ_ERR_INVALID_CODEC, "more than 4 transforms not supported");
+    if (p->checksum_bits != 0) return fail(c, KNZ_ERR_INVALID_PARAM, "block checksums not implemented on device");
+    hipStream_t s = c->stream;
+
+    const int nBlocks = (n == 0) ? 0 : (int)((n + bs - 1) / bs);
+    const size_t needOut = ((size_t)prologueBits + 7) / 8 + 16;
+    if (outCap < needOut) return fail(c, KNZ_ERR_WRITE_FILE, "output buffer too small");
+    u64* d_total;
+    if (int r = ws_get(c, "total", 64, (void**)&d_total)) return r;
+
+    if (nBlocks == 0) {
+        HIPCHK(c, hipMemsetAsync(d_out, 0, needOut, s));
+        if (prologueBits) {
+            u8* d_pro;
+            if (int r = ws_get(c, "prologue", 256, (void**)&d_pro)) return r;
+            HIPCHK(c, hipMemcpyAsync(d_pro, prologue, (prologueBits + 7) / 8, hipMemcpyHostToDevice, s));
+            launch_put_prologue(s, reinterpret_cast<u32*>(d_out), d_pro, prologueBits);
+        }
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (outBits) *outBits = (u64)prologueBits + ((framing && finish) ? 8 : 0);
+        return 0;
+    }
+
+    // block bookkeeping
+    u32 *d_origLen, *d_blockLen; u8* d_skip; BlockInfo* d_info;
+    if (int r = ws_get(c, "origLen", sizeof(u32) * nBlocks, (void**)&d_origLen)) return r;
+    if (int r = ws_get(c, "blockLen", sizeof(u32) * nBlocks, (void**)&d_blockLen)) return r;
+    if (int r = ws_get(c, "skip", nBlocks, (void**)&d_skip)) return r;
+    if (int r = ws_get(c, "info", sizeof(BlockInfo) * nBlocks, (void**)&d_info)) return r;
+    {
+        ProfScope ps(c, "k_init_blocks");
+        // NONE sequence = one NullTransform that always succeeds -> skipFlags 0x7F (TransformSequence.hpp:97,145)
+        launch_init_blocks(s, n, bs, nBlocks, d_origLen, d_blockLen, d_skip, 0x7F);
+    }
+
+    // ---- transform stage (only NONE so far: the entropy stage reads d_in directly)
+    BlockView view;
+    view.base = d_in; view.stride = bs; view.len = d_blockLen;
+    int maxLen = (int)((n < bs) ? n : bs);
+    for (int i = 0; i < nTok; i++) maxLen = max_encoded_len(tok[i], maxLen);
+
+    // ---- entropy stage
+    const int maxChunks = (maxLen + (int)ENT_CHUNK - 1) / (int)ENT_CHUNK;
+    const size_t nSlots = (size_t)nBlocks * maxChunks;
+    ChunkDesc* d_desc; u8* d_tmp; uint2* d_encTab;
+    if (int r = ws_get(c, "desc", sizeof(ChunkDesc) * nSlots, (void**)&d_desc)) return r;
+    if (p->entropy_type == KNZ_E_ANS0) {
+        if (int r = ws_get(c, "chunkTmp", (size_t)TMP_STRIDE * nSlots, (void**)&d_tmp)) return r;
+        if (int r = ws_get(c, "encTab", sizeof(uint2) * 256 * nSlots, (void**)&d_encTab)) return r;
+        ProfScope ps(c, "ans0_encode");
+        launch_ans0_encode(s, view, nBlocks, maxChunks, d_desc, d_encTab, d_tmp);
+    } else {
+        if (int r = ws_get(c, "chunkTmp", 64, (void**)&d_tmp)) return r;
+        ProfScope ps(c, "none_encode");
+        launch_none_encode(s, view, nBlocks, maxChunks, d_desc);
+    }
+
+    // ---- framing + assembly
+    FrameParams fp;
+    fp.framing = framing; fp.nTransforms = nTok; fp.checksumBits = p->checksum_bits; fp.finish = finish; fp.prologueBits = prologueBits;
+    {
+        ProfScope ps(c, "k_block_sum+scan");
+        launch_block_sum(s, d_desc, d_info, d_blockLen, nBlocks, maxChunks, ENT_CHUNK);
+        launch_block_scan(s, d_info, d_blockLen, nBlocks, fp, d_total);
+    }
+    // The output must be zero before the OR-assembly; its size is only known on the device, so the
+    // total is read back first (8 bytes) and only the used part is cleared.
+    u64* h_total = reinterpret_cast<u64*>(c->pinned);
+    HIPCHK(c, hipMemcpyAsync(h_total, d_total, sizeof(u64), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    const u64 totalBits = *h_total;
+    const size_t outBytes = (size_t)((totalBits + 7) >> 3);
+    if (outBytes + 8 > outCap) return fail(c, KNZ_ERR_WRITE_FILE, "output buffer too small: need %zu have %zu", outBytes + 8, outCap);
+    {
+        ProfScope ps(c, "memset_out");
+        HIPCHK(c, hipMemsetAsync(d_out, 0, (outBytes + 8 + 3) & ~(size_t)3, s));
+    }
+    if (prologueBits) {
+        u8* d_pro;
+        if (int r = ws_get(c, "prologue", 256, (void**)&d_pro)) return r;
+        if ((prologueBits + 7) / 8 > 200) return fail(c, KNZ_ERR_INVALID_PARAM, "prologue too long");
+        HIPCHK(c, hipMemcpyAsync(d_pro, prologue, (prologueBits + 7) / 8, hipMemcpyHostToDevice, s));
+        launch_put_prologue(s, reinterpret_cast<u32*>(d_out), d_pro, prologueBits);
+    }
+    {
+        ProfScope ps(c, "k_assemble");
+        launch_assemble(s, d_desc, d_info, d_blockLen, d_origLen, d_skip, nullptr, d_tmp, nBlocks, maxChunks, ENT_CHUNK, fp,
+                        reinterpret_cast<u32*>(d_out));
+    }
+    HIPCHK(c, hipGetLastError());
+    if (outBits) {
+        HIPCHK(c, hipStreamSynchronize(s));
+        *outBits = totalBits;
+    }
+    return 0;
+}
+
+int knz_hip_encode_blocks(knz_ctx* ctx, const knz_params* p, const uint8_t* d_in, size_t n, const uint8_t* prologue,
+                          uint32_t prologue_bits, int64_t first_block_id, int finish, uint8_t* d_out, size_t out_cap,
+                          uint64_t* out_bits)
+{
+    (void)first_block_id;
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    return encode_impl(c, p, d_in, n, prologue, prologue_bits, 1, finish, d_out, out_cap, out_bits);
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode
+// ------------------------------------------------------------------------------------------------
+struct WalkResultHost { u64 endBit; int64_t nBlocks; int32_t ended; int32_t error; };
+
+static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_t inBits, uint64_t startBit, int64_t maxBlocks,
+                       int framing, u32 rawLen, uint8_t* d_out, size_t outCap, uint64_t* outBytes, uint64_t* endBit,
+                       int64_t* blocksDone, int32_t* rawDecoded, uint64_t* usedBits)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    if ((reinterpret_cast<uintptr_t>(d_in) & 15) || (reinterpret_cast<uintptr_t>(d_out) & 15))
+        return fail(c, KNZ_ERR_INVALID_PARAM, "device buffers must be 16-byte aligned");
+    const u32 bs = (u32)p->block_size;
+    int tok[8];
+    const int nTok = count_transforms(p->transform_type, tok);
+    for (int i = 0; i < nTok; i++)
+        if (!transform_supported(tok[i])) return fail(c, KNZ_ERR_INVALID_CODEC, "transform id %d not implemented on device", tok[i]);
+    if (!entropy_supported(p->entropy_type)) return fail(c, KNZ_ERR_INVALID_CODEC, "entropy id %d not implemented on device", p->entropy_type);
+    if (p->checksum_bits != 0) return fail(c, KNZ_ERR_INVALID_PARAM, "block checksums not implemented on device");
+    hipStream_t s = c->stream;
+
+    BitSrc src;
+    src.words = reinterpret_cast<const u32*>(d_in);
+    src.nBytes = (inBits + 7) >> 3;
+    src.nWords = src.nBytes >> 2;
+    src.limitBits = inBits;
+
+    int64_t bound = framing ? (int64_t)(outCap / bs) + 2 : 1;
+    if (maxBlocks > 0 && maxBlocks < bound) bound = maxBlocks;
+    DecBlock* d_blocks; void* d_walk;
+    if (int r = ws_get(c, "decBlocks", sizeof(DecBlock) * (size_t)bound, (void**)&d_blocks)) return r;
+    if (int r = ws_get(c, "walk", 64, &d_walk)) return r;
+    {
+        ProfScope ps(c, "k_walk_blocks");
+        launch_walk_blocks(s, src, startBit, bound, framing, rawLen, p->checksum_bits, bs, d_blocks, d_walk);
+    }
+    WalkResultHost* h_walk = reinterpret_cast<WalkResultHost*>(c->pinned);
+    HIPCHK(c, hipMemcpyAsync(h_walk, d_walk, sizeof(WalkResultHost), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    const WalkResultHost walk = *h_walk;
+    if (walk.error) return fail(c, walk.error, "invalid block framing");
+    const int nBlocks = (int)walk.nBlocks;
+    if (endBit) *endBit = walk.ended ? walk.endBit : walk.endBit;
+    if (blocksDone) *blocksDone = nBlocks;
+    if (nBlocks == 0) { if (outBytes) *outBytes = 0; return 0; }
+    if (framing && (size_t)nBlocks * bs > outCap + bs) return fail(c, KNZ_ERR_WRITE_FILE, "output buffer too small");
+
+    const u32 maxPre = framing ? bs : rawLen;         // NONE transform: preTransformLength <= block size
+    const int maxChunks = (int)((maxPre + ENT_CHUNK - 1) / ENT_CHUNK) > 0 ? (int)((maxPre + ENT_CHUNK - 1) / ENT_CHUNK) : 1;
+    const size_t nSlots = (size_t)nBlocks * maxChunks;
+    const u64 outStride = framing ? bs : 0;
+
+    // entropy stage decodes straight into d_out (no transforms yet); guard lengths first
+    {
+        ProfScope ps(c, "k_check_prelen");
+        launch_check_prelen(s, d_blocks, nBlocks, maxPre, outCap, outStride);
+    }
+    if (p->entropy_type == KNZ_E_ANS0) {
+        void* d_meta;
+        if (int r = ws_get(c, "ansDecChunks", ans0_dec_chunk_bytes() * nSlots, &d_meta)) return r;
+        ProfScope ps(c, "ans0_decode");
+        launch_ans0_decode(s, src, d_blocks, nBlocks, maxChunks, d_meta, d_out, outStride);
+    } else {
+        ProfScope ps(c, "none_decode");
+        launch_none_decode(s, src, d_blocks, nBlocks, d_out, outStride);
+    }
+    HIPCHK(c, hipGetLastError());
+    // results
+    std::vector<DecBlock> hb((size_t)nBlocks);
+    HIPCHK(c, hipMemcpyAsync(hb.data(), d_blocks, sizeof(DecBlock) * (size_t)nBlocks, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    u64 total = 0;
+    for (int b = 0; b < nBlocks; b++) {
+        if (hb[b].error) {
+            if (rawDecoded) { *rawDecoded = -1; if (usedBits) *usedBits = hb[b].usedBits; return 0; }
+            return fail(c, hb[b].error, "block %d: decoding failed (code %d)", b + 1, hb[b].error);
+        }
+        if (framing && b + 1 < nBlocks && hb[b].preLen != bs)
+            return fail(c, KNZ_ERR_PROCESS_BLOCK, "block %d: short non-final block (%u bytes) not supported", b + 1, hb[b].preLen);
+        total += hb[b].preLen;
+    }
+    if (outBytes) *outBytes = total;
+    if (rawDecoded) *rawDecoded = (int32_t)hb[0].preLen;
+    if (usedBits) *usedBits = hb[0].usedBits;
+    return 0;
+}
+
+int knz_hip_decode_blocks(knz_ctx* ctx, const knz_params* p, const uint8_t* d_in, uint64_t in_bits, uint64_t start_bit,
+                          int64_t max_blocks, uint8_t* d_out, size_t out_cap, uint64_t* out_bytes, uint64_t* end_bit,
+                          int64_t* blocks_done)
+{
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    return decode_impl(c, p, d_in, in_bits, start_bit, max_blocks, 1, 0, d_out, out_cap, out_bytes, end_bit, blocks_done,
+                       nullptr, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-stage (host buffers)
+// ------------------------------------------------------------------------------------------------
+int knz_hip_entropy_encode(knz_ctx* ctx, int entropy_type, const uint8_t* in, uint32_t n, uint8_t* out, size_t out_cap,
+                           uint64_t* out_bits)
+{
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (n == 0) { *out_bits = 0; return 0; }
+    knz_params p; memset(&p, 0, sizeof(p));
+    p.entropy_type = entropy_type; p.block_size = (int32_t)((n + 15) & ~15u); p.transform_type = 0;
+    u8 *d_in, *d_out;
+    const size_t cap = knz_hip_encode_bound(&p, n);
+    if (int r = ws_get(c, "stageIn", (size_t)n + 64, (void**)&d_in)) return r;
+    if (int r = ws_get(c, "stageOut", cap, (void**)&d_out)) return r;
+    HIPCHK(c, hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, c->stream));
+    u64 bits = 0;
+    if (int r = encode_impl(c, &p, d_in, n, nullptr, 0, 0, 0, d_out, cap, &bits)) return r;
+    const size_t bytes = (size_t)((bits + 7) >> 3);
+    if (bytes > out_cap) return fail(c, KNZ_ERR_WRITE_FILE, "output buffer too small");
+    HIPCHK(c, hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *out_bits = bits;
+    return 0;
+}
+
+int knz_hip_entropy_decode(knz_ctx* ctx, int entropy_type, const uint8_t* in, uint64_t in_bits, uint64_t start_bit,
+                           uint8_t* out, uint32_t n, int32_t* decoded, uint64_t* used_bits)
+{
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (n == 0) { *decoded = 0; if (used_bits) *used_bits = 0; return 0; }
+    knz_params p; memset(&p, 0, sizeof(p));
+    p.entropy_type = entropy_type; p.block_size = (int32_t)((n + 15) & ~15u);
+    const size_t inBytes = (size_t)((in_bits + 7) >> 3);
+    u8 *d_in, *d_out;
+    if (int r = ws_get(c, "stageIn", inBytes + 64, (void**)&d_in)) return r;
+    if (int r = ws_get(c, "stageOut", (size_t)n + 64, (void**)&d_out)) return r;
+    HIPCHK(c, hipMemcpyAsync(d_in, in, inBytes, hipMemcpyHostToDevice, c->stream));
+    u64 ob = 0;
+    if (int r = decode_impl(c, &p, d_in, in_bits, start_bit, 1, 0, n, d_out, n, &ob, nullptr, nullptr, decoded, used_bits)) return r;
+    if (*decoded == (int32_t)n) {
+        HIPCHK(c, hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+int knz_hip_transform_forward(knz_ctx* ctx, int transform_type, const uint8_t* in, int32_t n, uint8_t* out, int32_t dst_cap,
+                              int entropy_type, int32_t* out_len, int32_t* ok)
+{
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    (void)in; (void)n; (void)out; (void)dst_cap; (void)entropy_type;
+    *out_len = 0; *ok = 0;
+    return fail(c, KNZ_ERR_INVALID_CODEC, "transform id %d not implemented on device", transform_type);
+}
+
+int knz_hip_transform_inverse(knz_ctx* ctx, int transform_type, const uint8_t* in, int32_t n, uint8_t* out, int32_t dst_cap,
+                              int32_t* out_len, int32_t* ok)
+{
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    (void)in; (void)n; (void)out; (void)dst_cap;
+    *out_len = 0; *ok = 0;
+    return fail(c, KNZ_ERR_INVALID_CODEC, "transform id %d not implemented on device", transform_type);
+}
+
+}  // extern "C"

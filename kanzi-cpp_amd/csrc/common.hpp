@@ -1,0 +1,213 @@
+// Internal definitions shared by the gfx950 kernels and the C-ABI layer.
+// Wave size is 64 on CDNA4; all wave-level code below hard-codes it.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/knz_hip.h"
+
+namespace knz {
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+constexpr int WAVE = 64;
+constexpr u32 ENT_CHUNK = 16384;          // ANS0 / Huffman chunk (ANSRangeEncoder.cpp:59, HuffmanCommon.cpp:20-21)
+constexpr u32 HDR_BYTES = 576;            // per-chunk header bit buffer (max 3498 bits for ANS0)
+constexpr u32 HDR_WORDS = HDR_BYTES / 4;
+constexpr u32 PAY_BYTES = 33280;          // per-chunk payload staging (>= 2 bytes/symbol + tail), multiple of 256
+constexpr u32 TMP_STRIDE = HDR_BYTES + PAY_BYTES;   // 33856, multiple of 64
+
+// Blocks of one batch: block b occupies [base + b*stride, +len[b]).
+struct BlockView {
+    const u8* base;
+    u64 stride;
+    const u32* len;     // device array
+};
+
+// What one entropy "chunk" contributes to the block's bit stream, in order:
+// hdr bits (from the chunk's header buffer), mid bytes (inline), up to 4 pieces (device pointers,
+// bit counts, MSB-first from the first byte), trailer bytes (inline).
+struct ChunkDesc {
+    u32 hdrBits;
+    u32 midLen;          // bytes
+    u32 mid[6];          // up to 24 inline bytes, memory order
+    u32 nPieces;
+    u32 pieceBits[4];
+    u32 trailerLen;      // bytes
+    u32 trailer[2];      // up to 8 inline bytes, memory order
+    u32 aux;             // codec specific (alphabet size)
+    const u8* piecePtr[4];
+    u64 relBit;          // bit offset of this chunk inside the block's entropy payload (k_block_sum)
+    u64 totalBits;
+};
+
+// Per-block framing results
+struct BlockInfo {
+    u64 payloadBits;     // entropy bits of the block
+    u64 written;         // header + payload ("written" in EncodingTask::run)
+    u64 bitOff;          // position of the 5-bit length prefix in the output stream
+    u32 hdrBits;         // mode byte (+skip byte) + length field + checksum
+    u32 lw;
+};
+
+__device__ __forceinline__ u32 bswap32(u32 v) { return __builtin_bswap32(v); }
+
+__device__ __forceinline__ int ilog2_u32(u32 x) { return 31 - __clz((int)x); }
+
+// number of bits needed to represent v (0 -> 0)
+__device__ __forceinline__ u32 bitlen_u32(u32 v) { return v == 0 ? 0u : (u32)(32 - __clz((int)v)); }
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// Inclusive wave scan (sum) over 64 lanes using DPP-free shuffles.
+__device__ __forceinline__ u32 wave_incl_scan(u32 v)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 t = (u32)__shfl_up((int)v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ u32 wave_sum(u32 v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += (u32)__shfl_xor((int)v, d, 64);
+    return v;
+}
+
+__device__ __forceinline__ u32 wave_max(u32 v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        u32 t = (u32)__shfl_xor((int)v, d, 64);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ u64 wave_incl_scan64(u64 v)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u64 t = (u64)__shfl_up((long long)v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// OR `n` bits (value right-aligned, n <= 32) at bit position `pos` of an MSB-first bit buffer held
+// as 32-bit words in "stream order" (word w holds stream bits [32w, 32w+32), MSB first). LDS or global.
+__device__ __forceinline__ void or_bits_words(u32* words, u32 pos, u32 value, u32 n)
+{
+    if (n == 0) return;
+    const u32 w = pos >> 5;
+    const u32 o = pos & 31;
+    const u64 v = ((u64)value << (64 - n)) >> o;     // value placed in a 64-bit window starting at word w
+    const u32 hi = (u32)(v >> 32);
+    const u32 lo = (u32)v;
+    if (hi) atomicOr(&words[w], hi);
+    if (lo) atomicOr(&words[w + 1], lo);
+}
+
+// Same, but the destination is a byte stream in memory (global), addressed as big-endian 32-bit words:
+// memory word w must contain bswap32(stream word w).
+__device__ __forceinline__ void or_bits_mem(u32* memWords, u64 pos, u64 value, u32 n)
+{
+    // n <= 64 - 31 is not required: handle up to 57 bits by splitting
+    while (n > 0) {
+        const u32 take = n > 32 ? n - 32 : n;        // first the high part
+        const u32 part = (u32)((value >> (n - take)) & (take == 32 ? 0xFFFFFFFFull : ((1ull << take) - 1)));
+        const u64 w = pos >> 5;
+        const u32 o = (u32)(pos & 31);
+        const u64 v = ((u64)part << (64 - take)) >> o;
+        const u32 hi = (u32)(v >> 32);
+        const u32 lo = (u32)v;
+        if (hi) atomicOr(&memWords[w], bswap32(hi));
+        if (lo) atomicOr(&memWords[w + 1], bswap32(lo));
+        pos += take;
+        n -= take;
+    }
+}
+
+// --- launch helpers (host) ---
+struct Ctx;
+const char* hipErrStr(hipError_t e);
+
+}  // namespace knz
+
+namespace knz {
+
+// MSB-first bit reader over a byte stream held in global memory, read as aligned 32-bit words.
+// `nWords` bounds the loads (words past the end read as zero); `error` latches reads past `limitBits`.
+struct BitSrc {
+    const u32* words;    // 4-byte aligned
+    u64 nWords;          // complete words available
+    u64 nBytes;          // bytes available (the last 1-3 bytes are read individually)
+    u64 limitBits;
+};
+
+__device__ __forceinline__ u32 src_word(const BitSrc& s, u64 w)
+{
+    if (w < s.nWords) return bswap32(s.words[w]);
+    u32 v = 0;
+    const u8* p = reinterpret_cast<const u8*>(s.words);
+    for (u64 i = w * 4, k = 0; k < 4; i++, k++) v = (v << 8) | (i < s.nBytes ? p[i] : 0u);
+    return v;
+}
+
+// n in [0, 32]
+__device__ __forceinline__ u32 peek_bits(const BitSrc& s, u64 pos, u32 n)
+{
+    if (n == 0) return 0;
+    const u64 w = pos >> 5;
+    const u64 win = ((u64)src_word(s, w) << 32) | (u64)src_word(s, w + 1);
+    return (u32)((win << (pos & 31)) >> (64 - n));
+}
+
+__device__ __forceinline__ u32 take_bits(const BitSrc& s, u64& pos, u32 n, int& err)
+{
+    if (pos + n > s.limitBits) { err = 1; pos = s.limitBits; return 0; }
+    const u32 v = peek_bits(s, pos, n);
+    pos += n;
+    return v;
+}
+
+// EntropyUtils::readVarInt (entropy/EntropyUtils.cpp:261-285)
+__device__ __forceinline__ u32 take_varint(const BitSrc& s, u64& pos, int& err)
+{
+    u32 value = take_bits(s, pos, 8, err);
+    u32 res = value & 0x7F;
+    for (int shift = 7; value >= 128 && !err; shift += 7) {
+        value = take_bits(s, pos, 8, err);
+        if (shift == 28) {
+            if (value >= 128 || (value & 0x70) != 0) { err = 1; return 0; }
+            res |= (value & 0x0F) << shift;
+            return res;
+        }
+        res |= (value & 0x7F) << shift;
+    }
+    return res;
+}
+
+// Per-block decode bookkeeping
+struct DecBlock {
+    u64 payloadBit;      // first bit of the block's private stream (mode byte)
+    u64 bits;            // length of the private stream
+    u64 entropyBit;      // first entropy bit (after mode/len/checksum)
+    u64 checksum;
+    u32 preLen;          // preTransformLength
+    u32 skipFlags;
+    u32 copyBlock;
+    int32_t error;       // 0 or kanzi error code
+    u64 usedBits;        // bits consumed by the entropy decoder (relative to entropyBit)
+};
+
+}  // namespace knz
