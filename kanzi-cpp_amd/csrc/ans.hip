@@ -667,9 +667,9 @@ void launch_ans0_decode(hipStream_t s, BitSrc src, DecBlock* blocks, int nBlocks
 {
     AnsDecChunk* chunks = reinterpret_cast<AnsDecChunk*>(chunkMeta);
     const int nSlots = nBlocks * maxChunks;
-    hipLaunchKernelGGL(k_ans0_scan, dim3((nBlocks + 63) / 64), dim3(64), 0, s, src, blocks, nBlocks, maxChunks, chunks);
-    hipLaunchKernelGGL(k_ans0_decode, dim3((nSlots + 15) / 16), dim3(64), 0, s, src, blocks, maxChunks,
-                       nSlots, chunks, out, outStride);
+    { KScope ks_("k_ans0_scan"); hipLaunchKernelGGL(k_ans0_scan, dim3((nBlocks + 63) / 64), dim3(64), 0, s, src, blocks, nBlocks, maxChunks, chunks); }
+    { KScope ks_("k_ans0_decode"); hipLaunchKernelGGL(k_ans0_decode, dim3((nSlots + 15) / 16), dim3(64), 0, s, src, blocks, maxChunks,
+                       nSlots, chunks, out, outStride); }
 }
 
 size_t ans0_dec_chunk_bytes() { return sizeof(AnsDecChunk); }
@@ -677,8 +677,8 @@ size_t ans0_dec_chunk_bytes() { return sizeof(AnsDecChunk); }
 void launch_ans0_encode(hipStream_t s, BlockView view, int nBlocks, int maxChunks, ChunkDesc* desc, uint2* encTab, u8* tmp)
 {
     const int nSlots = nBlocks * maxChunks;
-    hipLaunchKernelGGL(k_ans0_stats, dim3(nSlots), dim3(64), 0, s, view, maxChunks, desc, encTab, tmp);
-    hipLaunchKernelGGL(k_ans0_encode, dim3((nSlots + 15) / 16), dim3(64), 0, s, view, maxChunks, nSlots, desc, encTab, tmp);
+    { KScope ks_("k_ans0_stats"); hipLaunchKernelGGL(k_ans0_stats, dim3(nSlots), dim3(64), 0, s, view, maxChunks, desc, encTab, tmp); }
+    { KScope ks_("k_ans0_encode"); hipLaunchKernelGGL(k_ans0_encode, dim3((nSlots + 15) / 16), dim3(64), 0, s, view, maxChunks, nSlots, desc, encTab, tmp); }
 }
 
 }  // namespace knz

@@ -57,17 +57,33 @@ static int ws_get(Ctx* c, const char* name, size_t bytes, void** out)
     return 0;
 }
 
-struct ProfScope {
+thread_local ProfHook* g_prof = nullptr;
+
+struct CtxProf : ProfHook {
     Ctx* c; int idx = -1;
-    ProfScope(Ctx* ctx, const char* name) : c(ctx) {
-        if (!c->profiling) return;
+    explicit CtxProf(Ctx* ctx) : c(ctx) {}
+    void begin(const char* name) override {
         ProfEntry e; e.name = name;
         hipEventCreate(&e.a); hipEventCreate(&e.b);
         hipEventRecord(e.a, c->stream);
         c->prof.push_back(e);
         idx = (int)c->prof.size() - 1;
     }
-    ~ProfScope() { if (idx >= 0) hipEventRecord(c->prof[idx].b, c->stream); }
+    void end() override { if (idx >= 0) hipEventRecord(c->prof[idx].b, c->stream); idx = -1; }
+};
+
+// Installs the hook for the duration of one API call when profiling is enabled.
+struct ProfInstall {
+    CtxProf hook;
+    explicit ProfInstall(Ctx* c) : hook(c) { g_prof = c->profiling ? &hook : nullptr; }
+    ~ProfInstall() { g_prof = nullptr; }
+};
+
+// memset / memcpy segments are timed under their own names
+struct ProfScope {
+    bool on;
+    ProfScope(Ctx*, const char* name) : on(g_prof != nullptr) { if (on) g_prof->begin(name); }
+    ~ProfScope() { if (on) g_prof->end(); }
 };
 
 static int count_transforms(uint64_t t, int* tok)
@@ -225,6 +241,7 @@ int knz_hip_sync(knz_ctx* ctx)
 static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t n, const uint8_t* prologue,
                        uint32_t prologueBits, int framing, int finish, uint8_t* d_out, size_t outCap, uint64_t* outBits)
 {
+    ProfInstall pi_(c);
     HIPCHK(c, hipSetDevice(c->device));
     if ((reinterpret_cast<uintptr_t>(d_in) & 15) || (reinterpret_cast<uintptr_t>(d_out) & 15))
         return fail(c, KNZ_ERR_INVALID_PARAM, "device buffers must be 16-byte aligned");
@@ -265,8 +282,7 @@ static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t 
     if (int r = ws_get(c, "skip", nBlocks, (void**)&d_skip)) return r;
     if (int r = ws_get(c, "info", sizeof(BlockInfo) * nBlocks, (void**)&d_info)) return r;
     {
-        ProfScope ps(c, "k_init_blocks");
-        // NONE sequence = one NullTransform that always succeeds -> skipFlags 0x7F (TransformSequence.hpp:97,145)
+                // NONE sequence = one NullTransform that always succeeds -> skipFlags 0x7F (TransformSequence.hpp:97,145)
         launch_init_blocks(s, n, bs, nBlocks, d_origLen, d_blockLen, d_skip, 0x7F);
     }
 
@@ -284,20 +300,17 @@ static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t 
     if (p->entropy_type == KNZ_E_ANS0) {
         if (int r = ws_get(c, "chunkTmp", (size_t)TMP_STRIDE * nSlots, (void**)&d_tmp)) return r;
         if (int r = ws_get(c, "encTab", sizeof(uint2) * 256 * nSlots, (void**)&d_encTab)) return r;
-        ProfScope ps(c, "ans0_encode");
-        launch_ans0_encode(s, view, nBlocks, maxChunks, d_desc, d_encTab, d_tmp);
+                launch_ans0_encode(s, view, nBlocks, maxChunks, d_desc, d_encTab, d_tmp);
     } else {
         if (int r = ws_get(c, "chunkTmp", 64, (void**)&d_tmp)) return r;
-        ProfScope ps(c, "none_encode");
-        launch_none_encode(s, view, nBlocks, maxChunks, d_desc);
+                launch_none_encode(s, view, nBlocks, maxChunks, d_desc);
     }
 
     // ---- framing + assembly
     FrameParams fp;
     fp.framing = framing; fp.nTransforms = nTok; fp.checksumBits = p->checksum_bits; fp.finish = finish; fp.prologueBits = prologueBits;
     {
-        ProfScope ps(c, "k_block_sum+scan");
-        launch_block_sum(s, d_desc, d_info, d_blockLen, nBlocks, maxChunks, ENT_CHUNK);
+                launch_block_sum(s, d_desc, d_info, d_blockLen, nBlocks, maxChunks, ENT_CHUNK);
         launch_block_scan(s, d_info, d_blockLen, nBlocks, fp, d_total);
     }
     // The output must be zero before the OR-assembly; its size is only known on the device, so the
@@ -320,8 +333,7 @@ static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t 
         launch_put_prologue(s, reinterpret_cast<u32*>(d_out), d_pro, prologueBits);
     }
     {
-        ProfScope ps(c, "k_assemble");
-        launch_assemble(s, d_desc, d_info, d_blockLen, d_origLen, d_skip, nullptr, d_tmp, nBlocks, maxChunks, ENT_CHUNK, fp,
+                launch_assemble(s, d_desc, d_info, d_blockLen, d_origLen, d_skip, nullptr, d_tmp, nBlocks, maxChunks, ENT_CHUNK, fp,
                         reinterpret_cast<u32*>(d_out));
     }
     HIPCHK(c, hipGetLastError());
@@ -350,6 +362,7 @@ static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_
                        int framing, u32 rawLen, uint8_t* d_out, size_t outCap, uint64_t* outBytes, uint64_t* endBit,
                        int64_t* blocksDone, int32_t* rawDecoded, uint64_t* usedBits)
 {
+    ProfInstall pi_(c);
     HIPCHK(c, hipSetDevice(c->device));
     if ((reinterpret_cast<uintptr_t>(d_in) & 15) || (reinterpret_cast<uintptr_t>(d_out) & 15))
         return fail(c, KNZ_ERR_INVALID_PARAM, "device buffers must be 16-byte aligned");
@@ -374,8 +387,7 @@ static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_
     if (int r = ws_get(c, "decBlocks", sizeof(DecBlock) * (size_t)bound, (void**)&d_blocks)) return r;
     if (int r = ws_get(c, "walk", 64, &d_walk)) return r;
     {
-        ProfScope ps(c, "k_walk_blocks");
-        launch_walk_blocks(s, src, startBit, bound, framing, rawLen, p->checksum_bits, bs, d_blocks, d_walk);
+                launch_walk_blocks(s, src, startBit, bound, framing, rawLen, p->checksum_bits, bs, d_blocks, d_walk);
     }
     WalkResultHost* h_walk = reinterpret_cast<WalkResultHost*>(c->pinned);
     HIPCHK(c, hipMemcpyAsync(h_walk, d_walk, sizeof(WalkResultHost), hipMemcpyDeviceToHost, s));
@@ -395,17 +407,14 @@ static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_
 
     // entropy stage decodes straight into d_out (no transforms yet); guard lengths first
     {
-        ProfScope ps(c, "k_check_prelen");
-        launch_check_prelen(s, d_blocks, nBlocks, maxPre, outCap, outStride);
+                launch_check_prelen(s, d_blocks, nBlocks, maxPre, outCap, outStride);
     }
     if (p->entropy_type == KNZ_E_ANS0) {
         void* d_meta;
         if (int r = ws_get(c, "ansDecChunks", ans0_dec_chunk_bytes() * nSlots, &d_meta)) return r;
-        ProfScope ps(c, "ans0_decode");
-        launch_ans0_decode(s, src, d_blocks, nBlocks, maxChunks, d_meta, d_out, outStride);
+                launch_ans0_decode(s, src, d_blocks, nBlocks, maxChunks, d_meta, d_out, outStride);
     } else {
-        ProfScope ps(c, "none_decode");
-        launch_none_decode(s, src, d_blocks, nBlocks, d_out, outStride);
+                launch_none_decode(s, src, d_blocks, nBlocks, d_out, outStride);
     }
     HIPCHK(c, hipGetLastError());
     // results

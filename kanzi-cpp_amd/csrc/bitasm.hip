@@ -253,25 +253,25 @@ __global__ void k_walk_blocks(BitSrc src, u64 startBit, int64_t maxBlocks, int f
 void launch_walk_blocks(hipStream_t s, BitSrc src, u64 startBit, int64_t maxBlocks, int framing, u32 rawLen, int checksumBits,
                         u32 blockSize, DecBlock* blocks, void* res)
 {
-    hipLaunchKernelGGL(k_walk_blocks, dim3(1), dim3(64), 0, s, src, startBit, maxBlocks, framing, rawLen, checksumBits,
-                       blockSize, blocks, reinterpret_cast<WalkResult*>(res));
+    { KScope ks_("k_walk_blocks"); hipLaunchKernelGGL(k_walk_blocks, dim3(1), dim3(64), 0, s, src, startBit, maxBlocks, framing, rawLen, checksumBits,
+                       blockSize, blocks, reinterpret_cast<WalkResult*>(res)); }
 }
 
 void launch_block_sum(hipStream_t s, ChunkDesc* desc, BlockInfo* info, const u32* blockLen, int nBlocks, int maxChunks, u32 chunkSize)
 {
-    hipLaunchKernelGGL(k_block_sum, dim3(nBlocks), dim3(256), 0, s, desc, info, blockLen, maxChunks, chunkSize);
+    { KScope ks_("k_block_sum"); hipLaunchKernelGGL(k_block_sum, dim3(nBlocks), dim3(256), 0, s, desc, info, blockLen, maxChunks, chunkSize); }
 }
 
 void launch_block_scan(hipStream_t s, BlockInfo* info, const u32* blockLen, int nBlocks, FrameParams fp, u64* totalBits)
 {
-    hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(64), 0, s, info, blockLen, nBlocks, fp, totalBits);
+    { KScope ks_("k_block_scan"); hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(64), 0, s, info, blockLen, nBlocks, fp, totalBits); }
 }
 
 void launch_assemble(hipStream_t s, const ChunkDesc* desc, const BlockInfo* info, const u32* blockLen, const u32* origLen, const u8* skipFlags,
                      const u64* checksums, const u8* hdrBase, int nBlocks, int maxChunks, u32 chunkSize, FrameParams fp, u32* out)
 {
-    hipLaunchKernelGGL(k_assemble, dim3(nBlocks * maxChunks), dim3(64), 0, s, desc, info, blockLen, origLen, skipFlags, checksums,
-                       hdrBase, maxChunks, chunkSize, fp, out);
+    { KScope ks_("k_assemble"); hipLaunchKernelGGL(k_assemble, dim3(nBlocks * maxChunks), dim3(64), 0, s, desc, info, blockLen, origLen, skipFlags, checksums,
+                       hdrBase, maxChunks, chunkSize, fp, out); }
 }
 
 __global__ void k_init_blocks(u64 n, u32 blockSize, int nBlocks, u32* origLen, u32* blockLen, u8* skipFlags, u8 skipInit)
@@ -287,7 +287,7 @@ __global__ void k_init_blocks(u64 n, u32 blockSize, int nBlocks, u32* origLen, u
 
 void launch_init_blocks(hipStream_t s, u64 n, u32 blockSize, int nBlocks, u32* origLen, u32* blockLen, u8* skipFlags, u8 skipInit)
 {
-    hipLaunchKernelGGL(k_init_blocks, dim3((nBlocks + 255) / 256), dim3(256), 0, s, n, blockSize, nBlocks, origLen, blockLen, skipFlags, skipInit);
+    { KScope ks_("k_init_blocks"); hipLaunchKernelGGL(k_init_blocks, dim3((nBlocks + 255) / 256), dim3(256), 0, s, n, blockSize, nBlocks, origLen, blockLen, skipFlags, skipInit); }
 }
 
 // Reject blocks whose declared length cannot be written (guards every later kernel).
@@ -302,12 +302,12 @@ __global__ void k_check_prelen(DecBlock* blocks, int nBlocks, u32 maxPre, u64 ou
 
 void launch_check_prelen(hipStream_t s, DecBlock* blocks, int nBlocks, u32 maxPre, u64 outCap, u64 outStride)
 {
-    hipLaunchKernelGGL(k_check_prelen, dim3((nBlocks + 255) / 256), dim3(256), 0, s, blocks, nBlocks, maxPre, outCap, outStride);
+    { KScope ks_("k_check_prelen"); hipLaunchKernelGGL(k_check_prelen, dim3((nBlocks + 255) / 256), dim3(256), 0, s, blocks, nBlocks, maxPre, outCap, outStride); }
 }
 
 void launch_put_prologue(hipStream_t s, u32* out, const u8* d_prologue, u32 bits)
 {
-    hipLaunchKernelGGL(k_put_prologue, dim3(1), dim3(64), 0, s, out, d_prologue, bits);
+    { KScope ks_("k_put_prologue"); hipLaunchKernelGGL(k_put_prologue, dim3(1), dim3(64), 0, s, out, d_prologue, bits); }
 }
 
 }  // namespace knz

@@ -141,6 +141,18 @@ __device__ __forceinline__ void or_bits_mem(u32* memWords, u64 pos, u64 value, u
 struct Ctx;
 const char* hipErrStr(hipError_t e);
 
+// Optional per-kernel timing hook (HIP events on the launch stream), installed by the API layer.
+struct ProfHook {
+    virtual void begin(const char* name) = 0;
+    virtual void end() = 0;
+    virtual ~ProfHook() {}
+};
+extern thread_local ProfHook* g_prof;
+struct KScope {
+    explicit KScope(const char* n) { if (g_prof) g_prof->begin(n); }
+    ~KScope() { if (g_prof) g_prof->end(); }
+};
+
 }  // namespace knz
 
 namespace knz {

@@ -37,12 +37,12 @@ __global__ __launch_bounds__(256) void k_none_decode(BitSrc src, DecBlock* block
 void launch_none_encode(hipStream_t s, BlockView view, int nBlocks, int maxChunks, ChunkDesc* desc)
 {
     const int nSlots = nBlocks * maxChunks;
-    hipLaunchKernelGGL(k_none_encode, dim3((nSlots + 255) / 256), dim3(256), 0, s, view, nBlocks, maxChunks, desc);
+    { KScope ks_("k_none_encode"); hipLaunchKernelGGL(k_none_encode, dim3((nSlots + 255) / 256), dim3(256), 0, s, view, nBlocks, maxChunks, desc); }
 }
 
 void launch_none_decode(hipStream_t s, BitSrc src, DecBlock* blocks, int nBlocks, u8* out, u64 outStride)
 {
-    hipLaunchKernelGGL(k_none_decode, dim3(64, nBlocks), dim3(256), 0, s, src, blocks, out, outStride);
+    { KScope ks_("k_none_decode"); hipLaunchKernelGGL(k_none_decode, dim3(64, nBlocks), dim3(256), 0, s, src, blocks, out, outStride); }
 }
 
 }  // namespace knz

@@ -89,6 +89,9 @@ int knzo_decode_block(const uint8_t* in, uint64_t nbits, uint64_t ttype, int ety
 int knzo_compress(const uint8_t* in, size_t n, const char* transform, const char* entropy,
                   int blockSize, int checksum, uint64_t origSize, int headerless,
                   uint8_t* out, size_t cap, size_t* outLen);
+int knzo_compress_jobs(const uint8_t* in, size_t n, const char* transform, const char* entropy,
+                       int blockSize, int checksum, uint64_t origSize, int headerless, int jobs,
+                       uint8_t* out, size_t cap, size_t* outLen);
 int knzo_decompress(const uint8_t* in, size_t inLen, uint8_t* out, size_t cap, size_t* outLen);
 
 /* XXHash32/64 as used for block checksums (util/XXHash.hpp:61-115,153-230), seed 0x4B414E5A */

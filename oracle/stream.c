@@ -380,6 +380,15 @@ int knzo_compress(const uint8_t* in, size_t n, const char* transform, const char
                   int blockSize, int checksum, uint64_t origSize, int headerless,
                   uint8_t* out, size_t cap, size_t* outLen)
 {
+    return knzo_compress_jobs(in, n, transform, entropy, blockSize, checksum, origSize, headerless, 1, out, cap, outLen);
+}
+
+/* `jobs` only selects which buffer slot (and therefore which capacities) a block sees:
+ * block i runs on slot i % jobs (io/CompressedOutputStream.cpp:447-473); SURVEY.md App. C #1. */
+int knzo_compress_jobs(const uint8_t* in, size_t n, const char* transform, const char* entropy,
+                       int blockSize, int checksum, uint64_t origSize, int headerless, int jobs,
+                       uint8_t* out, size_t cap, size_t* outLen)
+{
     *outLen = 0;
     const uint64_t ttype = knzo_transform_type(transform);
     const int etype = knzo_entropy_type(entropy);
@@ -402,14 +411,27 @@ int knzo_compress(const uint8_t* in, size_t n, const char* transform, const char
         knzo_bw_bits(&w, 0, 15);
         knzo_bw_bits(&w, header_checksum(ckSize, (uint32_t)etype, ttype, (uint32_t)blockSize, szMask, origSize), 24);
     }
-    int dataCap = blockSize + (blockSize >> 3);
-    if (dataCap < DEFAULT_BUFFER_SIZE) dataCap = DEFAULT_BUFFER_SIZE;
-    int bufCap = 0;
+    if (jobs < 1 || jobs > 64) return ERR_INVALID_PARAM;
+    int dataCaps[64], bufCaps[64];
+    for (int j = 0; j < jobs; j++) {
+        if (j == 0) {
+            dataCaps[j] = blockSize + (blockSize >> 3);
+            if (dataCaps[j] < DEFAULT_BUFFER_SIZE) dataCaps[j] = DEFAULT_BUFFER_SIZE;
+        } else {
+            dataCaps[j] = blockSize + (blockSize >> 6);
+            if (dataCaps[j] < 65536) dataCaps[j] = 65536;
+        }
+        bufCaps[j] = 0;
+    }
+    size_t blockIdx = 0;
     const size_t tmpCap = (size_t)blockSize + ((size_t)blockSize >> 1) + 65536;
     uint8_t* tmp = (uint8_t*)malloc(tmpCap);
     size_t off = 0;
     while (off < n) {
         const int len = (n - off < (size_t)blockSize) ? (int)(n - off) : blockSize;
+        const int slot = (int)(blockIdx % (size_t)jobs);
+        int dataCap = dataCaps[slot], bufCap = bufCaps[slot];
+        blockIdx++;
         int tok[8];
         const int nb = seq_tokens(len <= 15 ? 0 : ttype, tok);
         const int req = seq_required(tok, nb, len);
@@ -424,6 +446,7 @@ int knzo_compress(const uint8_t* in, size_t n, const char* transform, const char
             if (bs2 < DEFAULT_BUFFER_SIZE) bs2 = DEFAULT_BUFFER_SIZE;
             if (dataCap < bs2) dataCap = bs2;
         }
+        dataCaps[slot] = dataCap; bufCaps[slot] = bufCap;
         const uint64_t written = (uint64_t)bits;
         const unsigned lw = (written < 8) ? 3u : (unsigned)ilog2((uint32_t)(written >> 3)) + 4u;
         knzo_bw_bits(&w, lw - 3, 5);

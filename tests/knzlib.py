@@ -73,6 +73,9 @@ class Oracle:
         L.knzo_compress.restype = C.c_int
         L.knzo_compress.argtypes = [u8p, C.c_size_t, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_uint64,
                                     C.c_int, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.knzo_compress_jobs.restype = C.c_int
+        L.knzo_compress_jobs.argtypes = [u8p, C.c_size_t, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_uint64,
+                                         C.c_int, C.c_int, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.knzo_decompress.restype = C.c_int
         L.knzo_decompress.argtypes = [u8p, C.c_size_t, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.knzo_transform_type.restype = C.c_uint64
@@ -119,12 +122,12 @@ class Oracle:
         ok = self.L.knzo_bwt_forward_raw(_buf(data), len(data), out, prim)
         return ok, bytes(out[:len(data)]), list(prim)
 
-    def compress(self, data, transform, entropy, block_size, checksum=0, orig_size=0, headerless=0):
+    def compress(self, data, transform, entropy, block_size, checksum=0, orig_size=0, headerless=0, jobs=1):
         cap = len(data) + len(data) // 2 + (1 << 20)
         out = (C.c_uint8 * cap)()
         ol = C.c_size_t(0)
-        rc = self.L.knzo_compress(_buf(data), len(data), transform.encode(), entropy.encode(), block_size,
-                                  checksum, orig_size, headerless, out, cap, C.byref(ol))
+        rc = self.L.knzo_compress_jobs(_buf(data), len(data), transform.encode(), entropy.encode(), block_size,
+                                       checksum, orig_size, headerless, jobs, out, cap, C.byref(ol))
         return rc, bytes(out[:ol.value])
 
     def decompress(self, enc, cap):

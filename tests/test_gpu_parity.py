@@ -1,0 +1,148 @@
+"""Parity tests proper: the HIP path (through the C ABI, libknz_hip.so) against the oracle, the
+golden vectors generated from the reference, and size-independent properties at full block sizes.
+Bit-exact everywhere (integer/byte work)."""
+import hashlib
+import importlib
+
+import numpy as np
+import pytest
+
+import knzlib
+import vectors
+
+pytestmark = pytest.mark.gpu
+
+ENTROPY_ON_DEVICE = ["NONE", "ANS0"]
+TRANSFORMS_ON_DEVICE = []
+
+
+def matches(packed, b):
+    if packed["len"] != len(b):
+        return False
+    if "hex" in packed:
+        return packed["hex"] == b.hex()
+    return packed["md5"] == hashlib.md5(b).hexdigest()
+
+
+def stream_supported(transform, entropy):
+    return entropy in ENTROPY_ON_DEVICE and all(t in TRANSFORMS_ON_DEVICE or t == "NONE" for t in transform.split("+"))
+
+
+def gpu_compress(hip, data, transform, entropy, bs, checksum=0, orig_size=0, headerless=0):
+    knzlib.load_pkg()
+    fr = importlib.import_module("kanzi_amd.framing")
+    p = hip.params(transform, entropy, bs, checksum)
+    hdr, hb = (b"", 0) if headerless else fr.make_header(p.entropy_type, p.transform_type, bs, checksum, orig_size)
+    cap = hip.encode_bound(p, len(data)) + 64
+    d_in, d_out = hip.malloc(len(data) + 64), hip.malloc(cap)
+    hip.h2d(d_in, data)
+    bits = hip.encode_blocks(p, d_in, len(data), d_out, cap, prologue=hdr, prologue_bits=hb)
+    out = hip.d2h(d_out, (bits + 7) // 8)
+    hip.free(d_in); hip.free(d_out)
+    return out, bits, hb
+
+
+def gpu_decompress(hip, enc, transform, entropy, bs, n, start_bit, checksum=0):
+    p = hip.params(transform, entropy, bs, checksum)
+    d_in, d_out = hip.malloc(len(enc) + 64), hip.malloc(n + bs + 64)
+    hip.h2d(d_in, enc)
+    ob, eb, nb = hip.decode_blocks(p, d_in, 8 * len(enc), start_bit, d_out, n + bs)
+    out = hip.d2h(d_out, ob)
+    hip.free(d_in); hip.free(d_out)
+    return out
+
+
+def test_entropy_stage_golden(hip, golden):
+    n = 0
+    for rec in golden["stages"]:
+        if rec["kind"] != "entropy" or rec["name"] not in ENTROPY_ON_DEVICE:
+            continue
+        d = vectors.make(tuple(rec["input"]))
+        enc, bits = hip.entropy_encode(rec["name"], d)
+        assert bits == rec["bits"], (rec["name"], rec["input"])
+        assert matches(rec["out"], enc), (rec["name"], rec["input"])
+        dec, out, used = hip.entropy_decode(rec["name"], enc, len(d))
+        assert dec == len(d) and out == d and used == bits, (rec["name"], rec["input"])
+        n += 1
+    assert n >= 2 * len(vectors.STAGE_INPUTS)
+
+
+def test_entropy_stage_vs_oracle_random(hip, oracle):
+    rng = np.random.default_rng(77)
+    for i in range(12):
+        n = int(rng.integers(33, 200000))
+        if i % 3 == 0:
+            d = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        elif i % 3 == 1:
+            d = bytes((rng.geometric(0.02 + 0.08 * i, n) % 256).astype(np.uint8))
+        else:
+            d = vectors.make(("mixedslice", 2 << 20, 5 + i, 1000 * i, 1000 * i + n))
+        for e in ENTROPY_ON_DEVICE:
+            ref, rbits = oracle.entropy_encode(e, d)
+            got, gbits = hip.entropy_encode(e, d)
+            assert gbits == rbits and got == ref, (e, i, n)
+            dec, out, used = hip.entropy_decode(e, ref, n)
+            assert dec == n and out == d and used == rbits, (e, i, n)
+
+
+def test_entropy_decode_at_bit_offset(hip, oracle):
+    # the block framing hands the decoder arbitrary bit offsets
+    d = vectors.make(("text", 50000, 9))
+    for e in ENTROPY_ON_DEVICE:
+        enc, bits = oracle.entropy_encode(e, d)
+        for shift in (1, 5, 13):
+            v = int.from_bytes(enc, "big") << (8 - (shift % 8)) % 8 if shift % 8 else int.from_bytes(enc, "big")
+            shifted = (int.from_bytes(enc, "big") << ((-shift) % 8)).to_bytes(len(enc) + 1, "big")
+            buf = bytes(shift // 8) + shifted
+            start = 8 * (shift // 8) + (8 - ((-shift) % 8)) % 8 if False else None
+            # simpler: build the bit string explicitly
+            bitstr = "1" * shift + bin(int.from_bytes(enc, "big"))[2:].zfill(8 * len(enc))
+            bitstr += "0" * ((-len(bitstr)) % 8)
+            buf = int(bitstr, 2).to_bytes(len(bitstr) // 8, "big")
+            dec, out, used = hip.entropy_decode(e, buf, len(d), start_bit=shift)
+            assert dec == len(d) and out == d and used == bits, (e, shift)
+
+
+def test_truncated_payload_rejected(hip, oracle):
+    # src/test/TestEntropyCodec.cpp:230-274
+    d = vectors.make(("formula13", 4096))
+    for e in [x for x in ENTROPY_ON_DEVICE if x != "NONE"]:
+        enc, bits = oracle.entropy_encode(e, d)
+        dec, out, used = hip.entropy_decode(e, enc[:len(enc) // 2], len(d))
+        assert dec != len(d) or out != d
+
+
+def test_stream_golden(hip, golden):
+    n = 0
+    for rec in golden["streams"]:
+        if not stream_supported(rec["transform"], rec["entropy"]) or rec["checksum"]:
+            continue
+        d = vectors.make(tuple(rec["input"]))
+        out, bits, hb = gpu_compress(hip, d, rec["transform"], rec["entropy"], rec["block"], rec["checksum"],
+                                     rec["orig_size"], rec["headerless"])
+        assert matches(rec["out"], out), rec
+        back = gpu_decompress(hip, out, rec["transform"], rec["entropy"], rec["block"], len(d), hb, rec["checksum"])
+        assert back == d, rec
+        n += 1
+    assert n >= 3
+
+
+def test_stream_vs_oracle_ragged(hip, oracle):
+    for spec, bs in [(("mixed", 3 * 262144 + 777, 4), 262144), (("text", 100000, 3), 1024), (("rand", 40000, 1), 16384),
+                     (("ramp", 15), 1024), (("ramp", 16), 1024), (("ramp", 33), 1024), (("const", 50000, 7), 4096)]:
+        d = vectors.make(spec)
+        for e in ENTROPY_ON_DEVICE:
+            rc, ref = oracle.compress(d, "NONE", e, bs, headerless=1)
+            out, bits, hb = gpu_compress(hip, d, "NONE", e, bs, headerless=1)
+            assert out == ref, (spec, e)
+            assert gpu_decompress(hip, ref, "NONE", e, bs, len(d), 0) == d, (spec, e)
+
+
+def test_full_size_roundtrip_properties(hip):
+    # BASELINE config 2 geometry (4 MiB blocks): round trip + determinism on 32 MiB, checked on the device side
+    d = vectors.make(("mixed", 32 << 20, 2))
+    for e in ENTROPY_ON_DEVICE:
+        out1, bits1, _ = gpu_compress(hip, d, "NONE", e, 4 << 20, headerless=1)
+        out2, bits2, _ = gpu_compress(hip, d, "NONE", e, 4 << 20, headerless=1)
+        assert out1 == out2
+        assert gpu_decompress(hip, out1, "NONE", e, 4 << 20, len(d), 0) == d

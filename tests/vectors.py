@@ -1,0 +1,83 @@
+"""Deterministic test inputs shared by the golden generator and the tests. An input is a spec tuple."""
+import numpy as np
+
+import knzlib
+
+
+def make(spec):
+    kind = spec[0]
+    c = knzlib.corpus()
+    if kind == "text":
+        return c.text(spec[1], spec[2])
+    if kind == "mixed":
+        return c.mixed(spec[1], spec[2])
+    if kind == "mixedslice":          # mixed(total, seed)[a:b]
+        return c.mixed(spec[1], spec[2])[spec[3]:spec[4]]
+    if kind == "rand":
+        return np.random.default_rng(spec[2]).integers(0, 256, spec[1], dtype=np.uint8).tobytes()
+    if kind == "geom":                # skewed alphabet
+        return bytes((np.random.default_rng(spec[2]).geometric(spec[3] / 100.0, spec[1]) % 256).astype(np.uint8))
+    if kind == "const":
+        return bytes([spec[2]]) * spec[1]
+    if kind == "ramp":
+        return bytes((np.arange(spec[1]) & 255).astype(np.uint8))
+    if kind == "formula13":           # src/test/TestEntropyCodec.cpp:237-238
+        i = np.arange(spec[1], dtype=np.int64)
+        return bytes((((i * 13) ^ (i >> 3) ^ ((i & 15) << 4)) & 255).astype(np.uint8))
+    if kind == "mul17":               # src/test/TestEntropyCodec.cpp:283-284
+        return bytes(((np.arange(spec[1], dtype=np.int64) * 17) & 255).astype(np.uint8))
+    if kind == "fill17":              # src/test/test_api.py fill_buffer: (i*17+3)&255
+        return bytes(((np.arange(spec[1], dtype=np.int64) * 17 + 3) & 255).astype(np.uint8))
+    if kind == "kat32":               # src/test/TestTransforms.cpp:889-899
+        return bytes([0, 1, 2, 2, 2, 2, 7, 9, 9, 16, 16, 16, 1] + [3] * 19)
+    if kind == "runs":
+        return b"".join(bytes([i % 251]) * ((i * 37) % spec[1] + 1) for i in range(spec[2]))
+    if kind == "twosym":
+        return bytes((np.random.default_rng(spec[2]).integers(0, 2, spec[1]) * 7).astype(np.uint8))
+    if kind == "ffmix":
+        return bytes([0xFE, 0xFF, 0, 0, 0, 5, 0xFF, 0xFF] * spec[1])
+    if kind == "bytes":
+        return bytes.fromhex(spec[1])
+    if kind == "str":
+        return spec[1].encode()
+    raise ValueError(kind)
+
+
+STAGE_INPUTS = [
+    ("kat32",), ("str", "mississippi"), ("str", "3.14159265358979323846264338327950288419716939937510"),
+    ("str", "SIX.MIXED.PIXIES.SIFT.SIXTY.PIXIE.DUST.BOXES"),
+    ("const", 33, 65), ("const", 70000, 0), ("ramp", 255), ("ramp", 256), ("ramp", 1000),
+    ("formula13", 4096), ("mul17", 65536), ("fill17", 1024), ("text", 65536, 1), ("text", 16385, 4), ("text", 16387, 4),
+    ("text", 4096, 3), ("mixedslice", 5 * 262144, 2, 3 * 262144, 3 * 262144 + 70000), ("mixed", 300000, 2),
+    ("rand", 50000, 7), ("geom", 100001, 3, 30), ("twosym", 50000, 5), ("ffmix", 3000), ("runs", 9000, 60),
+    ("str", "abcabcabcabcabcabcab"), ("ramp", 33), ("ramp", 15), ("ramp", 1),
+]
+
+STREAM_CASES = [
+    # (input spec, transform, entropy, block size, checksum, headerless)
+    (("text", 4194304, 1), "NONE", "HUFFMAN", 4 << 20, 0, 0),
+    (("text", 4194304, 1), "NONE", "ANS0", 4 << 20, 0, 0),
+    (("text", 4194304, 1), "BWT+MTFT+ZRLT", "ANS0", 1 << 20, 0, 0),
+    (("text", 4194304, 1), "BWT+SRT+ZRLT", "FPAQ", 1 << 20, 0, 0),
+    (("text", 4194304, 1), "RLT", "HUFFMAN", 1 << 20, 0, 0),
+    (("mixed", 4194304, 2), "NONE", "HUFFMAN", 4 << 20, 0, 0),
+    (("mixed", 4194304, 2), "NONE", "ANS0", 4 << 20, 0, 0),
+    (("mixed", 4194304, 2), "BWT+MTFT+ZRLT", "ANS0", 1 << 20, 0, 0),
+    (("mixed", 4194304, 2), "BWT+SRT+ZRLT", "FPAQ", 1 << 20, 0, 0),
+    (("mixed", 4194304, 2), "RLT", "HUFFMAN", 1 << 20, 0, 0),
+    (("mixed", 3 * (1 << 20) + 12345, 2), "NONE", "ANS0", 1 << 20, 0, 1),
+    (("mixed", 3 * (1 << 20) + 12345, 2), "BWT+MTFT+ZRLT", "ANS0", 1 << 18, 32, 0),
+    (("mixed", 1 << 20, 3), "ZRLT", "HUFFMAN", 16384, 64, 0),
+    (("mixed", 1 << 20, 3), "SRT", "ANS1", 1 << 20, 0, 0),
+    (("mixed", 1 << 20, 3), "RLT+ZRLT", "FPAQ", 1 << 19, 0, 0),
+    (("mixed", 1 << 20, 3), "MTFT", "NONE", 1 << 20, 0, 0),
+    (("rand", 300000, 9), "BWT+MTFT+ZRLT", "ANS0", 1 << 18, 0, 0),
+    (("rand", 300000, 9), "ZRLT", "ANS0", 1 << 16, 0, 0),
+    (("ramp", 0), "NONE", "ANS0", 1024, 0, 0),
+    (("ramp", 1), "BWT+MTFT+ZRLT", "ANS0", 1024, 0, 0),
+    (("ramp", 15), "BWT+MTFT+ZRLT", "ANS0", 1024, 0, 0),
+    (("ramp", 16), "BWT+MTFT+ZRLT", "ANS0", 1024, 0, 0),
+    (("ramp", 1025), "BWT+MTFT+ZRLT", "ANS0", 1024, 0, 0),
+    (("const", 100000, 0), "BWT+MTFT+ZRLT", "ANS0", 65536, 0, 0),
+    (("const", 100000, 0), "RLT", "NONE", 65536, 0, 0),
+]
