@@ -54,7 +54,8 @@ typedef struct {
     int32_t entropy_type;
     int32_t block_size;
     int32_t checksum_bits;
-    int32_t reserved;
+    int32_t jobs;            /* reference job count being reproduced (0/1 = single). It only selects the
+                                buffer slot, hence the capacities, a block sees. */
 } knz_params;
 
 /* Upper bound, in bytes, of the bit-packed output of knz_hip_encode_blocks for n input bytes. */

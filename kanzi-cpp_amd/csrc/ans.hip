@@ -38,7 +38,7 @@ __global__ __launch_bounds__(64) void k_ans0_stats(BlockView view, int maxChunks
     const u32 start = (u32)ci * ENT_CHUNK;
     if (start >= len) return;
     const int lane = lane_id();
-    const u8* blk = view.base + (size_t)b * view.stride + start;
+    const u8* blk = view.ptr[b] + start;
     ChunkDesc* cd = desc + slot;
 
     if (len <= 32) {
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(64) void k_ans0_encode(BlockView view, int maxChunk
         if (len > 32 && start < len && desc[slot].aux > 1) {
             act = true;
             n = (len - start < ENT_CHUNK) ? (len - start) : ENT_CHUNK;
-            blk = view.base + (size_t)b * view.stride + start;
+            blk = view.ptr[b] + start;
         }
     }
     // cooperative table load (all 16 groups)
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(64) void k_ans0_scan(BitSrc src, DecBlock* __restri
 // 16 chunks per wave. Phase 1: the whole wave rebuilds each chunk's tables (parallel frequency
 // parse using the group offsets found by the scan). Phase 2: 4 lanes per chunk run the 4 states.
 __global__ __launch_bounds__(64) void k_ans0_decode(BitSrc src, DecBlock* __restrict__ blocks, int maxChunks, int nSlots,
-                                                    const AnsDecChunk* __restrict__ chunks, u8* __restrict__ out, u64 outStride)
+                                                    const AnsDecChunk* __restrict__ chunks, u8* const* __restrict__ outPtr)
 {
     __shared__ u8 f2sAll[16 * 4096];                           // slot -> symbol
     __shared__ u32 symAll[16 * 256];                           // freq | cum << 16
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(64) void k_ans0_decode(BitSrc src, DecBlock* __rest
         const int b = slot / maxChunks;
         const int ci = slot - b * maxChunks;
         if (c.kind == 3 || blocks[b].error) continue;
-        u8* dst = out + (size_t)b * outStride + (size_t)ci * ENT_CHUNK;
+        u8* dst = outPtr[b] + (size_t)ci * ENT_CHUNK;
         const u32 preLen = blocks[b].preLen;
         if (c.kind == 2) {
             for (u32 i = lane; i < c.sz; i += 64) dst[i] = (u8)peek_bits(src, c.payloadBit + 8ull * i, 8);
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(64) void k_ans0_decode(BitSrc src, DecBlock* __rest
             act = true;
             const u32 preLen = blocks[b].preLen;
             n = (preLen - (u32)ci * ENT_CHUNK < ENT_CHUNK) ? (preLen - (u32)ci * ENT_CHUNK) : ENT_CHUNK;
-            dst = out + (size_t)b * outStride + (size_t)ci * ENT_CHUNK;
+            dst = outPtr[b] + (size_t)ci * ENT_CHUNK;
         }
         cmeta.payloadBit = c.payloadBit; cmeta.sz = c.sz; cmeta.lr = c.lr;
         cmeta.st[0] = c.st[0]; cmeta.st[1] = c.st[1]; cmeta.st[2] = c.st[2]; cmeta.st[3] = c.st[3];
@@ -663,13 +663,13 @@ __global__ __launch_bounds__(64) void k_ans0_decode(BitSrc src, DecBlock* __rest
 }
 
 void launch_ans0_decode(hipStream_t s, BitSrc src, DecBlock* blocks, int nBlocks, int maxChunks, void* chunkMeta,
-                        u8* out, u64 outStride)
+                        u8* const* outPtr)
 {
     AnsDecChunk* chunks = reinterpret_cast<AnsDecChunk*>(chunkMeta);
     const int nSlots = nBlocks * maxChunks;
     { KScope ks_("k_ans0_scan"); hipLaunchKernelGGL(k_ans0_scan, dim3((nBlocks + 63) / 64), dim3(64), 0, s, src, blocks, nBlocks, maxChunks, chunks); }
     { KScope ks_("k_ans0_decode"); hipLaunchKernelGGL(k_ans0_decode, dim3((nSlots + 15) / 16), dim3(64), 0, s, src, blocks, maxChunks,
-                       nSlots, chunks, out, outStride); }
+                       nSlots, chunks, outPtr); }
 }
 
 size_t ans0_dec_chunk_bytes() { return sizeof(AnsDecChunk); }

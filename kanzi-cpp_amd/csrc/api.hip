@@ -6,6 +6,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -96,8 +97,8 @@ static int count_transforms(uint64_t t, int* tok)
     return nb;
 }
 
-static bool transform_supported(int t) { return t == KNZ_T_NONE; }
-static bool entropy_supported(int e) { return e == KNZ_E_NONE || e == KNZ_E_ANS0; }
+static bool transform_supported(int t) { return t == KNZ_T_NONE || t == KNZ_T_ZRLT || t == KNZ_T_MTFT || t == KNZ_T_BWT; }
+static bool entropy_supported(int e) { return e == KNZ_E_NONE || e == KNZ_E_ANS0 || e == KNZ_E_HUFFMAN; }
 
 static int max_encoded_len(int t, int n)
 {
@@ -236,10 +237,111 @@ int knz_hip_sync(knz_ctx* ctx)
 }
 
 // ------------------------------------------------------------------------------------------------
+// shared plumbing
+// ------------------------------------------------------------------------------------------------
+static int seq_required(const int* tok, int nTok, int n)
+{
+    int req = n;
+    for (int i = 0; i < nTok; i++) { const int nx = max_encoded_len(tok[i], req); if (nx > req) req = nx; }
+    return req;
+}
+
+struct SeqWs {
+    SeqArrays a;
+    u32* d_capEven; u32* d_capOdd;
+    const u8** d_viewPtr;
+    u8** d_entDst;
+    u8* A; u8* B; u64 S;
+    u32* scratch;
+};
+
+static int seq_alloc(Ctx* c, int nBlocks, u64 S, bool needAB, size_t scratchU32, SeqWs* w)
+{
+    u8* base;
+    const size_t nb = (size_t)nBlocks;
+    // one slab for all small per-block arrays
+    const size_t bytes = nb * (5 * 1 + 4 * 6 + 8 * 4) + 1024;
+    if (int r = ws_get(c, "seqSmall", bytes + 256, (void**)&base)) return r;
+    size_t off = 0;
+    auto take = [&](size_t sz, size_t align) { off = (off + align - 1) & ~(align - 1); u8* p = base + off; off += sz; return p; };
+    w->a.src = (const u8**)take(nb * 8, 16);
+    w->a.dst = (u8**)take(nb * 8, 16);
+    w->d_viewPtr = (const u8**)take(nb * 8, 16);
+    w->d_entDst = (u8**)take(nb * 8, 16);
+    w->a.len = (u32*)take(nb * 4, 16);
+    w->a.alen = (u32*)take(nb * 4, 16);
+    w->a.cap = (u32*)take(nb * 4, 16);
+    w->a.newLen = (u32*)take(nb * 4, 16);
+    w->d_capEven = (u32*)take(nb * 4, 16);
+    w->d_capOdd = (u32*)take(nb * 4, 16);
+    w->a.where = take(nb, 16);
+    w->a.swaps = take(nb, 16);
+    w->a.active = take(nb, 16);
+    w->a.skip = take(nb, 16);
+    w->a.ok = take(nb, 16);
+    w->a.bufCap = w->d_capEven;
+    w->a.dataCap = w->d_capOdd;
+    w->S = S;
+    w->A = w->B = nullptr;
+    if (needAB) {
+        if (int r = ws_get(c, "xfA", (size_t)S * nb + 256, (void**)&w->A)) return r;
+        if (int r = ws_get(c, "xfB", (size_t)S * nb + 256, (void**)&w->B)) return r;
+    }
+    w->scratch = nullptr;
+    if (scratchU32) { if (int r = ws_get(c, "xfScratch", scratchU32 * 4 + 64, (void**)&w->scratch)) return r; }
+    return 0;
+}
+
+static size_t stage_scratch_u32(int t, int nBlocks, u32 maxLen)
+{
+    switch (t) {
+    case KNZ_T_ZRLT: return zrlt_scratch_u32(nBlocks, maxLen);
+    case KNZ_T_MTFT: return mtft_scratch_u32(nBlocks, maxLen);
+    default: return 0;
+    }
+}
+
+static int run_forward_stage(Ctx* c, hipStream_t s, int t, const XfStage& st)
+{
+    switch (t) {
+    case KNZ_T_ZRLT: launch_zrlt_forward(s, st); break;
+    case KNZ_T_MTFT: launch_mtft_forward(s, st); break;
+    case KNZ_T_BWT: {
+        const size_t bytes = bwt_forward_scratch_bytes(st.nBlocks, st.maxLen, (size_t)st.nBlocks * st.maxLen);
+        void* sc;
+        if (int r = ws_get(c, "bwtScratch", bytes, &sc)) return r;
+        if (launch_bwt_forward(s, st, sc, bytes, reinterpret_cast<u32*>(c->pinned)) != 0) return fail(c, -1, "BWT forward failed: %s", hipGetErrorString(hipGetLastError()));
+        break;
+    }
+    default: break;
+    }
+    return 0;
+}
+
+static int run_inverse_stage(Ctx* c, hipStream_t s, int t, const XfStage& st)
+{
+    switch (t) {
+    case KNZ_T_ZRLT: launch_zrlt_inverse(s, st); break;
+    case KNZ_T_MTFT: launch_mtft_inverse(s, st); break;
+    case KNZ_T_BWT: {
+        const size_t bytes = bwt_inverse_scratch_bytes(st.nBlocks, st.maxLen, (size_t)st.nBlocks * st.maxLen);
+        void* sc;
+        if (int r = ws_get(c, "bwtScratch", bytes, &sc)) return r;
+        if (launch_bwt_inverse(s, st, sc, bytes, reinterpret_cast<u32*>(c->pinned)) != 0) return fail(c, -1, "BWT inverse failed: %s", hipGetErrorString(hipGetLastError()));
+        break;
+    }
+    default: break;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // encode
 // ------------------------------------------------------------------------------------------------
+// capsMode: 0 = reference stream buffers (jobs model), otherwise every destination capacity = capsMode (per-stage API)
 static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t n, const uint8_t* prologue,
-                       uint32_t prologueBits, int framing, int finish, uint8_t* d_out, size_t outCap, uint64_t* outBits)
+                       uint32_t prologueBits, int framing, int finish, int64_t firstBlock, uint8_t* d_out, size_t outCap,
+                       uint64_t* outBits)
 {
     ProfInstall pi_(c);
     HIPCHK(c, hipSetDevice(c->device));
@@ -275,44 +377,91 @@ static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t 
         return 0;
     }
 
-    // block bookkeeping
-    u32 *d_origLen, *d_blockLen; u8* d_skip; BlockInfo* d_info;
+    // ---- block bookkeeping
+    u32 *d_origLen; BlockInfo* d_info;
     if (int r = ws_get(c, "origLen", sizeof(u32) * nBlocks, (void**)&d_origLen)) return r;
-    if (int r = ws_get(c, "blockLen", sizeof(u32) * nBlocks, (void**)&d_blockLen)) return r;
-    if (int r = ws_get(c, "skip", nBlocks, (void**)&d_skip)) return r;
     if (int r = ws_get(c, "info", sizeof(BlockInfo) * nBlocks, (void**)&d_info)) return r;
-    {
-                // NONE sequence = one NullTransform that always succeeds -> skipFlags 0x7F (TransformSequence.hpp:97,145)
-        launch_init_blocks(s, n, bs, nBlocks, d_origLen, d_blockLen, d_skip, 0x7F);
+    const int maxIn = (int)((n < bs) ? n : bs);
+    const int required = seq_required(tok, nTok, maxIn);
+    const u64 S = ((u64)required + 255) & ~255ull;
+    bool realStages = false;
+    size_t scratch = 0;
+    for (int i = 0; i < nTok; i++) if (tok[i] != KNZ_T_NONE) { realStages = true; const size_t q = stage_scratch_u32(tok[i], nBlocks, (u32)S); if (q > scratch) scratch = q; }
+    SeqWs w;
+    if (int r = seq_alloc(c, nBlocks, S, realStages, scratch, &w)) return r;
+    w.a.origLen = d_origLen;
+    launch_init_blocks(s, n, bs, nBlocks, d_origLen, w.a.len);
+
+    // destination capacities the reference would present (io/CompressedOutputStream.cpp:141,461-462,733-739):
+    // block i runs on buffer slot i % jobs; "data" of slot 0 is max(bs + bs/8, 256 KiB), of the others
+    // max(bs + bs/64, 64 KiB); "buffer" grows to the largest requiredSize seen on the slot.
+    if (realStages) {
+        const int jobs = (p->jobs <= 0) ? 1 : (p->jobs > 64 ? 64 : p->jobs);
+        if ((size_t)nBlocks * 8 > c->pinnedCap) return fail(c, KNZ_ERR_INVALID_PARAM, "too many blocks in one batch (%d)", nBlocks);
+        u32* h = reinterpret_cast<u32*>(c->pinned);
+        u32* hEven = h; u32* hOdd = h + nBlocks;
+        std::vector<u32> slotBuf((size_t)jobs, 0);
+        for (int64_t b = 0; b < nBlocks; b++) {
+            const int64_t gid = firstBlock + b;
+            const int slot = (int)(gid % jobs);
+            const u32 len = (u32)(((size_t)(b + 1) * bs <= n) ? bs : n - (size_t)b * bs);
+            const u32 req = (u32)seq_required(tok, nTok, (int)len);
+            // a slot's buffer is at least what a full block needed earlier on that slot
+            u32 bufc = slotBuf[slot];
+            if (gid >= jobs) { const u32 full = (u32)seq_required(tok, nTok, (int)bs); if (bufc < full) bufc = full; }
+            if (bufc < req) bufc = req;
+            slotBuf[slot] = bufc;
+            u32 datac = (slot == 0) ? std::max(bs + (bs >> 3), 256u * 1024u) : std::max(bs + (bs >> 6), 65536u);
+            if (!framing) { bufc = (u32)p->jobs; datac = (u32)p->jobs; }      // per-stage API: explicit capacity
+            hEven[b] = framing ? std::max(bufc, req) : bufc;
+            hOdd[b] = framing ? std::max(datac, req) : datac;
+        }
+        HIPCHK(c, hipMemcpyAsync(w.d_capEven, hEven, sizeof(u32) * nBlocks, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(w.d_capOdd, hOdd, sizeof(u32) * nBlocks, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipStreamSynchronize(s));     // pinned scratch is reused below
     }
 
-    // ---- transform stage (only NONE so far: the entropy stage reads d_in directly)
+    // ---- transform stages
+    for (int i = 0; i < nTok; i++) {
+        launch_seq_fwd_prepare(s, w.a, nBlocks, i, d_in, bs, w.A, w.B, S);
+        if (tok[i] == KNZ_T_NONE) {
+            launch_seq_fwd_null(s, w.a, nBlocks, i);
+            continue;
+        }
+        XfStage st;
+        st.src = w.a.src; st.dst = w.a.dst; st.len = w.a.alen; st.cap = w.a.cap; st.ok = w.a.ok; st.newLen = w.a.newLen;
+        st.nBlocks = nBlocks; st.maxLen = (u32)S; st.scratchU32 = w.scratch; st.entropyType = p->entropy_type;
+        if (int r = run_forward_stage(c, s, tok[i], st)) return r;
+        launch_seq_fwd_commit(s, w.a, nBlocks, i);
+    }
+    launch_seq_fwd_finish(s, w.a, nBlocks, d_in, bs, w.A, w.B, S, w.d_viewPtr);
     BlockView view;
-    view.base = d_in; view.stride = bs; view.len = d_blockLen;
-    int maxLen = (int)((n < bs) ? n : bs);
-    for (int i = 0; i < nTok; i++) maxLen = max_encoded_len(tok[i], maxLen);
+    view.ptr = w.d_viewPtr; view.len = w.a.len;
+    u32* d_blockLen = w.a.len;
+    u8* d_skip = w.a.skip;
 
     // ---- entropy stage
-    const int maxChunks = (maxLen + (int)ENT_CHUNK - 1) / (int)ENT_CHUNK;
+    const int maxChunks = (int)((S + ENT_CHUNK - 1) / ENT_CHUNK);
     const size_t nSlots = (size_t)nBlocks * maxChunks;
     ChunkDesc* d_desc; u8* d_tmp; uint2* d_encTab;
     if (int r = ws_get(c, "desc", sizeof(ChunkDesc) * nSlots, (void**)&d_desc)) return r;
     if (p->entropy_type == KNZ_E_ANS0) {
         if (int r = ws_get(c, "chunkTmp", (size_t)TMP_STRIDE * nSlots, (void**)&d_tmp)) return r;
         if (int r = ws_get(c, "encTab", sizeof(uint2) * 256 * nSlots, (void**)&d_encTab)) return r;
-                launch_ans0_encode(s, view, nBlocks, maxChunks, d_desc, d_encTab, d_tmp);
+        launch_ans0_encode(s, view, nBlocks, maxChunks, d_desc, d_encTab, d_tmp);
+    } else if (p->entropy_type == KNZ_E_HUFFMAN) {
+        if (int r = ws_get(c, "chunkTmp", (size_t)TMP_STRIDE * nSlots, (void**)&d_tmp)) return r;
+        launch_huffman_encode(s, view, nBlocks, maxChunks, d_desc, d_tmp);
     } else {
         if (int r = ws_get(c, "chunkTmp", 64, (void**)&d_tmp)) return r;
-                launch_none_encode(s, view, nBlocks, maxChunks, d_desc);
+        launch_none_encode(s, view, nBlocks, maxChunks, d_desc);
     }
 
     // ---- framing + assembly
     FrameParams fp;
     fp.framing = framing; fp.nTransforms = nTok; fp.checksumBits = p->checksum_bits; fp.finish = finish; fp.prologueBits = prologueBits;
-    {
-                launch_block_sum(s, d_desc, d_info, d_blockLen, nBlocks, maxChunks, ENT_CHUNK);
-        launch_block_scan(s, d_info, d_blockLen, nBlocks, fp, d_total);
-    }
+    launch_block_sum(s, d_desc, d_info, d_blockLen, nBlocks, maxChunks, ENT_CHUNK);
+    launch_block_scan(s, d_info, d_blockLen, nBlocks, fp, d_total);
     // The output must be zero before the OR-assembly; its size is only known on the device, so the
     // total is read back first (8 bytes) and only the used part is cleared.
     u64* h_total = reinterpret_cast<u64*>(c->pinned);
@@ -332,10 +481,8 @@ static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t 
         HIPCHK(c, hipMemcpyAsync(d_pro, prologue, (prologueBits + 7) / 8, hipMemcpyHostToDevice, s));
         launch_put_prologue(s, reinterpret_cast<u32*>(d_out), d_pro, prologueBits);
     }
-    {
-                launch_assemble(s, d_desc, d_info, d_blockLen, d_origLen, d_skip, nullptr, d_tmp, nBlocks, maxChunks, ENT_CHUNK, fp,
-                        reinterpret_cast<u32*>(d_out));
-    }
+    launch_assemble(s, d_desc, d_info, d_blockLen, d_origLen, d_skip, nullptr, d_tmp, nBlocks, maxChunks, ENT_CHUNK, fp,
+                    reinterpret_cast<u32*>(d_out));
     HIPCHK(c, hipGetLastError());
     if (outBits) {
         HIPCHK(c, hipStreamSynchronize(s));
@@ -348,9 +495,8 @@ int knz_hip_encode_blocks(knz_ctx* ctx, const knz_params* p, const uint8_t* d_in
                           uint32_t prologue_bits, int64_t first_block_id, int finish, uint8_t* d_out, size_t out_cap,
                           uint64_t* out_bits)
 {
-    (void)first_block_id;
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
-    return encode_impl(c, p, d_in, n, prologue, prologue_bits, 1, finish, d_out, out_cap, out_bits);
+    return encode_impl(c, p, d_in, n, prologue, prologue_bits, 1, finish, first_block_id, d_out, out_cap, out_bits);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -386,35 +532,60 @@ static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_
     DecBlock* d_blocks; void* d_walk;
     if (int r = ws_get(c, "decBlocks", sizeof(DecBlock) * (size_t)bound, (void**)&d_blocks)) return r;
     if (int r = ws_get(c, "walk", 64, &d_walk)) return r;
-    {
-                launch_walk_blocks(s, src, startBit, bound, framing, rawLen, p->checksum_bits, bs, d_blocks, d_walk);
-    }
+    launch_walk_blocks(s, src, startBit, bound, framing, rawLen, p->checksum_bits, bs, d_blocks, d_walk);
     WalkResultHost* h_walk = reinterpret_cast<WalkResultHost*>(c->pinned);
     HIPCHK(c, hipMemcpyAsync(h_walk, d_walk, sizeof(WalkResultHost), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     const WalkResultHost walk = *h_walk;
     if (walk.error) return fail(c, walk.error, "invalid block framing");
     const int nBlocks = (int)walk.nBlocks;
-    if (endBit) *endBit = walk.ended ? walk.endBit : walk.endBit;
+    if (endBit) *endBit = walk.endBit;
     if (blocksDone) *blocksDone = nBlocks;
     if (nBlocks == 0) { if (outBytes) *outBytes = 0; return 0; }
     if (framing && (size_t)nBlocks * bs > outCap + bs) return fail(c, KNZ_ERR_WRITE_FILE, "output buffer too small");
 
-    const u32 maxPre = framing ? bs : rawLen;         // NONE transform: preTransformLength <= block size
-    const int maxChunks = (int)((maxPre + ENT_CHUNK - 1) / ENT_CHUNK) > 0 ? (int)((maxPre + ENT_CHUNK - 1) / ENT_CHUNK) : 1;
+    // workspace stride: large enough for every valid preTransformLength of this chain
+    const u32 unit = framing ? bs : rawLen;
+    const int required = seq_required(tok, nTok, (int)unit);
+    const u64 S = ((u64)required + 255) & ~255ull;
+    const u32 maxPre = (u32)S;
+    bool realStages = false;
+    size_t scratch = 0;
+    for (int i = 0; i < nTok; i++) if (tok[i] != KNZ_T_NONE) { realStages = true; const size_t q = stage_scratch_u32(tok[i], nBlocks, (u32)S); if (q > scratch) scratch = q; }
+    SeqWs w;
+    if (int r = seq_alloc(c, nBlocks, S, realStages, scratch, &w)) return r;
+    const int maxChunks = (int)((S + ENT_CHUNK - 1) / ENT_CHUNK);
     const size_t nSlots = (size_t)nBlocks * maxChunks;
     const u64 outStride = framing ? bs : 0;
 
-    // entropy stage decodes straight into d_out (no transforms yet); guard lengths first
-    {
-                launch_check_prelen(s, d_blocks, nBlocks, maxPre, outCap, outStride);
-    }
+    // entropy stage decodes into workspace A (or straight into d_out when no transform applies)
+    launch_check_prelen(s, d_blocks, nBlocks, realStages ? maxPre : unit, outCap, outStride);
+    launch_seq_inv_entropy_dst(s, w.a, d_blocks, nBlocks, d_out, outStride, w.A, S, w.d_entDst);
     if (p->entropy_type == KNZ_E_ANS0) {
         void* d_meta;
         if (int r = ws_get(c, "ansDecChunks", ans0_dec_chunk_bytes() * nSlots, &d_meta)) return r;
-                launch_ans0_decode(s, src, d_blocks, nBlocks, maxChunks, d_meta, d_out, outStride);
+        launch_ans0_decode(s, src, d_blocks, nBlocks, maxChunks, d_meta, w.d_entDst);
+    } else if (p->entropy_type == KNZ_E_HUFFMAN) {
+        void* d_meta;
+        if (int r = ws_get(c, "hufDecChunks", huffman_dec_chunk_bytes() * nSlots, &d_meta)) return r;
+        launch_huffman_decode(s, src, d_blocks, nBlocks, maxChunks, d_meta, w.d_entDst);
     } else {
-                launch_none_decode(s, src, d_blocks, nBlocks, d_out, outStride);
+        launch_none_decode(s, src, d_blocks, nBlocks, w.d_entDst);
+    }
+    // inverse transforms, last stage first (TransformSequence.hpp:197-224)
+    if (realStages) {
+        const u32 capFinal = framing ? bs : (u32)p->jobs;           // per-stage API passes its capacity in p->jobs
+        const u32 blkLenModel = std::max(bs + 512u, bs + (bs >> 4));
+        const u32 capMid = framing ? (u32)std::min<u64>(S, blkLenModel) : (u32)p->jobs;
+        for (int i = nTok - 1; i >= 0; i--) {
+            if (tok[i] == KNZ_T_NONE) continue;
+            launch_seq_inv_prepare(s, w.a, d_blocks, nBlocks, i, d_out, outStride, w.A, w.B, S, capMid, capFinal);
+            XfStage st;
+            st.src = w.a.src; st.dst = w.a.dst; st.len = w.a.alen; st.cap = w.a.cap; st.ok = w.a.ok; st.newLen = w.a.newLen;
+            st.nBlocks = nBlocks; st.maxLen = (u32)S; st.scratchU32 = w.scratch; st.entropyType = p->entropy_type;
+            if (int r = run_inverse_stage(c, s, tok[i], st)) return r;
+            launch_seq_inv_commit(s, w.a, d_blocks, nBlocks, i, tok[i]);
+        }
     }
     HIPCHK(c, hipGetLastError());
     // results
@@ -462,7 +633,7 @@ int knz_hip_entropy_encode(knz_ctx* ctx, int entropy_type, const uint8_t* in, ui
     if (int r = ws_get(c, "stageOut", cap, (void**)&d_out)) return r;
     HIPCHK(c, hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, c->stream));
     u64 bits = 0;
-    if (int r = encode_impl(c, &p, d_in, n, nullptr, 0, 0, 0, d_out, cap, &bits)) return r;
+    if (int r = encode_impl(c, &p, d_in, n, nullptr, 0, 0, 0, 0, d_out, cap, &bits)) return r;
     const size_t bytes = (size_t)((bits + 7) >> 3);
     if (bytes > out_cap) return fail(c, KNZ_ERR_WRITE_FILE, "output buffer too small");
     HIPCHK(c, hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -492,22 +663,59 @@ int knz_hip_entropy_decode(knz_ctx* ctx, int entropy_type, const uint8_t* in, ui
     return 0;
 }
 
+static int transform_host(Ctx* c, int t, int forward, const uint8_t* in, int32_t n, uint8_t* out, int32_t dstCap, int etype,
+                          int32_t* outLen, int32_t* ok)
+{
+    ProfInstall pi_(c);
+    *outLen = 0; *ok = 0;
+    if (!transform_supported(t) || t == KNZ_T_NONE) return fail(c, KNZ_ERR_INVALID_CODEC, "transform id %d not implemented on device", t);
+    if (n < 0 || dstCap < 0) return fail(c, KNZ_ERR_INVALID_PARAM, "negative size");
+    if (n == 0) { *ok = 1; return 0; }
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const u32 maxLen = (u32)std::max(n, dstCap) + 2048;
+    SeqWs w;
+    if (int r = seq_alloc(c, 1, maxLen, false, stage_scratch_u32(t, 1, maxLen), &w)) return r;
+    u8 *d_in, *d_out;
+    if (int r = ws_get(c, "stageIn", (size_t)n + 64, (void**)&d_in)) return r;
+    if (int r = ws_get(c, "stageOut", (size_t)maxLen + 64, (void**)&d_out)) return r;
+    HIPCHK(c, hipMemcpyAsync(d_in, in, (size_t)n, hipMemcpyHostToDevice, s));
+    struct { const u8* src; u8* dst; u32 len; u32 cap; } h;
+    h.src = d_in; h.dst = d_out; h.len = (u32)n; h.cap = (u32)dstCap;
+    HIPCHK(c, hipMemcpyAsync(w.a.src, &h.src, 8, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(w.a.dst, &h.dst, 8, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(w.a.alen, &h.len, 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(w.a.cap, &h.cap, 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemsetAsync(w.a.ok, 0, 1, s));
+    HIPCHK(c, hipMemsetAsync(w.a.newLen, 0, 4, s));
+    XfStage st;
+    st.src = w.a.src; st.dst = w.a.dst; st.len = w.a.alen; st.cap = w.a.cap; st.ok = w.a.ok; st.newLen = w.a.newLen;
+    st.nBlocks = 1; st.maxLen = (u32)n; st.scratchU32 = w.scratch; st.entropyType = etype;
+    if (int r = forward ? run_forward_stage(c, s, t, st) : run_inverse_stage(c, s, t, st)) return r;
+    HIPCHK(c, hipGetLastError());
+    u8 hok = 0; u32 hlen = 0;
+    HIPCHK(c, hipMemcpyAsync(&hok, w.a.ok, 1, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&hlen, w.a.newLen, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    *ok = hok;
+    if (hok) {
+        *outLen = (int32_t)hlen;
+        HIPCHK(c, hipMemcpyAsync(out, d_out, hlen, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+    }
+    return 0;
+}
+
 int knz_hip_transform_forward(knz_ctx* ctx, int transform_type, const uint8_t* in, int32_t n, uint8_t* out, int32_t dst_cap,
                               int entropy_type, int32_t* out_len, int32_t* ok)
 {
-    Ctx* c = reinterpret_cast<Ctx*>(ctx);
-    (void)in; (void)n; (void)out; (void)dst_cap; (void)entropy_type;
-    *out_len = 0; *ok = 0;
-    return fail(c, KNZ_ERR_INVALID_CODEC, "transform id %d not implemented on device", transform_type);
+    return transform_host(reinterpret_cast<Ctx*>(ctx), transform_type, 1, in, n, out, dst_cap, entropy_type, out_len, ok);
 }
 
 int knz_hip_transform_inverse(knz_ctx* ctx, int transform_type, const uint8_t* in, int32_t n, uint8_t* out, int32_t dst_cap,
                               int32_t* out_len, int32_t* ok)
 {
-    Ctx* c = reinterpret_cast<Ctx*>(ctx);
-    (void)in; (void)n; (void)out; (void)dst_cap;
-    *out_len = 0; *ok = 0;
-    return fail(c, KNZ_ERR_INVALID_CODEC, "transform id %d not implemented on device", transform_type);
+    return transform_host(reinterpret_cast<Ctx*>(ctx), transform_type, 0, in, n, out, dst_cap, -1, out_len, ok);
 }
 
 }  // extern "C"

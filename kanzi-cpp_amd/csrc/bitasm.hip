@@ -274,7 +274,7 @@ void launch_assemble(hipStream_t s, const ChunkDesc* desc, const BlockInfo* info
                        hdrBase, maxChunks, chunkSize, fp, out); }
 }
 
-__global__ void k_init_blocks(u64 n, u32 blockSize, int nBlocks, u32* origLen, u32* blockLen, u8* skipFlags, u8 skipInit)
+__global__ void k_init_blocks(u64 n, u32 blockSize, int nBlocks, u32* origLen, u32* blockLen)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nBlocks) return;
@@ -282,12 +282,11 @@ __global__ void k_init_blocks(u64 n, u32 blockSize, int nBlocks, u32* origLen, u
     const u32 len = (n - off < blockSize) ? (u32)(n - off) : blockSize;
     origLen[b] = len;
     blockLen[b] = len;
-    skipFlags[b] = skipInit;
 }
 
-void launch_init_blocks(hipStream_t s, u64 n, u32 blockSize, int nBlocks, u32* origLen, u32* blockLen, u8* skipFlags, u8 skipInit)
+void launch_init_blocks(hipStream_t s, u64 n, u32 blockSize, int nBlocks, u32* origLen, u32* blockLen)
 {
-    { KScope ks_("k_init_blocks"); hipLaunchKernelGGL(k_init_blocks, dim3((nBlocks + 255) / 256), dim3(256), 0, s, n, blockSize, nBlocks, origLen, blockLen, skipFlags, skipInit); }
+    { KScope ks_("k_init_blocks"); hipLaunchKernelGGL(k_init_blocks, dim3((nBlocks + 255) / 256), dim3(256), 0, s, n, blockSize, nBlocks, origLen, blockLen); }
 }
 
 // Reject blocks whose declared length cannot be written (guards every later kernel).

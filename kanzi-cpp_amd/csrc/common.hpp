@@ -21,11 +21,10 @@ constexpr u32 HDR_WORDS = HDR_BYTES / 4;
 constexpr u32 PAY_BYTES = 33280;          // per-chunk payload staging (>= 2 bytes/symbol + tail), multiple of 256
 constexpr u32 TMP_STRIDE = HDR_BYTES + PAY_BYTES;   // 33856, multiple of 64
 
-// Blocks of one batch: block b occupies [base + b*stride, +len[b]).
+// Blocks of one batch: block b occupies [ptr[b], +len[b]).
 struct BlockView {
-    const u8* base;
-    u64 stride;
-    const u32* len;     // device array
+    const u8* const* ptr;   // device array of per-block pointers (16-byte aligned)
+    const u32* len;         // device array
 };
 
 // What one entropy "chunk" contributes to the block's bit stream, in order:

@@ -1,0 +1,134 @@
+// TransformSequence<byte>::forward / inverse bookkeeping (transform/TransformSequence.hpp:88-162,
+// :165-247) for a batch of blocks, kept on the device so that a batch needs no host round trip
+// between stages: which physical buffer holds each block, its current length, its skip flags and
+// the destination capacity the reference would present to the next transform (capacities change
+// results for ZRLT/RLT).
+#include "common.hpp"
+#include "stages.hpp"
+
+namespace knz {
+
+__device__ __forceinline__ const u8* fwd_ptr(u8 where, int b, const u8* in, u64 inStride, u8* A, u8* B, u64 S)
+{
+    return where == 0 ? in + (size_t)b * inStride : (where == 1 ? A + (size_t)b * S : B + (size_t)b * S);
+}
+
+// stage 0 additionally initialises the per-block state
+__global__ void k_seq_fwd_prepare(SeqArrays a, int nBlocks, int stage, const u8* in, u64 inStride, u8* A, u8* B, u64 S)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nBlocks) return;
+    if (stage == 0) {
+        a.where[b] = 0;
+        a.swaps[b] = 0;
+        a.len[b] = a.origLen[b];
+        // blocks <= 15 bytes: tType forced to NONE -> one NullTransform that succeeds -> 0x7F
+        // (io/CompressedOutputStream.cpp:691-695)
+        const bool copy = a.origLen[b] <= 15;
+        a.skip[b] = copy ? 0x7F : 0xFF;
+        a.active[b] = copy ? 0 : 1;
+    }
+    const u8 w = a.where[b];
+    a.src[b] = fwd_ptr(w, b, in, inStride, A, B, S);
+    a.dst[b] = (w == 1) ? B + (size_t)b * S : A + (size_t)b * S;
+    a.alen[b] = a.active[b] ? a.len[b] : 0;
+    // TransformSequence.hpp:104-115: out is the task's "buffer" after an even number of swaps, its "data"
+    // otherwise; either is replaced by a scratch of requiredSize when shorter than that.
+    // (bufCap/dataCap arrive from the host already raised to the block's requiredSize)
+    u32 cap = ((a.swaps[b] & 1) == 0) ? a.bufCap[b] : a.dataCap[b];
+    if (cap > S) cap = (u32)S;
+    a.cap[b] = cap;
+    a.ok[b] = 0;
+    a.newLen[b] = 0;
+}
+
+__global__ void k_seq_fwd_commit(SeqArrays a, int nBlocks, int stage)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nBlocks) return;
+    if (!a.active[b] || !a.ok[b]) return;
+    a.len[b] = a.newLen[b];
+    a.where[b] = (a.where[b] == 1) ? 2 : 1;
+    a.swaps[b]++;
+    a.skip[b] &= (u8)~(1u << (7 - stage));
+}
+
+// NullTransform stage: always succeeds, data stays where it is (transform/NullTransform.hpp:49-66)
+__global__ void k_seq_fwd_null(SeqArrays a, int nBlocks, int stage)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nBlocks) return;
+    if (!a.active[b]) return;
+    a.swaps[b]++;
+    a.skip[b] &= (u8)~(1u << (7 - stage));
+}
+
+__global__ void k_seq_fwd_finish(SeqArrays a, int nBlocks, const u8* in, u64 inStride, u8* A, u8* B, u64 S, const u8** viewPtr)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nBlocks) return;
+    viewPtr[b] = fwd_ptr(a.where[b], b, in, inStride, A, B, S);
+}
+
+// ---- inverse
+__global__ void k_seq_inv_entropy_dst(SeqArrays a, DecBlock* blocks, int nBlocks, u8* out, u64 outStride, u8* A, u64 S, u8** entDst)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nBlocks) return;
+    const DecBlock& db = blocks[b];
+    const bool any = !db.copyBlock && (db.skipFlags & 0xFF) != 0xFF;
+    a.skip[b] = db.copyBlock ? 0xFF : (u8)db.skipFlags;
+    a.where[b] = any ? 1 : 0;
+    a.len[b] = db.preLen;
+    entDst[b] = any ? A + (size_t)b * S : out + (size_t)b * outStride;
+}
+
+__global__ void k_seq_inv_prepare(SeqArrays a, DecBlock* blocks, int nBlocks, int stage, u8* out, u64 outStride, u8* A, u8* B, u64 S,
+                                  u32 capMid, u32 capFinal)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nBlocks) return;
+    const u8 skip = a.skip[b];
+    const bool applied = !blocks[b].error && !((skip >> (7 - stage)) & 1);
+    a.active[b] = applied ? 1 : 0;
+    a.alen[b] = applied ? a.len[b] : 0;
+    bool lower = false;
+    for (int j = 0; j < stage; j++) if (!((skip >> (7 - j)) & 1)) lower = true;
+    const u8 w = a.where[b];
+    a.src[b] = (w == 1) ? A + (size_t)b * S : B + (size_t)b * S;
+    if (lower) { a.dst[b] = (w == 1) ? B + (size_t)b * S : A + (size_t)b * S; a.cap[b] = capMid; }
+    else { a.dst[b] = out + (size_t)b * outStride; a.cap[b] = capFinal; }
+    a.swaps[b] = lower ? 1 : 0;      // 1 = result stays in a workspace
+    a.ok[b] = 0;
+    a.newLen[b] = 0;
+}
+
+__global__ void k_seq_inv_commit(SeqArrays a, DecBlock* blocks, int nBlocks, int stage, int ttype)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nBlocks) return;
+    if (!a.active[b]) return;
+    if (!a.ok[b]) { blocks[b].error = KNZ_ERR_PROCESS_BLOCK; return; }   // all inverse transforms must succeed
+    a.len[b] = a.newLen[b];
+    blocks[b].preLen = a.newLen[b];
+    a.where[b] = a.swaps[b] ? ((a.where[b] == 1) ? 2 : 1) : 0;
+}
+
+#define L1D(k, ...) hipLaunchKernelGGL(k, dim3((nBlocks + 255) / 256), dim3(256), 0, s, __VA_ARGS__)
+
+void launch_seq_fwd_prepare(hipStream_t s, const SeqArrays& a, int nBlocks, int stage, const u8* in, u64 inStride, u8* A, u8* B, u64 S)
+{ KScope ks_("k_seq_fwd_prepare"); L1D(k_seq_fwd_prepare, a, nBlocks, stage, in, inStride, A, B, S); }
+void launch_seq_fwd_commit(hipStream_t s, const SeqArrays& a, int nBlocks, int stage)
+{ KScope ks_("k_seq_fwd_commit"); L1D(k_seq_fwd_commit, a, nBlocks, stage); }
+void launch_seq_fwd_null(hipStream_t s, const SeqArrays& a, int nBlocks, int stage)
+{ KScope ks_("k_seq_fwd_null"); L1D(k_seq_fwd_null, a, nBlocks, stage); }
+void launch_seq_fwd_finish(hipStream_t s, const SeqArrays& a, int nBlocks, const u8* in, u64 inStride, u8* A, u8* B, u64 S, const u8** viewPtr)
+{ KScope ks_("k_seq_fwd_finish"); L1D(k_seq_fwd_finish, a, nBlocks, in, inStride, A, B, S, viewPtr); }
+void launch_seq_inv_entropy_dst(hipStream_t s, const SeqArrays& a, DecBlock* blocks, int nBlocks, u8* out, u64 outStride, u8* A, u64 S, u8** entDst)
+{ KScope ks_("k_seq_inv_entropy_dst"); L1D(k_seq_inv_entropy_dst, a, blocks, nBlocks, out, outStride, A, S, entDst); }
+void launch_seq_inv_prepare(hipStream_t s, const SeqArrays& a, DecBlock* blocks, int nBlocks, int stage, u8* out, u64 outStride, u8* A, u8* B, u64 S, u32 capMid, u32 capFinal)
+{ KScope ks_("k_seq_inv_prepare"); L1D(k_seq_inv_prepare, a, blocks, nBlocks, stage, out, outStride, A, B, S, capMid, capFinal); }
+void launch_seq_inv_commit(hipStream_t s, const SeqArrays& a, DecBlock* blocks, int nBlocks, int stage, int ttype)
+{ KScope ks_("k_seq_inv_commit"); L1D(k_seq_inv_commit, a, blocks, nBlocks, stage, ttype); }
+
+}  // namespace knz

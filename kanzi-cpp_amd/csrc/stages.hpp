@@ -13,7 +13,7 @@ struct FrameParams {
 };
 
 // bitasm.hip
-void launch_init_blocks(hipStream_t s, u64 n, u32 blockSize, int nBlocks, u32* origLen, u32* blockLen, u8* skipFlags, u8 skipInit);
+void launch_init_blocks(hipStream_t s, u64 n, u32 blockSize, int nBlocks, u32* origLen, u32* blockLen);
 void launch_block_sum(hipStream_t s, ChunkDesc* desc, BlockInfo* info, const u32* blockLen, int nBlocks, int maxChunks, u32 chunkSize);
 void launch_block_scan(hipStream_t s, BlockInfo* info, const u32* blockLen, int nBlocks, FrameParams fp, u64* totalBits);
 void launch_assemble(hipStream_t s, const ChunkDesc* desc, const BlockInfo* info, const u32* blockLen, const u32* origLen,
@@ -26,11 +26,69 @@ void launch_check_prelen(hipStream_t s, DecBlock* blocks, int nBlocks, u32 maxPr
 
 // none.hip
 void launch_none_encode(hipStream_t s, BlockView view, int nBlocks, int maxChunks, ChunkDesc* desc);
-void launch_none_decode(hipStream_t s, BitSrc src, DecBlock* blocks, int nBlocks, u8* out, u64 outStride);
+void launch_none_decode(hipStream_t s, BitSrc src, DecBlock* blocks, int nBlocks, u8* const* outPtr);
 
 // ans.hip
 void launch_ans0_encode(hipStream_t s, BlockView view, int nBlocks, int maxChunks, ChunkDesc* desc, uint2* encTab, u8* tmp);
-void launch_ans0_decode(hipStream_t s, BitSrc src, DecBlock* blocks, int nBlocks, int maxChunks, void* chunkMeta, u8* out, u64 outStride);
+void launch_ans0_decode(hipStream_t s, BitSrc src, DecBlock* blocks, int nBlocks, int maxChunks, void* chunkMeta, u8* const* outPtr);
 size_t ans0_dec_chunk_bytes();
+
+// One transform stage over a batch (all arrays are device arrays indexed by block).
+struct XfStage {
+    const u8* const* src;
+    u8* const* dst;
+    const u32* len;          // active length (0 = block does not take part in this stage)
+    const u32* cap;          // destination capacity seen by the transform
+    u8* ok;                  // out: 1 when the reference's forward()/inverse() would return true
+    u32* newLen;             // out: bytes produced
+    int nBlocks;
+    u32 maxLen;              // upper bound of len[] (grid sizing)
+    u32* scratchU32;         // stage scratch (8-byte aligned)
+    int entropyType;         // stream entropy id (RLT escape choice)
+};
+
+// zrlt_mtft.hip
+void launch_zrlt_forward(hipStream_t s, const XfStage& st);
+void launch_zrlt_inverse(hipStream_t s, const XfStage& st);
+void launch_mtft_forward(hipStream_t s, const XfStage& st);
+void launch_mtft_inverse(hipStream_t s, const XfStage& st);
+size_t zrlt_scratch_u32(int nBlocks, u32 maxLen);
+size_t mtft_scratch_u32(int nBlocks, u32 maxLen);
+
+// bwt.hip (these synchronise the stream: active-set sizes are read back through h_pinned)
+int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t scratchBytes, u32* h_pinned);
+int launch_bwt_inverse(hipStream_t s, const XfStage& st, void* scratch, size_t scratchBytes, u32* h_pinned);
+size_t bwt_forward_scratch_bytes(int nBlocks, u32 VS, size_t total);
+size_t bwt_inverse_scratch_bytes(int nBlocks, u32 VS, size_t total);
+
+// sequence.hip : TransformSequence bookkeeping on the device
+struct SeqArrays {
+    u8* where;               // 0 = caller buffer, 1 = workspace A, 2 = workspace B
+    u8* swaps;
+    u8* active;
+    u32* len;                // current data length per block
+    u32* alen;               // active length for the current stage
+    u8* skip;                // skip flags (bit 7-i set = stage i not applied)
+    const u8** src;
+    u8** dst;
+    u32* cap;
+    u8* ok;
+    u32* newLen;
+    const u32* origLen;
+    const u32* dataCap;      // reference buffer capacities (forward only)
+    const u32* bufCap;
+};
+void launch_seq_fwd_prepare(hipStream_t s, const SeqArrays& a, int nBlocks, int stage, const u8* in, u64 inStride, u8* A, u8* B, u64 S);
+void launch_seq_fwd_null(hipStream_t s, const SeqArrays& a, int nBlocks, int stage);
+void launch_seq_fwd_commit(hipStream_t s, const SeqArrays& a, int nBlocks, int stage);
+void launch_seq_fwd_finish(hipStream_t s, const SeqArrays& a, int nBlocks, const u8* in, u64 inStride, u8* A, u8* B, u64 S, const u8** viewPtr);
+void launch_seq_inv_entropy_dst(hipStream_t s, const SeqArrays& a, DecBlock* blocks, int nBlocks, u8* out, u64 outStride, u8* A, u64 S, u8** entDst);
+void launch_seq_inv_prepare(hipStream_t s, const SeqArrays& a, DecBlock* blocks, int nBlocks, int stage, u8* out, u64 outStride, u8* A, u8* B, u64 S, u32 capMid, u32 capFinal);
+void launch_seq_inv_commit(hipStream_t s, const SeqArrays& a, DecBlock* blocks, int nBlocks, int stage, int ttype);
+
+// huffman.hip
+void launch_huffman_encode(hipStream_t s, BlockView view, int nBlocks, int maxChunks, ChunkDesc* desc, u8* tmp);
+void launch_huffman_decode(hipStream_t s, BitSrc src, DecBlock* blocks, int nBlocks, int maxChunks, void* chunkMeta, u8* const* outPtr);
+size_t huffman_dec_chunk_bytes();
 
 }  // namespace knz

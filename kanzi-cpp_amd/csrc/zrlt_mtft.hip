@@ -1,0 +1,709 @@
+// ZRLT and MTFT byte transforms on gfx950, batched over all blocks of a call.
+//
+// Reference being replaced (bit-identical results, same success/failure decisions):
+//   ZRLT  transform/ZRLT.cpp:27-117 (forward), :119-215 (inverse)
+//   MTFT  transform/SBRT.cpp:46-97, :99-145 with MODE_MTF (:28-31) == classic move-to-front
+//
+// Both CPU loops are sequential; here they are rebuilt from scans:
+//   ZRLT forward   zero-run starts need the run end = next non-zero position: per-tile first-nonzero +
+//                  suffix-min over tiles; token sizes -> per-tile sums -> exclusive scan -> scatter.
+//   ZRLT inverse   tokens are classified by two prefix-max scans (parity inside 0xFF streaks decides
+//                  escape markers; "last non run-bit" gives each bit group); output offsets from a
+//                  scan; the output is pre-zeroed so zero runs cost no stores.
+//   MTFT forward   the recency list at a tile start is the symbols ordered by last occurrence
+//                  (prefix-max over tiles per symbol) -> rank-by-counting sort per tile; then one
+//                  lane per 1 KiB tile runs the short sequential search (ranks after BWT are tiny).
+//   MTFT inverse   the list permutation of a tile does not depend on its content: every lane decodes
+//                  its tile symbolically (initial-position ids), permutations are prefix-composed
+//                  per block, then a parallel gather resolves ids to symbols.
+#include "common.hpp"
+#include "stages.hpp"
+
+namespace knz {
+
+constexpr u32 ZT = 4096;            // ZRLT tile (bytes) per 256-thread workgroup
+constexpr u32 ZPT = 16;             // bytes per thread
+constexpr u32 NOPOS = 0xFFFFFFFFu;
+
+// exclusive sum over the 256 threads of a workgroup; returns the thread's offset, total in *tot
+__device__ __forceinline__ u32 block_excl_scan256(u32 v, u32* lds4, u32* tot)
+{
+    const u32 incl = wave_incl_scan(v);
+    const int wv = threadIdx.x >> 6;
+    if (lane_id() == 63) lds4[wv] = incl;
+    __syncthreads();
+    u32 off = 0;
+    for (int k = 0; k < wv; k++) off += lds4[k];
+    *tot = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+    __syncthreads();
+    return off + incl - v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic per-block scans over tile arrays (one workgroup per block)
+// ------------------------------------------------------------------------------------------------
+// exclusive sum of vals[b*per .. +cnt_b) in place; total -> tot[b]
+__global__ __launch_bounds__(256) void k_tile_excl_sum(u32* vals, int per, const u32* __restrict__ lens, u32 tile, u32* tot)
+{
+    const int b = blockIdx.x;
+    const u32 cnt = (lens[b] + tile - 1) / tile;
+    u32* v = vals + (size_t)b * per;
+    __shared__ u32 l4[4];
+    __shared__ u32 carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (u32 base = 0; base < cnt; base += 256) {
+        const u32 i = base + threadIdx.x;
+        const u32 x = i < cnt ? v[i] : 0;
+        u32 t;
+        const u32 off = block_excl_scan256(x, l4, &t);
+        if (i < cnt) v[i] = carry + off;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += t;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tot[b] = carry;
+}
+
+__device__ __forceinline__ u64 block_excl_scan256_64(u64 v, u64* lds4, u64* tot)
+{
+    const u64 incl = wave_incl_scan64(v);
+    const int wv = threadIdx.x >> 6;
+    if (lane_id() == 63) lds4[wv] = incl;
+    __syncthreads();
+    u64 off = 0;
+    for (int k = 0; k < wv; k++) off += lds4[k];
+    *tot = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+    __syncthreads();
+    return off + incl - v;
+}
+
+// 64-bit variant (ZRLT inverse: one token can expand to 2^30 zeros). Totals saturate at 2^32-1.
+__global__ __launch_bounds__(256) void k_tile_excl_sum64(u64* vals, int per, const u32* __restrict__ lens, u32 tile, u32* tot)
+{
+    const int b = blockIdx.x;
+    const u32 cnt = (lens[b] + tile - 1) / tile;
+    u64* v = vals + (size_t)b * per;
+    __shared__ u64 l4[4];
+    __shared__ u64 carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (u32 base = 0; base < cnt; base += 256) {
+        const u32 i = base + threadIdx.x;
+        const u64 x = i < cnt ? v[i] : 0;
+        u64 t;
+        const u64 off = block_excl_scan256_64(x, l4, &t);
+        if (i < cnt) v[i] = carry + off;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += t;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tot[b] = carry > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)carry;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ZRLT forward
+// ------------------------------------------------------------------------------------------------
+struct XfView {                     // per-block source/destination of one transform stage
+    const u8* const* src;           // device array of per-block pointers
+    u8* const* dst;
+    const u32* len;                 // current lengths
+    const u32* cap;                 // destination capacities (SliceArray::_length - _index)
+};
+
+__global__ __launch_bounds__(256) void k_zrlt_f_tileinfo(XfView v, int per, u32* __restrict__ firstNZ)
+{
+    const int b = blockIdx.y;
+    const u32 t = blockIdx.x;
+    const u32 n = v.len[b];
+    const u32 base = t * ZT;
+    if (base >= n) return;
+    const u8* s = v.src[b];
+    const u32 i0 = base + threadIdx.x * ZPT;
+    u32 mine = NOPOS;
+    for (u32 k = 0; k < ZPT; k++) {
+        const u32 i = i0 + k;
+        if (i < n && s[i] != 0) { mine = i; break; }
+    }
+    // block min
+    __shared__ u32 m;
+    if (threadIdx.x == 0) m = NOPOS;
+    __syncthreads();
+    if (mine != NOPOS) atomicMin(&m, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) firstNZ[(size_t)b * per + t] = m;
+}
+
+// per block: nextNZ[t] = first non-zero position in tiles >= t (n if none). One thread per block, tiles walked backwards.
+__global__ void k_zrlt_f_suffix(const u32* __restrict__ firstNZ, u32* __restrict__ nextNZ, int per, const u32* __restrict__ lens, int nBlocks)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nBlocks) return;
+    const u32 n = lens[b];
+    const u32 cnt = (n + ZT - 1) / ZT;
+    u32 cur = n;
+    for (int t = (int)cnt - 1; t >= 0; t--) {
+        const u32 f = firstNZ[(size_t)b * per + t];
+        if (f != NOPOS) cur = f;
+        nextNZ[(size_t)b * per + t] = cur;
+    }
+}
+
+// token size of position i (0 for zeros inside a run). runEnd = position of the next non-zero (or n).
+__device__ __forceinline__ u32 zrlt_tok(u8 c, bool runStart, u32 i, u32 runEnd)
+{
+    if (c != 0) return c >= 0xFE ? 2u : 1u;
+    if (!runStart) return 0;
+    return (u32)ilog2_u32(runEnd - i + 1);
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(256) void k_zrlt_f_pass(XfView v, int per, const u32* __restrict__ nextNZ, u32* __restrict__ tileSize,
+                                                     const u32* __restrict__ tileOff, const u8* __restrict__ okFlags)
+{
+    const int b = blockIdx.y;
+    const u32 t = blockIdx.x;
+    const u32 n = v.len[b];
+    const u32 base = t * ZT;
+    if (base >= n) return;
+    if (EMIT && !okFlags[b]) return;
+    const u8* s = v.src[b];
+    __shared__ u32 tnz[256];
+    __shared__ u32 l4[4];
+    const u32 i0 = base + threadIdx.x * ZPT;
+    u8 c[ZPT];
+    u32 myFirst = NOPOS;
+#pragma unroll
+    for (u32 k = 0; k < ZPT; k++) {
+        const u32 i = i0 + k;
+        c[k] = (i < n) ? s[i] : (u8)1;            // padding behaves as "non-zero" but is never emitted
+        if (myFirst == NOPOS && i < n && c[k] != 0) myFirst = i;
+    }
+    tnz[threadIdx.x] = myFirst;
+    __syncthreads();
+    // next non-zero after this thread's bytes: scan following threads, then the next tiles
+    u32 after = NOPOS;
+    {
+        // suffix min over threads (serial per thread is 256 steps worst case; do a log-step scan instead)
+        u32 val = myFirst;
+        for (int d = 1; d < 256; d <<= 1) {
+            __syncthreads();
+            const u32 o = (threadIdx.x + d < 256) ? tnz[threadIdx.x + d] : NOPOS;
+            __syncthreads();
+            val = o < val ? o : val;
+            tnz[threadIdx.x] = val;
+        }
+        __syncthreads();
+        after = (threadIdx.x + 1 < 256) ? tnz[threadIdx.x + 1] : NOPOS;
+        if (after == NOPOS) {
+            const u32 cnt = (n + ZT - 1) / ZT;
+            after = (t + 1 < cnt) ? nextNZ[(size_t)b * per + t + 1] : n;
+        }
+    }
+    const u8 prevByte = (i0 == 0 || i0 >= n + 1) ? (u8)1 : ((i0 - 1 < n) ? s[i0 - 1] : (u8)1);
+    u32 sizes[ZPT];
+    u32 sum = 0;
+#pragma unroll
+    for (u32 k = 0; k < ZPT; k++) {
+        const u32 i = i0 + k;
+        u32 sz = 0;
+        if (i < n) {
+            const u8 pv = (k == 0) ? prevByte : c[k - 1];
+            const bool runStart = (c[k] == 0) && (i == 0 || pv != 0);
+            u32 runEnd = after;
+            if (runStart) {
+                for (u32 q = k + 1; q < ZPT; q++) if (i0 + q < n && c[q] != 0) { runEnd = i0 + q; break; }
+                if (runEnd > n) runEnd = n;
+            }
+            sz = zrlt_tok(c[k], runStart, i, runEnd);
+        }
+        sizes[k] = sz;
+        sum += sz;
+    }
+    u32 tot;
+    const u32 off = block_excl_scan256(sum, l4, &tot);
+    if (!EMIT) {
+        if (threadIdx.x == 0) tileSize[(size_t)b * per + t] = tot;
+        return;
+    }
+    u8* d = v.dst[b] + tileOff[(size_t)b * per + t] + off;
+#pragma unroll
+    for (u32 k = 0; k < ZPT; k++) {
+        const u32 i = i0 + k;
+        if (i >= n || sizes[k] == 0) continue;
+        if (c[k] != 0) {
+            if (c[k] >= 0xFE) { d[0] = 0xFF; d[1] = (u8)(c[k] - 0xFE); d += 2; }
+            else { *d++ = (u8)(c[k] + 1); }
+        } else {
+            // run length L: emit the bits of L+1 below the MSB, one byte each (ZRLT.cpp:60-83)
+            u32 runEnd = after;
+            for (u32 q = k + 1; q < ZPT; q++) if (i0 + q < n && c[q] != 0) { runEnd = i0 + q; break; }
+            if (runEnd > n) runEnd = n;
+            const u32 rl = runEnd - i + 1;
+            for (int lg = (int)sizes[k] - 1; lg >= 0; lg--) *d++ = (u8)((rl >> lg) & 1);
+        }
+    }
+}
+
+// ok[b] = capacity >= n (getMaxEncodedLength) and every token fits; newLen[b] = total
+__global__ void k_zrlt_f_finish(const u32* __restrict__ lens, const u32* __restrict__ caps, const u32* __restrict__ totals,
+                                int nBlocks, u8* __restrict__ ok, u32* __restrict__ newLen)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nBlocks) return;
+    const u32 n = lens[b];
+    const bool good = (n == 0) || (caps[b] >= n && totals[b] <= caps[b]);
+    ok[b] = good ? 1 : 0;
+    newLen[b] = totals[b];
+}
+
+// ------------------------------------------------------------------------------------------------
+// ZRLT inverse
+// ------------------------------------------------------------------------------------------------
+// classes: 0 literal (emits v-1), 1 escape marker, 2 escape payload (emits 0xFE+v), 3 run bit
+__global__ __launch_bounds__(256) void k_zrlt_i_lastnonff(XfView v, int per, u32* __restrict__ tileLast)
+{
+    const int b = blockIdx.y;
+    const u32 t = blockIdx.x;
+    const u32 n = v.len[b];
+    const u32 base = t * ZT;
+    if (base >= n) return;
+    const u8* s = v.src[b];
+    __shared__ u32 m;                // position+1 of the last non-0xFF byte in the tile, 0 = none
+    if (threadIdx.x == 0) m = 0;
+    __syncthreads();
+    const u32 i0 = base + threadIdx.x * ZPT;
+    u32 mine = 0;
+    for (u32 k = 0; k < ZPT; k++) { const u32 i = i0 + k; if (i < n && s[i] != 0xFF) mine = i + 1; }
+    if (mine) atomicMax(&m, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) tileLast[(size_t)b * per + t] = m;
+}
+
+// exclusive prefix max over tiles (serial per block)
+__global__ void k_tile_prefix_max(const u32* __restrict__ in, u32* __restrict__ out, int per, const u32* __restrict__ lens, int nBlocks)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nBlocks) return;
+    const u32 cnt = (lens[b] + ZT - 1) / ZT;
+    u32 cur = 0;
+    for (u32 t = 0; t < cnt; t++) {
+        const u32 x = in[(size_t)b * per + t];
+        out[(size_t)b * per + t] = cur;
+        cur = x > cur ? x : cur;
+    }
+}
+
+// class of byte i given lastNonFF(i-1)+1 (= position+1 of the last non-0xFF byte strictly before i, 0 = none)
+__device__ __forceinline__ u32 zrlt_class(u8 c, u32 i, u32 lastNonFFBefore)
+{
+    // streak of 0xFF bytes immediately before i has length i - lastNonFFBefore; odd length => the byte at i
+    // is the payload of the marker at i-1
+    const u32 streak = i - lastNonFFBefore;
+    const bool payload = (streak & 1) != 0;
+    if (payload) return 2;
+    if (c == 0xFF) return 1;
+    if (c <= 1) return 3;
+    return 0;
+}
+
+// mode 0: tileLastNonR ; mode 1: tile output sizes ; mode 2: emit
+template <int MODE>
+__global__ __launch_bounds__(256) void k_zrlt_i_pass(XfView v, int per, const u32* __restrict__ prevNonFF, u32* __restrict__ tileLastNonR,
+                                                     const u32* __restrict__ prevNonR, u64* __restrict__ tileSize,
+                                                     const u64* __restrict__ tileOff, u32* __restrict__ errFlags, const u8* __restrict__ okFlags)
+{
+    const int b = blockIdx.y;
+    const u32 t = blockIdx.x;
+    const u32 n = v.len[b];
+    const u32 base = t * ZT;
+    if (base >= n) return;
+    if (MODE == 2 && !okFlags[b]) return;
+    const u8* s = v.src[b];
+    __shared__ u32 scan[256];
+    __shared__ u64 l4[4];
+    __shared__ u32 mx;
+    const u32 i0 = base + threadIdx.x * ZPT;
+    u8 c[ZPT];
+    u32 lastNonFF = 0;               // position+1 of last non-FF within my bytes
+#pragma unroll
+    for (u32 k = 0; k < ZPT; k++) {
+        const u32 i = i0 + k;
+        c[k] = (i < n) ? s[i] : (u8)2;
+        if (i < n && c[k] != 0xFF) lastNonFF = i + 1;
+    }
+    // exclusive prefix max over threads of lastNonFF
+    scan[threadIdx.x] = lastNonFF;
+    __syncthreads();
+    u32 val = lastNonFF;
+    for (int d = 1; d < 256; d <<= 1) {
+        const u32 o = ((int)threadIdx.x - d >= 0) ? scan[threadIdx.x - d] : 0;
+        __syncthreads();
+        val = o > val ? o : val;
+        scan[threadIdx.x] = val;
+        __syncthreads();
+    }
+    u32 before = (threadIdx.x > 0) ? scan[threadIdx.x - 1] : 0;
+    const u32 tp = prevNonFF[(size_t)b * per + t];
+    before = before > tp ? before : tp;
+    __syncthreads();
+
+    u32 cls[ZPT];
+    u32 lastNonR = 0;                // position+1 of last non-run-bit byte within my bytes
+    {
+        u32 lb = before;
+#pragma unroll
+        for (u32 k = 0; k < ZPT; k++) {
+            const u32 i = i0 + k;
+            cls[k] = (i < n) ? zrlt_class(c[k], i, lb) : 0u;
+            if (i < n && c[k] != 0xFF) lb = i + 1;
+            if (i < n && cls[k] != 3) lastNonR = i + 1;
+        }
+    }
+    if (MODE == 0) {
+        if (threadIdx.x == 0) mx = 0;
+        __syncthreads();
+        if (lastNonR) atomicMax(&mx, lastNonR);
+        __syncthreads();
+        if (threadIdx.x == 0) tileLastNonR[(size_t)b * per + t] = mx;
+        return;
+    }
+    // exclusive prefix max over threads of lastNonR
+    scan[threadIdx.x] = lastNonR;
+    __syncthreads();
+    val = lastNonR;
+    for (int d = 1; d < 256; d <<= 1) {
+        const u32 o = ((int)threadIdx.x - d >= 0) ? scan[threadIdx.x - d] : 0;
+        __syncthreads();
+        val = o > val ? o : val;
+        scan[threadIdx.x] = val;
+        __syncthreads();
+    }
+    u32 nrBefore = (threadIdx.x > 0) ? scan[threadIdx.x - 1] : 0;
+    const u32 tr = prevNonR[(size_t)b * per + t];
+    nrBefore = nrBefore > tr ? nrBefore : tr;
+    __syncthreads();
+
+    u32 sizes[ZPT];
+    u64 sum = 0;
+    u32 err = 0;
+    {
+        u32 nr = nrBefore;           // group start = nr (position of first run bit)
+#pragma unroll
+        for (u32 k = 0; k < ZPT; k++) {
+            const u32 i = i0 + k;
+            u32 sz = 0;
+            if (i < n) {
+                if (cls[k] == 0 || cls[k] == 2) sz = 1;
+                else if (cls[k] == 1) { if (i + 1 >= n) err = 1; }       // truncated escape (ZRLT.cpp:177-180)
+                else {
+                    // run bit: the group's last byte carries the whole run
+                    const bool last = (i + 1 >= n) || (((k + 1 < ZPT) ? c[k + 1] : s[i + 1]) > 1);
+                    if (last) {
+                        const u32 start = nr;
+                        const u32 klen = i - start + 1;
+                        if (klen > 30) err = 1;              // runs are bounded by the 1 GiB block size
+                        else {
+                            u32 rl = 1;
+                            for (u32 q = start; q <= i; q++) rl = (rl << 1) | (u32)s[q];
+                            sz = rl - 1;
+                        }
+                    }
+                }
+                if (cls[k] != 3) nr = i + 1;
+            }
+            sizes[k] = sz;
+            sum += sz;
+        }
+    }
+    u64 tot;
+    const u64 off = block_excl_scan256_64(sum, l4, &tot);
+    if (MODE == 1) {
+        if (err) atomicOr(&errFlags[b], 1u);
+        if (threadIdx.x == 0) tileSize[(size_t)b * per + t] = tot;
+        return;
+    }
+    u8* d = v.dst[b] + tileOff[(size_t)b * per + t] + off;
+#pragma unroll
+    for (u32 k = 0; k < ZPT; k++) {
+        const u32 i = i0 + k;
+        if (i >= n) continue;
+        if (cls[k] == 0) { *d = (u8)(c[k] - 1); d += 1; }
+        else if (cls[k] == 2) { *d = (u8)(0xFE + c[k]); d += 1; }
+        else d += sizes[k];          // zero run: destination was pre-zeroed
+    }
+}
+
+__global__ void k_zrlt_i_finish(const u32* __restrict__ lens, const u32* __restrict__ caps, const u32* __restrict__ totals,
+                                const u32* __restrict__ errFlags, int nBlocks, u8* __restrict__ ok, u32* __restrict__ newLen)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nBlocks) return;
+    const bool good = (lens[b] == 0) || (!errFlags[b] && totals[b] <= caps[b]);
+    ok[b] = good ? 1 : 0;
+    newLen[b] = totals[b];
+}
+
+// zero the destination prefix each block may write (capacity-bounded)
+__global__ __launch_bounds__(256) void k_zero_dst(XfView v, const u32* __restrict__ totals)
+{
+    const int b = blockIdx.y;
+    u32 n = totals[b];
+    if (n > v.cap[b]) n = v.cap[b];
+    u8* d = v.dst[b];
+    const size_t stride = (size_t)gridDim.x * 256 * 16;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16; i < n; i += stride) {
+        if (i + 16 <= n && ((reinterpret_cast<uintptr_t>(d + i) & 15) == 0)) *reinterpret_cast<uint4*>(d + i) = make_uint4(0, 0, 0, 0);
+        else for (size_t k = i; k < n && k < i + 16; k++) d[k] = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MTFT
+// ------------------------------------------------------------------------------------------------
+constexpr u32 MT = 1024;            // bytes per lane-tile
+constexpr u32 MW = 64 * MT;         // bytes per wave (64 KiB)
+
+// per lane-tile: last occurrence (position+1) of each symbol -> tileLast[b][t][256]
+__global__ __launch_bounds__(64) void k_mtf_f_last(XfView v, int perTiles, u32* __restrict__ tileLast)
+{
+    const int b = blockIdx.y;
+    const u32 n = v.len[b];
+    const u32 wbase = blockIdx.x * MW;
+    if (wbase >= n) return;
+    const u8* s = v.src[b];
+    __shared__ u32 last[256];
+    const int lane = lane_id();
+    for (u32 tt = 0; tt < 64; tt++) {
+        const u32 tbase = wbase + tt * MT;
+        if (tbase >= n) break;
+        for (int i = lane; i < 256; i += 64) last[i] = 0;
+        __syncthreads();
+        for (u32 k = lane; k < MT; k += 64) {
+            const u32 i = tbase + k;
+            if (i < n) atomicMax(&last[s[i]], i + 1);
+        }
+        __syncthreads();
+        u32* o = tileLast + ((size_t)b * perTiles + (wbase / MT) + tt) * 256;
+        for (int i = lane; i < 256; i += 64) o[i] = last[i];
+        __syncthreads();
+    }
+}
+
+// exclusive prefix max over the tiles of a block, one thread per symbol (loads are independent of the carry)
+__global__ __launch_bounds__(256) void k_mtf_f_scan(u32* __restrict__ tileLast, int perTiles, const u32* __restrict__ lens)
+{
+    const int b = blockIdx.x;
+    const u32 cnt = (lens[b] + MT - 1) / MT;
+    u32* p = tileLast + (size_t)b * perTiles * 256 + threadIdx.x;
+    u32 cur = 0;
+    for (u32 t = 0; t < cnt; t++) {
+        const u32 x = p[(size_t)t * 256];
+        p[(size_t)t * 256] = cur;
+        cur = x > cur ? x : cur;
+    }
+}
+
+// one wave = 64 lane-tiles. LDS lists are interleaved: element i of lane l at [i*64 + l].
+__global__ __launch_bounds__(64) void k_mtf_f_rank(XfView v, int perTiles, const u32* __restrict__ tileState)
+{
+    const int b = blockIdx.y;
+    const u32 n = (v.len[b] <= v.cap[b]) ? v.len[b] : 0;
+    const u32 wbase = blockIdx.x * MW;
+    if (wbase >= n) return;
+    const u8* s = v.src[b];
+    u8* d = v.dst[b];
+    __shared__ u8 lists[256 * 64];
+    __shared__ u32 keys[256];
+    const int lane = lane_id();
+    // build the start list of every lane-tile: symbols by last occurrence desc, unseen ascending
+    for (u32 tt = 0; tt < 64; tt++) {
+        const u32 tbase = wbase + tt * MT;
+        if (tbase >= n) break;
+        const u32* st = tileState + ((size_t)b * perTiles + (wbase / MT) + tt) * 256;
+        for (int i = lane; i < 256; i += 64) keys[i] = st[i];
+        __syncthreads();
+        for (int c = lane; c < 256; c += 64) {
+            const u32 kc = keys[c];
+            u32 r = 0;
+            for (int q = 0; q < 256; q++) {
+                const u32 kq = keys[q];
+                r += (kq > kc || (kq == kc && q < c)) ? 1u : 0u;
+            }
+            lists[r * 64 + tt] = (u8)c;
+        }
+        __syncthreads();
+    }
+    const u32 tbase = wbase + (u32)lane * MT;
+    if (tbase < n) {
+        const u32 cnt = (n - tbase < MT) ? (n - tbase) : MT;
+        u8* L = lists + lane;
+        for (u32 k = 0; k < cnt; k++) {
+            const u8 c = s[tbase + k];
+            u32 r = 0;
+            u8 prev = L[0];
+            if (prev != c) {
+                // shift while searching
+                do {
+                    r++;
+                    const u8 cur = L[r * 64];
+                    L[r * 64] = prev;
+                    prev = cur;
+                } while (prev != c);
+                L[0] = c;
+            }
+            d[tbase + k] = (u8)r;
+        }
+    }
+}
+
+// inverse, pass 1: symbolic decode with identity start; ids -> dst, final list (as ids) -> tilePerm
+__global__ __launch_bounds__(64) void k_mtf_i_symbolic(XfView v, int perTiles, u8* __restrict__ tilePerm)
+{
+    const int b = blockIdx.y;
+    const u32 n = (v.len[b] <= v.cap[b]) ? v.len[b] : 0;
+    const u32 wbase = blockIdx.x * MW;
+    if (wbase >= n) return;
+    const u8* s = v.src[b];
+    u8* d = v.dst[b];
+    __shared__ u8 lists[256 * 64];
+    const int lane = lane_id();
+    for (int i = 0; i < 256; i++) lists[i * 64 + lane] = (u8)i;
+    __syncthreads();
+    const u32 tbase = wbase + (u32)lane * MT;
+    if (tbase < n) {
+        const u32 cnt = (n - tbase < MT) ? (n - tbase) : MT;
+        u8* L = lists + lane;
+        for (u32 k = 0; k < cnt; k++) {
+            const u32 r = s[tbase + k];
+            const u8 c = L[r * 64];
+            for (u32 q = r; q > 0; q--) L[q * 64] = L[(q - 1) * 64];
+            L[0] = c;
+            d[tbase + k] = c;
+        }
+        u8* o = tilePerm + ((size_t)b * perTiles + tbase / MT) * 256;
+        for (int i = 0; i < 256; i++) o[i] = L[i * 64];
+    }
+}
+
+// inverse, pass 2: per block, state before tile t: S_0 = identity, S_{t+1}[j] = S_t[perm_t[j]] ; in place
+__global__ __launch_bounds__(256) void k_mtf_i_compose(u8* __restrict__ tilePerm, int perTiles, const u32* __restrict__ lens)
+{
+    const int b = blockIdx.x;
+    const u32 cnt = (lens[b] + MT - 1) / MT;
+    __shared__ u8 S[2][256];
+    S[0][threadIdx.x] = (u8)threadIdx.x;
+    __syncthreads();
+    u8* p = tilePerm + (size_t)b * perTiles * 256;
+    int cur = 0;
+    for (u32 t = 0; t < cnt; t++) {
+        const u8 pj = p[(size_t)t * 256 + threadIdx.x];
+        const u8 nv = S[cur][pj];
+        p[(size_t)t * 256 + threadIdx.x] = S[cur][threadIdx.x];   // state before tile t
+        S[cur ^ 1][threadIdx.x] = nv;
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+// inverse, pass 3: resolve ids in place: out[i] = state_tile[id]
+__global__ __launch_bounds__(256) void k_mtf_i_resolve(XfView v, int perTiles, const u8* __restrict__ tileState)
+{
+    const int b = blockIdx.y;
+    const u32 n = (v.len[b] <= v.cap[b]) ? v.len[b] : 0;
+    const u32 t = blockIdx.x;               // one workgroup per lane-tile (1 KiB)
+    const u32 base = t * MT;
+    if (base >= n) return;
+    __shared__ u8 S[256];
+    S[threadIdx.x] = tileState[((size_t)b * perTiles + t) * 256 + threadIdx.x];
+    __syncthreads();
+    u8* d = v.dst[b];
+    for (u32 k = threadIdx.x; k < MT; k += 256) {
+        const u32 i = base + k;
+        if (i < n) d[i] = S[d[i]];
+    }
+}
+
+__global__ void k_copy_ok(const u32* __restrict__ lens, const u32* __restrict__ caps, int nBlocks, u8* ok, u32* newLen)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nBlocks) return;
+    ok[b] = (lens[b] <= caps[b]) ? 1 : 0;       // SBRT.cpp:57-60
+    newLen[b] = lens[b];
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static XfView mk(const XfStage& st) { XfView v; v.src = st.src; v.dst = st.dst; v.len = st.len; v.cap = st.cap; return v; }
+
+void launch_zrlt_forward(hipStream_t s, const XfStage& st)
+{
+    const XfView v = mk(st);
+    const int per = (int)((st.maxLen + ZT - 1) / ZT);
+    u32* firstNZ = st.scratchU32;
+    u32* nextNZ = firstNZ + (size_t)st.nBlocks * per;
+    u32* tileSize = nextNZ + (size_t)st.nBlocks * per;
+    u32* totals = tileSize + (size_t)st.nBlocks * per;
+    const dim3 grid(per, st.nBlocks);
+    { KScope ks_("k_zrlt_f_tileinfo"); hipLaunchKernelGGL(k_zrlt_f_tileinfo, grid, dim3(256), 0, s, v, per, firstNZ); }
+    { KScope ks_("k_zrlt_f_suffix"); hipLaunchKernelGGL(k_zrlt_f_suffix, dim3((st.nBlocks + 63) / 64), dim3(64), 0, s, firstNZ, nextNZ, per, st.len, st.nBlocks); }
+    { KScope ks_("k_zrlt_f_count"); hipLaunchKernelGGL(k_zrlt_f_pass<false>, grid, dim3(256), 0, s, v, per, nextNZ, tileSize, nullptr, nullptr); }
+    { KScope ks_("k_tile_excl_sum"); hipLaunchKernelGGL(k_tile_excl_sum, dim3(st.nBlocks), dim3(256), 0, s, tileSize, per, st.len, ZT, totals); }
+    { KScope ks_("k_zrlt_f_finish"); hipLaunchKernelGGL(k_zrlt_f_finish, dim3((st.nBlocks + 255) / 256), dim3(256), 0, s, st.len, st.cap, totals, st.nBlocks, st.ok, st.newLen); }
+    { KScope ks_("k_zrlt_f_emit"); hipLaunchKernelGGL(k_zrlt_f_pass<true>, grid, dim3(256), 0, s, v, per, nextNZ, nullptr, tileSize, st.ok); }
+}
+
+void launch_zrlt_inverse(hipStream_t s, const XfStage& st)
+{
+    const XfView v = mk(st);
+    const int per = (int)(((st.maxLen + ZT - 1) / ZT + 1) & ~1u);
+    u32* a = st.scratchU32;                                  // tileLastNonFF -> prevNonFF (separate arrays)
+    u32* prevNonFF = a + (size_t)st.nBlocks * per;
+    u32* bArr = prevNonFF + (size_t)st.nBlocks * per;       // tileLastNonR
+    u32* prevNonR = bArr + (size_t)st.nBlocks * per;
+    u64* tileSize = reinterpret_cast<u64*>(prevNonR + (size_t)st.nBlocks * per);   // scratch is 8-byte aligned, per is padded even
+    u32* totals = reinterpret_cast<u32*>(tileSize + (size_t)st.nBlocks * per);
+    u32* errFlags = totals + st.nBlocks;
+    const dim3 grid(per, st.nBlocks);
+    hipMemsetAsync(errFlags, 0, sizeof(u32) * st.nBlocks, s);
+    { KScope ks_("k_zrlt_i_lastnonff"); hipLaunchKernelGGL(k_zrlt_i_lastnonff, grid, dim3(256), 0, s, v, per, a); }
+    { KScope ks_("k_tile_prefix_max"); hipLaunchKernelGGL(k_tile_prefix_max, dim3((st.nBlocks + 63) / 64), dim3(64), 0, s, a, prevNonFF, per, st.len, st.nBlocks); }
+    { KScope ks_("k_zrlt_i_class"); hipLaunchKernelGGL(k_zrlt_i_pass<0>, grid, dim3(256), 0, s, v, per, prevNonFF, bArr, nullptr, nullptr, nullptr, nullptr, nullptr); }
+    { KScope ks_("k_tile_prefix_max"); hipLaunchKernelGGL(k_tile_prefix_max, dim3((st.nBlocks + 63) / 64), dim3(64), 0, s, bArr, prevNonR, per, st.len, st.nBlocks); }
+    { KScope ks_("k_zrlt_i_count"); hipLaunchKernelGGL(k_zrlt_i_pass<1>, grid, dim3(256), 0, s, v, per, prevNonFF, nullptr, prevNonR, tileSize, nullptr, errFlags, nullptr); }
+    { KScope ks_("k_tile_excl_sum64"); hipLaunchKernelGGL(k_tile_excl_sum64, dim3(st.nBlocks), dim3(256), 0, s, tileSize, per, st.len, ZT, totals); }
+    { KScope ks_("k_zrlt_i_finish"); hipLaunchKernelGGL(k_zrlt_i_finish, dim3((st.nBlocks + 255) / 256), dim3(256), 0, s, st.len, st.cap, totals, errFlags, st.nBlocks, st.ok, st.newLen); }
+    { KScope ks_("k_zero_dst"); hipLaunchKernelGGL(k_zero_dst, dim3(256, st.nBlocks), dim3(256), 0, s, v, totals); }
+    { KScope ks_("k_zrlt_i_emit"); hipLaunchKernelGGL(k_zrlt_i_pass<2>, grid, dim3(256), 0, s, v, per, prevNonFF, nullptr, prevNonR, nullptr, tileSize, nullptr, st.ok); }
+}
+
+void launch_mtft_forward(hipStream_t s, const XfStage& st)
+{
+    const XfView v = mk(st);
+    const int perTiles = (int)((st.maxLen + MT - 1) / MT);
+    const int perWaves = (int)((st.maxLen + MW - 1) / MW);
+    u32* tileLast = st.scratchU32;                           // nBlocks * perTiles * 256
+    const dim3 grid(perWaves, st.nBlocks);
+    { KScope ks_("k_copy_ok"); hipLaunchKernelGGL(k_copy_ok, dim3((st.nBlocks + 255) / 256), dim3(256), 0, s, st.len, st.cap, st.nBlocks, st.ok, st.newLen); }
+    { KScope ks_("k_mtf_f_last"); hipLaunchKernelGGL(k_mtf_f_last, grid, dim3(64), 0, s, v, perTiles, tileLast); }
+    { KScope ks_("k_mtf_f_scan"); hipLaunchKernelGGL(k_mtf_f_scan, dim3(st.nBlocks), dim3(256), 0, s, tileLast, perTiles, st.len); }
+    { KScope ks_("k_mtf_f_rank"); hipLaunchKernelGGL(k_mtf_f_rank, grid, dim3(64), 0, s, v, perTiles, tileLast); }
+}
+
+void launch_mtft_inverse(hipStream_t s, const XfStage& st)
+{
+    const XfView v = mk(st);
+    const int perTiles = (int)((st.maxLen + MT - 1) / MT);
+    const int perWaves = (int)((st.maxLen + MW - 1) / MW);
+    u8* tilePerm = reinterpret_cast<u8*>(st.scratchU32);     // nBlocks * perTiles * 256 bytes
+    { KScope ks_("k_copy_ok"); hipLaunchKernelGGL(k_copy_ok, dim3((st.nBlocks + 255) / 256), dim3(256), 0, s, st.len, st.cap, st.nBlocks, st.ok, st.newLen); }
+    { KScope ks_("k_mtf_i_symbolic"); hipLaunchKernelGGL(k_mtf_i_symbolic, dim3(perWaves, st.nBlocks), dim3(64), 0, s, v, perTiles, tilePerm); }
+    { KScope ks_("k_mtf_i_compose"); hipLaunchKernelGGL(k_mtf_i_compose, dim3(st.nBlocks), dim3(256), 0, s, tilePerm, perTiles, st.len); }
+    { KScope ks_("k_mtf_i_resolve"); hipLaunchKernelGGL(k_mtf_i_resolve, dim3(perTiles, st.nBlocks), dim3(256), 0, s, v, perTiles, tilePerm); }
+}
+
+size_t zrlt_scratch_u32(int nBlocks, u32 maxLen) { return (size_t)nBlocks * ((maxLen + ZT - 1) / ZT + 2) * 6 + 2 * (size_t)nBlocks + 64; }
+size_t mtft_scratch_u32(int nBlocks, u32 maxLen) { return (size_t)nBlocks * ((maxLen + MT - 1) / MT) * 256 + 64; }
+
+}  // namespace knz

@@ -12,8 +12,8 @@ import vectors
 
 pytestmark = pytest.mark.gpu
 
-ENTROPY_ON_DEVICE = ["NONE", "ANS0"]
-TRANSFORMS_ON_DEVICE = []
+ENTROPY_ON_DEVICE = ["NONE", "ANS0", "HUFFMAN"]
+TRANSFORMS_ON_DEVICE = ["ZRLT", "MTFT", "BWT"]
 
 
 def matches(packed, b):

@@ -36,6 +36,19 @@ def make(spec):
         return bytes((np.random.default_rng(spec[2]).integers(0, 2, spec[1]) * 7).astype(np.uint8))
     if kind == "ffmix":
         return bytes([0xFE, 0xFF, 0, 0, 0, 5, 0xFF, 0xFF] * spec[1])
+    if kind == "fib":                 # Fibonacci frequencies: Huffman code lengths > 12 -> limitCodeLengths
+        a, b, out = 1, 1, bytearray()
+        for i in range(spec[1]):
+            out += bytes([(i * 7 + 3) & 255]) * a
+            a, b = b, a + b
+        rng = np.random.default_rng(spec[2])
+        arr = np.frombuffer(bytes(out), dtype=np.uint8).copy()
+        rng.shuffle(arr)
+        return arr.tobytes()
+    if kind == "pow":                 # frequencies ~ ratio^i: long tails of rare symbols
+        rng = np.random.default_rng(spec[3])
+        w = np.array([spec[2] ** (-i / 10.0) for i in range(spec[4])])
+        return bytes(rng.choice(spec[4], size=spec[1], p=w / w.sum()).astype(np.uint8))
     if kind == "bytes":
         return bytes.fromhex(spec[1])
     if kind == "str":
@@ -51,6 +64,7 @@ STAGE_INPUTS = [
     ("text", 4096, 3), ("mixedslice", 5 * 262144, 2, 3 * 262144, 3 * 262144 + 70000), ("mixed", 300000, 2),
     ("rand", 50000, 7), ("geom", 100001, 3, 30), ("twosym", 50000, 5), ("ffmix", 3000), ("runs", 9000, 60),
     ("str", "abcabcabcabcabcabcab"), ("ramp", 33), ("ramp", 15), ("ramp", 1),
+    ("fib", 19, 1), ("fib", 20, 2), ("pow", 16384, 14, 3, 200), ("pow", 16000, 20, 4, 120), ("pow", 40000, 17, 5, 256),
 ]
 
 STREAM_CASES = [
