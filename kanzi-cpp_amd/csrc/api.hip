@@ -97,8 +97,8 @@ static int count_transforms(uint64_t t, int* tok)
     return nb;
 }
 
-static bool transform_supported(int t) { return t == KNZ_T_NONE || t == KNZ_T_ZRLT || t == KNZ_T_MTFT || t == KNZ_T_BWT; }
-static bool entropy_supported(int e) { return e == KNZ_E_NONE || e == KNZ_E_ANS0 || e == KNZ_E_HUFFMAN; }
+static bool transform_supported(int t) { return t == KNZ_T_NONE || t == KNZ_T_ZRLT || t == KNZ_T_MTFT || t == KNZ_T_BWT || t == KNZ_T_SRT || t == KNZ_T_RLT; }
+static bool entropy_supported(int e) { return e == KNZ_E_NONE || e == KNZ_E_ANS0 || e == KNZ_E_HUFFMAN || e == KNZ_E_FPAQ; }
 
 static int max_encoded_len(int t, int n)
 {
@@ -306,6 +306,8 @@ static int run_forward_stage(Ctx* c, hipStream_t s, int t, const XfStage& st)
     switch (t) {
     case KNZ_T_ZRLT: launch_zrlt_forward(s, st); break;
     case KNZ_T_MTFT: launch_mtft_forward(s, st); break;
+    case KNZ_T_SRT: launch_srt_forward(s, st); break;
+    case KNZ_T_RLT: launch_rlt_forward(s, st); break;
     case KNZ_T_BWT: {
         const size_t bytes = bwt_forward_scratch_bytes(st.nBlocks, st.maxLen, (size_t)st.nBlocks * st.maxLen);
         void* sc;
@@ -323,6 +325,8 @@ static int run_inverse_stage(Ctx* c, hipStream_t s, int t, const XfStage& st)
     switch (t) {
     case KNZ_T_ZRLT: launch_zrlt_inverse(s, st); break;
     case KNZ_T_MTFT: launch_mtft_inverse(s, st); break;
+    case KNZ_T_SRT: launch_srt_inverse(s, st); break;
+    case KNZ_T_RLT: launch_rlt_inverse(s, st); break;
     case KNZ_T_BWT: {
         const size_t bytes = bwt_inverse_scratch_bytes(st.nBlocks, st.maxLen, (size_t)st.nBlocks * st.maxLen);
         void* sc;
@@ -441,7 +445,8 @@ static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t 
     u8* d_skip = w.a.skip;
 
     // ---- entropy stage
-    const int maxChunks = (int)((S + ENT_CHUNK - 1) / ENT_CHUNK);
+    const u32 entChunk = (p->entropy_type == KNZ_E_FPAQ) ? (4u << 20) : ENT_CHUNK;
+    const int maxChunks = (int)((S + entChunk - 1) / entChunk);
     const size_t nSlots = (size_t)nBlocks * maxChunks;
     ChunkDesc* d_desc; u8* d_tmp; uint2* d_encTab;
     if (int r = ws_get(c, "desc", sizeof(ChunkDesc) * nSlots, (void**)&d_desc)) return r;
@@ -452,6 +457,10 @@ static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t 
     } else if (p->entropy_type == KNZ_E_HUFFMAN) {
         if (int r = ws_get(c, "chunkTmp", (size_t)TMP_STRIDE * nSlots, (void**)&d_tmp)) return r;
         launch_huffman_encode(s, view, nBlocks, maxChunks, d_desc, d_tmp);
+    } else if (p->entropy_type == KNZ_E_FPAQ) {
+        const u64 fStride = (4u << 20) + (4u << 17) + 256;      // FPAQEncoder.cpp:65-68 buffer size (+ slack)
+        if (int r = ws_get(c, "chunkTmp", (size_t)fStride * nSlots, (void**)&d_tmp)) return r;
+        launch_fpaq_encode(s, view, d_origLen, nBlocks, maxChunks, d_desc, d_tmp, fStride);
     } else {
         if (int r = ws_get(c, "chunkTmp", 64, (void**)&d_tmp)) return r;
         launch_none_encode(s, view, nBlocks, maxChunks, d_desc);
@@ -460,7 +469,7 @@ static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t 
     // ---- framing + assembly
     FrameParams fp;
     fp.framing = framing; fp.nTransforms = nTok; fp.checksumBits = p->checksum_bits; fp.finish = finish; fp.prologueBits = prologueBits;
-    launch_block_sum(s, d_desc, d_info, d_blockLen, nBlocks, maxChunks, ENT_CHUNK);
+    launch_block_sum(s, d_desc, d_info, d_blockLen, nBlocks, maxChunks, entChunk);
     launch_block_scan(s, d_info, d_blockLen, nBlocks, fp, d_total);
     // The output must be zero before the OR-assembly; its size is only known on the device, so the
     // total is read back first (8 bytes) and only the used part is cleared.
@@ -481,7 +490,7 @@ static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t 
         HIPCHK(c, hipMemcpyAsync(d_pro, prologue, (prologueBits + 7) / 8, hipMemcpyHostToDevice, s));
         launch_put_prologue(s, reinterpret_cast<u32*>(d_out), d_pro, prologueBits);
     }
-    launch_assemble(s, d_desc, d_info, d_blockLen, d_origLen, d_skip, nullptr, d_tmp, nBlocks, maxChunks, ENT_CHUNK, fp,
+    launch_assemble(s, d_desc, d_info, d_blockLen, d_origLen, d_skip, nullptr, d_tmp, nBlocks, maxChunks, entChunk, fp,
                     reinterpret_cast<u32*>(d_out));
     HIPCHK(c, hipGetLastError());
     if (outBits) {
@@ -560,7 +569,9 @@ static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_
 
     // entropy stage decodes into workspace A (or straight into d_out when no transform applies)
     launch_check_prelen(s, d_blocks, nBlocks, realStages ? maxPre : unit, outCap, outStride);
-    launch_seq_inv_entropy_dst(s, w.a, d_blocks, nBlocks, d_out, outStride, w.A, S, w.d_entDst);
+    u32 realMask = 0;
+    for (int i = 0; i < nTok; i++) if (tok[i] != KNZ_T_NONE) realMask |= 1u << (7 - i);
+    launch_seq_inv_entropy_dst(s, w.a, d_blocks, nBlocks, d_out, outStride, w.A, S, w.d_entDst, realMask);
     if (p->entropy_type == KNZ_E_ANS0) {
         void* d_meta;
         if (int r = ws_get(c, "ansDecChunks", ans0_dec_chunk_bytes() * nSlots, &d_meta)) return r;
@@ -569,6 +580,8 @@ static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_
         void* d_meta;
         if (int r = ws_get(c, "hufDecChunks", huffman_dec_chunk_bytes() * nSlots, &d_meta)) return r;
         launch_huffman_decode(s, src, d_blocks, nBlocks, maxChunks, d_meta, w.d_entDst);
+    } else if (p->entropy_type == KNZ_E_FPAQ) {
+        launch_fpaq_decode(s, src, d_blocks, nBlocks, w.d_entDst);
     } else {
         launch_none_decode(s, src, d_blocks, nBlocks, w.d_entDst);
     }
@@ -579,7 +592,7 @@ static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_
         const u32 capMid = framing ? (u32)std::min<u64>(S, blkLenModel) : (u32)p->jobs;
         for (int i = nTok - 1; i >= 0; i--) {
             if (tok[i] == KNZ_T_NONE) continue;
-            launch_seq_inv_prepare(s, w.a, d_blocks, nBlocks, i, d_out, outStride, w.A, w.B, S, capMid, capFinal);
+            launch_seq_inv_prepare(s, w.a, d_blocks, nBlocks, i, d_out, outStride, w.A, w.B, S, capMid, capFinal, realMask);
             XfStage st;
             st.src = w.a.src; st.dst = w.a.dst; st.len = w.a.alen; st.cap = w.a.cap; st.ok = w.a.ok; st.newLen = w.a.newLen;
             st.nBlocks = nBlocks; st.maxLen = (u32)S; st.scratchU32 = w.scratch; st.entropyType = p->entropy_type;

@@ -71,12 +71,13 @@ __global__ void k_seq_fwd_finish(SeqArrays a, int nBlocks, const u8* in, u64 inS
 }
 
 // ---- inverse
-__global__ void k_seq_inv_entropy_dst(SeqArrays a, DecBlock* blocks, int nBlocks, u8* out, u64 outStride, u8* A, u64 S, u8** entDst)
+__global__ void k_seq_inv_entropy_dst(SeqArrays a, DecBlock* blocks, int nBlocks, u8* out, u64 outStride, u8* A, u64 S, u8** entDst, u32 realMask)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nBlocks) return;
     const DecBlock& db = blocks[b];
-    const bool any = !db.copyBlock && (db.skipFlags & 0xFF) != 0xFF;
+    // realMask: bit (7-i) set for every non-NONE stage i of the sequence
+    const bool any = !db.copyBlock && ((~db.skipFlags) & realMask & 0xFF) != 0;
     a.skip[b] = db.copyBlock ? 0xFF : (u8)db.skipFlags;
     a.where[b] = any ? 1 : 0;
     a.len[b] = db.preLen;
@@ -84,7 +85,7 @@ __global__ void k_seq_inv_entropy_dst(SeqArrays a, DecBlock* blocks, int nBlocks
 }
 
 __global__ void k_seq_inv_prepare(SeqArrays a, DecBlock* blocks, int nBlocks, int stage, u8* out, u64 outStride, u8* A, u8* B, u64 S,
-                                  u32 capMid, u32 capFinal)
+                                  u32 capMid, u32 capFinal, u32 realMask)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nBlocks) return;
@@ -93,7 +94,7 @@ __global__ void k_seq_inv_prepare(SeqArrays a, DecBlock* blocks, int nBlocks, in
     a.active[b] = applied ? 1 : 0;
     a.alen[b] = applied ? a.len[b] : 0;
     bool lower = false;
-    for (int j = 0; j < stage; j++) if (!((skip >> (7 - j)) & 1)) lower = true;
+    for (int j = 0; j < stage; j++) if (!((skip >> (7 - j)) & 1) && ((realMask >> (7 - j)) & 1)) lower = true;
     const u8 w = a.where[b];
     a.src[b] = (w == 1) ? A + (size_t)b * S : B + (size_t)b * S;
     if (lower) { a.dst[b] = (w == 1) ? B + (size_t)b * S : A + (size_t)b * S; a.cap[b] = capMid; }
@@ -124,10 +125,10 @@ void launch_seq_fwd_null(hipStream_t s, const SeqArrays& a, int nBlocks, int sta
 { KScope ks_("k_seq_fwd_null"); L1D(k_seq_fwd_null, a, nBlocks, stage); }
 void launch_seq_fwd_finish(hipStream_t s, const SeqArrays& a, int nBlocks, const u8* in, u64 inStride, u8* A, u8* B, u64 S, const u8** viewPtr)
 { KScope ks_("k_seq_fwd_finish"); L1D(k_seq_fwd_finish, a, nBlocks, in, inStride, A, B, S, viewPtr); }
-void launch_seq_inv_entropy_dst(hipStream_t s, const SeqArrays& a, DecBlock* blocks, int nBlocks, u8* out, u64 outStride, u8* A, u64 S, u8** entDst)
-{ KScope ks_("k_seq_inv_entropy_dst"); L1D(k_seq_inv_entropy_dst, a, blocks, nBlocks, out, outStride, A, S, entDst); }
-void launch_seq_inv_prepare(hipStream_t s, const SeqArrays& a, DecBlock* blocks, int nBlocks, int stage, u8* out, u64 outStride, u8* A, u8* B, u64 S, u32 capMid, u32 capFinal)
-{ KScope ks_("k_seq_inv_prepare"); L1D(k_seq_inv_prepare, a, blocks, nBlocks, stage, out, outStride, A, B, S, capMid, capFinal); }
+void launch_seq_inv_entropy_dst(hipStream_t s, const SeqArrays& a, DecBlock* blocks, int nBlocks, u8* out, u64 outStride, u8* A, u64 S, u8** entDst, u32 realMask)
+{ KScope ks_("k_seq_inv_entropy_dst"); L1D(k_seq_inv_entropy_dst, a, blocks, nBlocks, out, outStride, A, S, entDst, realMask); }
+void launch_seq_inv_prepare(hipStream_t s, const SeqArrays& a, DecBlock* blocks, int nBlocks, int stage, u8* out, u64 outStride, u8* A, u8* B, u64 S, u32 capMid, u32 capFinal, u32 realMask)
+{ KScope ks_("k_seq_inv_prepare"); L1D(k_seq_inv_prepare, a, blocks, nBlocks, stage, out, outStride, A, B, S, capMid, capFinal, realMask); }
 void launch_seq_inv_commit(hipStream_t s, const SeqArrays& a, DecBlock* blocks, int nBlocks, int stage, int ttype)
 { KScope ks_("k_seq_inv_commit"); L1D(k_seq_inv_commit, a, blocks, nBlocks, stage, ttype); }
 

@@ -61,6 +61,14 @@ int launch_bwt_inverse(hipStream_t s, const XfStage& st, void* scratch, size_t s
 size_t bwt_forward_scratch_bytes(int nBlocks, u32 VS, size_t total);
 size_t bwt_inverse_scratch_bytes(int nBlocks, u32 VS, size_t total);
 
+// serial.hip (one lane per block: FPAQ, SRT, RLT)
+void launch_fpaq_encode(hipStream_t s, BlockView view, const u32* origLen, int nBlocks, int maxChunks, ChunkDesc* desc, u8* tmp, u64 tmpStride);
+void launch_fpaq_decode(hipStream_t s, BitSrc src, DecBlock* blocks, int nBlocks, u8* const* outPtr);
+void launch_srt_forward(hipStream_t s, const XfStage& st);
+void launch_srt_inverse(hipStream_t s, const XfStage& st);
+void launch_rlt_forward(hipStream_t s, const XfStage& st);
+void launch_rlt_inverse(hipStream_t s, const XfStage& st);
+
 // sequence.hip : TransformSequence bookkeeping on the device
 struct SeqArrays {
     u8* where;               // 0 = caller buffer, 1 = workspace A, 2 = workspace B
@@ -82,8 +90,8 @@ void launch_seq_fwd_prepare(hipStream_t s, const SeqArrays& a, int nBlocks, int 
 void launch_seq_fwd_null(hipStream_t s, const SeqArrays& a, int nBlocks, int stage);
 void launch_seq_fwd_commit(hipStream_t s, const SeqArrays& a, int nBlocks, int stage);
 void launch_seq_fwd_finish(hipStream_t s, const SeqArrays& a, int nBlocks, const u8* in, u64 inStride, u8* A, u8* B, u64 S, const u8** viewPtr);
-void launch_seq_inv_entropy_dst(hipStream_t s, const SeqArrays& a, DecBlock* blocks, int nBlocks, u8* out, u64 outStride, u8* A, u64 S, u8** entDst);
-void launch_seq_inv_prepare(hipStream_t s, const SeqArrays& a, DecBlock* blocks, int nBlocks, int stage, u8* out, u64 outStride, u8* A, u8* B, u64 S, u32 capMid, u32 capFinal);
+void launch_seq_inv_entropy_dst(hipStream_t s, const SeqArrays& a, DecBlock* blocks, int nBlocks, u8* out, u64 outStride, u8* A, u64 S, u8** entDst, u32 realMask);
+void launch_seq_inv_prepare(hipStream_t s, const SeqArrays& a, DecBlock* blocks, int nBlocks, int stage, u8* out, u64 outStride, u8* A, u8* B, u64 S, u32 capMid, u32 capFinal, u32 realMask);
 void launch_seq_inv_commit(hipStream_t s, const SeqArrays& a, DecBlock* blocks, int nBlocks, int stage, int ttype);
 
 // huffman.hip

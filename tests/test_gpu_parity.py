@@ -12,8 +12,8 @@ import vectors
 
 pytestmark = pytest.mark.gpu
 
-ENTROPY_ON_DEVICE = ["NONE", "ANS0", "HUFFMAN"]
-TRANSFORMS_ON_DEVICE = ["ZRLT", "MTFT", "BWT"]
+ENTROPY_ON_DEVICE = ["NONE", "ANS0", "HUFFMAN", "FPAQ"]
+TRANSFORMS_ON_DEVICE = ["ZRLT", "MTFT", "BWT", "SRT", "RLT"]
 
 
 def matches(packed, b):
@@ -112,6 +112,80 @@ def test_truncated_payload_rejected(hip, oracle):
         assert dec != len(d) or out != d
 
 
+def test_transform_stage_golden(hip, golden):
+    n = 0
+    for rec in golden["stages"]:
+        if rec["kind"] != "transform" or rec["name"] not in TRANSFORMS_ON_DEVICE:
+            continue
+        d = vectors.make(tuple(rec["input"]))
+        if len(d) == 0:
+            continue
+        ok, out = hip.transform_forward(rec["name"], d, rec["cap"], rec["entropy"] or None)
+        assert int(bool(ok)) == rec["ok"], (rec["name"], rec["input"])
+        if rec["ok"]:
+            assert matches(rec["out"], out), (rec["name"], rec["input"])
+            k, back = hip.transform_inverse(rec["name"], out, max(len(d), len(out)) + 64)
+            assert k == 1 and back == d, (rec["name"], rec["input"])
+        n += 1
+    assert n > 100
+
+
+def test_transform_capacity_semantics(hip, oracle):
+    # destination capacity changes results (ZRLT/RLT): src/test/TestTransforms.cpp:371-498,500-757
+    rng = np.random.default_rng(5)
+    cases = [vectors.make(("mixed", 200000, 7)), rng.integers(0, 256, 30000, dtype=np.uint8).tobytes(),
+             vectors.make(("ffmix", 500)), bytes(5000), vectors.make(("runs", 300, 40))]
+    for d in cases:
+        for t in ["ZRLT", "RLT", "MTFT", "SRT", "BWT"]:
+            for cap in (len(d) // 2, len(d) - 1, len(d), len(d) + 1, len(d) + 33, len(d) + 1024, len(d) + 2048):
+                ok1, o1 = oracle.forward(t, d, cap, "ANS0")
+                ok2, o2 = hip.transform_forward(t, d, cap, "ANS0")
+                assert bool(ok1) == bool(ok2), (t, cap, len(d))
+                if ok1:
+                    assert o1 == o2, (t, cap)
+                    for icap in (len(d) - 1, len(d), len(d) + 1, max(len(d), len(o1)) + 64):
+                        k1, b1 = oracle.inverse(t, o1, icap)
+                        k2, b2 = hip.transform_inverse(t, o1, icap)
+                        assert bool(k1) == bool(k2), (t, cap, icap)
+                        if k1:
+                            assert b1 == b2
+    # the reference's own ZRLT KATs
+    assert hip.transform_inverse("ZRLT", bytes([2]), 1) == (1, bytes([1]))
+    assert hip.transform_inverse("ZRLT", bytes([2, 2]), 1)[0] == 0
+    assert hip.transform_inverse("ZRLT", bytes([0xFF]), 1)[0] == 0
+    assert hip.transform_forward("ZRLT", bytes([0xFE]), 1)[0] == 0
+    assert hip.transform_forward("ZRLT", bytes([0]), 1) == (1, bytes([0]))
+
+
+def test_bwt_known_strings(hip):
+    # src/test/TestBWT.cpp:42-60 ; header: mode byte + (primaryIndex-1)
+    for src, exp, pidx in [(b"mississippi", b"ipssmpissii", 5),
+                           (b"SIX.MIXED.PIXIES.SIFT.SIXTY.PIXIE.DUST.BOXES", b"STEXYDST.E.IXXIIXXSSMPPS.B..EE..USFXDIIOIIIT", 31)]:
+        ok, out = hip.transform_forward("BWT", src, len(src) + 64)
+        assert ok == 1 and out[0] == 0 and out[1] == pidx - 1 and out[2:] == exp
+    # invalid primary index must fail (src/test/TestBWT.cpp:274-347)
+    bad = bytes([0, 200]) + b"ipssmpissii"
+    assert hip.transform_inverse("BWT", bad, 64)[0] == 0
+
+
+def test_jobs_capacity_model(hip, oracle):
+    # the reference's output depends on -j through buffer-slot capacities
+    d = vectors.make(("mixed", 700001, 11))
+    outs = {}
+    for jobs in (1, 2, 3):
+        rc, ref = oracle.compress(d, "BWT+SRT+ZRLT", "ANS0", 262144, headerless=1, jobs=jobs)
+        p = hip.params("BWT+SRT+ZRLT", "ANS0", 262144, jobs=jobs)
+        cap = hip.encode_bound(p, len(d)) + 64
+        d_in, d_out = hip.malloc(len(d) + 64), hip.malloc(cap)
+        hip.h2d(d_in, d)
+        bits = hip.encode_blocks(p, d_in, len(d), d_out, cap)
+        got = hip.d2h(d_out, (bits + 7) // 8)
+        hip.free(d_in); hip.free(d_out)
+        assert got == ref, jobs
+        outs[jobs] = got
+    assert outs[1] == outs[2] and outs[1] != outs[3]
+
+
 def test_stream_golden(hip, golden):
     n = 0
     for rec in golden["streams"]:
@@ -124,7 +198,7 @@ def test_stream_golden(hip, golden):
         back = gpu_decompress(hip, out, rec["transform"], rec["entropy"], rec["block"], len(d), hb, rec["checksum"])
         assert back == d, rec
         n += 1
-    assert n >= 3
+    assert n >= 15
 
 
 def test_stream_vs_oracle_ragged(hip, oracle):
@@ -132,17 +206,19 @@ def test_stream_vs_oracle_ragged(hip, oracle):
                      (("ramp", 15), 1024), (("ramp", 16), 1024), (("ramp", 33), 1024), (("const", 50000, 7), 4096)]:
         d = vectors.make(spec)
         for e in ENTROPY_ON_DEVICE:
-            rc, ref = oracle.compress(d, "NONE", e, bs, headerless=1)
-            out, bits, hb = gpu_compress(hip, d, "NONE", e, bs, headerless=1)
-            assert out == ref, (spec, e)
-            assert gpu_decompress(hip, ref, "NONE", e, bs, len(d), 0) == d, (spec, e)
+            for t in ("NONE", "BWT+MTFT+ZRLT", "BWT+SRT+ZRLT"):
+                rc, ref = oracle.compress(d, t, e, bs, headerless=1)
+                out, bits, hb = gpu_compress(hip, d, t, e, bs, headerless=1)
+                assert out == ref, (spec, t, e)
+                assert gpu_decompress(hip, ref, t, e, bs, len(d), 0) == d, (spec, t, e)
 
 
 def test_full_size_roundtrip_properties(hip):
     # BASELINE config 2 geometry (4 MiB blocks): round trip + determinism on 32 MiB, checked on the device side
     d = vectors.make(("mixed", 32 << 20, 2))
-    for e in ENTROPY_ON_DEVICE:
-        out1, bits1, _ = gpu_compress(hip, d, "NONE", e, 4 << 20, headerless=1)
-        out2, bits2, _ = gpu_compress(hip, d, "NONE", e, 4 << 20, headerless=1)
-        assert out1 == out2
-        assert gpu_decompress(hip, out1, "NONE", e, 4 << 20, len(d), 0) == d
+    for t, e, bs in [("NONE", "ANS0", 4 << 20), ("NONE", "HUFFMAN", 4 << 20), ("BWT+MTFT+ZRLT", "ANS0", 8 << 20),
+                     ("BWT+SRT+ZRLT", "FPAQ", 32 << 20)]:
+        out1, bits1, _ = gpu_compress(hip, d, t, e, bs, headerless=1)
+        out2, bits2, _ = gpu_compress(hip, d, t, e, bs, headerless=1)
+        assert out1 == out2, (t, e)
+        assert gpu_decompress(hip, out1, t, e, bs, len(d), 0) == d, (t, e)
