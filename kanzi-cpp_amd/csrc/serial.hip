@@ -46,8 +46,8 @@ __device__ __forceinline__ void fpaq_enc_bit(u64& low, u64& high, u8* buf, u32& 
 }
 
 // one workgroup (lane 0 active) per block
-__global__ __launch_bounds__(64) void k_fpaq_encode(BlockView view, const u32* __restrict__ origLen, int maxChunks, ChunkDesc* __restrict__ desc,
-                                                    u8* __restrict__ tmp, u64 tmpStride)
+__global__ __launch_bounds__(64) void k_fpaq_encode(BlockView view, const u32* __restrict__ origLen, u32 copyThreshold, int maxChunks,
+                                                    ChunkDesc* __restrict__ desc, u8* __restrict__ tmp, u64 tmpStride)
 {
     const int b = blockIdx.x;
     __shared__ u16 probs[4][256];
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(64) void k_fpaq_encode(BlockView view, const u32* _
     const u32 count = view.len[b];
     const u8* blk = view.ptr[b];
     ChunkDesc* cds = desc + (size_t)b * maxChunks;
-    if (origLen[b] <= 15) {
+    if (origLen[b] <= copyThreshold) {
         // copy block: entropy type forced to NONE (io/CompressedOutputStream.cpp:691-695)
         ChunkDesc& cd = cds[0];
         cd.hdrBits = 0; cd.midLen = 0; cd.trailerLen = 0; cd.aux = 0;
@@ -185,10 +185,10 @@ __global__ __launch_bounds__(64) void k_fpaq_decode(BitSrc src, DecBlock* __rest
     db.usedBits = pos - db.entropyBit;
 }
 
-void launch_fpaq_encode(hipStream_t s, BlockView view, const u32* origLen, int nBlocks, int maxChunks, ChunkDesc* desc, u8* tmp, u64 tmpStride)
+void launch_fpaq_encode(hipStream_t s, BlockView view, const u32* origLen, u32 copyThreshold, int nBlocks, int maxChunks, ChunkDesc* desc, u8* tmp, u64 tmpStride)
 {
     hipMemsetAsync(desc, 0, sizeof(ChunkDesc) * (size_t)nBlocks * maxChunks, s);
-    { KScope ks_("k_fpaq_encode"); hipLaunchKernelGGL(k_fpaq_encode, dim3(nBlocks), dim3(64), 0, s, view, origLen, maxChunks, desc, tmp, tmpStride); }
+    { KScope ks_("k_fpaq_encode"); hipLaunchKernelGGL(k_fpaq_encode, dim3(nBlocks), dim3(64), 0, s, view, origLen, copyThreshold, maxChunks, desc, tmp, tmpStride); }
 }
 
 void launch_fpaq_decode(hipStream_t s, BitSrc src, DecBlock* blocks, int nBlocks, u8* const* outPtr)
