@@ -1,0 +1,368 @@
+// kanzi_amd.hpp -- C++ host mirror of the reference interfaces for the accelerated path.
+//
+// Same class names, method signatures, argument meaning and error behaviour as the reference so
+// that code written against kanzi-cpp's block pipeline compiles against this header with a
+// namespace change (kanzi -> kanzi_amd):
+//   SliceArray<T>                 src/SliceArray.hpp:24-68
+//   Transform<T>                  src/Transform.hpp:38-45
+//   EntropyEncoder / Decoder      src/EntropyEncoder.hpp:30-39, src/EntropyDecoder.hpp:30-39
+//   OutputBitStream / Input...    src/OutputBitStream.hpp:30-49, src/InputBitStream.hpp:29-50
+//   Default{Output,Input}BitStream src/bitstream/DefaultOutputBitStream.hpp, DefaultInputBitStream.hpp
+//   TransformFactory / Sequence   src/transform/TransformFactory.hpp:49-137,208-308, TransformSequence.hpp:88-265
+//   Entropy{En,De}coderFactory    src/entropy/EntropyEncoderFactory.hpp:37-175, EntropyDecoderFactory.hpp
+//   CompressedOutputStream        src/io/CompressedOutputStream.hpp:140-172
+//   CompressedInputStream         src/io/CompressedInputStream.hpp:180-230
+// Every forward/inverse/encode/decode call runs on the GPU through the C ABI in knz_hip.h
+// (libknz_hip.so). There is no CPU implementation behind these classes: without a GPU the
+// constructors throw.
+#ifndef KANZI_AMD_HPP
+#define KANZI_AMD_HPP
+
+#include <cstdint>
+#include <istream>
+#include <map>
+#include <ostream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "knz_hip.h"
+
+namespace kanzi_amd {
+
+typedef uint8_t byte;
+typedef unsigned int uint;
+typedef uint64_t uint64;
+typedef int64_t int64;
+
+struct Error {
+    enum ErrorCode {
+        ERR_MISSING_PARAM = 1, ERR_BLOCK_SIZE = 2, ERR_INVALID_CODEC = 3, ERR_CREATE_COMPRESSOR = 4,
+        ERR_CREATE_DECOMPRESSOR = 5, ERR_OUTPUT_IS_DIR = 6, ERR_OVERWRITE_FILE = 7, ERR_CREATE_FILE = 8,
+        ERR_CREATE_BITSTREAM = 9, ERR_OPEN_FILE = 10, ERR_READ_FILE = 11, ERR_WRITE_FILE = 12,
+        ERR_PROCESS_BLOCK = 13, ERR_CREATE_CODEC = 14, ERR_INVALID_FILE = 15, ERR_STREAM_VERSION = 16,
+        ERR_CREATE_STREAM = 17, ERR_INVALID_PARAM = 18, ERR_CRC_CHECK = 19, ERR_RESERVED_NAME = 20, ERR_UNKNOWN = 127
+    };
+};
+
+class IOException : public std::runtime_error {
+public:
+    IOException(const std::string& msg, int error = Error::ERR_UNKNOWN) : std::runtime_error(msg), _code(error) {}
+    int error() const { return _code; }
+private:
+    int _code;
+};
+
+class BitStreamException : public std::runtime_error {
+public:
+    enum { UNDEFINED = 0, INPUT_OUTPUT = 1, END_OF_STREAM = 2, INVALID_STREAM = 3, STREAM_CLOSED = 4 };
+    BitStreamException(const std::string& msg, int code = UNDEFINED) : std::runtime_error(msg), _code(code) {}
+    int error() const { return _code; }
+private:
+    int _code;
+};
+
+template <class T>
+class SliceArray {
+public:
+    T* _array;
+    int _length;   // capacity
+    int _index;
+    SliceArray(T* arr, int len, int index = 0) : _array(arr), _length(len), _index(index) {}
+    static bool isValid(const SliceArray& sa) { return (sa._array != nullptr) && (sa._index >= 0) && (sa._length >= 0) && (sa._index <= sa._length); }
+};
+
+// String-keyed parameter map (src/Context.hpp:49-86). Keys read here: bsVersion, entropy, jobs, size.
+class Context {
+public:
+    bool has(const std::string& key) const { return _ints.count(key) || _strs.count(key); }
+    int getInt(const std::string& key, int def = 0) const { auto it = _ints.find(key); return it == _ints.end() ? def : int(it->second); }
+    int64 getLong(const std::string& key, int64 def = 0) const { auto it = _ints.find(key); return it == _ints.end() ? def : it->second; }
+    std::string getString(const std::string& key, const std::string& def = "") const { auto it = _strs.find(key); return it == _strs.end() ? def : it->second; }
+    void putInt(const std::string& key, int v) { _ints[key] = v; }
+    void putLong(const std::string& key, int64 v) { _ints[key] = v; }
+    void putString(const std::string& key, const std::string& v) { _strs[key] = v; }
+private:
+    std::map<std::string, int64> _ints;
+    std::map<std::string, std::string> _strs;
+};
+
+class OutputBitStream {
+public:
+    virtual void writeBit(int bit) = 0;
+    virtual uint writeBits(uint64 bits, uint length) = 0;
+    virtual uint writeBits(const byte bits[], uint length) = 0;
+    virtual void close() = 0;
+    virtual uint64 written() const = 0;
+    virtual ~OutputBitStream() {}
+};
+
+class InputBitStream {
+public:
+    virtual int readBit() = 0;
+    virtual uint64 readBits(uint length) = 0;
+    virtual uint readBits(byte bits[], uint length) = 0;
+    virtual void close() = 0;
+    virtual uint64 read() const = 0;
+    virtual bool hasMoreToRead() = 0;
+    virtual ~InputBitStream() {}
+};
+
+// MSB-first bit streams over std streams (bitstream/DefaultOutputBitStream.hpp:83-131, DefaultInputBitStream.hpp:88-150)
+class DefaultOutputBitStream : public OutputBitStream {
+public:
+    explicit DefaultOutputBitStream(std::ostream& os, uint bufferSize = 65536);
+    ~DefaultOutputBitStream();
+    void writeBit(int bit);
+    uint writeBits(uint64 bits, uint length);
+    uint writeBits(const byte bits[], uint length);
+    void close();
+    uint64 written() const { return _written; }
+    bool isClosed() const { return _closed; }
+private:
+    std::ostream& _os;
+    std::vector<byte> _buf;
+    uint64 _current;
+    uint _avail;       // free bits in _current
+    uint64 _written;
+    bool _closed;
+    void push();
+    void flush();
+};
+
+class DefaultInputBitStream : public InputBitStream {
+public:
+    explicit DefaultInputBitStream(std::istream& is, uint bufferSize = 65536);
+    ~DefaultInputBitStream();
+    int readBit();
+    uint64 readBits(uint length);
+    uint readBits(byte bits[], uint length);
+    void close();
+    uint64 read() const { return _read; }
+    bool hasMoreToRead();
+    // Device decoders need the bits they will consume in one buffer: returns everything not yet
+    // consumed (bit 0 of the result = next unread bit) without consuming it, and lets the caller
+    // advance afterwards.
+    void peekRemaining(const byte** data, uint64* startBit, uint64* endBit);
+    void skip(uint64 nbits);
+private:
+    std::istream& _is;
+    std::vector<byte> _data;   // bytes fetched from the stream so far and not yet fully consumed
+    uint64 _pos;               // bit position in _data
+    uint64 _read;
+    bool _closed;
+    bool _eof;
+    uint _chunk;
+    bool fill(uint64 needBits);
+};
+
+template <class T>
+class Transform {
+public:
+    virtual bool forward(SliceArray<T>& src, SliceArray<T>& dst, int length) = 0;
+    virtual bool inverse(SliceArray<T>& src, SliceArray<T>& dst, int length) = 0;
+    virtual int getMaxEncodedLength(int srcLen) const = 0;
+    virtual ~Transform() {}
+};
+
+class EntropyEncoder {
+public:
+    virtual int encode(const byte block[], uint blkptr, uint len) = 0;
+    virtual OutputBitStream& getBitStream() const = 0;
+    virtual void dispose() = 0;
+    virtual ~EntropyEncoder() {}
+};
+
+class EntropyDecoder {
+public:
+    virtual int decode(byte block[], uint blkptr, uint len) = 0;
+    virtual InputBitStream& getBitStream() const = 0;
+    virtual void dispose() = 0;
+    virtual ~EntropyDecoder() {}
+};
+
+// One device context per process and device id (lazy). Throws IOException when no GPU is usable.
+knz_ctx* deviceContext(int device = -1);
+void setDefaultDevice(int device);
+
+// ---- transforms on the device ------------------------------------------------------------------
+class DeviceTransform : public Transform<byte> {
+public:
+    DeviceTransform(int type, Context* ctx);
+    bool forward(SliceArray<byte>& src, SliceArray<byte>& dst, int length);
+    bool inverse(SliceArray<byte>& src, SliceArray<byte>& dst, int length);
+    int getMaxEncodedLength(int srcLen) const;
+    int type() const { return _type; }
+protected:
+    int _type;
+    int _entropy;     // stream entropy id from the context (RLT escape choice), -1 if absent
+};
+
+class BWTBlockCodec : public DeviceTransform { public: explicit BWTBlockCodec(Context& ctx) : DeviceTransform(KNZ_T_BWT, &ctx) {} BWTBlockCodec() : DeviceTransform(KNZ_T_BWT, nullptr) {} };
+class SBRT : public DeviceTransform {
+public:
+    static const int MODE_MTF = 1, MODE_RANK = 2, MODE_TIMESTAMP = 3;
+    explicit SBRT(int mode);
+    SBRT(int mode, Context& ctx);
+};
+class SRT : public DeviceTransform { public: explicit SRT(Context& ctx) : DeviceTransform(KNZ_T_SRT, &ctx) {} SRT() : DeviceTransform(KNZ_T_SRT, nullptr) {} };
+class ZRLT : public DeviceTransform { public: explicit ZRLT(Context& ctx) : DeviceTransform(KNZ_T_ZRLT, &ctx) {} ZRLT() : DeviceTransform(KNZ_T_ZRLT, nullptr) {} };
+class RLT : public DeviceTransform { public: explicit RLT(Context& ctx) : DeviceTransform(KNZ_T_RLT, &ctx) {} RLT() : DeviceTransform(KNZ_T_RLT, nullptr) {} };
+class NullTransform : public Transform<byte> {
+public:
+    NullTransform() {}
+    explicit NullTransform(Context&) {}
+    bool forward(SliceArray<byte>& src, SliceArray<byte>& dst, int length) { return doCopy(src, dst, length); }
+    bool inverse(SliceArray<byte>& src, SliceArray<byte>& dst, int length) { return doCopy(src, dst, length); }
+    int getMaxEncodedLength(int n) const { return n; }
+private:
+    bool doCopy(SliceArray<byte>& src, SliceArray<byte>& dst, int length) const;
+};
+
+template <class T>
+class TransformSequence : public Transform<T> {
+public:
+    TransformSequence(Transform<T>* transforms[8], bool deallocate);
+    ~TransformSequence();
+    bool forward(SliceArray<T>& src, SliceArray<T>& dst, int length);
+    bool inverse(SliceArray<T>& src, SliceArray<T>& dst, int length);
+    int getMaxEncodedLength(int srcLen) const;
+    int getNbTransforms() const { return _length; }
+    byte getSkipFlags() const { return _skipFlags; }
+    void setSkipFlags(byte flags) { _skipFlags = flags; }
+private:
+    Transform<T>* _transforms[8];
+    bool _deallocate;
+    int _length;
+    byte _skipFlags;
+};
+
+template <class T>
+class TransformFactory {
+public:
+    enum TransformType { NONE_TYPE = 0, BWT_TYPE = 1, BWTS_TYPE = 2, LZ_TYPE = 3, SNAPPY_TYPE = 4, RLT_TYPE = 5, ZRLT_TYPE = 6,
+                         MTFT_TYPE = 7, RANK_TYPE = 8, EXE_TYPE = 9, DICT_TYPE = 10, ROLZ_TYPE = 11, ROLZX_TYPE = 12, SRT_TYPE = 13,
+                         LZP_TYPE = 14, MM_TYPE = 15, LZX_TYPE = 16, UTF_TYPE = 17, PACK_TYPE = 18, DNA_TYPE = 19 };
+    static uint64 getType(const char* name);           // throws std::invalid_argument for unknown names / > 8 stages
+    static uint64 getTypeToken(const char* name);
+    static std::string getName(uint64 functionType);
+    static TransformSequence<T>* newTransform(Context& ctx, uint64 functionType);   // throws for stages without a device kernel
+    static const int ONE_SHIFT = 6;
+    static const int MAX_SHIFT = (8 - 1) * ONE_SHIFT;
+    static const int MASK = (1 << ONE_SHIFT) - 1;
+};
+
+// ---- entropy codecs on the device --------------------------------------------------------------
+class DeviceEntropyEncoder : public EntropyEncoder {
+public:
+    DeviceEntropyEncoder(OutputBitStream& obs, int type) : _obs(obs), _type(type) {}
+    int encode(const byte block[], uint blkptr, uint len);
+    OutputBitStream& getBitStream() const { return _obs; }
+    void dispose() {}
+private:
+    OutputBitStream& _obs;
+    int _type;
+};
+
+class DeviceEntropyDecoder : public EntropyDecoder {
+public:
+    DeviceEntropyDecoder(InputBitStream& ibs, int type) : _ibs(ibs), _type(type) {}
+    int decode(byte block[], uint blkptr, uint len);
+    InputBitStream& getBitStream() const { return _ibs; }
+    void dispose() {}
+private:
+    InputBitStream& _ibs;
+    int _type;
+};
+
+class ANSRangeEncoder : public DeviceEntropyEncoder { public: ANSRangeEncoder(OutputBitStream& obs, int order = 0); };
+class ANSRangeDecoder : public DeviceEntropyDecoder { public: ANSRangeDecoder(InputBitStream& ibs, int order = 0); };
+class HuffmanEncoder : public DeviceEntropyEncoder { public: explicit HuffmanEncoder(OutputBitStream& obs) : DeviceEntropyEncoder(obs, KNZ_E_HUFFMAN) {} };
+class HuffmanDecoder : public DeviceEntropyDecoder { public: explicit HuffmanDecoder(InputBitStream& ibs) : DeviceEntropyDecoder(ibs, KNZ_E_HUFFMAN) {} };
+class FPAQEncoder : public DeviceEntropyEncoder { public: explicit FPAQEncoder(OutputBitStream& obs) : DeviceEntropyEncoder(obs, KNZ_E_FPAQ) {} };
+class FPAQDecoder : public DeviceEntropyDecoder { public: explicit FPAQDecoder(InputBitStream& ibs) : DeviceEntropyDecoder(ibs, KNZ_E_FPAQ) {} };
+class NullEntropyEncoder : public DeviceEntropyEncoder { public: explicit NullEntropyEncoder(OutputBitStream& obs) : DeviceEntropyEncoder(obs, KNZ_E_NONE) {} };
+class NullEntropyDecoder : public DeviceEntropyDecoder { public: explicit NullEntropyDecoder(InputBitStream& ibs) : DeviceEntropyDecoder(ibs, KNZ_E_NONE) {} };
+
+class EntropyEncoderFactory {
+public:
+    static const short NONE_TYPE = 0, HUFFMAN_TYPE = 1, FPAQ_TYPE = 2, PAQ_TYPE = 3, RANGE_TYPE = 4, ANS0_TYPE = 5, CM_TYPE = 6,
+                       TPAQ_TYPE = 7, ANS1_TYPE = 8, TPAQX_TYPE = 9;
+    static EntropyEncoder* newEncoder(OutputBitStream& obs, Context& ctx, short entropyType);
+    static const char* getName(short entropyType);
+    static short getType(const char* name);
+};
+
+class EntropyDecoderFactory {
+public:
+    static EntropyDecoder* newDecoder(InputBitStream& ibs, Context& ctx, short entropyType);
+    static const char* getName(short entropyType) { return EntropyEncoderFactory::getName(entropyType); }
+    static short getType(const char* name) { return EntropyEncoderFactory::getType(name); }
+};
+
+// ---- block framing ------------------------------------------------------------------------------
+class CompressedOutputStream : public std::ostream {
+public:
+    CompressedOutputStream(std::ostream& os, int jobs = 1, const std::string& entropy = "NONE", const std::string& transform = "NONE",
+                           int blockSize = 4 * 1024 * 1024, int checksum = 0, uint64 originalSize = 0, bool headerless = false);
+    ~CompressedOutputStream();
+    std::ostream& write(const char* s, std::streamsize n);
+    std::ostream& put(char c);
+    void close();
+    uint64 getWritten() const { return _written; }
+    // number of blocks handed to the device per call (default: jobs, like the reference keeps `jobs` blocks in flight)
+    void setBatchBlocks(int n) { if (n > 0) _batchBlocks = n; }
+private:
+    std::ostream& _os;
+    int _jobs, _blockSize, _checksum;
+    short _entropyType;
+    uint64 _transformType;
+    uint64 _inputSize;
+    bool _headless, _closed, _headerDone;
+    int _batchBlocks;
+    int64 _blockId;               // blocks submitted so far
+    std::vector<byte> _buffer;    // pending uncompressed bytes
+    byte _pendingByte;            // partial last byte of the stream written so far
+    uint _pendingBits;
+    uint64 _written;              // bytes that reached the sink
+    void* _dIn; size_t _dInCap; void* _dOut; size_t _dOutCap;
+    std::vector<byte> _host;
+    void submit(bool last);
+};
+
+class CompressedInputStream : public std::istream {
+public:
+    CompressedInputStream(std::istream& is, int jobs = 1, const std::string& entropy = "NONE", const std::string& transform = "NONE",
+                          int blockSize = 4 * 1024 * 1024, int checksum = 0, uint64 originalSize = 0, bool headerless = false,
+                          int bsVersion = 6);
+    ~CompressedInputStream();
+    std::istream& read(char* s, std::streamsize n);
+    int get();
+    int peek();
+    std::streamsize gcount() const { return _gcount; }
+    void close();
+    uint64 getRead() const { return (_consumedBits + 7) >> 3; }
+    void setBatchBlocks(int n) { if (n > 0) _batchBlocks = n; }
+private:
+    std::istream& _is;
+    int _jobs, _blockSize, _checksum;
+    short _entropyType;
+    uint64 _transformType;
+    uint64 _outputSize;
+    bool _headless, _closed, _headerDone, _ended;
+    int _batchBlocks;
+    std::vector<byte> _comp;      // compressed bytes fetched and not yet decoded
+    uint64 _compBit;              // next unread bit in _comp
+    uint64 _consumedBits;
+    std::vector<byte> _plain;     // decoded bytes not yet delivered
+    size_t _plainPos;
+    std::streamsize _gcount;
+    bool _srcEof;
+    void* _dIn; size_t _dInCap; void* _dOut; size_t _dOutCap;
+    void readHeader();
+    bool fetch(size_t minBytes);
+    bool decodeBatch();
+};
+
+}  // namespace kanzi_amd
+#endif

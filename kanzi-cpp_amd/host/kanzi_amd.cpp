@@ -1,0 +1,1141 @@
+// Host side of the drop-in: the reference's block-pipeline interfaces (include/kanzi_amd.hpp) and
+// C API (include/kanzi_api.h) implemented over the device C ABI (include/knz_hip.h).
+// Host code only splits, stages and appends; every transform / entropy / framing bit comes from
+// the GPU. Reference semantics cited per function.
+#include "kanzi_amd.hpp"
+#include "kanzi_api.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <sstream>
+#include <sys/stat.h>
+
+namespace kanzi_amd {
+
+// ------------------------------------------------------------------------------------------------
+// device context
+// ------------------------------------------------------------------------------------------------
+static std::mutex g_devMutex;
+static std::map<int, knz_ctx*> g_ctx;
+static int g_defaultDevice = -1;
+
+void setDefaultDevice(int device) { std::lock_guard<std::mutex> l(g_devMutex); g_defaultDevice = device; }
+
+knz_ctx* deviceContext(int device)
+{
+    std::lock_guard<std::mutex> l(g_devMutex);
+    if (device < 0) {
+        if (g_defaultDevice < 0) {
+            const char* e = getenv("KNZ_DEVICE");
+            if (!e) e = getenv("LOCAL_RANK");
+            g_defaultDevice = e ? atoi(e) : 0;
+        }
+        device = g_defaultDevice;
+    }
+    auto it = g_ctx.find(device);
+    if (it != g_ctx.end()) return it->second;
+    knz_ctx* c = nullptr;
+    if (knz_hip_create(device, nullptr, &c) != 0 || c == nullptr)
+        throw IOException("No usable GPU: the kanzi_amd block pipeline has no CPU fallback", Error::ERR_CREATE_CODEC);
+    g_ctx[device] = c;
+    return c;
+}
+
+static void devCheck(knz_ctx* c, int rc, const char* what)
+{
+    if (rc == 0) return;
+    std::stringstream ss;
+    ss << what << ": " << knz_hip_last_error(c);
+    if (rc > 0) throw IOException(ss.str(), rc);
+    throw std::runtime_error(ss.str());
+}
+
+// ------------------------------------------------------------------------------------------------
+// bit streams
+// ------------------------------------------------------------------------------------------------
+DefaultOutputBitStream::DefaultOutputBitStream(std::ostream& os, uint bufferSize)
+    : _os(os), _current(0), _avail(64), _written(0), _closed(false)
+{
+    if (bufferSize < 1024) throw std::invalid_argument("Invalid buffer size (must be at least 1024)");
+    if (bufferSize > (1u << 29)) throw std::invalid_argument("Invalid buffer size (must be at most 536870912)");
+    if ((bufferSize & 7) != 0) throw std::invalid_argument("Invalid buffer size (must be a multiple of 8)");
+    _buf.reserve(bufferSize);
+}
+
+DefaultOutputBitStream::~DefaultOutputBitStream() { try { close(); } catch (...) {} }
+
+void DefaultOutputBitStream::flush()
+{
+    if (!_buf.empty()) {
+        _os.write(reinterpret_cast<const char*>(_buf.data()), std::streamsize(_buf.size()));
+        if (_os.fail()) throw BitStreamException("Write to bitstream failed", BitStreamException::INPUT_OUTPUT);
+        _buf.clear();
+    }
+}
+
+void DefaultOutputBitStream::push()
+{
+    for (int s = 56; s >= 0; s -= 8) _buf.push_back(byte(_current >> s));
+    _current = 0;
+    _avail = 64;
+    if (_buf.size() + 8 >= _buf.capacity()) flush();
+}
+
+void DefaultOutputBitStream::writeBit(int bit)
+{
+    if (_closed) throw BitStreamException("Stream closed", BitStreamException::STREAM_CLOSED);
+    _avail--;
+    _current |= (uint64(bit & 1) << _avail);
+    _written++;
+    if (_avail == 0) push();
+}
+
+uint DefaultOutputBitStream::writeBits(uint64 value, uint count)
+{
+    if ((count == 0) || (count > 64)) return 0;
+    if (_closed) throw BitStreamException("Stream closed", BitStreamException::STREAM_CLOSED);
+    if (count < 64) value &= ((uint64(1) << count) - 1);
+    _written += count;
+    if (count < _avail) {
+        _avail -= count;
+        _current |= (value << _avail);
+    } else {
+        const uint remaining = count - _avail;
+        _current |= (remaining == 64 ? 0 : (value >> remaining));
+        push();
+        if (remaining != 0) {
+            _avail -= remaining;
+            _current = value << _avail;
+        }
+    }
+    return count;
+}
+
+uint DefaultOutputBitStream::writeBits(const byte bits[], uint count)
+{
+    if (_closed) throw BitStreamException("Stream closed", BitStreamException::STREAM_CLOSED);
+    uint remaining = count, start = 0;
+    if ((_avail & 7) == 0) {
+        // byte aligned: drain the accumulator and append whole bytes directly
+        while ((_avail != 64) && (remaining >= 8)) { writeBits(uint64(bits[start]), 8); start++; remaining -= 8; }
+        const uint r = remaining >> 3;
+        if (_avail == 64 && r > 0) {
+            flush();
+            _os.write(reinterpret_cast<const char*>(&bits[start]), std::streamsize(r));
+            if (_os.fail()) throw BitStreamException("Write to bitstream failed", BitStreamException::INPUT_OUTPUT);
+            _written += uint64(r) << 3;
+            start += r;
+            remaining -= (r << 3);
+        }
+    }
+    while (remaining >= 8) { writeBits(uint64(bits[start]), 8); start++; remaining -= 8; }
+    if (remaining > 0) writeBits(uint64(bits[start]) >> (8 - remaining), remaining);
+    return count;
+}
+
+void DefaultOutputBitStream::close()
+{
+    if (_closed) return;
+    // push the last bytes; the very last one may be incomplete (zero padded), written() stays exact
+    for (int s = 56; _avail < 64; s -= 8, _avail += 8) _buf.push_back(byte(_current >> s));
+    _avail = 64;
+    _current = 0;
+    flush();
+    _os.flush();
+    _closed = true;
+}
+
+DefaultInputBitStream::DefaultInputBitStream(std::istream& is, uint bufferSize)
+    : _is(is), _pos(0), _read(0), _closed(false), _eof(false), _chunk(bufferSize)
+{
+    if (bufferSize < 1024) throw std::invalid_argument("Invalid buffer size (must be at least 1024)");
+    if ((bufferSize & 7) != 0) throw std::invalid_argument("Invalid buffer size (must be a multiple of 8)");
+}
+
+DefaultInputBitStream::~DefaultInputBitStream() {}
+
+bool DefaultInputBitStream::fill(uint64 needBits)
+{
+    while (!_eof && uint64(_data.size()) * 8 < _pos + needBits) {
+        // drop fully consumed bytes from the front now and then
+        if (_pos >= (uint64(1) << 26)) { const size_t drop = size_t(_pos >> 3); _data.erase(_data.begin(), _data.begin() + drop); _pos &= 7; }
+        const size_t old = _data.size();
+        _data.resize(old + _chunk);
+        _is.read(reinterpret_cast<char*>(&_data[old]), std::streamsize(_chunk));
+        const size_t got = size_t(_is.gcount());
+        _data.resize(old + got);
+        if (got < _chunk) _eof = true;
+    }
+    return uint64(_data.size()) * 8 >= _pos + needBits;
+}
+
+int DefaultInputBitStream::readBit() { return int(readBits(1)); }
+
+uint64 DefaultInputBitStream::readBits(uint count)
+{
+    if (_closed) throw BitStreamException("Stream closed", BitStreamException::STREAM_CLOSED);
+    if ((count == 0) || (count > 64)) throw BitStreamException("Invalid bit count", BitStreamException::INVALID_STREAM);
+    if (!fill(count)) throw BitStreamException("No more data to read in the bitstream", BitStreamException::END_OF_STREAM);
+    uint64 v = 0;
+    uint left = count;
+    while (left > 0) {
+        const size_t b = size_t(_pos >> 3);
+        const uint used = uint(_pos & 7), room = 8 - used;
+        const uint take = left < room ? left : room;
+        v = (v << take) | ((_data[b] >> (room - take)) & ((1u << take) - 1u));
+        _pos += take;
+        left -= take;
+    }
+    _read += count;
+    return v;
+}
+
+uint DefaultInputBitStream::readBits(byte bits[], uint count)
+{
+    uint remaining = count, start = 0;
+    while (remaining >= 8) { bits[start++] = byte(readBits(8)); remaining -= 8; }
+    if (remaining > 0) bits[start] = byte(readBits(remaining) << (8 - remaining));
+    return count;
+}
+
+void DefaultInputBitStream::close() { _closed = true; }
+
+bool DefaultInputBitStream::hasMoreToRead() { return !_closed && fill(1); }
+
+void DefaultInputBitStream::peekRemaining(const byte** data, uint64* startBit, uint64* endBit)
+{
+    while (!_eof) fill((uint64(_data.size()) * 8 - _pos) + uint64(_chunk) * 8);
+    *data = _data.data();
+    *startBit = _pos;
+    *endBit = uint64(_data.size()) * 8;
+}
+
+void DefaultInputBitStream::skip(uint64 nbits)
+{
+    if (!fill(nbits)) throw BitStreamException("No more data to read in the bitstream", BitStreamException::END_OF_STREAM);
+    _pos += nbits;
+    _read += nbits;
+}
+
+// ------------------------------------------------------------------------------------------------
+// transforms
+// ------------------------------------------------------------------------------------------------
+static int entropyIdFromName(const std::string& nm)
+{
+    std::string s = nm;
+    std::transform(s.begin(), s.end(), s.begin(), ::toupper);
+    if (s == "NONE") return 0; if (s == "HUFFMAN") return 1; if (s == "FPAQ") return 2; if (s == "RANGE") return 4;
+    if (s == "ANS0") return 5; if (s == "CM") return 6; if (s == "TPAQ") return 7; if (s == "ANS1") return 8; if (s == "TPAQX") return 9;
+    return -1;
+}
+
+DeviceTransform::DeviceTransform(int type, Context* ctx) : _type(type), _entropy(-1)
+{
+    if (ctx != nullptr && ctx->has("entropy")) _entropy = entropyIdFromName(ctx->getString("entropy"));
+    deviceContext();        // fail early (and loudly) when there is no GPU
+}
+
+int DeviceTransform::getMaxEncodedLength(int n) const
+{
+    switch (_type) {
+    case KNZ_T_BWT: return n + 33;                      // BWTBlockCodec.hpp:47-50
+    case KNZ_T_SRT: return n + 1024;                    // SRT.hpp:38
+    case KNZ_T_RLT: return (n <= 512) ? n + 32 : n;     // RLT.hpp:43
+    default: return n;
+    }
+}
+
+bool DeviceTransform::forward(SliceArray<byte>& src, SliceArray<byte>& dst, int length)
+{
+    if (length == 0) return true;
+    if (!SliceArray<byte>::isValid(src)) throw std::invalid_argument("Invalid input block");
+    if (!SliceArray<byte>::isValid(dst)) throw std::invalid_argument("Invalid output block");
+    if ((length < 0) || (length > src._length - src._index)) return false;
+    if (src._array == dst._array) return false;
+    knz_ctx* c = deviceContext();
+    int32_t outLen = 0, ok = 0;
+    devCheck(c, knz_hip_transform_forward(c, _type, src._array + src._index, length, dst._array + dst._index,
+                                          dst._length - dst._index, _entropy, &outLen, &ok), "transform forward");
+    if (!ok) return false;
+    src._index += length;
+    dst._index += outLen;
+    return true;
+}
+
+bool DeviceTransform::inverse(SliceArray<byte>& src, SliceArray<byte>& dst, int length)
+{
+    if (length == 0) return true;
+    if (!SliceArray<byte>::isValid(src)) throw std::invalid_argument("Invalid input block");
+    if (!SliceArray<byte>::isValid(dst)) throw std::invalid_argument("Invalid output block");
+    if ((length < 0) || (length > src._length - src._index)) return false;
+    if (src._array == dst._array) return false;
+    knz_ctx* c = deviceContext();
+    int32_t outLen = 0, ok = 0;
+    devCheck(c, knz_hip_transform_inverse(c, _type, src._array + src._index, length, dst._array + dst._index,
+                                          dst._length - dst._index, &outLen, &ok), "transform inverse");
+    if (!ok) return false;
+    src._index += length;
+    dst._index += outLen;
+    return true;
+}
+
+SBRT::SBRT(int mode) : DeviceTransform(KNZ_T_MTFT, nullptr)
+{
+    if ((mode != MODE_MTF) && (mode != MODE_RANK) && (mode != MODE_TIMESTAMP)) throw std::invalid_argument("Invalid mode parameter");
+    if (mode != MODE_MTF) throw std::invalid_argument("SBRT: only MODE_MTF has a device kernel (RANK/TIMESTAMP are out of scope)");
+}
+
+SBRT::SBRT(int mode, Context& ctx) : DeviceTransform(KNZ_T_MTFT, &ctx)
+{
+    if ((mode != MODE_MTF) && (mode != MODE_RANK) && (mode != MODE_TIMESTAMP)) throw std::invalid_argument("Invalid mode parameter");
+    if (mode != MODE_MTF) throw std::invalid_argument("SBRT: only MODE_MTF has a device kernel (RANK/TIMESTAMP are out of scope)");
+}
+
+bool NullTransform::doCopy(SliceArray<byte>& input, SliceArray<byte>& output, int length) const
+{
+    if (length == 0) return true;
+    if (!SliceArray<byte>::isValid(input)) throw std::invalid_argument("Invalid input block");
+    if (!SliceArray<byte>::isValid(output)) throw std::invalid_argument("Invalid output block");
+    if (input._index + length > input._length) return false;
+    if (output._index + length > output._length) return false;
+    memmove(&output._array[output._index], &input._array[input._index], size_t(length));
+    input._index += length;
+    output._index += length;
+    return true;
+}
+
+// ---- TransformSequence (transform/TransformSequence.hpp:58-265) ---------------------------------
+template <class T>
+TransformSequence<T>::TransformSequence(Transform<T>* transforms[8], bool deallocate)
+{
+    _deallocate = deallocate;
+    _length = 8;
+    _skipFlags = 0;
+    for (int i = 7; i >= 0; i--) {
+        _transforms[i] = transforms[i];
+        if (_transforms[i] == nullptr) _length = i;
+    }
+    if (_length == 0) throw std::invalid_argument("At least one transform required");
+}
+
+template <class T>
+TransformSequence<T>::~TransformSequence()
+{
+    if (_deallocate) for (int i = 0; i < 8; i++) delete _transforms[i];
+}
+
+template <class T>
+int TransformSequence<T>::getMaxEncodedLength(int srcLength) const
+{
+    int req = srcLength;
+    for (int i = 0; i < _length; i++) {
+        if (_transforms[i] == nullptr) continue;
+        const int nx = _transforms[i]->getMaxEncodedLength(req);
+        if (nx > req) req = nx;
+    }
+    return req;
+}
+
+template <class T>
+bool TransformSequence<T>::forward(SliceArray<T>& input, SliceArray<T>& output, int count)
+{
+    if (!SliceArray<T>::isValid(input)) throw std::invalid_argument("Invalid input block");
+    if (!SliceArray<T>::isValid(output)) throw std::invalid_argument("Invalid output block");
+    if ((count < 0) || (count > input._length - input._index)) return false;
+    _skipFlags = 0xFF;
+    if (count == 0) return true;
+    const int blockSize = count;
+    const int requiredSize = getMaxEncodedLength(blockSize);
+    std::vector<T> scratch;
+    SliceArray<T> buffer(nullptr, 0, 0);
+    SliceArray<T>* in = &input;
+    SliceArray<T>* out = &output;
+    int swaps = 0;
+    for (int i = 0; i < _length; i++) {
+        if (_transforms[i] == nullptr) continue;
+        if (out->_length < requiredSize) {
+            if ((out == &input) || (out == &output)) out = &buffer;
+            if (out->_length < requiredSize) { scratch.resize(size_t(requiredSize)); out->_array = scratch.data(); out->_length = requiredSize; }
+        }
+        const int savedIIdx = in->_index, savedOIdx = out->_index;
+        if (_transforms[i]->forward(*in, *out, count) == false) {
+            in->_index = savedIIdx;
+            out->_index = savedOIdx;
+            continue;
+        }
+        _skipFlags &= byte(~(1 << (7 - i)));
+        count = out->_index - savedOIdx;
+        in->_index = savedIIdx;
+        out->_index = savedOIdx;
+        std::swap(in, out);
+        swaps++;
+    }
+    if ((swaps & 1) == 0) {
+        if ((count > output._length - output._index) || (count > in->_length - in->_index)) _skipFlags = 0xFF;
+        else memmove(&output._array[output._index], &in->_array[in->_index], size_t(count));
+    }
+    input._index += blockSize;
+    output._index += count;
+    return _skipFlags != 0xFF;
+}
+
+template <class T>
+bool TransformSequence<T>::inverse(SliceArray<T>& input, SliceArray<T>& output, int count)
+{
+    if (!SliceArray<T>::isValid(input)) throw std::invalid_argument("Invalid input block");
+    if (!SliceArray<T>::isValid(output)) throw std::invalid_argument("Invalid output block");
+    if ((count < 0) || (count > input._length - input._index)) return false;
+    if (count == 0) return true;
+    if (count > output._length - output._index) return false;
+    if (_skipFlags == 0xFF) {
+        memmove(&output._array[output._index], &input._array[input._index], size_t(count));
+        input._index += count;
+        output._index += count;
+        return true;
+    }
+    const int blockSize = count;
+    bool res = true;
+    std::vector<T> scratch;
+    SliceArray<T> buffer(nullptr, 0, 0);
+    SliceArray<T>* in = &input;
+    SliceArray<T>* out = &output;
+    int swaps = 0;
+    for (int i = _length - 1; i >= 0; i--) {
+        if ((_skipFlags & byte(1 << (7 - i))) != 0) continue;
+        if (_transforms[i] == nullptr) continue;
+        if (out->_length < output._length) {
+            if ((out == &input) || (out == &output)) out = &buffer;
+            if (out->_length < output._length) { scratch.resize(size_t(output._length)); out->_array = scratch.data(); out->_length = output._length; }
+        }
+        const int savedIIdx = in->_index, savedOIdx = out->_index;
+        res = _transforms[i]->inverse(*in, *out, count);
+        if (!res) break;
+        count = out->_index - savedOIdx;
+        in->_index = savedIIdx;
+        out->_index = savedOIdx;
+        std::swap(in, out);
+        swaps++;
+    }
+    if (res && ((swaps & 1) == 0)) {
+        if ((count > output._length - output._index) || (count > in->_length - in->_index)) res = false;
+        else memmove(&output._array[output._index], &in->_array[in->_index], size_t(count));
+    }
+    input._index += blockSize;
+    output._index += count;
+    return res;
+}
+
+template class TransformSequence<byte>;
+
+// ---- TransformFactory (transform/TransformFactory.hpp:100-308) ----------------------------------
+static const struct { const char* name; int type; } TNAMES[] = {
+    {"NONE", 0}, {"BWT", 1}, {"BWTS", 2}, {"LZ", 3}, {"RLT", 5}, {"ZRLT", 6}, {"MTFT", 7}, {"RANK", 8}, {"EXE", 9}, {"TEXT", 10},
+    {"ROLZ", 11}, {"ROLZX", 12}, {"SRT", 13}, {"LZP", 14}, {"MM", 15}, {"LZX", 16}, {"UTF", 17}, {"PACK", 18}, {"DNA", 19} };
+
+template <class T>
+uint64 TransformFactory<T>::getTypeToken(const char* tName)
+{
+    std::string name(tName);
+    std::transform(name.begin(), name.end(), name.begin(), ::toupper);
+    for (auto& e : TNAMES) if (name == e.name) return uint64(e.type);
+    throw std::invalid_argument("Unknown transform type: '" + name + "'");
+}
+
+template <class T>
+uint64 TransformFactory<T>::getType(const char* tName)
+{
+    std::string name(tName);
+    size_t pos = name.find('+');
+    if (pos == std::string::npos) return getTypeToken(name.c_str()) << MAX_SHIFT;
+    size_t prv = 0;
+    int n = 0;
+    uint64 res = 0;
+    int shift = MAX_SHIFT;
+    name += '+';
+    while (pos != std::string::npos) {
+        if (++n > 8) throw std::invalid_argument("Only 8 transforms allowed: " + name);
+        const std::string token = name.substr(prv, pos - prv);
+        const uint64 typeTk = getTypeToken(token.c_str());
+        if (typeTk != NONE_TYPE) { res |= (typeTk << shift); shift -= ONE_SHIFT; }
+        prv = pos + 1;
+        pos = name.find('+', prv);
+    }
+    return res;
+}
+
+template <class T>
+std::string TransformFactory<T>::getName(uint64 functionType)
+{
+    std::string res;
+    for (int i = 0; i < 8; i++) {
+        const uint64 t = (functionType >> (MAX_SHIFT - ONE_SHIFT * i)) & MASK;
+        if (t == NONE_TYPE) continue;
+        const char* nm = nullptr;
+        for (auto& e : TNAMES) if (uint64(e.type) == t) nm = e.name;
+        if (nm == nullptr) throw std::invalid_argument("Unknown transform type");
+        if (!res.empty()) res += '+';
+        res += nm;
+    }
+    return res.empty() ? std::string("NONE") : res;
+}
+
+template <class T>
+TransformSequence<T>* TransformFactory<T>::newTransform(Context& ctx, uint64 functionType)
+{
+    Transform<T>* transforms[8];
+    int nbtr = 0;
+    for (int i = 0; i < 8; i++) transforms[i] = nullptr;
+    try {
+        for (int i = 0; i < 8; i++) {
+            const uint64 t = (functionType >> (MAX_SHIFT - ONE_SHIFT * i)) & MASK;
+            if ((t == NONE_TYPE) && (i != 0)) continue;
+            switch (int(t)) {
+            case NONE_TYPE: transforms[nbtr++] = new NullTransform(ctx); break;
+            case BWT_TYPE: transforms[nbtr++] = new BWTBlockCodec(ctx); break;
+            case MTFT_TYPE: transforms[nbtr++] = new SBRT(SBRT::MODE_MTF, ctx); break;
+            case SRT_TYPE: transforms[nbtr++] = new SRT(ctx); break;
+            case ZRLT_TYPE: transforms[nbtr++] = new ZRLT(ctx); break;
+            case RLT_TYPE: transforms[nbtr++] = new RLT(ctx); break;
+            default: {
+                std::stringstream ss;
+                ss << "Transform type " << t << " has no device kernel (out of scope of the accelerated block pipeline)";
+                throw std::invalid_argument(ss.str());
+            }
+            }
+        }
+    } catch (...) {
+        for (int i = 0; i < 8; i++) delete transforms[i];
+        throw;
+    }
+    return new TransformSequence<T>(transforms, true);
+}
+
+template class TransformFactory<byte>;
+
+// ------------------------------------------------------------------------------------------------
+// entropy codecs
+// ------------------------------------------------------------------------------------------------
+int DeviceEntropyEncoder::encode(const byte block[], uint blkptr, uint len)
+{
+    if (len == 0) return 0;
+    knz_ctx* c = deviceContext();
+    knz_params p;
+    memset(&p, 0, sizeof(p));
+    p.entropy_type = _type;
+    p.block_size = int32_t((len + 15) & ~15u);
+    const size_t cap = knz_hip_encode_bound(&p, len) + 64;
+    std::vector<byte> out(cap);
+    uint64_t bits = 0;
+    devCheck(c, knz_hip_entropy_encode(c, _type, &block[blkptr], len, out.data(), cap, &bits), "entropy encode");
+    uint64 done = 0;
+    while (done < bits) {
+        const uint64 chunk = std::min<uint64>(bits - done, uint64(1) << 30);   // multiple of 8 except for the last piece
+        _obs.writeBits(&out[size_t(done >> 3)], uint(chunk));
+        done += chunk;
+    }
+    return int(len);
+}
+
+int DeviceEntropyDecoder::decode(byte block[], uint blkptr, uint len)
+{
+    if (len == 0) return 0;
+    knz_ctx* c = deviceContext();
+    int32_t decoded = 0;
+    uint64_t used = 0;
+    DefaultInputBitStream* dibs = dynamic_cast<DefaultInputBitStream*>(&_ibs);
+    if (dibs != nullptr) {
+        const byte* data; uint64 startBit, endBit;
+        dibs->peekRemaining(&data, &startBit, &endBit);
+        devCheck(c, knz_hip_entropy_decode(c, _type, data, endBit, startBit, &block[blkptr], len, &decoded, &used), "entropy decode");
+        if (decoded == int32_t(len)) dibs->skip(used);
+        return int(decoded);
+    }
+    // generic InputBitStream: the device needs the bits in one buffer, so the rest of the stream is drained
+    std::vector<byte> rest;
+    try { while (_ibs.hasMoreToRead()) rest.push_back(byte(_ibs.readBits(8))); } catch (const BitStreamException&) {}
+    devCheck(c, knz_hip_entropy_decode(c, _type, rest.data(), uint64(rest.size()) * 8, 0, &block[blkptr], len, &decoded, &used), "entropy decode");
+    return int(decoded);
+}
+
+ANSRangeEncoder::ANSRangeEncoder(OutputBitStream& obs, int order) : DeviceEntropyEncoder(obs, KNZ_E_ANS0)
+{
+    if ((order != 0) && (order != 1)) throw std::invalid_argument("ANS Codec: The order must be 0 or 1");
+    if (order == 1) throw std::invalid_argument("ANS Codec: order 1 has no device kernel yet (stretch row of the scope table)");
+}
+
+ANSRangeDecoder::ANSRangeDecoder(InputBitStream& ibs, int order) : DeviceEntropyDecoder(ibs, KNZ_E_ANS0)
+{
+    if ((order != 0) && (order != 1)) throw std::invalid_argument("ANS Codec: The order must be 0 or 1");
+    if (order == 1) throw std::invalid_argument("ANS Codec: order 1 has no device kernel yet (stretch row of the scope table)");
+}
+
+static const struct { const char* name; short type; } ENAMES[] = {
+    {"NONE", 0}, {"HUFFMAN", 1}, {"FPAQ", 2}, {"RANGE", 4}, {"ANS0", 5}, {"CM", 6}, {"TPAQ", 7}, {"ANS1", 8}, {"TPAQX", 9} };
+
+const char* EntropyEncoderFactory::getName(short entropyType)
+{
+    for (auto& e : ENAMES) if (e.type == entropyType) return e.name;
+    throw std::invalid_argument("Unknown entropy codec type");
+}
+
+short EntropyEncoderFactory::getType(const char* str)
+{
+    std::string name(str);
+    std::transform(name.begin(), name.end(), name.begin(), ::toupper);
+    for (auto& e : ENAMES) if (name == e.name) return e.type;
+    throw std::invalid_argument("Unsupported entropy codec type: '" + name + "'");
+}
+
+EntropyEncoder* EntropyEncoderFactory::newEncoder(OutputBitStream& obs, Context&, short entropyType)
+{
+    switch (entropyType) {
+    case HUFFMAN_TYPE: return new HuffmanEncoder(obs);
+    case ANS0_TYPE: return new ANSRangeEncoder(obs, 0);
+    case FPAQ_TYPE: return new FPAQEncoder(obs);
+    case NONE_TYPE: return new NullEntropyEncoder(obs);
+    default: throw std::invalid_argument(std::string("Entropy codec '") + getName(entropyType) + "' has no device kernel");
+    }
+}
+
+EntropyDecoder* EntropyDecoderFactory::newDecoder(InputBitStream& ibs, Context&, short entropyType)
+{
+    switch (entropyType) {
+    case EntropyEncoderFactory::HUFFMAN_TYPE: return new HuffmanDecoder(ibs);
+    case EntropyEncoderFactory::ANS0_TYPE: return new ANSRangeDecoder(ibs, 0);
+    case EntropyEncoderFactory::FPAQ_TYPE: return new FPAQDecoder(ibs);
+    case EntropyEncoderFactory::NONE_TYPE: return new NullEntropyDecoder(ibs);
+    default: throw std::invalid_argument(std::string("Entropy codec '") + getName(entropyType) + "' has no device kernel");
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stream header (io/CompressedOutputStream.cpp:277-342, io/CompressedInputStream.cpp:511-663)
+// ------------------------------------------------------------------------------------------------
+static uint32_t headerChecksum(uint32_t ckSize, uint32_t etype, uint64 ttype, uint32_t blockSize, int szMask, uint64 size)
+{
+    const uint32_t HASH = 0x1E35A7BDu;
+    uint32_t c = HASH * (0x01030507u * 6u);
+    c ^= HASH * uint32_t(~ckSize);
+    c ^= HASH * uint32_t(~etype);
+    c ^= HASH * uint32_t((~ttype) >> 32);
+    c ^= HASH * uint32_t(~ttype);
+    c ^= HASH * uint32_t(~blockSize);
+    if (szMask != 0) { c ^= HASH * uint32_t((~size) >> 32); c ^= HASH * uint32_t(~size); }
+    return ((c >> 23) ^ (c >> 3)) & 0xFFFFFFu;
+}
+
+struct BitPacker {
+    std::vector<byte> bytes; uint64 nbits = 0;
+    void put(uint64 v, uint n) { for (int i = int(n) - 1; i >= 0; i--) { if ((nbits & 7) == 0) bytes.push_back(0); bytes.back() |= byte(((v >> i) & 1) << (7 - (nbits & 7))); nbits++; } }
+};
+
+static uint64 getBitsAt(const std::vector<byte>& d, uint64 pos, uint n)
+{
+    uint64 v = 0;
+    for (uint i = 0; i < n; i++, pos++) v = (v << 1) | ((d[size_t(pos >> 3)] >> (7 - (pos & 7))) & 1);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// CompressedOutputStream
+// ------------------------------------------------------------------------------------------------
+CompressedOutputStream::CompressedOutputStream(std::ostream& os, int tasks, const std::string& entropy, const std::string& transform,
+                                               int blockSize, int checksum, uint64 fileSize, bool headerless)
+    : std::ostream(os.rdbuf()), _os(os)
+{
+    if ((tasks <= 0) || (tasks > 64)) throw std::invalid_argument("The number of jobs must be in [1..64]");
+    if (blockSize > 1024 * 1024 * 1024) throw std::invalid_argument("The block size must be at most 1024 MB");
+    if (blockSize < 1024) throw std::invalid_argument("The block size must be at least 1024");
+    if ((blockSize & -16) != blockSize) throw std::invalid_argument("The block size must be a multiple of 16");
+    if ((checksum != 0) && (checksum != 32) && (checksum != 64)) throw std::invalid_argument("The block checksum size must be 0, 32 or 64");
+    if (checksum != 0) throw std::invalid_argument("Block checksums have no device kernel yet");
+    _jobs = tasks; _blockSize = blockSize; _checksum = checksum;
+    _entropyType = EntropyEncoderFactory::getType(entropy.c_str());
+    _transformType = TransformFactory<byte>::getType(transform.c_str());
+    _inputSize = fileSize;
+    _headless = headerless; _closed = false; _headerDone = false;
+    _batchBlocks = tasks;
+    const char* e = getenv("KNZ_BATCH_BLOCKS");
+    if (e && atoi(e) > 0) _batchBlocks = atoi(e);
+    _blockId = 0;
+    _pendingByte = 0; _pendingBits = 0; _written = 0;
+    _dIn = _dOut = nullptr; _dInCap = _dOutCap = 0;
+    deviceContext();
+}
+
+CompressedOutputStream::~CompressedOutputStream()
+{
+    try { close(); } catch (...) {}
+    knz_ctx* c = nullptr;
+    try { c = deviceContext(); } catch (...) {}
+    if (c) { if (_dIn) knz_hip_free(c, _dIn); if (_dOut) knz_hip_free(c, _dOut); }
+}
+
+std::ostream& CompressedOutputStream::write(const char* data, std::streamsize length)
+{
+    if (length < 0) throw IOException("Invalid buffer size");
+    if (_closed) throw IOException("Stream closed", Error::ERR_WRITE_FILE);
+    _buffer.insert(_buffer.end(), reinterpret_cast<const byte*>(data), reinterpret_cast<const byte*>(data) + length);
+    const size_t batchBytes = size_t(_batchBlocks) * size_t(_blockSize);
+    while (_buffer.size() >= batchBytes) submit(false);
+    return *this;
+}
+
+std::ostream& CompressedOutputStream::put(char c) { return write(&c, 1); }
+
+void CompressedOutputStream::submit(bool last)
+{
+    knz_ctx* c = deviceContext();
+    const size_t batchBytes = size_t(_batchBlocks) * size_t(_blockSize);
+    const size_t n = last ? _buffer.size() : batchBytes;
+    knz_params p;
+    memset(&p, 0, sizeof(p));
+    p.transform_type = _transformType; p.entropy_type = _entropyType; p.block_size = _blockSize; p.checksum_bits = _checksum; p.jobs = _jobs;
+    // prologue: the stream header before the first block, afterwards the pending bits of the last byte
+    BitPacker pro;
+    if (!_headerDone) {
+        if (!_headless) {
+            const uint32_t ckSize = _checksum == 32 ? 1 : (_checksum == 64 ? 2 : 0);
+            pro.put(0x4B414E5Au, 32); pro.put(6, 4); pro.put(ckSize, 2); pro.put(uint64(_entropyType), 5); pro.put(_transformType, 48);
+            pro.put(uint64(_blockSize >> 4), 28);
+            int szMask = 0;
+            if (_inputSize != 0 && _inputSize < (uint64(1) << 48)) { int lg = 63; while (!((_inputSize >> lg) & 1)) lg--; szMask = (lg >> 4) + 1; }
+            pro.put(uint64(szMask), 2);
+            if (szMask) pro.put(_inputSize, uint(16 * szMask));
+            pro.put(0, 15);
+            pro.put(headerChecksum(ckSize, uint32_t(_entropyType), _transformType, uint32_t(_blockSize), szMask, _inputSize), 24);
+        }
+        _headerDone = true;
+    } else if (_pendingBits) {
+        pro.put(uint64(_pendingByte >> (8 - _pendingBits)), _pendingBits);
+    }
+    const size_t cap = knz_hip_encode_bound(&p, n) + pro.bytes.size() + 256;
+    if (_dInCap < n + 64) { if (_dIn) knz_hip_free(c, _dIn); devCheck(c, knz_hip_malloc(c, n + 64 + (n >> 2), &_dIn), "malloc"); _dInCap = n + 64 + (n >> 2); }
+    if (_dOutCap < cap) { if (_dOut) knz_hip_free(c, _dOut); devCheck(c, knz_hip_malloc(c, cap + (cap >> 2), &_dOut), "malloc"); _dOutCap = cap + (cap >> 2); }
+    if (n) devCheck(c, knz_hip_memcpy_h2d(c, _dIn, _buffer.data(), n), "h2d");
+    uint64_t bits = 0;
+    devCheck(c, knz_hip_encode_blocks(c, &p, static_cast<const uint8_t*>(_dIn), n, pro.bytes.empty() ? nullptr : pro.bytes.data(), uint32_t(pro.nbits),
+                                      _blockId, last ? 1 : 0, static_cast<uint8_t*>(_dOut), _dOutCap, &bits), "encode blocks");
+    const size_t bytes = size_t((bits + 7) >> 3);
+    _host.resize(bytes + 8);
+    if (bytes) devCheck(c, knz_hip_memcpy_d2h(c, _host.data(), _dOut, bytes), "d2h");
+    const size_t full = size_t(bits >> 3);
+    const uint rem = uint(bits & 7);
+    size_t toWrite = full;
+    if (last && rem) toWrite = full + 1;          // close(): the last byte is zero padded
+    if (toWrite) {
+        _os.write(reinterpret_cast<const char*>(_host.data()), std::streamsize(toWrite));
+        if (_os.fail()) throw IOException("Write to bitstream failed", Error::ERR_WRITE_FILE);
+        _written += toWrite;
+    }
+    _pendingBits = last ? 0 : rem;
+    _pendingByte = (rem && !last) ? _host[full] : 0;
+    _blockId += int64((n + size_t(_blockSize) - 1) / size_t(_blockSize));
+    _buffer.erase(_buffer.begin(), _buffer.begin() + n);
+}
+
+void CompressedOutputStream::close()
+{
+    if (_closed) return;
+    _closed = true;
+    try {
+        submit(true);
+        _os.flush();
+    } catch (const std::exception& e) {
+        setstate(std::ios::badbit);
+        throw IOException(e.what(), Error::ERR_WRITE_FILE);
+    }
+    setstate(std::ios::eofbit);
+}
+
+// ------------------------------------------------------------------------------------------------
+// CompressedInputStream
+// ------------------------------------------------------------------------------------------------
+CompressedInputStream::CompressedInputStream(std::istream& is, int tasks, const std::string& entropy, const std::string& transform,
+                                             int blockSize, int checksum, uint64 originalSize, bool headerless, int bsVersion)
+    : std::istream(is.rdbuf()), _is(is)
+{
+    if ((tasks <= 0) || (tasks > 64)) throw std::invalid_argument("The number of jobs must be in [1..64]");
+    _jobs = tasks; _blockSize = blockSize; _checksum = checksum; _outputSize = originalSize;
+    _headless = headerless; _closed = false; _headerDone = false; _ended = false;
+    _entropyType = 0; _transformType = 0;
+    if (headerless) {
+        if (bsVersion != 6) throw std::invalid_argument("Only bitstream version 6 is supported");
+        if ((blockSize < 1024) || (blockSize > 1024 * 1024 * 1024) || ((blockSize & -16) != blockSize)) throw std::invalid_argument("Invalid block size");
+        _entropyType = EntropyEncoderFactory::getType(entropy.c_str());
+        _transformType = TransformFactory<byte>::getType(transform.c_str());
+    }
+    _batchBlocks = tasks;
+    const char* e = getenv("KNZ_BATCH_BLOCKS");
+    if (e && atoi(e) > 0) _batchBlocks = atoi(e);
+    _compBit = 0; _consumedBits = 0; _plainPos = 0; _gcount = 0; _srcEof = false;
+    _dIn = _dOut = nullptr; _dInCap = _dOutCap = 0;
+    deviceContext();
+}
+
+CompressedInputStream::~CompressedInputStream()
+{
+    knz_ctx* c = nullptr;
+    try { c = deviceContext(); } catch (...) {}
+    if (c) { if (_dIn) knz_hip_free(c, _dIn); if (_dOut) knz_hip_free(c, _dOut); }
+}
+
+bool CompressedInputStream::fetch(size_t minBytes)
+{
+    // make at least minBytes available after the current byte position
+    const size_t have = _comp.size() - size_t(_compBit >> 3);
+    if (have >= minBytes) return true;
+    if (_srcEof) return false;
+    if ((_compBit >> 3) > (size_t(1) << 24)) {   // drop consumed bytes, keep 16-byte alignment of the remainder
+        const size_t drop = size_t(_compBit >> 3) & ~size_t(15);
+        _comp.erase(_comp.begin(), _comp.begin() + drop);
+        _compBit -= uint64(drop) * 8;
+    }
+    size_t want = std::max<size_t>(minBytes - have, size_t(1) << 20);
+    const size_t old = _comp.size();
+    _comp.resize(old + want);
+    _is.read(reinterpret_cast<char*>(&_comp[old]), std::streamsize(want));
+    const size_t got = size_t(_is.gcount());
+    _comp.resize(old + got);
+    if (got < want) _srcEof = true;
+    return (_comp.size() - size_t(_compBit >> 3)) >= minBytes;
+}
+
+void CompressedInputStream::readHeader()
+{
+    if (_headerDone) return;
+    _headerDone = true;
+    if (_headless) return;
+    if (!fetch(20)) throw IOException("Invalid stream type", Error::ERR_INVALID_FILE);
+    fetch(24);
+    _comp.resize(_comp.size() + 8, 0);           // reading margin for getBitsAt
+    uint64 pos = _compBit;
+    auto get = [&](uint n) { const uint64 v = getBitsAt(_comp, pos, n); pos += n; return v; };
+    const bool enough24 = (_comp.size() - 8) >= 24;
+    if (uint32_t(get(32)) != 0x4B414E5Au) throw IOException("Invalid stream type", Error::ERR_INVALID_FILE);
+    const int bsVersion = int(get(4));
+    if (bsVersion > 6) throw IOException("Invalid bitstream, cannot read this version of the stream", Error::ERR_STREAM_VERSION);
+    if (bsVersion < 6) throw IOException("Bitstream versions below 6 are not supported by the device path", Error::ERR_STREAM_VERSION);
+    const uint64 ckSize = get(2);
+    if (ckSize == 3) throw IOException("Invalid bitstream, incorrect block checksum size", Error::ERR_INVALID_FILE);
+    _checksum = int(32 * ckSize);
+    _entropyType = short(get(5));
+    try { EntropyEncoderFactory::getName(_entropyType); } catch (const std::invalid_argument&) { throw IOException("Invalid bitstream, unknown entropy type", Error::ERR_INVALID_CODEC); }
+    _transformType = get(48);
+    try { TransformFactory<byte>::getName(_transformType); } catch (const std::invalid_argument&) { throw IOException("Invalid bitstream, unknown transform type", Error::ERR_INVALID_CODEC); }
+    _blockSize = int(get(28) << 4);
+    if ((_blockSize < 1024) || (_blockSize > 1024 * 1024 * 1024)) throw IOException("Invalid bitstream, incorrect block size", Error::ERR_BLOCK_SIZE);
+    const int szMask = int(get(2));
+    if (szMask != 0) { if (!enough24 && szMask > 1) throw IOException("Invalid stream type", Error::ERR_INVALID_FILE); _outputSize = get(uint(16 * szMask)); }
+    get(15);
+    const uint32_t ck1 = uint32_t(get(24));
+    if (ck1 != headerChecksum(uint32_t(ckSize), uint32_t(_entropyType), _transformType, uint32_t(_blockSize), szMask, _outputSize))
+        throw IOException("Invalid bitstream, header checksum mismatch", Error::ERR_CRC_CHECK);
+    _comp.resize(_comp.size() - 8);
+    _consumedBits += pos - _compBit;
+    _compBit = pos;
+    if (_checksum != 0) throw IOException("Block checksums have no device kernel yet", Error::ERR_INVALID_CODEC);
+}
+
+bool CompressedInputStream::decodeBatch()
+{
+    if (_ended) return false;
+    readHeader();
+    // walk the block length prefixes on the host (framing only) to find complete blocks
+    uint64 pos = _compBit;
+    int nb = 0;
+    bool sawEnd = false;
+    while (nb < _batchBlocks) {
+        if (!fetch(size_t(((pos + 40) >> 3) + 1 - (_compBit >> 3)))) {
+            if (uint64(_comp.size()) * 8 < pos + 8) { if (nb == 0) throw IOException("Unexpected end of stream", Error::ERR_READ_FILE); break; }
+        }
+        _comp.resize(_comp.size() + 8, 0);
+        const uint lr = 3 + uint(getBitsAt(_comp, pos, 5));
+        const uint64 len = getBitsAt(_comp, pos + 5, lr);
+        _comp.resize(_comp.size() - 8);
+        if (uint64(_comp.size()) * 8 < pos + 5 + lr) throw IOException("Unexpected end of stream", Error::ERR_READ_FILE);
+        if (len == 0) { sawEnd = true; pos += 5 + lr; break; }
+        if (len > (uint64(1) << 34)) throw IOException("Invalid block size", Error::ERR_BLOCK_SIZE);
+        const uint64 next = pos + 5 + lr + len;
+        if (!fetch(size_t(((next + 7) >> 3) - (_compBit >> 3)))) throw IOException("Unexpected end of stream", Error::ERR_READ_FILE);
+        pos = next;
+        nb++;
+    }
+    if (nb > 0) {
+        knz_ctx* c = deviceContext();
+        knz_params p;
+        memset(&p, 0, sizeof(p));
+        p.transform_type = _transformType; p.entropy_type = _entropyType; p.block_size = _blockSize; p.checksum_bits = _checksum; p.jobs = _jobs;
+        const size_t firstByte = size_t(_compBit >> 3) & ~size_t(15);
+        const size_t lastByte = size_t((pos + 7) >> 3);
+        const size_t inBytes = lastByte - firstByte;
+        const size_t outCap = size_t(nb) * size_t(_blockSize) + 64;
+        if (_dInCap < inBytes + 64) { if (_dIn) knz_hip_free(c, _dIn); devCheck(c, knz_hip_malloc(c, inBytes + 64 + (inBytes >> 2), &_dIn), "malloc"); _dInCap = inBytes + 64 + (inBytes >> 2); }
+        if (_dOutCap < outCap) { if (_dOut) knz_hip_free(c, _dOut); devCheck(c, knz_hip_malloc(c, outCap + (outCap >> 2), &_dOut), "malloc"); _dOutCap = outCap + (outCap >> 2); }
+        devCheck(c, knz_hip_memcpy_h2d(c, _dIn, &_comp[firstByte], inBytes), "h2d");
+        uint64_t outBytes = 0, endBit = 0;
+        int64_t done = 0;
+        const uint64 startBit = _compBit - uint64(firstByte) * 8;
+        devCheck(c, knz_hip_decode_blocks(c, &p, static_cast<const uint8_t*>(_dIn), uint64(inBytes) * 8, startBit, nb,
+                                          static_cast<uint8_t*>(_dOut), outCap, &outBytes, &endBit, &done), "decode blocks");
+        _plain.resize(size_t(outBytes));
+        _plainPos = 0;
+        if (outBytes) devCheck(c, knz_hip_memcpy_d2h(c, _plain.data(), _dOut, size_t(outBytes)), "d2h");
+    }
+    _consumedBits += pos - _compBit;
+    _compBit = pos;
+    if (sawEnd) _ended = true;
+    return nb > 0;
+}
+
+std::istream& CompressedInputStream::read(char* data, std::streamsize length)
+{
+    _gcount = 0;
+    if (_closed) throw IOException("Stream closed", Error::ERR_READ_FILE);
+    std::streamsize remaining = length;
+    while (remaining > 0) {
+        if (_plainPos >= _plain.size()) {
+            _plain.clear(); _plainPos = 0;
+            if (!decodeBatch()) { setstate(std::ios::eofbit); break; }
+            if (_plain.empty()) continue;
+        }
+        const size_t take = std::min<size_t>(size_t(remaining), _plain.size() - _plainPos);
+        memcpy(data + _gcount, &_plain[_plainPos], take);
+        _plainPos += take;
+        _gcount += std::streamsize(take);
+        remaining -= std::streamsize(take);
+    }
+    return *this;
+}
+
+int CompressedInputStream::peek()
+{
+    if (_plainPos >= _plain.size()) {
+        _plain.clear(); _plainPos = 0;
+        while (_plain.empty()) if (!decodeBatch()) { setstate(std::ios::eofbit); return EOF; }
+    }
+    return int(_plain[_plainPos]);
+}
+
+int CompressedInputStream::get()
+{
+    const int c = peek();
+    if (c != EOF) { _plainPos++; _gcount = 1; } else _gcount = 0;
+    return c;
+}
+
+void CompressedInputStream::close()
+{
+    if (_closed) return;
+    _closed = true;
+    setstate(std::ios::eofbit);
+}
+
+}  // namespace kanzi_amd
+
+// ================================================================================================
+// C API (src/api/Compressor.cpp:183-358, src/api/Decompressor.cpp:108-313)
+// ================================================================================================
+using namespace kanzi_amd;
+
+namespace {
+
+class FileOutBuf : public std::streambuf {
+public:
+    explicit FileOutBuf(FILE* f) : _f(f) {}
+protected:
+    std::streamsize xsputn(const char* s, std::streamsize n) override { return std::streamsize(fwrite(s, 1, size_t(n), _f)); }
+    int_type overflow(int_type ch) override { if (ch == traits_type::eof()) return traits_type::not_eof(ch); const char c = char(ch); return fwrite(&c, 1, 1, _f) == 1 ? ch : traits_type::eof(); }
+    int sync() override { return fflush(_f) == 0 ? 0 : -1; }
+private:
+    FILE* _f;
+};
+
+class FileInBuf : public std::streambuf {
+public:
+    explicit FileInBuf(FILE* f) : _f(f) {}
+protected:
+    std::streamsize xsgetn(char* s, std::streamsize n) override { return std::streamsize(fread(s, 1, size_t(n), _f)); }
+    int_type underflow() override { const size_t r = fread(&_c, 1, 1, _f); if (r != 1) return traits_type::eof(); setg(&_c, &_c, &_c + 1); return traits_type::to_int_type(_c); }
+private:
+    FILE* _f; char _c;
+};
+
+}  // namespace
+
+struct cContext {
+    CompressedOutputStream* pCos; FileOutBuf* buf; std::ostream* os; size_t blockSize;
+};
+
+struct dContext {
+    CompressedInputStream* pCis; FileInBuf* buf; std::istream* is; size_t bufferSize;
+};
+
+extern "C" {
+
+unsigned int getCompressorVersion(void) { return (1u << 16) | (0u << 8) | 0u; }
+unsigned int getDecompressorVersion(void) { return (1u << 16) | (0u << 8) | 0u; }
+
+int initCompressor(struct cData* pData, FILE* dst, struct cContext** pCtx)
+{
+    if ((pData == nullptr) || (pCtx == nullptr) || (dst == nullptr)) return Error::ERR_INVALID_PARAM;
+    cContext* cctx = nullptr;
+    try {
+        if ((memchr(pData->transform, 0, sizeof(pData->transform)) == nullptr) || (memchr(pData->entropy, 0, sizeof(pData->entropy)) == nullptr))
+            return Error::ERR_INVALID_PARAM;
+        const std::string transform = TransformFactory<byte>::getName(TransformFactory<byte>::getType(pData->transform));
+        const std::string entropy = EntropyEncoderFactory::getName(EntropyEncoderFactory::getType(pData->entropy));
+        if ((transform.length() >= sizeof(pData->transform)) || (entropy.length() >= sizeof(pData->entropy))) return Error::ERR_INVALID_PARAM;
+        memset(pData->transform, 0, sizeof(pData->transform));
+        strncpy(pData->transform, transform.c_str(), sizeof(pData->transform) - 1);
+        memset(pData->entropy, 0, sizeof(pData->entropy));
+        strncpy(pData->entropy, entropy.c_str(), sizeof(pData->entropy) - 1);
+        pData->blockSize = (pData->blockSize + 15) & size_t(-16);
+        *pCtx = nullptr;
+        size_t fileSize = 0;
+        const int fd = fileno(dst);
+        struct stat sbuf;
+        if (fd >= 0 && fstat(fd, &sbuf) == 0) fileSize = size_t(sbuf.st_size);
+        cctx = new cContext();
+        cctx->buf = new FileOutBuf(dst);
+        cctx->os = new std::ostream(cctx->buf);
+        cctx->pCos = nullptr;
+        cctx->pCos = new CompressedOutputStream(*cctx->os, int(pData->jobs), pData->entropy, pData->transform, int(pData->blockSize),
+                                                pData->checksum, uint64(fileSize), pData->headerless != 0);
+        cctx->blockSize = pData->blockSize;
+        *pCtx = cctx;
+    } catch (const std::exception&) {
+        if (cctx) { delete cctx->pCos; delete cctx->os; delete cctx->buf; delete cctx; }
+        return Error::ERR_CREATE_COMPRESSOR;
+    }
+    return 0;
+}
+
+int compress(struct cContext* pCtx, const unsigned char* src, size_t inSize, size_t* outSize)
+{
+    if ((pCtx == nullptr) || (outSize == nullptr)) return Error::ERR_INVALID_PARAM;
+    if ((src == nullptr) && (inSize != 0)) return Error::ERR_INVALID_PARAM;
+    if (inSize > pCtx->blockSize) return Error::ERR_INVALID_PARAM;
+    *outSize = 0;
+    CompressedOutputStream* pCos = pCtx->pCos;
+    if (pCos == nullptr) return Error::ERR_INVALID_PARAM;
+    try {
+        const uint64 w = pCos->getWritten();
+        pCos->write(reinterpret_cast<const char*>(src), std::streamsize(inSize));
+        *outSize = size_t(pCos->getWritten() - w);
+        return pCos->good() ? 0 : int(Error::ERR_WRITE_FILE);
+    } catch (const IOException& ioe) {
+        return ioe.error();
+    } catch (const std::exception&) {
+        return Error::ERR_UNKNOWN;
+    }
+}
+
+int disposeCompressor(struct cContext** ppCtx, size_t* outSize)
+{
+    if ((ppCtx == nullptr) || (*ppCtx == nullptr) || (outSize == nullptr)) return Error::ERR_INVALID_PARAM;
+    *outSize = 0;
+    cContext* pCtx = *ppCtx;
+    int res = 0;
+    try {
+        if (pCtx->pCos != nullptr) {
+            const uint64 w = pCtx->pCos->getWritten();
+            pCtx->pCos->close();
+            *outSize = size_t(pCtx->pCos->getWritten() - w);
+        }
+    } catch (const IOException& ioe) {
+        res = ioe.error();
+    } catch (const std::exception&) {
+        res = Error::ERR_UNKNOWN;
+    }
+    delete pCtx->pCos;
+    if (pCtx->os) pCtx->os->flush();
+    delete pCtx->os;
+    delete pCtx->buf;
+    delete pCtx;
+    *ppCtx = nullptr;
+    return res;
+}
+
+int initDecompressor(struct dData* pData, FILE* src, struct dContext** pCtx)
+{
+    if ((pData == nullptr) || (pCtx == nullptr) || (src == nullptr)) return Error::ERR_INVALID_PARAM;
+    if (pData->bufferSize > size_t(2) * 1024 * 1024 * 1024) return Error::ERR_INVALID_PARAM;
+    dContext* dctx = nullptr;
+    try {
+        if ((pData->headerless != 0) && ((memchr(pData->transform, 0, sizeof(pData->transform)) == nullptr) ||
+                                         (memchr(pData->entropy, 0, sizeof(pData->entropy)) == nullptr)))
+            return Error::ERR_INVALID_PARAM;
+        *pCtx = nullptr;
+        dctx = new dContext();
+        dctx->buf = new FileInBuf(src);
+        dctx->is = new std::istream(dctx->buf);
+        dctx->pCis = nullptr;
+        if (pData->headerless != 0) {
+            const std::string transform = TransformFactory<byte>::getName(TransformFactory<byte>::getType(pData->transform));
+            const std::string entropy = EntropyEncoderFactory::getName(EntropyEncoderFactory::getType(pData->entropy));
+            if ((transform.length() >= sizeof(pData->transform)) || (entropy.length() >= sizeof(pData->entropy))) {
+                delete dctx->is; delete dctx->buf; delete dctx;
+                return Error::ERR_INVALID_PARAM;
+            }
+            memset(pData->transform, 0, sizeof(pData->transform));
+            strncpy(pData->transform, transform.c_str(), sizeof(pData->transform) - 1);
+            memset(pData->entropy, 0, sizeof(pData->entropy));
+            strncpy(pData->entropy, entropy.c_str(), sizeof(pData->entropy) - 1);
+            pData->blockSize = (pData->blockSize + 15) & unsigned(-16);
+            dctx->pCis = new CompressedInputStream(*dctx->is, int(pData->jobs), pData->entropy, pData->transform, int(pData->blockSize),
+                                                   pData->checksum, uint64(pData->originalSize), true, pData->bsVersion);
+        } else {
+            dctx->pCis = new CompressedInputStream(*dctx->is, int(pData->jobs));
+        }
+        dctx->bufferSize = pData->bufferSize;
+        *pCtx = dctx;
+    } catch (const std::exception&) {
+        if (dctx) { delete dctx->pCis; delete dctx->is; delete dctx->buf; delete dctx; }
+        return Error::ERR_CREATE_DECOMPRESSOR;
+    }
+    return 0;
+}
+
+int decompress(struct dContext* pCtx, unsigned char* dst, size_t* inSize, size_t* outSize)
+{
+    if ((pCtx == nullptr) || (outSize == nullptr)) return Error::ERR_INVALID_PARAM;
+    if (*outSize > pCtx->bufferSize) return Error::ERR_INVALID_PARAM;
+    if (*outSize == 0) return 0;
+    if (dst == nullptr) return Error::ERR_INVALID_PARAM;
+    if (inSize) *inSize = 0;
+    CompressedInputStream* pCis = pCtx->pCis;
+    if (pCis == nullptr) { *outSize = 0; return Error::ERR_INVALID_PARAM; }
+    try {
+        const uint64 r = pCis->getRead();
+        pCis->read(reinterpret_cast<char*>(dst), std::streamsize(*outSize));
+        if (!pCis->good() && !pCis->eof()) return Error::ERR_READ_FILE;
+        if (inSize) *inSize = size_t(pCis->getRead() - r);
+        *outSize = size_t(pCis->gcount());
+    } catch (const IOException& ioe) {
+        *outSize = 0;
+        return ioe.error();
+    } catch (const std::exception&) {
+        *outSize = 0;
+        return Error::ERR_UNKNOWN;
+    }
+    return 0;
+}
+
+int disposeDecompressor(struct dContext** ppCtx)
+{
+    if ((ppCtx == nullptr) || (*ppCtx == nullptr)) return Error::ERR_INVALID_PARAM;
+    dContext* pCtx = *ppCtx;
+    int res = 0;
+    try { if (pCtx->pCis) pCtx->pCis->close(); } catch (const IOException& ioe) { res = ioe.error(); } catch (const std::exception&) { res = Error::ERR_UNKNOWN; }
+    delete pCtx->pCis;
+    delete pCtx->is;
+    delete pCtx->buf;
+    delete pCtx;
+    *ppCtx = nullptr;
+    return res;
+}
+
+}  // extern "C"

@@ -1,0 +1,128 @@
+"""Compressor / Decompressor classes over the C API of libkanzi_amd.so.
+
+Mirrors the reference's ctypes shim (src/api/kanzi_c_api.py:88-137 for the bindings,
+src/api/kanzi.py for the two classes): same struct layouts, same call sequence
+(init -> compress()/decompress() per block -> dispose). Only marshals data.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkanzi_amd.so")
+
+C_API_SYMBOLS = ["getCompressorVersion", "initCompressor", "compress", "disposeCompressor",
+                 "getDecompressorVersion", "initDecompressor", "decompress", "disposeDecompressor"]
+
+
+class cData(C.Structure):
+    _fields_ = [("transform", C.c_char * 64), ("entropy", C.c_char * 16), ("blockSize", C.c_size_t),
+                ("jobs", C.c_uint), ("checksum", C.c_int), ("headerless", C.c_int)]
+
+
+class dData(C.Structure):
+    _fields_ = [("bufferSize", C.c_size_t), ("jobs", C.c_uint), ("headerless", C.c_int), ("transform", C.c_char * 64),
+                ("entropy", C.c_char * 16), ("blockSize", C.c_uint), ("originalSize", C.c_size_t), ("checksum", C.c_int),
+                ("bsVersion", C.c_int)]
+
+
+_lib = None
+_libc = None
+
+
+def lib():
+    global _lib, _libc
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libkanzi_amd.so not built: run __graft_entry__.build()")
+        L = C.CDLL(LIB_PATH)
+        L.getCompressorVersion.restype = C.c_uint
+        L.getDecompressorVersion.restype = C.c_uint
+        L.initCompressor.argtypes = [C.POINTER(cData), C.c_void_p, C.POINTER(C.c_void_p)]
+        L.compress.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.disposeCompressor.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.initDecompressor.argtypes = [C.POINTER(dData), C.c_void_p, C.POINTER(C.c_void_p)]
+        L.decompress.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        L.disposeDecompressor.argtypes = [C.POINTER(C.c_void_p)]
+        _lib = L
+        _libc = C.CDLL(None)
+        _libc.fopen.restype = C.c_void_p
+        _libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+        _libc.fclose.argtypes = [C.c_void_p]
+    return _lib
+
+
+class KanziError(RuntimeError):
+    def __init__(self, code, what):
+        super().__init__("%s failed with kanzi error %d" % (what, code))
+        self.code = code
+
+
+class Compressor:
+    def __init__(self, path, transform="NONE", entropy="NONE", block_size=4 << 20, jobs=1, checksum=0, headerless=False):
+        L = lib()
+        self._f = _libc.fopen(path.encode(), b"wb")
+        if not self._f:
+            raise OSError("cannot open " + path)
+        self.params = cData(transform.encode(), entropy.encode(), block_size, jobs, checksum, 1 if headerless else 0)
+        self._ctx = C.c_void_p()
+        rc = L.initCompressor(C.byref(self.params), self._f, C.byref(self._ctx))
+        if rc != 0:
+            _libc.fclose(self._f)
+            self._f = None
+            raise KanziError(rc, "initCompressor")
+        self.written = 0
+
+    def compress(self, data):
+        out = C.c_size_t(0)
+        rc = lib().compress(self._ctx, data, len(data), C.byref(out))
+        if rc != 0:
+            raise KanziError(rc, "compress")
+        self.written += out.value
+        return out.value
+
+    def close(self):
+        if self._ctx:
+            out = C.c_size_t(0)
+            rc = lib().disposeCompressor(C.byref(self._ctx), C.byref(out))
+            self.written += out.value
+            self._ctx = C.c_void_p()
+            _libc.fclose(self._f)
+            self._f = None
+            if rc != 0:
+                raise KanziError(rc, "disposeCompressor")
+        return self.written
+
+
+class Decompressor:
+    def __init__(self, path, buffer_size=4 << 20, jobs=1, headerless=False, transform="NONE", entropy="NONE", block_size=0,
+                 original_size=0, checksum=0, bs_version=6):
+        L = lib()
+        self._f = _libc.fopen(path.encode(), b"rb")
+        if not self._f:
+            raise OSError("cannot open " + path)
+        self.params = dData(buffer_size, jobs, 1 if headerless else 0, transform.encode(), entropy.encode(), block_size,
+                            original_size, checksum, bs_version)
+        self._ctx = C.c_void_p()
+        rc = L.initDecompressor(C.byref(self.params), self._f, C.byref(self._ctx))
+        if rc != 0:
+            _libc.fclose(self._f)
+            self._f = None
+            raise KanziError(rc, "initDecompressor")
+        self.buffer_size = buffer_size
+
+    def decompress(self, n):
+        buf = (C.c_uint8 * max(1, n))()
+        ins, outs = C.c_size_t(0), C.c_size_t(n)
+        rc = lib().decompress(self._ctx, buf, C.byref(ins), C.byref(outs))
+        if rc != 0:
+            raise KanziError(rc, "decompress")
+        return bytes(buf[:outs.value])
+
+    def close(self):
+        if self._ctx:
+            rc = lib().disposeDecompressor(C.byref(self._ctx))
+            self._ctx = C.c_void_p()
+            _libc.fclose(self._f)
+            self._f = None
+            if rc != 0:
+                raise KanziError(rc, "disposeDecompressor")

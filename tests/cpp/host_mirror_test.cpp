@@ -1,0 +1,184 @@
+// Exercises the C++ host mirror (include/kanzi_amd.hpp) the way the reference's own unit tests
+// exercise the reference classes: src/test/TestBWT.cpp, TestTransforms.cpp, TestEntropyCodec.cpp,
+// TestCompressedStream.cpp, TestFactories.cpp. Runs on the GPU box (pytest -m gpu drives it) and
+// returns 0 / non-zero like the reference's test executables.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <sstream>
+#include <vector>
+
+#include "kanzi_amd.hpp"
+
+using namespace kanzi_amd;
+
+static int fails = 0;
+#define CHECK(c) do { if (!(c)) { printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #c); fails++; } } while (0)
+
+static std::vector<byte> gen(int kind, size_t n, unsigned seed)
+{
+    std::vector<byte> v(n);
+    unsigned x = seed * 2654435761u + 12345u;
+    for (size_t i = 0; i < n; i++) {
+        x = x * 1664525u + 1013904223u;
+        switch (kind) {
+        case 0: v[i] = byte(x >> 24); break;                                   // random
+        case 1: v[i] = byte(65 + ((x >> 24) % 4)); break;                      // small alphabet
+        case 2: v[i] = byte((i / 37) & 1 ? 0 : (x >> 28)); break;              // zero heavy
+        case 3: v[i] = byte((i * 17 + 3) & 255); break;                        // src/test/test_api.py fill_buffer
+        default: v[i] = byte("the quick brown fox jumps over the lazy dog. "[i % 45]); break;
+        }
+    }
+    return v;
+}
+
+static void testTransforms()
+{
+    const char* names[] = { "BWT", "MTFT", "ZRLT", "SRT", "RLT", "BWT+MTFT+ZRLT", "BWT+SRT+ZRLT" };
+    for (const char* nm : names) {
+        for (int kind = 0; kind < 5; kind++) {
+            for (size_t n : { size_t(20), size_t(512), size_t(80000) }) {
+                std::vector<byte> in = gen(kind, n, unsigned(kind * 7 + n));
+                Context ctx;
+                ctx.putInt("bsVersion", 6);
+                ctx.putString("entropy", "ANS0");
+                TransformSequence<byte>* f = TransformFactory<byte>::newTransform(ctx, TransformFactory<byte>::getType(nm));
+                std::vector<byte> a(in), b(size_t(f->getMaxEncodedLength(int(n))) + 64), c(n + 2048);
+                SliceArray<byte> sa1(a.data(), int(a.size()), 0), sa2(b.data(), int(b.size()), 0), sa3(c.data(), int(c.size()), 0);
+                const bool ok = f->forward(sa1, sa2, int(n));
+                if (!ok) { CHECK(sa1._index == int(n)); delete f; continue; }   // "does not apply" is accepted (TestTransforms.cpp:1079-1096)
+                const int enc = sa2._index;
+                TransformSequence<byte>* g = TransformFactory<byte>::newTransform(ctx, TransformFactory<byte>::getType(nm));
+                g->setSkipFlags(f->getSkipFlags());
+                sa2._index = 0;
+                CHECK(g->inverse(sa2, sa3, enc));
+                CHECK(sa3._index == int(n) && memcmp(c.data(), in.data(), n) == 0);
+                delete f; delete g;
+            }
+        }
+    }
+    // BWT known answers (src/test/TestBWT.cpp:42-60)
+    {
+        const char* s = "mississippi";
+        std::vector<byte> in(s, s + 11), out(64);
+        BWTBlockCodec bwt;
+        SliceArray<byte> sa1(in.data(), 11, 0), sa2(out.data(), 64, 0);
+        CHECK(bwt.forward(sa1, sa2, 11));
+        CHECK(sa2._index == 13 && out[1] == 4 && memcmp(&out[2], "ipssmpissii", 11) == 0);
+    }
+    // invalid SliceArray -> std::invalid_argument (src/Transform.hpp contract)
+    {
+        ZRLT z;
+        SliceArray<byte> bad(nullptr, 10, 0);
+        std::vector<byte> o(16);
+        SliceArray<byte> good(o.data(), 16, 0);
+        bool threw = false;
+        try { z.forward(bad, good, 4); } catch (const std::invalid_argument&) { threw = true; }
+        CHECK(threw);
+    }
+}
+
+static void testEntropy()
+{
+    const short types[] = { EntropyEncoderFactory::NONE_TYPE, EntropyEncoderFactory::HUFFMAN_TYPE, EntropyEncoderFactory::ANS0_TYPE,
+                            EntropyEncoderFactory::FPAQ_TYPE };
+    for (short t : types) {
+        for (int kind = 0; kind < 5; kind++) {
+            for (size_t n : { size_t(20), size_t(4096), size_t(100000) }) {
+                std::vector<byte> in = gen(kind, n, unsigned(kind + n));
+                std::stringstream ss;
+                Context ctx;
+                {
+                    DefaultOutputBitStream obs(ss, 16384);
+                    obs.writeBits(uint64(5), 3);                       // the codec starts at a non-aligned bit
+                    EntropyEncoder* ee = EntropyEncoderFactory::newEncoder(obs, ctx, t);
+                    CHECK(ee->encode(in.data(), 0, uint(n)) == int(n));
+                    ee->dispose();
+                    delete ee;
+                    obs.close();
+                }
+                std::vector<byte> out(n);
+                DefaultInputBitStream ibs(ss, 16384);
+                CHECK(ibs.readBits(3) == 5);
+                EntropyDecoder* ed = EntropyDecoderFactory::newDecoder(ibs, ctx, t);
+                CHECK(ed->decode(out.data(), 0, uint(n)) == int(n));
+                ed->dispose();
+                delete ed;
+                CHECK(memcmp(out.data(), in.data(), n) == 0);
+            }
+        }
+    }
+}
+
+static void testFactories()
+{
+    CHECK(TransformFactory<byte>::getType("BWT+MTFT+ZRLT") == 0x47180000000ull);
+    CHECK(TransformFactory<byte>::getName(0x47180000000ull) == "BWT+MTFT+ZRLT");
+    CHECK(TransformFactory<byte>::getType("none") == 0);
+    bool threw = false;
+    try { TransformFactory<byte>::getType("A+B"); } catch (const std::invalid_argument&) { threw = true; }
+    CHECK(threw);
+    threw = false;
+    try { TransformFactory<byte>::getType("BWT+BWT+BWT+BWT+BWT+BWT+BWT+BWT+BWT"); } catch (const std::invalid_argument&) { threw = true; }
+    CHECK(threw);
+    CHECK(EntropyEncoderFactory::getType("ans0") == 5 && std::string(EntropyEncoderFactory::getName(2)) == "FPAQ");
+}
+
+static void testStreams()
+{
+    // src/test/TestCompressedStream.cpp: sizes 64 KiB .. 4 MiB, several job counts, write/read after close
+    struct Cfg { const char* t; const char* e; int bs; } cfgs[] = {
+        { "NONE", "ANS0", 65536 }, { "BWT+MTFT+ZRLT", "ANS0", 262144 }, { "RLT+ZRLT", "HUFFMAN", 65536 }, { "BWT+SRT+ZRLT", "FPAQ", 262144 } };
+    for (const Cfg& cf : cfgs) {
+        for (int jobs = 1; jobs <= 4; jobs += 3) {
+            for (size_t n : { size_t(0), size_t(1), size_t(65536), size_t(1000001) }) {
+                std::vector<byte> in = gen(int(n % 5), n, unsigned(n + jobs));
+                std::stringstream ss;
+                {
+                    CompressedOutputStream cos(ss, jobs, cf.e, cf.t, cf.bs);
+                    size_t off = 0;
+                    while (off < n) { const size_t c = std::min<size_t>(n - off, 77777); cos.write(reinterpret_cast<const char*>(&in[off]), std::streamsize(c)); off += c; }
+                    cos.close();
+                    bool threw = false;
+                    try { cos.write("x", 1); } catch (const IOException& e) { threw = (e.error() == Error::ERR_WRITE_FILE); }
+                    CHECK(threw);
+                    CHECK(cos.getWritten() == uint64(ss.str().size()));
+                }
+                std::vector<byte> out(n + 16);
+                CompressedInputStream cis(ss, jobs);
+                cis.read(reinterpret_cast<char*>(out.data()), std::streamsize(out.size()));
+                CHECK(size_t(cis.gcount()) == n);
+                CHECK(cis.eof());
+                CHECK(n == 0 || memcmp(out.data(), in.data(), n) == 0);
+                cis.close();
+            }
+        }
+    }
+    // malformed header (src/test/TestMalformedStream.cpp)
+    {
+        std::string bad(64, '\0');
+        std::stringstream ss(bad);
+        CompressedInputStream cis(ss, 1);
+        char buf[16];
+        bool threw = false;
+        try { cis.read(buf, 16); } catch (const IOException& e) { threw = (e.error() == Error::ERR_INVALID_FILE); }
+        CHECK(threw);
+    }
+}
+
+int main(int argc, char** argv)
+{
+    const std::string what = argc > 1 ? argv[1] : "all";
+    try {
+        if (what == "all" || what == "factories") testFactories();
+        if (what == "all" || what == "transforms") testTransforms();
+        if (what == "all" || what == "entropy") testEntropy();
+        if (what == "all" || what == "streams") testStreams();
+    } catch (const std::exception& e) {
+        printf("EXCEPTION %s\n", e.what());
+        return 2;
+    }
+    printf(fails ? "FAILED (%d)\n" : "OK\n", fails);
+    return fails ? 1 : 0;
+}

@@ -1,0 +1,87 @@
+"""The drop-in boundary on the GPU: the reference-compatible C API (include/kanzi_api.h, through the
+ctypes classes that mirror src/api/kanzi.py) and the C++ mirror classes (tests/cpp/host_mirror_test,
+modelled on the reference's own test executables)."""
+import importlib
+import os
+import subprocess
+
+import pytest
+
+import knzlib
+import vectors
+
+pytestmark = pytest.mark.gpu
+
+
+def _kanzi():
+    knzlib.load_pkg()
+    return importlib.import_module("kanzi_amd.kanzi")
+
+
+def test_cpp_host_mirror_suite():
+    exe = os.path.join(knzlib.ROOT, "tests", "cpp", "host_mirror_test")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    r = subprocess.run([exe, "all"], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_c_api_roundtrip_and_bit_exact(tmp_path, oracle):
+    # src/test/test_api.py / TestAPI.c: fill_buffer(size) = (i*17+3)&255, several blocks, parameter rewriting
+    kz = _kanzi()
+    assert kz.lib().getCompressorVersion() == 0x010000 and kz.lib().getDecompressorVersion() == 0x010000
+    for transform, entropy, bs, jobs, n in [("none", "huffman", 1024, 1, 1024 * 3 + 100), ("BWT+MTFT+ZRLT", "ANS0", 65536, 2, 300000),
+                                            ("bwt+srt+zrlt", "fpaq", 65530, 3, 200001), ("RLT", "NONE", 4096, 1, 0)]:
+        data = vectors.make(("fill17", n)) if n < 5000 else vectors.make(("mixed", n, 5))
+        path = str(tmp_path / "x.knz")
+        c = kz.Compressor(path, transform, entropy, bs, jobs)
+        assert c.params.transform.decode() == transform.upper() and c.params.entropy.decode() == entropy.upper()
+        block = c.params.blockSize
+        assert block == (bs + 15) & -16
+        total = 0
+        for off in range(0, len(data), block):
+            total += c.compress(data[off:off + block])
+        with pytest.raises(kz.KanziError) as ei:
+            c.compress(bytes(block + 1))                       # inSize > blockSize -> ERR_INVALID_PARAM
+        assert ei.value.code == 18
+        total = c.close()
+        enc = open(path, "rb").read()
+        assert total == len(enc)
+        rc, ref = oracle.compress(data, transform.upper(), entropy.upper(), block, orig_size=0, jobs=jobs)
+        assert rc == 0 and enc == ref, (transform, entropy)
+        d = kz.Decompressor(path, buffer_size=block, jobs=jobs)
+        out = bytearray()
+        while True:
+            chunk = d.decompress(block)
+            out += chunk
+            if len(chunk) < block:
+                break
+        d.close()
+        assert bytes(out) == data
+
+
+def test_c_api_parameter_validation(tmp_path):
+    kz = _kanzi()
+    with pytest.raises(kz.KanziError) as ei:
+        kz.Compressor(str(tmp_path / "y.knz"), "BOGUS", "ANS0", 4096)
+    assert ei.value.code == 4                                   # ERR_CREATE_COMPRESSOR (unknown names throw inside init)
+    with pytest.raises(kz.KanziError):
+        kz.Compressor(str(tmp_path / "y.knz"), "NONE", "ANS0", 100)     # block size below 1024
+
+
+def test_c_api_headerless(tmp_path):
+    kz = _kanzi()
+    data = vectors.make(("text", 70000, 2))
+    path = str(tmp_path / "h.knz")
+    c = kz.Compressor(path, "ZRLT", "HUFFMAN", 16384, 1, headerless=True)
+    for off in range(0, len(data), 16384):
+        c.compress(data[off:off + 16384])
+    c.close()
+    d = kz.Decompressor(path, buffer_size=16384, headerless=True, transform="ZRLT", entropy="HUFFMAN", block_size=16384)
+    out = bytearray()
+    while True:
+        chunk = d.decompress(16384)
+        out += chunk
+        if len(chunk) < 16384:
+            break
+    d.close()
+    assert bytes(out) == data

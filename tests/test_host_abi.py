@@ -20,6 +20,22 @@ def test_library_exports_declared_symbols():
     assert declared == set(hipapi.SYMBOLS)
 
 
+def test_host_library_exports_reference_c_api():
+    # include/kanzi_api.h: the eight entry points of src/api/Compressor.hpp:80-116 / Decompressor.hpp:83-117
+    knzlib.load_pkg()
+    kz = importlib.import_module("kanzi_amd.kanzi")
+    assert os.path.exists(kz.LIB_PATH), "run __graft_entry__.build() first"
+    import ctypes
+    L = ctypes.CDLL(kz.LIB_PATH)
+    hdr = open(os.path.join(knzlib.ROOT, "include", "kanzi_api.h")).read()
+    declared = set(re.findall(r"KANZI_API\s+[\w\s]+?\b(\w+)\s*\(", hdr))
+    assert declared == set(kz.C_API_SYMBOLS)
+    for sym in declared:
+        assert hasattr(L, sym), sym
+    assert L.getCompressorVersion() == 0x010000          # no GPU needed
+    assert ctypes.sizeof(kz.cData) == 104 and ctypes.sizeof(kz.dData) == 120   # struct layouts of the reference headers
+
+
 def test_header_matches_oracle(oracle):
     knzlib.load_pkg()
     fr = importlib.import_module("kanzi_amd.framing")
