@@ -92,6 +92,9 @@ int knzo_compress(const uint8_t* in, size_t n, const char* transform, const char
 int knzo_compress_jobs(const uint8_t* in, size_t n, const char* transform, const char* entropy,
                        int blockSize, int checksum, uint64_t origSize, int headerless, int jobs,
                        uint8_t* out, size_t cap, size_t* outLen);
+int knzo_compress_run(const uint8_t* in, size_t n, const char* transform, const char* entropy,
+                      int blockSize, int checksum, uint64_t origSize, int headerless, int jobs,
+                      uint64_t firstBlock, int finish, uint8_t* out, size_t cap, size_t* outLen, uint64_t* outBits);
 int knzo_decompress(const uint8_t* in, size_t inLen, uint8_t* out, size_t cap, size_t* outLen);
 
 /* XXHash32/64 as used for block checksums (util/XXHash.hpp:61-115,153-230), seed 0x4B414E5A */

@@ -389,6 +389,16 @@ int knzo_compress_jobs(const uint8_t* in, size_t n, const char* transform, const
                        int blockSize, int checksum, uint64_t origSize, int headerless, int jobs,
                        uint8_t* out, size_t cap, size_t* outLen)
 {
+    uint64_t bits = 0;
+    return knzo_compress_run(in, n, transform, entropy, blockSize, checksum, origSize, headerless, jobs, 0, 1, out, cap, outLen, &bits);
+}
+
+/* A run of consecutive blocks of a larger stream: firstBlock = index of the first block (selects the
+ * buffer slots), finish = append the end marker. *outBits = exact bit count (multi-GPU sharding tests). */
+int knzo_compress_run(const uint8_t* in, size_t n, const char* transform, const char* entropy,
+                      int blockSize, int checksum, uint64_t origSize, int headerless, int jobs,
+                      uint64_t firstBlock, int finish, uint8_t* out, size_t cap, size_t* outLen, uint64_t* outBits)
+{
     *outLen = 0;
     const uint64_t ttype = knzo_transform_type(transform);
     const int etype = knzo_entropy_type(entropy);
@@ -423,7 +433,14 @@ int knzo_compress_jobs(const uint8_t* in, size_t n, const char* transform, const
         }
         bufCaps[j] = 0;
     }
-    size_t blockIdx = 0;
+    size_t blockIdx = (size_t)firstBlock;
+    if (firstBlock > 0) {
+        /* slots already used by earlier (full-size) blocks have grown their buffers */
+        int tok0[8];
+        const int nb0 = seq_tokens(ttype, tok0);
+        const int req0 = seq_required(tok0, nb0, blockSize);
+        for (int j = 0; j < jobs; j++) if ((uint64_t)j < firstBlock) bufCaps[j] = req0;
+    }
     const size_t tmpCap = (size_t)blockSize + ((size_t)blockSize >> 1) + 65536;
     uint8_t* tmp = (uint8_t*)malloc(tmpCap);
     size_t off = 0;
@@ -455,10 +472,13 @@ int knzo_compress_jobs(const uint8_t* in, size_t n, const char* transform, const
         off += (size_t)len;
     }
     free(tmp);
-    knzo_bw_bits(&w, 0, 5);
-    knzo_bw_bits(&w, 0, 3);
+    if (finish) {
+        knzo_bw_bits(&w, 0, 5);
+        knzo_bw_bits(&w, 0, 3);
+    }
     if (w.overflow) return ERR_WRITE_FILE;
     *outLen = (size_t)((w.bits + 7) >> 3);
+    *outBits = w.bits;
     return 0;
 }
 

@@ -76,6 +76,9 @@ class Oracle:
         L.knzo_compress_jobs.restype = C.c_int
         L.knzo_compress_jobs.argtypes = [u8p, C.c_size_t, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_uint64,
                                          C.c_int, C.c_int, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.knzo_compress_run.restype = C.c_int
+        L.knzo_compress_run.argtypes = [u8p, C.c_size_t, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int,
+                                        C.c_uint64, C.c_int, u8p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]
         L.knzo_decompress.restype = C.c_int
         L.knzo_decompress.argtypes = [u8p, C.c_size_t, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.knzo_transform_type.restype = C.c_uint64
@@ -129,6 +132,15 @@ class Oracle:
         rc = self.L.knzo_compress_jobs(_buf(data), len(data), transform.encode(), entropy.encode(), block_size,
                                        checksum, orig_size, headerless, jobs, out, cap, C.byref(ol))
         return rc, bytes(out[:ol.value])
+
+    def compress_run(self, data, transform, entropy, block_size, first_block, finish, jobs=1, headerless=1, orig_size=0):
+        """Blocks [first_block, ...) of a stream as a bit run: returns (rc, bytes, nbits)."""
+        cap = len(data) + len(data) // 2 + (1 << 20)
+        out = (C.c_uint8 * cap)()
+        ol, ob = C.c_size_t(0), C.c_uint64(0)
+        rc = self.L.knzo_compress_run(_buf(data), len(data), transform.encode(), entropy.encode(), block_size, 0, orig_size,
+                                      headerless, jobs, first_block, 1 if finish else 0, out, cap, C.byref(ol), C.byref(ob))
+        return rc, bytes(out[:ol.value]), ob.value
 
     def decompress(self, enc, cap):
         out = (C.c_uint8 * max(1, cap))()

@@ -222,3 +222,20 @@ def test_full_size_roundtrip_properties(hip):
         out2, bits2, _ = gpu_compress(hip, d, t, e, bs, headerless=1)
         assert out1 == out2, (t, e)
         assert gpu_decompress(hip, out1, t, e, bs, len(d), 0) == d, (t, e)
+
+
+def test_sharded_runs_concatenate_to_single_stream(hip, oracle):
+    # multi-GPU path on one device: two block ranges encoded as separate runs (first_block_id honoured),
+    # concatenated on the host, must equal the single-stream bytes (kanzi-cpp_amd/sharded.py)
+    sh = importlib.import_module("kanzi_amd.sharded")
+    d = vectors.make(("mixed", 700001, 11))
+    for t, e, bs, jobs in [("BWT+MTFT+ZRLT", "ANS0", 65536, 1), ("BWT+SRT+ZRLT", "ANS0", 262144, 3)]:
+        enc = sh.DeviceRunEncoder(0, t, e, bs, jobs=jobs, orig_size=len(d))
+        ranges = sh.block_ranges(len(d), bs, 2)
+        runs = []
+        for r, (first, cnt) in enumerate(ranges):
+            chunk = d[first * bs:min(len(d), (first + cnt) * bs)]
+            runs.append(enc(chunk, first, r == 0, r == 1))
+        got = sh.concat_bit_runs(runs)[0]
+        rc, ref = oracle.compress(d, t, e, bs, orig_size=len(d), jobs=jobs)
+        assert got == ref, (t, e, jobs)
