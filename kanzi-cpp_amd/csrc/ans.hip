@@ -398,282 +398,6 @@ __global__ __launch_bounds__(64) void k_ans0_encode(BlockView view, int maxChunk
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// decode
-// ------------------------------------------------------------------------------------------------
-struct AnsDecChunk {
-    u64 maskBit;         // first presence-mask byte (partial alphabet), unused when asz == 256
-    u64 freqBit;         // first frequency group
-    u64 payloadBit;      // first payload byte
-    u32 sz;              // payload bytes
-    u32 st[4];
-    u16 asz;
-    u8 lr;
-    u8 kind;             // 0 = coded, 1 = single symbol fill, 2 = raw bytes, 3 = unused slot
-    u8 sym;              // fill symbol for kind 1
-    u8 pad[3];
-    u16 grp[44];         // per frequency group: (bit offset relative to freqBit of the logMax field) | logMax << 12
-};
-
-constexpr u32 ANS_MAX_CHUNK = 1u << 27;
-
-// One lane per block: walks the chunk headers (ANSRangeDecoder.cpp:80-175, :218-232) to locate every
-// chunk. The per-symbol frequencies are decoded later, in parallel, by k_ans0_decode.
-__global__ __launch_bounds__(64) void k_ans0_scan(BitSrc src, DecBlock* __restrict__ blocks, int nBlocks, int maxChunks,
-                                                  AnsDecChunk* __restrict__ chunks)
-{
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= nBlocks) return;
-    DecBlock& db = blocks[b];
-    AnsDecChunk* cs = chunks + (size_t)b * maxChunks;
-    for (int i = 0; i < maxChunks; i++) cs[i].kind = 3;
-    if (db.error) return;
-    BitSrc s = src;
-    s.limitBits = db.payloadBit + ((db.bits + 7) & ~7ull);
-    u64 pos = db.entropyBit;
-    const u32 preLen = db.preLen;
-    int err = 0;
-    if (db.copyBlock || preLen <= 32) {
-        cs[0].kind = 2;
-        cs[0].payloadBit = pos;
-        cs[0].sz = preLen;
-        pos += 8ull * preLen;
-        if (pos > s.limitBits) db.error = KNZ_ERR_PROCESS_BLOCK;
-        db.usedBits = pos - db.entropyBit;
-        return;
-    }
-    const u32 nChunks = (preLen + ENT_CHUNK - 1) / ENT_CHUNK;
-    for (u32 ci = 0; ci < nChunks && !err; ci++) {
-        AnsDecChunk& c = cs[ci];
-        const u32 lr = 8 + take_bits(s, pos, 3, err);
-        if (lr > ANS_LR) { err = 1; break; }          // kanzi encoders always emit 12; > 12 unsupported here
-        c.lr = (u8)lr;
-        u32 asz;
-        u32 firstSym = 0;
-        c.maskBit = 0;
-        if (take_bits(s, pos, 1, err) == 0) {
-            asz = (take_bits(s, pos, 1, err) == 0) ? 256u : 0u;
-        } else {
-            const u32 lastMask = take_bits(s, pos, 5, err);
-            c.maskBit = pos;
-            asz = 0;
-            bool found = false;
-            for (u32 m = 0; m <= lastMask; m++) {
-                const u32 byte = take_bits(s, pos, 8, err);
-                if (!found && byte) { firstSym = 8 * m + (u32)(__ffs((int)byte) - 1); found = true; }
-                asz += __popc(byte);
-            }
-        }
-        if (err) break;
-        if (asz == 0) { err = 2; break; }             // decode() returns a short count -> failure
-        c.asz = (u16)asz;
-        c.freqBit = pos;
-        const u32 chk = (asz >= 64) ? 8u : 6u;
-        const u32 llr = (u32)ilog2_u32(lr) + 1u;
-        u32 g = 0;
-        for (u32 i = 1; i < asz; i += chk, g++) {
-            const u32 rel = (u32)(pos - c.freqBit);
-            const u32 logMax = take_bits(s, pos, llr, err);
-            if (logMax > lr) err = 1;
-            const u32 endj = (i + chk < asz) ? i + chk : asz;
-            c.grp[g] = (u16)(rel | (logMax << 12));
-            pos += (u64)(endj - i) * logMax;
-            if (err) break;
-        }
-        if (err) break;
-        if (asz == 1) {
-            c.kind = 1;
-            c.sym = (u8)firstSym;
-            c.sz = 0;
-        } else {
-            const u32 sz = take_varint(s, pos, err);
-            if (sz >= ANS_MAX_CHUNK || sz > 2 * ENT_CHUNK - 2) { err = 1; break; }
-            for (int k = 0; k < 4; k++) c.st[k] = take_bits(s, pos, 32, err);
-            c.payloadBit = pos;
-            c.sz = sz;
-            pos += 8ull * sz;
-            if (pos > s.limitBits) err = 1;
-            c.kind = 0;
-        }
-    }
-    if (err) db.error = KNZ_ERR_PROCESS_BLOCK;
-    db.usedBits = pos - db.entropyBit;
-}
-
-// 16 chunks per wave. Phase 1: the whole wave rebuilds each chunk's tables (parallel frequency
-// parse using the group offsets found by the scan). Phase 2: 4 lanes per chunk run the 4 states.
-__global__ __launch_bounds__(64) void k_ans0_decode(BitSrc src, DecBlock* __restrict__ blocks, int maxChunks, int nSlots,
-                                                    const AnsDecChunk* __restrict__ chunks, u8* const* __restrict__ outPtr)
-{
-    __shared__ u8 f2sAll[16 * 4096];                           // slot -> symbol
-    __shared__ u32 symAll[16 * 256];                           // freq | cum << 16
-    const int lane = lane_id();
-    const int slotBase = blockIdx.x * 16;
-    __shared__ int chunkErr[16];
-    if (lane < 16) chunkErr[lane] = 0;
-    __syncthreads();
-
-    for (int gg = 0; gg < 16; gg++) {
-        const int slot = slotBase + gg;
-        if (slot >= nSlots) break;
-        const AnsDecChunk& c = chunks[slot];
-        const int b = slot / maxChunks;
-        const int ci = slot - b * maxChunks;
-        if (c.kind == 3 || blocks[b].error) continue;
-        u8* dst = outPtr[b] + (size_t)ci * ENT_CHUNK;
-        const u32 preLen = blocks[b].preLen;
-        if (c.kind == 2) {
-            for (u32 i = lane; i < c.sz; i += 64) dst[i] = (u8)peek_bits(src, c.payloadBit + 8ull * i, 8);
-            continue;
-        }
-        const u32 n = (preLen - (u32)ci * ENT_CHUNK < ENT_CHUNK) ? (preLen - (u32)ci * ENT_CHUNK) : ENT_CHUNK;
-        if (c.kind == 1) {
-            for (u32 i = lane; i < n; i += 64) dst[i] = c.sym;
-            continue;
-        }
-        // ---- tables (ANSRangeDecoder.cpp:113-171)
-        const u32 lr = c.lr;
-        const u32 scale = 1u << lr;
-        const u32 asz = c.asz;
-        u32 present;
-        if (asz == 256) present = 0xF;
-        else {
-            const u32 m = (u32)lane >> 1;
-            // bytes beyond lastMask are not in the stream: bound by freqBit
-            const u64 mb = c.maskBit + 8ull * m;
-            const u32 byte = (mb + 8 <= c.freqBit) ? peek_bits(src, mb, 8) : 0u;
-            present = (lane & 1) ? (byte >> 4) : (byte & 0xF);
-        }
-        const u32 myCount = __popc(present);
-        const u32 incl = wave_incl_scan(myCount);
-        u32 r = incl - myCount;
-        const u32 chk = (asz >= 64) ? 8u : 6u;
-        const u32 llr = (u32)ilog2_u32(lr) + 1u;
-        u32 f[4] = { 0, 0, 0, 0 };
-        u32 lsum = 0;
-        int bad = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if ((present >> k) & 1) {
-                if (r >= 1) {
-                    const u32 g = (r - 1) / chk;
-                    const u32 ge = c.grp[g];
-                    const u32 lm = ge >> 12;
-                    const u32 fv = lm ? peek_bits(src, c.freqBit + (ge & 0xFFF) + llr + (u64)((r - 1) - g * chk) * lm, lm) + 1u : 1u;
-                    if (fv >= scale) bad = 1;
-                    f[k] = fv;
-                    lsum += fv;
-                }
-                r++;
-            }
-        }
-        const u32 sumOthers = wave_sum(lsum);
-        if (scale <= sumOthers) bad = 1;
-        // first alphabet symbol gets the remainder
-        if (!bad) {
-            u32 rr = incl - myCount;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if ((present >> k) & 1) { if (rr == 0) f[k] = scale - sumOthers; rr++; }
-            }
-        }
-        if (__ballot(bad) != 0) { if (lane == 0) chunkErr[gg] = 1; continue; }
-        const u32 tot = f[0] + f[1] + f[2] + f[3];
-        const u32 cincl = wave_incl_scan(tot);
-        u32 cum = cincl - tot;
-        u8* f2s = f2sAll + gg * 4096;
-        u32* symt = symAll + gg * 256;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const u32 fr = f[k];
-            const u32 fclip = (fr >= scale) ? scale - 1 : fr;
-            symt[4 * lane + k] = fclip | (cum << 16);
-            for (u32 t = 0; t < fr; t++) f2s[cum + t] = (u8)(4 * lane + k);
-            cum += fr;
-        }
-    }
-    __syncthreads();
-
-    // ---- phase 2
-    const int g = lane >> 2;
-    const int j = lane & 3;
-    const int slot = slotBase + g;
-    bool act = false;
-    AnsDecChunk cmeta;
-    u32 n = 0;
-    u8* dst = nullptr;
-    if (slot < nSlots) {
-        const int b = slot / maxChunks;
-        const int ci = slot - b * maxChunks;
-        const AnsDecChunk& c = chunks[slot];
-        if (c.kind == 0 && !blocks[b].error && !chunkErr[g]) {
-            act = true;
-            const u32 preLen = blocks[b].preLen;
-            n = (preLen - (u32)ci * ENT_CHUNK < ENT_CHUNK) ? (preLen - (u32)ci * ENT_CHUNK) : ENT_CHUNK;
-            dst = outPtr[b] + (size_t)ci * ENT_CHUNK;
-        }
-        cmeta.payloadBit = c.payloadBit; cmeta.sz = c.sz; cmeta.lr = c.lr;
-        cmeta.st[0] = c.st[0]; cmeta.st[1] = c.st[1]; cmeta.st[2] = c.st[2]; cmeta.st[3] = c.st[3];
-    }
-    if (__ballot(act) == 0) {
-        // still report table errors
-        if (lane < 16 && chunkErr[lane] && slotBase + lane < nSlots) blocks[(slotBase + lane) / maxChunks].error = KNZ_ERR_PROCESS_BLOCK;
-        return;
-    }
-    const u32 lr = act ? cmeta.lr : ANS_LR;
-    const u32 mask = (1u << lr) - 1;
-    u32 st = act ? cmeta.st[j] : 0;
-    const u32 count4 = n & ~3u;
-    const u32 steps = act ? (count4 >> 2) : 0;
-    const u32 maxSteps = wave_max(steps);
-    const u8* f2s = f2sAll + g * 4096;
-    const u32* symt = symAll + g * 256;
-    u32 p = 0;                                       // byte offset in the payload
-    const u32 grpShift = (u32)(lane & ~3);
-    const u32 higherMask = (0xFu << (j + 1)) & 0xFu; // lanes consumed before me in one iteration: j' > j
-    const u64 payBit = cmeta.payloadBit;
-    for (u32 s = 0; s < maxSteps; s++) {
-        const bool on = s < steps;
-        const u32 slotv = st & mask;
-        const u32 sym = f2s[slotv];
-        const u32 e = symt[sym];
-        if (on) {
-            dst[4 * s + (3 - j)] = (u8)sym;
-            st = (e & 0xFFFF) * (st >> lr) + slotv - (e >> 16);
-        }
-        const bool flag = on && (st < ANS_TOP);
-        const u64 m = __ballot(flag);
-        const u32 grp = (u32)(m >> grpShift) & 0xF;
-        if (flag) {
-            const u32 before = __popc(grp & higherMask);
-            const u32 v = peek_bits(src, payBit + 8ull * (p + 2 * before), 16);
-            st = (st << 16) | v;
-        }
-        p += 2 * __popc(grp);
-    }
-    if (act) {
-        const u32 tail = n - count4;
-        if (j == 0) {
-            for (u32 t = 0; t < tail; t++) dst[count4 + t] = (u8)peek_bits(src, payBit + 8ull * (p + t), 8);
-            if (p + tail != cmeta.sz) chunkErr[g] = 1;      // ANSRangeDecoder.cpp:291
-        }
-    }
-    __syncthreads();
-    if (lane < 16 && chunkErr[lane] && slotBase + lane < nSlots) blocks[(slotBase + lane) / maxChunks].error = KNZ_ERR_PROCESS_BLOCK;
-}
-
-void launch_ans0_decode(hipStream_t s, BitSrc src, DecBlock* blocks, int nBlocks, int maxChunks, void* chunkMeta,
-                        u8* const* outPtr)
-{
-    AnsDecChunk* chunks = reinterpret_cast<AnsDecChunk*>(chunkMeta);
-    const int nSlots = nBlocks * maxChunks;
-    { KScope ks_("k_ans0_scan"); hipLaunchKernelGGL(k_ans0_scan, dim3((nBlocks + 63) / 64), dim3(64), 0, s, src, blocks, nBlocks, maxChunks, chunks); }
-    { KScope ks_("k_ans0_decode"); hipLaunchKernelGGL(k_ans0_decode, dim3((nSlots + 15) / 16), dim3(64), 0, s, src, blocks, maxChunks,
-                       nSlots, chunks, outPtr); }
-}
-
-size_t ans0_dec_chunk_bytes() { return sizeof(AnsDecChunk); }
-
 void launch_ans0_encode(hipStream_t s, BlockView view, int nBlocks, int maxChunks, ChunkDesc* desc, uint2* encTab, u8* tmp)
 {
     const int nSlots = nBlocks * maxChunks;

@@ -1,0 +1,451 @@
+// rANS order-0 decoder (kanzi "ANS0") on gfx950.
+//
+// Reference being replaced: entropy/ANSRangeDecoder.cpp:80-175 (decodeHeader), :177-216 (decode),
+// :218-292 (decodeChunk), entropy/ANSRangeDecoder.hpp:85-103 (decodeSymbol),
+// entropy/EntropyUtils.cpp:91-123 (decodeAlphabet), :261-285 (readVarInt).
+//
+//   k_ans0_scan    The stream has no chunk directory and chunk headers are bit-granular, so finding
+//                  chunk c+1 needs the header of chunk c: a serial chain of (#chunks) steps per block.
+//                  One WAVE per block: the 64 lanes stage the next 640 bytes of the stream in LDS with
+//                  one coalesced load, the presence masks are counted in parallel (ballot/popcount),
+//                  and only the group walk (<= 43 dependent 4-bit reads) runs on one lane, from LDS.
+//   k_ans0_decode  8 chunks per wave. Phase 1 rebuilds each chunk's tables with the whole wave (parallel
+//                  frequency parse from the group offsets the scan recorded; slot->symbol table filled
+//                  64 slots per lane). Phase 2: 4 lanes per chunk = the 4 interleaved states; the shared
+//                  forward byte pointer of the reference is a ballot + popcount per step; the payload is
+//                  streamed through a 1 KiB LDS ring per chunk (refilled cooperatively every 32 steps)
+//                  so that no global load sits on the dependent chain; 4x4 symbols are transposed
+//                  with shuffles so that every lane stores one aligned dword.
+#include "common.hpp"
+#include "stages.hpp"
+
+namespace knz {
+
+constexpr u32 ANS_TOP = 1u << 15;
+constexpr u32 ANS_LR = 12;
+constexpr u32 ANS_MAX_CHUNK = 1u << 27;
+
+struct AnsDecChunk {
+    u64 maskBit;         // first presence-mask byte (partial alphabet), unused when asz == 256
+    u64 freqBit;         // first frequency group
+    u64 payloadBit;      // first payload byte
+    u32 sz;              // payload bytes
+    u32 st[4];
+    u16 asz;
+    u8 lr;
+    u8 kind;             // 0 = coded, 1 = single symbol fill, 2 = raw bytes, 3 = unused slot
+    u8 sym;              // fill symbol for kind 1
+    u8 pad[3];
+    u16 grp[44];         // per frequency group: (bit offset relative to freqBit of the logMax field) | logMax << 12
+};
+
+constexpr u32 SCAN_WIN_WORDS = 176;      // 704 bytes: header (<= 3498 bits) + var-int + 4 states + slack
+
+// window reader: bits relative to winBit0 (a multiple of 32)
+__device__ __forceinline__ u32 win_bits(const u32* win, u64 winBit0, u64 pos, u32 n)
+{
+    if (n == 0) return 0;
+    const u32 rel = (u32)(pos - winBit0);
+    const u32 w = rel >> 5;
+    const u64 v = ((u64)win[w] << 32) | (u64)win[w + 1];
+    return (u32)((v << (rel & 31)) >> (64 - n));
+}
+
+__global__ __launch_bounds__(64) void k_ans0_scan(BitSrc src, DecBlock* __restrict__ blocks, int nBlocks, int maxChunks,
+                                                  AnsDecChunk* __restrict__ chunks)
+{
+    const int b = blockIdx.x;
+    const int lane = lane_id();
+    DecBlock& db = blocks[b];
+    AnsDecChunk* cs = chunks + (size_t)b * maxChunks;
+    for (int i = lane; i < maxChunks; i += 64) cs[i].kind = 3;
+    if (db.error) return;
+    __shared__ u32 win[SCAN_WIN_WORDS + 2];
+    __shared__ u64 sh_pos;
+    __shared__ int sh_err;
+    const u64 limit = db.payloadBit + ((db.bits + 7) & ~7ull);
+    u64 pos = db.entropyBit;
+    const u32 preLen = db.preLen;
+    if (db.copyBlock || preLen <= 32) {
+        if (lane == 0) {
+            cs[0].kind = 2;
+            cs[0].payloadBit = pos;
+            cs[0].sz = preLen;
+            pos += 8ull * preLen;
+            if (pos > limit) db.error = KNZ_ERR_PROCESS_BLOCK;
+            db.usedBits = pos - db.entropyBit;
+        }
+        return;
+    }
+    const u32 nChunks = (preLen + ENT_CHUNK - 1) / ENT_CHUNK;
+    int err = 0;
+    for (u32 ci = 0; ci < nChunks; ci++) {
+        // ---- stage the window
+        const u64 winBit0 = pos & ~31ull;
+        const u64 w0 = winBit0 >> 5;
+        for (u32 i = lane; i < SCAN_WIN_WORDS + 2; i += 64) win[i] = src_word(src, w0 + i);
+        __syncthreads();
+        AnsDecChunk& c = cs[ci];
+        u64 p = pos;
+        // header prefix is uniform work: every lane decodes the same few fields
+        const u32 lr = 8 + win_bits(win, winBit0, p, 3); p += 3;
+        u32 asz = 0, firstSym = 0;
+        u64 maskBit = 0;
+        bool partial = false;
+        u32 lastMask = 0;
+        if (lr > ANS_LR) err = 1;                      // kanzi encoders always emit 12; > 12 unsupported here
+        if (!err) {
+            if (win_bits(win, winBit0, p, 1) == 0) { asz = (win_bits(win, winBit0, p + 1, 1) == 0) ? 256u : 0u; p += 2; }
+            else {
+                partial = true;
+                lastMask = win_bits(win, winBit0, p + 1, 5);
+                p += 6;
+                maskBit = p;
+                // one mask byte per lane
+                const u32 byte = ((u32)lane <= lastMask) ? win_bits(win, winBit0, p + 8ull * lane, 8) : 0u;
+                const u32 pc = __popc(byte);
+                asz = wave_sum(pc);
+                const u64 nz = __ballot(byte != 0);
+                if (nz) {
+                    const int fl = __ffsll((long long)nz) - 1;
+                    const u32 fb = (u32)__shfl((int)byte, fl, 64);
+                    firstSym = 8u * (u32)fl + (u32)(__ffs((int)fb) - 1);
+                }
+                p += 8ull * (lastMask + 1);
+            }
+            if (asz == 0) err = 2;                     // decode() returns a short count -> failure
+        }
+        (void)partial;
+        if (!err && lane == 0) {
+            c.lr = (u8)lr;
+            c.maskBit = maskBit;
+            c.asz = (u16)asz;
+            c.freqBit = p;
+            const u32 chk = (asz >= 64) ? 8u : 6u;
+            const u32 llr = (u32)ilog2_u32(lr) + 1u;
+            u32 g = 0;
+            u64 q = p;
+            int e2 = 0;
+            for (u32 i = 1; i < asz; i += chk, g++) {
+                const u32 rel = (u32)(q - p);
+                const u32 logMax = win_bits(win, winBit0, q, llr);
+                q += llr;
+                if (logMax > lr) { e2 = 1; break; }
+                const u32 endj = (i + chk < asz) ? i + chk : asz;
+                c.grp[g] = (u16)(rel | (logMax << 12));
+                q += (u64)(endj - i) * logMax;
+            }
+            if (!e2) {
+                if (asz == 1) {
+                    c.kind = 1; c.sym = (u8)firstSym; c.sz = 0;
+                } else {
+                    // var-int, 4 states (all inside the window: header <= 3498 bits, window 5632 bits)
+                    u32 value = win_bits(win, winBit0, q, 8); q += 8;
+                    u32 res = value & 0x7F;
+                    for (int shift = 7; value >= 128; shift += 7) {
+                        value = win_bits(win, winBit0, q, 8); q += 8;
+                        if (shift == 28) { if (value >= 128 || (value & 0x70) != 0) e2 = 1; res |= (value & 0x0F) << shift; break; }
+                        res |= (value & 0x7F) << shift;
+                    }
+                    const u32 sz = res;
+                    if (sz >= ANS_MAX_CHUNK || sz > 2 * ENT_CHUNK - 2) e2 = 1;
+                    for (int k = 0; k < 4; k++) { c.st[k] = win_bits(win, winBit0, q, 32); q += 32; }
+                    c.payloadBit = q;
+                    c.sz = sz;
+                    q += 8ull * sz;
+                    c.kind = 0;
+                }
+            }
+            if (q > limit) e2 = 1;
+            sh_pos = q;
+            sh_err = e2;
+        }
+        __syncthreads();
+        if (err) break;
+        err = sh_err;
+        pos = sh_pos;
+        __syncthreads();
+        if (err) break;
+    }
+    if (lane == 0) {
+        if (err) db.error = KNZ_ERR_PROCESS_BLOCK;
+        db.usedBits = pos - db.entropyBit;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+constexpr int DCH = 8;               // chunks per wave
+constexpr u32 RING = 1024;           // payload ring bytes per chunk
+constexpr u32 REFILL_STEPS = 32;     // <= 8 bytes consumed per step -> 256 bytes per interval
+
+__global__ __launch_bounds__(64) void k_ans0_decode(BitSrc src, DecBlock* __restrict__ blocks, int maxChunks, int nSlots,
+                                                    const AnsDecChunk* __restrict__ chunks, u8* const* __restrict__ outPtr)
+{
+    __shared__ u8 f2sAll[DCH * 4096];                          // slot -> symbol
+    __shared__ u32 symAll[DCH * 256];                          // freq | cum << 16
+    __shared__ u32 ringAll[DCH * (RING / 4)];                  // payload bytes, stream order
+    __shared__ u16 cumArr[258];
+    __shared__ int chunkErr[DCH];
+    __shared__ u32 pArr[DCH];                                  // bytes consumed per chunk
+    __shared__ u32 baseArr[DCH];                               // stream offset of ring[0] per chunk (multiple of 512)
+    const int lane = lane_id();
+    const int slotBase = blockIdx.x * DCH;
+    if (lane < DCH) { chunkErr[lane] = 0; pArr[lane] = 0; baseArr[lane] = 0; }
+    __syncthreads();
+
+    // ---- phase 1: tables (ANSRangeDecoder.cpp:113-171) and simple chunk kinds
+    for (int gg = 0; gg < DCH; gg++) {
+        const int slot = slotBase + gg;
+        if (slot >= nSlots) break;
+        const AnsDecChunk& c = chunks[slot];
+        const int b = slot / maxChunks;
+        const int ci = slot - b * maxChunks;
+        if (c.kind == 3 || blocks[b].error) continue;
+        u8* dst = outPtr[b] + (size_t)ci * ENT_CHUNK;
+        const u32 preLen = blocks[b].preLen;
+        if (c.kind == 2) {
+            for (u32 i = lane; i < c.sz; i += 64) dst[i] = (u8)peek_bits(src, c.payloadBit + 8ull * i, 8);
+            continue;
+        }
+        const u32 n = (preLen - (u32)ci * ENT_CHUNK < ENT_CHUNK) ? (preLen - (u32)ci * ENT_CHUNK) : ENT_CHUNK;
+        if (c.kind == 1) {
+            const u32 v4 = 0x01010101u * c.sym;
+            if ((reinterpret_cast<uintptr_t>(dst) & 3) == 0) {
+                for (u32 i = lane; i < (n >> 2); i += 64) reinterpret_cast<u32*>(dst)[i] = v4;
+                for (u32 i = (n & ~3u) + lane; i < n; i += 64) dst[i] = c.sym;
+            } else {
+                for (u32 i = lane; i < n; i += 64) dst[i] = c.sym;
+            }
+            continue;
+        }
+        const u32 lr = c.lr;
+        const u32 scale = 1u << lr;
+        const u32 asz = c.asz;
+        u32 present;
+        if (asz == 256) present = 0xF;
+        else {
+            const u32 m = (u32)lane >> 1;
+            const u64 mb = c.maskBit + 8ull * m;
+            const u32 byte = (mb + 8 <= c.freqBit) ? peek_bits(src, mb, 8) : 0u;
+            present = (lane & 1) ? (byte >> 4) : (byte & 0xF);
+        }
+        const u32 myCount = __popc(present);
+        const u32 incl = wave_incl_scan(myCount);
+        u32 r = incl - myCount;
+        const u32 chk = (asz >= 64) ? 8u : 6u;
+        const u32 llr = (u32)ilog2_u32(lr) + 1u;
+        u32 f[4] = { 0, 0, 0, 0 };
+        u32 lsum = 0;
+        int bad = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if ((present >> k) & 1) {
+                if (r >= 1) {
+                    const u32 g = (r - 1) / chk;
+                    const u32 ge = c.grp[g];
+                    const u32 lm = ge >> 12;
+                    const u32 fv = lm ? peek_bits(src, c.freqBit + (ge & 0xFFF) + llr + (u64)((r - 1) - g * chk) * lm, lm) + 1u : 1u;
+                    if (fv >= scale) bad = 1;
+                    f[k] = fv;
+                    lsum += fv;
+                }
+                r++;
+            }
+        }
+        const u32 sumOthers = wave_sum(lsum);
+        if (scale <= sumOthers) bad = 1;
+        if (!bad) {
+            u32 rr = incl - myCount;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if ((present >> k) & 1) { if (rr == 0) f[k] = scale - sumOthers; rr++; }
+            }
+        }
+        if (__ballot(bad) != 0) { if (lane == 0) chunkErr[gg] = 1; continue; }
+        const u32 tot = f[0] + f[1] + f[2] + f[3];
+        const u32 cincl = wave_incl_scan(tot);
+        u32 cum = cincl - tot;
+        u32* symt = symAll + gg * 256;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u32 fr = f[k];
+            const u32 fclip = (fr >= scale) ? scale - 1 : fr;
+            symt[4 * lane + k] = fclip | (cum << 16);
+            cumArr[4 * lane + k] = (u16)cum;
+            cum += fr;
+        }
+        if (lane == 63) { cumArr[256] = (u16)scale; cumArr[257] = (u16)scale; }
+        __syncthreads();
+        // slot -> symbol: lane fills slots [64*lane, 64*lane+64) ; start symbol by binary search on cum[]
+        {
+            u8* f2s = f2sAll + gg * 4096;
+            for (u32 base = (u32)lane * 64; base < scale; base += 4096) {
+                // largest s with cum[s] <= base (among all 256 entries; absent symbols have zero width)
+                u32 lo = 0, hi = 255;
+                while (lo < hi) {
+                    const u32 mid = (lo + hi + 1) >> 1;
+                    if (cumArr[mid] <= base) lo = mid; else hi = mid - 1;
+                }
+                u32 s = lo;
+                // skip zero-width symbols that share the same cum value (take the one that really covers `base`)
+                u32 t = base;
+                u32 word = 0;
+                for (u32 k = 0; k < 64; k++, t++) {
+                    while (s < 255 && cumArr[s + 1] <= t) s++;
+                    word |= s << (8 * (k & 3));
+                    if ((k & 3) == 3) { *reinterpret_cast<u32*>(f2s + base + (k & ~3u)) = word; word = 0; }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+
+    // ---- phase 2
+    const int g = lane >> 2;              // lanes 0..31 decode, 32..63 only help with refills
+    const int j = lane & 3;
+    bool act = false;
+    u32 n = 0, sz = 0, lr = ANS_LR;
+    u64 payBit = 0;
+    u8* dst = nullptr;
+    u32 st = 0;
+    if (g < DCH) {
+        const int slot = slotBase + g;
+        if (slot < nSlots) {
+            const int b = slot / maxChunks;
+            const int ci = slot - b * maxChunks;
+            const AnsDecChunk& c = chunks[slot];
+            if (c.kind == 0 && !blocks[b].error && !chunkErr[g]) {
+                act = true;
+                const u32 preLen = blocks[b].preLen;
+                n = (preLen - (u32)ci * ENT_CHUNK < ENT_CHUNK) ? (preLen - (u32)ci * ENT_CHUNK) : ENT_CHUNK;
+                dst = outPtr[b] + (size_t)ci * ENT_CHUNK;
+                payBit = c.payloadBit; sz = c.sz; lr = c.lr;
+                st = c.st[j];
+            }
+        }
+    }
+    const u64 anyAct = __ballot(act);
+    if (anyAct == 0) {
+        if (lane < DCH && chunkErr[lane] && slotBase + lane < nSlots) blocks[(slotBase + lane) / maxChunks].error = KNZ_ERR_PROCESS_BLOCK;
+        return;
+    }
+    // chunk payload descriptors visible to all lanes (for the cooperative ring refills)
+    __shared__ u64 payBitArr[DCH];
+    __shared__ u32 actArr[DCH];
+    if (g < DCH && j == 0) { payBitArr[g] = payBit; actArr[g] = act ? 1u : 0u; }
+    __syncthreads();
+    // initial fill: ring[c][0..1024) = stream bytes [0, 1024) ; 8 chunks * 256 words / 64 lanes
+    for (int idx = lane; idx < DCH * (int)(RING / 4); idx += 64) {
+        const int cc = idx / (int)(RING / 4);
+        const int w = idx - cc * (int)(RING / 4);
+        ringAll[idx] = actArr[cc] ? bswap32(peek_bits(src, payBitArr[cc] + 32ull * w, 32)) : 0u;
+    }
+    __syncthreads();
+
+    const u32 mask = (1u << lr) - 1;
+    const u32 count4 = n & ~3u;
+    const u32 steps = act ? (count4 >> 2) : 0;
+    const u32 maxSteps = wave_max(steps);
+    const u8* f2s = f2sAll + (g < DCH ? g : 0) * 4096;
+    const u32* symt = symAll + (g < DCH ? g : 0) * 256;
+    const u8* ring = reinterpret_cast<const u8*>(ringAll + (g < DCH ? g : 0) * (RING / 4));
+    u32 p = 0;
+    const u32 grpShift = (u32)(lane & ~3);
+    const u32 higherMask = (0xFu << (j + 1)) & 0xFu;
+    const bool aligned4 = act && ((reinterpret_cast<uintptr_t>(dst) & 3) == 0);
+    u32 acc = 0;                          // my symbols of the last 4 steps (step k in byte k)
+
+    for (u32 s0 = 0; s0 < maxSteps; s0 += REFILL_STEPS) {
+        const u32 s1 = (s0 + REFILL_STEPS < maxSteps) ? s0 + REFILL_STEPS : maxSteps;
+        for (u32 s = s0; s < s1; s++) {
+            const bool on = s < steps;
+            const u32 slotv = st & mask;
+            const u32 sym = f2s[slotv];
+            const u32 e = symt[sym];
+            acc |= sym << (8 * (s & 3));
+            if (on) st = (e & 0xFFFF) * (st >> lr) + slotv - (e >> 16);
+            const bool flag = on && (st < ANS_TOP);
+            const u64 m = __ballot(flag);
+            const u32 grp = (u32)(m >> grpShift) & 0xF;
+            if (flag) {
+                const u32 off = (p + 2 * __popc(grp & higherMask)) & (RING - 1);
+                const u32 v = *reinterpret_cast<const u16*>(ring + off);       // p is even: aligned
+                st = (st << 16) | ((v & 0xFF) << 8) | (v >> 8);
+            }
+            p += 2 * __popc(grp);
+            if ((s & 3) == 3) {
+                // 4x4 transpose among the 4 lanes of the chunk: lane k stores the dword of step s-3+k
+                const int base = lane & ~3;
+                const u32 a3 = (u32)__shfl((int)acc, base + 3, 64);
+                const u32 a2 = (u32)__shfl((int)acc, base + 2, 64);
+                const u32 a1 = (u32)__shfl((int)acc, base + 1, 64);
+                const u32 a0 = (u32)__shfl((int)acc, base + 0, 64);
+                const u32 sh = 8u * (u32)j;
+                const u32 word = ((a3 >> sh) & 0xFF) | (((a2 >> sh) & 0xFF) << 8) | (((a1 >> sh) & 0xFF) << 16) | (((a0 >> sh) & 0xFF) << 24);
+                const u32 stepIdx = (s & ~3u) + (u32)j;
+                if (act && stepIdx < steps) {
+                    if (aligned4) reinterpret_cast<u32*>(dst)[stepIdx] = word;
+                    else { dst[4 * stepIdx] = (u8)word; dst[4 * stepIdx + 1] = (u8)(word >> 8); dst[4 * stepIdx + 2] = (u8)(word >> 16); dst[4 * stepIdx + 3] = (u8)(word >> 24); }
+                }
+                acc = 0;
+            }
+        }
+        if (s1 >= maxSteps) break;
+        // ---- cooperative refill: a chunk that consumed past base+512 gets the next 512 bytes
+        if (g < DCH && j == 0) pArr[g] = p;
+        __syncthreads();
+        for (int cc = 0; cc < DCH; cc++) {
+            if (!actArr[cc]) continue;
+            const u32 pc = pArr[cc];
+            u32 bs0 = baseArr[cc];
+            if (pc >= bs0 + 512) {
+                // stream bytes [bs0 + 1024, bs0 + 1536) replace ring bytes [bs0 % 1024, +512)
+                for (int w = lane; w < 128; w += 64) {
+                    const u32 streamOff = bs0 + RING + 4u * (u32)w;
+                    ringAll[cc * (RING / 4) + ((streamOff & (RING - 1)) >> 2)] = bswap32(peek_bits(src, payBitArr[cc] + 8ull * streamOff, 32));
+                }
+                if (lane == 0) baseArr[cc] = bs0 + 512;
+            }
+        }
+        __syncthreads();
+    }
+    // steps not a multiple of 4 cannot happen (count4 / 4 steps each store via the transpose when (s&3)==3):
+    // steps counts groups of 4 symbols, every step writes 4 bytes -> the transpose above handles whole quads
+    // of steps; flush a partial quad here
+    {
+        const u32 rem = maxSteps & 3;
+        if (rem) {
+            const int base = lane & ~3;
+            const u32 a3 = (u32)__shfl((int)acc, base + 3, 64);
+            const u32 a2 = (u32)__shfl((int)acc, base + 2, 64);
+            const u32 a1 = (u32)__shfl((int)acc, base + 1, 64);
+            const u32 a0 = (u32)__shfl((int)acc, base + 0, 64);
+            const u32 sh = 8u * (u32)j;
+            const u32 word = ((a3 >> sh) & 0xFF) | (((a2 >> sh) & 0xFF) << 8) | (((a1 >> sh) & 0xFF) << 16) | (((a0 >> sh) & 0xFF) << 24);
+            const u32 stepIdx = (maxSteps & ~3u) + (u32)j;
+            if (act && stepIdx < steps) {
+                dst[4 * stepIdx] = (u8)word; dst[4 * stepIdx + 1] = (u8)(word >> 8); dst[4 * stepIdx + 2] = (u8)(word >> 16); dst[4 * stepIdx + 3] = (u8)(word >> 24);
+            }
+        }
+    }
+    if (act && j == 0) {
+        const u32 tail = n - count4;
+        for (u32 t = 0; t < tail; t++) dst[count4 + t] = (u8)peek_bits(src, payBit + 8ull * (p + t), 8);
+        if (p + tail != sz) chunkErr[g] = 1;          // ANSRangeDecoder.cpp:291
+    }
+    __syncthreads();
+    if (lane < DCH && chunkErr[lane] && slotBase + lane < nSlots) blocks[(slotBase + lane) / maxChunks].error = KNZ_ERR_PROCESS_BLOCK;
+}
+
+void launch_ans0_decode(hipStream_t s, BitSrc src, DecBlock* blocks, int nBlocks, int maxChunks, void* chunkMeta, u8* const* outPtr)
+{
+    AnsDecChunk* chunks = reinterpret_cast<AnsDecChunk*>(chunkMeta);
+    const int nSlots = nBlocks * maxChunks;
+    { KScope ks_("k_ans0_scan"); hipLaunchKernelGGL(k_ans0_scan, dim3(nBlocks), dim3(64), 0, s, src, blocks, nBlocks, maxChunks, chunks); }
+    { KScope ks_("k_ans0_decode"); hipLaunchKernelGGL(k_ans0_decode, dim3((nSlots + DCH - 1) / DCH), dim3(64), 0, s, src, blocks, maxChunks, nSlots, chunks, outPtr); }
+}
+
+size_t ans0_dec_chunk_bytes() { return sizeof(AnsDecChunk); }
+
+}  // namespace knz

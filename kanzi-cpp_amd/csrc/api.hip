@@ -359,7 +359,7 @@ static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t 
         if (!transform_supported(tok[i])) return fail(c, KNZ_ERR_INVALID_CODEC, "transform id %d not implemented on device", tok[i]);
     if (!entropy_supported(p->entropy_type)) return fail(c, KNZ_ERR_INVALID_CODEC, "entropy id %d not implemented on device", p->entropy_type);
     if (nTok > 4) return fail(c, KNZ_ERR_INVALID_CODEC, "more than 4 transforms not supported");
-    if (p->checksum_bits != 0) return fail(c, KNZ_ERR_INVALID_PARAM, "block checksums not implemented on device");
+    if (p->checksum_bits != 0 && p->checksum_bits != 32 && p->checksum_bits != 64) return fail(c, KNZ_ERR_INVALID_PARAM, "checksum must be 0, 32 or 64");
     hipStream_t s = c->stream;
 
     const int nBlocks = (n == 0) ? 0 : (int)((n + bs - 1) / bs);
@@ -395,6 +395,13 @@ static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t 
     if (int r = seq_alloc(c, nBlocks, S, realStages, scratch, &w)) return r;
     w.a.origLen = d_origLen;
     launch_init_blocks(s, n, bs, nBlocks, d_origLen, w.a.len);
+    // block checksums of the ORIGINAL bytes (io/CompressedOutputStream.cpp:675-682)
+    u64* d_sums = nullptr;
+    if (p->checksum_bits) {
+        if (int r = ws_get(c, "sums", sizeof(u64) * nBlocks, (void**)&d_sums)) return r;
+        launch_block_ptrs(s, d_in, bs, nBlocks, w.d_viewPtr);
+        launch_xxhash(s, w.d_viewPtr, d_origLen, nBlocks, p->checksum_bits, d_sums);
+    }
 
     // destination capacities the reference would present (io/CompressedOutputStream.cpp:141,461-462,733-739):
     // block i runs on buffer slot i % jobs; "data" of slot 0 is max(bs + bs/8, 256 KiB), of the others
@@ -490,7 +497,7 @@ static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t 
         HIPCHK(c, hipMemcpyAsync(d_pro, prologue, (prologueBits + 7) / 8, hipMemcpyHostToDevice, s));
         launch_put_prologue(s, reinterpret_cast<u32*>(d_out), d_pro, prologueBits);
     }
-    launch_assemble(s, d_desc, d_info, d_blockLen, d_origLen, d_skip, nullptr, d_tmp, nBlocks, maxChunks, entChunk, fp,
+    launch_assemble(s, d_desc, d_info, d_blockLen, d_origLen, d_skip, d_sums, d_tmp, nBlocks, maxChunks, entChunk, fp,
                     reinterpret_cast<u32*>(d_out));
     HIPCHK(c, hipGetLastError());
     if (outBits) {
@@ -527,7 +534,7 @@ static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_
     for (int i = 0; i < nTok; i++)
         if (!transform_supported(tok[i])) return fail(c, KNZ_ERR_INVALID_CODEC, "transform id %d not implemented on device", tok[i]);
     if (!entropy_supported(p->entropy_type)) return fail(c, KNZ_ERR_INVALID_CODEC, "entropy id %d not implemented on device", p->entropy_type);
-    if (p->checksum_bits != 0) return fail(c, KNZ_ERR_INVALID_PARAM, "block checksums not implemented on device");
+    if (p->checksum_bits != 0 && p->checksum_bits != 32 && p->checksum_bits != 64) return fail(c, KNZ_ERR_INVALID_PARAM, "checksum must be 0, 32 or 64");
     hipStream_t s = c->stream;
 
     BitSrc src;
@@ -599,6 +606,11 @@ static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_
             if (int r = run_inverse_stage(c, s, tok[i], st)) return r;
             launch_seq_inv_commit(s, w.a, d_blocks, nBlocks, i, tok[i]);
         }
+    }
+    if (p->checksum_bits && framing) {
+        u64* d_sums;
+        if (int r = ws_get(c, "sums", sizeof(u64) * nBlocks, (void**)&d_sums)) return r;
+        launch_verify_checksums(s, d_blocks, nBlocks, p->checksum_bits, d_out, outStride, w.d_viewPtr, w.a.alen, d_sums);
     }
     HIPCHK(c, hipGetLastError());
     // results

@@ -69,6 +69,12 @@ void launch_srt_inverse(hipStream_t s, const XfStage& st);
 void launch_rlt_forward(hipStream_t s, const XfStage& st);
 void launch_rlt_inverse(hipStream_t s, const XfStage& st);
 
+// xxhash.hip
+void launch_xxhash(hipStream_t s, const u8* const* ptr, const u32* lens, int nBlocks, int bits, u64* out);
+void launch_block_ptrs(hipStream_t s, const u8* base, u64 stride, int nBlocks, const u8** ptr);
+void launch_verify_checksums(hipStream_t s, DecBlock* blocks, int nBlocks, int bits, const u8* out, u64 outStride, const u8** ptrScratch,
+                             u32* lenScratch, u64* sumScratch);
+
 // sequence.hip : TransformSequence bookkeeping on the device
 struct SeqArrays {
     u8* where;               // 0 = caller buffer, 1 = workspace A, 2 = workspace B

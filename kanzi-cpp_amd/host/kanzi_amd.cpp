@@ -650,7 +650,6 @@ CompressedOutputStream::CompressedOutputStream(std::ostream& os, int tasks, cons
     if (blockSize < 1024) throw std::invalid_argument("The block size must be at least 1024");
     if ((blockSize & -16) != blockSize) throw std::invalid_argument("The block size must be a multiple of 16");
     if ((checksum != 0) && (checksum != 32) && (checksum != 64)) throw std::invalid_argument("The block checksum size must be 0, 32 or 64");
-    if (checksum != 0) throw std::invalid_argument("Block checksums have no device kernel yet");
     _jobs = tasks; _blockSize = blockSize; _checksum = checksum;
     _entropyType = EntropyEncoderFactory::getType(entropy.c_str());
     _transformType = TransformFactory<byte>::getType(transform.c_str());
@@ -836,7 +835,6 @@ void CompressedInputStream::readHeader()
     _comp.resize(_comp.size() - 8);
     _consumedBits += pos - _compBit;
     _compBit = pos;
-    if (_checksum != 0) throw IOException("Block checksums have no device kernel yet", Error::ERR_INVALID_CODEC);
 }
 
 bool CompressedInputStream::decodeBatch()

@@ -189,7 +189,7 @@ def test_jobs_capacity_model(hip, oracle):
 def test_stream_golden(hip, golden):
     n = 0
     for rec in golden["streams"]:
-        if not stream_supported(rec["transform"], rec["entropy"]) or rec["checksum"]:
+        if not stream_supported(rec["transform"], rec["entropy"]):
             continue
         d = vectors.make(tuple(rec["input"]))
         out, bits, hb = gpu_compress(hip, d, rec["transform"], rec["entropy"], rec["block"], rec["checksum"],
@@ -239,3 +239,24 @@ def test_sharded_runs_concatenate_to_single_stream(hip, oracle):
         got = sh.concat_bit_runs(runs)[0]
         rc, ref = oracle.compress(d, t, e, bs, orig_size=len(d), jobs=jobs)
         assert got == ref, (t, e, jobs)
+
+
+def test_block_checksums(hip, oracle):
+    # -x32 / -x64 (util/XXHash.hpp); a corrupted payload must be rejected with ERR_CRC_CHECK (19)
+    from kanzi_amd.hipapi import KnzError
+    d = vectors.make(("mixed", 300000, 4))
+    for ck in (32, 64):
+        for t, e, bs in [("NONE", "ANS0", 65536), ("BWT+MTFT+ZRLT", "HUFFMAN", 131072)]:
+            rc, ref = oracle.compress(d, t, e, bs, checksum=ck, headerless=1)
+            out, bits, hb = gpu_compress(hip, d, t, e, bs, checksum=ck, headerless=1)
+            assert out == ref, (ck, t, e)
+            assert gpu_decompress(hip, ref, t, e, bs, len(d), 0, checksum=ck) == d
+    # flip one stored checksum bit of block 0: 5-bit lw-3 field gives the width of the length field
+    rc, ref = oracle.compress(d, "NONE", "NONE", 65536, checksum=32, headerless=1)
+    bad = bytearray(ref)
+    lw = 3 + (bad[0] >> 3)
+    ck_bit = 5 + lw + 8 + 24                                   # mode byte + 3-byte length (65536 -> dataSize 3)
+    bad[(ck_bit + 7) // 8] ^= 0x10
+    with pytest.raises(KnzError) as ei:
+        gpu_decompress(hip, bytes(bad), "NONE", "NONE", 65536, len(d), 0, checksum=32)
+    assert ei.value.code == 19
