@@ -353,20 +353,63 @@ __global__ __launch_bounds__(256) void k_bwt_i_keys(BwtView v, const BwtHdr* __r
     }
 }
 
-// node j (global slot) : next[j], dist[j]; the node holding BWT index 0 is the end of the text
-__global__ __launch_bounds__(256) void k_bwt_i_links(const BwtHdr* __restrict__ hd, const u32* __restrict__ base, int nBlocks, u32 total,
+// ---- list ranking with random splitters (Helman-JaJa style) ------------------------------------
+// Node j = F-position (global slot). rec[j] = next node (31 bits) | "next is a splitter" (bit 31) | symbol << 32.
+// The node holding BWT index 0 is the end of the text (self loop). Splitters: a pseudo-random 1/64 of the
+// nodes + every block's chain head + the terminals. Each splitter walks to the next splitter (sub-list
+// length), the short splitter list is ranked by pointer jumping, then each splitter walks its sub-list
+// again and writes the text. Two O(n) random-access passes instead of log2(n) of them.
+constexpr int SPLIT_LOG = 6;
+
+__device__ __forceinline__ bool hash_split(u32 j) { return ((j * 2654435761u) >> (32 - SPLIT_LOG)) == 0; }
+
+__global__ __launch_bounds__(256) void k_bwt_i_links(const BwtHdr* __restrict__ hd, const u32* __restrict__ base, u32 total,
                                                      const u32* __restrict__ keysSorted, const u32* __restrict__ valsSorted,
-                                                     u32* __restrict__ next, u32* __restrict__ dist)
+                                                     u64* __restrict__ rec, u32* __restrict__ flags)
 {
     const u32 j = blockIdx.x * 256 + threadIdx.x;
     if (j >= total) return;
-    const u32 b = keysSorted[j] >> 8;
+    const u32 key = keysSorted[j];
+    const u32 b = key >> 8;
     const u32 i = valsSorted[j];
     const u32 pIdx = hd[b].pIdx;
-    if (i == 0) { next[j] = j; dist[j] = 0; return; }
-    const u32 t = (i < pIdx) ? i - 1 : i;                   // BWT.cpp:203-215
-    next[j] = base[b] + t;
-    dist[j] = 1;
+    u32 nx;
+    if (i == 0) nx = j;                                       // end of text
+    else nx = base[b] + ((i < pIdx) ? i - 1 : i);            // BWT.cpp:203-215
+    rec[j] = (u64)nx | ((u64)(key & 0xFF) << 32);
+    u32 f = (hash_split(j) || i == 0) ? 1u : 0u;
+    if (j == base[b] + pIdx - 1) f = 1;                      // chain head of the block
+    flags[j] = f;
+}
+
+__global__ __launch_bounds__(256) void k_bwt_i_fold(u64* __restrict__ rec, const u32* __restrict__ flags, u32 total)
+{
+    const u32 j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= total) return;
+    const u64 r = rec[j];
+    const u32 nx = (u32)r & 0x7FFFFFFFu;
+    if (flags[nx]) rec[j] = r | 0x80000000ull;
+}
+
+// walk 1: sub-list length and successor splitter (compact indices)
+__global__ __launch_bounds__(256) void k_bwt_i_walk1(const u64* __restrict__ rec, const u32* __restrict__ splitNode, const u32* __restrict__ scanIdx,
+                                                     u32 count, u32 limit, u32* __restrict__ succ, u32* __restrict__ dist)
+{
+    const u32 c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= count) return;
+    u32 node = splitNode[c];
+    u64 r = rec[node];
+    if (((u32)r & 0x7FFFFFFFu) == node) { succ[c] = c; dist[c] = 0; return; }    // terminal
+    u32 len = 0;
+    while (true) {
+        len++;
+        const u32 nx = (u32)r & 0x7FFFFFFFu;
+        if ((r >> 31) & 1) { succ[c] = scanIdx[nx]; break; }
+        if (len > limit) { succ[c] = c; break; }              // malformed input (cycle without splitter)
+        node = nx;
+        r = rec[node];
+    }
+    dist[c] = len;
 }
 
 __global__ __launch_bounds__(256) void k_bwt_i_jump(const u32* __restrict__ nextIn, const u32* __restrict__ distIn, u32 total,
@@ -379,15 +422,26 @@ __global__ __launch_bounds__(256) void k_bwt_i_jump(const u32* __restrict__ next
     nextOut[j] = nextIn[nx];
 }
 
-__global__ __launch_bounds__(256) void k_bwt_i_scatter(BwtView v, const BwtHdr* __restrict__ hd, const u32* __restrict__ base, u32 total,
-                                                       const u32* __restrict__ keysSorted, const u32* __restrict__ dist)
+// walk 2: every splitter writes the text bytes of its sub-list
+__global__ __launch_bounds__(256) void k_bwt_i_walk2(BwtView v, const BwtHdr* __restrict__ hd, const u64* __restrict__ rec,
+                                                     const u32* __restrict__ splitNode, const u32* __restrict__ keysSorted,
+                                                     const u32* __restrict__ dEnd, u32 count, u32 limit)
 {
-    const u32 j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= total) return;
-    const u32 b = keysSorted[j] >> 8;
+    const u32 c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= count) return;
+    u32 node = splitNode[c];
+    const u32 b = keysSorted[node] >> 8;
     const u32 n = hd[b].n;
-    const u32 d = dist[j];
-    if (d < n) v.dst[b][n - 1 - d] = (u8)(keysSorted[j] & 0xFF);
+    u8* dst = v.dst[b];
+    u32 d = dEnd[c];
+    u32 steps = 0;
+    while (true) {
+        const u64 r = rec[node];
+        if (d < n) dst[n - 1 - d] = (u8)(r >> 32);
+        if (((r >> 31) & 1) || d == 0 || ++steps > limit) break;
+        node = (u32)r & 0x7FFFFFFFu;
+        d--;
+    }
 }
 
 __global__ void k_bwt_i_tiny(BwtView v, const BwtHdr* __restrict__ hd)
@@ -400,26 +454,34 @@ __global__ void k_bwt_i_tiny(BwtView v, const BwtHdr* __restrict__ hd)
 
 size_t bwt_inverse_scratch_bytes(int nBlocks, u32 VS, size_t total)
 {
-    size_t primSort = 0;
+    size_t primSort = 0, primScan = 0;
     rocprim::radix_sort_pairs(nullptr, primSort, (u32*)nullptr, (u32*)nullptr, (u32*)nullptr, (u32*)nullptr, total, 0u, 32u, (hipStream_t)0);
-    return 2 * align256(4 * total) + 6 * align256(4 * total) + align256(sizeof(BwtHdr) * (size_t)nBlocks) + align256(4ull * (nBlocks + 2)) +
-           align256(primSort) + 8192;
+    rocprim::exclusive_scan(nullptr, primScan, (u32*)nullptr, (u32*)nullptr, 0u, total, rocprim::plus<u32>(), (hipStream_t)0);
+    const size_t prim = primSort > primScan ? primSort : primScan;
+    return 4 * align256(4 * total) + align256(8 * total) + 2 * align256(4 * total) + 6 * align256(4 * (total / 8 + 4096 + 3 * (size_t)nBlocks)) +
+           align256(sizeof(BwtHdr) * (size_t)nBlocks) + align256(4ull * (nBlocks + 2)) + align256(prim) + 16384;
 }
 
 int launch_bwt_inverse(hipStream_t s, const XfStage& st, void* scratch, size_t scratchBytes, u32* h_pinned)
 {
     BwtView v; v.src = st.src; v.dst = st.dst; v.len = st.len; v.cap = st.cap; v.VS = st.maxLen; v.nBlocks = st.nBlocks;
     const size_t maxTotal = (size_t)st.nBlocks * v.VS;
+    if (maxTotal >= (1ull << 31)) return -2;                 // node ids share a word with the splitter flag
+    const size_t maxSplit = maxTotal / 8 + 4096 + 3 * (size_t)st.nBlocks;
     u8* q = reinterpret_cast<u8*>(scratch);
     auto take = [&](size_t sz) { u8* r = q; q += align256(sz); return r; };
     u32* keysA = (u32*)take(4 * maxTotal); u32* keysB = (u32*)take(4 * maxTotal);
     u32* valsA = (u32*)take(4 * maxTotal); u32* valsB = (u32*)take(4 * maxTotal);
-    u32* nextA = (u32*)take(4 * maxTotal); u32* nextB = (u32*)take(4 * maxTotal);
-    u32* distA = (u32*)take(4 * maxTotal); u32* distB = (u32*)take(4 * maxTotal);
+    u64* rec = (u64*)take(8 * maxTotal);
+    u32* flags = (u32*)take(4 * maxTotal); u32* scanIdx = (u32*)take(4 * maxTotal);
+    u32* splitNode = (u32*)take(4 * maxSplit);
+    u32* nA = (u32*)take(4 * maxSplit); u32* nB = (u32*)take(4 * maxSplit);
+    u32* dA = (u32*)take(4 * maxSplit); u32* dB = (u32*)take(4 * maxSplit);
+    u32* spare = (u32*)take(4 * maxSplit); (void)spare;
     BwtHdr* hd = (BwtHdr*)take(sizeof(BwtHdr) * (size_t)st.nBlocks);
     u32* base = (u32*)take(4ull * (st.nBlocks + 2));
     void* prim = q;
-    size_t primBytes = scratchBytes - (size_t)(q - reinterpret_cast<u8*>(scratch));
+    const size_t primBytes = scratchBytes - (size_t)(q - reinterpret_cast<u8*>(scratch));
     { KScope ks_("k_bwt_i_header"); hipLaunchKernelGGL(k_bwt_i_header, dim3(1), dim3(64), 0, s, v, hd, base, st.ok, st.newLen); }
     if (hipMemcpyAsync(h_pinned, base + st.nBlocks, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
     if (hipStreamSynchronize(s) != hipSuccess) return -1;
@@ -432,14 +494,23 @@ int launch_bwt_inverse(hipStream_t s, const XfStage& st, void* scratch, size_t s
     int bbits = 0;
     while ((1 << bbits) < st.nBlocks) bbits++;
     { KScope ks_("rocprim_sort_symbols"); if (rocprim::radix_sort_pairs(prim, pb, keysA, keysB, valsA, valsB, (size_t)total, 0u, (unsigned)(8 + bbits), s) != hipSuccess) return -1; }
-    { KScope ks_("k_bwt_i_links"); hipLaunchKernelGGL(k_bwt_i_links, GRID1(total), hd, base, st.nBlocks, total, keysB, valsB, nextA, distA); }
-    u32 maxN = v.VS;
-    u32* nA = nextA; u32* nB = nextB; u32* dA = distA; u32* dB = distB;
-    for (u32 span = 1; span < maxN; span <<= 1) {
-        { KScope ks_("k_bwt_i_jump"); hipLaunchKernelGGL(k_bwt_i_jump, GRID1(total), nA, dA, total, nB, dB); }
+    { KScope ks_("k_bwt_i_links"); hipLaunchKernelGGL(k_bwt_i_links, GRID1(total), hd, base, total, keysB, valsB, rec, flags); }
+    { KScope ks_("k_bwt_i_fold"); hipLaunchKernelGGL(k_bwt_i_fold, GRID1(total), rec, flags, total); }
+    pb = primBytes;
+    { KScope ks_("rocprim_scan_sum"); if (rocprim::exclusive_scan(prim, pb, flags, scanIdx, 0u, (size_t)total, rocprim::plus<u32>(), s) != hipSuccess) return -1; }
+    { KScope ks_("k_compact"); hipLaunchKernelGGL(k_compact, GRID1(total), flags, scanIdx, (const u32*)nullptr, total, splitNode); }
+    hipMemcpyAsync(h_pinned, scanIdx + (total - 1), 4, hipMemcpyDeviceToHost, s);
+    hipMemcpyAsync(h_pinned + 1, flags + (total - 1), 4, hipMemcpyDeviceToHost, s);
+    if (hipStreamSynchronize(s) != hipSuccess) return -1;
+    const u32 count = h_pinned[0] + h_pinned[1];
+    if (count == 0 || count > maxSplit) return -3;
+    const u32 limit = v.VS + 1;
+    { KScope ks_("k_bwt_i_walk1"); hipLaunchKernelGGL(k_bwt_i_walk1, GRID1(count), rec, splitNode, scanIdx, count, limit, nA, dA); }
+    for (u32 span = 1; span < count; span <<= 1) {
+        { KScope ks_("k_bwt_i_jump"); hipLaunchKernelGGL(k_bwt_i_jump, GRID1(count), nA, dA, count, nB, dB); }
         std::swap(nA, nB); std::swap(dA, dB);
     }
-    { KScope ks_("k_bwt_i_scatter"); hipLaunchKernelGGL(k_bwt_i_scatter, GRID1(total), v, hd, base, total, keysB, dA); }
+    { KScope ks_("k_bwt_i_walk2"); hipLaunchKernelGGL(k_bwt_i_walk2, GRID1(count), v, hd, rec, splitNode, keysB, dA, count, limit); }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

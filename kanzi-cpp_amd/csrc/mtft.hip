@@ -1,0 +1,290 @@
+// MTFT (move-to-front) on gfx950, batched over all blocks of a call.
+//
+// Reference being replaced: transform/SBRT.cpp:46-97 (forward), :99-145 (inverse) with MODE_MTF
+// (:28-31), i.e. the classic move-to-front over the identity initial list.
+//
+// The CPU loop is one dependency chain per block. Here a block is cut into 4 KiB tiles and
+//   forward   the recency list at a tile start is recovered without running the chain: symbols
+//             ordered by last occurrence before the tile (per-tile last-occurrence table, exclusive
+//             prefix-max over tiles), never-seen symbols in ascending order (rank-by-counting sort);
+//   inverse   a tile's effect on the list is a permutation of list POSITIONS that does not depend on
+//             the list's content, so every tile is decoded symbolically (from the identity list),
+//             the permutations are prefix-composed per block, and a parallel gather resolves ids.
+// Inside a tile ONE WAVE HOLDS THE WHOLE 256-ENTRY LIST IN REGISTERS, 4 entries per lane packed in a
+// dword: finding a symbol is a SWAR zero-byte test + ballot, move-to-front is one cross-lane shift.
+// Cost per byte is therefore independent of the rank (the CPU loop, and a lane-serial GPU loop, pay
+// O(rank)); many waves per SIMD hide the short dependent chain.
+#include "common.hpp"
+#include "stages.hpp"
+
+namespace knz {
+
+constexpr u32 MT = 4096;            // bytes per tile (one wave)
+
+struct XfView {
+    const u8* const* src;
+    u8* const* dst;
+    const u32* len;
+    const u32* cap;
+};
+
+// rotate list positions [0, rank] right by one and put `front` at position 0.
+// w: my 4 entries (position 4*lane in byte 0). rank = 4*lane0 + byteIdx (uniform).
+__device__ __forceinline__ u32 mtf_rotate(u32 w, int lane, int lane0, int byteIdx, u32 front)
+{
+    const u32 prev = (u32)__shfl_up((int)w, 1, 64);
+    const u32 carry = (lane == 0) ? front : (prev >> 24);
+    const u32 shifted = (w << 8) | carry;
+    if (lane < lane0) return shifted;
+    if (lane == lane0) {
+        const u32 mask = (byteIdx == 3) ? 0xFFFFFFFFu : ((1u << (8 * (byteIdx + 1))) - 1u);
+        return (shifted & mask) | (w & ~mask);
+    }
+    return w;
+}
+
+// per tile: last occurrence (position+1) of each symbol -> tileLast[b][t][256]
+__global__ __launch_bounds__(64) void k_mtf_f_last(XfView v, int perTiles, u32* __restrict__ tileLast)
+{
+    const int b = blockIdx.y;
+    const u32 n = (v.len[b] <= v.cap[b]) ? v.len[b] : 0;
+    const u32 tbase = blockIdx.x * MT;
+    if (tbase >= n) return;
+    const u8* s = v.src[b];
+    __shared__ u32 last[256];
+    const int lane = lane_id();
+    for (int i = lane; i < 256; i += 64) last[i] = 0;
+    __syncthreads();
+    const u32 end = (tbase + MT < n) ? tbase + MT : n;
+    for (u32 i = tbase + lane; i < end; i += 64) atomicMax(&last[s[i]], i + 1);
+    __syncthreads();
+    u32* o = tileLast + ((size_t)b * perTiles + blockIdx.x) * 256;
+    for (int i = lane; i < 256; i += 64) o[i] = last[i];
+}
+
+// exclusive prefix max over the tiles of a block, one thread per symbol (loads are independent of the carry)
+__global__ __launch_bounds__(256) void k_mtf_f_scan(u32* __restrict__ tileLast, int perTiles, const u32* __restrict__ lens)
+{
+    const int b = blockIdx.x;
+    const u32 cnt = (lens[b] + MT - 1) / MT;
+    u32* p = tileLast + (size_t)b * perTiles * 256 + threadIdx.x;
+    u32 cur = 0;
+    for (u32 t = 0; t < cnt; t++) {
+        const u32 x = p[(size_t)t * 256];
+        p[(size_t)t * 256] = cur;
+        cur = x > cur ? x : cur;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_mtf_f_rank(XfView v, int perTiles, const u32* __restrict__ tileState)
+{
+    const int b = blockIdx.y;
+    const u32 n = (v.len[b] <= v.cap[b]) ? v.len[b] : 0;
+    const u32 tbase = blockIdx.x * MT;
+    if (tbase >= n) return;
+    const u8* s = v.src[b];
+    u8* d = v.dst[b];
+    __shared__ u32 keys[256];
+    __shared__ u32 listw[64];
+    const int lane = lane_id();
+    // start list: symbols by last occurrence desc, never-seen symbols ascending
+    const u32* st = tileState + ((size_t)b * perTiles + blockIdx.x) * 256;
+    for (int i = lane; i < 256; i += 64) keys[i] = st[i];
+    __syncthreads();
+    u8* listb = reinterpret_cast<u8*>(listw);
+    for (int c = lane; c < 256; c += 64) {
+        const u32 kc = keys[c];
+        u32 r = 0;
+        for (int q = 0; q < 256; q++) {
+            const u32 kq = keys[q];
+            r += (kq > kc || (kq == kc && q < c)) ? 1u : 0u;
+        }
+        listb[r] = (u8)c;
+    }
+    __syncthreads();
+    u32 w = listw[lane];
+    u32 front = (u32)__builtin_amdgcn_readfirstlane((int)w) & 0xFF;   // symbol at list position 0 (uniform)
+    const u32 cnt = (n - tbase < MT) ? (n - tbase) : MT;
+    const u8* src = s + tbase;
+    u8* dst = d + tbase;
+    const bool al = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 3) == 0;
+    u32 k = 0;
+    for (; k + 4 <= cnt; k += 4) {
+        u32 in4;
+        if (al) in4 = *reinterpret_cast<const u32*>(src + k);
+        else in4 = (u32)src[k] | ((u32)src[k + 1] << 8) | ((u32)src[k + 2] << 16) | ((u32)src[k + 3] << 24);
+        in4 = (u32)__builtin_amdgcn_readfirstlane((int)in4);
+        u32 out4 = 0;
+        if (in4 != front * 0x01010101u) {       // runs (the common case after a BWT) keep the list unchanged: rank 0
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const u32 c = (in4 >> (8 * q)) & 0xFF;
+            if (c == front) continue;
+            front = c;
+            const u32 x = w ^ (c * 0x01010101u);
+            const u32 hz = (x - 0x01010101u) & ~x & 0x80808080u;
+            const u64 m = __ballot(hz != 0);
+            const int lane0 = __ffsll((long long)m) - 1;
+            const u32 hz0 = (u32)__builtin_amdgcn_readlane((int)hz, lane0);
+            const int byteIdx = (__ffs((int)hz0) - 1) >> 3;
+            out4 |= (u32)(4 * lane0 + byteIdx) << (8 * q);
+            w = mtf_rotate(w, lane, lane0, byteIdx, c);
+        }
+        }
+        if (lane == 0) {
+            if (al) *reinterpret_cast<u32*>(dst + k) = out4;
+            else { dst[k] = (u8)out4; dst[k + 1] = (u8)(out4 >> 8); dst[k + 2] = (u8)(out4 >> 16); dst[k + 3] = (u8)(out4 >> 24); }
+        }
+    }
+    for (; k < cnt; k++) {
+        const u32 c = (u32)__builtin_amdgcn_readfirstlane((int)src[k]);
+        if (c == front) { if (lane == 0) dst[k] = 0; continue; }
+        front = c;
+        const u32 x = w ^ (c * 0x01010101u);
+        const u32 hz = (x - 0x01010101u) & ~x & 0x80808080u;
+        const u64 m = __ballot(hz != 0);
+        const int lane0 = __ffsll((long long)m) - 1;
+        const u32 hz0 = (u32)__builtin_amdgcn_readlane((int)hz, lane0);
+        const int byteIdx = (__ffs((int)hz0) - 1) >> 3;
+        if (lane == 0) dst[k] = (u8)(4 * lane0 + byteIdx);
+        w = mtf_rotate(w, lane, lane0, byteIdx, c);
+    }
+}
+
+// inverse, pass 1: symbolic decode from the identity list; ids -> dst, final list (ids) -> tilePerm
+__global__ __launch_bounds__(64) void k_mtf_i_symbolic(XfView v, int perTiles, u8* __restrict__ tilePerm)
+{
+    const int b = blockIdx.y;
+    const u32 n = (v.len[b] <= v.cap[b]) ? v.len[b] : 0;
+    const u32 tbase = blockIdx.x * MT;
+    if (tbase >= n) return;
+    const u8* src = v.src[b] + tbase;
+    u8* dst = v.dst[b] + tbase;
+    const int lane = lane_id();
+    u32 w = (u32)(4 * lane) | ((u32)(4 * lane + 1) << 8) | ((u32)(4 * lane + 2) << 16) | ((u32)(4 * lane + 3) << 24);
+    u32 front = 0;                                   // id at list position 0 (uniform)
+    const u32 cnt = (n - tbase < MT) ? (n - tbase) : MT;
+    const bool al = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 3) == 0;
+    u32 k = 0;
+    for (; k + 4 <= cnt; k += 4) {
+        u32 in4;
+        if (al) in4 = *reinterpret_cast<const u32*>(src + k);
+        else in4 = (u32)src[k] | ((u32)src[k + 1] << 8) | ((u32)src[k + 2] << 16) | ((u32)src[k + 3] << 24);
+        in4 = (u32)__builtin_amdgcn_readfirstlane((int)in4);
+        u32 out4 = 0;
+        if (in4 == 0) out4 = front * 0x01010101u;       // rank 0 four times: the front symbol repeats
+        else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const u32 r = (in4 >> (8 * q)) & 0xFF;
+            if (r == 0) { out4 |= front << (8 * q); continue; }
+            const int lane0 = (int)(r >> 2);
+            const int byteIdx = (int)(r & 3);
+            const u32 wl = (u32)__builtin_amdgcn_readlane((int)w, lane0);
+            const u32 c = (wl >> (8 * byteIdx)) & 0xFF;
+            out4 |= c << (8 * q);
+            front = c;
+            w = mtf_rotate(w, lane, lane0, byteIdx, c);
+        }
+        }
+        if (lane == 0) {
+            if (al) *reinterpret_cast<u32*>(dst + k) = out4;
+            else { dst[k] = (u8)out4; dst[k + 1] = (u8)(out4 >> 8); dst[k + 2] = (u8)(out4 >> 16); dst[k + 3] = (u8)(out4 >> 24); }
+        }
+    }
+    for (; k < cnt; k++) {
+        const u32 r = (u32)__builtin_amdgcn_readfirstlane((int)src[k]);
+        if (r == 0) { if (lane == 0) dst[k] = (u8)front; continue; }
+        const int lane0 = (int)(r >> 2);
+        const int byteIdx = (int)(r & 3);
+        const u32 wl = (u32)__builtin_amdgcn_readlane((int)w, lane0);
+        const u32 c = (wl >> (8 * byteIdx)) & 0xFF;
+        if (lane == 0) dst[k] = (u8)c;
+        front = c;
+        w = mtf_rotate(w, lane, lane0, byteIdx, c);
+    }
+    reinterpret_cast<u32*>(tilePerm + ((size_t)b * perTiles + blockIdx.x) * 256)[lane] = w;
+}
+
+// inverse, pass 2: per block, state before tile t: S_0 = identity, S_{t+1}[j] = S_t[perm_t[j]] ; in place
+__global__ __launch_bounds__(256) void k_mtf_i_compose(u8* __restrict__ tilePerm, int perTiles, const u32* __restrict__ lens)
+{
+    const int b = blockIdx.x;
+    const u32 cnt = (lens[b] + MT - 1) / MT;
+    __shared__ u8 S[2][256];
+    S[0][threadIdx.x] = (u8)threadIdx.x;
+    __syncthreads();
+    u8* p = tilePerm + (size_t)b * perTiles * 256;
+    int cur = 0;
+    u8 pj = cnt ? p[threadIdx.x] : (u8)0;
+    for (u32 t = 0; t < cnt; t++) {
+        const u8 pjNext = (t + 1 < cnt) ? p[(size_t)(t + 1) * 256 + threadIdx.x] : (u8)0;   // prefetch: independent of the chain
+        const u8 nv = S[cur][pj];
+        p[(size_t)t * 256 + threadIdx.x] = S[cur][threadIdx.x];   // state before tile t
+        S[cur ^ 1][threadIdx.x] = nv;
+        __syncthreads();
+        cur ^= 1;
+        pj = pjNext;
+    }
+}
+
+// inverse, pass 3: resolve ids in place: out[i] = state_tile[id]
+__global__ __launch_bounds__(256) void k_mtf_i_resolve(XfView v, int perTiles, const u8* __restrict__ tileState)
+{
+    const int b = blockIdx.y;
+    const u32 n = (v.len[b] <= v.cap[b]) ? v.len[b] : 0;
+    const u32 t = blockIdx.x;
+    const u32 base = t * MT;
+    if (base >= n) return;
+    __shared__ u8 S[256];
+    S[threadIdx.x] = tileState[((size_t)b * perTiles + t) * 256 + threadIdx.x];
+    __syncthreads();
+    u8* d = v.dst[b];
+    const u32 end = (base + MT < n) ? base + MT : n;
+    if (((reinterpret_cast<uintptr_t>(d) & 3) == 0) && end == base + MT) {
+        u32* d4 = reinterpret_cast<u32*>(d + base);
+        for (u32 k = threadIdx.x; k < MT / 4; k += 256) {
+            const u32 x = d4[k];
+            d4[k] = (u32)S[x & 0xFF] | ((u32)S[(x >> 8) & 0xFF] << 8) | ((u32)S[(x >> 16) & 0xFF] << 16) | ((u32)S[x >> 24] << 24);
+        }
+    } else {
+        for (u32 i = base + threadIdx.x; i < end; i += 256) d[i] = S[d[i]];
+    }
+}
+
+__global__ void k_copy_ok(const u32* __restrict__ lens, const u32* __restrict__ caps, int nBlocks, u8* ok, u32* newLen)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nBlocks) return;
+    ok[b] = (lens[b] <= caps[b]) ? 1 : 0;       // SBRT.cpp:57-60
+    newLen[b] = lens[b];
+}
+
+static XfView mk(const XfStage& st) { XfView v; v.src = st.src; v.dst = st.dst; v.len = st.len; v.cap = st.cap; return v; }
+
+void launch_mtft_forward(hipStream_t s, const XfStage& st)
+{
+    const XfView v = mk(st);
+    const int perTiles = (int)((st.maxLen + MT - 1) / MT);
+    u32* tileLast = st.scratchU32;                           // nBlocks * perTiles * 256
+    const dim3 grid(perTiles, st.nBlocks);
+    { KScope ks_("k_copy_ok"); hipLaunchKernelGGL(k_copy_ok, dim3((st.nBlocks + 255) / 256), dim3(256), 0, s, st.len, st.cap, st.nBlocks, st.ok, st.newLen); }
+    { KScope ks_("k_mtf_f_last"); hipLaunchKernelGGL(k_mtf_f_last, grid, dim3(64), 0, s, v, perTiles, tileLast); }
+    { KScope ks_("k_mtf_f_scan"); hipLaunchKernelGGL(k_mtf_f_scan, dim3(st.nBlocks), dim3(256), 0, s, tileLast, perTiles, st.len); }
+    { KScope ks_("k_mtf_f_rank"); hipLaunchKernelGGL(k_mtf_f_rank, grid, dim3(64), 0, s, v, perTiles, tileLast); }
+}
+
+void launch_mtft_inverse(hipStream_t s, const XfStage& st)
+{
+    const XfView v = mk(st);
+    const int perTiles = (int)((st.maxLen + MT - 1) / MT);
+    u8* tilePerm = reinterpret_cast<u8*>(st.scratchU32);     // nBlocks * perTiles * 256 bytes
+    { KScope ks_("k_copy_ok"); hipLaunchKernelGGL(k_copy_ok, dim3((st.nBlocks + 255) / 256), dim3(256), 0, s, st.len, st.cap, st.nBlocks, st.ok, st.newLen); }
+    { KScope ks_("k_mtf_i_symbolic"); hipLaunchKernelGGL(k_mtf_i_symbolic, dim3(perTiles, st.nBlocks), dim3(64), 0, s, v, perTiles, tilePerm); }
+    { KScope ks_("k_mtf_i_compose"); hipLaunchKernelGGL(k_mtf_i_compose, dim3(st.nBlocks), dim3(256), 0, s, tilePerm, perTiles, st.len); }
+    { KScope ks_("k_mtf_i_resolve"); hipLaunchKernelGGL(k_mtf_i_resolve, dim3(perTiles, st.nBlocks), dim3(256), 0, s, v, perTiles, tilePerm); }
+}
+
+size_t mtft_scratch_u32(int nBlocks, u32 maxLen) { return (size_t)nBlocks * ((maxLen + MT - 1) / MT) * 256 + 64; }
+
+}  // namespace knz

@@ -459,180 +459,6 @@ __global__ __launch_bounds__(256) void k_zero_dst(XfView v, const u32* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// MTFT
-// ------------------------------------------------------------------------------------------------
-constexpr u32 MT = 1024;            // bytes per lane-tile
-constexpr u32 MW = 64 * MT;         // bytes per wave (64 KiB)
-
-// per lane-tile: last occurrence (position+1) of each symbol -> tileLast[b][t][256]
-__global__ __launch_bounds__(64) void k_mtf_f_last(XfView v, int perTiles, u32* __restrict__ tileLast)
-{
-    const int b = blockIdx.y;
-    const u32 n = v.len[b];
-    const u32 wbase = blockIdx.x * MW;
-    if (wbase >= n) return;
-    const u8* s = v.src[b];
-    __shared__ u32 last[256];
-    const int lane = lane_id();
-    for (u32 tt = 0; tt < 64; tt++) {
-        const u32 tbase = wbase + tt * MT;
-        if (tbase >= n) break;
-        for (int i = lane; i < 256; i += 64) last[i] = 0;
-        __syncthreads();
-        for (u32 k = lane; k < MT; k += 64) {
-            const u32 i = tbase + k;
-            if (i < n) atomicMax(&last[s[i]], i + 1);
-        }
-        __syncthreads();
-        u32* o = tileLast + ((size_t)b * perTiles + (wbase / MT) + tt) * 256;
-        for (int i = lane; i < 256; i += 64) o[i] = last[i];
-        __syncthreads();
-    }
-}
-
-// exclusive prefix max over the tiles of a block, one thread per symbol (loads are independent of the carry)
-__global__ __launch_bounds__(256) void k_mtf_f_scan(u32* __restrict__ tileLast, int perTiles, const u32* __restrict__ lens)
-{
-    const int b = blockIdx.x;
-    const u32 cnt = (lens[b] + MT - 1) / MT;
-    u32* p = tileLast + (size_t)b * perTiles * 256 + threadIdx.x;
-    u32 cur = 0;
-    for (u32 t = 0; t < cnt; t++) {
-        const u32 x = p[(size_t)t * 256];
-        p[(size_t)t * 256] = cur;
-        cur = x > cur ? x : cur;
-    }
-}
-
-// one wave = 64 lane-tiles. LDS lists are interleaved: element i of lane l at [i*64 + l].
-__global__ __launch_bounds__(64) void k_mtf_f_rank(XfView v, int perTiles, const u32* __restrict__ tileState)
-{
-    const int b = blockIdx.y;
-    const u32 n = (v.len[b] <= v.cap[b]) ? v.len[b] : 0;
-    const u32 wbase = blockIdx.x * MW;
-    if (wbase >= n) return;
-    const u8* s = v.src[b];
-    u8* d = v.dst[b];
-    __shared__ u8 lists[256 * 64];
-    __shared__ u32 keys[256];
-    const int lane = lane_id();
-    // build the start list of every lane-tile: symbols by last occurrence desc, unseen ascending
-    for (u32 tt = 0; tt < 64; tt++) {
-        const u32 tbase = wbase + tt * MT;
-        if (tbase >= n) break;
-        const u32* st = tileState + ((size_t)b * perTiles + (wbase / MT) + tt) * 256;
-        for (int i = lane; i < 256; i += 64) keys[i] = st[i];
-        __syncthreads();
-        for (int c = lane; c < 256; c += 64) {
-            const u32 kc = keys[c];
-            u32 r = 0;
-            for (int q = 0; q < 256; q++) {
-                const u32 kq = keys[q];
-                r += (kq > kc || (kq == kc && q < c)) ? 1u : 0u;
-            }
-            lists[r * 64 + tt] = (u8)c;
-        }
-        __syncthreads();
-    }
-    const u32 tbase = wbase + (u32)lane * MT;
-    if (tbase < n) {
-        const u32 cnt = (n - tbase < MT) ? (n - tbase) : MT;
-        u8* L = lists + lane;
-        for (u32 k = 0; k < cnt; k++) {
-            const u8 c = s[tbase + k];
-            u32 r = 0;
-            u8 prev = L[0];
-            if (prev != c) {
-                // shift while searching
-                do {
-                    r++;
-                    const u8 cur = L[r * 64];
-                    L[r * 64] = prev;
-                    prev = cur;
-                } while (prev != c);
-                L[0] = c;
-            }
-            d[tbase + k] = (u8)r;
-        }
-    }
-}
-
-// inverse, pass 1: symbolic decode with identity start; ids -> dst, final list (as ids) -> tilePerm
-__global__ __launch_bounds__(64) void k_mtf_i_symbolic(XfView v, int perTiles, u8* __restrict__ tilePerm)
-{
-    const int b = blockIdx.y;
-    const u32 n = (v.len[b] <= v.cap[b]) ? v.len[b] : 0;
-    const u32 wbase = blockIdx.x * MW;
-    if (wbase >= n) return;
-    const u8* s = v.src[b];
-    u8* d = v.dst[b];
-    __shared__ u8 lists[256 * 64];
-    const int lane = lane_id();
-    for (int i = 0; i < 256; i++) lists[i * 64 + lane] = (u8)i;
-    __syncthreads();
-    const u32 tbase = wbase + (u32)lane * MT;
-    if (tbase < n) {
-        const u32 cnt = (n - tbase < MT) ? (n - tbase) : MT;
-        u8* L = lists + lane;
-        for (u32 k = 0; k < cnt; k++) {
-            const u32 r = s[tbase + k];
-            const u8 c = L[r * 64];
-            for (u32 q = r; q > 0; q--) L[q * 64] = L[(q - 1) * 64];
-            L[0] = c;
-            d[tbase + k] = c;
-        }
-        u8* o = tilePerm + ((size_t)b * perTiles + tbase / MT) * 256;
-        for (int i = 0; i < 256; i++) o[i] = L[i * 64];
-    }
-}
-
-// inverse, pass 2: per block, state before tile t: S_0 = identity, S_{t+1}[j] = S_t[perm_t[j]] ; in place
-__global__ __launch_bounds__(256) void k_mtf_i_compose(u8* __restrict__ tilePerm, int perTiles, const u32* __restrict__ lens)
-{
-    const int b = blockIdx.x;
-    const u32 cnt = (lens[b] + MT - 1) / MT;
-    __shared__ u8 S[2][256];
-    S[0][threadIdx.x] = (u8)threadIdx.x;
-    __syncthreads();
-    u8* p = tilePerm + (size_t)b * perTiles * 256;
-    int cur = 0;
-    for (u32 t = 0; t < cnt; t++) {
-        const u8 pj = p[(size_t)t * 256 + threadIdx.x];
-        const u8 nv = S[cur][pj];
-        p[(size_t)t * 256 + threadIdx.x] = S[cur][threadIdx.x];   // state before tile t
-        S[cur ^ 1][threadIdx.x] = nv;
-        __syncthreads();
-        cur ^= 1;
-    }
-}
-
-// inverse, pass 3: resolve ids in place: out[i] = state_tile[id]
-__global__ __launch_bounds__(256) void k_mtf_i_resolve(XfView v, int perTiles, const u8* __restrict__ tileState)
-{
-    const int b = blockIdx.y;
-    const u32 n = (v.len[b] <= v.cap[b]) ? v.len[b] : 0;
-    const u32 t = blockIdx.x;               // one workgroup per lane-tile (1 KiB)
-    const u32 base = t * MT;
-    if (base >= n) return;
-    __shared__ u8 S[256];
-    S[threadIdx.x] = tileState[((size_t)b * perTiles + t) * 256 + threadIdx.x];
-    __syncthreads();
-    u8* d = v.dst[b];
-    for (u32 k = threadIdx.x; k < MT; k += 256) {
-        const u32 i = base + k;
-        if (i < n) d[i] = S[d[i]];
-    }
-}
-
-__global__ void k_copy_ok(const u32* __restrict__ lens, const u32* __restrict__ caps, int nBlocks, u8* ok, u32* newLen)
-{
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nBlocks) return;
-    ok[b] = (lens[b] <= caps[b]) ? 1 : 0;       // SBRT.cpp:57-60
-    newLen[b] = lens[b];
-}
-
-// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 static XfView mk(const XfStage& st) { XfView v; v.src = st.src; v.dst = st.dst; v.len = st.len; v.cap = st.cap; return v; }
@@ -678,32 +504,6 @@ void launch_zrlt_inverse(hipStream_t s, const XfStage& st)
     { KScope ks_("k_zrlt_i_emit"); hipLaunchKernelGGL(k_zrlt_i_pass<2>, grid, dim3(256), 0, s, v, per, prevNonFF, nullptr, prevNonR, nullptr, tileSize, nullptr, st.ok); }
 }
 
-void launch_mtft_forward(hipStream_t s, const XfStage& st)
-{
-    const XfView v = mk(st);
-    const int perTiles = (int)((st.maxLen + MT - 1) / MT);
-    const int perWaves = (int)((st.maxLen + MW - 1) / MW);
-    u32* tileLast = st.scratchU32;                           // nBlocks * perTiles * 256
-    const dim3 grid(perWaves, st.nBlocks);
-    { KScope ks_("k_copy_ok"); hipLaunchKernelGGL(k_copy_ok, dim3((st.nBlocks + 255) / 256), dim3(256), 0, s, st.len, st.cap, st.nBlocks, st.ok, st.newLen); }
-    { KScope ks_("k_mtf_f_last"); hipLaunchKernelGGL(k_mtf_f_last, grid, dim3(64), 0, s, v, perTiles, tileLast); }
-    { KScope ks_("k_mtf_f_scan"); hipLaunchKernelGGL(k_mtf_f_scan, dim3(st.nBlocks), dim3(256), 0, s, tileLast, perTiles, st.len); }
-    { KScope ks_("k_mtf_f_rank"); hipLaunchKernelGGL(k_mtf_f_rank, grid, dim3(64), 0, s, v, perTiles, tileLast); }
-}
-
-void launch_mtft_inverse(hipStream_t s, const XfStage& st)
-{
-    const XfView v = mk(st);
-    const int perTiles = (int)((st.maxLen + MT - 1) / MT);
-    const int perWaves = (int)((st.maxLen + MW - 1) / MW);
-    u8* tilePerm = reinterpret_cast<u8*>(st.scratchU32);     // nBlocks * perTiles * 256 bytes
-    { KScope ks_("k_copy_ok"); hipLaunchKernelGGL(k_copy_ok, dim3((st.nBlocks + 255) / 256), dim3(256), 0, s, st.len, st.cap, st.nBlocks, st.ok, st.newLen); }
-    { KScope ks_("k_mtf_i_symbolic"); hipLaunchKernelGGL(k_mtf_i_symbolic, dim3(perWaves, st.nBlocks), dim3(64), 0, s, v, perTiles, tilePerm); }
-    { KScope ks_("k_mtf_i_compose"); hipLaunchKernelGGL(k_mtf_i_compose, dim3(st.nBlocks), dim3(256), 0, s, tilePerm, perTiles, st.len); }
-    { KScope ks_("k_mtf_i_resolve"); hipLaunchKernelGGL(k_mtf_i_resolve, dim3(perTiles, st.nBlocks), dim3(256), 0, s, v, perTiles, tilePerm); }
-}
-
 size_t zrlt_scratch_u32(int nBlocks, u32 maxLen) { return (size_t)nBlocks * ((maxLen + ZT - 1) / ZT + 2) * 6 + 2 * (size_t)nBlocks + 64; }
-size_t mtft_scratch_u32(int nBlocks, u32 maxLen) { return (size_t)nBlocks * ((maxLen + MT - 1) / MT) * 256 + 64; }
 
 }  // namespace knz
