@@ -16,6 +16,8 @@
 //            sorts 9-bit symbols packed in a 64-bit key, later rounds sort only the members of still
 //            unsorted groups on (group head, rank[i+h]). The two device-wide primitives (LSD radix
 //            sort of 64-bit keys, scans) come from rocPRIM; everything else is hand-written.
+//            (Measured alternative, rejected: rocprim::segmented_radix_sort_pairs on 32-bit rank[i+h] keys
+//            per group is 2.4x slower per round here -- tens of millions of tiny segments.)
 //   inverse  psi by a stable 8-bit counting sort of the BWT symbols, then list ranking by pointer
 //            jumping (log2 n rounds of next[next[j]]) gives every F-position its text offset; the
 //            8 chains the reference walks serially become one data-parallel scatter.
