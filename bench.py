@@ -111,7 +111,8 @@ def main():
     n = len(data)
     bs = cfg["block"]
     dev = torch.device("cuda", local_rank)
-    stream = torch.cuda.current_stream()
+    torch.cuda.set_device(dev)
+    stream = torch.cuda.Stream(device=dev)  # the library launches (and HIP-event-times) on this stream
     ctx = hipapi.Context(local_rank, stream=stream.cuda_stream)
 
     h_in = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy())
@@ -186,7 +187,9 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(dom_name)
+            tj = json.load(open(tpath)).get("config%d" % args.config, {})
+            # measured with rocprofv3 --pmc on the same workload; only valid for the same input size
+            traffic = tj.get(dom_name) if tj.get("n_bytes") == n else None
         except Exception:
             traffic = None
     roofline = dict(bound="hbm", kernel=dom_name, achieved=round(achieved, 2), peak=8000.0, unit="GB/s",
