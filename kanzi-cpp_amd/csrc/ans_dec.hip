@@ -174,23 +174,48 @@ __global__ __launch_bounds__(64) void k_ans0_scan(BitSrc src, DecBlock* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-constexpr int DCH = 8;               // chunks per wave
-constexpr u32 RING = 1024;           // payload ring bytes per chunk
-constexpr u32 REFILL_STEPS = 32;     // <= 8 bytes consumed per step -> 256 bytes per interval
+// k_ans0_decode.  The kernel is bound by the dependent chain of one decode step times the 4096 steps of a
+// chunk, so the layout is chosen to (1) keep every chunk of a 200 MB job resident at once (2.3 KiB of LDS
+// per chunk, 16 chunks per wave, 4 waves per CU) and (2) keep that chain at two LDS round trips:
+//   bkt[slot >> 2]  -> rank of the first present symbol that covers the 4-slot bucket        (1 KiB / chunk)
+//   symt[rank..+3]  -> the (at most 4) symbols a bucket can hold, cum << 20 | freq << 8 | sym  (1 KiB / chunk)
+// and a branch-free pick of the entry with the largest cum <= slot.  The payload bytes a step may need
+// (4 big-endian 16-bit items at the shared pointer) are read from a 256-byte LDS ring at the top of the step,
+// off the chain; the ring is topped up 64 bytes at a time by the chunk's own 4 lanes, with the global loads
+// issued one check interval (8 steps) before their data is written to LDS.
+constexpr int DCH = 16;              // chunks per wave (4 lanes each)
+constexpr u32 RB = 256;              // ring bytes per chunk
+constexpr u32 RQ = 64;               // refill quantum (16 bytes per lane)
+constexpr u32 RSTRIDE = RB / 4 + 2;  // ring words per chunk incl. 8 mirrored bytes
+constexpr u32 CHECK_STEPS = 8;       // <= 8 bytes consumed per step -> <= RQ per interval
+constexpr u32 SYM_STRIDE = 260;
+
+template <int K>
+__device__ __forceinline__ u32 quad_bcast(u32 v)
+{
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, K * 0x55, 0xF, 0xF, false);
+}
+
+__device__ __forceinline__ u32 quad_transpose_word(u32 acc, int j)
+{
+    // lanes of a quad hold acc = symbols of steps 0..3 (byte k = step k); lane j returns the dword
+    // {state0, state1, state2, state3} of step j, i.e. output bytes [4j, 4j+4)
+    const u32 a0 = quad_bcast<0>(acc), a1 = quad_bcast<1>(acc), a2 = quad_bcast<2>(acc), a3 = quad_bcast<3>(acc);
+    const u32 sh = 8u * (u32)j;
+    return ((a3 >> sh) & 0xFF) | (((a2 >> sh) & 0xFF) << 8) | (((a1 >> sh) & 0xFF) << 16) | (((a0 >> sh) & 0xFF) << 24);
+}
 
 __global__ __launch_bounds__(64) void k_ans0_decode(BitSrc src, DecBlock* __restrict__ blocks, int maxChunks, int nSlots,
                                                     const AnsDecChunk* __restrict__ chunks, u8* const* __restrict__ outPtr)
 {
-    __shared__ u8 f2sAll[DCH * 4096];                          // slot -> symbol
-    __shared__ u32 symAll[DCH * 256];                          // freq | cum << 16
-    __shared__ u32 ringAll[DCH * (RING / 4)];                  // payload bytes, stream order
-    __shared__ u16 cumArr[258];
+    __shared__ u8 bktAll[DCH * 1024];                          // (slot >> 2) -> rank of first covering symbol
+    __shared__ u32 symAll[DCH * SYM_STRIDE];                   // by rank: cum << 20 | freq << 8 | sym
+    __shared__ u32 ringAll[DCH * RSTRIDE];                     // payload as 16-bit items (value form)
+    __shared__ u16 cumArr[260];
     __shared__ int chunkErr[DCH];
-    __shared__ u32 pArr[DCH];                                  // bytes consumed per chunk
-    __shared__ u32 baseArr[DCH];                               // stream offset of ring[0] per chunk (multiple of 512)
     const int lane = lane_id();
     const int slotBase = blockIdx.x * DCH;
-    if (lane < DCH) { chunkErr[lane] = 0; pArr[lane] = 0; baseArr[lane] = 0; }
+    if (lane < DCH) chunkErr[lane] = 0;
     __syncthreads();
 
     // ---- phase 1: tables (ANSRangeDecoder.cpp:113-171) and simple chunk kinds
@@ -231,7 +256,8 @@ __global__ __launch_bounds__(64) void k_ans0_decode(BitSrc src, DecBlock* __rest
         }
         const u32 myCount = __popc(present);
         const u32 incl = wave_incl_scan(myCount);
-        u32 r = incl - myCount;
+        const u32 rank0 = incl - myCount;
+        u32 r = rank0;
         const u32 chk = (asz >= 64) ? 8u : 6u;
         const u32 llr = (u32)ilog2_u32(lr) + 1u;
         u32 f[4] = { 0, 0, 0, 0 };
@@ -255,7 +281,7 @@ __global__ __launch_bounds__(64) void k_ans0_decode(BitSrc src, DecBlock* __rest
         const u32 sumOthers = wave_sum(lsum);
         if (scale <= sumOthers) bad = 1;
         if (!bad) {
-            u32 rr = incl - myCount;
+            u32 rr = rank0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 if ((present >> k) & 1) { if (rr == 0) f[k] = scale - sumOthers; rr++; }
@@ -265,35 +291,40 @@ __global__ __launch_bounds__(64) void k_ans0_decode(BitSrc src, DecBlock* __rest
         const u32 tot = f[0] + f[1] + f[2] + f[3];
         const u32 cincl = wave_incl_scan(tot);
         u32 cum = cincl - tot;
-        u32* symt = symAll + gg * 256;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const u32 fr = f[k];
-            const u32 fclip = (fr >= scale) ? scale - 1 : fr;
-            symt[4 * lane + k] = fclip | (cum << 16);
-            cumArr[4 * lane + k] = (u16)cum;
-            cum += fr;
-        }
-        if (lane == 63) { cumArr[256] = (u16)scale; cumArr[257] = (u16)scale; }
-        __syncthreads();
-        // slot -> symbol: lane fills slots [64*lane, 64*lane+64) ; start symbol by binary search on cum[]
+        u32* symt = symAll + gg * SYM_STRIDE;
         {
-            u8* f2s = f2sAll + gg * 4096;
+            u32 rr = rank0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if ((present >> k) & 1) {
+                    const u32 fr = f[k];
+                    const u32 fclip = (fr >= scale) ? scale - 1 : fr;       // ANSRangeDecoder.hpp:47-49
+                    const u32 e = (cum << 20) | (fclip << 8) | (4u * (u32)lane + (u32)k);
+                    symt[rr] = e;
+                    cumArr[rr] = (u16)cum;
+                    if (rr + 1 == asz) { symt[rr + 1] = e; symt[rr + 2] = e; symt[rr + 3] = e; cumArr[rr + 1] = (u16)scale; }
+                    cum += fr;
+                    rr++;
+                }
+            }
+        }
+        __syncthreads();
+        // bucket -> rank: lane fills buckets [16*lane, 16*lane+16) (+ 1024-bucket strides for completeness)
+        {
+            u8* bkt = bktAll + gg * 1024;
             for (u32 base = (u32)lane * 64; base < scale; base += 4096) {
-                // largest s with cum[s] <= base (among all 256 entries; absent symbols have zero width)
-                u32 lo = 0, hi = 255;
+                u32 lo = 0, hi = asz - 1;
                 while (lo < hi) {
                     const u32 mid = (lo + hi + 1) >> 1;
                     if (cumArr[mid] <= base) lo = mid; else hi = mid - 1;
                 }
                 u32 s = lo;
-                // skip zero-width symbols that share the same cum value (take the one that really covers `base`)
                 u32 t = base;
                 u32 word = 0;
-                for (u32 k = 0; k < 64; k++, t++) {
-                    while (s < 255 && cumArr[s + 1] <= t) s++;
+                for (u32 k = 0; k < 16; k++, t += 4) {
+                    while (cumArr[s + 1] <= t) s++;                 // cumArr[asz] = scale > t
                     word |= s << (8 * (k & 3));
-                    if ((k & 3) == 3) { *reinterpret_cast<u32*>(f2s + base + (k & ~3u)) = word; word = 0; }
+                    if ((k & 3) == 3) { *reinterpret_cast<u32*>(bkt + (base >> 2) + (k & ~3u)) = word; word = 0; }
                 }
             }
         }
@@ -302,14 +333,14 @@ __global__ __launch_bounds__(64) void k_ans0_decode(BitSrc src, DecBlock* __rest
     __syncthreads();
 
     // ---- phase 2
-    const int g = lane >> 2;              // lanes 0..31 decode, 32..63 only help with refills
+    const int g = lane >> 2;
     const int j = lane & 3;
     bool act = false;
     u32 n = 0, sz = 0, lr = ANS_LR;
     u64 payBit = 0;
     u8* dst = nullptr;
     u32 st = 0;
-    if (g < DCH) {
+    {
         const int slot = slotBase + g;
         if (slot < nSlots) {
             const int b = slot / maxChunks;
@@ -330,16 +361,36 @@ __global__ __launch_bounds__(64) void k_ans0_decode(BitSrc src, DecBlock* __rest
         if (lane < DCH && chunkErr[lane] && slotBase + lane < nSlots) blocks[(slotBase + lane) / maxChunks].error = KNZ_ERR_PROCESS_BLOCK;
         return;
     }
-    // chunk payload descriptors visible to all lanes (for the cooperative ring refills)
-    __shared__ u64 payBitArr[DCH];
-    __shared__ u32 actArr[DCH];
-    if (g < DCH && j == 0) { payBitArr[g] = payBit; actArr[g] = act ? 1u : 0u; }
-    __syncthreads();
-    // initial fill: ring[c][0..1024) = stream bytes [0, 1024) ; 8 chunks * 256 words / 64 lanes
-    for (int idx = lane; idx < DCH * (int)(RING / 4); idx += 64) {
-        const int cc = idx / (int)(RING / 4);
-        const int w = idx - cc * (int)(RING / 4);
-        ringAll[idx] = actArr[cc] ? bswap32(peek_bits(src, payBitArr[cc] + 32ull * w, 32)) : 0u;
+    u32* ringW = ringAll + g * RSTRIDE;
+    // Refill loads are branch-free so that their latency is not waited for at the load: word indices are
+    // clamped to the last (possibly partial) word of the buffer -- bytes past the stream end are never consumed,
+    // and an aligned dword never straddles a page.  Raw words are converted when they are stored to LDS.
+    const u64 lastWord = ((src.nBytes + 3) >> 2) - 1;
+    auto load5 = [&](u32 streamOff, u32 raw[5]) {
+        const u64 w0 = (payBit + 8ull * streamOff) >> 5;
+#pragma unroll
+        for (int k = 0; k < 5; k++) { const u64 w = w0 + k; raw[k] = src.words[w < lastWord ? w : lastWord]; }
+    };
+    // item form of 4 stream bytes s0 s1 s2 s3 (big-endian word v): low half = s0<<8|s1, high half = s2<<8|s3
+    auto store4 = [&](u32 streamOff, const u32 raw[5]) {
+        const u32 sh = (u32)(payBit + 8ull * streamOff) & 31;
+        const u32 wo = (streamOff & (RB - 1)) >> 2;
+        u32 it[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u32 v = (u32)(((((u64)bswap32(raw[k]) << 32) | bswap32(raw[k + 1])) << sh) >> 32);
+            it[k] = (v >> 16) | (v << 16);
+            ringW[wo + k] = it[k];
+        }
+        if (wo == 0) { ringW[RB / 4] = it[0]; ringW[RB / 4 + 1] = it[1]; }
+    };
+    // initial fill: stream bytes [0, RB) of each active chunk, 64 bytes per lane
+    if (act) {
+        for (u32 t = 0; t < RB / RQ; t++) {
+            u32 tmp[5];
+            load5(t * RQ + 16u * (u32)j, tmp);
+            store4(t * RQ + 16u * (u32)j, tmp);
+        }
     }
     __syncthreads();
 
@@ -347,89 +398,64 @@ __global__ __launch_bounds__(64) void k_ans0_decode(BitSrc src, DecBlock* __rest
     const u32 count4 = n & ~3u;
     const u32 steps = act ? (count4 >> 2) : 0;
     const u32 maxSteps = wave_max(steps);
-    const u8* f2s = f2sAll + (g < DCH ? g : 0) * 4096;
-    const u32* symt = symAll + (g < DCH ? g : 0) * 256;
-    const u8* ring = reinterpret_cast<const u8*>(ringAll + (g < DCH ? g : 0) * (RING / 4));
-    u32 p = 0;
-    const u32 grpShift = (u32)(lane & ~3);
+    const u8* bkt = bktAll + g * 1024;
+    const u32* symt = symAll + g * SYM_STRIDE;
+    const u16* ring16 = reinterpret_cast<const u16*>(ringW);
+    u32 q = 0;                            // 16-bit items consumed (shared by the chunk's 4 lanes)
+    u32 F = RB;                           // stream bytes [F - RB, F) are in the ring
+    u32 pend[5] = { 0, 0, 0, 0, 0 };
+    bool hasPend = false;
+    const u32 grpShift = (u32)(lane & 28);
     const u32 higherMask = (0xFu << (j + 1)) & 0xFu;
     const bool aligned4 = act && ((reinterpret_cast<uintptr_t>(dst) & 3) == 0);
     u32 acc = 0;                          // my symbols of the last 4 steps (step k in byte k)
 
-    for (u32 s0 = 0; s0 < maxSteps; s0 += REFILL_STEPS) {
-        const u32 s1 = (s0 + REFILL_STEPS < maxSteps) ? s0 + REFILL_STEPS : maxSteps;
-        for (u32 s = s0; s < s1; s++) {
-            const bool on = s < steps;
-            const u32 slotv = st & mask;
-            const u32 sym = f2s[slotv];
-            const u32 e = symt[sym];
-            acc |= sym << (8 * (s & 3));
-            if (on) st = (e & 0xFFFF) * (st >> lr) + slotv - (e >> 16);
-            const bool flag = on && (st < ANS_TOP);
-            const u64 m = __ballot(flag);
-            const u32 grp = (u32)(m >> grpShift) & 0xF;
-            if (flag) {
-                const u32 off = (p + 2 * __popc(grp & higherMask)) & (RING - 1);
-                const u32 v = *reinterpret_cast<const u16*>(ring + off);       // p is even: aligned
-                st = (st << 16) | ((v & 0xFF) << 8) | (v >> 8);
-            }
-            p += 2 * __popc(grp);
-            if ((s & 3) == 3) {
-                // 4x4 transpose among the 4 lanes of the chunk: lane k stores the dword of step s-3+k
-                const int base = lane & ~3;
-                const u32 a3 = (u32)__shfl((int)acc, base + 3, 64);
-                const u32 a2 = (u32)__shfl((int)acc, base + 2, 64);
-                const u32 a1 = (u32)__shfl((int)acc, base + 1, 64);
-                const u32 a0 = (u32)__shfl((int)acc, base + 0, 64);
-                const u32 sh = 8u * (u32)j;
-                const u32 word = ((a3 >> sh) & 0xFF) | (((a2 >> sh) & 0xFF) << 8) | (((a1 >> sh) & 0xFF) << 16) | (((a0 >> sh) & 0xFF) << 24);
-                const u32 stepIdx = (s & ~3u) + (u32)j;
-                if (act && stepIdx < steps) {
-                    if (aligned4) reinterpret_cast<u32*>(dst)[stepIdx] = word;
-                    else { dst[4 * stepIdx] = (u8)word; dst[4 * stepIdx + 1] = (u8)(word >> 8); dst[4 * stepIdx + 2] = (u8)(word >> 16); dst[4 * stepIdx + 3] = (u8)(word >> 24); }
-                }
-                acc = 0;
-            }
+    for (u32 s = 0; s < maxSteps; s++) {
+        if ((s & (CHECK_STEPS - 1)) == 0 && s != 0) {
+            if (hasPend) { store4(F + 16u * (u32)j, pend); F += RQ; hasPend = false; }
+            if (act && F < sz && F + RQ <= 2 * q + RB) { load5(F + 16u * (u32)j, pend); hasPend = true; }
         }
-        if (s1 >= maxSteps) break;
-        // ---- cooperative refill: a chunk that consumed past base+512 gets the next 512 bytes
-        if (g < DCH && j == 0) pArr[g] = p;
-        __syncthreads();
-        for (int cc = 0; cc < DCH; cc++) {
-            if (!actArr[cc]) continue;
-            const u32 pc = pArr[cc];
-            u32 bs0 = baseArr[cc];
-            if (pc >= bs0 + 512) {
-                // stream bytes [bs0 + 1024, bs0 + 1536) replace ring bytes [bs0 % 1024, +512)
-                for (int w = lane; w < 128; w += 64) {
-                    const u32 streamOff = bs0 + RING + 4u * (u32)w;
-                    ringAll[cc * (RING / 4) + ((streamOff & (RING - 1)) >> 2)] = bswap32(peek_bits(src, payBitArr[cc] + 8ull * streamOff, 32));
-                }
-                if (lane == 0) baseArr[cc] = bs0 + 512;
-            }
-        }
-        __syncthreads();
-    }
-    // steps not a multiple of 4 cannot happen (count4 / 4 steps each store via the transpose when (s&3)==3):
-    // steps counts groups of 4 symbols, every step writes 4 bytes -> the transpose above handles whole quads
-    // of steps; flush a partial quad here
-    {
-        const u32 rem = maxSteps & 3;
-        if (rem) {
-            const int base = lane & ~3;
-            const u32 a3 = (u32)__shfl((int)acc, base + 3, 64);
-            const u32 a2 = (u32)__shfl((int)acc, base + 2, 64);
-            const u32 a1 = (u32)__shfl((int)acc, base + 1, 64);
-            const u32 a0 = (u32)__shfl((int)acc, base + 0, 64);
-            const u32 sh = 8u * (u32)j;
-            const u32 word = ((a3 >> sh) & 0xFF) | (((a2 >> sh) & 0xFF) << 8) | (((a1 >> sh) & 0xFF) << 16) | (((a0 >> sh) & 0xFF) << 24);
-            const u32 stepIdx = (maxSteps & ~3u) + (u32)j;
+        const bool on = s < steps;
+        const u32 slotv = st & mask;
+        const u32 rk = bkt[slotv >> 2];
+        const u32 qi = q & (RB / 2 - 1);
+        const u32 i0 = ring16[qi], i1 = ring16[qi + 1], i2 = ring16[qi + 2], i3 = ring16[qi + 3];
+        const u32 e0 = symt[rk], e1 = symt[rk + 1], e2 = symt[rk + 2], e3 = symt[rk + 3];
+        const u32 key = (slotv << 20) | 0xFFFFFu;
+        u32 e = e0;
+        if (e1 <= key) e = e1;
+        if (e2 <= key) e = e2;
+        if (e3 <= key) e = e3;
+        acc |= (e & 0xFF) << (8 * (s & 3));
+        if (on) st = ((e >> 8) & 0xFFF) * (st >> lr) + slotv - (e >> 20);
+        const bool flag = on && (st < ANS_TOP);
+        const u64 m = __ballot(flag);
+        const u32 half = (lane < 32) ? (u32)m : (u32)(m >> 32);
+        const u32 grp = (half >> grpShift) & 0xF;
+        const u32 kk = __popc(grp & higherMask);
+        const u32 item = (kk & 2) ? ((kk & 1) ? i3 : i2) : ((kk & 1) ? i1 : i0);
+        if (flag) st = (st << 16) | item;
+        q += __popc(grp);
+        if ((s & 3) == 3) {
+            const u32 word = quad_transpose_word(acc, j);
+            const u32 stepIdx = (s & ~3u) + (u32)j;
             if (act && stepIdx < steps) {
-                dst[4 * stepIdx] = (u8)word; dst[4 * stepIdx + 1] = (u8)(word >> 8); dst[4 * stepIdx + 2] = (u8)(word >> 16); dst[4 * stepIdx + 3] = (u8)(word >> 24);
+                if (aligned4) reinterpret_cast<u32*>(dst)[stepIdx] = word;
+                else { dst[4 * stepIdx] = (u8)word; dst[4 * stepIdx + 1] = (u8)(word >> 8); dst[4 * stepIdx + 2] = (u8)(word >> 16); dst[4 * stepIdx + 3] = (u8)(word >> 24); }
             }
+            acc = 0;
+        }
+    }
+    // flush a partial quad of steps
+    if (maxSteps & 3) {
+        const u32 word = quad_transpose_word(acc, j);
+        const u32 stepIdx = (maxSteps & ~3u) + (u32)j;
+        if (act && stepIdx < steps) {
+            dst[4 * stepIdx] = (u8)word; dst[4 * stepIdx + 1] = (u8)(word >> 8); dst[4 * stepIdx + 2] = (u8)(word >> 16); dst[4 * stepIdx + 3] = (u8)(word >> 24);
         }
     }
     if (act && j == 0) {
+        const u32 p = 2 * q;
         const u32 tail = n - count4;
         for (u32 t = 0; t < tail; t++) dst[count4 + t] = (u8)peek_bits(src, payBit + 8ull * (p + t), 8);
         if (p + tail != sz) chunkErr[g] = 1;          // ANSRangeDecoder.cpp:291
