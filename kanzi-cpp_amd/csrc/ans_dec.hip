@@ -371,6 +371,21 @@ __global__ __launch_bounds__(64) void k_ans0_decode(BitSrc src, DecBlock* __rest
 #pragma unroll
         for (int k = 0; k < 5; k++) { const u64 w = w0 + k; raw[k] = src.words[w < lastWord ? w : lastWord]; }
     };
+    // The in-loop prefetch is issued through inline asm: hipcc's waitcnt pass otherwise parks an
+    // s_waitcnt vmcnt(0) right behind the loads (at the join that follows the divergent refill branch), which
+    // makes the prefetch synchronous.  The matching wait is wait_pend(), 8 steps later.
+    auto load5_async = [&](u32 streamOff, u32 raw[5]) {
+        const u64 w0 = (payBit + 8ull * streamOff) >> 5;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const u64 w = w0 + k;
+            const u32* a = src.words + (w < lastWord ? w : lastWord);
+            asm volatile("global_load_dword %0, %1, off" : "=v"(raw[k]) : "v"(a));
+        }
+    };
+    auto wait_pend = [&](u32 raw[5]) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]));
+    };
     // item form of 4 stream bytes s0 s1 s2 s3 (big-endian word v): low half = s0<<8|s1, high half = s2<<8|s3
     auto store4 = [&](u32 streamOff, const u32 raw[5]) {
         const u32 sh = (u32)(payBit + 8ull * streamOff) & 31;
@@ -405,53 +420,71 @@ __global__ __launch_bounds__(64) void k_ans0_decode(BitSrc src, DecBlock* __rest
     u32 F = RB;                           // stream bytes [F - RB, F) are in the ring
     u32 pend[5] = { 0, 0, 0, 0, 0 };
     bool hasPend = false;
-    const u32 grpShift = (u32)(lane & 28);
+    const u32 grpShift64 = (u32)(lane & ~3);
     const u32 higherMask = (0xFu << (j + 1)) & 0xFu;
     const bool aligned4 = act && ((reinterpret_cast<uintptr_t>(dst) & 3) == 0);
-    u32 acc = 0;                          // my symbols of the last 4 steps (step k in byte k)
 
-    for (u32 s = 0; s < maxSteps; s++) {
-        if ((s & (CHECK_STEPS - 1)) == 0 && s != 0) {
-            if (hasPend) { store4(F + 16u * (u32)j, pend); F += RQ; hasPend = false; }
-            if (act && F < sz && F + RQ <= 2 * q + RB) { load5(F + 16u * (u32)j, pend); hasPend = true; }
-        }
-        const bool on = s < steps;
+    typedef u64 __attribute__((aligned(2))) u64_a2;
+    // one decode step; returns the symbol in the low byte of `e`
+    auto step = [&](u32 s) -> u32 {
         const u32 slotv = st & mask;
         const u32 rk = bkt[slotv >> 2];
-        const u32 qi = q & (RB / 2 - 1);
-        const u32 i0 = ring16[qi], i1 = ring16[qi + 1], i2 = ring16[qi + 2], i3 = ring16[qi + 3];
+        const u64 items = *reinterpret_cast<const u64_a2*>(ring16 + (q & (RB / 2 - 1)));
         const u32 e0 = symt[rk], e1 = symt[rk + 1], e2 = symt[rk + 2], e3 = symt[rk + 3];
         const u32 key = (slotv << 20) | 0xFFFFFu;
         u32 e = e0;
-        if (e1 <= key) e = e1;
-        if (e2 <= key) e = e2;
-        if (e3 <= key) e = e3;
-        acc |= (e & 0xFF) << (8 * (s & 3));
-        if (on) st = ((e >> 8) & 0xFFF) * (st >> lr) + slotv - (e >> 20);
-        const bool flag = on && (st < ANS_TOP);
+        e = (e1 <= key) ? e1 : e;
+        e = (e2 <= key) ? e2 : e;
+        e = (e3 <= key) ? e3 : e;
+        // lanes past their last step (or without a chunk) keep computing on in-bounds garbage; they never
+        // flag, store or move the shared pointer
+        st = __umul24((e >> 8) & 0xFFF, st >> lr) + slotv - (e >> 20);
+        const bool flag = (st < ANS_TOP) && (s < steps);
         const u64 m = __ballot(flag);
-        const u32 half = (lane < 32) ? (u32)m : (u32)(m >> 32);
-        const u32 grp = (half >> grpShift) & 0xF;
+        const u32 grp = (u32)(m >> grpShift64) & 0xF;
         const u32 kk = __popc(grp & higherMask);
-        const u32 item = (kk & 2) ? ((kk & 1) ? i3 : i2) : ((kk & 1) ? i1 : i0);
-        if (flag) st = (st << 16) | item;
+        const u32 item = (u32)(items >> (16 * kk)) & 0xFFFF;
+        st = flag ? ((st << 16) | item) : st;
         q += __popc(grp);
-        if ((s & 3) == 3) {
-            const u32 word = quad_transpose_word(acc, j);
-            const u32 stepIdx = (s & ~3u) + (u32)j;
-            if (act && stepIdx < steps) {
-                if (aligned4) reinterpret_cast<u32*>(dst)[stepIdx] = word;
-                else { dst[4 * stepIdx] = (u8)word; dst[4 * stepIdx + 1] = (u8)(word >> 8); dst[4 * stepIdx + 2] = (u8)(word >> 16); dst[4 * stepIdx + 3] = (u8)(word >> 24); }
-            }
-            acc = 0;
+        return e & 0xFF;
+    };
+    auto put_word = [&](u32 word, u32 stepIdx) {
+        if (stepIdx < steps) {
+            if (aligned4) reinterpret_cast<u32*>(dst)[stepIdx] = word;
+            else { dst[4 * stepIdx] = (u8)word; dst[4 * stepIdx + 1] = (u8)(word >> 8); dst[4 * stepIdx + 2] = (u8)(word >> 16); dst[4 * stepIdx + 3] = (u8)(word >> 24); }
+        }
+    };
+    u32 s0 = 0;
+    u32 heldWord = 0, heldIdx = 0xFFFFFFFFu;          // second quad of an interval, stored one step into the next
+    for (; s0 + CHECK_STEPS <= maxSteps; s0 += CHECK_STEPS) {
+        // ring upkeep: the last output store was issued 6 steps ago, so the vmcnt wait in front of the LDS
+        // write finds the prefetch (issued 8 steps ago) and that store already complete
+        if (s0) {
+            if (hasPend) { wait_pend(pend); store4(F + 16u * (u32)j, pend); F += RQ; hasPend = false; }
+            if (act && F < sz && F + RQ <= 2 * q + RB) { load5_async(F + 16u * (u32)j, pend); hasPend = true; }
+        }
+        u32 acc = 0;
+#pragma unroll
+        for (u32 u = 0; u < CHECK_STEPS; u++) {
+            acc |= step(s0 + u) << (8 * (u & 3));
+            if (u == 1) put_word(heldWord, heldIdx);
+            if (u == 3) { put_word(quad_transpose_word(acc, j), s0 + (u32)j); acc = 0; }
+            if (u == 7) { heldWord = quad_transpose_word(acc, j); heldIdx = s0 + 4 + (u32)j; }
         }
     }
-    // flush a partial quad of steps
-    if (maxSteps & 3) {
-        const u32 word = quad_transpose_word(acc, j);
-        const u32 stepIdx = (maxSteps & ~3u) + (u32)j;
-        if (act && stepIdx < steps) {
-            dst[4 * stepIdx] = (u8)word; dst[4 * stepIdx + 1] = (u8)(word >> 8); dst[4 * stepIdx + 2] = (u8)(word >> 16); dst[4 * stepIdx + 3] = (u8)(word >> 24);
+    put_word(heldWord, heldIdx);
+    // remaining (< 8) steps; the ring still holds >= 64 unread bytes or everything up to the chunk's end
+    if (hasPend) { wait_pend(pend); store4(F + 16u * (u32)j, pend); F += RQ; hasPend = false; }
+    {
+        u32 acc = 0;
+        for (u32 s = s0; s < maxSteps; s++) {
+            acc |= step(s) << (8 * (s & 3));
+            if ((s & 3) == 3) { put_word(quad_transpose_word(acc, j), (s & ~3u) + (u32)j); acc = 0; }
+        }
+        if (maxSteps & 3) {
+            const u32 word = quad_transpose_word(acc, j);
+            const u32 stepIdx = (maxSteps & ~3u) + (u32)j;
+            if (stepIdx < steps) { dst[4 * stepIdx] = (u8)word; dst[4 * stepIdx + 1] = (u8)(word >> 8); dst[4 * stepIdx + 2] = (u8)(word >> 16); dst[4 * stepIdx + 3] = (u8)(word >> 24); }
         }
     }
     if (act && j == 0) {
