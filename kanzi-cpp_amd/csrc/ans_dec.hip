@@ -39,15 +39,23 @@ struct AnsDecChunk {
     u16 grp[44];         // per frequency group: (bit offset relative to freqBit of the logMax field) | logMax << 12
 };
 
-constexpr u32 SCAN_WIN_WORDS = 176;      // 704 bytes: header (<= 3498 bits) + var-int + 4 states + slack
+// The scan stages a 1 KiB window of the stream (4 words per lane, byte-swapped to bit order) in LDS.  Everything
+// the header walk reads is wave-uniform: all lanes run the same short dependent chain (one LDS read + a
+// handful of VALU operations per field), with no cross-lane traffic.
+constexpr u32 SCAN_WIN_BITS = 8192;
+constexpr u32 SCAN_NEED_BITS = 3498 + 40 + 128 + 64;   // longest header + var-int + 4 states + one spare dword pair
 
-// window reader: bits relative to winBit0 (a multiple of 32)
-__device__ __forceinline__ u32 win_bits(const u32* win, u64 winBit0, u64 pos, u32 n)
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ u32 rl(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ __forceinline__ u32 uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ u64 uni64(u64 v) { return ((u64)uni((u32)(v >> 32)) << 32) | uni((u32)v); }
+
+// n in [1, 32]; rel = bit offset from the window start
+__device__ __forceinline__ u32 lds_bits(const u32* win, u32 rel, u32 n)
 {
-    if (n == 0) return 0;
-    const u32 rel = (u32)(pos - winBit0);
-    const u32 w = rel >> 5;
-    const u64 v = ((u64)win[w] << 32) | (u64)win[w + 1];
+    const u32 i = rel >> 5;
+    const u64 v = ((u64)win[i] << 32) | (u64)win[i + 1];
     return (u32)((v << (rel & 31)) >> (64 - n));
 }
 
@@ -60,12 +68,11 @@ __global__ __launch_bounds__(64) void k_ans0_scan(BitSrc src, DecBlock* __restri
     AnsDecChunk* cs = chunks + (size_t)b * maxChunks;
     for (int i = lane; i < maxChunks; i += 64) cs[i].kind = 3;
     if (db.error) return;
-    __shared__ u32 win[SCAN_WIN_WORDS + 2];
-    __shared__ u64 sh_pos;
-    __shared__ int sh_err;
-    const u64 limit = db.payloadBit + ((db.bits + 7) & ~7ull);
-    u64 pos = db.entropyBit;
-    const u32 preLen = db.preLen;
+    __shared__ u32 win[256 + 8];
+    const u64 limit = uni64(db.payloadBit + ((db.bits + 7) & ~7ull));
+    u64 pos = uni64(db.entropyBit);
+    const u64 entropyBit = pos;
+    const u32 preLen = uni(db.preLen);
     if (db.copyBlock || preLen <= 32) {
         if (lane == 0) {
             cs[0].kind = 2;
@@ -78,98 +85,150 @@ __global__ __launch_bounds__(64) void k_ans0_scan(BitSrc src, DecBlock* __restri
         return;
     }
     const u32 nChunks = (preLen + ENT_CHUNK - 1) / ENT_CHUNK;
+    const u64 lastWord = ((src.nBytes + 3) >> 2) - 1;
+    // words past the end of the buffer are clamped to its last word: positions past `limit` are rejected
+    // before anything read there is trusted
+    auto issue = [&](u64 bit0, u32x4& dstv) {
+        const u64 w = (bit0 >> 5) + 4ull * (u32)lane;
+        const u64 w1 = w + 1, w2 = w + 2, w3 = w + 3;
+        const bool inside = w3 <= lastWord;
+        if (__builtin_expect(__ballot(!inside) == 0, 1)) {
+            const u32* a = src.words + w;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dstv) : "v"(a));
+        } else {
+            const u32* p = src.words;
+            const u32* a0 = p + (w < lastWord ? w : lastWord);
+            const u32* a1 = p + (w1 < lastWord ? w1 : lastWord);
+            const u32* a2 = p + (w2 < lastWord ? w2 : lastWord);
+            const u32* a3 = p + (w3 < lastWord ? w3 : lastWord);
+            u32 t0, t1, t2, t3;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(t0) : "v"(a0));
+            asm volatile("global_load_dword %0, %1, off" : "=v"(t1) : "v"(a1));
+            asm volatile("global_load_dword %0, %1, off" : "=v"(t2) : "v"(a2));
+            asm volatile("global_load_dword %0, %1, off" : "=v"(t3) : "v"(a3));
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+            dstv.x = t0; dstv.y = t1; dstv.z = t2; dstv.w = t3;
+        }
+    };
+    u32x4 wr = { 0, 0, 0, 0 };
+    u64 winBit0 = 0;
+    u32x4 guess = { 0, 0, 0, 0 };
+    u64 guessBit0 = 0;
+    bool guessValid = false;
+    u64 prevPos = pos;
+    u32 myGrp = 0;
     int err = 0;
     for (u32 ci = 0; ci < nChunks; ci++) {
-        // ---- stage the window
-        const u64 winBit0 = pos & ~31ull;
-        const u64 w0 = winBit0 >> 5;
-        for (u32 i = lane; i < SCAN_WIN_WORDS + 2; i += 64) win[i] = src_word(src, w0 + i);
+        // ---- window: the prefetched guess if it covers this header, else an exact (blocking) load
+        if (guessValid && guessBit0 <= pos && pos + SCAN_NEED_BITS <= guessBit0 + SCAN_WIN_BITS) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(guess));
+            wr = guess; winBit0 = guessBit0;
+        } else {
+            if (guessValid) asm volatile("s_waitcnt vmcnt(0)" : "+v"(guess));
+            winBit0 = pos & ~31ull;
+            issue(winBit0, wr);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(wr));
+        }
         __syncthreads();
+        {
+            u32x4 sw = { bswap32(wr.x), bswap32(wr.y), bswap32(wr.z), bswap32(wr.w) };
+            *reinterpret_cast<u32x4*>(&win[4 * lane]) = sw;
+        }
+        __syncthreads();
+        // ---- prefetch for the next chunk: same compressed size as this one, window centred on the estimate
+        guessValid = false;
+        if (ci >= 1 && ci + 1 < nChunks) {
+            const u64 est = pos + (pos - prevPos);
+            guessBit0 = (est > 2304 ? est - 2304 : 0) & ~31ull;
+            issue(guessBit0, guess);
+            guessValid = true;
+        }
+        prevPos = pos;
         AnsDecChunk& c = cs[ci];
-        u64 p = pos;
-        // header prefix is uniform work: every lane decodes the same few fields
-        const u32 lr = 8 + win_bits(win, winBit0, p, 3); p += 3;
+        u32 p = (u32)(pos - winBit0);                  // all header positions are window-relative from here
+        const u32 lr = 8 + lds_bits(win, p, 3); p += 3;
         u32 asz = 0, firstSym = 0;
         u64 maskBit = 0;
-        bool partial = false;
-        u32 lastMask = 0;
         if (lr > ANS_LR) err = 1;                      // kanzi encoders always emit 12; > 12 unsupported here
         if (!err) {
-            if (win_bits(win, winBit0, p, 1) == 0) { asz = (win_bits(win, winBit0, p + 1, 1) == 0) ? 256u : 0u; p += 2; }
+            const u32 hb = lds_bits(win, p, 7);        // flag bits and (partial alphabets) the mask count
+            if ((hb >> 6) == 0) { asz = ((hb >> 5) & 1) ? 0u : 256u; p += 2; }
             else {
-                partial = true;
-                lastMask = win_bits(win, winBit0, p + 1, 5);
+                const u32 lastMask = (hb >> 1) & 31;
                 p += 6;
-                maskBit = p;
+                maskBit = winBit0 + p;
                 // one mask byte per lane
-                const u32 byte = ((u32)lane <= lastMask) ? win_bits(win, winBit0, p + 8ull * lane, 8) : 0u;
+                const u32 byte = ((u32)lane <= lastMask) ? lds_bits(win, p + 8u * (u32)lane, 8) : 0u;
                 const u32 pc = __popc(byte);
                 asz = wave_sum(pc);
                 const u64 nz = __ballot(byte != 0);
                 if (nz) {
                     const int fl = __ffsll((long long)nz) - 1;
-                    const u32 fb = (u32)__shfl((int)byte, fl, 64);
+                    const u32 fb = rl(byte, (u32)fl);
                     firstSym = 8u * (u32)fl + (u32)(__ffs((int)fb) - 1);
                 }
-                p += 8ull * (lastMask + 1);
+                p += 8u * (lastMask + 1);
             }
             if (asz == 0) err = 2;                     // decode() returns a short count -> failure
         }
-        (void)partial;
-        if (!err && lane == 0) {
+        if (err) break;
+        asz = uni(asz);
+        // ---- group walk (uniform): remember (offset | logMax << 12) of group g in lane g
+        const u32 chk = (asz >= 64) ? 8u : 6u;
+        const u32 llr = (u32)ilog2_u32(lr) + 1u;       // 4 for every legal lr (8..12)
+        u32 q = p;
+        const u32 nGroups = (asz - 1 + chk - 1) / chk;
+        const u32 lastCnt = (asz - 1) - (nGroups - 1) * chk;
+        u32 tooBig = 0;
+        for (u32 g = 0; g < nGroups; g++) {
+            const u32 logMax = lds_bits(win, q, llr);
+            tooBig |= (logMax > lr) ? 1u : 0u;          // checked after the walk; a bad value cannot run away:
+            if ((u32)lane == g) myGrp = (q - p) | (logMax << 12);   // q grows by <= 4 + 8*15 per group, the
+            q += llr + ((g + 1 == nGroups) ? lastCnt : chk) * logMax;   // window has 32 spare bytes behind it
+        }
+        if (tooBig) { err = 1; break; }
+        const u32 g = nGroups;
+        if ((u32)lane < g) c.grp[lane] = (u16)myGrp;
+        u32 kind, sz = 0, st0 = 0, st1 = 0, st2 = 0, st3 = 0;
+        u64 payloadBit = 0;
+        if (asz == 1) {
+            kind = 1;
+        } else {
+            // var-int and the 4 states; all inside the window (SCAN_NEED_BITS)
+            u32 value = lds_bits(win, q, 8); q += 8;
+            u32 res = value & 0x7F;
+            for (int shift = 7; value >= 128; shift += 7) {
+                value = lds_bits(win, q, 8); q += 8;
+                if (shift == 28) { if (value >= 128 || (value & 0x70) != 0) err = 1; res |= (value & 0x0F) << shift; break; }
+                res |= (value & 0x7F) << shift;
+            }
+            sz = res;
+            if (sz >= ANS_MAX_CHUNK || sz > 2 * ENT_CHUNK - 2) err = 1;
+            st0 = lds_bits(win, q, 32); st1 = lds_bits(win, q + 32, 32); st2 = lds_bits(win, q + 64, 32); st3 = lds_bits(win, q + 96, 32);
+            q += 128;
+            payloadBit = winBit0 + q;
+            kind = 0;
+        }
+        const u64 endPos = winBit0 + q + 8ull * sz;
+        if (endPos > limit) err = 1;
+        if (err) break;
+        if (lane == 0) {
             c.lr = (u8)lr;
             c.maskBit = maskBit;
             c.asz = (u16)asz;
-            c.freqBit = p;
-            const u32 chk = (asz >= 64) ? 8u : 6u;
-            const u32 llr = (u32)ilog2_u32(lr) + 1u;
-            u32 g = 0;
-            u64 q = p;
-            int e2 = 0;
-            for (u32 i = 1; i < asz; i += chk, g++) {
-                const u32 rel = (u32)(q - p);
-                const u32 logMax = win_bits(win, winBit0, q, llr);
-                q += llr;
-                if (logMax > lr) { e2 = 1; break; }
-                const u32 endj = (i + chk < asz) ? i + chk : asz;
-                c.grp[g] = (u16)(rel | (logMax << 12));
-                q += (u64)(endj - i) * logMax;
-            }
-            if (!e2) {
-                if (asz == 1) {
-                    c.kind = 1; c.sym = (u8)firstSym; c.sz = 0;
-                } else {
-                    // var-int, 4 states (all inside the window: header <= 3498 bits, window 5632 bits)
-                    u32 value = win_bits(win, winBit0, q, 8); q += 8;
-                    u32 res = value & 0x7F;
-                    for (int shift = 7; value >= 128; shift += 7) {
-                        value = win_bits(win, winBit0, q, 8); q += 8;
-                        if (shift == 28) { if (value >= 128 || (value & 0x70) != 0) e2 = 1; res |= (value & 0x0F) << shift; break; }
-                        res |= (value & 0x7F) << shift;
-                    }
-                    const u32 sz = res;
-                    if (sz >= ANS_MAX_CHUNK || sz > 2 * ENT_CHUNK - 2) e2 = 1;
-                    for (int k = 0; k < 4; k++) { c.st[k] = win_bits(win, winBit0, q, 32); q += 32; }
-                    c.payloadBit = q;
-                    c.sz = sz;
-                    q += 8ull * sz;
-                    c.kind = 0;
-                }
-            }
-            if (q > limit) e2 = 1;
-            sh_pos = q;
-            sh_err = e2;
+            c.freqBit = winBit0 + p;
+            c.sym = (u8)firstSym;
+            c.sz = sz;
+            c.st[0] = st0; c.st[1] = st1; c.st[2] = st2; c.st[3] = st3;
+            c.payloadBit = payloadBit;
+            c.kind = (u8)kind;
         }
-        __syncthreads();
-        if (err) break;
-        err = sh_err;
-        pos = sh_pos;
-        __syncthreads();
-        if (err) break;
+        pos = endPos;
     }
+    if (guessValid) asm volatile("s_waitcnt vmcnt(0)" : "+v"(guess));
     if (lane == 0) {
         if (err) db.error = KNZ_ERR_PROCESS_BLOCK;
-        db.usedBits = pos - db.entropyBit;
+        db.usedBits = pos - entropyBit;
     }
 }
 
