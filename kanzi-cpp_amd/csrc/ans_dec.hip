@@ -59,9 +59,15 @@ __device__ __forceinline__ u32 lds_bits(const u32* win, u32 rel, u32 n)
     return (u32)((v << (rel & 31)) >> (64 - n));
 }
 
-__global__ __launch_bounds__(64) void k_ans0_scan(BitSrc src, DecBlock* __restrict__ blocks, int nBlocks, int maxChunks,
-                                                  AnsDecChunk* __restrict__ chunks)
+// ORDER 0: one table per 16 KiB chunk, meta slot ci.  ORDER 1: 256 tables per 4 MiB chunk, meta slots
+// ci*257 + ctx, the chunk record (payload, states) in slot ci*257 + 256.
+template <int ORDER>
+__global__ __launch_bounds__(64) void k_ans_scan(BitSrc src, DecBlock* __restrict__ blocks, int nBlocks, int maxChunks,
+                                                 AnsDecChunk* __restrict__ chunks)
 {
+    constexpr u32 CHUNK = ORDER ? ANS1_CHUNK : ENT_CHUNK;
+    constexpr u32 DIM = ORDER ? 256u : 1u;
+    constexpr u32 MAX_LR = ORDER ? 11u : ANS_LR;       // kanzi encoders emit 12 (order 0) / 11 (order 1); larger tables are not provisioned
     const int b = blockIdx.x;
     const int lane = lane_id();
     DecBlock& db = blocks[b];
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(64) void k_ans0_scan(BitSrc src, DecBlock* __restri
         }
         return;
     }
-    const u32 nChunks = (preLen + ENT_CHUNK - 1) / ENT_CHUNK;
+    const u32 nChunks = (preLen + CHUNK - 1) / CHUNK;
     const u64 lastWord = ((src.nBytes + 3) >> 2) - 1;
     // words past the end of the buffer are clamped to its last word: positions past `limit` are rejected
     // before anything read there is trusted
@@ -112,15 +118,15 @@ __global__ __launch_bounds__(64) void k_ans0_scan(BitSrc src, DecBlock* __restri
     };
     u32x4 wr = { 0, 0, 0, 0 };
     u64 winBit0 = 0;
+    bool winValid = false;
     u32x4 guess = { 0, 0, 0, 0 };
     u64 guessBit0 = 0;
     bool guessValid = false;
-    u64 prevPos = pos;
-    u32 myGrp = 0;
-    int err = 0;
-    for (u32 ci = 0; ci < nChunks; ci++) {
-        // ---- window: the prefetched guess if it covers this header, else an exact (blocking) load
-        if (guessValid && guessBit0 <= pos && pos + SCAN_NEED_BITS <= guessBit0 + SCAN_WIN_BITS) {
+    // make stream bits [pos, pos + need) readable through `win`: keep the current window if it still covers
+    // them, else take the prefetched guess if it does, else load exactly (blocking)
+    auto ensure = [&](u32 need) {
+        if (winValid && winBit0 <= pos && pos + need <= winBit0 + SCAN_WIN_BITS) return;
+        if (guessValid && guessBit0 <= pos && pos + need <= guessBit0 + SCAN_WIN_BITS) {
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(guess));
             wr = guess; winBit0 = guessBit0;
         } else {
@@ -129,29 +135,43 @@ __global__ __launch_bounds__(64) void k_ans0_scan(BitSrc src, DecBlock* __restri
             issue(winBit0, wr);
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(wr));
         }
+        guessValid = false;
         __syncthreads();
         {
             u32x4 sw = { bswap32(wr.x), bswap32(wr.y), bswap32(wr.z), bswap32(wr.w) };
             *reinterpret_cast<u32x4*>(&win[4 * lane]) = sw;
         }
         __syncthreads();
-        // ---- prefetch for the next chunk: same compressed size as this one, window centred on the estimate
-        guessValid = false;
-        if (ci >= 1 && ci + 1 < nChunks) {
-            const u64 est = pos + (pos - prevPos);
-            guessBit0 = (est > 2304 ? est - 2304 : 0) & ~31ull;
-            issue(guessBit0, guess);
-            guessValid = true;
+        winValid = true;
+    };
+    u64 prevPos = pos;
+    u32 myGrp = 0;
+    int err = 0;
+    for (u32 ci = 0; ci < nChunks && !err; ci++) {
+        ensure(ORDER ? 3498u + 64u : SCAN_NEED_BITS);
+        if (ORDER == 0) {
+            // prefetch for the next chunk: same compressed size as this one, window centred on the estimate
+            if (guessValid) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(guess)); guessValid = false; }
+            if (ci >= 1 && ci + 1 < nChunks) {
+                const u64 est = pos + (pos - prevPos);
+                guessBit0 = (est > 2304 ? est - 2304 : 0) & ~31ull;
+                issue(guessBit0, guess);
+                guessValid = true;
+            }
+            prevPos = pos;
         }
-        prevPos = pos;
-        AnsDecChunk& c = cs[ci];
-        u32 p = (u32)(pos - winBit0);                  // all header positions are window-relative from here
-        const u32 lr = 8 + lds_bits(win, p, 3); p += 3;
-        u32 asz = 0, firstSym = 0;
-        u64 maskBit = 0;
-        if (lr > ANS_LR) err = 1;                      // kanzi encoders always emit 12; > 12 unsupported here
-        if (!err) {
-            const u32 hb = lds_bits(win, p, 7);        // flag bits and (partial alphabets) the mask count
+        const u32 lr = 8 + lds_bits(win, (u32)(pos - winBit0), 3);
+        pos += 3;
+        if (lr > MAX_LR) { err = 1; break; }
+        u32 aszSum = 0;
+        u32 firstSym = 0;
+        for (u32 k = 0; k < DIM; k++) {
+            if (ORDER) ensure(3498u + 64u);
+            AnsDecChunk& c = cs[ORDER ? ci * 257 + k : ci];
+            u32 p = (u32)(pos - winBit0);                  // header positions are window-relative from here
+            u32 asz = 0;
+            u64 maskBit = 0;
+            const u32 hb = lds_bits(win, p, 7);            // flag bits and (partial alphabets) the mask count
             if ((hb >> 6) == 0) { asz = ((hb >> 5) & 1) ? 0u : 256u; p += 2; }
             else {
                 const u32 lastMask = (hb >> 1) & 31;
@@ -169,32 +189,50 @@ __global__ __launch_bounds__(64) void k_ans0_scan(BitSrc src, DecBlock* __restri
                 }
                 p += 8u * (lastMask + 1);
             }
-            if (asz == 0) err = 2;                     // decode() returns a short count -> failure
+            asz = uni(asz);
+            if (asz == 0) {
+                if (ORDER == 0) { err = 2; break; }        // decode() returns a short count -> failure
+                pos = winBit0 + p;                         // order 1: unused context, no table
+                continue;
+            }
+            aszSum += asz;
+            // ---- group walk (uniform): remember (offset | logMax << 12) of group g in lane g
+            const u32 chk = (asz >= 64) ? 8u : 6u;
+            const u32 llr = (u32)ilog2_u32(lr) + 1u;       // 4 for every legal lr (8..12)
+            u32 q = p;
+            const u32 nGroups = (asz - 1 + chk - 1) / chk;
+            const u32 lastCnt = (asz - 1) - (nGroups - 1) * chk;
+            u32 tooBig = 0;
+            for (u32 g = 0; g < nGroups; g++) {
+                const u32 logMax = lds_bits(win, q, llr);
+                tooBig |= (logMax > lr) ? 1u : 0u;          // checked after the walk; a bad value cannot fault:
+                if ((u32)lane == g) myGrp = (q - p) | (logMax << 12);   // LDS reads past the window just return
+                q += llr + ((g + 1 == nGroups) ? lastCnt : chk) * logMax;   // unrelated words
+            }
+            if (tooBig) { err = 1; break; }
+            if ((u32)lane < nGroups) c.grp[lane] = (u16)myGrp;
+            if (lane == 0) {
+                c.lr = (u8)lr;
+                c.maskBit = maskBit;
+                c.asz = (u16)asz;
+                c.freqBit = winBit0 + p;
+                c.sym = (u8)firstSym;
+                if (ORDER) c.kind = 0;
+            }
+            pos = winBit0 + q;
         }
         if (err) break;
-        asz = uni(asz);
-        // ---- group walk (uniform): remember (offset | logMax << 12) of group g in lane g
-        const u32 chk = (asz >= 64) ? 8u : 6u;
-        const u32 llr = (u32)ilog2_u32(lr) + 1u;       // 4 for every legal lr (8..12)
-        u32 q = p;
-        const u32 nGroups = (asz - 1 + chk - 1) / chk;
-        const u32 lastCnt = (asz - 1) - (nGroups - 1) * chk;
-        u32 tooBig = 0;
-        for (u32 g = 0; g < nGroups; g++) {
-            const u32 logMax = lds_bits(win, q, llr);
-            tooBig |= (logMax > lr) ? 1u : 0u;          // checked after the walk; a bad value cannot run away:
-            if ((u32)lane == g) myGrp = (q - p) | (logMax << 12);   // q grows by <= 4 + 8*15 per group, the
-            q += llr + ((g + 1 == nGroups) ? lastCnt : chk) * logMax;   // window has 32 spare bytes behind it
-        }
-        if (tooBig) { err = 1; break; }
-        const u32 g = nGroups;
-        if ((u32)lane < g) c.grp[lane] = (u16)myGrp;
+        AnsDecChunk& cr = cs[ORDER ? ci * 257 + 256 : ci];
         u32 kind, sz = 0, st0 = 0, st1 = 0, st2 = 0, st3 = 0;
         u64 payloadBit = 0;
-        if (asz == 1) {
+        u64 endPos = pos;
+        if (ORDER == 0 && aszSum == 1) {
             kind = 1;
         } else {
-            // var-int and the 4 states; all inside the window (SCAN_NEED_BITS)
+            if (ORDER && aszSum == 0) { err = 2; break; }   // ANSRangeDecoder.cpp:196-199: short count
+            // var-int and the 4 states
+            if (ORDER) ensure(40u + 128u + 64u);
+            u32 q = (u32)(pos - winBit0);
             u32 value = lds_bits(win, q, 8); q += 8;
             u32 res = value & 0x7F;
             for (int shift = 7; value >= 128; shift += 7) {
@@ -203,25 +241,21 @@ __global__ __launch_bounds__(64) void k_ans0_scan(BitSrc src, DecBlock* __restri
                 res |= (value & 0x7F) << shift;
             }
             sz = res;
-            if (sz >= ANS_MAX_CHUNK || sz > 2 * ENT_CHUNK - 2) err = 1;
+            if (sz >= ANS_MAX_CHUNK || sz > 2 * CHUNK - 2) err = 1;
             st0 = lds_bits(win, q, 32); st1 = lds_bits(win, q + 32, 32); st2 = lds_bits(win, q + 64, 32); st3 = lds_bits(win, q + 96, 32);
             q += 128;
             payloadBit = winBit0 + q;
+            endPos = payloadBit + 8ull * sz;
             kind = 0;
         }
-        const u64 endPos = winBit0 + q + 8ull * sz;
         if (endPos > limit) err = 1;
         if (err) break;
         if (lane == 0) {
-            c.lr = (u8)lr;
-            c.maskBit = maskBit;
-            c.asz = (u16)asz;
-            c.freqBit = winBit0 + p;
-            c.sym = (u8)firstSym;
-            c.sz = sz;
-            c.st[0] = st0; c.st[1] = st1; c.st[2] = st2; c.st[3] = st3;
-            c.payloadBit = payloadBit;
-            c.kind = (u8)kind;
+            cr.sz = sz;
+            cr.st[0] = st0; cr.st[1] = st1; cr.st[2] = st2; cr.st[3] = st3;
+            cr.payloadBit = payloadBit;
+            cr.kind = (u8)kind;
+            if (ORDER) cr.lr = (u8)lr;
         }
         pos = endPos;
     }
@@ -560,8 +594,234 @@ void launch_ans0_decode(hipStream_t s, BitSrc src, DecBlock* blocks, int nBlocks
 {
     AnsDecChunk* chunks = reinterpret_cast<AnsDecChunk*>(chunkMeta);
     const int nSlots = nBlocks * maxChunks;
-    { KScope ks_("k_ans0_scan"); hipLaunchKernelGGL(k_ans0_scan, dim3(nBlocks), dim3(64), 0, s, src, blocks, nBlocks, maxChunks, chunks); }
+    { KScope ks_("k_ans0_scan"); hipLaunchKernelGGL(k_ans_scan<0>, dim3(nBlocks), dim3(64), 0, s, src, blocks, nBlocks, maxChunks, chunks); }
     { KScope ks_("k_ans0_decode"); hipLaunchKernelGGL(k_ans0_decode, dim3((nSlots + DCH - 1) / DCH), dim3(64), 0, s, src, blocks, maxChunks, nSlots, chunks, outPtr); }
+}
+
+// ------------------------------------------------------------------------------------------------
+// order 1 (ANSRangeDecoder.cpp:80-175 with 256 contexts, :218-292 order-1 branch)
+// ------------------------------------------------------------------------------------------------
+constexpr u32 A1_SLOTS_PER_CTX = 2048;       // 1 << 11
+
+// one wave per (chunk, context): slotTab[slot] = sym | freq << 8 | cum << 20
+__global__ __launch_bounds__(64) void k_ans1_tables(BitSrc src, DecBlock* __restrict__ blocks, int chunksPerBlock, int maxChunks,
+                                                    const AnsDecChunk* __restrict__ chunks, u32* __restrict__ slotTab)
+{
+    const int gc = blockIdx.x >> 8;
+    const u32 ctx = blockIdx.x & 255;
+    const int b = gc / chunksPerBlock;
+    const int ci = gc - b * chunksPerBlock;
+    if (blocks[b].error) return;
+    const AnsDecChunk* cs = chunks + (size_t)b * maxChunks + (size_t)ci * 257;
+    if (cs[256].kind != 0) return;
+    const AnsDecChunk& c = cs[ctx];
+    if (c.kind != 0) return;
+    const int lane = lane_id();
+    __shared__ u32 ent[260];
+    __shared__ u16 cumArr[260];
+    const u32 lr = c.lr;
+    const u32 scale = 1u << lr;
+    const u32 asz = c.asz;
+    u32 present;
+    if (asz == 256) present = 0xF;
+    else {
+        const u32 m = (u32)lane >> 1;
+        const u64 mb = c.maskBit + 8ull * m;
+        const u32 byte = (mb + 8 <= c.freqBit) ? peek_bits(src, mb, 8) : 0u;
+        present = (lane & 1) ? (byte >> 4) : (byte & 0xF);
+    }
+    const u32 myCount = __popc(present);
+    const u32 incl = wave_incl_scan(myCount);
+    const u32 rank0 = incl - myCount;
+    u32 r = rank0;
+    const u32 chk = (asz >= 64) ? 8u : 6u;
+    const u32 llr = (u32)ilog2_u32(lr) + 1u;
+    u32 f[4] = { 0, 0, 0, 0 };
+    u32 lsum = 0;
+    int bad = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if ((present >> k) & 1) {
+            if (r >= 1) {
+                const u32 g = (r - 1) / chk;
+                const u32 ge = c.grp[g];
+                const u32 lm = ge >> 12;
+                const u32 fv = lm ? peek_bits(src, c.freqBit + (ge & 0xFFF) + llr + (u64)((r - 1) - g * chk) * lm, lm) + 1u : 1u;
+                if (fv >= scale) bad = 1;
+                f[k] = fv;
+                lsum += fv;
+            }
+            r++;
+        }
+    }
+    const u32 sumOthers = wave_sum(lsum);
+    if (scale <= sumOthers) bad = 1;
+    if (__ballot(bad) != 0) { if (lane == 0) blocks[b].error = KNZ_ERR_PROCESS_BLOCK; return; }
+    {
+        u32 rr = rank0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if ((present >> k) & 1) { if (rr == 0) f[k] = scale - sumOthers; rr++; }
+        }
+    }
+    const u32 tot = f[0] + f[1] + f[2] + f[3];
+    const u32 cincl = wave_incl_scan(tot);
+    u32 cum = cincl - tot;
+    {
+        u32 rr = rank0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if ((present >> k) & 1) {
+                const u32 fr = f[k];
+                const u32 fclip = (fr >= scale) ? scale - 1 : fr;       // ANSRangeDecoder.hpp:47-49
+                ent[rr] = (4u * (u32)lane + (u32)k) | (fclip << 8) | (cum << 20);
+                cumArr[rr] = (u16)cum;
+                if (rr + 1 == asz) cumArr[rr + 1] = (u16)scale;
+                cum += fr;
+                rr++;
+            }
+        }
+    }
+    __syncthreads();
+    u32* tab = slotTab + ((size_t)gc * 256 + ctx) * A1_SLOTS_PER_CTX;
+    const u32 per = scale >> 6;                  // slots per lane (scale >= 256)
+    const u32 base = (u32)lane * per;
+    u32 lo = 0, hi = asz - 1;
+    while (lo < hi) {
+        const u32 mid = (lo + hi + 1) >> 1;
+        if (cumArr[mid] <= base) lo = mid; else hi = mid - 1;
+    }
+    u32 sr = lo;
+    for (u32 k = 0; k < per; k++) {
+        const u32 t = base + k;
+        while (cumArr[sr + 1] <= t) sr++;        // cumArr[asz] = scale > t
+        tab[t] = ent[sr];
+    }
+}
+
+constexpr u32 A1_RN = 1024;                  // ring items (16-bit)
+constexpr u32 A1_INTERVAL = 64;              // steps between ring checks (<= 4 items per step)
+
+// one wave per chunk: lanes 0-3 are the 4 states (state j decodes quarter j forwards, context = previous symbol
+// of the same quarter), all lanes keep the payload ring filled
+__global__ __launch_bounds__(64) void k_ans1_decode(BitSrc src, DecBlock* __restrict__ blocks, int chunksPerBlock, int maxChunks,
+                                                    const AnsDecChunk* __restrict__ chunks, const u32* __restrict__ slotTab,
+                                                    u8* const* __restrict__ outPtr)
+{
+    const int gc = blockIdx.x;
+    const int b = gc / chunksPerBlock;
+    const int ci = gc - b * chunksPerBlock;
+    const int lane = lane_id();
+    if (blocks[b].error) return;
+    const AnsDecChunk* cs = chunks + (size_t)b * maxChunks + (size_t)ci * 257;
+    if (ci == 0 && cs[0].kind == 2) {
+        // raw block (<= 32 bytes or copy block)
+        u8* dst = outPtr[b];
+        for (u32 i = lane; i < cs[0].sz; i += 64) dst[i] = (u8)peek_bits(src, cs[0].payloadBit + 8ull * i, 8);
+        return;
+    }
+    const AnsDecChunk& rec = cs[256];
+    if (rec.kind != 0) return;
+    const u32 preLen = blocks[b].preLen;
+    const u32 n = (preLen - (u32)ci * ANS1_CHUNK < ANS1_CHUNK) ? (preLen - (u32)ci * ANS1_CHUNK) : ANS1_CHUNK;
+    u8* dst = outPtr[b] + (size_t)ci * ANS1_CHUNK;
+    const u32 count4 = n & ~3u;
+    const u32 quarter = count4 >> 2;
+    const u32 lr = rec.lr;
+    const u32 mask = (1u << lr) - 1;
+    const u64 payBit = rec.payloadBit;
+    const u32 sz = rec.sz;
+    const u32* tab = slotTab + (size_t)gc * 256 * A1_SLOTS_PER_CTX;
+
+    __shared__ u32 ring[A1_RN / 2 + 2];          // 16-bit items in value form, 2 per word, + 4 mirrored items
+    const u64 lastWord = ((src.nBytes + 3) >> 2) - 1;
+    // lane loads stream bytes [off + 16*lane, +16) -> 8 items
+    auto fill_half = [&](u32 streamOff) {
+        const u32 off = streamOff + 16u * (u32)lane;
+        const u64 bit = payBit + 8ull * off;
+        const u64 w0 = bit >> 5;
+        const u32 sh = (u32)bit & 31;
+        u32 raw[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) { const u64 w = w0 + k; raw[k] = bswap32(src.words[w < lastWord ? w : lastWord]); }
+        const u32 wo = (off & (2 * A1_RN - 1)) >> 2;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u32 v = (u32)(((((u64)raw[k] << 32) | raw[k + 1]) << sh) >> 32);
+            const u32 it = (v >> 16) | (v << 16);
+            ring[wo + k] = it;
+            if (wo + k < 2) ring[A1_RN / 2 + wo + k] = it;
+        }
+    };
+    fill_half(0);
+    fill_half(A1_RN);                            // bytes: one half = A1_RN/2 items = A1_RN bytes
+    __syncthreads();
+    u32 base = 0;                                // item index of ring slot 0's current content start (multiple of RN/2)
+    u32 q = 0;                                   // items consumed
+    u32 st = (lane < 4) ? rec.st[lane & 3] : 0u;
+    const u32 j = (u32)lane & 3;
+    const u32 higherMask = (0xFu << (j + 1)) & 0xFu;
+    const u16* ring16 = reinterpret_cast<const u16*>(ring);
+    u8* myDst = dst + (size_t)j * quarter;
+    const bool aligned4 = (reinterpret_cast<uintptr_t>(myDst) & 3) == 0;
+    u32 prv = 0;
+    u32 acc = 0;
+    for (u32 s0 = 0; s0 < quarter; s0 += A1_INTERVAL) {
+        // ring upkeep (uniform): once the consumer is in the upper half of what the ring holds, replace the lower half
+        const u32 qu = uni(q);
+        if (qu - base >= A1_RN / 2) {
+            __syncthreads();
+            fill_half(2 * (base + A1_RN));       // next half in stream order lands on the slots of the oldest half
+            base += A1_RN / 2;
+            __syncthreads();
+        }
+        if (lane < 4) {
+            const u32 s1 = (s0 + A1_INTERVAL < quarter) ? s0 + A1_INTERVAL : quarter;
+            for (u32 s = s0; s < s1; s++) {
+                const u32 slotv = st & mask;
+                const u32 e = tab[prv * A1_SLOTS_PER_CTX + slotv];
+                const u32 sym = e & 0xFF;
+                st = ((e >> 8) & 0xFFF) * (st >> lr) + slotv - (e >> 20);
+                const bool flag = st < ANS_TOP;
+                const u32 m = (u32)__ballot(flag) & 0xF;
+                if (flag) {
+                    const u32 kk = __popc(m & higherMask);
+                    st = (st << 16) | (u32)ring16[(q + kk) & (A1_RN - 1)];
+                }
+                q += __popc(m);
+                prv = sym;
+                acc |= sym << (8 * (s & 3));
+                if ((s & 3) == 3) {
+                    if (aligned4) *reinterpret_cast<u32*>(myDst + (s & ~3u)) = acc;
+                    else { myDst[s - 3] = (u8)acc; myDst[s - 2] = (u8)(acc >> 8); myDst[s - 1] = (u8)(acc >> 16); myDst[s] = (u8)(acc >> 24); }
+                    acc = 0;
+                }
+            }
+        }
+    }
+    if (lane < 4) {
+        const u32 rem = quarter & 3;
+        for (u32 k = 0; k < rem; k++) myDst[(quarter & ~3u) + k] = (u8)(acc >> (8 * k));
+    }
+    if (lane == 0) {
+        const u32 p = 2 * q;
+        const u32 tail = n - count4;
+        for (u32 t = 0; t < tail; t++) dst[count4 + t] = (u8)peek_bits(src, payBit + 8ull * (p + t), 8);
+        if (p + tail != sz) blocks[b].error = KNZ_ERR_PROCESS_BLOCK;          // ANSRangeDecoder.cpp:291
+    }
+}
+
+size_t ans1_meta_bytes(size_t nChunks) { return nChunks * 257 * sizeof(AnsDecChunk); }
+size_t ans1_slottab_bytes(size_t nChunks) { return nChunks * 256 * A1_SLOTS_PER_CTX * sizeof(u32); }
+
+void launch_ans1_decode(hipStream_t s, BitSrc src, DecBlock* blocks, int nBlocks, int chunksPerBlock, const Ans1DecWs& ws, u8* const* outPtr)
+{
+    AnsDecChunk* chunks = reinterpret_cast<AnsDecChunk*>(ws.meta);
+    const int maxChunks = chunksPerBlock * 257;
+    const int nCh = nBlocks * chunksPerBlock;
+    { KScope ks_("k_ans1_scan"); hipLaunchKernelGGL(k_ans_scan<1>, dim3(nBlocks), dim3(64), 0, s, src, blocks, nBlocks, maxChunks, chunks); }
+    { KScope ks_("k_ans1_tables"); hipLaunchKernelGGL(k_ans1_tables, dim3(nCh * 256), dim3(64), 0, s, src, blocks, chunksPerBlock, maxChunks, chunks, ws.slotTab); }
+    { KScope ks_("k_ans1_decode"); hipLaunchKernelGGL(k_ans1_decode, dim3(nCh), dim3(64), 0, s, src, blocks, chunksPerBlock, maxChunks, chunks, ws.slotTab, outPtr); }
 }
 
 size_t ans0_dec_chunk_bytes() { return sizeof(AnsDecChunk); }

@@ -98,7 +98,7 @@ static int count_transforms(uint64_t t, int* tok)
 }
 
 static bool transform_supported(int t) { return t == KNZ_T_NONE || t == KNZ_T_ZRLT || t == KNZ_T_MTFT || t == KNZ_T_BWT || t == KNZ_T_SRT || t == KNZ_T_RLT; }
-static bool entropy_supported(int e) { return e == KNZ_E_NONE || e == KNZ_E_ANS0 || e == KNZ_E_HUFFMAN || e == KNZ_E_FPAQ; }
+static bool entropy_supported(int e) { return e == KNZ_E_NONE || e == KNZ_E_ANS0 || e == KNZ_E_ANS1 || e == KNZ_E_HUFFMAN || e == KNZ_E_FPAQ; }
 
 static int max_encoded_len(int t, int n)
 {
@@ -159,7 +159,10 @@ size_t knz_hip_encode_bound(const knz_params* p, size_t n)
     const size_t bs = (size_t)p->block_size;
     const size_t nb = (n + bs - 1) / bs + 1;
     // worst case: every symbol emits 16 bits (ANS) or 12 bits (Huffman) plus per-chunk headers
-    return 2 * n + nb * 64 + ((n / ENT_CHUNK) + nb) * (HDR_BYTES + 32) + 4096;
+    size_t bound = 2 * n + nb * 64 + ((n / ENT_CHUNK) + nb) * (HDR_BYTES + 32) + 4096;
+    // order-1 rANS writes 256 frequency tables per 4 MiB chunk (<= 3498 bits each), however small the block
+    if (p->entropy_type == KNZ_E_ANS1) bound += (n / ANS1_CHUNK + nb) * 256 * (size_t)HDR_BYTES;
+    return bound;
 }
 
 int knz_hip_set_profiling(knz_ctx* ctx, int enabled)
@@ -452,8 +455,12 @@ static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t 
     u8* d_skip = w.a.skip;
 
     // ---- entropy stage
-    const u32 entChunk = (p->entropy_type == KNZ_E_FPAQ) ? (4u << 20) : ENT_CHUNK;
-    const int maxChunks = (int)((S + entChunk - 1) / entChunk);
+    const bool ans1 = (p->entropy_type == KNZ_E_ANS1);
+    const u32 entChunk = (p->entropy_type == KNZ_E_FPAQ || ans1) ? (4u << 20) : ENT_CHUNK;
+    const u32 slotMul = ans1 ? ANS1_SLOTS : 1u;
+    u32 hdrStride = TMP_STRIDE;
+    const int chunksPerBlock = (int)((S + entChunk - 1) / entChunk);
+    const int maxChunks = chunksPerBlock * (int)slotMul;
     const size_t nSlots = (size_t)nBlocks * maxChunks;
     ChunkDesc* d_desc; u8* d_tmp; uint2* d_encTab;
     if (int r = ws_get(c, "desc", sizeof(ChunkDesc) * nSlots, (void**)&d_desc)) return r;
@@ -461,6 +468,17 @@ static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t 
         if (int r = ws_get(c, "chunkTmp", (size_t)TMP_STRIDE * nSlots, (void**)&d_tmp)) return r;
         if (int r = ws_get(c, "encTab", sizeof(uint2) * 256 * nSlots, (void**)&d_encTab)) return r;
         launch_ans0_encode(s, view, nBlocks, maxChunks, d_desc, d_encTab, d_tmp);
+    } else if (ans1) {
+        const size_t nCh = (size_t)nBlocks * chunksPerBlock;
+        Ans1EncWs aw;
+        aw.payStride = (2ull * std::min<u64>(S, ANS1_CHUNK) + 511) & ~255ull;
+        if (int r = ws_get(c, "ans1Hist", ans1_hist_bytes(nCh), (void**)&aw.hist)) return r;
+        if (int r = ws_get(c, "ans1EncTab", ans1_enctab_bytes(nCh), (void**)&aw.encTab)) return r;
+        if (int r = ws_get(c, "chunkTmp", (size_t)HDR_BYTES * nSlots, (void**)&d_tmp)) return r;
+        if (int r = ws_get(c, "ans1Pay", (size_t)aw.payStride * nCh, (void**)&aw.pay)) return r;
+        aw.hdr = d_tmp;
+        hdrStride = HDR_BYTES;
+        launch_ans1_encode(s, view, nBlocks, chunksPerBlock, d_desc, aw);
     } else if (p->entropy_type == KNZ_E_HUFFMAN) {
         if (int r = ws_get(c, "chunkTmp", (size_t)TMP_STRIDE * nSlots, (void**)&d_tmp)) return r;
         launch_huffman_encode(s, view, nBlocks, maxChunks, d_desc, d_tmp);
@@ -476,7 +494,7 @@ static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t 
     // ---- framing + assembly
     FrameParams fp;
     fp.framing = framing; fp.nTransforms = nTok; fp.checksumBits = p->checksum_bits; fp.finish = finish; fp.prologueBits = prologueBits;
-    launch_block_sum(s, d_desc, d_info, d_blockLen, nBlocks, maxChunks, entChunk);
+    launch_block_sum(s, d_desc, d_info, d_blockLen, nBlocks, maxChunks, entChunk, slotMul);
     launch_block_scan(s, d_info, d_blockLen, nBlocks, fp, d_total);
     // The output must be zero before the OR-assembly; its size is only known on the device, so the
     // total is read back first (8 bytes) and only the used part is cleared.
@@ -497,7 +515,7 @@ static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t 
         HIPCHK(c, hipMemcpyAsync(d_pro, prologue, (prologueBits + 7) / 8, hipMemcpyHostToDevice, s));
         launch_put_prologue(s, reinterpret_cast<u32*>(d_out), d_pro, prologueBits);
     }
-    launch_assemble(s, d_desc, d_info, d_blockLen, d_origLen, d_skip, d_sums, d_tmp, nBlocks, maxChunks, entChunk, fp,
+    launch_assemble(s, d_desc, d_info, d_blockLen, d_origLen, d_skip, d_sums, d_tmp, nBlocks, maxChunks, entChunk, slotMul, hdrStride, fp,
                     reinterpret_cast<u32*>(d_out));
     HIPCHK(c, hipGetLastError());
     if (outBits) {
@@ -583,6 +601,13 @@ static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_
         void* d_meta;
         if (int r = ws_get(c, "ansDecChunks", ans0_dec_chunk_bytes() * nSlots, &d_meta)) return r;
         launch_ans0_decode(s, src, d_blocks, nBlocks, maxChunks, d_meta, w.d_entDst);
+    } else if (p->entropy_type == KNZ_E_ANS1) {
+        const int chunksPerBlock = (int)((S + ANS1_CHUNK - 1) / ANS1_CHUNK);
+        const size_t nCh = (size_t)nBlocks * chunksPerBlock;
+        Ans1DecWs aw;
+        if (int r = ws_get(c, "ans1Meta", ans1_meta_bytes(nCh), &aw.meta)) return r;
+        if (int r = ws_get(c, "ans1SlotTab", ans1_slottab_bytes(nCh), (void**)&aw.slotTab)) return r;
+        launch_ans1_decode(s, src, d_blocks, nBlocks, chunksPerBlock, aw, w.d_entDst);
     } else if (p->entropy_type == KNZ_E_HUFFMAN) {
         void* d_meta;
         if (int r = ws_get(c, "hufDecChunks", huffman_dec_chunk_bytes() * nSlots, &d_meta)) return r;

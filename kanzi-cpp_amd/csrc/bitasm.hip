@@ -64,11 +64,11 @@ __device__ __forceinline__ u32 block_data_size(u32 postLen)
 
 
 __global__ __launch_bounds__(256) void k_block_sum(ChunkDesc* __restrict__ desc, BlockInfo* __restrict__ info,
-                                                    const u32* __restrict__ blockLen, int maxChunks, u32 chunkSize)
+                                                    const u32* __restrict__ blockLen, int maxChunks, u32 chunkSize, u32 slotMul)
 {
     const int b = blockIdx.x;
     const u32 len = blockLen[b];
-    const u32 nChunks = (len + chunkSize - 1) / chunkSize;
+    const u32 nChunks = ((len + chunkSize - 1) / chunkSize) * slotMul;
     __shared__ u64 waveTot[4];
     __shared__ u64 carry;
     if (threadIdx.x == 0) carry = 0;
@@ -131,13 +131,13 @@ __global__ void k_block_scan(BlockInfo* __restrict__ info, const u32* __restrict
 __global__ __launch_bounds__(64) void k_assemble(const ChunkDesc* __restrict__ desc, const BlockInfo* __restrict__ info,
                                                  const u32* __restrict__ blockLen, const u32* __restrict__ origLen,
                                                  const u8* __restrict__ skipFlags, const u64* __restrict__ checksums, const u8* __restrict__ hdrBase,
-                                                 int maxChunks, u32 chunkSize, FrameParams fp, u32* __restrict__ out)
+                                                 int maxChunks, u32 chunkSize, u32 slotMul, u32 hdrStride, FrameParams fp, u32* __restrict__ out)
 {
     const int slot = blockIdx.x;
     const int b = slot / maxChunks;
     const int ci = slot - b * maxChunks;
     const u32 len = blockLen[b];
-    const u32 nChunks = (len + chunkSize - 1) / chunkSize;
+    const u32 nChunks = ((len + chunkSize - 1) / chunkSize) * slotMul;
     if ((u32)ci >= nChunks) return;
     const BlockInfo bi = info[b];
     const int lane = lane_id();
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(64) void k_assemble(const ChunkDesc* __restrict__ d
     const ChunkDesc& cd = desc[slot];
     pos += cd.relBit;
     // hdr bits
-    wave_copy_bits(out, pos, hdrBase + (size_t)slot * TMP_STRIDE, cd.hdrBits);
+    wave_copy_bits(out, pos, hdrBase + (size_t)slot * hdrStride, cd.hdrBits);
     pos += cd.hdrBits;
     if (lane == 0) lane_put_bytes(out, pos, cd.mid, cd.midLen);
     pos += 8ull * cd.midLen;
@@ -257,9 +257,9 @@ void launch_walk_blocks(hipStream_t s, BitSrc src, u64 startBit, int64_t maxBloc
                        blockSize, blocks, reinterpret_cast<WalkResult*>(res)); }
 }
 
-void launch_block_sum(hipStream_t s, ChunkDesc* desc, BlockInfo* info, const u32* blockLen, int nBlocks, int maxChunks, u32 chunkSize)
+void launch_block_sum(hipStream_t s, ChunkDesc* desc, BlockInfo* info, const u32* blockLen, int nBlocks, int maxChunks, u32 chunkSize, u32 slotMul)
 {
-    { KScope ks_("k_block_sum"); hipLaunchKernelGGL(k_block_sum, dim3(nBlocks), dim3(256), 0, s, desc, info, blockLen, maxChunks, chunkSize); }
+    { KScope ks_("k_block_sum"); hipLaunchKernelGGL(k_block_sum, dim3(nBlocks), dim3(256), 0, s, desc, info, blockLen, maxChunks, chunkSize, slotMul); }
 }
 
 void launch_block_scan(hipStream_t s, BlockInfo* info, const u32* blockLen, int nBlocks, FrameParams fp, u64* totalBits)
@@ -268,10 +268,11 @@ void launch_block_scan(hipStream_t s, BlockInfo* info, const u32* blockLen, int 
 }
 
 void launch_assemble(hipStream_t s, const ChunkDesc* desc, const BlockInfo* info, const u32* blockLen, const u32* origLen, const u8* skipFlags,
-                     const u64* checksums, const u8* hdrBase, int nBlocks, int maxChunks, u32 chunkSize, FrameParams fp, u32* out)
+                     const u64* checksums, const u8* hdrBase, int nBlocks, int maxChunks, u32 chunkSize, u32 slotMul, u32 hdrStride,
+                     FrameParams fp, u32* out)
 {
     { KScope ks_("k_assemble"); hipLaunchKernelGGL(k_assemble, dim3(nBlocks * maxChunks), dim3(64), 0, s, desc, info, blockLen, origLen, skipFlags, checksums,
-                       hdrBase, maxChunks, chunkSize, fp, out); }
+                       hdrBase, maxChunks, chunkSize, slotMul, hdrStride, fp, out); }
 }
 
 __global__ void k_init_blocks(u64 n, u32 blockSize, int nBlocks, u32* origLen, u32* blockLen)

@@ -14,11 +14,12 @@ struct FrameParams {
 
 // bitasm.hip
 void launch_init_blocks(hipStream_t s, u64 n, u32 blockSize, int nBlocks, u32* origLen, u32* blockLen);
-void launch_block_sum(hipStream_t s, ChunkDesc* desc, BlockInfo* info, const u32* blockLen, int nBlocks, int maxChunks, u32 chunkSize);
+// A block owns ceil(len / chunkSize) * slotMul consecutive ChunkDesc slots (slotMul > 1: ANS1, one slot per context table).
+void launch_block_sum(hipStream_t s, ChunkDesc* desc, BlockInfo* info, const u32* blockLen, int nBlocks, int maxChunks, u32 chunkSize, u32 slotMul);
 void launch_block_scan(hipStream_t s, BlockInfo* info, const u32* blockLen, int nBlocks, FrameParams fp, u64* totalBits);
 void launch_assemble(hipStream_t s, const ChunkDesc* desc, const BlockInfo* info, const u32* blockLen, const u32* origLen,
                      const u8* skipFlags, const u64* checksums, const u8* hdrBase, int nBlocks, int maxChunks, u32 chunkSize,
-                     FrameParams fp, u32* out);
+                     u32 slotMul, u32 hdrStride, FrameParams fp, u32* out);
 void launch_put_prologue(hipStream_t s, u32* out, const u8* d_prologue, u32 bits);
 void launch_walk_blocks(hipStream_t s, BitSrc src, u64 startBit, int64_t maxBlocks, int framing, u32 rawLen, int checksumBits,
                         u32 blockSize, DecBlock* blocks, void* res);
@@ -32,6 +33,18 @@ void launch_none_decode(hipStream_t s, BitSrc src, DecBlock* blocks, int nBlocks
 void launch_ans0_encode(hipStream_t s, BlockView view, int nBlocks, int maxChunks, ChunkDesc* desc, uint2* encTab, u8* tmp);
 void launch_ans0_decode(hipStream_t s, BitSrc src, DecBlock* blocks, int nBlocks, int maxChunks, void* chunkMeta, u8* const* outPtr);
 size_t ans0_dec_chunk_bytes();
+
+// ans1.hip (order-1 rANS: 4 MiB chunks, 256 context tables per chunk)
+constexpr u32 ANS1_CHUNK = 4u << 20;
+constexpr u32 ANS1_SLOTS = 257;              // ChunkDesc slots per chunk: 256 context headers + (var-int, states, payload)
+struct Ans1EncWs { u32* hist; uint2* encTab; u8* hdr; u8* pay; u64 payStride; };
+void launch_ans1_encode(hipStream_t s, BlockView view, int nBlocks, int chunksPerBlock, ChunkDesc* desc, const Ans1EncWs& ws);
+size_t ans1_hist_bytes(size_t nChunks);
+size_t ans1_enctab_bytes(size_t nChunks);
+struct Ans1DecWs { void* meta; u32* slotTab; };
+void launch_ans1_decode(hipStream_t s, BitSrc src, DecBlock* blocks, int nBlocks, int chunksPerBlock, const Ans1DecWs& ws, u8* const* outPtr);
+size_t ans1_meta_bytes(size_t nChunks);
+size_t ans1_slottab_bytes(size_t nChunks);
 
 // One transform stage over a batch (all arrays are device arrays indexed by block).
 struct XfStage {

@@ -58,10 +58,9 @@ for name, d in datasets():
         print("%-10s %-8s enc %s dec %s %s" % (name, e, ok, dok, msg))
 
 # stream-level: blocks + framing
-for name, d, bs, e in [("text4m", c.text(4 << 20, 1), 1 << 20, "ANS0"), ("mixed3m+", c.mixed(3 * (1 << 20) + 12345, 2), 1 << 20, "ANS0"),
-                       ("mixed4m", c.mixed(4 << 20, 2), 4 << 20, "ANS0"), ("tiny", b"hello world!", 1024, "ANS0"),
-                       ("text4m-none", c.text(4 << 20, 1), 1 << 20, "NONE")]:
-    if e not in ents: continue
+STREAMS = [("text4m", c.text(4 << 20, 1), 1 << 20), ("mixed3m+", c.mixed(3 * (1 << 20) + 12345, 2), 1 << 20),
+           ("mixed4m", c.mixed(4 << 20, 2), 4 << 20), ("tiny", b"hello world!", 1024), ("mixed9m", c.mixed(9 * (1 << 20) + 3, 5), 16 << 20)]
+for name, d, bs, e in [(nm, dd, b_, e_) for e_ in ents for (nm, dd, b_) in STREAMS]:
     rc, ref = O.compress(d, "NONE", e, bs, headerless=1)
     p = ctx.params("NONE", e, bs)
     cap = ctx.encode_bound(p, len(d))
