@@ -593,7 +593,9 @@ static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_
     const u64 outStride = framing ? bs : 0;
 
     // entropy stage decodes into workspace A (or straight into d_out when no transform applies)
-    launch_check_prelen(s, d_blocks, nBlocks, realStages ? maxPre : unit, outCap, outStride);
+    // with inverse stages the entropy decoder writes into the workspace (any valid preTransformLength fits);
+    // the room in the caller's buffer is enforced where the last inverse stage gets its capacity
+    launch_check_prelen(s, d_blocks, nBlocks, realStages ? maxPre : unit, realStages ? ~0ull : (u64)outCap, outStride);
     u32 realMask = 0;
     for (int i = 0; i < nTok; i++) if (tok[i] != KNZ_T_NONE) realMask |= 1u << (7 - i);
     launch_seq_inv_entropy_dst(s, w.a, d_blocks, nBlocks, d_out, outStride, w.A, S, w.d_entDst, realMask);
@@ -624,7 +626,7 @@ static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_
         const u32 capMid = framing ? (u32)std::min<u64>(S, blkLenModel) : (u32)p->jobs;
         for (int i = nTok - 1; i >= 0; i--) {
             if (tok[i] == KNZ_T_NONE) continue;
-            launch_seq_inv_prepare(s, w.a, d_blocks, nBlocks, i, d_out, outStride, w.A, w.B, S, capMid, capFinal, realMask);
+            launch_seq_inv_prepare(s, w.a, d_blocks, nBlocks, i, d_out, outStride, w.A, w.B, S, capMid, capFinal, realMask, framing ? (u64)outCap : ~0ull);
             XfStage st;
             st.src = w.a.src; st.dst = w.a.dst; st.len = w.a.alen; st.cap = w.a.cap; st.ok = w.a.ok; st.newLen = w.a.newLen;
             st.nBlocks = nBlocks; st.maxLen = (u32)S; st.scratchU32 = w.scratch; st.entropyType = p->entropy_type;

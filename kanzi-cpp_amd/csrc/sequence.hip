@@ -85,7 +85,7 @@ __global__ void k_seq_inv_entropy_dst(SeqArrays a, DecBlock* blocks, int nBlocks
 }
 
 __global__ void k_seq_inv_prepare(SeqArrays a, DecBlock* blocks, int nBlocks, int stage, u8* out, u64 outStride, u8* A, u8* B, u64 S,
-                                  u32 capMid, u32 capFinal, u32 realMask)
+                                  u32 capMid, u32 capFinal, u32 realMask, u64 outCap)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nBlocks) return;
@@ -98,7 +98,14 @@ __global__ void k_seq_inv_prepare(SeqArrays a, DecBlock* blocks, int nBlocks, in
     const u8 w = a.where[b];
     a.src[b] = (w == 1) ? A + (size_t)b * S : B + (size_t)b * S;
     if (lower) { a.dst[b] = (w == 1) ? B + (size_t)b * S : A + (size_t)b * S; a.cap[b] = capMid; }
-    else { a.dst[b] = out + (size_t)b * outStride; a.cap[b] = capFinal; }
+    else {
+        // the last inverse to run writes into the caller's buffer, never past its end (a short last block may
+        // leave less than a block of room)
+        const u64 off = (u64)b * outStride;
+        const u64 room = (outCap > off) ? outCap - off : 0;
+        a.dst[b] = out + off;
+        a.cap[b] = (room < capFinal) ? (u32)room : capFinal;
+    }
     a.swaps[b] = lower ? 1 : 0;      // 1 = result stays in a workspace
     a.ok[b] = 0;
     a.newLen[b] = 0;
@@ -127,8 +134,8 @@ void launch_seq_fwd_finish(hipStream_t s, const SeqArrays& a, int nBlocks, const
 { KScope ks_("k_seq_fwd_finish"); L1D(k_seq_fwd_finish, a, nBlocks, in, inStride, A, B, S, viewPtr); }
 void launch_seq_inv_entropy_dst(hipStream_t s, const SeqArrays& a, DecBlock* blocks, int nBlocks, u8* out, u64 outStride, u8* A, u64 S, u8** entDst, u32 realMask)
 { KScope ks_("k_seq_inv_entropy_dst"); L1D(k_seq_inv_entropy_dst, a, blocks, nBlocks, out, outStride, A, S, entDst, realMask); }
-void launch_seq_inv_prepare(hipStream_t s, const SeqArrays& a, DecBlock* blocks, int nBlocks, int stage, u8* out, u64 outStride, u8* A, u8* B, u64 S, u32 capMid, u32 capFinal, u32 realMask)
-{ KScope ks_("k_seq_inv_prepare"); L1D(k_seq_inv_prepare, a, blocks, nBlocks, stage, out, outStride, A, B, S, capMid, capFinal, realMask); }
+void launch_seq_inv_prepare(hipStream_t s, const SeqArrays& a, DecBlock* blocks, int nBlocks, int stage, u8* out, u64 outStride, u8* A, u8* B, u64 S, u32 capMid, u32 capFinal, u32 realMask, u64 outCap)
+{ KScope ks_("k_seq_inv_prepare"); L1D(k_seq_inv_prepare, a, blocks, nBlocks, stage, out, outStride, A, B, S, capMid, capFinal, realMask, outCap); }
 void launch_seq_inv_commit(hipStream_t s, const SeqArrays& a, DecBlock* blocks, int nBlocks, int stage, int ttype)
 { KScope ks_("k_seq_inv_commit"); L1D(k_seq_inv_commit, a, blocks, nBlocks, stage, ttype); }
 

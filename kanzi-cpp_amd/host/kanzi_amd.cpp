@@ -559,16 +559,14 @@ int DeviceEntropyDecoder::decode(byte block[], uint blkptr, uint len)
     return int(decoded);
 }
 
-ANSRangeEncoder::ANSRangeEncoder(OutputBitStream& obs, int order) : DeviceEntropyEncoder(obs, KNZ_E_ANS0)
+ANSRangeEncoder::ANSRangeEncoder(OutputBitStream& obs, int order) : DeviceEntropyEncoder(obs, order == 1 ? KNZ_E_ANS1 : KNZ_E_ANS0)
 {
     if ((order != 0) && (order != 1)) throw std::invalid_argument("ANS Codec: The order must be 0 or 1");
-    if (order == 1) throw std::invalid_argument("ANS Codec: order 1 has no device kernel yet (stretch row of the scope table)");
 }
 
-ANSRangeDecoder::ANSRangeDecoder(InputBitStream& ibs, int order) : DeviceEntropyDecoder(ibs, KNZ_E_ANS0)
+ANSRangeDecoder::ANSRangeDecoder(InputBitStream& ibs, int order) : DeviceEntropyDecoder(ibs, order == 1 ? KNZ_E_ANS1 : KNZ_E_ANS0)
 {
     if ((order != 0) && (order != 1)) throw std::invalid_argument("ANS Codec: The order must be 0 or 1");
-    if (order == 1) throw std::invalid_argument("ANS Codec: order 1 has no device kernel yet (stretch row of the scope table)");
 }
 
 static const struct { const char* name; short type; } ENAMES[] = {
@@ -593,6 +591,7 @@ EntropyEncoder* EntropyEncoderFactory::newEncoder(OutputBitStream& obs, Context&
     switch (entropyType) {
     case HUFFMAN_TYPE: return new HuffmanEncoder(obs);
     case ANS0_TYPE: return new ANSRangeEncoder(obs, 0);
+    case ANS1_TYPE: return new ANSRangeEncoder(obs, 1);
     case FPAQ_TYPE: return new FPAQEncoder(obs);
     case NONE_TYPE: return new NullEntropyEncoder(obs);
     default: throw std::invalid_argument(std::string("Entropy codec '") + getName(entropyType) + "' has no device kernel");
@@ -604,6 +603,7 @@ EntropyDecoder* EntropyDecoderFactory::newDecoder(InputBitStream& ibs, Context&,
     switch (entropyType) {
     case EntropyEncoderFactory::HUFFMAN_TYPE: return new HuffmanDecoder(ibs);
     case EntropyEncoderFactory::ANS0_TYPE: return new ANSRangeDecoder(ibs, 0);
+    case EntropyEncoderFactory::ANS1_TYPE: return new ANSRangeDecoder(ibs, 1);
     case EntropyEncoderFactory::FPAQ_TYPE: return new FPAQDecoder(ibs);
     case EntropyEncoderFactory::NONE_TYPE: return new NullEntropyDecoder(ibs);
     default: throw std::invalid_argument(std::string("Entropy codec '") + getName(entropyType) + "' has no device kernel");

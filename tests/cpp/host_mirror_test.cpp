@@ -82,7 +82,7 @@ static void testTransforms()
 static void testEntropy()
 {
     const short types[] = { EntropyEncoderFactory::NONE_TYPE, EntropyEncoderFactory::HUFFMAN_TYPE, EntropyEncoderFactory::ANS0_TYPE,
-                            EntropyEncoderFactory::FPAQ_TYPE };
+                            EntropyEncoderFactory::ANS1_TYPE, EntropyEncoderFactory::FPAQ_TYPE };
     for (short t : types) {
         for (int kind = 0; kind < 5; kind++) {
             for (size_t n : { size_t(20), size_t(4096), size_t(100000) }) {
@@ -129,12 +129,13 @@ static void testStreams()
 {
     // src/test/TestCompressedStream.cpp: sizes 64 KiB .. 4 MiB, several job counts, write/read after close
     struct Cfg { const char* t; const char* e; int bs; } cfgs[] = {
-        { "NONE", "ANS0", 65536 }, { "BWT+MTFT+ZRLT", "ANS0", 262144 }, { "RLT+ZRLT", "HUFFMAN", 65536 }, { "BWT+SRT+ZRLT", "FPAQ", 262144 } };
+        { "NONE", "ANS0", 65536 }, { "BWT+MTFT+ZRLT", "ANS0", 262144 }, { "RLT+ZRLT", "HUFFMAN", 65536 }, { "BWT+SRT+ZRLT", "FPAQ", 262144 }, { "SRT", "ANS1", 262144 } };
     for (const Cfg& cf : cfgs) {
         for (int jobs = 1; jobs <= 4; jobs += 3) {
             for (size_t n : { size_t(0), size_t(1), size_t(65536), size_t(1000001) }) {
                 std::vector<byte> in = gen(int(n % 5), n, unsigned(n + jobs));
                 std::stringstream ss;
+                if (getenv("KNZ_TEST_VERBOSE")) { printf("stream %s %s bs=%d jobs=%d n=%zu\n", cf.t, cf.e, cf.bs, jobs, n); fflush(stdout); }
                 {
                     CompressedOutputStream cos(ss, jobs, cf.e, cf.t, cf.bs);
                     size_t off = 0;

@@ -30,7 +30,8 @@ def test_c_api_roundtrip_and_bit_exact(tmp_path, oracle):
     kz = _kanzi()
     assert kz.lib().getCompressorVersion() == 0x010000 and kz.lib().getDecompressorVersion() == 0x010000
     for transform, entropy, bs, jobs, n in [("none", "huffman", 1024, 1, 1024 * 3 + 100), ("BWT+MTFT+ZRLT", "ANS0", 65536, 2, 300000),
-                                            ("bwt+srt+zrlt", "fpaq", 65530, 3, 200001), ("RLT", "NONE", 4096, 1, 0)]:
+                                            ("bwt+srt+zrlt", "fpaq", 65530, 3, 200001), ("RLT", "NONE", 4096, 1, 0),
+                                            ("srt", "ans1", 262144, 2, 600000)]:
         data = vectors.make(("fill17", n)) if n < 5000 else vectors.make(("mixed", n, 5))
         path = str(tmp_path / "x.knz")
         c = kz.Compressor(path, transform, entropy, bs, jobs)

@@ -12,7 +12,7 @@ import vectors
 
 pytestmark = pytest.mark.gpu
 
-ENTROPY_ON_DEVICE = ["NONE", "ANS0", "HUFFMAN", "FPAQ"]
+ENTROPY_ON_DEVICE = ["NONE", "ANS0", "ANS1", "HUFFMAN", "FPAQ"]
 TRANSFORMS_ON_DEVICE = ["ZRLT", "MTFT", "BWT", "SRT", "RLT"]
 
 
@@ -217,7 +217,7 @@ def test_full_size_roundtrip_properties(hip):
     # BASELINE config 2 geometry (4 MiB blocks): round trip + determinism on 32 MiB, checked on the device side
     d = vectors.make(("mixed", 32 << 20, 2))
     for t, e, bs in [("NONE", "ANS0", 4 << 20), ("NONE", "HUFFMAN", 4 << 20), ("BWT+MTFT+ZRLT", "ANS0", 8 << 20),
-                     ("BWT+SRT+ZRLT", "FPAQ", 32 << 20)]:
+                     ("BWT+SRT+ZRLT", "FPAQ", 32 << 20), ("NONE", "ANS1", 16 << 20)]:
         out1, bits1, _ = gpu_compress(hip, d, t, e, bs, headerless=1)
         out2, bits2, _ = gpu_compress(hip, d, t, e, bs, headerless=1)
         assert out1 == out2, (t, e)
