@@ -117,10 +117,17 @@ __global__ __launch_bounds__(64) void k_ans0_stats(BlockView view, int maxChunks
 // ------------------------------------------------------------------------------------------------
 // encode: 16 chunks per wave, 4 lanes (= 4 rANS states) per chunk
 // ------------------------------------------------------------------------------------------------
+template <int K>
+__device__ __forceinline__ u32 quad_bcast(u32 v)
+{
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, K * 0x55, 0xF, 0xF, false);
+}
+
 __global__ __launch_bounds__(64) void k_ans0_encode(BlockView view, int maxChunks, int nSlots, ChunkDesc* __restrict__ desc,
                                                     const uint2* __restrict__ encTab, u8* __restrict__ tmp)
 {
     __shared__ uint2 tab[16][256];                   // 32 KiB
+    __shared__ uint4 stage[16][16];                  // 256 B of staged output per chunk
     const int lane = lane_id();
     const int g = lane >> 2;
     const int j = lane & 3;
@@ -157,44 +164,92 @@ __global__ __launch_bounds__(64) void k_ans0_encode(BlockView view, int maxChunk
     u8* pay = tmp + (size_t)slot * TMP_STRIDE + HDR_BYTES;
     // exclusive end of the payload area; shifted by one when the raw tail is odd so that every
     // 16-bit emission lands on an even address
-    u32 top = PAY_BYTES - (tail & 1);
+    const u32 top = PAY_BYTES - (tail & 1);
+    // Emissions are staged in a 256-byte LDS ring per chunk (payload offset & 255) and written out in
+    // 128-byte lines by the chunk's own 4 lanes; the input is read 16 steps ahead (4 dwords per lane).
+    u8* stg = reinterpret_cast<u8*>(stage[g]);
     if (act && j == 0) {
-        for (u32 t = 0; t < tail; t++) pay[top - tail + t] = blk[end4 + t];   // ANSRangeEncoder.cpp:204-205
+        for (u32 t = 0; t < tail; t++) stg[(top - tail + t) & 255] = blk[end4 + t];   // ANSRangeEncoder.cpp:204-205
     }
     u32 q = top - tail;                               // current (exclusive) low end of emitted bytes
+    u32 Hi = PAY_BYTES;                               // payload bytes [Hi, PAY_BYTES) are already in global memory
     u32 st = ANS_TOP;
     const u32 steps = act ? (end4 >> 2) : 0;
     const u32 maxSteps = wave_max(steps);
-    const u32 jsh = 8u * (3u - (u32)j);
     const uint2* mytab = tab[g];
     const u32 grpShift = (u32)(lane & ~3);
     const u32 lowMask = (1u << j) - 1u;
-
-    for (u32 s = 0; s < maxSteps; s++) {
-        const bool on = s < steps;
-        u32 sym = 0;
-        if (on) {
-            const u32 w = *reinterpret_cast<const u32*>(blk + end4 - 4 - 4 * s);
-            sym = (w >> jsh) & 0xFF;
+    const u32 jsh = 8u * (3u - (u32)j);
+    // step s encodes dword (end4/4 - 1 - s); lanes without a chunk read a harmless valid address instead
+    const u32* blkw = act ? reinterpret_cast<const u32*>(blk) : reinterpret_cast<const u32*>(encTab);
+    const int nDw = act ? (int)(end4 >> 2) : 0;
+    // dwords of interval k (steps 16k .. 16k+15): lane j holds dwords nDw - 16(k+1) + 4j + c, c = 0..3 (clamped at 0)
+    auto load_interval = [&](u32 k, u32 r[4]) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            int idx = nDw - 16 * (int)(k + 1) + 4 * (int)j + c;
+            idx = idx < 0 ? 0 : idx;
+            r[c] = blkw[idx];
         }
-        const uint2 e = mytab[sym];
+    };
+    auto flush_line = [&]() {
+        // payload bytes [Hi - 128, Hi) are final: lane j writes 32 of them
+        const u32 off = Hi - 128 + 32u * (u32)j;
+        const uint4 v0 = *reinterpret_cast<const uint4*>(stg + (off & 255));
+        const uint4 v1 = *reinterpret_cast<const uint4*>(stg + ((off + 16) & 255));
+        *reinterpret_cast<uint4*>(pay + off) = v0;
+        *reinterpret_cast<uint4*>(pay + off + 16) = v1;
+    };
+    // one step with the table entry already in registers (the entry of the next step is fetched before this
+    // one is processed, so the LDS latency is off the state chain)
+    auto step = [&](u32 s, uint2 e) {
+        const bool on = s < steps;
         const u32 fr = e.y & 0x1FFF;
         const u32 sh = (e.y >> 13) & 0xF;
         const u32 bias = e.y >> 17;
         const bool flag = on && (st >= (fr << 19));
         const u64 m = __ballot(flag);
         const u32 grp = (u32)(m >> grpShift) & 0xF;
-        if (flag) {
-            const u32 before = __popc(grp & lowMask);
-            const u32 a = q - 2 * (before + 1);
-            *reinterpret_cast<u16*>(pay + a) = (u16)(((st >> 8) & 0xFF) | ((st & 0xFF) << 8));
-            st >>= 16;
-        }
+        const u32 before = __popc(grp & lowMask);
+        const u32 a = q - 2 * (before + 1);
+        if (flag) *reinterpret_cast<u16*>(stg + (a & 255)) = (u16)(((st >> 8) & 0xFF) | ((st & 0xFF) << 8));
+        st = flag ? (st >> 16) : st;
         q -= 2 * __popc(grp);
-        if (on) {
-            const u32 qd = __umulhi(st, e.x) >> sh;
-            st = st + bias + qd * (ANS_SCALE - fr);
+        const u32 qd = __umulhi(st, e.x) >> sh;
+        const u32 stn = st + bias + qd * (ANS_SCALE - fr);
+        st = on ? stn : st;
+    };
+    // dword d (0..15) of an interval held as r[d & 3] of lane d >> 2
+    auto entry_of = [&](const u32 r[4], int d) -> uint2 {
+        u32 w;
+        switch (d >> 2) {
+        case 0: w = quad_bcast<0>(r[d & 3]); break;
+        case 1: w = quad_bcast<1>(r[d & 3]); break;
+        case 2: w = quad_bcast<2>(r[d & 3]); break;
+        default: w = quad_bcast<3>(r[d & 3]); break;
         }
+        return mytab[(w >> jsh) & 0xFF];
+    };
+    u32 cur[4], nxt[4];
+    load_interval(0, cur);
+    const u32 nIntervals = (maxSteps + 15) >> 4;
+    uint2 e = entry_of(cur, 15);                      // step 16k+u uses dword 15-u of interval k
+    for (u32 k = 0; k < nIntervals; k++) {
+        load_interval(k + 1, nxt);
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const uint2 en = (u < 15) ? entry_of(cur, 14 - u) : entry_of(nxt, 15);
+            step(16 * k + (u32)u, e);
+            e = en;
+        }
+        if (act && q + 128 <= Hi) { flush_line(); Hi -= 128; }
+#pragma unroll
+        for (int c = 0; c < 4; c++) cur[c] = nxt[c];
+    }
+    // remaining staged bytes [q, Hi): 16-bit units, interleaved over the chunk's 4 lanes
+    if (act) {
+        for (u32 a = q + 2 * (u32)j; a < Hi; a += 8)
+            *reinterpret_cast<u16*>(pay + a) = *reinterpret_cast<const u16*>(stg + (a & 255));
     }
 
     // varint(size) + 4 states -> mid ; payload piece
