@@ -52,15 +52,18 @@ __global__ __launch_bounds__(64) void k_ans0_stats(BlockView view, int maxChunks
     }
     const u32 n = (len - start < ENT_CHUNK) ? (len - start) : ENT_CHUNK;
 
-    __shared__ u32 hist[4][256];
+    // 8 private histograms, chosen by lane: one ds_add instruction never sends more than 8 lanes to the same
+    // copy, which is what bounds the same-address serialisation on skewed data (text: 15 % spaces)
+    __shared__ u32 hist[8][256];
     __shared__ u32 hdrw[HDR_WORDS];
     __shared__ u32 grpMax[64];
-    for (int i = lane; i < 1024; i += 64) (&hist[0][0])[i] = 0;
+    for (int i = lane; i < 2048; i += 64) (&hist[0][0])[i] = 0;
     for (int i = lane; i < (int)HDR_WORDS; i += 64) hdrw[i] = 0;
     grpMax[lane] = 0;
     __syncthreads();
 
-    // ---- histogram (Global.cpp:170-221): 16 bytes per lane per iteration, 4 private copies
+    // ---- histogram (Global.cpp:170-221): 16 bytes per lane per iteration
+    u32* myHist = hist[lane & 7];
     const u32 n16 = n & ~15u;
     const bool aligned = ((reinterpret_cast<uintptr_t>(blk) & 15) == 0);
     if (aligned) {
@@ -70,16 +73,16 @@ __global__ __launch_bounds__(64) void k_ans0_stats(BlockView view, int maxChunks
             const u32 w[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                atomicAdd(&hist[0][w[k] & 0xFF], 1u);
-                atomicAdd(&hist[1][(w[k] >> 8) & 0xFF], 1u);
-                atomicAdd(&hist[2][(w[k] >> 16) & 0xFF], 1u);
-                atomicAdd(&hist[3][w[k] >> 24], 1u);
+                atomicAdd(&myHist[w[k] & 0xFF], 1u);
+                atomicAdd(&myHist[(w[k] >> 8) & 0xFF], 1u);
+                atomicAdd(&myHist[(w[k] >> 16) & 0xFF], 1u);
+                atomicAdd(&myHist[w[k] >> 24], 1u);
             }
         }
     } else {
-        for (u32 i = lane; i < n16; i += 64) atomicAdd(&hist[i & 3][blk[i]], 1u);
+        for (u32 i = lane; i < n16; i += 64) atomicAdd(&myHist[blk[i]], 1u);
     }
-    for (u32 i = n16 + lane; i < n; i += 64) atomicAdd(&hist[0][blk[i]], 1u);
+    for (u32 i = n16 + lane; i < n; i += 64) atomicAdd(&myHist[blk[i]], 1u);
     __syncthreads();
 
     // lane owns symbols 4*lane .. 4*lane+3
@@ -87,7 +90,10 @@ __global__ __launch_bounds__(64) void k_ans0_stats(BlockView view, int maxChunks
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int s = 4 * lane + k;
-        f[k] = hist[0][s] + hist[1][s] + hist[2][s] + hist[3][s];
+        u32 acc = 0;
+#pragma unroll
+        for (int c = 0; c < 8; c++) acc += hist[c][s];
+        f[k] = acc;
     }
     u32 present = 0;
 #pragma unroll

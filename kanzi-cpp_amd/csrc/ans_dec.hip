@@ -97,24 +97,11 @@ __global__ __launch_bounds__(64) void k_ans_scan(BitSrc src, DecBlock* __restric
     auto issue = [&](u64 bit0, u32x4& dstv) {
         const u64 w = (bit0 >> 5) + 4ull * (u32)lane;
         const u64 w1 = w + 1, w2 = w + 2, w3 = w + 3;
-        const bool inside = w3 <= lastWord;
-        if (__builtin_expect(__ballot(!inside) == 0, 1)) {
-            const u32* a = src.words + w;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dstv) : "v"(a));
-        } else {
-            const u32* p = src.words;
-            const u32* a0 = p + (w < lastWord ? w : lastWord);
-            const u32* a1 = p + (w1 < lastWord ? w1 : lastWord);
-            const u32* a2 = p + (w2 < lastWord ? w2 : lastWord);
-            const u32* a3 = p + (w3 < lastWord ? w3 : lastWord);
-            u32 t0, t1, t2, t3;
-            asm volatile("global_load_dword %0, %1, off" : "=v"(t0) : "v"(a0));
-            asm volatile("global_load_dword %0, %1, off" : "=v"(t1) : "v"(a1));
-            asm volatile("global_load_dword %0, %1, off" : "=v"(t2) : "v"(a2));
-            asm volatile("global_load_dword %0, %1, off" : "=v"(t3) : "v"(a3));
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
-            dstv.x = t0; dstv.y = t1; dstv.z = t2; dstv.w = t3;
-        }
+        const u32* p = src.words;
+        dstv.x = p[w < lastWord ? w : lastWord];
+        dstv.y = p[w1 < lastWord ? w1 : lastWord];
+        dstv.z = p[w2 < lastWord ? w2 : lastWord];
+        dstv.w = p[w3 < lastWord ? w3 : lastWord];
     };
     u32x4 wr = { 0, 0, 0, 0 };
     u64 winBit0 = 0;
@@ -127,13 +114,10 @@ __global__ __launch_bounds__(64) void k_ans_scan(BitSrc src, DecBlock* __restric
     auto ensure = [&](u32 need) {
         if (winValid && winBit0 <= pos && pos + need <= winBit0 + SCAN_WIN_BITS) return;
         if (guessValid && guessBit0 <= pos && pos + need <= guessBit0 + SCAN_WIN_BITS) {
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(guess));
             wr = guess; winBit0 = guessBit0;
         } else {
-            if (guessValid) asm volatile("s_waitcnt vmcnt(0)" : "+v"(guess));
             winBit0 = pos & ~31ull;
             issue(winBit0, wr);
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(wr));
         }
         guessValid = false;
         __syncthreads();
@@ -151,7 +135,7 @@ __global__ __launch_bounds__(64) void k_ans_scan(BitSrc src, DecBlock* __restric
         ensure(ORDER ? 3498u + 64u : SCAN_NEED_BITS);
         if (ORDER == 0) {
             // prefetch for the next chunk: same compressed size as this one, window centred on the estimate
-            if (guessValid) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(guess)); guessValid = false; }
+            guessValid = false;
             if (ci >= 1 && ci + 1 < nChunks) {
                 const u64 est = pos + (pos - prevPos);
                 guessBit0 = (est > 2304 ? est - 2304 : 0) & ~31ull;
@@ -259,7 +243,6 @@ __global__ __launch_bounds__(64) void k_ans_scan(BitSrc src, DecBlock* __restric
         }
         pos = endPos;
     }
-    if (guessValid) asm volatile("s_waitcnt vmcnt(0)" : "+v"(guess));
     if (lane == 0) {
         if (err) db.error = KNZ_ERR_PROCESS_BLOCK;
         db.usedBits = pos - entropyBit;
@@ -274,8 +257,9 @@ __global__ __launch_bounds__(64) void k_ans_scan(BitSrc src, DecBlock* __restric
 //   symt[rank..+3]  -> the (at most 4) symbols a bucket can hold, cum << 20 | freq << 8 | sym  (1 KiB / chunk)
 // and a branch-free pick of the entry with the largest cum <= slot.  The payload bytes a step may need
 // (4 big-endian 16-bit items at the shared pointer) are read from a 256-byte LDS ring at the top of the step,
-// off the chain; the ring is topped up 64 bytes at a time by the chunk's own 4 lanes, with the global loads
-// issued one check interval (8 steps) before their data is written to LDS.
+// off the chain; the ring is topped up 64 bytes at a time by the chunk's own 4 lanes: every 8 steps each lane
+// loads the next 16 bytes behind the filled part unconditionally (so the loads are plain, pipelined loads) and
+// commits the data loaded 8 steps earlier if the consumer has made room for it.
 constexpr int DCH = 16;              // chunks per wave (4 lanes each)
 constexpr u32 RB = 256;              // ring bytes per chunk
 constexpr u32 RQ = 64;               // refill quantum (16 bytes per lane)
@@ -464,21 +448,6 @@ __global__ __launch_bounds__(64) void k_ans0_decode(BitSrc src, DecBlock* __rest
 #pragma unroll
         for (int k = 0; k < 5; k++) { const u64 w = w0 + k; raw[k] = src.words[w < lastWord ? w : lastWord]; }
     };
-    // The in-loop prefetch is issued through inline asm: hipcc's waitcnt pass otherwise parks an
-    // s_waitcnt vmcnt(0) right behind the loads (at the join that follows the divergent refill branch), which
-    // makes the prefetch synchronous.  The matching wait is wait_pend(), 8 steps later.
-    auto load5_async = [&](u32 streamOff, u32 raw[5]) {
-        const u64 w0 = (payBit + 8ull * streamOff) >> 5;
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            const u64 w = w0 + k;
-            const u32* a = src.words + (w < lastWord ? w : lastWord);
-            asm volatile("global_load_dword %0, %1, off" : "=v"(raw[k]) : "v"(a));
-        }
-    };
-    auto wait_pend = [&](u32 raw[5]) {
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]));
-    };
     // item form of 4 stream bytes s0 s1 s2 s3 (big-endian word v): low half = s0<<8|s1, high half = s2<<8|s3
     auto store4 = [&](u32 streamOff, const u32 raw[5]) {
         const u32 sh = (u32)(payBit + 8ull * streamOff) & 31;
@@ -511,8 +480,7 @@ __global__ __launch_bounds__(64) void k_ans0_decode(BitSrc src, DecBlock* __rest
     const u16* ring16 = reinterpret_cast<const u16*>(ringW);
     u32 q = 0;                            // 16-bit items consumed (shared by the chunk's 4 lanes)
     u32 F = RB;                           // stream bytes [F - RB, F) are in the ring
-    u32 pend[5] = { 0, 0, 0, 0, 0 };
-    bool hasPend = false;
+    u32 pend[5];                          // raw words of stream bytes [F + 16j, +16), loaded one interval ago
     const u32 grpShift64 = (u32)(lane & ~3);
     const u32 higherMask = (0xFu << (j + 1)) & 0xFu;
     const bool aligned4 = act && ((reinterpret_cast<uintptr_t>(dst) & 3) == 0);
@@ -547,15 +515,15 @@ __global__ __launch_bounds__(64) void k_ans0_decode(BitSrc src, DecBlock* __rest
             else { dst[4 * stepIdx] = (u8)word; dst[4 * stepIdx + 1] = (u8)(word >> 8); dst[4 * stepIdx + 2] = (u8)(word >> 16); dst[4 * stepIdx + 3] = (u8)(word >> 24); }
         }
     };
+    load5(F + 16u * (u32)j, pend);
     u32 s0 = 0;
     u32 heldWord = 0, heldIdx = 0xFFFFFFFFu;          // second quad of an interval, stored one step into the next
     for (; s0 + CHECK_STEPS <= maxSteps; s0 += CHECK_STEPS) {
-        // ring upkeep: the last output store was issued 6 steps ago, so the vmcnt wait in front of the LDS
-        // write finds the prefetch (issued 8 steps ago) and that store already complete
-        if (s0) {
-            if (hasPend) { wait_pend(pend); store4(F + 16u * (u32)j, pend); F += RQ; hasPend = false; }
-            if (act && F < sz && F + RQ <= 2 * q + RB) { load5_async(F + 16u * (u32)j, pend); hasPend = true; }
-        }
+        // ring upkeep.  Every interval every lane loads the next quantum at F (plain loads, no divergence, so
+        // the compiler pipelines them across the interval); one interval later the data is committed to the
+        // ring if the consumer has made room for it, else it is simply loaded again.
+        if (s0 && act && F < sz && F + RQ <= 2 * q + RB) { store4(F + 16u * (u32)j, pend); F += RQ; }
+        load5(F + 16u * (u32)j, pend);
         u32 acc = 0;
 #pragma unroll
         for (u32 u = 0; u < CHECK_STEPS; u++) {
@@ -567,7 +535,7 @@ __global__ __launch_bounds__(64) void k_ans0_decode(BitSrc src, DecBlock* __rest
     }
     put_word(heldWord, heldIdx);
     // remaining (< 8) steps; the ring still holds >= 64 unread bytes or everything up to the chunk's end
-    if (hasPend) { wait_pend(pend); store4(F + 16u * (u32)j, pend); F += RQ; hasPend = false; }
+    if (s0 && act && F < sz && F + RQ <= 2 * q + RB) { store4(F + 16u * (u32)j, pend); F += RQ; }
     {
         u32 acc = 0;
         for (u32 s = s0; s < maxSteps; s++) {
