@@ -197,150 +197,6 @@ void launch_fpaq_decode(hipStream_t s, BitSrc src, DecBlock* blocks, int nBlocks
 }
 
 // ================================================================================================
-// SRT
-// ================================================================================================
-__device__ int srt_preprocess(const u32* freqs, u8* symbols)
-{
-    int nbSymbols = 0;
-    for (int i = 0; i < 256; i++) { if (freqs[i] == 0) continue; symbols[nbSymbols++] = (u8)i; }
-    int h = 4;
-    while (h < nbSymbols) h = h * 3 + 1;
-    do {
-        h /= 3;
-        for (int i = h; i < nbSymbols; i++) {
-            const u8 t = symbols[i];
-            int b;
-            for (b = i - h; b >= 0; b -= h) {
-                const int val = (int)(freqs[symbols[b]] - freqs[t]);
-                if ((val >= 0) && ((val != 0) || (t >= symbols[b]))) break;
-                symbols[b + h] = symbols[b];
-            }
-            symbols[b + h] = t;
-        }
-    } while (h != 1);
-    return nbSymbols;
-}
-
-__global__ __launch_bounds__(64) void k_srt_forward(XfStage st)
-{
-    const int b = blockIdx.x;
-    if (threadIdx.x != 0) return;
-    const u32 length = st.len[b];
-    st.ok[b] = 0; st.newLen[b] = 0;
-    if (length == 0) { st.ok[b] = 1; return; }
-    if (st.cap[b] < length + 1024) return;                     // SRT.hpp:38
-    __shared__ u32 freqs[256];
-    __shared__ int buckets[256];
-    __shared__ u8 s2r[256], r2s[256], symbols[256];
-    for (int i = 0; i < 256; i++) { freqs[i] = 0; buckets[i] = 0; s2r[i] = 0; r2s[i] = 0; }
-    const u8* src = st.src[b];
-    u8* out = st.dst[b];
-    for (u32 i = 0, bb = 0; i < length;) {
-        const u8 c = src[i];
-        u32 j = i + 1;
-        while ((j < length) && (src[j] == c)) j++;
-        if (freqs[c] == 0) { r2s[bb] = c; s2r[c] = (u8)bb; bb++; }
-        freqs[c] += (j - i);
-        i = j;
-    }
-    const int nbSymbols = srt_preprocess(freqs, symbols);
-    for (int i = 0, bucketPos = 0; i < nbSymbols; i++) {
-        const u8 c = symbols[i];
-        buckets[c] = bucketPos;
-        bucketPos += (int)freqs[c];
-    }
-    u32 hdr = 0;
-    for (int i = 0; i < 256; i++) {
-        u32 f = freqs[i];
-        for (int k = 0; k < 4 && f >= 128; k++) { out[hdr++] = (u8)(0x80 | f); f >>= 7; }
-        out[hdr++] = (u8)f;
-    }
-    u8* dst = out + hdr;
-    for (u32 i = 0; i < length;) {
-        const u8 c = src[i];
-        int r = s2r[c];
-        int p = buckets[c];
-        dst[p++] = (u8)r;
-        if (r != 0) {
-            do {
-                const u8 t = r2s[r - 1];
-                r2s[r] = t;
-                s2r[t] = (u8)r;
-                r--;
-            } while (r != 0);
-            r2s[0] = c;
-            s2r[c] = 0;
-        }
-        i++;
-        while ((i < length) && (src[i] == c)) { dst[p++] = 0; i++; }
-        buckets[c] = p;
-    }
-    st.ok[b] = 1;
-    st.newLen[b] = hdr + length;
-}
-
-__global__ __launch_bounds__(64) void k_srt_inverse(XfStage st)
-{
-    const int b = blockIdx.x;
-    if (threadIdx.x != 0) return;
-    int length = (int)st.len[b];
-    st.ok[b] = 0; st.newLen[b] = 0;
-    if (length == 0) { st.ok[b] = 1; return; }
-    if (length < 256) return;                                  // SRT.cpp:122
-    __shared__ u32 freqs[256];
-    __shared__ int buckets[256], bucketEnds[256];
-    __shared__ u8 r2s[256], symbols[256];
-    const u8* in = st.src[b];
-    int srcIdx = 0;
-    for (int i = 0; i < 256; i++) {
-        u32 res = 0;
-        int shift = 0;
-        for (int j = 0; j < 5; j++) {
-            if (srcIdx >= length) return;
-            const u32 val = in[srcIdx++];
-            res |= ((val & 0x7F) << shift);
-            if ((val & 0x80) == 0) break;
-            if (j == 4) return;
-            shift += 7;
-        }
-        freqs[i] = res;
-    }
-    length -= srcIdx;
-    if (length < 0 || (u32)length > st.cap[b]) return;
-    const u8* src = in + srcIdx;
-    for (int i = 0; i < 256; i++) { buckets[i] = 0; bucketEnds[i] = 0; r2s[i] = 0; symbols[i] = 0; }
-    int nbSymbols = srt_preprocess(freqs, symbols);
-    for (int i = 0, bucketPos = 0; i < nbSymbols; i++) {
-        const u8 c = symbols[i];
-        if ((bucketPos < 0) || (bucketPos >= length)) return;
-        r2s[src[bucketPos]] = c;
-        buckets[c] = bucketPos + 1;
-        bucketPos += (int)freqs[c];
-        bucketEnds[c] = bucketPos;
-    }
-    u8 c = r2s[0];
-    u8* dst = st.dst[b];
-    for (int i = 0; i < length; i++) {
-        dst[i] = c;
-        if (buckets[c] < bucketEnds[c]) {
-            const u8 r = src[buckets[c]];
-            buckets[c]++;
-            if (r == 0) continue;
-            for (int q = 0; q < (int)r; q++) r2s[q] = r2s[q + 1];
-            r2s[r] = c;
-            c = r2s[0];
-        } else {
-            if (nbSymbols == 1) continue;
-            nbSymbols--;
-            for (int q = 0; q < nbSymbols; q++) r2s[q] = r2s[q + 1];
-            c = r2s[0];
-        }
-    }
-    st.ok[b] = 1;
-    st.newLen[b] = (u32)length;
-}
-
-// ================================================================================================
 // RLT
 // ================================================================================================
 constexpr int RLT_ENC1 = 224;
@@ -531,8 +387,6 @@ __global__ __launch_bounds__(64) void k_rlt_inverse(XfStage st)
     st.newLen[b] = (u32)dstIdx;
 }
 
-void launch_srt_forward(hipStream_t s, const XfStage& st) { KScope ks_("k_srt_forward"); hipLaunchKernelGGL(k_srt_forward, dim3(st.nBlocks), dim3(64), 0, s, st); }
-void launch_srt_inverse(hipStream_t s, const XfStage& st) { KScope ks_("k_srt_inverse"); hipLaunchKernelGGL(k_srt_inverse, dim3(st.nBlocks), dim3(64), 0, s, st); }
 void launch_rlt_forward(hipStream_t s, const XfStage& st) { KScope ks_("k_rlt_forward"); hipLaunchKernelGGL(k_rlt_forward, dim3(st.nBlocks), dim3(64), 0, s, st); }
 void launch_rlt_inverse(hipStream_t s, const XfStage& st) { KScope ks_("k_rlt_inverse"); hipLaunchKernelGGL(k_rlt_inverse, dim3(st.nBlocks), dim3(64), 0, s, st); }
 
