@@ -454,111 +454,211 @@ struct HufDecChunk {
     u8 sizes[256];
 };
 
-__device__ __forceinline__ int eg_decode_signed(const BitSrc& s, u64& pos, int& err)
+typedef u32 hu32x4 __attribute__((ext_vector_type(4)));
+
+// n in [1, 32]; rel = bit offset from the start of the LDS window (words in bit order)
+__device__ __forceinline__ u32 hwin_bits(const u32* win, u32 rel, u32 n)
 {
-    if (take_bits(s, pos, 1, err) == 1) return 0;
-    u32 lg = 1;
-    while (take_bits(s, pos, 1, err) == 0) { lg++; if (err) return 0; }
-    lg &= 7;
-    int res = (int)take_bits(s, pos, lg + 1, err);
-    const int sgn = res & 1;
-    res = (res >> 1) + (1 << lg) - 1;
-    return (int)(int8_t)(u8)((res - sgn) ^ -sgn);
+    const u32 i = rel >> 5;
+    const u64 v = ((u64)win[i] << 32) | (u64)win[i + 1];
+    return (u32)((v << (rel & 31)) >> (64 - n));
 }
 
+constexpr u32 HSCAN_WIN_BITS = 8192;
+constexpr u32 HSCAN_NEED_BITS = 6 + 256 + 256 * 8 + 4 * 40 + 64;     // alphabet + 256 deltas (|d| <= 11: 8 bits) + 4 var-ints
+
+// One wave per block walks the chunk headers (readLengths, HuffmanDecoder.cpp:65-108, and the 4 fragment sizes,
+// :204-246).  Same scheme as the rANS scan: a 1 KiB window of the stream in LDS, the next window prefetched at a
+// guessed position, presence masks counted in parallel; the Exp-Golomb deltas are a short uniform chain
+// (one LDS read + count-leading-zeros per code).
 __global__ __launch_bounds__(64) void k_huff_scan(BitSrc src, DecBlock* __restrict__ blocks, int nBlocks, int maxChunks,
                                                   HufDecChunk* __restrict__ chunks)
 {
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= nBlocks) return;
+    const int b = blockIdx.x;
+    const int lane = lane_id();
     DecBlock& db = blocks[b];
     HufDecChunk* cs = chunks + (size_t)b * maxChunks;
-    for (int i = 0; i < maxChunks; i++) cs[i].kind = 3;
+    for (int i = lane; i < maxChunks; i += 64) cs[i].kind = 3;
     if (db.error) return;
-    BitSrc s = src;
-    s.limitBits = db.payloadBit + ((db.bits + 7) & ~7ull);
+    __shared__ u32 win[256 + 8];
+    __shared__ u8 codeSize[256];
+    const u64 limit = db.payloadBit + ((db.bits + 7) & ~7ull);
     u64 pos = db.entropyBit;
+    const u64 entropyBit = pos;
     const u32 preLen = db.preLen;
-    int err = 0;
     if (db.copyBlock) {
-        cs[0].kind = 2; cs[0].tailBit = pos;
-        pos += 8ull * preLen;
-        if (pos > s.limitBits) db.error = KNZ_ERR_PROCESS_BLOCK;
-        db.usedBits = pos - db.entropyBit;
+        if (lane == 0) {
+            cs[0].kind = 2; cs[0].tailBit = pos;
+            pos += 8ull * preLen;
+            if (pos > limit) db.error = KNZ_ERR_PROCESS_BLOCK;
+            db.usedBits = pos - entropyBit;
+        }
         return;
     }
+    const u64 lastWord = ((src.nBytes + 3) >> 2) - 1;
+    auto issue = [&](u64 bit0, hu32x4& dstv) {
+        const u64 w = (bit0 >> 5) + 4ull * (u32)lane;
+        const u64 w1 = w + 1, w2 = w + 2, w3 = w + 3;
+        const u32* p = src.words;
+        dstv.x = p[w < lastWord ? w : lastWord];
+        dstv.y = p[w1 < lastWord ? w1 : lastWord];
+        dstv.z = p[w2 < lastWord ? w2 : lastWord];
+        dstv.w = p[w3 < lastWord ? w3 : lastWord];
+    };
+    hu32x4 wr = { 0, 0, 0, 0 }, guess = { 0, 0, 0, 0 };
+    u64 winBit0 = 0, guessBit0 = 0;
+    bool winValid = false, guessValid = false;
+    auto ensure = [&](u32 need) {
+        if (winValid && winBit0 <= pos && pos + need <= winBit0 + HSCAN_WIN_BITS) return;
+        if (guessValid && guessBit0 <= pos && pos + need <= guessBit0 + HSCAN_WIN_BITS) { wr = guess; winBit0 = guessBit0; }
+        else { winBit0 = pos & ~31ull; issue(winBit0, wr); }
+        guessValid = false;
+        __syncthreads();
+        {
+            hu32x4 sw = { bswap32(wr.x), bswap32(wr.y), bswap32(wr.z), bswap32(wr.w) };
+            *reinterpret_cast<hu32x4*>(&win[4 * lane]) = sw;
+        }
+        __syncthreads();
+        winValid = true;
+    };
     const u32 nChunks = (preLen + ENT_CHUNK - 1) / ENT_CHUNK;
+    u64 prevPos = pos;
+    int err = 0;
     for (u32 ci = 0; ci < nChunks && !err; ci++) {
         HufDecChunk& c = cs[ci];
         const u32 n = (preLen - ci * ENT_CHUNK < ENT_CHUNK) ? (preLen - ci * ENT_CHUNK) : ENT_CHUNK;
         if (n < 32) {
-            c.kind = 2; c.tailBit = pos;
+            if (lane == 0) { c.kind = 2; c.tailBit = pos; }
             pos += 8ull * n;
-            if (pos > s.limitBits) err = 1;
+            if (pos > limit) err = 1;
             continue;
         }
-        for (int i = 0; i < 256; i++) c.sizes[i] = 0;
-        // readLengths (HuffmanDecoder.cpp:65-108)
-        u32 asz = 0;
-        u32 firstSym = 0;
-        int curSize = 2;
-        if (take_bits(s, pos, 1, err) == 0) {
-            const u32 full = (take_bits(s, pos, 1, err) == 0) ? 256u : 0u;
-            for (u32 sy = 0; sy < full && !err; sy++) {
-                curSize = (int)(int8_t)(curSize + eg_decode_signed(s, pos, err));
-                if (curSize <= 0 || curSize > HUF_MAX_LEN) { err = 1; break; }
-                c.sizes[sy] = (u8)curSize;
-            }
-            asz = full;
-        } else {
-            const u32 lastMask = take_bits(s, pos, 5, err);
-            u64 mpos = pos;
-            pos += 8ull * (lastMask + 1);
-            if (pos > s.limitBits) err = 1;
-            bool found = false;
-            for (u32 m = 0; m <= lastMask && !err; m++) {
-                u32 byte = take_bits(s, mpos, 8, err);
-                while (byte && !err) {
-                    const u32 bit = (u32)(__ffs((int)byte) - 1);
-                    byte &= byte - 1;
-                    const u32 sy = 8 * m + bit;
-                    if (!found) { firstSym = sy; found = true; }
-                    curSize = (int)(int8_t)(curSize + eg_decode_signed(s, pos, err));
-                    if (curSize <= 0 || curSize > HUF_MAX_LEN) { err = 1; break; }
-                    c.sizes[sy] = (u8)curSize;
-                    asz++;
-                }
+        ensure(HSCAN_NEED_BITS);
+        guessValid = false;
+        if (ci >= 1 && ci + 1 < nChunks) {
+            const u64 est = pos + (pos - prevPos);
+            guessBit0 = (est > 2304 ? est - 2304 : 0) & ~31ull;
+            issue(guessBit0, guess);
+            guessValid = true;
+        }
+        prevPos = pos;
+        u32 p = (u32)(pos - winBit0);
+        // ---- alphabet (EntropyUtils.cpp:91-123): which of my 4 symbols are present
+        u32 asz, present, firstSym = 0;
+        const u32 hb = hwin_bits(win, p, 7);
+        if ((hb >> 6) == 0) { asz = ((hb >> 5) & 1) ? 0u : 256u; present = asz ? 0xFu : 0u; p += 2; }
+        else {
+            const u32 lastMask = (hb >> 1) & 31;
+            p += 6;
+            const u32 m = (u32)lane >> 1;
+            const u32 byte = (m <= lastMask) ? hwin_bits(win, p + 8u * m, 8) : 0u;
+            present = (lane & 1) ? (byte >> 4) : (byte & 0xF);
+            p += 8u * (lastMask + 1);
+            asz = wave_sum(__popc(present));
+            const u64 nz = __ballot(present != 0);
+            if (nz) {
+                const int fl = __ffsll((long long)nz) - 1;
+                const u32 fp = (u32)__builtin_amdgcn_readlane((int)present, fl);
+                firstSym = 4u * (u32)fl + (u32)(__ffs((int)fp) - 1);
             }
         }
-        if (err) break;
+        asz = (u32)__builtin_amdgcn_readfirstlane((int)asz);
         if (asz == 0) { err = 2; break; }
-        c.asz = (u16)asz;
-        if (asz == 1) { c.kind = 1; c.sym = (u8)firstSym; continue; }
-        // decodeChunk prologue (HuffmanDecoder.cpp:204-246)
+        // ---- code length deltas (ExpGolombDecoder.hpp:52-75), uniform chain
+        // A valid delta has |d| <= 11, i.e. a code of at most 8 bits (prefix of <= 3 zeros); a longer prefix can only
+        // decode to an out-of-range length, so it is rejected right away.  Codes are parsed from a 64-bit register
+        // window that is reloaded from LDS only when fewer than 8 bits are left.
+        int curSize = 2;
+        u32 q = (u32)__builtin_amdgcn_readfirstlane((int)p);                 // keep the whole chain on the scalar unit
+        u64 buf = 0;
+        u32 avail = 0;
+        for (u32 k = 0; k < asz; k++) {
+            if (avail < 8) {
+                if (q > HSCAN_WIN_BITS - 96) { err = 1; break; }             // longer than any valid header
+                const u32 i = q >> 5;
+                const u32 wh = (u32)__builtin_amdgcn_readfirstlane((int)win[i]);
+                const u32 wl = (u32)__builtin_amdgcn_readfirstlane((int)win[i + 1]);
+                buf = (((u64)wh << 32) | (u64)wl) << (q & 31);
+                avail = 64 - (q & 31);
+            }
+            int delta = 0;
+            u32 total = 1;
+            if ((buf >> 63) == 0) {
+                const u32 rest = (u32)(buf >> 31);                           // the 32 bits after the leading 0
+                const u32 lg = 1u + (u32)__clz((int)rest);
+                if (rest == 0 || lg > 3) { err = 1; break; }
+                total = 2 * lg + 2;
+                int res = (int)((buf >> (64 - total)) & ((1u << (lg + 1)) - 1u));
+                const int sgn = res & 1;
+                res = (res >> 1) + (1 << lg) - 1;
+                delta = (int)(int8_t)(u8)((res - sgn) ^ -sgn);
+            }
+            curSize = (int)(int8_t)(curSize + delta);
+            if (curSize <= 0 || curSize > HUF_MAX_LEN) { err = 1; break; }
+            codeSize[k] = (u8)curSize;                                       // every lane stores the same value
+            buf <<= total;
+            avail -= total;
+            q += total;
+        }
+        if (err) break;
+        __syncthreads();
+        {
+            u32 r = wave_incl_scan(__popc(present)) - __popc(present);
+            u32 packed = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) if ((present >> k) & 1) { packed |= (u32)codeSize[r] << (8 * k); r++; }
+            reinterpret_cast<u32*>(c.sizes)[lane] = packed;
+        }
+        __syncthreads();
+        if (asz == 1) {
+            if (lane == 0) { c.asz = 1; c.kind = 1; c.sym = (u8)firstSym; }
+            pos = winBit0 + q;
+            continue;
+        }
+        // ---- decodeChunk prologue (HuffmanDecoder.cpp:204-246): 4 fragment sizes in bits
         const u32 maxFragBits = 8192u << 3;
         u32 szb[4];
         for (int j = 0; j < 4; j++) {
-            szb[j] = take_varint(s, pos, err);
-            if ((int)szb[j] < 0 || szb[j] > maxFragBits) err = 1;
+            u32 value = hwin_bits(win, q, 8); q += 8;
+            u32 res = value & 0x7F;
+            for (int shift = 7; value >= 128; shift += 7) {
+                value = hwin_bits(win, q, 8); q += 8;
+                if (shift == 28) { if (value >= 128 || (value & 0x70) != 0) err = 1; res |= (value & 0x0F) << shift; break; }
+                res |= (value & 0x7F) << shift;
+            }
+            szb[j] = res;
+            if ((int)res < 0 || res > maxFragBits) err = 1;
         }
         if (err) break;
-        for (int j = 0; j < 4; j++) { c.fragBit[j] = pos; c.fragBits[j] = szb[j]; pos += szb[j]; }
-        c.tailBit = pos;
-        pos += 8ull * (n - 4 * (n / 4));
-        if (pos > s.limitBits) err = 1;
-        c.kind = 0;
+        u64 fp = winBit0 + q;
+        if (lane == 0) {
+            c.asz = (u16)asz;
+            for (int j = 0; j < 4; j++) { c.fragBit[j] = fp; c.fragBits[j] = szb[j]; fp += szb[j]; }
+            c.tailBit = fp;
+            c.kind = 0;
+        }
+        pos = winBit0 + q + (u64)szb[0] + szb[1] + szb[2] + szb[3] + 8ull * (n - 4 * (n / 4));
+        if (pos > limit) err = 1;
     }
-    if (err) db.error = KNZ_ERR_PROCESS_BLOCK;
-    db.usedBits = pos - db.entropyBit;
+    if (lane == 0) {
+        if (err) db.error = KNZ_ERR_PROCESS_BLOCK;
+        db.usedBits = pos - entropyBit;
+    }
 }
 
-constexpr int HUF_DEC_CHUNKS = 8;   // chunks per wave (4 lanes each)
+constexpr int HUF_DEC_CHUNKS = 8;   // chunks per wave (4 lanes = 4 fragments each)
 
+// 8 chunks per wave.  Phase 1: the whole wave builds each chunk's 4096-entry table (canonical order by counting:
+// per code length a wave prefix sum of how many of my 4 symbols have it).  Phase 2: one lane per fragment keeps
+// 32..64 bits of its stream in a register pair; the next 32 bits are loaded every 2 steps without a branch and
+// only committed when there is room (the load is simply repeated otherwise), so no global access sits on the
+// table-lookup chain.
 __global__ __launch_bounds__(64) void k_huff_decode(BitSrc src, DecBlock* __restrict__ blocks, int maxChunks, int nSlots,
                                                     const HufDecChunk* __restrict__ chunks, u8* const* __restrict__ outPtr)
 {
     __shared__ u16 tables[HUF_DEC_CHUNKS][4096];      // (sym << 8) | len
-    __shared__ u16 symCode[256];
+    __shared__ u16 rStart[260];                       // table index where canonical rank r starts
+    __shared__ u16 rVal[260];
     __shared__ int chunkErr[HUF_DEC_CHUNKS];
     const int lane = lane_id();
     const int slotBase = blockIdx.x * HUF_DEC_CHUNKS;
@@ -584,44 +684,50 @@ __global__ __launch_bounds__(64) void k_huff_decode(BitSrc src, DecBlock* __rest
             continue;
         }
         // ---- canonical codes + table (HuffmanCommon.cpp:29-63, HuffmanDecoder.cpp:111-140)
-        u16* tab = tables[gg];
-        for (int i = lane; i < 4096; i += 64) tab[i] = 0x0707;
-        __syncthreads();
-        if (lane == 0) {
-            int code = 0, curLen = 0, first = 1, bad = 0;
-            for (int l = 1; l <= HUF_MAX_LEN; l++) {
-                for (int sy = 0; sy < 256; sy++) {
-                    if (c.sizes[sy] != l) continue;
-                    if (first) { curLen = l; first = 0; }
-                    code <<= (l - curLen);
-                    curLen = l;
-                    symCode[sy] = (u16)code;
-                    if (((code + 1) << (HUF_MAX_LEN - l)) > 4096) bad = 1;
-                    code++;
-                }
+        const u32 packed = reinterpret_cast<const u32*>(c.sizes)[lane];
+        u32 sz[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) sz[k] = (packed >> (8 * k)) & 0xFF;
+        u32 rank[4] = { 0, 0, 0, 0 }, start[4] = { 0, 0, 0, 0 };
+        u32 rankBase = 0, startBase = 0;
+        for (u32 l = 1; l <= (u32)HUF_MAX_LEN; l++) {
+            u32 mine = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) mine += (sz[k] == l) ? 1u : 0u;
+            const u32 incl = wave_incl_scan(mine);
+            const u32 totalL = (u32)__shfl((int)incl, 63, 64);
+            u32 idx = incl - mine;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (sz[k] == l) { rank[k] = rankBase + idx; start[k] = startBase + (idx << (HUF_MAX_LEN - l)); idx++; }
             }
-            if (bad) chunkErr[gg] = 1;
+            rankBase += totalL;
+            startBase += totalL << (HUF_MAX_LEN - l);
         }
-        __syncthreads();
-        if (chunkErr[gg]) continue;
-        // wide ranges cooperatively, narrow ranges per lane
-        for (int sy = 0; sy < 256; sy++) {
-            const u32 l = c.sizes[sy];
-            if (l == 0 || l > 6) continue;
-            const u32 w = 1u << (HUF_MAX_LEN - l);
-            const u32 idx = (u32)symCode[sy] * w;
-            const u16 val = (u16)((sy << 8) | l);
-            for (u32 t = lane; t < w; t += 64) tab[idx + t] = val;
-        }
+        const u32 asz = rankBase;
+        if (startBase > 4096 || asz < 2) { if (lane == 0) chunkErr[gg] = 1; continue; }     // :130-133 (end > table size)
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int sy = 4 * lane + k;
-            const u32 l = c.sizes[sy];
-            if (l > 6) {
-                const u32 w = 1u << (HUF_MAX_LEN - l);
-                const u32 idx = (u32)symCode[sy] * w;
-                const u16 val = (u16)((sy << 8) | l);
-                for (u32 t = 0; t < w; t++) tab[idx + t] = val;
+            if (sz[k]) { rStart[rank[k]] = (u16)start[k]; rVal[rank[k]] = (u16)(((4u * (u32)lane + (u32)k) << 8) | sz[k]); }
+        }
+        if (lane == 0) { rStart[asz] = (u16)startBase; rVal[asz] = 0x0707; rStart[asz + 1] = 4097; }
+        __syncthreads();
+        {
+            // lane fills table slots [64*lane, 64*lane+64): find the rank covering the first slot, then walk
+            u16* tab = tables[gg];
+            const u32 base = (u32)lane * 64;
+            u32 lo = 0, hi = asz;                     // rank asz = the unassigned tail (0x0707)
+            while (lo < hi) {
+                const u32 mid = (lo + hi + 1) >> 1;
+                if (rStart[mid] <= base) lo = mid; else hi = mid - 1;
+            }
+            u32 r = lo;
+            u32 word = 0;
+            for (u32 k = 0; k < 64; k++) {
+                const u32 t = base + k;
+                while (rStart[r + 1] <= t) r++;
+                word |= (u32)rVal[r] << (16 * (k & 1));
+                if (k & 1) { *reinterpret_cast<u32*>(tab + base + (k & ~1u)) = word; word = 0; }
             }
         }
         __syncthreads();
@@ -631,44 +737,96 @@ __global__ __launch_bounds__(64) void k_huff_decode(BitSrc src, DecBlock* __rest
     // ---- one lane per fragment
     const int g = lane >> 2;
     const int j = lane & 3;
+    bool act = false;
+    u32 szFrag = 0, fragBits = 0;
+    u64 fbeg = 0;
+    u8* dst = nullptr;
+    u32 n = 0;
+    int b = 0, ci = 0;
     if (g < HUF_DEC_CHUNKS) {
         const int slot = slotBase + g;
         if (slot < nSlots) {
             const HufDecChunk& c = chunks[slot];
-            const int b = slot / maxChunks;
-            const int ci = slot - b * maxChunks;
+            b = slot / maxChunks;
+            ci = slot - b * maxChunks;
             if (c.kind == 0 && !blocks[b].error && !chunkErr[g]) {
+                act = true;
                 const u32 preLen = blocks[b].preLen;
-                const u32 n = (preLen - (u32)ci * ENT_CHUNK < ENT_CHUNK) ? (preLen - (u32)ci * ENT_CHUNK) : ENT_CHUNK;
-                const u32 szFrag = n / 4;
-                u8* dst = outPtr[b] + (size_t)ci * ENT_CHUNK + (size_t)j * szFrag;
-                const u16* tab = tables[g];
-                // private view of the fragment: bits past its end read as zero (guard bytes of the reference)
-                BitSrc fs = src;
-                const u64 fbeg = c.fragBit[j];
-                const u64 fend = fbeg + c.fragBits[j];
-                u64 used = 0;
-                bool bad = false;
-                for (u32 i = 0; i < szFrag; i++) {
-                    const u64 p = fbeg + used;
-                    u32 win = peek_bits(fs, p, 12);
-                    if (p + 12 > fend) {
-                        const u32 valid = (p < fend) ? (u32)(fend - p) : 0u;
-                        win &= ~((1u << (12 - valid)) - 1u);
-                    }
-                    const u16 val = tab[win];
-                    dst[i] = (u8)(val >> 8);
-                    used += (val & 0xFF);
-                    if (used > (8192u << 3)) { bad = true; break; }
-                }
-                if (used != c.fragBits[j]) bad = true;
-                if (j == 0) {
-                    for (u32 i = 4 * szFrag; i < n; i++)
-                        outPtr[b][(size_t)ci * ENT_CHUNK + i] = (u8)peek_bits(src, c.tailBit + 8ull * (i - 4 * szFrag), 8);
-                }
-                if (bad) chunkErr[g] = 1;
+                n = (preLen - (u32)ci * ENT_CHUNK < ENT_CHUNK) ? (preLen - (u32)ci * ENT_CHUNK) : ENT_CHUNK;
+                szFrag = n / 4;
+                dst = outPtr[b] + (size_t)ci * ENT_CHUNK + (size_t)j * szFrag;
+                fbeg = c.fragBit[j];
+                fragBits = c.fragBits[j];
             }
         }
+    }
+    const u64 lastWord = ((src.nBytes + 3) >> 2) - 1;
+    const u64 w0 = fbeg >> 5;
+    const u32 sh = (u32)fbeg & 31;
+    auto raw_word = [&](u32 k) -> u32 { const u64 w = w0 + k; return bswap32(src.words[w < lastWord ? w : lastWord]); };
+    // 32 stream bits starting at fragment bit 32*(k-1), bits past the fragment's end are zero (the reference
+    // decodes from a zero-padded copy of the fragment)
+    auto frag_word = [&](u32 k, u32 prevRaw, u32 raw) -> u32 {
+        const u32 v = sh ? ((prevRaw << sh) | (raw >> (32 - sh))) : prevRaw;
+        const u32 done = 32u * (k - 1);
+        const u32 valid = (fragBits > done) ? ((fragBits - done < 32u) ? fragBits - done : 32u) : 0u;
+        return valid == 32u ? v : (valid ? (v & ~((1u << (32 - valid)) - 1u)) : 0u);
+    };
+    const u16* tab = tables[g < HUF_DEC_CHUNKS ? g : 0];
+    u32 rawPrev = raw_word(0);
+    u32 k = 1;
+    u32 rawNext = raw_word(k);
+    u64 bitbuf = (u64)frag_word(k, rawPrev, rawNext) << 32;
+    rawPrev = rawNext; k++;
+    rawNext = raw_word(k);
+    bitbuf |= (u64)frag_word(k, rawPrev, rawNext);
+    rawPrev = rawNext; k++;
+    u32 cnt = 64;
+    rawNext = raw_word(k);
+    u32 used = 0;
+    bool bad = false;
+    const u32 steps = act ? szFrag : 0;
+    const u32 maxSteps = wave_max(steps);
+    const bool al4 = act && ((reinterpret_cast<uintptr_t>(dst) & 3) == 0);
+    for (u32 i = 0; i < maxSteps; i += 4) {
+        u32 acc = 0;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            // commit the word loaded two steps ago if there is room for it, then load the next candidate
+            const bool room = cnt <= 32;
+            const u32 v = frag_word(k, rawPrev, rawNext);
+            bitbuf |= room ? ((u64)v << (32 - cnt)) : 0ull;
+            cnt += room ? 32u : 0u;
+            rawPrev = room ? rawNext : rawPrev;
+            k += room ? 1u : 0u;
+            rawNext = raw_word(k);
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const u32 val = tab[(u32)(bitbuf >> 52)];
+                const u32 len = val & 0xFF;
+                const bool on = (i + 2 * h + t) < steps;
+                acc |= (val >> 8) << (8 * (2 * h + t));
+                bitbuf = on ? (bitbuf << len) : bitbuf;
+                cnt -= on ? len : 0u;
+                used += on ? len : 0u;
+            }
+        }
+        if (used > (8192u << 3)) bad = true;
+        if (i + 4 <= steps) {
+            if (al4) *reinterpret_cast<u32*>(dst + i) = acc;
+            else { dst[i] = (u8)acc; dst[i + 1] = (u8)(acc >> 8); dst[i + 2] = (u8)(acc >> 16); dst[i + 3] = (u8)(acc >> 24); }
+        } else {
+            for (u32 t = 0; i + t < steps; t++) dst[i + t] = (u8)(acc >> (8 * t));
+        }
+    }
+    if (act) {
+        if (used != fragBits) bad = true;
+        if (j == 0) {
+            const HufDecChunk& c = chunks[slotBase + g];
+            for (u32 i = 4 * szFrag; i < n; i++)
+                outPtr[b][(size_t)ci * ENT_CHUNK + i] = (u8)peek_bits(src, c.tailBit + 8ull * (i - 4 * szFrag), 8);
+        }
+        if (bad) chunkErr[g] = 1;
     }
     __syncthreads();
     if (lane < HUF_DEC_CHUNKS && chunkErr[lane] && slotBase + lane < nSlots)
@@ -685,7 +843,7 @@ void launch_huffman_decode(hipStream_t s, BitSrc src, DecBlock* blocks, int nBlo
 {
     HufDecChunk* chunks = reinterpret_cast<HufDecChunk*>(chunkMeta);
     const int nSlots = nBlocks * maxChunks;
-    { KScope ks_("k_huff_scan"); hipLaunchKernelGGL(k_huff_scan, dim3((nBlocks + 63) / 64), dim3(64), 0, s, src, blocks, nBlocks, maxChunks, chunks); }
+    { KScope ks_("k_huff_scan"); hipLaunchKernelGGL(k_huff_scan, dim3(nBlocks), dim3(64), 0, s, src, blocks, nBlocks, maxChunks, chunks); }
     { KScope ks_("k_huff_decode"); hipLaunchKernelGGL(k_huff_decode, dim3((nSlots + HUF_DEC_CHUNKS - 1) / HUF_DEC_CHUNKS), dim3(64), 0, s, src, blocks,
                        maxChunks, nSlots, chunks, outPtr); }
 }
