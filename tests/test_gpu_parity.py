@@ -260,3 +260,52 @@ def test_block_checksums(hip, oracle):
     with pytest.raises(KnzError) as ei:
         gpu_decompress(hip, bytes(bad), "NONE", "NONE", 65536, len(d), 0, checksum=32)
     assert ei.value.code == 19
+
+
+def test_corrupted_streams_fail_cleanly(hip, oracle):
+    # src/test/TestMalformedStream.cpp in spirit: flipped bytes, overwritten ranges and truncation must come back as
+    # an error code (or as wrong bytes when the damage is undetectable), never as a hang or a device fault
+    rng = np.random.default_rng(11)
+    d = vectors.make(("mixed", 200000, 3))
+    cases = [("NONE", "ANS0", 65536), ("NONE", "ANS1", 65536), ("NONE", "HUFFMAN", 65536), ("NONE", "FPAQ", 16384),
+             ("BWT+MTFT+ZRLT", "ANS0", 65536), ("BWT+SRT+ZRLT", "HUFFMAN", 65536), ("RLT+ZRLT", "ANS0", 65536)]
+    errors = 0
+    for t, e, bs in cases:
+        rc, ref = oracle.compress(d, t, e, bs, headerless=1)
+        p = hip.params(t, e, bs)
+        d_enc, d_dec = hip.malloc(len(ref) + 4096), hip.malloc(len(d) + 2 * bs + 64)
+        for r in range(6):
+            buf = bytearray(ref)
+            if r % 3 == 0:
+                for _ in range(1 + r):
+                    buf[int(rng.integers(0, len(buf)))] ^= int(rng.integers(1, 256))
+            elif r % 3 == 1:
+                a = int(rng.integers(0, len(buf) - 64))
+                buf[a:a + 64] = bytes(rng.integers(0, 256, 64, dtype=np.uint8))
+            else:
+                buf = buf[:int(rng.integers(8, len(buf)))]
+            hip.h2d(d_enc, bytes(buf) + bytes(64))
+            try:
+                hip.decode_blocks(p, d_enc, 8 * len(buf), 0, d_dec, len(d) + bs)
+            except Exception as ex:
+                assert "knz_hip error" in str(ex)
+                errors += 1
+        hip.free(d_enc)
+        hip.free(d_dec)
+    assert errors > 0
+    # the context is still usable afterwards
+    out, bits, hb = gpu_compress(hip, d, "NONE", "ANS0", 65536, headerless=1)
+    assert gpu_decompress(hip, out, "NONE", "ANS0", 65536, len(d), 0) == d
+
+
+def test_repeated_round_trips_are_stable(hip):
+    # intermittent faults (races, unsynchronised prefetches) show up as a differing stream or a failed decode
+    d = vectors.make(("mixed", 24 << 20, 2))
+    first = None
+    for i in range(40):
+        out, bits, hb = gpu_compress(hip, d, "NONE", "ANS0", 4 << 20, headerless=1)
+        if first is None:
+            first = out
+        assert out == first, i
+        if i % 8 == 0:
+            assert gpu_decompress(hip, out, "NONE", "ANS0", 4 << 20, len(d), 0) == d, i
