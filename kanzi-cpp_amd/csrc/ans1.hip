@@ -41,14 +41,24 @@ __global__ __launch_bounds__(256) void k_ans1_hist(BlockView view, int chunksPer
     const u32 quarter = end >> 2;
     const u32 counted = quarter ? 4 * quarter : end;
     u32* h = hist + (size_t)gc * 65536;
+    // every thread walks its own contiguous slice and merges repeats of the same (context, symbol) pair in a
+    // register, so that runs (the worst case for same-address atomics) cost one atomic per run and thread
     const u32 part = (counted + gridDim.x - 1) / gridDim.x;
     const u32 lo = blockIdx.x * part;
     const u32 hi = (lo + part < counted) ? lo + part : counted;
-    for (u32 i = lo + threadIdx.x; i < hi; i += 256) {
+    const u32 per = (part + 255) / 256;
+    u32 i = lo + threadIdx.x * per;
+    const u32 iend = (i + per < hi) ? i + per : hi;
+    u32 curKey = 0xFFFFFFFFu, curCnt = 0;
+    for (; i < iend; i++) {
         const bool first = quarter ? (i % quarter == 0) : (i == 0);
         const u32 ctx = first ? 0u : (u32)blk[i - 1];
-        atomicAdd(&h[ctx * 256 + blk[i]], 1u);
+        const u32 key = ctx * 256 + blk[i];
+        if (key == curKey) { curCnt++; continue; }
+        if (curCnt) atomicAdd(&h[curKey], curCnt);
+        curKey = key; curCnt = 1;
     }
+    if (curCnt) atomicAdd(&h[curKey], curCnt);
 }
 
 // one wave per (chunk, context): normalise the row, emit its header bits, build its encoder table
