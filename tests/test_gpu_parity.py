@@ -309,3 +309,13 @@ def test_repeated_round_trips_are_stable(hip):
         assert out == first, i
         if i % 8 == 0:
             assert gpu_decompress(hip, out, "NONE", "ANS0", 4 << 20, len(d), 0) == d, i
+
+
+def test_randomised_soak(hip):
+    # random chains / codecs / block sizes / inputs / jobs / checksums against the oracle (tools/gpu_soak.py)
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_soak.py"), "5", "25"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
