@@ -366,6 +366,9 @@ static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t 
     hipStream_t s = c->stream;
 
     const int nBlocks = (n == 0) ? 0 : (int)((n + bs - 1) / bs);
+    // device-side positions of a batch are 32-bit (suffix array slots, bit offsets inside staging areas): a batch
+    // is limited to 2 GiB of input; the host layers split larger inputs into several calls
+    if (n > (size_t)0x7FFFFFFF - 8ull * (size_t)(nBlocks + 1) * 1056) return fail(c, KNZ_ERR_INVALID_PARAM, "batch of %zu bytes exceeds the 2 GiB per-call limit", n);
     const size_t needOut = ((size_t)prologueBits + 7) / 8 + 16;
     if (outCap < needOut) return fail(c, KNZ_ERR_WRITE_FILE, "output buffer too small");
     u64* d_total;
@@ -577,6 +580,7 @@ static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_
     if (blocksDone) *blocksDone = nBlocks;
     if (nBlocks == 0) { if (outBytes) *outBytes = 0; return 0; }
     if (framing && (size_t)nBlocks * bs > outCap + bs) return fail(c, KNZ_ERR_WRITE_FILE, "output buffer too small");
+    if (framing && (size_t)nBlocks * bs > (size_t)0x7FFFFFFF) return fail(c, KNZ_ERR_INVALID_PARAM, "batch of %d blocks exceeds the 2 GiB per-call limit (pass max_blocks)", nBlocks);
 
     // workspace stride: large enough for every valid preTransformLength of this chain
     const u32 unit = framing ? bs : rawLen;

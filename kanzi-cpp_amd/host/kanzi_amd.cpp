@@ -658,6 +658,8 @@ CompressedOutputStream::CompressedOutputStream(std::ostream& os, int tasks, cons
     _batchBlocks = tasks;
     const char* e = getenv("KNZ_BATCH_BLOCKS");
     if (e && atoi(e) > 0) _batchBlocks = atoi(e);
+    // one device call takes at most 2 GiB of input (32-bit positions on the device side)
+    { const int64_t lim = (int64_t(1) << 31) / int64_t(blockSize) - 1; if (_batchBlocks > lim) _batchBlocks = int(lim < 1 ? 1 : lim); }
     _blockId = 0;
     _pendingByte = 0; _pendingBits = 0; _written = 0;
     _dIn = _dOut = nullptr; _dInCap = _dOutCap = 0;
@@ -845,7 +847,10 @@ bool CompressedInputStream::decodeBatch()
     uint64 pos = _compBit;
     int nb = 0;
     bool sawEnd = false;
-    while (nb < _batchBlocks) {
+    // one device call produces at most 2 GiB of output (32-bit positions on the device side)
+    const int64_t lim = (int64_t(1) << 31) / int64_t(_blockSize > 0 ? _blockSize : 1) - 1;
+    const int batch = (_batchBlocks > lim) ? int(lim < 1 ? 1 : lim) : _batchBlocks;
+    while (nb < batch) {
         if (!fetch(size_t(((pos + 40) >> 3) + 1 - (_compBit >> 3)))) {
             if (uint64(_comp.size()) * 8 < pos + 8) { if (nb == 0) throw IOException("Unexpected end of stream", Error::ERR_READ_FILE); break; }
         }
