@@ -342,7 +342,7 @@ public:
     std::streamsize gcount() const { return _gcount; }
     void close();
     uint64 getRead() const { return (_consumedBits + 7) >> 3; }
-    void setBatchBlocks(int n) { if (n > 0) _batchBlocks = n; }
+    void setBatchBlocks(int n) { if (n > 0) { _batchBlocks = n; _batchFromEnv = true; } }
 private:
     std::istream& _is;
     int _jobs, _blockSize, _checksum;
@@ -351,6 +351,7 @@ private:
     uint64 _outputSize;
     bool _headless, _closed, _headerDone, _ended;
     int _batchBlocks;
+    bool _batchFromEnv;
     std::vector<byte> _comp;      // compressed bytes fetched and not yet decoded
     uint64 _compBit;              // next unread bit in _comp
     uint64 _consumedBits;

@@ -655,7 +655,9 @@ CompressedOutputStream::CompressedOutputStream(std::ostream& os, int tasks, cons
     _transformType = TransformFactory<byte>::getType(transform.c_str());
     _inputSize = fileSize;
     _headless = headerless; _closed = false; _headerDone = false;
-    _batchBlocks = tasks;
+    // Blocks per device call.  `jobs` only selects the reference's buffer-slot capacities in the bitstream; the
+    // GPU wants many blocks per launch, so by default up to 256 MiB (at most 64 blocks) are gathered per call.
+    { const int64_t want = (int64_t(256) << 20) / int64_t(blockSize); _batchBlocks = std::max(tasks, int(std::min<int64_t>(64, std::max<int64_t>(1, want)))); }
     const char* e = getenv("KNZ_BATCH_BLOCKS");
     if (e && atoi(e) > 0) _batchBlocks = atoi(e);
     // one device call takes at most 2 GiB of input (32-bit positions on the device side)
@@ -768,9 +770,10 @@ CompressedInputStream::CompressedInputStream(std::istream& is, int tasks, const 
         _entropyType = EntropyEncoderFactory::getType(entropy.c_str());
         _transformType = TransformFactory<byte>::getType(transform.c_str());
     }
-    _batchBlocks = tasks;
+    _batchBlocks = std::max(tasks, 64);               // clamped to 256 MiB / 2 GiB once the block size is known
     const char* e = getenv("KNZ_BATCH_BLOCKS");
-    if (e && atoi(e) > 0) _batchBlocks = atoi(e);
+    _batchFromEnv = false;
+    if (e && atoi(e) > 0) { _batchBlocks = atoi(e); _batchFromEnv = true; }
     _compBit = 0; _consumedBits = 0; _plainPos = 0; _gcount = 0; _srcEof = false;
     _dIn = _dOut = nullptr; _dInCap = _dOutCap = 0;
     deviceContext();
@@ -848,8 +851,10 @@ bool CompressedInputStream::decodeBatch()
     int nb = 0;
     bool sawEnd = false;
     // one device call produces at most 2 GiB of output (32-bit positions on the device side)
-    const int64_t lim = (int64_t(1) << 31) / int64_t(_blockSize > 0 ? _blockSize : 1) - 1;
-    const int batch = (_batchBlocks > lim) ? int(lim < 1 ? 1 : lim) : _batchBlocks;
+    const int64_t bsz = int64_t(_blockSize > 0 ? _blockSize : 1);
+    const int64_t lim = (int64_t(1) << 31) / bsz - 1;
+    int batch = (_batchBlocks > lim) ? int(lim < 1 ? 1 : lim) : _batchBlocks;
+    if (!_batchFromEnv) batch = std::max(_jobs, int(std::min<int64_t>(batch, std::max<int64_t>(1, (int64_t(256) << 20) / bsz))));
     while (nb < batch) {
         if (!fetch(size_t(((pos + 40) >> 3) + 1 - (_compBit >> 3)))) {
             if (uint64(_comp.size()) * 8 < pos + 8) { if (nb == 0) throw IOException("Unexpected end of stream", Error::ERR_READ_FILE); break; }
