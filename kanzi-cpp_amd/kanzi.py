@@ -111,12 +111,12 @@ class Decompressor:
         self.buffer_size = buffer_size
 
     def decompress(self, n):
-        buf = (C.c_uint8 * max(1, n))()
+        buf = C.create_string_buffer(max(1, n))
         ins, outs = C.c_size_t(0), C.c_size_t(n)
         rc = lib().decompress(self._ctx, buf, C.byref(ins), C.byref(outs))
         if rc != 0:
             raise KanziError(rc, "decompress")
-        return bytes(buf[:outs.value])
+        return C.string_at(buf, outs.value)
 
     def close(self):
         if self._ctx:
