@@ -6,16 +6,16 @@
 //            entropy/ANSRangeEncoder.hpp:92-131 ; entropy/EntropyUtils.cpp:57-89,131-245
 //   decoder  entropy/ANSRangeDecoder.cpp:80-175 (decodeHeader), :177-216 (decode), :218-292 (decodeChunk)
 //
-// Mapping (not a translation of the CPU loops):
-//   k_ans0_stats   one wave per 16 KiB chunk: 4-way privatised LDS histogram from 16 B/lane coalesced
+// Mapping (not a translation of the CPU loops); the decoder lives in ans_dec.hip, order 1 in ans1.hip:
+//   k_ans0_stats   one wave per 16 KiB chunk: 8 lane-selected private LDS histograms from 16 B/lane coalesced
 //                  loads, wave-parallel normalizeFrequencies (4 symbols per lane, shuffle reductions and
 //                  prefix sums reproduce the reference's order-dependent error spreading), encoder
-//                  table (reciprocals) and the bit-granular chunk header built with LDS atomicOr.
+//                  table (reciprocals) and the bit-granular chunk header built with LDS atomicOr
+//                  (the table/header code is shared with order 1: ans_common.hpp).
 //   k_ans0_encode  4 lanes per chunk = the 4 interleaved rANS states, 16 chunks per wave. The shared
-//                  backward byte pointer of the reference becomes a ballot + popcount per step.
-//   k_ans0_scan    one lane per block walks the chunk headers (they are bit-granular and carry no
-//                  directory) to find every chunk's payload position.
-//   k_ans0_decode  4 lanes per chunk, shared forward pointer again via ballot/popcount.
+//                  backward byte pointer of the reference becomes a ballot + popcount per step; input
+//                  dwords are read one 16-step interval ahead, the table entry of step s+1 before step s
+//                  is processed, and emissions are staged in LDS and written out as 128-byte lines.
 #include "common.hpp"
 #include "stages.hpp"
 #include "ans_common.hpp"

@@ -4,18 +4,22 @@
 // :218-292 (decodeChunk), entropy/ANSRangeDecoder.hpp:85-103 (decodeSymbol),
 // entropy/EntropyUtils.cpp:91-123 (decodeAlphabet), :261-285 (readVarInt).
 //
-//   k_ans0_scan    The stream has no chunk directory and chunk headers are bit-granular, so finding
+//   k_ans_scan<0>  The stream has no chunk directory and chunk headers are bit-granular, so finding
 //                  chunk c+1 needs the header of chunk c: a serial chain of (#chunks) steps per block.
-//                  One WAVE per block: the 64 lanes stage the next 640 bytes of the stream in LDS with
-//                  one coalesced load, the presence masks are counted in parallel (ballot/popcount),
-//                  and only the group walk (<= 43 dependent 4-bit reads) runs on one lane, from LDS.
-//   k_ans0_decode  8 chunks per wave. Phase 1 rebuilds each chunk's tables with the whole wave (parallel
-//                  frequency parse from the group offsets the scan recorded; slot->symbol table filled
-//                  64 slots per lane). Phase 2: 4 lanes per chunk = the 4 interleaved states; the shared
-//                  forward byte pointer of the reference is a ballot + popcount per step; the payload is
-//                  streamed through a 1 KiB LDS ring per chunk (refilled cooperatively every 32 steps)
-//                  so that no global load sits on the dependent chain; 4x4 symbols are transposed
-//                  with shuffles so that every lane stores one aligned dword.
+//                  One WAVE per block: a 1 KiB window of the stream is staged in LDS (bit order), the window
+//                  of the next chunk is prefetched at a guessed position while this one is parsed, the
+//                  presence masks are counted in parallel (ballot/popcount), and the group walk
+//                  (<= 32 dependent 4-bit reads) is a short uniform chain from LDS.  <1> walks the 256 context
+//                  tables of an order-1 chunk with the same code.
+//   k_ans0_decode  16 chunks per wave. Phase 1 rebuilds each chunk's tables with the whole wave (parallel
+//                  frequency parse from the group offsets the scan recorded; two-level slot lookup:
+//                  4-slot buckets -> rank, compact entries by rank). Phase 2: 4 lanes per chunk = the 4
+//                  interleaved states; the shared forward byte pointer of the reference is a ballot +
+//                  popcount per step; the payload is streamed through a 256-byte LDS ring per chunk kept
+//                  filled by the chunk's own lanes (loads issued 8 steps ahead), so that no global load
+//                  sits on the dependent chain; 4x4 symbols are transposed with DPP so that every lane
+//                  stores one aligned dword.
+//   k_ans1_*       order 1: per-context slot tables in HBM, one wave per 4 MiB chunk (see below).
 #include "common.hpp"
 #include "stages.hpp"
 

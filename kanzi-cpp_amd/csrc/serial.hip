@@ -4,9 +4,6 @@
 //   FPAQ  entropy/FPAQEncoder.cpp:58-110, FPAQEncoder.hpp:72-94 ; FPAQDecoder.cpp:62-120, .hpp:74-117
 //         56-bit binary arithmetic coder whose interval and 1024 adaptive probabilities carry across
 //         every bit of the block (SURVEY.md section 7 "hard parts": no bit-exact parallel form for the decoder).
-//   SRT   transform/SRT.cpp:22-109 (forward), :111-204 (inverse), :206-308 (preprocess / header).
-//         The inverse reads each symbol's next rank from that symbol's own bucket, so the order of
-//         reads depends on the decoded text itself.
 //   RLT   transform/RLT.cpp:39-221, :223-245, :247-369. Kept serial in round 1 (its 4-byte stride scan and
 //         MAX_RUN splitting are reproduced literally); a scan-based version is future work.
 //
