@@ -31,12 +31,20 @@ __device__ void wave_copy_bits(u32* __restrict__ dst, u64 dstBit, const u8* __re
         const u64 s = lo - dstBit;
         const u64 b0 = s >> 3;
         const u32 sh = (u32)(s & 7);
+        // 40 source bits starting at byte b0 (big-endian): one (unaligned) dword + one byte when they are inside
+        // the piece, single bytes only at its tail
         u64 win = 0;
+        if (b0 + 5 <= srcBytes) {
+            u32 x;
+            __builtin_memcpy(&x, src + b0, 4);
+            win = ((u64)bswap32(x) << 8) | (u64)src[b0 + 4];
+        } else {
 #pragma unroll
-        for (int i = 0; i < 5; i++) {
-            const u64 idx = b0 + i;
-            const u64 v = idx < srcBytes ? (u64)src[idx] : 0ull;
-            win |= v << (32 - 8 * i);
+            for (int i = 0; i < 5; i++) {
+                const u64 idx = b0 + i;
+                const u64 v = idx < srcBytes ? (u64)src[idx] : 0ull;
+                win |= v << (32 - 8 * i);
+            }
         }
         const u32 val = (u32)((win >> (40 - sh - nb)) & (nb == 32 ? 0xFFFFFFFFull : ((1ull << nb) - 1)));
         const u32 word = val << (u32)((wb + 32) - hi);
