@@ -204,7 +204,7 @@ def main():
     if rank == 0:
         cpu = None
         bit_exact = None
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:       # the CPU baseline is a single-GPU report line
             sample_n = min(n, args.cpu_sample)
             sample_n -= sample_n % bs if sample_n >= bs else 0
             sample = data[:sample_n]
