@@ -1,11 +1,9 @@
-// Stages whose reference definition is a single dependency chain per block. They run as ONE LANE
+// The stage whose reference definition is a single dependency chain per block. It runs as ONE LANE
 // PER BLOCK (blocks of a batch in parallel), i.e. they are latency-bound, not bandwidth-bound:
 //
 //   FPAQ  entropy/FPAQEncoder.cpp:58-110, FPAQEncoder.hpp:72-94 ; FPAQDecoder.cpp:62-120, .hpp:74-117
 //         56-bit binary arithmetic coder whose interval and 1024 adaptive probabilities carry across
 //         every bit of the block (SURVEY.md section 7 "hard parts": no bit-exact parallel form for the decoder).
-//   RLT   transform/RLT.cpp:39-221, :223-245, :247-369. Kept serial in round 1 (its 4-byte stride scan and
-//         MAX_RUN splitting are reproduced literally); a scan-based version is future work.
 //
 // They exist so that every BASELINE config runs end-to-end on the device with a bit-exact stream;
 // DESIGN.md reports them as latency-bound.
@@ -192,199 +190,5 @@ void launch_fpaq_decode(hipStream_t s, BitSrc src, DecBlock* blocks, int nBlocks
 {
     { KScope ks_("k_fpaq_decode"); hipLaunchKernelGGL(k_fpaq_decode, dim3(nBlocks), dim3(64), 0, s, src, blocks, outPtr); }
 }
-
-// ================================================================================================
-// RLT
-// ================================================================================================
-constexpr int RLT_ENC1 = 224;
-constexpr int RLT_ENC2 = (255 - RLT_ENC1) << 8;
-constexpr int RLT_THRESHOLD = 3;
-constexpr int RLT_MAX_RUN = 0xFFFF + RLT_ENC2 + RLT_THRESHOLD - 1;
-constexpr int RLT_MAX_RUN4 = RLT_MAX_RUN - 4;
-
-__device__ int rlt_emit_run(u8* dst, int run, u8 escape, u8 val)
-{
-    dst[0] = val;
-    dst[1] = 0;
-    int dstIdx = (val == escape) ? 2 : 1;
-    dst[dstIdx++] = escape;
-    run -= RLT_THRESHOLD;
-    if (run >= RLT_ENC1) {
-        if (run < RLT_ENC2) { run -= RLT_ENC1; dst[dstIdx++] = (u8)(RLT_ENC1 + (run >> 8)); }
-        else { run -= RLT_ENC2; dst[dstIdx++] = 0xFF; dst[dstIdx++] = (u8)(run >> 8); }
-    }
-    dst[dstIdx] = (u8)run;
-    return dstIdx + 1;
-}
-
-// Global.cpp:354-397 (only the classes RLT cares about: DNA / BASE64 refuse the transform)
-__device__ int rlt_refuses(int count, const u32* f)
-{
-    const char DNA[] = "acgntuACGNTU";
-    const char NUM[] = "0123456789+-*/=,.:; ";
-    const char B64[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
-    int sum = 0;
-    for (int i = 0; i < 12; i++) sum += (int)f[(u8)DNA[i]];
-    if (sum > (count - count / 12)) return 1;                 // DNA
-    sum = 0;
-    for (int i = 0; i < 20; i++) sum += (int)f[(u8)NUM[i]];
-    if (sum == count) return 0;                               // NUMERIC
-    sum = (f[0x3D] == 1) ? 1 : 0;
-    for (int i = 0; i < 64; i++) sum += (int)f[(u8)B64[i]];
-    if (sum == count) return 1;                               // BASE64
-    return 0;
-}
-
-__global__ __launch_bounds__(64) void k_rlt_forward(XfStage st)
-{
-    const int b = blockIdx.x;
-    if (threadIdx.x != 0) return;
-    const int count = (int)st.len[b];
-    st.ok[b] = 0; st.newLen[b] = 0;
-    if (count == 0) { st.ok[b] = 1; return; }
-    if (count < 16) return;
-    const int maxEnc = (count <= 512) ? count + 32 : count;
-    if ((int)st.cap[b] < maxEnc) return;
-    const u8* src = st.src[b];
-    u8* dst = st.dst[b];
-    const int etype = st.entropyType;
-    const bool findBestEscape = !(etype == KNZ_E_NONE || etype == KNZ_E_ANS0 || etype == KNZ_E_HUFFMAN || etype == 4);
-    u8 escape = 0xFB;
-    if (findBestEscape) {
-        __shared__ u32 freqs[256];
-        for (int i = 0; i < 256; i++) freqs[i] = 0;
-        for (int i = 0; i < count; i++) freqs[src[i]]++;
-        if (rlt_refuses(count, freqs)) return;
-        int minIdx = 0;
-        if (freqs[minIdx] > 0) {
-            for (int i = 1; i < 256; i++) {
-                if (freqs[i] < freqs[minIdx]) { minIdx = i; if (freqs[i] == 0) break; }
-            }
-        }
-        escape = (u8)minIdx;
-    }
-    int srcIdx = 0, dstIdx = 0;
-    const int srcEnd = count, srcEnd4 = srcEnd - 4, dstEnd = (int)st.cap[b];
-    int res = 1, run = 0;
-    u8 prev = src[srcIdx++];
-    dst[dstIdx++] = escape;
-    dst[dstIdx++] = prev;
-    if (prev == escape) dst[dstIdx++] = 0;
-    while (true) {
-        if (prev == src[srcIdx]) {
-            const u32 v = 0x01010101u * (u32)prev;
-            const u32 w = (u32)src[srcIdx] | ((u32)src[srcIdx + 1] << 8) | ((u32)src[srcIdx + 2] << 16) | ((u32)src[srcIdx + 3] << 24);
-            const u32 diff = w ^ v;
-            if (diff == 0) {
-                srcIdx += 4; run += 4;
-                if ((run < RLT_MAX_RUN4) && (srcIdx < srcEnd4)) continue;
-            } else {
-                const int n = (__ffs((int)diff) - 1) >> 3;
-                srcIdx += n;
-                run += n;
-            }
-        }
-        if (run > RLT_THRESHOLD) {
-            if (dstIdx + 6 >= dstEnd) { res = 0; break; }
-            dstIdx += rlt_emit_run(&dst[dstIdx], run, escape, prev);
-        } else if (prev != escape) {
-            if (dstIdx + run >= dstEnd) { res = 0; break; }
-            if (run-- > 0) dst[dstIdx++] = prev;
-            while (run-- > 0) dst[dstIdx++] = prev;
-        } else {
-            if (dstIdx + (2 * run) >= dstEnd) { res = 0; break; }
-            while (run-- > 0) { dst[dstIdx++] = escape; dst[dstIdx++] = 0; }
-        }
-        prev = src[srcIdx];
-        srcIdx++;
-        run = 1;
-        if (srcIdx >= srcEnd4) break;
-    }
-    if (res) {
-        if (prev != escape) {
-            if (dstIdx + run < dstEnd) while (run-- > 0) dst[dstIdx++] = prev;
-        } else {
-            if (dstIdx + (2 * run) < dstEnd) while (run-- > 0) { dst[dstIdx++] = escape; dst[dstIdx++] = 0; }
-        }
-        while ((srcIdx < srcEnd) && (dstIdx < dstEnd)) {
-            if (src[srcIdx] == escape) {
-                if (dstIdx + 2 >= dstEnd) { res = 0; break; }
-                dst[dstIdx++] = escape;
-                dst[dstIdx++] = 0;
-                srcIdx++;
-                continue;
-            }
-            dst[dstIdx++] = src[srcIdx++];
-        }
-        res &= (srcIdx == srcEnd) ? 1 : 0;
-    }
-    st.ok[b] = (res && (dstIdx < srcIdx)) ? 1 : 0;
-    st.newLen[b] = (u32)dstIdx;
-}
-
-__global__ __launch_bounds__(64) void k_rlt_inverse(XfStage st)
-{
-    const int b = blockIdx.x;
-    if (threadIdx.x != 0) return;
-    const int count = (int)st.len[b];
-    st.ok[b] = 0; st.newLen[b] = 0;
-    if (count == 0) { st.ok[b] = 1; return; }
-    const u8* src = st.src[b];
-    u8* dst = st.dst[b];
-    int srcIdx = 0, dstIdx = 0;
-    const int srcEnd = count, dstEnd = (int)st.cap[b];
-    int res = 1;
-    const u8 escape = src[srcIdx++];
-    if ((srcIdx < srcEnd) && (src[srcIdx] == escape)) {
-        srcIdx++;
-        if ((srcIdx < srcEnd) && (src[srcIdx] != 0)) return;
-        if (dstIdx >= dstEnd) return;
-        dst[dstIdx++] = escape;
-        srcIdx++;
-    }
-    while (srcIdx < srcEnd) {
-        // literal span up to the next escape
-        int q = srcIdx;
-        while (q < srcEnd && src[q] != escape) q++;
-        const int literalLen = q - srcIdx;
-        if (literalLen > 0) {
-            if (literalLen > dstEnd - dstIdx) { res = 0; break; }
-            for (int k = 0; k < literalLen; k++) dst[dstIdx + k] = src[srcIdx + k];
-            srcIdx += literalLen;
-            dstIdx += literalLen;
-        }
-        if (srcIdx >= srcEnd) break;
-        srcIdx++;
-        if (srcIdx >= srcEnd) { res = 0; break; }
-        int run = src[srcIdx++];
-        if (run == 0) {
-            if (dstIdx >= dstEnd) { res = 0; break; }
-            dst[dstIdx++] = escape;
-            continue;
-        }
-        if (run == 0xFF) {
-            if (srcIdx + 1 >= srcEnd) { res = 0; break; }
-            run = ((int)src[srcIdx] << 8) | (int)src[srcIdx + 1];
-            srcIdx += 2;
-            run += RLT_ENC2;
-        } else if (run >= RLT_ENC1) {
-            if (srcIdx >= srcEnd) { res = 0; break; }
-            run = ((run - RLT_ENC1) << 8) | (int)src[srcIdx];
-            srcIdx++;
-            run += RLT_ENC1;
-        }
-        run += (RLT_THRESHOLD - 1);
-        if ((dstIdx + run > dstEnd) || (run > RLT_MAX_RUN)) { res = 0; break; }
-        if (dstIdx == 0) { res = 0; break; }
-        const u8 v = dst[dstIdx - 1];
-        for (int k = 0; k < run; k++) dst[dstIdx + k] = v;
-        dstIdx += run;
-    }
-    st.ok[b] = (res && (srcIdx == srcEnd)) ? 1 : 0;
-    st.newLen[b] = (u32)dstIdx;
-}
-
-void launch_rlt_forward(hipStream_t s, const XfStage& st) { KScope ks_("k_rlt_forward"); hipLaunchKernelGGL(k_rlt_forward, dim3(st.nBlocks), dim3(64), 0, s, st); }
-void launch_rlt_inverse(hipStream_t s, const XfStage& st) { KScope ks_("k_rlt_inverse"); hipLaunchKernelGGL(k_rlt_inverse, dim3(st.nBlocks), dim3(64), 0, s, st); }
 
 }  // namespace knz
