@@ -191,11 +191,33 @@ __global__ __launch_bounds__(64) void k_ans_scan(BitSrc src, DecBlock* __restric
             const u32 nGroups = (asz - 1 + chk - 1) / chk;
             const u32 lastCnt = (asz - 1) - (nGroups - 1) * chk;
             u32 tooBig = 0;
-            for (u32 g = 0; g < nGroups; g++) {
-                const u32 logMax = lds_bits(win, q, llr);
-                tooBig |= (logMax > lr) ? 1u : 0u;          // checked after the walk; a bad value cannot fault:
-                if ((u32)lane == g) myGrp = (q - p) | (logMax << 12);   // LDS reads past the window just return
-                q += llr + ((g + 1 == nGroups) ? lastCnt : chk) * logMax;   // unrelated words
+            if (chk == 8) {
+                // Groups of 8: every width field sits at a multiple of 4 bits from p.  Re-align the header so that p
+                // is bit 0 of a 128-word register window (word k in lane k & 63 of r0 / r1): a field never straddles
+                // a word, and the walk becomes readlane + scalar arithmetic with no LDS round trip on the chain.
+                const u32 wi = uni(p) >> 5, sh = uni(p) & 31;
+                const u32 a0 = win[wi + (u32)lane], b0 = win[wi + (u32)lane + 1];
+                const u32 a1 = win[wi + (u32)lane + 64], b1 = win[wi + (u32)lane + 65];
+                const u32 r0 = sh ? ((a0 << sh) | (b0 >> (32 - sh))) : a0;
+                const u32 r1 = sh ? ((a1 << sh) | (b1 >> (32 - sh))) : a1;
+                u32 rel = 0;
+                for (u32 g = 0; g < nGroups; g++) {
+                    const u32 i = rel >> 5;
+                    const u32 wlo = rl(r0, i & 63), whi = rl(r1, i & 63);
+                    const u32 wsel = (i < 64) ? wlo : whi;
+                    const u32 logMax = (i < 128) ? ((wsel >> (28 - (rel & 31))) & 15u) : 15u;   // past the window: invalid
+                    tooBig |= (logMax > lr) ? 1u : 0u;
+                    if ((u32)lane == g) myGrp = rel | (logMax << 12);
+                    rel += llr + ((g + 1 == nGroups) ? lastCnt : chk) * logMax;
+                }
+                q = p + rel;
+            } else {
+                for (u32 g = 0; g < nGroups; g++) {
+                    const u32 logMax = lds_bits(win, q, llr);
+                    tooBig |= (logMax > lr) ? 1u : 0u;          // checked after the walk; a bad value cannot fault:
+                    if ((u32)lane == g) myGrp = (q - p) | (logMax << 12);   // LDS reads past the window just return
+                    q += llr + ((g + 1 == nGroups) ? lastCnt : chk) * logMax;   // unrelated words
+                }
             }
             if (tooBig) { err = 1; break; }
             if ((u32)lane < nGroups) c.grp[lane] = (u16)myGrp;
