@@ -62,43 +62,54 @@ __device__ __forceinline__ u32 bitlen_u32(u32 v) { return v == 0 ? 0u : (u32)(32
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
-// Inclusive wave scan (sum) over 64 lanes using DPP-free shuffles.
+// Wave64 scans and reductions on the DPP data path (row shifts inside 16-lane rows, then row_bcast15 / row_bcast31
+// to carry across rows): about a dozen VALU instructions, where the ds_bpermute-based __shfl versions pay an LDS
+// round trip per step.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ u32 dpp_or0(u32 v)
+{
+    // lanes without a source lane (or masked out) receive 0
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+
 __device__ __forceinline__ u32 wave_incl_scan(u32 v)
 {
-    const int lane = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        u32 t = (u32)__shfl_up((int)v, d, 64);
-        if (lane >= d) v += t;
-    }
+    v += dpp_or0<0x111, 0xF>(v);      // row_shr:1
+    v += dpp_or0<0x112, 0xF>(v);      // row_shr:2
+    v += dpp_or0<0x114, 0xF>(v);      // row_shr:4
+    v += dpp_or0<0x118, 0xF>(v);      // row_shr:8
+    v += dpp_or0<0x142, 0xA>(v);      // row_bcast:15 -> rows 1 and 3
+    v += dpp_or0<0x143, 0xC>(v);      // row_bcast:31 -> rows 2 and 3
     return v;
 }
 
 __device__ __forceinline__ u32 wave_sum(u32 v)
 {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += (u32)__shfl_xor((int)v, d, 64);
-    return v;
+    return (u32)__builtin_amdgcn_readlane((int)wave_incl_scan(v), 63);
 }
 
 __device__ __forceinline__ u32 wave_max(u32 v)
 {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        u32 t = (u32)__shfl_xor((int)v, d, 64);
-        v = t > v ? t : v;
-    }
-    return v;
+    u32 t;
+    t = dpp_or0<0x111, 0xF>(v); v = t > v ? t : v;
+    t = dpp_or0<0x112, 0xF>(v); v = t > v ? t : v;
+    t = dpp_or0<0x114, 0xF>(v); v = t > v ? t : v;
+    t = dpp_or0<0x118, 0xF>(v); v = t > v ? t : v;
+    t = dpp_or0<0x142, 0xA>(v); v = t > v ? t : v;
+    t = dpp_or0<0x143, 0xC>(v); v = t > v ? t : v;
+    return (u32)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 __device__ __forceinline__ u64 wave_incl_scan64(u64 v)
 {
-    const int lane = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        u64 t = (u64)__shfl_up((long long)v, d, 64);
-        if (lane >= d) v += t;
-    }
+#define KNZ_SCAN64_STEP(CTRL, RM) { const u32 lo = dpp_or0<CTRL, RM>((u32)v); const u32 hi = dpp_or0<CTRL, RM>((u32)(v >> 32)); v += ((u64)hi << 32) | lo; }
+    KNZ_SCAN64_STEP(0x111, 0xF)
+    KNZ_SCAN64_STEP(0x112, 0xF)
+    KNZ_SCAN64_STEP(0x114, 0xF)
+    KNZ_SCAN64_STEP(0x118, 0xF)
+    KNZ_SCAN64_STEP(0x142, 0xA)
+    KNZ_SCAN64_STEP(0x143, 0xC)
+#undef KNZ_SCAN64_STEP
     return v;
 }
 
