@@ -54,10 +54,10 @@ __global__ __launch_bounds__(64) void k_ans0_stats(BlockView view, int maxChunks
 
     // 8 private histograms, chosen by lane: one ds_add instruction never sends more than 8 lanes to the same
     // copy, which is what bounds the same-address serialisation on skewed data (text: 15 % spaces)
-    __shared__ u32 hist[8][256];
+    __shared__ u32 hist[8][264];                 // row stride 264: copy c of a symbol sits 8c banks away, not in the same bank
     __shared__ u32 hdrw[HDR_WORDS];
     __shared__ u32 grpMax[64];
-    for (int i = lane; i < 2048; i += 64) (&hist[0][0])[i] = 0;
+    for (int i = lane; i < 8 * 264; i += 64) (&hist[0][0])[i] = 0;
     for (int i = lane; i < (int)HDR_WORDS; i += 64) hdrw[i] = 0;
     grpMax[lane] = 0;
     __syncthreads();
