@@ -132,7 +132,7 @@ __device__ __forceinline__ u32 quad_bcast(u32 v)
 __global__ __launch_bounds__(64) void k_ans0_encode(BlockView view, int maxChunks, int nSlots, ChunkDesc* __restrict__ desc,
                                                     const uint2* __restrict__ encTab, u8* __restrict__ tmp)
 {
-    __shared__ uint2 tab[16][256];                   // 32 KiB
+    __shared__ uint2 tab[16][257];                   // 32 KiB; odd row stride: the same symbol of different chunks sits in different banks
     __shared__ uint4 stage[16][16];                  // 256 B of staged output per chunk
     const int lane = lane_id();
     const int g = lane >> 2;
