@@ -152,7 +152,7 @@ __global__ __launch_bounds__(64) void k_huff_encode(BlockView view, int maxChunk
         return;
     }
 
-    __shared__ u32 hist[4][256];
+    __shared__ u32 hist[8][264];     // 8 lane-selected copies, rows 8 banks apart (see k_ans0_stats)
     __shared__ u32 hdrw[HDR_WORDS];
     __shared__ u32 keys[256];        // (freq << 8) | sym of present symbols, then sorted
     __shared__ u32 sorted[256];
@@ -163,11 +163,12 @@ __global__ __launch_bounds__(64) void k_huff_encode(BlockView view, int maxChunk
     __shared__ u32 fragw[HUF_FRAG_WORDS];
     __shared__ u32 sh_hdrBits;
 
-    for (int i = lane; i < 1024; i += 64) (&hist[0][0])[i] = 0;
+    for (int i = lane; i < 8 * 264; i += 64) (&hist[0][0])[i] = 0;
     for (int i = lane; i < (int)HDR_WORDS; i += 64) hdrw[i] = 0;
     __syncthreads();
 
     // ---- histogram
+    u32* myHist = hist[lane & 7];
     const u32 n16 = n & ~15u;
     const bool aligned = ((reinterpret_cast<uintptr_t>(blk) & 15) == 0);
     if (aligned) {
@@ -177,25 +178,30 @@ __global__ __launch_bounds__(64) void k_huff_encode(BlockView view, int maxChunk
             const u32 w[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                atomicAdd(&hist[0][w[k] & 0xFF], 1u);
-                atomicAdd(&hist[1][(w[k] >> 8) & 0xFF], 1u);
-                atomicAdd(&hist[2][(w[k] >> 16) & 0xFF], 1u);
-                atomicAdd(&hist[3][w[k] >> 24], 1u);
+                atomicAdd(&myHist[w[k] & 0xFF], 1u);
+                atomicAdd(&myHist[(w[k] >> 8) & 0xFF], 1u);
+                atomicAdd(&myHist[(w[k] >> 16) & 0xFF], 1u);
+                atomicAdd(&myHist[w[k] >> 24], 1u);
             }
         }
     } else {
-        for (u32 i = lane; i < n16; i += 64) atomicAdd(&hist[i & 3][blk[i]], 1u);
+        for (u32 i = lane; i < n16; i += 64) atomicAdd(&myHist[blk[i]], 1u);
     }
-    for (u32 i = n16 + lane; i < n; i += 64) atomicAdd(&hist[0][blk[i]], 1u);
+    for (u32 i = n16 + lane; i < n; i += 64) atomicAdd(&myHist[blk[i]], 1u);
     __syncthreads();
 
     u32 f[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int s = 4 * lane + k;
-        f[k] = hist[0][s] + hist[1][s] + hist[2][s] + hist[3][s];
-        hist[0][s] = f[k];                         // keep totals for the fallback path
+        u32 acc = 0;
+#pragma unroll
+        for (int c = 0; c < 8; c++) acc += hist[c][s];
+        f[k] = acc;
     }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) hist[0][4 * lane + k] = f[k];      // keep totals for the fallback path
     u32 present = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) present |= (f[k] != 0 ? 1u : 0u) << k;
