@@ -8,6 +8,7 @@
 #include <string.h>
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -31,7 +32,9 @@ struct Ctx {
     std::vector<ProfEntry> prof;
     void* pinned = nullptr;      // small pinned host scratch
     size_t pinnedCap = 0;
+    std::recursive_mutex mu;     // a context is one stream + one set of workspaces: calls on it are serialised
 };
+#define CTX_LOCK(c) std::lock_guard<std::recursive_mutex> ctx_lock_((c)->mu)
 
 static int fail(Ctx* c, int code, const char* fmt, ...)
 {
@@ -168,6 +171,7 @@ size_t knz_hip_encode_bound(const knz_params* p, size_t n)
 int knz_hip_set_profiling(knz_ctx* ctx, int enabled)
 {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    CTX_LOCK(c);
     c->profiling = enabled != 0;
     for (auto& e : c->prof) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     c->prof.clear();
@@ -177,6 +181,7 @@ int knz_hip_set_profiling(knz_ctx* ctx, int enabled)
 int knz_hip_get_kernel_times(knz_ctx* ctx, knz_kernel_time* out, int cap)
 {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    CTX_LOCK(c);
     hipStreamSynchronize(c->stream);
     std::vector<std::string> order;
     std::map<std::string, std::pair<float, uint64_t>> agg;
@@ -204,6 +209,7 @@ int knz_hip_get_kernel_times(knz_ctx* ctx, knz_kernel_time* out, int cap)
 int knz_hip_malloc(knz_ctx* ctx, size_t bytes, void** d_ptr)
 {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    CTX_LOCK(c);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMalloc(d_ptr, bytes ? bytes : 1));
     return 0;
@@ -212,6 +218,7 @@ int knz_hip_malloc(knz_ctx* ctx, size_t bytes, void** d_ptr)
 int knz_hip_free(knz_ctx* ctx, void* d_ptr)
 {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    CTX_LOCK(c);
     HIPCHK(c, hipFree(d_ptr));
     return 0;
 }
@@ -219,6 +226,7 @@ int knz_hip_free(knz_ctx* ctx, void* d_ptr)
 int knz_hip_memcpy_h2d(knz_ctx* ctx, void* d_dst, const void* src, size_t bytes)
 {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    CTX_LOCK(c);
     HIPCHK(c, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -227,6 +235,7 @@ int knz_hip_memcpy_h2d(knz_ctx* ctx, void* d_dst, const void* src, size_t bytes)
 int knz_hip_memcpy_d2h(knz_ctx* ctx, void* dst, const void* d_src, size_t bytes)
 {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    CTX_LOCK(c);
     HIPCHK(c, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -235,6 +244,7 @@ int knz_hip_memcpy_d2h(knz_ctx* ctx, void* dst, const void* d_src, size_t bytes)
 int knz_hip_sync(knz_ctx* ctx)
 {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    CTX_LOCK(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -533,6 +543,7 @@ int knz_hip_encode_blocks(knz_ctx* ctx, const knz_params* p, const uint8_t* d_in
                           uint64_t* out_bits)
 {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    CTX_LOCK(c);
     return encode_impl(c, p, d_in, n, prologue, prologue_bits, 1, finish, first_block_id, d_out, out_cap, out_bits);
 }
 
@@ -669,6 +680,7 @@ int knz_hip_decode_blocks(knz_ctx* ctx, const knz_params* p, const uint8_t* d_in
                           int64_t* blocks_done)
 {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    CTX_LOCK(c);
     return decode_impl(c, p, d_in, in_bits, start_bit, max_blocks, 1, 0, d_out, out_cap, out_bytes, end_bit, blocks_done,
                        nullptr, nullptr);
 }
@@ -680,6 +692,7 @@ int knz_hip_entropy_encode(knz_ctx* ctx, int entropy_type, const uint8_t* in, ui
                            uint64_t* out_bits)
 {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    CTX_LOCK(c);
     if (n == 0) { *out_bits = 0; return 0; }
     knz_params p; memset(&p, 0, sizeof(p));
     p.entropy_type = entropy_type; p.block_size = (int32_t)((n + 15) & ~15u); p.transform_type = 0;
@@ -702,6 +715,7 @@ int knz_hip_entropy_decode(knz_ctx* ctx, int entropy_type, const uint8_t* in, ui
                            uint8_t* out, uint32_t n, int32_t* decoded, uint64_t* used_bits)
 {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    CTX_LOCK(c);
     if (n == 0) { *decoded = 0; if (used_bits) *used_bits = 0; return 0; }
     knz_params p; memset(&p, 0, sizeof(p));
     p.entropy_type = entropy_type; p.block_size = (int32_t)((n + 15) & ~15u);
@@ -722,6 +736,7 @@ int knz_hip_entropy_decode(knz_ctx* ctx, int entropy_type, const uint8_t* in, ui
 static int transform_host(Ctx* c, int t, int forward, const uint8_t* in, int32_t n, uint8_t* out, int32_t dstCap, int etype,
                           int32_t* outLen, int32_t* ok)
 {
+    CTX_LOCK(c);
     ProfInstall pi_(c);
     *outLen = 0; *ok = 0;
     if (!transform_supported(t) || t == KNZ_T_NONE) return fail(c, KNZ_ERR_INVALID_CODEC, "transform id %d not implemented on device", t);

@@ -86,3 +86,14 @@ def test_c_api_headerless(tmp_path):
             break
     d.close()
     assert bytes(out) == data
+
+
+def test_threads_share_the_device(tmp_path):
+    # src/api: "separate contexts are independent" -- four threads with their own compressor/decompressor objects
+    # share the device context of the process (tools/gpu_threads.py)
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_threads.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
