@@ -410,7 +410,8 @@ static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t 
     SeqWs w;
     if (int r = seq_alloc(c, nBlocks, S, realStages, scratch, &w)) return r;
     w.a.origLen = d_origLen;
-    launch_init_blocks(s, n, bs, nBlocks, d_origLen, w.a.len);
+    const bool direct = !realStages && !p->checksum_bits;      // NullTransforms only: one bookkeeping launch
+    if (!direct) launch_init_blocks(s, n, bs, nBlocks, d_origLen, w.a.len);
     // block checksums of the ORIGINAL bytes (io/CompressedOutputStream.cpp:675-682)
     u64* d_sums = nullptr;
     if (p->checksum_bits) {
@@ -449,7 +450,8 @@ static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t 
     }
 
     // ---- transform stages
-    for (int i = 0; i < nTok; i++) {
+    if (direct) launch_seq_fwd_direct(s, w.a, d_origLen, n, bs, nBlocks, nTok, d_in, w.d_viewPtr);
+    for (int i = 0; i < nTok && !direct; i++) {
         launch_seq_fwd_prepare(s, w.a, nBlocks, i, d_in, bs, w.A, w.B, S);
         if (tok[i] == KNZ_T_NONE) {
             launch_seq_fwd_null(s, w.a, nBlocks, i);
@@ -461,7 +463,7 @@ static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t 
         if (int r = run_forward_stage(c, s, tok[i], st)) return r;
         launch_seq_fwd_commit(s, w.a, nBlocks, i);
     }
-    launch_seq_fwd_finish(s, w.a, nBlocks, d_in, bs, w.A, w.B, S, w.d_viewPtr);
+    if (!direct) launch_seq_fwd_finish(s, w.a, nBlocks, d_in, bs, w.A, w.B, S, w.d_viewPtr);
     BlockView view;
     view.ptr = w.d_viewPtr; view.len = w.a.len;
     u32* d_blockLen = w.a.len;

@@ -70,6 +70,24 @@ __global__ void k_seq_fwd_finish(SeqArrays a, int nBlocks, const u8* in, u64 inS
     viewPtr[b] = fwd_ptr(a.where[b], b, in, inStride, A, B, S);
 }
 
+// Chains made of NullTransforms only (e.g. "-t NONE"): everything k_init_blocks + prepare + null + finish would
+// compute, in one launch.  Every stage "succeeds", the data never leaves the caller's buffer.
+__global__ void k_seq_fwd_direct(SeqArrays a, u32* origLen, u64 n, u32 blockSize, int nBlocks, int nStages, const u8* in, const u8** viewPtr)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nBlocks) return;
+    const u64 off = (u64)b * blockSize;
+    const u32 len = (n - off < blockSize) ? (u32)(n - off) : blockSize;
+    origLen[b] = len;
+    a.len[b] = len;
+    a.where[b] = 0;
+    const bool copy = len <= 15;                    // io/CompressedOutputStream.cpp:691-695
+    u8 skip = copy ? 0x7F : 0xFF;
+    if (!copy) for (int i = 0; i < nStages; i++) skip &= (u8)~(1u << (7 - i));
+    a.skip[b] = skip;
+    viewPtr[b] = in + off;
+}
+
 // ---- inverse
 __global__ void k_seq_inv_entropy_dst(SeqArrays a, DecBlock* blocks, int nBlocks, u8* out, u64 outStride, u8* A, u64 S, u8** entDst, u32 realMask)
 {
@@ -124,6 +142,8 @@ __global__ void k_seq_inv_commit(SeqArrays a, DecBlock* blocks, int nBlocks, int
 
 #define L1D(k, ...) hipLaunchKernelGGL(k, dim3((nBlocks + 255) / 256), dim3(256), 0, s, __VA_ARGS__)
 
+void launch_seq_fwd_direct(hipStream_t s, const SeqArrays& a, u32* origLen, u64 n, u32 blockSize, int nBlocks, int nStages, const u8* in, const u8** viewPtr)
+{ KScope ks_("k_seq_fwd_direct"); L1D(k_seq_fwd_direct, a, origLen, n, blockSize, nBlocks, nStages, in, viewPtr); }
 void launch_seq_fwd_prepare(hipStream_t s, const SeqArrays& a, int nBlocks, int stage, const u8* in, u64 inStride, u8* A, u8* B, u64 S)
 { KScope ks_("k_seq_fwd_prepare"); L1D(k_seq_fwd_prepare, a, nBlocks, stage, in, inStride, A, B, S); }
 void launch_seq_fwd_commit(hipStream_t s, const SeqArrays& a, int nBlocks, int stage)

@@ -105,6 +105,7 @@ struct SeqArrays {
     const u32* dataCap;      // reference buffer capacities (forward only)
     const u32* bufCap;
 };
+void launch_seq_fwd_direct(hipStream_t s, const SeqArrays& a, u32* origLen, u64 n, u32 blockSize, int nBlocks, int nStages, const u8* in, const u8** viewPtr);
 void launch_seq_fwd_prepare(hipStream_t s, const SeqArrays& a, int nBlocks, int stage, const u8* in, u64 inStride, u8* A, u8* B, u64 S);
 void launch_seq_fwd_null(hipStream_t s, const SeqArrays& a, int nBlocks, int stage);
 void launch_seq_fwd_commit(hipStream_t s, const SeqArrays& a, int nBlocks, int stage);
