@@ -108,29 +108,53 @@ __global__ __launch_bounds__(64) void k_mtf_f_rank(XfView v, int perTiles, const
     const u8* src = s + tbase;
     u8* dst = d + tbase;
     const bool al = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 3) == 0;
+    // four input bytes (uniform) -> four ranks
+    auto rank4 = [&](u32 in4) -> u32 {
+        u32 out4 = 0;
+        if (in4 != front * 0x01010101u) {       // runs (the common case after a BWT) keep the list unchanged: rank 0
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const u32 c = (in4 >> (8 * q)) & 0xFF;
+                if (c == front) continue;
+                front = c;
+                const u32 x = w ^ (c * 0x01010101u);
+                const u32 hz = (x - 0x01010101u) & ~x & 0x80808080u;
+                const u64 m = __ballot(hz != 0);
+                const int lane0 = __ffsll((long long)m) - 1;
+                const u32 hz0 = (u32)__builtin_amdgcn_readlane((int)hz, lane0);
+                const int byteIdx = (__ffs((int)hz0) - 1) >> 3;
+                out4 |= (u32)(4 * lane0 + byteIdx) << (8 * q);
+                w = mtf_rotate(w, lane, lane0, byteIdx, c);
+            }
+        }
+        return out4;
+    };
     u32 k = 0;
+    if (al && cnt == MT) {
+        // full tile: the 4 KiB are loaded up front (16 dwords per lane, coalesced) and handed to the chain with
+        // readlane, results are collected the same way and stored coalesced -- no memory latency inside the chain
+        u32 inr[16], outr[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) inr[t] = reinterpret_cast<const u32*>(src)[64 * t + lane];
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            u32 acc = 0;
+            for (int l = 0; l < 64; l++) {
+                const u32 o = rank4((u32)__builtin_amdgcn_readlane((int)inr[t], l));
+                acc = (lane == l) ? o : acc;
+            }
+            outr[t] = acc;
+        }
+#pragma unroll
+        for (int t = 0; t < 16; t++) reinterpret_cast<u32*>(dst)[64 * t + lane] = outr[t];
+        k = MT;
+    }
     for (; k + 4 <= cnt; k += 4) {
         u32 in4;
         if (al) in4 = *reinterpret_cast<const u32*>(src + k);
         else in4 = (u32)src[k] | ((u32)src[k + 1] << 8) | ((u32)src[k + 2] << 16) | ((u32)src[k + 3] << 24);
         in4 = (u32)__builtin_amdgcn_readfirstlane((int)in4);
-        u32 out4 = 0;
-        if (in4 != front * 0x01010101u) {       // runs (the common case after a BWT) keep the list unchanged: rank 0
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const u32 c = (in4 >> (8 * q)) & 0xFF;
-            if (c == front) continue;
-            front = c;
-            const u32 x = w ^ (c * 0x01010101u);
-            const u32 hz = (x - 0x01010101u) & ~x & 0x80808080u;
-            const u64 m = __ballot(hz != 0);
-            const int lane0 = __ffsll((long long)m) - 1;
-            const u32 hz0 = (u32)__builtin_amdgcn_readlane((int)hz, lane0);
-            const int byteIdx = (__ffs((int)hz0) - 1) >> 3;
-            out4 |= (u32)(4 * lane0 + byteIdx) << (8 * q);
-            w = mtf_rotate(w, lane, lane0, byteIdx, c);
-        }
-        }
+        const u32 out4 = rank4(in4);
         if (lane == 0) {
             if (al) *reinterpret_cast<u32*>(dst + k) = out4;
             else { dst[k] = (u8)out4; dst[k + 1] = (u8)(out4 >> 8); dst[k + 2] = (u8)(out4 >> 16); dst[k + 3] = (u8)(out4 >> 24); }
@@ -165,28 +189,50 @@ __global__ __launch_bounds__(64) void k_mtf_i_symbolic(XfView v, int perTiles, u
     u32 front = 0;                                   // id at list position 0 (uniform)
     const u32 cnt = (n - tbase < MT) ? (n - tbase) : MT;
     const bool al = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 3) == 0;
+    // four ranks (uniform) -> four list ids
+    auto ids4 = [&](u32 in4) -> u32 {
+        u32 out4 = 0;
+        if (in4 == 0) out4 = front * 0x01010101u;       // rank 0 four times: the front symbol repeats
+        else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const u32 r = (in4 >> (8 * q)) & 0xFF;
+                if (r == 0) { out4 |= front << (8 * q); continue; }
+                const int lane0 = (int)(r >> 2);
+                const int byteIdx = (int)(r & 3);
+                const u32 wl = (u32)__builtin_amdgcn_readlane((int)w, lane0);
+                const u32 c = (wl >> (8 * byteIdx)) & 0xFF;
+                out4 |= c << (8 * q);
+                front = c;
+                w = mtf_rotate(w, lane, lane0, byteIdx, c);
+            }
+        }
+        return out4;
+    };
     u32 k = 0;
+    if (al && cnt == MT) {
+        u32 inr[16], outr[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) inr[t] = reinterpret_cast<const u32*>(src)[64 * t + lane];
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            u32 acc = 0;
+            for (int l = 0; l < 64; l++) {
+                const u32 o = ids4((u32)__builtin_amdgcn_readlane((int)inr[t], l));
+                acc = (lane == l) ? o : acc;
+            }
+            outr[t] = acc;
+        }
+#pragma unroll
+        for (int t = 0; t < 16; t++) reinterpret_cast<u32*>(dst)[64 * t + lane] = outr[t];
+        k = MT;
+    }
     for (; k + 4 <= cnt; k += 4) {
         u32 in4;
         if (al) in4 = *reinterpret_cast<const u32*>(src + k);
         else in4 = (u32)src[k] | ((u32)src[k + 1] << 8) | ((u32)src[k + 2] << 16) | ((u32)src[k + 3] << 24);
         in4 = (u32)__builtin_amdgcn_readfirstlane((int)in4);
-        u32 out4 = 0;
-        if (in4 == 0) out4 = front * 0x01010101u;       // rank 0 four times: the front symbol repeats
-        else {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const u32 r = (in4 >> (8 * q)) & 0xFF;
-            if (r == 0) { out4 |= front << (8 * q); continue; }
-            const int lane0 = (int)(r >> 2);
-            const int byteIdx = (int)(r & 3);
-            const u32 wl = (u32)__builtin_amdgcn_readlane((int)w, lane0);
-            const u32 c = (wl >> (8 * byteIdx)) & 0xFF;
-            out4 |= c << (8 * q);
-            front = c;
-            w = mtf_rotate(w, lane, lane0, byteIdx, c);
-        }
-        }
+        const u32 out4 = ids4(in4);
         if (lane == 0) {
             if (al) *reinterpret_cast<u32*>(dst + k) = out4;
             else { dst[k] = (u8)out4; dst[k + 1] = (u8)(out4 >> 8); dst[k + 2] = (u8)(out4 >> 16); dst[k + 3] = (u8)(out4 >> 24); }
