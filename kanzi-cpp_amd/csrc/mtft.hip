@@ -32,7 +32,7 @@ struct XfView {
 // w: my 4 entries (position 4*lane in byte 0). rank = 4*lane0 + byteIdx (uniform).
 __device__ __forceinline__ u32 mtf_rotate(u32 w, int lane, int lane0, int byteIdx, u32 front)
 {
-    const u32 prev = (u32)__shfl_up((int)w, 1, 64);
+    const u32 prev = (u32)__builtin_amdgcn_update_dpp(0, (int)w, 0x138, 0xF, 0xF, false);   // wave_shr:1 (lane i <- lane i-1)
     const u32 carry = (lane == 0) ? front : (prev >> 24);
     const u32 shifted = (w << 8) | carry;
     if (lane < lane0) return shifted;

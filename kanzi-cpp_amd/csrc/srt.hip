@@ -23,7 +23,7 @@ namespace knz {
 // rotate list positions [0, rank] right by one and put `front` at position 0 (rank = 4*lane0 + byteIdx)
 __device__ __forceinline__ u32 srt_to_front(u32 w, int lane, int lane0, int byteIdx, u32 front)
 {
-    const u32 prev = (u32)__shfl_up((int)w, 1, 64);
+    const u32 prev = (u32)__builtin_amdgcn_update_dpp(0, (int)w, 0x138, 0xF, 0xF, false);   // wave_shr:1 (lane i <- lane i-1)
     const u32 carry = (lane == 0) ? front : (prev >> 24);
     const u32 shifted = (w << 8) | carry;
     if (lane < lane0) return shifted;
@@ -40,7 +40,7 @@ __device__ __forceinline__ u32 srt_drop_front(u32 w, int lane, u32 rank, bool in
 {
     const int lane0 = (int)(rank >> 2);
     const u32 byteIdx = rank & 3;
-    const u32 next = (u32)__shfl_down((int)w, 1, 64);
+    const u32 next = (u32)__builtin_amdgcn_update_dpp(0, (int)w, 0x130, 0xF, 0xF, false);   // wave_shl:1 (lane i <- lane i+1)
     const u32 shifted = (w >> 8) | (next << 24);
     if (lane < lane0) return shifted;
     if (lane == lane0) {
