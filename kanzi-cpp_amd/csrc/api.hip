@@ -5,6 +5,7 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <map>
@@ -58,6 +59,10 @@ static int ws_get(Ctx* c, const char* name, size_t bytes, void** out)
         w.cap = want;
     }
     *out = w.p;
+    // KNZ_POISON_WS=1 (debugging aid): fill every workspace with a pattern on every request, so that a kernel that
+    // relies on what an earlier call left behind fails deterministically instead of once in a few thousand runs
+    static const int poison = getenv("KNZ_POISON_WS") ? atoi(getenv("KNZ_POISON_WS")) : 0;
+    if (poison && bytes) HIPCHK(c, hipMemsetAsync(w.p, poison == 2 ? 0xFF : 0xA5, bytes, c->stream));
     return 0;
 }
 
@@ -664,6 +669,7 @@ static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_
     u64 total = 0;
     for (int b = 0; b < nBlocks; b++) {
         if (hb[b].error) {
+            if (getenv("KNZ_DEBUG_ERR")) fprintf(stderr, "DBG block %d error %d used %llu\n", b, hb[b].error, (unsigned long long)hb[b].usedBits);
             if (rawDecoded) { *rawDecoded = -1; if (usedBits) *usedBits = hb[b].usedBits; return 0; }
             return fail(c, hb[b].error, "block %d: decoding failed (code %d)", b + 1, hb[b].error);
         }

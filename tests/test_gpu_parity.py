@@ -3,6 +3,7 @@ golden vectors generated from the reference, and size-independent properties at 
 Bit-exact everywhere (integer/byte work)."""
 import hashlib
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -65,6 +66,20 @@ def test_entropy_stage_golden(hip, golden):
         assert dec == len(d) and out == d and used == bits, (rec["name"], rec["input"])
         n += 1
     assert n >= 2 * len(vectors.STAGE_INPUTS)
+
+
+def test_reference_quirks(hip):
+    """tests/golden/quirks.json: streams the reference emits but cannot decode. Bit-exact means the same stream out
+    and the same refusal on the way back (a decoder that 'repairs' them would accept streams the reference rejects)."""
+    import json
+    recs = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "quirks.json")))
+    for rec in recs:
+        d = bytes.fromhex(rec["input_hex"])
+        enc, bits = hip.entropy_encode(rec["entropy"], d)
+        assert bits == rec["bits"] and hashlib.md5(enc).hexdigest() == rec["enc_md5"], rec["name"]
+        dec, out, used = hip.entropy_decode(rec["entropy"], enc, len(d))
+        got = len(d) if (dec == len(d) and out == d) else -1
+        assert got == rec["ref_decoded"], rec["name"]
 
 
 def test_entropy_stage_vs_oracle_random(hip, oracle):

@@ -31,6 +31,21 @@ def test_entropy_stage_vectors(oracle, golden):
     assert n > 100
 
 
+def test_reference_quirks(oracle):
+    """Inputs on which the reference misbehaves (tests/golden/quirks.json): the oracle reproduces the encoder's
+    output bit for bit and fails to decode it exactly as the reference does."""
+    import json, os
+    recs = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "quirks.json")))
+    assert recs
+    for rec in recs:
+        d = bytes.fromhex(rec["input_hex"])
+        enc, bits = oracle.entropy_encode(rec["entropy"], d)
+        assert bits == rec["bits"] and hashlib.md5(enc).hexdigest() == rec["enc_md5"], rec["name"]
+        r = oracle.entropy_decode(rec["entropy"], enc, len(d))
+        got = len(d) if (r[0] == len(d) and r[1] == d) else -1
+        assert got == rec["ref_decoded"], rec["name"]
+
+
 def test_transform_stage_vectors(oracle, golden):
     n = 0
     for rec in golden["stages"]:
