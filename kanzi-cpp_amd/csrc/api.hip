@@ -105,7 +105,7 @@ static int count_transforms(uint64_t t, int* tok)
     return nb;
 }
 
-static bool transform_supported(int t) { return t == KNZ_T_NONE || t == KNZ_T_ZRLT || t == KNZ_T_MTFT || t == KNZ_T_BWT || t == KNZ_T_SRT || t == KNZ_T_RLT; }
+static bool transform_supported(int t) { return t == KNZ_T_NONE || t == KNZ_T_ZRLT || t == KNZ_T_MTFT || t == KNZ_T_BWT || t == KNZ_T_SRT || t == KNZ_T_RLT || t == KNZ_T_LZ || t == KNZ_T_LZX; }
 static bool entropy_supported(int e) { return e == KNZ_E_NONE || e == KNZ_E_ANS0 || e == KNZ_E_ANS1 || e == KNZ_E_HUFFMAN || e == KNZ_E_FPAQ; }
 
 static int max_encoded_len(int t, int n)
@@ -114,6 +114,7 @@ static int max_encoded_len(int t, int n)
     case KNZ_T_BWT: return n + 33;
     case KNZ_T_SRT: return n + 1024;
     case KNZ_T_RLT: return (n <= 512) ? n + 32 : n;
+    case KNZ_T_LZ: case KNZ_T_LZX: return ((n <= 1024) ? n + 16 : n + n / 64) + 2;     // LZCodec.hpp:91-95
     default: return n;
     }
 }
@@ -310,11 +311,12 @@ static int seq_alloc(Ctx* c, int nBlocks, u64 S, bool needAB, size_t scratchU32,
     return 0;
 }
 
-static size_t stage_scratch_u32(int t, int nBlocks, u32 maxLen)
+static size_t stage_scratch_u32(int t, int nBlocks, u32 maxLen, bool forward = true)
 {
     switch (t) {
     case KNZ_T_ZRLT: return zrlt_scratch_u32(nBlocks, maxLen);
     case KNZ_T_MTFT: return mtft_scratch_u32(nBlocks, maxLen);
+    case KNZ_T_LZ: case KNZ_T_LZX: return forward ? lz_scratch_u32(t, nBlocks, maxLen) : 0;    // hash tables + side sections
     default: return 0;
     }
 }
@@ -326,6 +328,7 @@ static int run_forward_stage(Ctx* c, hipStream_t s, int t, const XfStage& st)
     case KNZ_T_MTFT: launch_mtft_forward(s, st); break;
     case KNZ_T_SRT: launch_srt_forward(s, st); break;
     case KNZ_T_RLT: launch_rlt_forward(s, st); break;
+    case KNZ_T_LZ: case KNZ_T_LZX: launch_lz_forward(s, st, t); break;
     case KNZ_T_BWT: {
         const size_t bytes = bwt_forward_scratch_bytes(st.nBlocks, st.maxLen, (size_t)st.nBlocks * st.maxLen);
         void* sc;
@@ -345,6 +348,7 @@ static int run_inverse_stage(Ctx* c, hipStream_t s, int t, const XfStage& st)
     case KNZ_T_MTFT: launch_mtft_inverse(s, st); break;
     case KNZ_T_SRT: launch_srt_inverse(s, st); break;
     case KNZ_T_RLT: launch_rlt_inverse(s, st); break;
+    case KNZ_T_LZ: case KNZ_T_LZX: launch_lz_inverse(s, st); break;
     case KNZ_T_BWT: {
         const size_t bytes = bwt_inverse_scratch_bytes(st.nBlocks, st.maxLen, (size_t)st.nBlocks * st.maxLen);
         void* sc;
@@ -607,7 +611,7 @@ static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_
     const u32 maxPre = (u32)S;
     bool realStages = false;
     size_t scratch = 0;
-    for (int i = 0; i < nTok; i++) if (tok[i] != KNZ_T_NONE) { realStages = true; const size_t q = stage_scratch_u32(tok[i], nBlocks, (u32)S); if (q > scratch) scratch = q; }
+    for (int i = 0; i < nTok; i++) if (tok[i] != KNZ_T_NONE) { realStages = true; const size_t q = stage_scratch_u32(tok[i], nBlocks, (u32)S, false); if (q > scratch) scratch = q; }
     SeqWs w;
     if (int r = seq_alloc(c, nBlocks, S, realStages, scratch, &w)) return r;
     const int maxChunks = (int)((S + ENT_CHUNK - 1) / ENT_CHUNK);
@@ -754,7 +758,7 @@ static int transform_host(Ctx* c, int t, int forward, const uint8_t* in, int32_t
     hipStream_t s = c->stream;
     const u32 maxLen = (u32)std::max(n, dstCap) + 2048;
     SeqWs w;
-    if (int r = seq_alloc(c, 1, maxLen, false, stage_scratch_u32(t, 1, maxLen), &w)) return r;
+    if (int r = seq_alloc(c, 1, maxLen, false, stage_scratch_u32(t, 1, maxLen, forward != 0), &w)) return r;
     u8 *d_in, *d_out;
     if (int r = ws_get(c, "stageIn", (size_t)n + 64, (void**)&d_in)) return r;
     if (int r = ws_get(c, "stageOut", (size_t)maxLen + 64, (void**)&d_out)) return r;

@@ -189,6 +189,7 @@ static int max_encoded_len(int t, int n)
     case 1: return n + 33;
     case 13: return n + 1024;
     case 5: return (n <= 512) ? n + 32 : n;
+    case 3: case 16: return knzo_lz_max_encoded(n);
     default: return n;
     }
 }
@@ -203,7 +204,7 @@ static int seq_required(const int* tok, int nb, int n)
     return req;
 }
 
-static int supported_transform(int t) { return t == 0 || t == 1 || t == 5 || t == 6 || t == 7 || t == 13; }
+static int supported_transform(int t) { return t == 0 || t == 1 || t == 3 || t == 5 || t == 6 || t == 7 || t == 13 || t == 16; }
 static int supported_entropy(int e) { return e == 0 || e == 1 || e == 2 || e == 5 || e == 8; }
 
 /* TransformSequence::forward with explicit capacities. data = block input (capacity dataCap),

@@ -561,6 +561,8 @@ int knzo_transform_forward(int ttype, const uint8_t* src, int n, uint8_t* dst, i
     case 6:  return zrlt_forward(src, n, dst, dstCap, outLen);
     case 7:  return mtft_forward(src, n, dst, dstCap, outLen);
     case 13: return srt_forward(src, n, dst, dstCap, outLen);
+    case 3:  return knzo_lz_forward(src, n, dst, dstCap, 0, outLen);
+    case 16: return knzo_lz_forward(src, n, dst, dstCap, 1, outLen);
     default: *outLen = 0; return 0;
     }
 }
@@ -574,6 +576,7 @@ int knzo_transform_inverse(int ttype, const uint8_t* src, int n, uint8_t* dst, i
     case 6:  return zrlt_inverse(src, n, dst, dstCap, outLen);
     case 7:  return mtft_inverse(src, n, dst, dstCap, outLen);
     case 13: return srt_inverse(src, n, dst, dstCap, outLen);
+    case 3: case 16: return knzo_lz_inverse(src, n, dst, dstCap, outLen);
     default: *outLen = 0; return 0;
     }
 }

@@ -56,7 +56,7 @@ def ensure_ref():
 
 
 ETYPE = {"NONE": 0, "HUFFMAN": 1, "FPAQ": 2, "ANS0": 5, "ANS1": 8}
-TTYPE = {"NONE": 0, "BWT": 1, "RLT": 5, "ZRLT": 6, "MTFT": 7, "SRT": 13}
+TTYPE = {"NONE": 0, "BWT": 1, "LZ": 3, "RLT": 5, "ZRLT": 6, "MTFT": 7, "SRT": 13, "LZX": 16}
 
 
 class Oracle:
@@ -192,11 +192,11 @@ class Ref:
                                   (entropy or "").encode(), C.byref(ol), C.byref(sk))
         return ok, bytes(out[:ol.value]), sk.value
 
-    def inverse(self, name, data, dst_cap, skip=0):
+    def inverse(self, name, data, dst_cap, skip=0, src_cap=0):
         out = (C.c_uint8 * (dst_cap + 64))()
         ol = C.c_int(0)
         sk = C.c_int(skip)
-        ok = self.L.ref_transform(name.encode(), 0, _buf(data), len(data), 0, out, dst_cap, b"",
+        ok = self.L.ref_transform(name.encode(), 0, _buf(data), len(data), src_cap, out, dst_cap, b"",
                                   C.byref(ol), C.byref(sk))
         return ok, bytes(out[:ol.value])
 

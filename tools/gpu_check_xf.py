@@ -23,10 +23,14 @@ for spec in specs:
     d = vectors.make(spec)
     if len(d) == 0: continue
     for t in names:
-        for cap in ([len(d), len(d) + 2048] if t in ("ZRLT", "RLT") else [len(d) + 2048]):
+        caps = [len(d), len(d) + 2048] if t in ("ZRLT", "RLT") else [len(d) + 2048]
+        if t in ("LZ", "LZX"): caps = [len(d) + len(d) // 64 + 64, len(d) + 17]
+        for cap in caps:
             ok1, o1 = O.forward(t, d, cap, "ANS0")
             try:
+                t0 = time.time()
                 ok2, o2 = ctx.transform_forward(t, d, cap, "ANS0")
+                if "-t" in sys.argv: print("   %s %s n=%d forward %.1f ms" % (str(spec)[:30], t, len(d), 1e3 * (time.time() - t0)))
             except Exception as ex:
                 print(spec, t, "FWD EXC", ex); bad += 1; continue
             good = (bool(ok1) == bool(ok2)) and (not ok1 or o1 == o2)
@@ -37,7 +41,9 @@ for spec in specs:
             if ok1:
                 icap = max(len(d), len(o1)) + 64
                 k1, b1 = O.inverse(t, o1, icap)
+                t0 = time.time()
                 k2, b2 = ctx.transform_inverse(t, o1, icap)
+                if "-t" in sys.argv: print("   %s %s n=%d inverse %.1f ms" % (str(spec)[:30], t, len(d), 1e3 * (time.time() - t0)))
                 ig = (bool(k1) == bool(k2)) and (not k1 or b1 == b2) and (b1 == d)
                 if not ig:
                     bad += 1; msg += " | inv ok %d/%d len %d/%d firstdiff %d" % (k1, k2, len(b1), len(b2), first_diff(b1, b2))
