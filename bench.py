@@ -28,9 +28,10 @@ CONFIGS = {
     2: dict(transform="NONE", entropy="ANS0", block=4 << 20, corpus="silesia"),
     3: dict(transform="BWT+MTFT+ZRLT", entropy="ANS0", block=8 << 20, corpus="silesia"),
     4: dict(transform="BWT+SRT+ZRLT", entropy="FPAQ", block=32 << 20, corpus="enwik9"),
-    # not BASELINE lines: config 1's codec on the device (BASELINE runs it on the CPU) and config 5 without LZX
+    5: dict(transform="LZX", entropy="ANS1", block=16 << 20, corpus="silesia"),
+    # not BASELINE lines: config 1's codec on the device (BASELINE runs it on the CPU), config 5's entropy stage alone
     1: dict(transform="NONE", entropy="HUFFMAN", block=4 << 20, corpus="silesia"),
-    5: dict(transform="NONE", entropy="ANS1", block=16 << 20, corpus="silesia"),
+    6: dict(transform="NONE", entropy="ANS1", block=16 << 20, corpus="silesia"),
 }
 
 # Algorithmic HBM bytes of one launch of each kernel (ideal one-pass traffic),

@@ -208,6 +208,13 @@ public:
 class SRT : public DeviceTransform { public: explicit SRT(Context& ctx) : DeviceTransform(KNZ_T_SRT, &ctx) {} SRT() : DeviceTransform(KNZ_T_SRT, nullptr) {} };
 class ZRLT : public DeviceTransform { public: explicit ZRLT(Context& ctx) : DeviceTransform(KNZ_T_ZRLT, &ctx) {} ZRLT() : DeviceTransform(KNZ_T_ZRLT, nullptr) {} };
 class RLT : public DeviceTransform { public: explicit RLT(Context& ctx) : DeviceTransform(KNZ_T_RLT, &ctx) {} RLT() : DeviceTransform(KNZ_T_RLT, nullptr) {} };
+// transform/LZCodec.hpp:27-52: "LZ" (16-bit hash) or "LZX" (19-bit hash, deeper look-ahead) chosen by the context's
+// "lz" entry, which TransformFactory sets (TransformFactory.hpp:257-267). LZP has no device kernel.
+class LZCodec : public DeviceTransform {
+public:
+    LZCodec() : DeviceTransform(KNZ_T_LZ, nullptr) {}
+    explicit LZCodec(Context& ctx);
+};
 class NullTransform : public Transform<byte> {
 public:
     NullTransform() {}

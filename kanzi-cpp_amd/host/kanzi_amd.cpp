@@ -243,6 +243,7 @@ int DeviceTransform::getMaxEncodedLength(int n) const
     case KNZ_T_BWT: return n + 33;                      // BWTBlockCodec.hpp:47-50
     case KNZ_T_SRT: return n + 1024;                    // SRT.hpp:38
     case KNZ_T_RLT: return (n <= 512) ? n + 32 : n;     // RLT.hpp:43
+    case KNZ_T_LZ: case KNZ_T_LZX: return ((n <= 1024) ? n + 16 : n + (n / 64)) + 2;    // LZCodec.hpp:91-95
     default: return n;
     }
 }
@@ -271,6 +272,8 @@ bool DeviceTransform::inverse(SliceArray<byte>& src, SliceArray<byte>& dst, int 
     if (!SliceArray<byte>::isValid(dst)) throw std::invalid_argument("Invalid output block");
     if ((length < 0) || (length > src._length - src._index)) return false;
     if (src._array == dst._array) return false;
+    // LZCodec.cpp:486-490: readLength() may look two bytes past the block, which therefore must exist
+    if ((_type == KNZ_T_LZ || _type == KNZ_T_LZX) && (length > src._length - src._index - 2)) return false;
     knz_ctx* c = deviceContext();
     int32_t outLen = 0, ok = 0;
     devCheck(c, knz_hip_transform_inverse(c, _type, src._array + src._index, length, dst._array + dst._index,
@@ -280,6 +283,15 @@ bool DeviceTransform::inverse(SliceArray<byte>& src, SliceArray<byte>& dst, int 
     dst._index += outLen;
     return true;
 }
+
+static int lzTypeFromContext(Context& ctx)
+{
+    const int t = ctx.getInt("lz", 3);
+    if (t == 14) throw std::invalid_argument("LZP has no device kernel (out of scope of the accelerated block pipeline)");
+    return (t == 16) ? KNZ_T_LZX : KNZ_T_LZ;
+}
+
+LZCodec::LZCodec(Context& ctx) : DeviceTransform(lzTypeFromContext(ctx), &ctx) {}
 
 SBRT::SBRT(int mode) : DeviceTransform(KNZ_T_MTFT, nullptr)
 {
@@ -498,6 +510,8 @@ TransformSequence<T>* TransformFactory<T>::newTransform(Context& ctx, uint64 fun
             case SRT_TYPE: transforms[nbtr++] = new SRT(ctx); break;
             case ZRLT_TYPE: transforms[nbtr++] = new ZRLT(ctx); break;
             case RLT_TYPE: transforms[nbtr++] = new RLT(ctx); break;
+            case LZ_TYPE: ctx.putInt("lz", LZ_TYPE); transforms[nbtr++] = new LZCodec(ctx); break;
+            case LZX_TYPE: ctx.putInt("lz", LZX_TYPE); transforms[nbtr++] = new LZCodec(ctx); break;
             default: {
                 std::stringstream ss;
                 ss << "Transform type " << t << " has no device kernel (out of scope of the accelerated block pipeline)";

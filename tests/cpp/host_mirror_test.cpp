@@ -35,7 +35,7 @@ static std::vector<byte> gen(int kind, size_t n, unsigned seed)
 
 static void testTransforms()
 {
-    const char* names[] = { "BWT", "MTFT", "ZRLT", "SRT", "RLT", "BWT+MTFT+ZRLT", "BWT+SRT+ZRLT" };
+    const char* names[] = { "BWT", "MTFT", "ZRLT", "SRT", "RLT", "LZ", "LZX", "BWT+MTFT+ZRLT", "BWT+SRT+ZRLT", "RLT+LZX" };
     for (const char* nm : names) {
         for (int kind = 0; kind < 5; kind++) {
             for (size_t n : { size_t(20), size_t(512), size_t(80000) }) {
@@ -129,7 +129,7 @@ static void testStreams()
 {
     // src/test/TestCompressedStream.cpp: sizes 64 KiB .. 4 MiB, several job counts, write/read after close
     struct Cfg { const char* t; const char* e; int bs; } cfgs[] = {
-        { "NONE", "ANS0", 65536 }, { "BWT+MTFT+ZRLT", "ANS0", 262144 }, { "RLT+ZRLT", "HUFFMAN", 65536 }, { "BWT+SRT+ZRLT", "FPAQ", 262144 }, { "SRT", "ANS1", 262144 } };
+        { "NONE", "ANS0", 65536 }, { "BWT+MTFT+ZRLT", "ANS0", 262144 }, { "RLT+ZRLT", "HUFFMAN", 65536 }, { "BWT+SRT+ZRLT", "FPAQ", 262144 }, { "SRT", "ANS1", 262144 }, { "LZX", "ANS1", 262144 } };
     for (const Cfg& cf : cfgs) {
         for (int jobs = 1; jobs <= 4; jobs += 3) {
             for (size_t n : { size_t(0), size_t(1), size_t(65536), size_t(1000001) }) {

@@ -32,9 +32,11 @@ def main():
         for e in ["NONE", "HUFFMAN", "ANS0", "ANS1", "FPAQ"]:
             enc, bits = R.entropy_encode(e, d)
             out["stages"].append({"kind": "entropy", "name": e, "input": list(spec), "bits": bits, "out": pack(enc)})
-        for t in ["BWT", "MTFT", "ZRLT", "SRT", "RLT"]:
+        for t in ["BWT", "MTFT", "ZRLT", "SRT", "RLT", "LZ", "LZX"]:
             for ent in (["", "ANS0", "FPAQ"] if t == "RLT" else [""]):
                 cap = len(d) if t == "ZRLT" else len(d) + 2048
+                if t in ("LZ", "LZX"):
+                    cap = len(d) + len(d) // 64 + 64          # >= getMaxEncodedLength, or the codec refuses
                 ok, o, sk = R.forward(t, d, cap, ent or None)
                 rec = {"kind": "transform", "name": t, "entropy": ent, "input": list(spec), "cap": cap, "ok": int(ok == 1)}
                 if ok == 1:

@@ -14,7 +14,7 @@ import vectors
 pytestmark = pytest.mark.gpu
 
 ENTROPY_ON_DEVICE = ["NONE", "ANS0", "ANS1", "HUFFMAN", "FPAQ"]
-TRANSFORMS_ON_DEVICE = ["ZRLT", "MTFT", "BWT", "SRT", "RLT"]
+TRANSFORMS_ON_DEVICE = ["ZRLT", "MTFT", "BWT", "SRT", "RLT", "LZ", "LZX"]
 
 
 def matches(packed, b):
@@ -151,8 +151,9 @@ def test_transform_capacity_semantics(hip, oracle):
     cases = [vectors.make(("mixed", 200000, 7)), rng.integers(0, 256, 30000, dtype=np.uint8).tobytes(),
              vectors.make(("ffmix", 500)), bytes(5000), vectors.make(("runs", 300, 40))]
     for d in cases:
-        for t in ["ZRLT", "RLT", "MTFT", "SRT", "BWT"]:
-            for cap in (len(d) // 2, len(d) - 1, len(d), len(d) + 1, len(d) + 33, len(d) + 1024, len(d) + 2048):
+        for t in ["ZRLT", "RLT", "MTFT", "SRT", "BWT", "LZ", "LZX"]:
+            lzmax = ((len(d) + 16) if len(d) <= 1024 else len(d) + len(d) // 64) + 2      # LZCodec.hpp:91-95
+            for cap in (len(d) // 2, len(d) - 1, len(d), len(d) + 1, len(d) + 33, len(d) + 1024, len(d) + 2048, lzmax - 1, lzmax):
                 ok1, o1 = oracle.forward(t, d, cap, "ANS0")
                 ok2, o2 = hip.transform_forward(t, d, cap, "ANS0")
                 assert bool(ok1) == bool(ok2), (t, cap, len(d))

@@ -33,21 +33,27 @@ def test_entropy_matches_reference(oracle, ref):
 
 def test_transforms_match_reference(oracle, ref):
     for d in _inputs():
-        for t in ["BWT", "MTFT", "ZRLT", "SRT", "RLT"]:
+        for t in ["BWT", "MTFT", "ZRLT", "SRT", "RLT", "LZ", "LZX"]:
             cap = len(d) if t == "ZRLT" else len(d) + 2048
+            if t in ("LZ", "LZX"):
+                cap = len(d) + len(d) // 64 + 18
             ok1, o1 = oracle.forward(t, d, cap, "ANS0")
             ok2, o2, _ = ref.forward(t, d, cap, "ANS0")
             assert bool(ok1) == (ok2 == 1), t
             if ok1:
                 assert o1 == o2, t
-                k, back = ref.inverse(t, o1, max(len(d), len(o1)) + 64)
+                # LZ's inverse wants two readable bytes behind its input (LZCodec.cpp:486-490)
+                k, back = ref.inverse(t, o1, max(len(d), len(o1)) + 64, src_cap=len(o1) + 2)
+                assert k == 1 and back == d
+                k, back = oracle.inverse(t, o1, max(len(d), len(o1)) + 64)
                 assert k == 1 and back == d
 
 
 def test_streams_match_reference(oracle, ref):
     d = vectors.make(("mixed", 700001, 11))
     for t, e, bs, ck in [("BWT+MTFT+ZRLT", "ANS0", 65536, 0), ("BWT+SRT+ZRLT", "FPAQ", 262144, 32),
-                         ("RLT+ZRLT", "HUFFMAN", 16384, 64), ("NONE", "ANS1", 1 << 20, 0)]:
+                         ("RLT+ZRLT", "HUFFMAN", 16384, 64), ("NONE", "ANS1", 1 << 20, 0),
+                         ("LZX", "ANS1", 262144, 0), ("LZ+ZRLT", "HUFFMAN", 65536, 32)]:
         for jobs in (1, 3):
             # the job count selects buffer slots, hence capacities, hence ZRLT's success on short last blocks
             rc1, a = oracle.compress(d, t, e, bs, ck, jobs=jobs)

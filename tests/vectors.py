@@ -94,4 +94,9 @@ STREAM_CASES = [
     (("ramp", 1025), "BWT+MTFT+ZRLT", "ANS0", 1024, 0, 0),
     (("const", 100000, 0), "BWT+MTFT+ZRLT", "ANS0", 65536, 0, 0),
     (("const", 100000, 0), "RLT", "NONE", 65536, 0, 0),
+    (("text", 4194304, 1), "LZX", "ANS1", 1 << 20, 0, 0),
+    (("mixed", 4194304, 2), "LZ", "HUFFMAN", 1 << 20, 0, 0),
+    (("mixed", 1 << 20, 3), "RLT+LZX", "ANS0", 1 << 18, 32, 0),
+    (("rand", 300000, 9), "LZX", "ANS0", 1 << 16, 0, 0),
+    (("const", 100000, 0), "LZ", "NONE", 65536, 0, 0),
 ]
