@@ -40,8 +40,35 @@ __device__ __forceinline__ u64 sgpr64(u64 v)
 template <int HASH_LOG>
 __device__ __forceinline__ u32 lz_hash(u64 w) { return (u32)(((w << 24) * 0x1E35A7BDull) >> (64 - HASH_LOG)); }
 
-__device__ __forceinline__ int tab_get(int* t, u32 h) { return __hip_atomic_load(t + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void tab_put(int* t, u32 h, int p) { __hip_atomic_fetch_max(t + h, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// The table belongs to one wave, so plain loads and stores are coherent (same CU, same L1) and no access has to
+// travel to the device-wide coherence point. Positions only grow, so a store is the reference's overwrite.
+__device__ __forceinline__ int tab_get(const int* t, u32 h) { return t[h]; }
+__device__ __forceinline__ void tab_put(int* t, u32 h, int p) { t[h] = p; }
+
+// 64 Kbit LDS filter over the low 16 hash bits: returns true when some lane of `act` may share its hash with
+// another one (never misses a real duplicate); leaves the filter clear
+__device__ __forceinline__ bool lz_maybe_dups(u32* seen, u32 h, bool act)
+{
+    const u32 fbit = 1u << (h & 31), fidx = (h >> 5) & 2047;
+    const u32 old = act ? atomicOr(&seen[fidx], fbit) : 0u;
+    if (act) atomicAnd(&seen[fidx], ~fbit);
+    return __ballot(act && (old & fbit)) != 0;
+}
+
+// table[h] = p for every lane of `act`, in lane order: with equal hashes the highest lane (latest position) stays
+__device__ __forceinline__ void tab_put_wave(int* t, u32* seen, u32 h, int p, bool act, int lane)
+{
+    bool lose = false;
+    if (lz_maybe_dups(seen, h, act)) {
+#pragma unroll 9
+        for (int j = 1; j < 64; j++) {
+            const u32 hj = (u32)__builtin_amdgcn_readlane((int)h, j);
+            const int aj = __builtin_amdgcn_readlane(act ? 1 : 0, j);
+            if (aj && j > lane && hj == h) lose = true;
+        }
+    }
+    if (act && !lose) t[h] = p;
+}
 
 // LZCodec.hpp:227-246 with the whole wave: compares whole 8-byte words only (so the result can stop up to 7 bytes
 // short of `limit`), lane l looks at word n/8 + l
@@ -66,13 +93,13 @@ __device__ int lz_match(const u8* s, int a, int b, int limit, int lane)
     }
 }
 
-// non-overlapping copy, 8 bytes per lane
+// non-overlapping copy: 8 bytes per lane for the bulk, one byte per lane for the last < 8 bytes, so that even a
+// 5-byte copy is one load and one store deep (a byte loop in one lane would be a chain of load -> store pairs)
 __device__ __forceinline__ void wave_copy(u8* dst, const u8* src, int len, int lane)
 {
-    for (int i = 8 * lane; i < len; i += 512) {
-        if (i + 8 <= len) st64u(dst + i, ld64u(src + i));
-        else for (int k = i; k < len; k++) dst[k] = src[k];
-    }
+    const int bulk = len & ~7;
+    for (int i = 8 * lane; i < bulk; i += 512) st64u(dst + i, ld64u(src + i));
+    if (lane < len - bulk) dst[bulk + lane] = src[bulk + lane];
 }
 
 // LZCodec.hpp:192-210 (the reference's 3-byte form also stores a zero byte that the next write covers)
@@ -91,6 +118,19 @@ __device__ __forceinline__ int lz_put_len(u8* p, int len, int lane)
 
 struct LzScratch { int* tables; u8* side; size_t secStride; };
 
+__device__ __forceinline__ u64 readlane64(u64 v, int l)
+{
+    return ((u64)(u32)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (u32)__builtin_amdgcn_readlane((int)v, l);
+}
+
+// The positions the reference visits while it finds nothing (a literal run) do not depend on one another except
+// through the hash table, so up to 64 of them are evaluated at once: lane i takes the i-th position the serial loop
+// would visit, looks up its bucket, and tests the three candidates (bucket, two repeat distances) for the 4-byte
+// equality that precedes every findMatch.  A lane whose bucket was filled by an earlier lane of the same batch
+// takes that lane's position instead (found exactly; a 64 Kbit LDS filter says when the search is needed at all).
+// Lanes before the first one with an equality are misses for sure: their buckets are written and the serial state
+// (position, skip counter) jumps over them.  The first lane with an equality is then handled by the serial code
+// below, with the candidates already known for it and for the next two positions.
 template <int HASH_LOG, bool EXTRA>
 __global__ __launch_bounds__(64) void k_lz_forward(XfStage st, LzScratch ws)
 {
@@ -105,6 +145,9 @@ __global__ __launch_bounds__(64) void k_lz_forward(XfStage st, LzScratch ws)
     u8* tk = ws.side + (size_t)b * 3 * ws.secStride;
     u8* mb = tk + ws.secStride;
     u8* ml = mb + ws.secStride;
+    __shared__ u32 seen[2048];
+    for (int i = lane; i < 2048; i += 64) seen[i] = 0;
+    __syncthreads();
     if (st.cap[b] >= (u32)lz_max_encoded(n) && n >= LZ_MINBLOCK) {
         const int srcEnd = n - 16 - 2;
         const int maxDist = (srcEnd < 4 * LZ_MAXD1) ? LZ_MAXD1 : LZ_MAXD2;
@@ -112,19 +155,69 @@ __global__ __launch_bounds__(64) void k_lz_forward(XfStage st, LzScratch ws)
         int rep0 = n, rep1 = n, recent = 0, skip = 0;
         bool reject = false;
         while (pos < srcEnd) {
-            const u64 w0 = sgpr64(ld64u(src + pos));
-            const u32 h0 = lz_hash<HASH_LOG>(w0);
-            const int cand = sgpr(tab_get(table, h0));
-            if (lane == 0) tab_put(table, h0, pos);
+            // ---- the next (up to 64) positions of a literal run, all at once
+            const int stride = 1 + (skip >> 6);
+            const int cnt = 64 - (skip & 63);                 // visits until the stride of the reference changes
+            const int bp = pos + lane * stride;
+            const bool act = (lane < cnt) && (bp < srcEnd);
+            const u64 bw = act ? ld64u(src + bp) : 0ull;
+            const u32 bh = lz_hash<HASH_LOG>(bw);
+            int cd = act ? tab_get(table, bh) : 0;
+            const bool dups = lz_maybe_dups(seen, bh, act);
+            if (dups) {
+#pragma unroll 9
+                for (int j = 0; j < 63; j++) {
+                    const u32 hj = (u32)__builtin_amdgcn_readlane((int)bh, j);
+                    const int aj = __builtin_amdgcn_readlane(act ? 1 : 0, j);
+                    if (aj && lane > j && hj == bh) cd = pos + j * stride;
+                }
+            }
+            bool hit = false;
+            u32 cw = 0, xw = 0, yw = 0;
+            if (act) {
+                const int blo = (bp - maxDist > 0) ? bp - maxDist : 0;
+                const int rx = bp + 1 - rep0, ry = bp + 1 - rep1;
+                cw = ld32u(src + (cd > blo ? cd : 0));
+                xw = ld32u(src + (rx > blo ? rx : 0));
+                yw = ld32u(src + (ry > blo ? ry : 0));
+                const u32 n4 = (u32)(bw >> 8);
+                hit = (cd > blo && cw == (u32)bw) || (rx > blo && xw == n4) || (ry > blo && yw == n4);
+            }
+            const u64 hitMask = __ballot(hit);
+            const u64 endMask = hitMask | __ballot(!act);
+            const int f = endMask ? __ffsll((long long)endMask) - 1 : 64;       // lanes below f found nothing
+            if (!dups) { if (lane < f) tab_put(table, bh, bp); }
+            else {
+                bool lose = false;
+#pragma unroll 9
+                for (int j = 1; j < 64; j++) {
+                    const u32 hj = (u32)__builtin_amdgcn_readlane((int)bh, j);
+                    if (j < f && j > lane && hj == bh) lose = true;
+                }
+                if (lane < f && !lose) tab_put(table, bh, bp);
+            }
+            if (f > 0) { skip += f; recent = 0; pos += f * stride; }
+            if (f == 64 || !((hitMask >> f) & 1)) continue;
+
+            // ---- the serial step of the reference at `pos`
+            const u64 w0 = readlane64(bw, f);
+            const int cand = __builtin_amdgcn_readlane(cd, f);
+            const bool near1 = (stride == 1) && (f + 1 < 64) && ((__ballot(act) >> ((f + 1) & 63)) & 1);
+            const bool near2 = (stride == 1) && (f + 2 < 64) && ((__ballot(act) >> ((f + 2) & 63)) & 1);
+            const int bc1 = __builtin_amdgcn_readlane(cd, (f + 1) & 63);
+            const int bc2 = __builtin_amdgcn_readlane(cd, (f + 2) & 63);
+            const u64 bw1 = readlane64(bw, (f + 1) & 63), bw2 = readlane64(bw, (f + 2) & 63);
+            if (lane == 0) tab_put(table, lz_hash<HASH_LOG>(w0), pos);
             const int nxt = pos + 1;
             const int lo = (pos - maxDist > 0) ? pos - maxDist : 0;
             const u32 nx4 = (u32)(w0 >> 8);
             const int refA = nxt - (recent ? rep1 : rep0);
             const int refB = nxt - (recent ? rep0 : rep1);
-            // the three candidate words are fetched together (clamped addresses; validity decided afterwards)
-            const u32 a4 = (u32)sgpr((int)ld32u(src + (refA > lo ? refA : 0)));
-            const u32 b4 = (u32)sgpr((int)ld32u(src + (refB > lo ? refB : 0)));
-            const u32 c4 = (u32)sgpr((int)ld32u(src + (cand > lo ? cand : 0)));
+            // the candidate words were fetched by the batch (same clamped addresses)
+            const u32 x4 = (u32)__builtin_amdgcn_readlane((int)xw, f), y4 = (u32)__builtin_amdgcn_readlane((int)yw, f);
+            const u32 a4 = recent ? y4 : x4;
+            const u32 b4 = recent ? x4 : y4;
+            const u32 c4 = (u32)__builtin_amdgcn_readlane((int)cw, f);
             int best = 0, ref = refA;
             if (refA > lo && a4 == nx4) best = lz_match(src, nxt, refA, min(srcEnd - nxt, LZ_MAXMATCH), lane);
             else {
@@ -138,13 +231,13 @@ __global__ __launch_bounds__(64) void k_lz_forward(XfStage st, LzScratch ws)
                 if (pos - ref != rep0 && pos - ref != rep1) {
                     // new distance: is the match one (LZX: two) position(s) further at least as long?
                     const int p1 = nxt, p2 = nxt + 1;
-                    const u32 h1 = lz_hash<HASH_LOG>(sgpr64(ld64u(src + p1)));
-                    const int c1 = sgpr(tab_get(table, h1));
+                    const u32 h1 = lz_hash<HASH_LOG>(near1 ? bw1 : sgpr64(ld64u(src + p1)));
+                    const int c1 = near1 ? bc1 : sgpr(tab_get(table, h1));
                     if (lane == 0) tab_put(table, h1, p1);
                     int c2 = 0;
                     if (EXTRA) {
-                        const u32 h2 = lz_hash<HASH_LOG>(sgpr64(ld64u(src + p2)));
-                        c2 = sgpr(tab_get(table, h2));     // p1 is already in the table, as in the serial order
+                        const u32 h2 = lz_hash<HASH_LOG>(near2 ? bw2 : sgpr64(ld64u(src + p2)));
+                        c2 = near2 ? bc2 : sgpr(tab_get(table, h2));      // p1 is in the table, as in the serial order
                         if (lane == 0) tab_put(table, h2, p2);
                     }
                     if (c1 > lo + 1 && sgpr((int)ld32u(src + p1 + best - 3)) == sgpr((int)ld32u(src + c1 + best - 3))) {
@@ -211,7 +304,8 @@ __global__ __launch_bounds__(64) void k_lz_forward(XfStage st, LzScratch ws)
             anchor = pos + best;
             for (int p0 = pos + 1; p0 < anchor; p0 += 64) {
                 const int p = p0 + lane;
-                if (p < anchor) tab_put(table, lz_hash<HASH_LOG>(ld64u(src + p)), p);
+                const bool in = p < anchor;
+                tab_put_wave(table, seen, lz_hash<HASH_LOG>(in ? ld64u(src + p) : 0ull), p, in, lane);
             }
             pos = anchor;
         }
@@ -237,15 +331,40 @@ __global__ __launch_bounds__(64) void k_lz_forward(XfStage st, LzScratch ws)
     if (lane == 0) { st.ok[b] = (u8)ok; st.newLen[b] = (u32)outLen; }
 }
 
-// LZCodec.hpp:212-225; bytes past the block read as zero (the reference relies on two bytes of padding)
-__device__ __forceinline__ u32 lz_get_len(const u8* s, int& pos, int limit)
+// A 256-byte window over one of the four byte sequences the decoder walks (tokens, distances, length extensions,
+// literal-run extensions), held 4 bytes per lane: the token chain reads it with readlane, so no load sits on it.
+// Bytes past the block read as zero (the reference relies on two bytes of padding, LZCodec.cpp:486-490).
+struct LzByteWin {
+    u32 reg;
+    int base;
+    __device__ __forceinline__ void refill(const u8* s, int from, int limit, int lane)
+    {
+        base = from;
+        const int o = from + 4 * lane;
+        if (o + 4 <= limit) reg = ld32u(s + o);
+        else {
+            u32 v = 0;
+            for (int k = 0; k < 4; k++) if (o + k < limit) v |= (u32)s[o + k] << (8 * k);
+            reg = v;
+        }
+    }
+    __device__ __forceinline__ u32 at(const u8* s, int x, int limit, int lane)
+    {
+        if (x < base || x >= base + 256) refill(s, x, limit, lane);
+        const int o = x - base;
+        const u32 wv = (u32)__builtin_amdgcn_readlane((int)reg, sgpr(o >> 2));
+        return (wv >> (8 * (o & 3))) & 0xFFu;
+    }
+};
+
+// LZCodec.hpp:212-225
+__device__ __forceinline__ u32 lz_get_len(LzByteWin& w, const u8* s, int& pos, int limit, int lane)
 {
-    u32 v[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = (pos + k < limit) ? (u32)s[pos + k] : 0u;
-    const u32 b0 = (u32)sgpr((int)v[0]), b1 = (u32)sgpr((int)v[1]), b2 = (u32)sgpr((int)v[2]), b3 = (u32)sgpr((int)v[3]);
+    const u32 b0 = w.at(s, pos, limit, lane);
     if (b0 < 254) { pos += 1; return b0; }
+    const u32 b1 = w.at(s, pos + 1, limit, lane), b2 = w.at(s, pos + 2, limit, lane);
     if (b0 == 254) { pos += 3; return 254 + ((b1 << 8) | b2); }
+    const u32 b3 = w.at(s, pos + 3, limit, lane);
     pos += 4;
     return 255 + ((b1 << 16) | (b2 << 8) | b3);
 }
@@ -271,28 +390,28 @@ __global__ __launch_bounds__(64) void k_lz_inverse(XfStage st)
         const int mm = ((flags >> 1) & 7) + 2;
         int s = 13, rep0 = n, rep1 = n;
         int settled = 0;                         // output bytes below this index are known to have left the wave
+        LzByteWin wt, wm, wl, ws;
+        wt.refill(src, t, n, lane); wm.refill(src, m, n, lane); wl.refill(src, l, n, lane); ws.refill(src, s, n, lane);
         ok = 1;
         for (;;) {
-            const int token = (t < n) ? sgpr((int)src[t]) : 0;
+            const int token = (int)wt.at(src, t, n, lane);
             t++;
             int mlen, dist;
             if ((token & 0x18) == 0) {
                 mlen = token & 3;
-                mlen = (mlen == 3) ? 3 + mm + (int)lz_get_len(src, l, n) : mlen + mm;
+                mlen = (mlen == 3) ? 3 + mm + (int)lz_get_len(wl, src, l, n, lane) : mlen + mm;
                 dist = (token & 4) ? rep1 : rep0;
             } else {
                 mlen = token & 7;
-                mlen = (mlen == 7) ? 7 + mm + (int)lz_get_len(src, l, n) : mlen + mm;
-                const int nb = (token >> 3) & 3;
-                u32 v[3];
-#pragma unroll
-                for (int k = 0; k < 3; k++) v[k] = (m + k < n) ? (u32)src[m + k] : 0u;
-                const int d0 = sgpr((int)v[0]), d1 = sgpr((int)v[1]), d2 = sgpr((int)v[2]);
-                dist = (nb == 1) ? d0 : (nb == 2) ? ((d0 << 8) | d1) : ((d0 << 16) | (d1 << 8) | d2);
+                mlen = (mlen == 7) ? 7 + mm + (int)lz_get_len(wl, src, l, n, lane) : mlen + mm;
+                const int nb = (token >> 3) & 3;          // 1, 2 or 3 distance bytes, most significant first
+                dist = (int)wm.at(src, m, n, lane);
+                if (nb >= 2) dist = (dist << 8) | (int)wm.at(src, m + 1, n, lane);
+                if (nb == 3) dist = (dist << 8) | (int)wm.at(src, m + 2, n, lane);
                 m += nb;
             }
             if (token >= 32) {
-                const u32 lit = (token >= 0xE0) ? 7u + lz_get_len(src, s, n) : (u32)(token >> 5);
+                const u32 lit = (token >= 0xE0) ? 7u + lz_get_len(ws, src, s, n, lane) : (u32)(token >> 5);
                 if (lit > (u32)(cap - d) || lit > (u32)(litEnd - s)) { ok = 0; break; }
                 wave_copy(dst + d, src + s, (int)lit, lane);
                 s += (int)lit; d += (int)lit;
@@ -301,12 +420,12 @@ __global__ __launch_bounds__(64) void k_lz_inverse(XfStage st)
             rep1 = rep0; rep0 = dist;
             const int end = d + mlen;
             const int ref = d - dist;
-            if (ref < 0 || dist > maxDist || end > cap || mlen < 0) { ok = 0; break; }
+            if (ref < 0 || dist > maxDist || end > cap) { ok = 0; break; }
             // bytes this match reads may still be in flight from an earlier copy of this wave
-            if (ref + (mlen < dist ? mlen : dist) > settled) { __threadfence_block(); settled = d; }
+            if (ref + (mlen < dist ? mlen : dist) > settled) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); settled = d; }
             if (dist >= mlen) wave_copy(dst + d, dst + ref, mlen, lane);
             else {
-                const u32 ud = (u32)dist;
+                const u32 ud = dist ? (u32)dist : 1u;          // distance 0 only occurs in corrupt input
                 for (int i = lane; i < mlen; i += 64) dst[d + i] = dst[ref + (int)((u32)i % ud)];
             }
             d = end;
