@@ -284,7 +284,8 @@ def test_corrupted_streams_fail_cleanly(hip, oracle):
     rng = np.random.default_rng(11)
     d = vectors.make(("mixed", 200000, 3))
     cases = [("NONE", "ANS0", 65536), ("NONE", "ANS1", 65536), ("NONE", "HUFFMAN", 65536), ("NONE", "FPAQ", 16384),
-             ("BWT+MTFT+ZRLT", "ANS0", 65536), ("BWT+SRT+ZRLT", "HUFFMAN", 65536), ("RLT+ZRLT", "ANS0", 65536)]
+             ("BWT+MTFT+ZRLT", "ANS0", 65536), ("BWT+SRT+ZRLT", "HUFFMAN", 65536), ("RLT+ZRLT", "ANS0", 65536),
+             ("LZX", "NONE", 65536), ("LZ", "ANS0", 65536)]
     errors = 0
     for t, e, bs in cases:
         rc, ref = oracle.compress(d, t, e, bs, headerless=1)

@@ -13,7 +13,8 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 7)
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 CASES = [("NONE", "ANS0", 65536), ("NONE", "ANS1", 65536), ("NONE", "HUFFMAN", 65536), ("NONE", "FPAQ", 16384),
          ("BWT+MTFT+ZRLT", "ANS0", 65536), ("BWT+SRT+ZRLT", "HUFFMAN", 65536), ("RLT+ZRLT", "ANS0", 65536), ("SRT", "NONE", 65536),
-         ("BWT", "NONE", 65536), ("MTFT", "NONE", 65536), ("ZRLT", "NONE", 65536), ("RLT", "NONE", 65536)]
+         ("BWT", "NONE", 65536), ("MTFT", "NONE", 65536), ("ZRLT", "NONE", 65536), ("RLT", "NONE", 65536),
+         ("LZX", "NONE", 65536), ("LZ", "ANS0", 65536), ("LZX", "ANS1", 262144)]
 d = vectors.make(("mixed", 200000, 3))
 stats = {"ok_same": 0, "ok_diff": 0, "error": 0}
 t0 = time.time()
