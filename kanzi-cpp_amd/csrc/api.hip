@@ -316,7 +316,6 @@ static size_t stage_scratch_u32(int t, int nBlocks, u32 maxLen, bool forward = t
     switch (t) {
     case KNZ_T_ZRLT: return zrlt_scratch_u32(nBlocks, maxLen);
     case KNZ_T_MTFT: return mtft_scratch_u32(nBlocks, maxLen);
-    case KNZ_T_LZ: case KNZ_T_LZX: return forward ? lz_scratch_u32(t, nBlocks, maxLen) : 0;    // hash tables + side sections
     default: return 0;
     }
 }
@@ -328,7 +327,13 @@ static int run_forward_stage(Ctx* c, hipStream_t s, int t, const XfStage& st)
     case KNZ_T_MTFT: launch_mtft_forward(s, st); break;
     case KNZ_T_SRT: launch_srt_forward(s, st); break;
     case KNZ_T_RLT: launch_rlt_forward(s, st); break;
-    case KNZ_T_LZ: case KNZ_T_LZX: launch_lz_forward(s, st, t); break;
+    case KNZ_T_LZ: case KNZ_T_LZX: {
+        const size_t bytes = lz_forward_scratch_bytes(t, st.nBlocks, st.maxLen);
+        void* sc;
+        if (int r = ws_get(c, "lzScratch", bytes, &sc)) return r;
+        if (launch_lz_forward(s, st, t, sc, bytes) != 0) return fail(c, -1, "LZ forward failed: %s", hipGetErrorString(hipGetLastError()));
+        break;
+    }
     case KNZ_T_BWT: {
         const size_t bytes = bwt_forward_scratch_bytes(st.nBlocks, st.maxLen, (size_t)st.nBlocks * st.maxLen);
         void* sc;

@@ -17,6 +17,9 @@
 // overlapping match (distance < length) is a modulo gather from the bytes already written.
 #include "common.hpp"
 #include "stages.hpp"
+#include <cstring>
+#include <algorithm>
+#include <rocprim/rocprim.hpp>
 
 namespace knz {
 
@@ -72,9 +75,8 @@ __device__ __forceinline__ void tab_put_wave(int* t, u32* seen, u32 h, int p, bo
 
 // LZCodec.hpp:227-246 with the whole wave: compares whole 8-byte words only (so the result can stop up to 7 bytes
 // short of `limit`), lane l looks at word n/8 + l
-__device__ int lz_match(const u8* s, int a, int b, int limit, int lane)
+__device__ int lz_match(const u8* s, int a, int b, int limit, int lane, int n = 0)
 {
-    int n = 0;
     for (;;) {
         const int o = n + 8 * lane;
         const bool valid = o + 8 <= limit;
@@ -116,23 +118,89 @@ __device__ __forceinline__ int lz_put_len(u8* p, int len, int lane)
     return 4;
 }
 
-struct LzScratch { int* tables; u8* side; size_t secStride; };
+// ------------------------------------------------------------------------------------------------
+// Encoder.  What sits in bucket hash(q) when the reference looks at position q is, with one exception, simply the
+// previous position with the same hash: every position below q has been stored by then (visited positions by the
+// step that visited them, positions under a match by the fill behind it).  The exception are the positions the
+// reference jumps over once a literal run has seen 64 misses (its stride then grows); they are only stored if a
+// later match extends back over them.  So a first phase computes for ALL positions of ALL blocks in parallel
+//   prev[q]  = previous position with the same hash (stable radix sort of (block, hash) keys, neighbours compared),
+//   info[q]  = findMatch(q, prev[q]) up to LZ_LCAP bytes, plus "stopped at a difference" (exact) in bit 15,
+// and the serial walk (one wave per block) uses prev[q] as the bucket content whenever prev[q] lies above the highest
+// position ever jumped over (`maxGap`), or is 0; only otherwise it reads the real table, which is still kept exactly
+// as the reference leaves it (stores only, off the dependent chain).  Checked on the CPU against the reference's
+// own table at every lookup (zero mispredictions; 0.3 - 17 % of the lookups take the table path).
+// ------------------------------------------------------------------------------------------------
+constexpr int LZ_LCAP = 248;          // longest candidate length phase 1 measures (multiple of 8)
+constexpr int LZW = 1024;             // positions per LDS window of the walk
+
+struct LzWs {
+    int* tables; u8* side; size_t secStride;
+    u32* keysA; u32* keysB; u32* valsA; u32* valsB; u32* prev; u16* info;
+    u32 S;                            // positions per block in the flat arrays
+};
+
+template <int HL>
+__global__ __launch_bounds__(256) void k_lz_keys(XfStage st, u32 S, int nBlocks, u32* __restrict__ keys, u32* __restrict__ vals)
+{
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= (size_t)nBlocks * S) return;
+    const int b = (int)(g / S);
+    const u32 q = (u32)(g - (size_t)b * S);
+    const int n = (int)st.len[b];
+    const bool live = n >= LZ_MINBLOCK && st.cap[b] >= (u32)lz_max_encoded(n) && (int)q < n - 18;
+    keys[g] = live ? (((u32)b << HL) | lz_hash<HL>(ld64u(st.src[b] + q))) : ((u32)nBlocks << HL);
+    vals[g] = (u32)g;
+}
+
+template <int HL>
+__global__ __launch_bounds__(256) void k_lz_prev(XfStage st, u32 S, int nBlocks, size_t total, const u32* __restrict__ keysS,
+                                                 const u32* __restrict__ valsS, u32* __restrict__ prev, u16* __restrict__ info)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const u32 key = keysS[i];
+    const int b = (int)(key >> HL);
+    if (b >= nBlocks) return;
+    const u32 g = valsS[i];
+    const u32 base = (u32)b * S;
+    const u32 q = g - base;
+    u32 pv = 0;
+    if (i > 0 && keysS[i - 1] == key) pv = valsS[i - 1] - base;
+    prev[g] = pv;
+    u32 inf = 0;
+    if (pv) {
+        const u8* __restrict__ src = st.src[b];
+        const int srcEnd = (int)st.len[b] - 18;
+        const int limit = min(srcEnd - (int)q, LZ_MAXMATCH);
+        int l = 0;
+        while (l + 8 <= limit && l < LZ_LCAP) {
+            const u64 x = ld64u(src + q + l) ^ ld64u(src + pv + l);
+            if (x) { l += (int)(__ffsll((long long)x) - 1) >> 3; inf = 0x8000u; break; }
+            l += 8;
+        }
+        inf |= (u32)l;
+    }
+    info[g] = (u16)inf;
+}
 
 __device__ __forceinline__ u64 readlane64(u64 v, int l)
 {
     return ((u64)(u32)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (u32)__builtin_amdgcn_readlane((int)v, l);
 }
 
-// The positions the reference visits while it finds nothing (a literal run) do not depend on one another except
-// through the hash table, so up to 64 of them are evaluated at once: lane i takes the i-th position the serial loop
-// would visit, looks up its bucket, and tests the three candidates (bucket, two repeat distances) for the 4-byte
-// equality that precedes every findMatch.  A lane whose bucket was filled by an earlier lane of the same batch
-// takes that lane's position instead (found exactly; a 64 Kbit LDS filter says when the search is needed at all).
-// Lanes before the first one with an equality are misses for sure: their buckets are written and the serial state
-// (position, skip counter) jumps over them.  The first lane with an equality is then handled by the serial code
-// below, with the candidates already known for it and for the next two positions.
+// The walk.  Positions of a literal run do not depend on one another except through the table, so the next <= 64
+// positions the reference would visit are tested at once (lane i = i-th visit): bucket candidate (from prev / info,
+// or the table) and the two repeat distances (one 8-byte gather each: the byte before the candidate and the four
+// bytes compared).  Lanes before the first one with a possible match are misses for sure: their buckets are
+// stored and the serial state jumps over them.  The first lane with a possible match goes through the reference's
+// step with everything it needs already in registers; its look-ahead candidates come from the same window.
+// While the reference's stride is 1 the per-position data comes from an LDS window over phase 1's arrays; with a
+// larger stride (an incompressible stretch) the batch reads source and table directly, and a lane whose bucket was
+// last written by an earlier lane of the batch takes that lane's position (exact search, run when a 64 Kbit LDS
+// filter over the hashes reports a possible duplicate).
 template <int HASH_LOG, bool EXTRA>
-__global__ __launch_bounds__(64) void k_lz_forward(XfStage st, LzScratch ws)
+__global__ __launch_bounds__(64) void k_lz_walk(XfStage st, LzWs ws)
 {
     const int b = blockIdx.x;
     const int lane = lane_id();
@@ -145,7 +213,16 @@ __global__ __launch_bounds__(64) void k_lz_forward(XfStage st, LzScratch ws)
     u8* tk = ws.side + (size_t)b * 3 * ws.secStride;
     u8* mb = tk + ws.secStride;
     u8* ml = mb + ws.secStride;
+    const size_t gbase = (size_t)b * ws.S;
+    const u32* __restrict__ gPrev = ws.prev + gbase;
+    const u32* __restrict__ gKeys = ws.keysA + gbase;
+    const u16* __restrict__ gInfo = ws.info + gbase;
+    constexpr u32 HMASK = (1u << HASH_LOG) - 1;
     __shared__ u32 seen[2048];
+    __shared__ u32 wPrev[LZW];
+    __shared__ u32 wHash[LZW];
+    __shared__ u16 wInfo[LZW];
+    __shared__ u32 wSrc[LZW / 4 + 4];
     for (int i = lane; i < 2048; i += 64) seen[i] = 0;
     __syncthreads();
     if (st.cap[b] >= (u32)lz_max_encoded(n) && n >= LZ_MINBLOCK) {
@@ -153,18 +230,69 @@ __global__ __launch_bounds__(64) void k_lz_forward(XfStage st, LzScratch ws)
         const int maxDist = (srcEnd < 4 * LZ_MAXD1) ? LZ_MAXD1 : LZ_MAXD2;
         int pos = 0, d = 13, anchor = 0, nm = 0, nl = 0, nt = 0;
         int rep0 = n, rep1 = n, recent = 0, skip = 0;
+        int maxGap = -1;
+        int wbase = -(1 << 30);
         bool reject = false;
+        auto refill = [&](int from) {
+            wbase = from;
+            __syncthreads();
+#pragma unroll 4
+            for (int k = 0; k < LZW / 64; k++) {
+                const int idx = lane + 64 * k;
+                const u32 g = (u32)(from + idx);
+                const bool in = g < ws.S;
+                wPrev[idx] = in ? gPrev[g] : 0u;
+                wHash[idx] = in ? (gKeys[g] & HMASK) : 0u;
+                wInfo[idx] = in ? gInfo[g] : (u16)0;
+            }
+            for (int k = lane; k < LZW / 4 + 4; k += 64) {
+                const int o = from + 4 * k;
+                u32 v = 0;
+                if (o + 4 <= n) v = ld32u(src + o);
+                else for (int j = 0; j < 4; j++) if (o + j < n) v |= (u32)src[o + j] << (8 * j);
+                wSrc[k] = v;
+            }
+            __syncthreads();
+        };
+        auto win4 = [&](int o) -> u32 {                       // 4 source bytes at window offset o
+            const u32 a = wSrc[o >> 2], c = wSrc[(o >> 2) + 1];
+            const int sh = 8 * (o & 3);
+            return sh ? ((a >> sh) | (c << (32 - sh))) : a;
+        };
+        auto hash_at = [&](int p) -> u32 {                    // uniform p
+            const int o = p - wbase;
+            return (o >= 0 && o < LZW) ? (u32)sgpr((int)wHash[o]) : ((u32)sgpr((int)gKeys[p]) & HMASK);
+        };
         while (pos < srcEnd) {
             // ---- the next (up to 64) positions of a literal run, all at once
             const int stride = 1 + (skip >> 6);
+            const bool fast = stride == 1;
             const int cnt = 64 - (skip & 63);                 // visits until the stride of the reference changes
             const int bp = pos + lane * stride;
             const bool act = (lane < cnt) && (bp < srcEnd);
-            const u64 bw = act ? ld64u(src + bp) : 0ull;
-            const u32 bh = lz_hash<HASH_LOG>(bw);
-            int cd = act ? tab_get(table, bh) : 0;
+            u32 bh = 0, w4 = 0, n4 = 0, inf = 0;
+            int cd = 0;
+            bool fromPrev = false;
+            if (fast) {
+                if (pos < wbase || pos + 66 > wbase + LZW) refill(pos);
+                const int o = bp - wbase;                     // < LZW for every lane
+                const u32 pv = wPrev[o];
+                bh = wHash[o];
+                inf = wInfo[o];
+                w4 = win4(o);
+                n4 = win4(o + 1);
+                fromPrev = (pv == 0) || ((int)pv > maxGap);
+                cd = (int)pv;
+                if (act && !fromPrev) cd = tab_get(table, bh);
+            } else {
+                const u64 bw = act ? ld64u(src + bp) : 0ull;
+                bh = lz_hash<HASH_LOG>(bw);
+                w4 = (u32)bw;
+                n4 = (u32)(bw >> 8);
+                cd = act ? tab_get(table, bh) : 0;
+            }
             const bool dups = lz_maybe_dups(seen, bh, act);
-            if (dups) {
+            if (!fast && dups) {
 #pragma unroll 9
                 for (int j = 0; j < 63; j++) {
                     const u32 hj = (u32)__builtin_amdgcn_readlane((int)bh, j);
@@ -173,15 +301,17 @@ __global__ __launch_bounds__(64) void k_lz_forward(XfStage st, LzScratch ws)
                 }
             }
             bool hit = false;
-            u32 cw = 0, xw = 0, yw = 0;
+            u64 x8 = 0, y8 = 0;
+            u32 cw = 0;
             if (act) {
                 const int blo = (bp - maxDist > 0) ? bp - maxDist : 0;
                 const int rx = bp + 1 - rep0, ry = bp + 1 - rep1;
-                cw = ld32u(src + (cd > blo ? cd : 0));
-                xw = ld32u(src + (rx > blo ? rx : 0));
-                yw = ld32u(src + (ry > blo ? ry : 0));
-                const u32 n4 = (u32)(bw >> 8);
-                hit = (cd > blo && cw == (u32)bw) || (rx > blo && xw == n4) || (ry > blo && yw == n4);
+                x8 = ld64u(src + (rx > blo ? rx - 1 : 0));    // byte 0: the byte before the candidate, bytes 1-4: compared
+                y8 = ld64u(src + (ry > blo ? ry - 1 : 0));
+                bool hh;
+                if (fromPrev) hh = (inf & 0x7FFFu) >= 4;
+                else { cw = ld32u(src + (cd > blo ? cd : 0)); hh = cw == w4; }
+                hit = (cd > blo && hh) || (rx > blo && (u32)(x8 >> 8) == n4) || (ry > blo && (u32)(y8 >> 8) == n4);
             }
             const u64 hitMask = __ballot(hit);
             const u64 endMask = hitMask | __ballot(!act);
@@ -196,59 +326,79 @@ __global__ __launch_bounds__(64) void k_lz_forward(XfStage st, LzScratch ws)
                 }
                 if (lane < f && !lose) tab_put(table, bh, bp);
             }
-            if (f > 0) { skip += f; recent = 0; pos += f * stride; }
+            if (f > 0) {
+                skip += f; recent = 0; pos += f * stride;
+                if (stride > 1) maxGap = pos - 1;
+            }
             if (f == 64 || !((hitMask >> f) & 1)) continue;
 
             // ---- the serial step of the reference at `pos`
-            const u64 w0 = readlane64(bw, f);
+            const u32 w4f = (u32)__builtin_amdgcn_readlane((int)w4, f);
+            const u32 nx4 = (u32)__builtin_amdgcn_readlane((int)n4, f);
+            const u32 h0 = (u32)__builtin_amdgcn_readlane((int)bh, f);
             const int cand = __builtin_amdgcn_readlane(cd, f);
-            const bool near1 = (stride == 1) && (f + 1 < 64) && ((__ballot(act) >> ((f + 1) & 63)) & 1);
-            const bool near2 = (stride == 1) && (f + 2 < 64) && ((__ballot(act) >> ((f + 2) & 63)) & 1);
-            const int bc1 = __builtin_amdgcn_readlane(cd, (f + 1) & 63);
-            const int bc2 = __builtin_amdgcn_readlane(cd, (f + 2) & 63);
-            const u64 bw1 = readlane64(bw, (f + 1) & 63), bw2 = readlane64(bw, (f + 2) & 63);
-            if (lane == 0) tab_put(table, lz_hash<HASH_LOG>(w0), pos);
+            const bool candPrev = __builtin_amdgcn_readlane(fromPrev ? 1 : 0, f) != 0;
+            const u32 inf0 = (u32)__builtin_amdgcn_readlane((int)inf, f);
+            const u32 c4 = (u32)__builtin_amdgcn_readlane((int)cw, f);
+            const u64 x8f = readlane64(x8, f), y8f = readlane64(y8, f);
+            if (lane == 0) tab_put(table, h0, pos);
             const int nxt = pos + 1;
             const int lo = (pos - maxDist > 0) ? pos - maxDist : 0;
-            const u32 nx4 = (u32)(w0 >> 8);
             const int refA = nxt - (recent ? rep1 : rep0);
             const int refB = nxt - (recent ? rep0 : rep1);
-            // the candidate words were fetched by the batch (same clamped addresses)
-            const u32 x4 = (u32)__builtin_amdgcn_readlane((int)xw, f), y4 = (u32)__builtin_amdgcn_readlane((int)yw, f);
-            const u32 a4 = recent ? y4 : x4;
-            const u32 b4 = recent ? x4 : y4;
-            const u32 c4 = (u32)__builtin_amdgcn_readlane((int)cw, f);
+            const u64 A8 = recent ? y8f : x8f, B8 = recent ? x8f : y8f;
             int best = 0, ref = refA;
-            if (refA > lo && a4 == nx4) best = lz_match(src, nxt, refA, min(srcEnd - nxt, LZ_MAXMATCH), lane);
+            u32 beforeRef = (u32)A8 & 0xFF;
+            if (refA > lo && (u32)(A8 >> 8) == nx4) best = lz_match(src, nxt, refA, min(srcEnd - nxt, LZ_MAXMATCH), lane);
             else {
-                ref = refB;
-                if (refB > lo && b4 == nx4) best = lz_match(src, nxt, refB, min(srcEnd - nxt, LZ_MAXMATCH), lane);
+                ref = refB; beforeRef = (u32)B8 & 0xFF;
+                if (refB > lo && (u32)(B8 >> 8) == nx4) best = lz_match(src, nxt, refB, min(srcEnd - nxt, LZ_MAXMATCH), lane);
             }
             if (best < LZ_MM) {
                 ref = cand;
-                if (cand > lo && c4 == (u32)w0) best = lz_match(src, pos, cand, min(srcEnd - pos, LZ_MAXMATCH), lane);
-                if (best < LZ_MM) { pos = nxt + (skip >> 6); skip++; recent = 0; continue; }
+                if (cand > lo) {
+                    const int lim0 = min(srcEnd - pos, LZ_MAXMATCH);
+                    if (candPrev) {
+                        const int l0 = (int)(inf0 & 0x7FFFu);
+                        if (l0 >= 4) best = (!(inf0 >> 15) && l0 == LZ_LCAP && l0 + 8 <= lim0) ? lz_match(src, pos, cand, lim0, lane, LZ_LCAP) : l0;
+                    } else if (c4 == w4f) best = lz_match(src, pos, cand, lim0, lane);
+                }
+                if (best < LZ_MM) {
+                    if (skip >> 6) maxGap = nxt + (skip >> 6) - 1;
+                    pos = nxt + (skip >> 6); skip++; recent = 0;
+                    continue;
+                }
                 if (pos - ref != rep0 && pos - ref != rep1) {
                     // new distance: is the match one (LZX: two) position(s) further at least as long?
-                    const int p1 = nxt, p2 = nxt + 1;
-                    const u32 h1 = lz_hash<HASH_LOG>(near1 ? bw1 : sgpr64(ld64u(src + p1)));
-                    const int c1 = near1 ? bc1 : sgpr(tab_get(table, h1));
-                    if (lane == 0) tab_put(table, h1, p1);
-                    int c2 = 0;
-                    if (EXTRA) {
-                        const u32 h2 = lz_hash<HASH_LOG>(near2 ? bw2 : sgpr64(ld64u(src + p2)));
-                        c2 = near2 ? bc2 : sgpr(tab_get(table, h2));      // p1 is in the table, as in the serial order
-                        if (lane == 0) tab_put(table, h2, p2);
-                    }
-                    if (c1 > lo + 1 && sgpr((int)ld32u(src + p1 + best - 3)) == sgpr((int)ld32u(src + c1 + best - 3))) {
-                        const int b1 = lz_match(src, p1, c1, min(srcEnd - p1, LZ_MAXMATCH), lane);
-                        if (b1 >= best) { ref = c1; best = b1; pos = p1; }
-                    }
-                    if (EXTRA) {
-                        if (c2 > lo + 2 && sgpr((int)ld32u(src + p2 + best - 3)) == sgpr((int)ld32u(src + c2 + best - 3))) {
-                            const int b2 = lz_match(src, p2, c2, min(srcEnd - p2, LZ_MAXMATCH), lane);
-                            if (b2 >= best) { ref = c2; best = b2; pos = p2; }
+                    const int origin = pos;
+                    for (int k = 1; k <= (EXTRA ? 2 : 1); k++) {
+                        const int pk = origin + k;
+                        const int ok_ = pk - wbase;
+                        const bool inWin = fast && ok_ >= 0 && ok_ < LZW;
+                        u32 hk, infk = 0;
+                        int ck;
+                        bool fromk = false;
+                        if (inWin) {
+                            const int pvk = sgpr((int)wPrev[ok_]);
+                            hk = (u32)sgpr((int)wHash[ok_]);
+                            infk = (u32)sgpr((int)wInfo[ok_]);
+                            fromk = (pvk == 0) || (pvk > maxGap);
+                            ck = fromk ? pvk : sgpr(tab_get(table, hk));
+                        } else {
+                            hk = lz_hash<HASH_LOG>(sgpr64(ld64u(src + pk)));
+                            ck = sgpr(tab_get(table, hk));
                         }
+                        if (lane == 0) tab_put(table, hk, pk);
+                        if (ck <= lo + k) continue;
+                        const int limk = min(srcEnd - pk, LZ_MAXMATCH);
+                        const int lk = (int)(infk & 0x7FFFu);
+                        const bool capped = !(infk >> 15) && lk == LZ_LCAP && lk + 8 <= limk;
+                        int bk = -1;
+                        if (fromk && (infk >> 15)) { if (lk >= best + 1) bk = lk; }
+                        else if (fromk && lk >= best + 1) bk = capped ? lz_match(src, pk, ck, limk, lane, LZ_LCAP) : lk;
+                        else if (sgpr((int)ld32u(src + pk + best - 3)) == sgpr((int)ld32u(src + ck + best - 3)))
+                            bk = lz_match(src, pk, ck, limk, lane);
+                        if (bk >= best) { ref = ck; best = bk; pos = pk; }
                     }
                 }
                 // extend backwards, 64 bytes per step
@@ -262,9 +412,10 @@ __global__ __launch_bounds__(64) void k_lz_forward(XfStage st, LzScratch ws)
                 if (best > LZ_MAXMATCH) { ref += best - LZ_MAXMATCH; pos += best - LZ_MAXMATCH; best = LZ_MAXMATCH; }
             } else {
                 // repeat match at pos + 1: take the byte at pos with it when it matches too
-                if (best >= LZ_MAXMATCH || sgpr((int)src[pos]) != sgpr((int)src[ref - 1])) {
+                if (best >= LZ_MAXMATCH || (w4f & 0xFF) != beforeRef) {
                     pos++;
-                    if (lane == 0) tab_put(table, lz_hash<HASH_LOG>(ld64u(src + pos)), pos);
+                    const u32 hp = hash_at(pos);
+                    if (lane == 0) tab_put(table, hp, pos);
                 } else { best++; ref--; }
             }
             skip = 0;
@@ -305,7 +456,10 @@ __global__ __launch_bounds__(64) void k_lz_forward(XfStage st, LzScratch ws)
             for (int p0 = pos + 1; p0 < anchor; p0 += 64) {
                 const int p = p0 + lane;
                 const bool in = p < anchor;
-                tab_put_wave(table, seen, lz_hash<HASH_LOG>(in ? ld64u(src + p) : 0ull), p, in, lane);
+                const int o = p - wbase;
+                u32 hp = 0;
+                if (in) hp = (o >= 0 && o < LZW) ? wHash[o] : (gKeys[p] & HMASK);
+                tab_put_wave(table, seen, hp, p, in, lane);
             }
             pos = anchor;
         }
@@ -435,24 +589,71 @@ __global__ __launch_bounds__(64) void k_lz_inverse(XfStage st)
     if (lane == 0) { st.ok[b] = (u8)(ok ? 1 : 0); st.newLen[b] = (u32)d; }
 }
 
-size_t lz_scratch_u32(int ttype, int nBlocks, u32 maxLen)
+static int lz_group_blocks(int ttype, int nBlocks)
 {
-    const size_t tab = (size_t)nBlocks << (ttype == KNZ_T_LZX ? 19 : 16);
-    const size_t sec = ((size_t)maxLen + 64 + 15) & ~(size_t)15;
-    return tab + (size_t)nBlocks * 3 * sec / 4 + 64;
+    const int hl = (ttype == KNZ_T_LZX) ? 19 : 16;
+    const int most = (1 << (32 - hl)) - 2;            // (block id + 1) << hl has to fit the 32-bit sort key
+    return nBlocks < most ? nBlocks : most;
 }
 
-void launch_lz_forward(hipStream_t s, const XfStage& st, int ttype)
+static size_t lz_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+size_t lz_forward_scratch_bytes(int ttype, int nBlocks, u32 maxLen)
 {
-    const int hashLog = (ttype == KNZ_T_LZX) ? 19 : 16;
-    LzScratch ws;
-    ws.tables = reinterpret_cast<int*>(st.scratchU32);
-    ws.side = reinterpret_cast<u8*>(st.scratchU32 + ((size_t)st.nBlocks << hashLog));
-    ws.secStride = ((size_t)st.maxLen + 64 + 15) & ~(size_t)15;
-    hipMemsetAsync(ws.tables, 0, ((size_t)st.nBlocks << hashLog) * sizeof(int), s);
-    KScope ks_("k_lz_forward");
-    if (ttype == KNZ_T_LZX) hipLaunchKernelGGL((k_lz_forward<19, true>), dim3(st.nBlocks), dim3(64), 0, s, st, ws);
-    else hipLaunchKernelGGL((k_lz_forward<16, false>), dim3(st.nBlocks), dim3(64), 0, s, st, ws);
+    const int hl = (ttype == KNZ_T_LZX) ? 19 : 16;
+    const int G = lz_group_blocks(ttype, nBlocks);
+    const size_t total = (size_t)G * maxLen;
+    const size_t sec = ((size_t)maxLen + 64 + 15) & ~(size_t)15;
+    size_t prim = 0;
+    rocprim::radix_sort_pairs(nullptr, prim, (u32*)nullptr, (u32*)nullptr, (u32*)nullptr, (u32*)nullptr, total, 0u, 32u, (hipStream_t)0);
+    return lz_align(((size_t)G << hl) * 4) + lz_align((size_t)G * 3 * sec) + 5 * lz_align(total * 4) + lz_align(total * 2) + lz_align(prim) + 256;
+}
+
+// Returns 0 or a negative value on a HIP / rocPRIM error.
+int launch_lz_forward(hipStream_t s, const XfStage& stAll, int ttype, void* scratch, size_t scratchBytes)
+{
+    const int hl = (ttype == KNZ_T_LZX) ? 19 : 16;
+    const int G = lz_group_blocks(ttype, stAll.nBlocks);
+    const u32 S = stAll.maxLen;
+    const size_t totalMax = (size_t)G * S;
+    const size_t sec = ((size_t)S + 64 + 15) & ~(size_t)15;
+    u8* p = reinterpret_cast<u8*>(scratch);
+    LzWs ws;
+    ws.tables = reinterpret_cast<int*>(p); p += lz_align(((size_t)G << hl) * 4);
+    ws.side = p; p += lz_align((size_t)G * 3 * sec);
+    ws.secStride = sec;
+    ws.keysA = reinterpret_cast<u32*>(p); p += lz_align(totalMax * 4);
+    ws.keysB = reinterpret_cast<u32*>(p); p += lz_align(totalMax * 4);
+    ws.valsA = reinterpret_cast<u32*>(p); p += lz_align(totalMax * 4);
+    ws.valsB = reinterpret_cast<u32*>(p); p += lz_align(totalMax * 4);
+    ws.prev = reinterpret_cast<u32*>(p); p += lz_align(totalMax * 4);
+    ws.info = reinterpret_cast<u16*>(p); p += lz_align(totalMax * 2);
+    void* prim = p;
+    const size_t primBytes = scratchBytes - (size_t)(p - reinterpret_cast<u8*>(scratch));
+    ws.S = S;
+    for (int g0 = 0; g0 < stAll.nBlocks; g0 += G) {
+        XfStage st = stAll;
+        st.src += g0; st.dst += g0; st.len += g0; st.cap += g0; st.ok += g0; st.newLen += g0;
+        st.nBlocks = (stAll.nBlocks - g0 < G) ? stAll.nBlocks - g0 : G;
+        const size_t total = (size_t)st.nBlocks * S;
+        int bbits = 1;
+        while ((1 << bbits) < st.nBlocks + 1) bbits++;
+        const dim3 grid((unsigned)((total + 255) / 256));
+        if (hipMemsetAsync(ws.tables, 0, ((size_t)st.nBlocks << hl) * sizeof(int), s) != hipSuccess) return -1;
+        size_t pb = primBytes;
+        if (ttype == KNZ_T_LZX) {
+            { KScope ks_("k_lz_keys"); hipLaunchKernelGGL((k_lz_keys<19>), grid, dim3(256), 0, s, st, S, st.nBlocks, ws.keysA, ws.valsA); }
+            { KScope ks_("rocprim_sort_lz"); if (rocprim::radix_sort_pairs(prim, pb, ws.keysA, ws.keysB, ws.valsA, ws.valsB, total, 0u, (unsigned)(19 + bbits), s) != hipSuccess) return -1; }
+            { KScope ks_("k_lz_prev"); hipLaunchKernelGGL((k_lz_prev<19>), grid, dim3(256), 0, s, st, S, st.nBlocks, total, ws.keysB, ws.valsB, ws.prev, ws.info); }
+            { KScope ks_("k_lz_walk"); hipLaunchKernelGGL((k_lz_walk<19, true>), dim3(st.nBlocks), dim3(64), 0, s, st, ws); }
+        } else {
+            { KScope ks_("k_lz_keys"); hipLaunchKernelGGL((k_lz_keys<16>), grid, dim3(256), 0, s, st, S, st.nBlocks, ws.keysA, ws.valsA); }
+            { KScope ks_("rocprim_sort_lz"); if (rocprim::radix_sort_pairs(prim, pb, ws.keysA, ws.keysB, ws.valsA, ws.valsB, total, 0u, (unsigned)(16 + bbits), s) != hipSuccess) return -1; }
+            { KScope ks_("k_lz_prev"); hipLaunchKernelGGL((k_lz_prev<16>), grid, dim3(256), 0, s, st, S, st.nBlocks, total, ws.keysB, ws.valsB, ws.prev, ws.info); }
+            { KScope ks_("k_lz_walk"); hipLaunchKernelGGL((k_lz_walk<16, false>), dim3(st.nBlocks), dim3(64), 0, s, st, ws); }
+        }
+    }
+    return 0;
 }
 
 void launch_lz_inverse(hipStream_t s, const XfStage& st) { KScope ks_("k_lz_inverse"); hipLaunchKernelGGL(k_lz_inverse, dim3(st.nBlocks), dim3(64), 0, s, st); }

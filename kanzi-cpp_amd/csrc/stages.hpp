@@ -83,9 +83,9 @@ void launch_rlt_forward(hipStream_t s, const XfStage& st);
 void launch_rlt_inverse(hipStream_t s, const XfStage& st);
 
 // lz.hip (ttype = KNZ_T_LZ or KNZ_T_LZX)
-void launch_lz_forward(hipStream_t s, const XfStage& st, int ttype);
+int launch_lz_forward(hipStream_t s, const XfStage& st, int ttype, void* scratch, size_t scratchBytes);
 void launch_lz_inverse(hipStream_t s, const XfStage& st);
-size_t lz_scratch_u32(int ttype, int nBlocks, u32 maxLen);
+size_t lz_forward_scratch_bytes(int ttype, int nBlocks, u32 maxLen);
 
 // xxhash.hip
 void launch_xxhash(hipStream_t s, const u8* const* ptr, const u32* lens, int nBlocks, int bits, u64* out);

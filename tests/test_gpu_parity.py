@@ -229,6 +229,26 @@ def test_stream_vs_oracle_ragged(hip, oracle):
                 assert gpu_decompress(hip, ref, t, e, bs, len(d), 0) == d, (spec, t, e)
 
 
+def test_lz_block_groups_and_long_matches(hip, oracle):
+    # the LZ encoder sorts (block, hash) keys in groups of at most 8190 (LZX) blocks: more blocks than one group
+    d = vectors.make(("mixed", 9000 * 1024 + 321, 6))
+    rc, ref = oracle.compress(d, "LZX", "NONE", 1024, headerless=1)
+    out, bits, hb = gpu_compress(hip, d, "LZX", "NONE", 1024, headerless=1)
+    assert rc == 0 and out == ref
+    assert gpu_decompress(hip, ref, "LZX", "NONE", 1024, len(d), 0) == d
+    # matches longer than the candidate lengths measured up front (248) and than MAX_MATCH (65793), overlapping copies
+    rng = np.random.default_rng(8)
+    unit = rng.integers(0, 256, 3000, dtype=np.uint8).tobytes()
+    d = bytes(200000) + unit * 70 + b"ab" * 40000 + unit[:777] * 90 + rng.integers(0, 256, 70000, dtype=np.uint8).tobytes() + unit * 5
+    for t in ("LZ", "LZX"):
+        cap = len(d) + len(d) // 64 + 64
+        ok1, o1 = oracle.forward(t, d, cap)
+        ok2, o2 = hip.transform_forward(t, d, cap)
+        assert ok1 == 1 and ok2 == 1 and o1 == o2, t
+        k, back = hip.transform_inverse(t, o1, len(d) + 64)
+        assert k == 1 and back == d, t
+
+
 def test_full_size_roundtrip_properties(hip):
     # BASELINE config 2 geometry (4 MiB blocks): round trip + determinism on 32 MiB, checked on the device side
     d = vectors.make(("mixed", 32 << 20, 2))
