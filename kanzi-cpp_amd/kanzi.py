@@ -57,13 +57,25 @@ class KanziError(RuntimeError):
         self.code = code
 
 
+def _name(v):
+    """Codec names arrive as str or, as in the reference's shim (src/api/kanzi.py), as bytes."""
+    if isinstance(v, (bytes, bytearray)):
+        return bytes(v)
+    if isinstance(v, str):
+        return v.encode()
+    raise TypeError("codec name must be str or bytes, not %s" % type(v).__name__)
+
+
 class Compressor:
+    """src/api/kanzi.py Compressor: same positional/keyword arguments, `compress(data)`, `close()`, context manager."""
+
     def __init__(self, path, transform="NONE", entropy="NONE", block_size=4 << 20, jobs=1, checksum=0, headerless=False):
         L = lib()
-        self._f = _libc.fopen(path.encode(), b"wb")
+        tname, ename = _name(transform), _name(entropy)
+        self._f = _libc.fopen(os.fsencode(path), b"wb")
         if not self._f:
-            raise OSError("cannot open " + path)
-        self.params = cData(transform.encode(), entropy.encode(), block_size, jobs, checksum, 1 if headerless else 0)
+            raise OSError("cannot open %s" % path)
+        self.params = cData(tname, ename, block_size, jobs, checksum, 1 if headerless else 0)
         self._ctx = C.c_void_p()
         rc = L.initCompressor(C.byref(self.params), self._f, C.byref(self._ctx))
         if rc != 0:
@@ -72,9 +84,15 @@ class Compressor:
             raise KanziError(rc, "initCompressor")
         self.written = 0
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        self.close()
+
     def compress(self, data):
         out = C.c_size_t(0)
-        rc = lib().compress(self._ctx, data, len(data), C.byref(out))
+        rc = lib().compress(self._ctx, bytes(data), len(data), C.byref(out))
         if rc != 0:
             raise KanziError(rc, "compress")
         self.written += out.value
@@ -94,13 +112,22 @@ class Compressor:
 
 
 class Decompressor:
+    """src/api/kanzi.py Decompressor: `Decompressor(path, buffer_size, jobs, headerless, **headerless_params)` with the
+    reference's parameter names (transform, entropy, blockSize, originalSize, checksum, bsVersion; the snake_case
+    spellings are accepted too), `decompress_block(max_output)`, `close()`, context manager."""
+
     def __init__(self, path, buffer_size=4 << 20, jobs=1, headerless=False, transform="NONE", entropy="NONE", block_size=0,
-                 original_size=0, checksum=0, bs_version=6):
+                 original_size=0, checksum=0, bs_version=6, **ref_names):
         L = lib()
-        self._f = _libc.fopen(path.encode(), b"rb")
+        block_size = ref_names.pop("blockSize", block_size)
+        original_size = ref_names.pop("originalSize", original_size)
+        bs_version = ref_names.pop("bsVersion", bs_version)
+        if ref_names:
+            raise TypeError("unexpected arguments: %s" % ", ".join(sorted(ref_names)))
+        self._f = _libc.fopen(os.fsencode(path), b"rb")
         if not self._f:
-            raise OSError("cannot open " + path)
-        self.params = dData(buffer_size, jobs, 1 if headerless else 0, transform.encode(), entropy.encode(), block_size,
+            raise OSError("cannot open %s" % path)
+        self.params = dData(buffer_size, jobs, 1 if headerless else 0, _name(transform), _name(entropy), block_size,
                             original_size, checksum, bs_version)
         self._ctx = C.c_void_p()
         rc = L.initDecompressor(C.byref(self.params), self._f, C.byref(self._ctx))
@@ -109,6 +136,15 @@ class Decompressor:
             self._f = None
             raise KanziError(rc, "initDecompressor")
         self.buffer_size = buffer_size
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        self.close()
+
+    def decompress_block(self, max_output):
+        return self.decompress(max_output)
 
     def decompress(self, n):
         buf = C.create_string_buffer(max(1, n))

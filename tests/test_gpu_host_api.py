@@ -60,6 +60,63 @@ def test_c_api_roundtrip_and_bit_exact(tmp_path, oracle):
         assert bytes(out) == data
 
 
+def test_reference_python_api_cases(tmp_path, oracle):
+    """The cases of the reference's own ctypes test (src/test/test_api.py), written against the same class interface
+    (bytes codec names, context managers, decompress_block, the reference's keyword names), plus what that test does
+    not check: the file on disk is byte-identical to the reference's. One deviation: its headerless case passes
+    bsVersion=1 (harmless there: a 25-byte block is stored raw); decoding older bitstream versions is not built, so
+    the case runs with bsVersion=6."""
+    kz = _kanzi()
+    fill = lambda size: bytes((i * 17 + 3) & 0xFF for i in range(size))
+    lzx = dict(transform=b"LZX", entropy=b"HUFFMAN", block_size=1024, jobs=1, checksum=0, headerless=0)
+    with pytest.raises(Exception):
+        kz.Compressor(str(tmp_path / "bad.knz"), transform=None)                   # test_init_invalid
+    with kz.Compressor(str(tmp_path / "a.knz"), **lzx) as c:                      # test_init_dispose
+        assert c is not None
+    with kz.Compressor(str(tmp_path / "b.knz"), **lzx) as c:                      # test_compress_small
+        assert c.compress(fill(256)) >= 0
+    with kz.Compressor(str(tmp_path / "c.knz"), **lzx) as c:                      # test_compress_too_big
+        with pytest.raises(kz.KanziError):
+            c.compress(fill(4096))
+    with kz.Compressor(str(tmp_path / "d.knz"), **lzx) as c:                      # test_compress_two_blocks
+        assert c.compress(fill(300)) >= 0 and c.compress(fill(500)) >= 0
+    # test_basic_decompression
+    msg = b"Hello Kanzi! Hello Compression!"
+    path = str(tmp_path / "e.knz")
+    with kz.Compressor(path, transform=b"LZ", entropy=b"ANS0", block_size=1 << 16, jobs=1, checksum=32, headerless=0) as c:
+        c.compress(msg)
+    assert open(path, "rb").read() == oracle.compress(msg, "LZ", "ANS0", 1 << 16, checksum=32)[1]
+    with kz.Decompressor(path, buffer_size=1 << 16, jobs=1, headerless=0) as d:
+        assert d.decompress_block(1024) == msg
+    # test_large_multi_block
+    size = 2 * 1024 * 1024
+    data = bytes((i * 7) & 0xFF for i in range(size))
+    path = str(tmp_path / "f.knz")
+    with kz.Compressor(path, transform=b"LZ", entropy=b"FPAQ", block_size=256 * 1024, jobs=1, checksum=64, headerless=0) as c:
+        for off in range(0, size, 256 * 1024):
+            c.compress(data[off:off + 256 * 1024])
+    assert open(path, "rb").read() == oracle.compress(data, "LZ", "FPAQ", 256 * 1024, checksum=64)[1]
+    out = bytearray()
+    with kz.Decompressor(path, buffer_size=256 * 1024, jobs=1, headerless=0) as d:
+        while True:
+            try:
+                block = d.decompress_block(256 * 1024)
+                if not block:
+                    break
+                out.extend(block)
+            except kz.KanziError:
+                break
+    assert bytes(out) == data
+    # test_headerless
+    msg = b"HEADERLESS MODE IS ACTIVE"
+    path = str(tmp_path / "g.knz")
+    with kz.Compressor(path, transform=b"LZ", entropy=b"ANS0", block_size=1 << 15, jobs=1, checksum=0, headerless=1) as c:
+        c.compress(msg)
+    with kz.Decompressor(path, buffer_size=1 << 15, jobs=1, headerless=1, transform=b"LZ", entropy=b"ANS0", blockSize=1 << 15,
+                         originalSize=len(msg), checksum=0, bsVersion=6) as d:
+        assert d.decompress_block(256) == msg
+
+
 def test_c_api_parameter_validation(tmp_path):
     kz = _kanzi()
     with pytest.raises(kz.KanziError) as ei:
