@@ -349,6 +349,12 @@ public:
     std::streamsize gcount() const { return _gcount; }
     void close();
     uint64 getRead() const { return (_consumedBits + 7) >> 3; }
+    // io/CompressedInputStream.hpp:227-229,329-384. The only valid positions are block boundaries. tell() is the bit
+    // position (in the compressed stream) of the first block that has not been decoded yet, hence always a valid
+    // argument for seek(); with the default batching that is up to a batch of blocks ahead of what read() has
+    // delivered, call setBatchBlocks(1) to step block by block. seek() drops everything decoded and not yet read.
+    bool seek(int64 bitPos);
+    int64 tell();
     void setBatchBlocks(int n) { if (n > 0) { _batchBlocks = n; _batchFromEnv = true; } }
 private:
     std::istream& _is;
@@ -362,6 +368,7 @@ private:
     std::vector<byte> _comp;      // compressed bytes fetched and not yet decoded
     uint64 _compBit;              // next unread bit in _comp
     uint64 _consumedBits;
+    int64 _originBit;             // bit position in the underlying stream that _compBit == 0 corresponds to
     std::vector<byte> _plain;     // decoded bytes not yet delivered
     size_t _plainPos;
     std::streamsize _gcount;

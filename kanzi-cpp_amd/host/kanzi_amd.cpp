@@ -789,6 +789,7 @@ CompressedInputStream::CompressedInputStream(std::istream& is, int tasks, const 
     _batchFromEnv = false;
     if (e && atoi(e) > 0) { _batchBlocks = atoi(e); _batchFromEnv = true; }
     _compBit = 0; _consumedBits = 0; _plainPos = 0; _gcount = 0; _srcEof = false;
+    { _is.clear(); const std::streamoff at = std::streamoff(_is.tellg()); _originBit = (at < 0) ? 0 : 8 * int64(at); _is.clear(); }
     _dIn = _dOut = nullptr; _dInCap = _dOutCap = 0;
     deviceContext();
 }
@@ -810,6 +811,7 @@ bool CompressedInputStream::fetch(size_t minBytes)
         const size_t drop = size_t(_compBit >> 3) & ~size_t(15);
         _comp.erase(_comp.begin(), _comp.begin() + drop);
         _compBit -= uint64(drop) * 8;
+        _originBit += int64(drop) * 8;
     }
     size_t want = std::max<size_t>(minBytes - have, size_t(1) << 20);
     const size_t old = _comp.size();
@@ -946,6 +948,32 @@ int CompressedInputStream::get()
     const int c = peek();
     if (c != EOF) { _plainPos++; _gcount = 1; } else _gcount = 0;
     return c;
+}
+
+int64 CompressedInputStream::tell()
+{
+    if (_closed) return -1;
+    if (!_ended && !_headerDone) {            // the first block starts behind the stream header
+        try { readHeader(); } catch (const IOException&) { _headerDone = false; return _originBit + int64(_compBit); }
+    }
+    return _originBit + int64(_compBit);
+}
+
+bool CompressedInputStream::seek(int64 bitPos)
+{
+    if (_closed || bitPos < 0) return false;
+    _is.clear();
+    _is.seekg(std::streampos(bitPos >> 3));
+    if (_is.fail()) return false;
+    // forget everything fetched or decoded; the stream parameters (header) stay
+    _comp.clear();
+    _plain.clear(); _plainPos = 0;
+    _gcount = 0;
+    _srcEof = false; _ended = false;
+    _originBit = (bitPos >> 3) * 8;
+    _compBit = uint64(bitPos & 7);
+    this->clear();
+    return true;
 }
 
 void CompressedInputStream::close()

@@ -168,6 +168,58 @@ static void testStreams()
     }
 }
 
+static void testSeek()
+{
+    // io/CompressedInputStream.hpp:329-384: block boundaries are the only valid positions; tell() hands them out
+    const int bs = 65536;
+    const size_t n = 5 * size_t(bs) + 1234;
+    std::vector<byte> in = gen(4, n, 7);
+    for (int headerless = 0; headerless < 2; headerless++) {
+        std::stringstream ss;
+        {
+            CompressedOutputStream cos(ss, 2, "ANS0", "LZX", bs, 32, 0, headerless != 0);
+            cos.write(reinterpret_cast<const char*>(in.data()), std::streamsize(n));
+            cos.close();
+        }
+        CompressedInputStream cis(ss, 1, "ANS0", "LZX", bs, 32, 0, headerless != 0);
+        cis.setBatchBlocks(1);
+        std::vector<int64> bounds;
+        std::vector<byte> out(n + 16);
+        bounds.push_back(cis.tell());
+        CHECK(bounds[0] == (headerless ? 0 : 160));
+        size_t off = 0;
+        while (off < n) {
+            const size_t c = std::min<size_t>(size_t(bs), n - off);
+            cis.read(reinterpret_cast<char*>(&out[off]), std::streamsize(c));
+            CHECK(size_t(cis.gcount()) == c);
+            off += c;
+            bounds.push_back(cis.tell());
+        }
+        CHECK(memcmp(out.data(), in.data(), n) == 0);
+        CHECK(bounds.size() == 7);
+        const int order[] = { 3, 1, 5, 0, 4 };
+        for (int k : order) {
+            CHECK(cis.seek(bounds[size_t(k)]));
+            const size_t want = std::min<size_t>(size_t(bs), n - size_t(k) * bs);
+            std::vector<byte> blk(size_t(bs) + 16);
+            cis.read(reinterpret_cast<char*>(blk.data()), std::streamsize(want));
+            CHECK(size_t(cis.gcount()) == want);
+            CHECK(memcmp(blk.data(), &in[size_t(k) * bs], want) == 0);
+            CHECK(cis.tell() == bounds[size_t(k) + 1]);
+        }
+        // read through the end after a seek, then come back
+        CHECK(cis.seek(bounds[4]));
+        cis.read(reinterpret_cast<char*>(out.data()), std::streamsize(out.size()));
+        CHECK(size_t(cis.gcount()) == n - 4 * size_t(bs) && cis.eof());
+        CHECK(cis.seek(bounds[0]));
+        cis.read(reinterpret_cast<char*>(out.data()), 100);
+        CHECK(cis.gcount() == 100 && memcmp(out.data(), in.data(), 100) == 0);
+        CHECK(!cis.seek(-1));
+        cis.close();
+        CHECK(!cis.seek(bounds[0]) && cis.tell() == -1);
+    }
+}
+
 int main(int argc, char** argv)
 {
     const std::string what = argc > 1 ? argv[1] : "all";
@@ -176,6 +228,7 @@ int main(int argc, char** argv)
         if (what == "all" || what == "transforms") testTransforms();
         if (what == "all" || what == "entropy") testEntropy();
         if (what == "all" || what == "streams") testStreams();
+        if (what == "all" || what == "seek") testSeek();
     } catch (const std::exception& e) {
         printf("EXCEPTION %s\n", e.what());
         return 2;
