@@ -28,7 +28,8 @@ extern "C" {
 
 /* kanzi ids: entropy (entropy/EntropyEncoderFactory.hpp:37-52) and transforms (transform/TransformFactory.hpp:49-73) */
 enum { KNZ_E_NONE = 0, KNZ_E_HUFFMAN = 1, KNZ_E_FPAQ = 2, KNZ_E_ANS0 = 5, KNZ_E_ANS1 = 8 };
-enum { KNZ_T_NONE = 0, KNZ_T_BWT = 1, KNZ_T_LZ = 3, KNZ_T_RLT = 5, KNZ_T_ZRLT = 6, KNZ_T_MTFT = 7, KNZ_T_SRT = 13, KNZ_T_LZX = 16 };
+enum { KNZ_T_NONE = 0, KNZ_T_BWT = 1, KNZ_T_LZ = 3, KNZ_T_RLT = 5, KNZ_T_ZRLT = 6, KNZ_T_MTFT = 7, KNZ_T_RANK = 8, KNZ_T_SRT = 13, KNZ_T_LZX = 16,
+       KNZ_T_TIMESTAMP = 64 /* SBRT's third mode: no kanzi id, never part of a chain; per-stage entry points only */ };
 
 /* kanzi error codes surfaced for data errors (src/Error.hpp:26-48) */
 enum { KNZ_ERR_BLOCK_SIZE = 2, KNZ_ERR_INVALID_CODEC = 3, KNZ_ERR_READ_FILE = 11, KNZ_ERR_WRITE_FILE = 12,

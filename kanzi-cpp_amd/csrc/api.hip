@@ -105,7 +105,7 @@ static int count_transforms(uint64_t t, int* tok)
     return nb;
 }
 
-static bool transform_supported(int t) { return t == KNZ_T_NONE || t == KNZ_T_ZRLT || t == KNZ_T_MTFT || t == KNZ_T_BWT || t == KNZ_T_SRT || t == KNZ_T_RLT || t == KNZ_T_LZ || t == KNZ_T_LZX; }
+static bool transform_supported(int t) { return t == KNZ_T_NONE || t == KNZ_T_ZRLT || t == KNZ_T_MTFT || t == KNZ_T_BWT || t == KNZ_T_SRT || t == KNZ_T_RLT || t == KNZ_T_LZ || t == KNZ_T_LZX || t == KNZ_T_RANK || t == KNZ_T_TIMESTAMP; }
 static bool entropy_supported(int e) { return e == KNZ_E_NONE || e == KNZ_E_ANS0 || e == KNZ_E_ANS1 || e == KNZ_E_HUFFMAN || e == KNZ_E_FPAQ; }
 
 static int max_encoded_len(int t, int n)
@@ -327,6 +327,8 @@ static int run_forward_stage(Ctx* c, hipStream_t s, int t, const XfStage& st)
     case KNZ_T_MTFT: launch_mtft_forward(s, st); break;
     case KNZ_T_SRT: launch_srt_forward(s, st); break;
     case KNZ_T_RLT: launch_rlt_forward(s, st); break;
+    case KNZ_T_RANK: launch_sbrt_forward(s, st, 2); break;
+    case KNZ_T_TIMESTAMP: launch_sbrt_forward(s, st, 3); break;
     case KNZ_T_LZ: case KNZ_T_LZX: {
         const size_t bytes = lz_forward_scratch_bytes(t, st.nBlocks, st.maxLen);
         void* sc;
@@ -353,6 +355,8 @@ static int run_inverse_stage(Ctx* c, hipStream_t s, int t, const XfStage& st)
     case KNZ_T_MTFT: launch_mtft_inverse(s, st); break;
     case KNZ_T_SRT: launch_srt_inverse(s, st); break;
     case KNZ_T_RLT: launch_rlt_inverse(s, st); break;
+    case KNZ_T_RANK: launch_sbrt_inverse(s, st, 2); break;
+    case KNZ_T_TIMESTAMP: launch_sbrt_inverse(s, st, 3); break;
     case KNZ_T_LZ: case KNZ_T_LZX: launch_lz_inverse(s, st); break;
     case KNZ_T_BWT: {
         const size_t bytes = bwt_inverse_scratch_bytes(st.nBlocks, st.maxLen, (size_t)st.nBlocks * st.maxLen);

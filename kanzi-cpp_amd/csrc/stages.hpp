@@ -82,6 +82,10 @@ void launch_srt_inverse(hipStream_t s, const XfStage& st);
 void launch_rlt_forward(hipStream_t s, const XfStage& st);
 void launch_rlt_inverse(hipStream_t s, const XfStage& st);
 
+// sbrt.hip (mode 2 = RANK, 3 = TIMESTAMP; 1 = MTF for cross-checks)
+void launch_sbrt_forward(hipStream_t s, const XfStage& st, int mode);
+void launch_sbrt_inverse(hipStream_t s, const XfStage& st, int mode);
+
 // lz.hip (ttype = KNZ_T_LZ or KNZ_T_LZX)
 int launch_lz_forward(hipStream_t s, const XfStage& st, int ttype, void* scratch, size_t scratchBytes);
 void launch_lz_inverse(hipStream_t s, const XfStage& st);

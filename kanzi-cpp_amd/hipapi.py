@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libknz_hip.so")
 
 E_NONE, E_HUFFMAN, E_FPAQ, E_ANS0, E_ANS1 = 0, 1, 2, 5, 8
 ENTROPY_IDS = {"NONE": 0, "HUFFMAN": 1, "FPAQ": 2, "ANS0": 5, "ANS1": 8}
-TRANSFORM_IDS = {"NONE": 0, "BWT": 1, "LZ": 3, "RLT": 5, "ZRLT": 6, "MTFT": 7, "SRT": 13, "LZX": 16}
+TRANSFORM_IDS = {"NONE": 0, "BWT": 1, "LZ": 3, "RLT": 5, "ZRLT": 6, "MTFT": 7, "RANK": 8, "SRT": 13, "LZX": 16, "TIMESTAMP": 64}
 
 SYMBOLS = [
     "knz_hip_device_count", "knz_hip_create", "knz_hip_destroy", "knz_hip_last_error", "knz_hip_encode_bound",

@@ -293,17 +293,15 @@ static int lzTypeFromContext(Context& ctx)
 
 LZCodec::LZCodec(Context& ctx) : DeviceTransform(lzTypeFromContext(ctx), &ctx) {}
 
-SBRT::SBRT(int mode) : DeviceTransform(KNZ_T_MTFT, nullptr)
+static int sbrtType(int mode)
 {
-    if ((mode != MODE_MTF) && (mode != MODE_RANK) && (mode != MODE_TIMESTAMP)) throw std::invalid_argument("Invalid mode parameter");
-    if (mode != MODE_MTF) throw std::invalid_argument("SBRT: only MODE_MTF has a device kernel (RANK/TIMESTAMP are out of scope)");
+    if ((mode != SBRT::MODE_MTF) && (mode != SBRT::MODE_RANK) && (mode != SBRT::MODE_TIMESTAMP)) throw std::invalid_argument("Invalid mode parameter");
+    return (mode == SBRT::MODE_MTF) ? KNZ_T_MTFT : ((mode == SBRT::MODE_RANK) ? KNZ_T_RANK : KNZ_T_TIMESTAMP);
 }
 
-SBRT::SBRT(int mode, Context& ctx) : DeviceTransform(KNZ_T_MTFT, &ctx)
-{
-    if ((mode != MODE_MTF) && (mode != MODE_RANK) && (mode != MODE_TIMESTAMP)) throw std::invalid_argument("Invalid mode parameter");
-    if (mode != MODE_MTF) throw std::invalid_argument("SBRT: only MODE_MTF has a device kernel (RANK/TIMESTAMP are out of scope)");
-}
+SBRT::SBRT(int mode) : DeviceTransform(sbrtType(mode), nullptr) {}
+
+SBRT::SBRT(int mode, Context& ctx) : DeviceTransform(sbrtType(mode), &ctx) {}
 
 bool NullTransform::doCopy(SliceArray<byte>& input, SliceArray<byte>& output, int length) const
 {
@@ -507,6 +505,7 @@ TransformSequence<T>* TransformFactory<T>::newTransform(Context& ctx, uint64 fun
             case NONE_TYPE: transforms[nbtr++] = new NullTransform(ctx); break;
             case BWT_TYPE: transforms[nbtr++] = new BWTBlockCodec(ctx); break;
             case MTFT_TYPE: transforms[nbtr++] = new SBRT(SBRT::MODE_MTF, ctx); break;
+            case RANK_TYPE: transforms[nbtr++] = new SBRT(SBRT::MODE_RANK, ctx); break;
             case SRT_TYPE: transforms[nbtr++] = new SRT(ctx); break;
             case ZRLT_TYPE: transforms[nbtr++] = new ZRLT(ctx); break;
             case RLT_TYPE: transforms[nbtr++] = new RLT(ctx); break;

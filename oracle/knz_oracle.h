@@ -63,7 +63,8 @@ int64_t knzo_entropy_encode(int etype, const uint8_t* in, uint32_t n, uint8_t* o
 int knzo_entropy_decode(int etype, const uint8_t* in, size_t inBytes, uint8_t* out, uint32_t n);
 
 /* ---- Transforms. Return 1 on success (0 = "does not apply"/failed). *outLen bytes written.
- * ttype = kanzi transform id (1 BWT(block codec), 3 LZ, 5 RLT, 6 ZRLT, 7 MTFT, 13 SRT, 16 LZX, 0 NONE).
+ * ttype = kanzi transform id (1 BWT(block codec), 3 LZ, 5 RLT, 6 ZRLT, 7 MTFT, 8 RANK, 13 SRT, 16 LZX, 0 NONE;
+ * 64 selects SBRT's TIMESTAMP mode, which has no kanzi id).
  * dstCap mirrors SliceArray::_length - _index of the destination. etype is the stream's entropy
  * id (RLT picks its escape from it, transform/RLT.cpp:59-106); pass -1 when "entropy" is absent. */
 int knzo_transform_forward(int ttype, const uint8_t* src, int n, uint8_t* dst, int dstCap, int etype, int* outLen);

@@ -20,6 +20,7 @@
 #include "Context.hpp"
 #include "SliceArray.hpp"
 #include "transform/TransformFactory.hpp"
+#include "transform/SBRT.hpp"
 #include "entropy/EntropyEncoderFactory.hpp"
 #include "entropy/EntropyDecoderFactory.hpp"
 #include "bitstream/DefaultOutputBitStream.hpp"
@@ -94,6 +95,23 @@ int ref_transform(const char* name, int forward, const uint8_t* in, int n, int s
         }
         *outLen = sa2._index;
         delete seq;
+        return res ? 1 : 0;
+    } catch (const std::exception&) {
+        return -1;
+    }
+}
+
+// SBRT with an explicit mode (1 MTF, 2 RANK, 3 TIMESTAMP): TIMESTAMP has no factory id.
+int ref_sbrt(int mode, int forward, const uint8_t* in, int n, uint8_t* out, int dstCap, int* outLen)
+{
+    try {
+        SBRT t(mode);
+        std::vector<byte> src(size_t(n > 0 ? n : 1));
+        memcpy(src.data(), in, size_t(n));
+        SliceArray<byte> sa1(src.data(), n, 0);
+        SliceArray<byte> sa2(reinterpret_cast<byte*>(out), dstCap, 0);
+        const bool res = forward ? t.forward(sa1, sa2, n) : t.inverse(sa1, sa2, n);
+        *outLen = sa2._index;
         return res ? 1 : 0;
     } catch (const std::exception&) {
         return -1;

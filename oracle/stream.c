@@ -204,7 +204,7 @@ static int seq_required(const int* tok, int nb, int n)
     return req;
 }
 
-static int supported_transform(int t) { return t == 0 || t == 1 || t == 3 || t == 5 || t == 6 || t == 7 || t == 13 || t == 16; }
+static int supported_transform(int t) { return t == 0 || t == 1 || t == 3 || t == 5 || t == 6 || t == 7 || t == 8 || t == 13 || t == 16; }
 static int supported_entropy(int e) { return e == 0 || e == 1 || e == 2 || e == 5 || e == 8; }
 
 /* TransformSequence::forward with explicit capacities. data = block input (capacity dataCap),

@@ -147,6 +147,33 @@ static int mtft_inverse(const uint8_t* src, int count, uint8_t* dst, int dstCap,
     return 1;
 }
 
+/* ------------------------------------------------------------------ SBRT, modes RANK (2) and TIMESTAMP (3)
+ * transform/SBRT.cpp:46-97 (forward), :99-145 (inverse), masks :26-31. The list is kept ordered by a key q[s]
+ * (larger first, the newcomer ahead of equal keys): q = (i + previous position of the symbol) / 2 for RANK,
+ * q = previous position for TIMESTAMP; MTF (q = i) is the special case restated above. */
+static int sbrt_run(int mode, int inverse, const uint8_t* src, int count, uint8_t* dst, int dstCap, int* outLen)
+{
+    *outLen = 0;
+    if (count == 0) return 1;
+    if (count < 0 || count > dstCap) return 0;
+    const int useTime = (mode != 3), usePrev = (mode != 1), shift = (mode == 2);
+    int p[256] = { 0 }, q[256] = { 0 };
+    uint8_t r2s[256];
+    for (int i = 0; i < 256; i++) r2s[i] = (uint8_t)i;
+    for (int i = 0; i < count; i++) {
+        int r, c;
+        if (inverse) { r = src[i]; c = r2s[r]; dst[i] = (uint8_t)c; }
+        else { c = src[i]; r = 0; while (r2s[r] != c) r++; dst[i] = (uint8_t)r; }
+        const int qc = ((useTime ? i : 0) + (usePrev ? p[c] : 0)) >> shift;
+        p[c] = i;
+        q[c] = qc;
+        while (r > 0 && q[r2s[r - 1]] <= qc) { r2s[r] = r2s[r - 1]; r--; }
+        r2s[r] = (uint8_t)c;
+    }
+    *outLen = count;
+    return 1;
+}
+
 /* ------------------------------------------------------------------ SRT */
 static int srt_preprocess(const uint32_t* freqs, uint8_t* symbols)
 {
@@ -560,6 +587,8 @@ int knzo_transform_forward(int ttype, const uint8_t* src, int n, uint8_t* dst, i
     case 5:  return rlt_forward(src, n, dst, dstCap, etype, outLen);
     case 6:  return zrlt_forward(src, n, dst, dstCap, outLen);
     case 7:  return mtft_forward(src, n, dst, dstCap, outLen);
+    case 8:  return sbrt_run(2, 0, src, n, dst, dstCap, outLen);
+    case 64: return sbrt_run(3, 0, src, n, dst, dstCap, outLen);   /* TIMESTAMP: no kanzi id, test-only selector */
     case 13: return srt_forward(src, n, dst, dstCap, outLen);
     case 3:  return knzo_lz_forward(src, n, dst, dstCap, 0, outLen);
     case 16: return knzo_lz_forward(src, n, dst, dstCap, 1, outLen);
@@ -575,6 +604,8 @@ int knzo_transform_inverse(int ttype, const uint8_t* src, int n, uint8_t* dst, i
     case 5:  return rlt_inverse(src, n, dst, dstCap, outLen);
     case 6:  return zrlt_inverse(src, n, dst, dstCap, outLen);
     case 7:  return mtft_inverse(src, n, dst, dstCap, outLen);
+    case 8:  return sbrt_run(2, 1, src, n, dst, dstCap, outLen);
+    case 64: return sbrt_run(3, 1, src, n, dst, dstCap, outLen);
     case 13: return srt_inverse(src, n, dst, dstCap, outLen);
     case 3: case 16: return knzo_lz_inverse(src, n, dst, dstCap, outLen);
     default: *outLen = 0; return 0;

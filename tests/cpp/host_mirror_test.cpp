@@ -35,7 +35,7 @@ static std::vector<byte> gen(int kind, size_t n, unsigned seed)
 
 static void testTransforms()
 {
-    const char* names[] = { "BWT", "MTFT", "ZRLT", "SRT", "RLT", "LZ", "LZX", "BWT+MTFT+ZRLT", "BWT+SRT+ZRLT", "RLT+LZX" };
+    const char* names[] = { "BWT", "MTFT", "ZRLT", "SRT", "RLT", "LZ", "LZX", "RANK", "BWT+MTFT+ZRLT", "BWT+SRT+ZRLT", "RLT+LZX", "BWT+RANK+ZRLT" };
     for (const char* nm : names) {
         for (int kind = 0; kind < 5; kind++) {
             for (size_t n : { size_t(20), size_t(512), size_t(80000) }) {

@@ -32,7 +32,7 @@ def main():
         for e in ["NONE", "HUFFMAN", "ANS0", "ANS1", "FPAQ"]:
             enc, bits = R.entropy_encode(e, d)
             out["stages"].append({"kind": "entropy", "name": e, "input": list(spec), "bits": bits, "out": pack(enc)})
-        for t in ["BWT", "MTFT", "ZRLT", "SRT", "RLT", "LZ", "LZX"]:
+        for t in ["BWT", "MTFT", "ZRLT", "SRT", "RLT", "LZ", "LZX", "RANK"]:
             for ent in (["", "ANS0", "FPAQ"] if t == "RLT" else [""]):
                 cap = len(d) if t == "ZRLT" else len(d) + 2048
                 if t in ("LZ", "LZX"):

@@ -56,7 +56,7 @@ def ensure_ref():
 
 
 ETYPE = {"NONE": 0, "HUFFMAN": 1, "FPAQ": 2, "ANS0": 5, "ANS1": 8}
-TTYPE = {"NONE": 0, "BWT": 1, "LZ": 3, "RLT": 5, "ZRLT": 6, "MTFT": 7, "SRT": 13, "LZX": 16}
+TTYPE = {"NONE": 0, "BWT": 1, "LZ": 3, "RLT": 5, "ZRLT": 6, "MTFT": 7, "RANK": 8, "SRT": 13, "LZX": 16, "TIMESTAMP": 64}
 
 
 class Oracle:
@@ -198,6 +198,13 @@ class Ref:
         sk = C.c_int(skip)
         ok = self.L.ref_transform(name.encode(), 0, _buf(data), len(data), src_cap, out, dst_cap, b"",
                                   C.byref(ol), C.byref(sk))
+        return ok, bytes(out[:ol.value])
+
+    def sbrt(self, mode, forward, data):
+        """SBRT(mode) constructed directly (mode 3, TIMESTAMP, has no transform id)."""
+        out = (C.c_uint8 * max(1, len(data)))()
+        ol = C.c_int(0)
+        ok = self.L.ref_sbrt(mode, 1 if forward else 0, _buf(data), len(data), out, len(data), C.byref(ol))
         return ok, bytes(out[:ol.value])
 
     def compress(self, data, transform, entropy, block_size, jobs=1, checksum=0, orig_size=0, headerless=0):

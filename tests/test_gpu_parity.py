@@ -14,7 +14,7 @@ import vectors
 pytestmark = pytest.mark.gpu
 
 ENTROPY_ON_DEVICE = ["NONE", "ANS0", "ANS1", "HUFFMAN", "FPAQ"]
-TRANSFORMS_ON_DEVICE = ["ZRLT", "MTFT", "BWT", "SRT", "RLT", "LZ", "LZX"]
+TRANSFORMS_ON_DEVICE = ["ZRLT", "MTFT", "BWT", "SRT", "RLT", "LZ", "LZX", "RANK"]
 
 
 def matches(packed, b):
@@ -171,6 +171,25 @@ def test_transform_capacity_semantics(hip, oracle):
     assert hip.transform_inverse("ZRLT", bytes([0xFF]), 1)[0] == 0
     assert hip.transform_forward("ZRLT", bytes([0xFE]), 1)[0] == 0
     assert hip.transform_forward("ZRLT", bytes([0]), 1) == (1, bytes([0]))
+
+
+def test_sbrt_rank_and_timestamp(hip, oracle):
+    # SBRT modes 2 and 3 (transform/SBRT.cpp): typical input is BWT output; also raw data, tiny and 64-byte-edge sizes
+    rng = np.random.default_rng(4)
+    cases = [vectors.make(("text", 70000, 2)), vectors.make(("mixed", 200001, 9)), rng.integers(0, 256, 5000, dtype=np.uint8).tobytes(),
+             bytes(1000), b"a", bytes(range(256)) * 3, vectors.make(("text", 64, 1)), vectors.make(("text", 65, 1)), vectors.make(("text", 63, 1))]
+    for d in cases:
+        x = oracle.forward("BWT", d, len(d) + 64)[1]
+        for data in (d, x):
+            if not data:
+                continue
+            for name in ("RANK", "TIMESTAMP"):
+                ok1, o1 = oracle.forward(name, data, len(data))
+                ok2, o2 = hip.transform_forward(name, data, len(data))
+                assert ok1 == 1 and ok2 == 1 and o1 == o2, (name, len(data))
+                k, back = hip.transform_inverse(name, o1, len(data))
+                assert k == 1 and back == data, (name, len(data))
+                assert hip.transform_forward(name, data, len(data) - 1)[0] == 0          # count > capacity -> false
 
 
 def test_bwt_known_strings(hip):

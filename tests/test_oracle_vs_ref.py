@@ -33,7 +33,7 @@ def test_entropy_matches_reference(oracle, ref):
 
 def test_transforms_match_reference(oracle, ref):
     for d in _inputs():
-        for t in ["BWT", "MTFT", "ZRLT", "SRT", "RLT", "LZ", "LZX"]:
+        for t in ["BWT", "MTFT", "ZRLT", "SRT", "RLT", "LZ", "LZX", "RANK"]:
             cap = len(d) if t == "ZRLT" else len(d) + 2048
             if t in ("LZ", "LZX"):
                 cap = len(d) + len(d) // 64 + 18
@@ -47,6 +47,18 @@ def test_transforms_match_reference(oracle, ref):
                 assert k == 1 and back == d
                 k, back = oracle.inverse(t, o1, max(len(d), len(o1)) + 64)
                 assert k == 1 and back == d
+
+
+def test_sbrt_modes_match_reference(oracle, ref):
+    # SBRT(mode) constructed directly: RANK (also reachable as transform id 8) and TIMESTAMP (no id)
+    for d in _inputs():
+        x = oracle.forward("BWT", d, len(d) + 64)[1] if len(d) else d
+        for data in (d, x):
+            for name, mode in (("RANK", 2), ("TIMESTAMP", 3)):
+                ok1, o1 = oracle.forward(name, data, len(data))
+                ok2, o2 = ref.sbrt(mode, True, data)
+                assert bool(ok1) == (ok2 == 1) and o1 == o2, name
+                assert ref.sbrt(mode, False, o1)[1] == data and oracle.inverse(name, o1, len(data))[1] == data
 
 
 def test_streams_match_reference(oracle, ref):

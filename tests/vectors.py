@@ -99,4 +99,5 @@ STREAM_CASES = [
     (("mixed", 1 << 20, 3), "RLT+LZX", "ANS0", 1 << 18, 32, 0),
     (("rand", 300000, 9), "LZX", "ANS0", 1 << 16, 0, 0),
     (("const", 100000, 0), "LZ", "NONE", 65536, 0, 0),
+    (("mixed", 1 << 20, 3), "BWT+RANK+ZRLT", "ANS0", 1 << 18, 0, 0),
 ]

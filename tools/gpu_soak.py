@@ -15,7 +15,7 @@ rng = np.random.default_rng(seed)
 # chains whose even-indexed stages cannot expand into the caller's buffer
 # (BWT+ZRLT and BWT+RLT+ZRLT are left out: with a skipped or expanding second stage the reference writes streams
 # that it cannot decode itself -- checked with oracle/_ref -- so there is nothing to be bit-exact with)
-CHAINS = ["NONE", "BWT", "BWT+MTFT+ZRLT", "BWT+SRT+ZRLT", "BWT+MTFT", "RLT", "ZRLT", "SRT", "RLT+ZRLT", "MTFT", "BWT+SRT", "LZ", "LZX", "RLT+LZX"]
+CHAINS = ["NONE", "BWT", "BWT+MTFT+ZRLT", "BWT+SRT+ZRLT", "BWT+MTFT", "RLT", "ZRLT", "SRT", "RLT+ZRLT", "MTFT", "BWT+SRT", "LZ", "LZX", "RLT+LZX", "RANK", "BWT+RANK+ZRLT"]
 ENTS = ["NONE", "ANS0", "ANS1", "HUFFMAN", "FPAQ"]
 KINDS = ["text", "mixed", "rand", "runs", "sparse", "small_alpha"]
 
