@@ -107,8 +107,17 @@ KNZ_API int knz_hip_entropy_decode(knz_ctx* ctx, int entropy_type, const uint8_t
                                    uint64_t* used_bits);
 
 /* Transform<byte>::forward / inverse for one buffer (src/Transform.hpp:38-45). dst_cap mirrors
- * SliceArray::_length - _index of the destination (it changes results for ZRLT/RLT). *ok = 1 when the
- * reference would return true. entropy_type: the stream's entropy id (RLT escape choice), -1 if unset. */
+ * SliceArray::_length - _index of the destination (it changes results for ZRLT/RLT; LZ/LZX refuse a
+ * destination below getMaxEncodedLength). *ok = 1 when the reference would return true. entropy_type: the
+ * stream's entropy id (RLT escape choice), -1 if unset. Classes replaced, by transform_type:
+ *   KNZ_T_BWT   BWTBlockCodec        transform/BWTBlockCodec.cpp:32-87,89-168 (+ BWT.cpp, DivSufSort.cpp)
+ *   KNZ_T_MTFT / KNZ_T_RANK / KNZ_T_TIMESTAMP   SBRT modes 1 / 2 / 3   transform/SBRT.cpp:46-97,99-145
+ *   KNZ_T_SRT   SRT                  transform/SRT.cpp:22-109,111-204
+ *   KNZ_T_ZRLT  ZRLT                 transform/ZRLT.cpp:27-117,119-215
+ *   KNZ_T_RLT   RLT                  transform/RLT.cpp:39-221,247-369
+ *   KNZ_T_LZ / KNZ_T_LZX   LZCodec -> LZXCodec<false> / LZXCodec<true>   transform/LZCodec.cpp:119-456,470-640
+ * (the inverse of LZ/LZX expects what the reference expects: two readable bytes behind `in + n`,
+ * LZCodec.cpp:486-490; the library stages the input itself, so callers need not pad). */
 KNZ_API int knz_hip_transform_forward(knz_ctx* ctx, int transform_type, const uint8_t* in, int32_t n,
                                       uint8_t* out, int32_t dst_cap, int entropy_type, int32_t* out_len, int32_t* ok);
 KNZ_API int knz_hip_transform_inverse(knz_ctx* ctx, int transform_type, const uint8_t* in, int32_t n,
