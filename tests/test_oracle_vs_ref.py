@@ -49,6 +49,44 @@ def test_transforms_match_reference(oracle, ref):
                 assert k == 1 and back == d
 
 
+def test_lz_randomised_against_reference(oracle, ref):
+    # LZ / LZX on generated inputs that exercise what the fixed vectors do not: matches longer than MAX_MATCH,
+    # repeats at every distance class (1, 2, 3 distance bytes), incompressible stretches (the accelerating stride of
+    # the literal loop), tiny blocks around MIN_BLOCK_LENGTH, and rejected blocks
+    import numpy as np
+    rng = np.random.default_rng(12)
+    base = rng.integers(0, 256, 6000, dtype=np.uint8).tobytes()
+    cases = [b"abcdefghabcdefghabcdefg", b"abcdefghabcdefghabcdefgh", bytes(70000), b"abc" * 30000,
+             base * 3 + bytes(70000) + base[:3000] * 9, rng.integers(0, 256, 90000, dtype=np.uint8).tobytes()]
+    for i in range(10):
+        n = int(rng.integers(24, 200000))
+        parts = []
+        while sum(map(len, parts)) < n:
+            k = int(rng.integers(0, 4))
+            if k == 0:
+                a = int(rng.integers(0, 5000)); parts.append(base[a:a + int(rng.integers(4, 900))])
+            elif k == 1:
+                parts.append(rng.integers(0, 256, int(rng.integers(1, 3000)), dtype=np.uint8).tobytes())
+            elif k == 2:
+                parts.append(bytes([int(rng.integers(0, 256))]) * int(rng.integers(1, 400)))
+            else:
+                parts.append(vectors.make(("text", int(rng.integers(16, 4000)), i)))
+        cases.append(b"".join(parts)[:n])
+    for d in cases:
+        for t in ("LZ", "LZX"):
+            cap = ((len(d) + 16) if len(d) <= 1024 else len(d) + len(d) // 64) + 2
+            ok1, o1 = oracle.forward(t, d, cap)
+            ok2, o2, _ = ref.forward(t, d, cap)
+            assert bool(ok1) == (ok2 == 1), (t, len(d))
+            if ok1:
+                assert o1 == o2, (t, len(d))
+                assert oracle.inverse(t, o1, len(d) + 64) == (1, d)
+                assert ref.inverse(t, o1, len(d) + 64, src_cap=len(o1) + 2)[:2] == (1, d)
+            # destination below getMaxEncodedLength: the codec refuses (LZCodec.cpp:131-132); the harness goes through
+            # TransformSequence, which would swap in a larger buffer first, so only the restatement is asked here
+            assert oracle.forward(t, d, cap - 1)[0] == 0
+
+
 def test_sbrt_modes_match_reference(oracle, ref):
     # SBRT(mode) constructed directly: RANK (also reachable as transform id 8) and TIMESTAMP (no id)
     for d in _inputs():
