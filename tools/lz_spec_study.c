@@ -14,6 +14,8 @@ typedef struct { int anchor, rep0, rep1; } Ev;
 
 /* the reference's parse from an arbitrary state; candidates from prev[] when table == NULL, else from the table.
  * stops at pos >= end, or (stopAccel) when the skip counter reaches 64. returns #events; *why = 1 if stopped by accel */
+static uint8_t* g_ins;   /* prev-based mode: 1 = position is in the table */
+static int look(const int* prev, int q) { int c = prev[q]; while (c > 0 && !g_ins[c]) c = prev[c]; return c; }
 static int parse(const uint8_t* src, int n, const int* prev, int32_t* table, unsigned hl, int extra,
                  int pos, int end, int stopAccel, Ev* ev, int maxEv, int* why)
 {
@@ -25,7 +27,7 @@ static int parse(const uint8_t* src, int n, const int* prev, int32_t* table, uns
     while (pos < end) {
         if (stopAccel && skip >= 64) { *why = 1; break; }
         int cand;
-        if (table) { const uint32_t h = hsh(src + pos, hl); cand = table[h]; table[h] = pos; } else cand = prev[pos];
+        if (table) { const uint32_t h = hsh(src + pos, hl); cand = table[h]; table[h] = pos; } else { cand = look(prev, pos); g_ins[pos] = 1; }
         const int nxt = pos + 1;
         const int lo = (pos - maxDist > 0) ? pos - maxDist : 0;
         int best = 0, ref = nxt - rep[recent];
@@ -40,7 +42,7 @@ static int parse(const uint8_t* src, int n, const int* prev, int32_t* table, uns
                 for (int k = 1; k <= (extra ? 2 : 1); k++) {
                     const int pk = origin + k;
                     int ck;
-                    if (table) { const uint32_t h = hsh(src + pk, hl); ck = table[h]; table[h] = pk; } else ck = prev[pk];
+                    if (table) { const uint32_t h = hsh(src + pk, hl); ck = table[h]; table[h] = pk; } else { ck = look(prev, pk); g_ins[pk] = 1; }
                     if (ck > lo + k && ld32(src + pk + best - 3) == ld32(src + ck + best - 3)) {
                         const int bk = mlen(src, pk, ck, imin(srcEnd - pk, MAXMATCH));
                         if (bk >= best) { ref = ck; best = bk; pos = pk; }
@@ -50,14 +52,14 @@ static int parse(const uint8_t* src, int n, const int* prev, int32_t* table, uns
             while (pos > anchor && ref > lo && src[pos - 1] == src[ref - 1]) { best++; ref--; pos--; }
             if (best > MAXMATCH) { ref += best - MAXMATCH; pos += best - MAXMATCH; best = MAXMATCH; }
         } else {
-            if (best >= MAXMATCH || src[pos] != src[ref - 1]) { pos++; if (table) table[hsh(src + pos, hl)] = pos; }
+            if (best >= MAXMATCH || src[pos] != src[ref - 1]) { pos++; if (table) table[hsh(src + pos, hl)] = pos; else g_ins[pos] = 1; }
             else { best++; ref--; }
         }
         skip = 0;
         const int dist = pos - ref;
         rep[1] = rep[0]; rep[0] = dist; recent = 1;
         anchor = pos + best;
-        if (table) for (int p = pos + 1; p < anchor; p++) table[hsh(src + p, hl)] = p;
+        if (table) for (int p = pos + 1; p < anchor; p++) table[hsh(src + p, hl)] = p; else for (int p = pos + 1; p < anchor; p++) g_ins[p] = 1;
         pos = anchor;
         if (ne < maxEv) { ev[ne].anchor = anchor; ev[ne].rep0 = rep[0]; ev[ne].rep1 = rep[1]; ne++; }
     }
@@ -67,7 +69,7 @@ static int parse(const uint8_t* src, int n, const int* prev, int32_t* table, uns
 int main(int argc, char** argv)
 {
     FILE* f = fopen(argv[1], "rb"); fseek(f, 0, SEEK_END); long fl = ftell(f); fseek(f, 0, SEEK_SET);
-    const int bs = atoi(argv[2]), seg = atoi(argv[3]), extra = 1; const unsigned hl = 19;
+    const int bs = atoi(argv[2]), seg = atoi(argv[3]), extra = 1; const unsigned hl = 19; const int stopAccelFlag = argc > 4 ? atoi(argv[4]) : 0;
     uint8_t* all = malloc(fl + 64); if (fread(all, 1, fl, f) != (size_t)fl) return 2; fclose(f);
     long totSeg = 0, conv = 0, accel = 0, noconv = 0, wrong = 0; double sumOff = 0; long maxOff = 0, serialBytes = 0, totalBytes = 0;
     for (long off = 0; off < fl; off += bs) {
@@ -79,30 +81,36 @@ int main(int argc, char** argv)
         Ev* T = malloc(sizeof(Ev) * (size_t)(n / 4 + 16)); int why;
         const int nT = parse(src, n, prev, last, hl, extra, 0, srcEnd, 0, T, n / 4 + 16, &why);   /* the true parse */
         Ev* S = malloc(sizeof(Ev) * (size_t)(seg / 4 + 64));
+        g_ins = malloc((size_t)n + 8);
         totalBytes += n; serialBytes += imin(seg, n);
         for (int s = seg; s < srcEnd; s += seg) {
             const int e = imin(s + seg, srcEnd);
-            const int nS = parse(src, n, prev, NULL, hl, extra, s, e, 1, S, seg / 4 + 64, &why);
+            memset(g_ins, 1, (size_t)s); memset(g_ins + s, 0, (size_t)(n - s) + 8);
+            const int nS = parse(src, n, prev, NULL, hl, extra, s, e, stopAccelFlag, S, seg / 4 + 64, &why);
             totSeg++;
-            /* first speculative event that coincides with a true one */
-            int ci = -1, ti = -1;
-            for (int i = 0; i < nS && ci < 0; i++) {
-                int lo = 0, hi = nT - 1;
-                while (lo <= hi) { const int m = (lo + hi) >> 1; if (T[m].anchor < S[i].anchor) lo = m + 1; else if (T[m].anchor > S[i].anchor) hi = m - 1; else { if (T[m].rep0 == S[i].rep0 && T[m].rep1 == S[i].rep1) { ci = i; ti = m; } break; } }
+            if (why) accel++;
+            /* walk the true events of this segment; adopt runs of speculative events that coincide with them */
+            int m = 0; while (m < nT && T[m].anchor < s) m++;
+            int i = 0; long covered = 0; int firstMeet = -1, runs = 0;
+            while (m < nT && T[m].anchor <= e && i < nS) {
+                if (S[i].anchor < T[m].anchor) { i++; continue; }
+                if (S[i].anchor > T[m].anchor) { m++; continue; }
+                if (S[i].rep0 != T[m].rep0 || S[i].rep1 != T[m].rep1) { i++; m++; continue; }
+                /* same state: follow both while they agree */
+                if (firstMeet < 0) firstMeet = S[i].anchor - s;
+                const int a0 = S[i].anchor; runs++;
+                while (i + 1 < nS && m + 1 < nT && S[i + 1].anchor == T[m + 1].anchor && S[i + 1].rep0 == T[m + 1].rep0 && S[i + 1].rep1 == T[m + 1].rep1) { i++; m++; }
+                covered += S[i].anchor - a0;
+                i++; m++;
             }
-            if (ci < 0) { if (why) accel++; else noconv++; serialBytes += e - s; continue; }
-            /* from there on the two must be the same parse */
-            int good = 1;
-            for (int i = ci, m = ti; i < nS; i++, m++) if (m >= nT || T[m].anchor != S[i].anchor || T[m].rep0 != S[i].rep0 || T[m].rep1 != S[i].rep1) { good = 0; break; }
-            const long o = S[ci].anchor - s;
-            if (!good) { wrong++; serialBytes += e - s; continue; }
-            conv++; sumOff += o; if (o > maxOff) maxOff = o;
-            serialBytes += o;
-            if (why) { accel++; serialBytes += e - S[nS - 1].anchor; }   /* the tail after the accelerated stretch is serial */
+            if (firstMeet < 0) noconv++; else { conv++; sumOff += firstMeet; if (firstMeet > maxOff) maxOff = firstMeet; }
+            if (runs > 1) wrong++;
+            serialBytes += (e - s) - covered;
         }
+        free(g_ins);
         free(prev); free(last); free(T); free(S);
     }
-    printf("%s bs=%d seg=%d: segments %ld converged %ld (mean offset %.0f B, max %ld B) diverged-after-meeting %ld never-met %ld hit-accelerated %ld | serial share %.1f%%\n",
-           argv[1], bs, seg, totSeg, conv, conv ? sumOff / conv : 0.0, maxOff, wrong, noconv, accel, 100.0 * serialBytes / totalBytes);
+    printf("%s bs=%d seg=%d: segments %ld met %ld (first meeting after %.0f B on average, max %ld B) needed more than one run %ld never-met %ld | serial share %.1f%%\n",
+           argv[1], bs, seg, totSeg, conv, conv ? sumOff / conv : 0.0, maxOff, wrong, noconv, 100.0 * serialBytes / totalBytes);
     return 0;
 }
