@@ -2,13 +2,21 @@
 """Benchmark of the kanzi block pipeline on MI355X.
 
 Metric (BASELINE.json): encode+decode MB/s on silesia.tar, bit-exact; % of the HBM roofline.
-A "step" = one pass of the hot path over the whole corpus resident in HBM: encode every block to
-the kanzi bit stream (device buffer -> device buffer) and decode that stream back (device ->
-device). value = bytes / (t_enc + t_dec) in MB/s (MB = 1e6), summed over ranks (weak scaling:
-every rank processes its own corpus-sized shard; blocks are independent so there is no collective
-in the data path, only the timing barrier / MAX all-reduce).
+Default workload = BASELINE config 3, the configuration the north-star target is stated on:
+`-t BWT+MTFT+ZRLT -e ANS0 -b 8m` on silesia.tar (or its synthetic stand-in when the corpus is absent).
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+A "step" = one pass of the hot path over the corpus resident in HBM: encode every block to the kanzi
+bit stream (device buffer -> device buffer) and decode that stream back (device -> device).
+value = corpus bytes / (t_enc + t_dec) in MB/s (MB = 1e6 B).
+
+Multi-GPU (--gpus N, one process per GPU under torch.distributed.run): the blocks of the ONE corpus are
+sharded over the ranks in contiguous ranges (kanzi-cpp_amd/sharded.py:block_ranges); every rank
+encodes and decodes its own range, there is no collective in the data path (only the timing barrier and the MAX
+all-reduce of the elapsed time). That is strong scaling: 26 blocks over 8 GPUs is 4,4,3,3,3,3,3,3, so the best
+possible speed-up is 6.5x. `--scaling weak` gives every rank the whole corpus instead.
+
+    python bench.py                      # N=1, config 3
+    python bench.py --config 2           # -t NONE -e ANS0 -b 4m
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
@@ -24,7 +32,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 CONFIGS = {
-    # BASELINE.json configs (1-based); config 2 is the one the metric is quoted on for 1 GPU
+    # BASELINE.json configs (1-based)
     2: dict(transform="NONE", entropy="ANS0", block=4 << 20, corpus="silesia"),
     3: dict(transform="BWT+MTFT+ZRLT", entropy="ANS0", block=8 << 20, corpus="silesia"),
     4: dict(transform="BWT+SRT+ZRLT", entropy="FPAQ", block=32 << 20, corpus="enwik9"),
@@ -34,49 +42,139 @@ CONFIGS = {
     6: dict(transform="NONE", entropy="ANS1", block=16 << 20, corpus="silesia"),
 }
 
-# Algorithmic HBM bytes of one launch of each kernel (ideal one-pass traffic),
-# as a function of N = uncompressed bytes and C = compressed bytes of the batch.
-KERNEL_BYTES = {
-    "k_ans0_stats": lambda N, Cc: N,                 # reads every input byte once (tables/headers are << N)
-    "k_ans0_encode": lambda N, Cc: N + Cc,           # reads symbols, writes rANS bytes
-    "k_assemble": lambda N, Cc: 2 * Cc,              # reads staged pieces, writes the packed stream
-    "memset_out": lambda N, Cc: Cc,
-    "k_ans0_scan": lambda N, Cc: Cc,                 # walks the compressed stream's headers (upper bound: whole stream)
-    "k_ans0_decode": lambda N, Cc: N + Cc,           # reads rANS bytes, writes symbols
-    "k_none_decode": lambda N, Cc: N + Cc,
-}
+# Kernel name (the KScope label of the launch) -> pipeline stage. First matching prefix wins.
+STAGE_PREFIXES = [
+    ("k_bwt_f", "bwt_forward"), ("bwt_f", "bwt_forward"),
+    ("k_bwt_i", "bwt_inverse"), ("bwt_i", "bwt_inverse"), ("k_bwt_bases", "bwt_forward"),
+    ("k_mtf_f", "mtft_forward"), ("k_mtf_i", "mtft_inverse"),
+    ("k_zrlt_f", "zrlt_forward"), ("k_zrlt_i", "zrlt_inverse"), ("k_zero_dst", "zrlt_inverse"),
+    ("k_srt_f", "srt_forward"), ("k_srt_zero", "srt_forward"), ("k_srt_i", "srt_inverse"),
+    ("k_lz_inverse", "lz_inverse"), ("k_lz", "lz_forward"), ("rocprim_lz", "lz_forward"),
+    ("k_ans0_stats", "ans0_encode"), ("k_ans0_encode", "ans0_encode"),
+    ("k_ans0_scan", "ans0_decode"), ("k_ans0_decode", "ans0_decode"),
+    ("k_ans1_hist", "ans1_encode"), ("k_ans1_ctx", "ans1_encode"), ("k_ans1_encode", "ans1_encode"),
+    ("k_ans1_scan", "ans1_decode"), ("k_ans1_tables", "ans1_decode"), ("k_ans1_decode", "ans1_decode"),
+    ("k_huff_encode", "huffman_encode"), ("k_huff_scan", "huffman_decode"), ("k_huff_decode", "huffman_decode"),
+    ("k_fpaq_e", "fpaq_encode"), ("k_fpaq_d", "fpaq_decode"),
+    ("k_block_sum", "bit_assembly"), ("k_block_scan", "bit_assembly"), ("k_assemble", "bit_assembly"),
+    ("memset_out", "bit_assembly"), ("k_put_prologue", "bit_assembly"),
+    ("k_walk_blocks", "framing_walk"), ("k_check_prelen", "framing_walk"),
+]
 
 
-def cpu_baseline(sample, cfg, cores):
-    """Reference kanzi (oracle/_ref, unmodified sources) on the host cores: compress + decompress a
-    bounded sample through CompressedOutputStream/InputStream with -j min(cores, 64, #blocks)."""
+def stage_of(name, direction):
+    for pre, st in STAGE_PREFIXES:
+        if name.startswith(pre):
+            return st
+    # helpers shared by several stages (tile scans, compaction, sequence bookkeeping) are charged to the direction
+    return "other_" + direction
+
+
+def stage_bytes(stage, N, Cc, nblocks):
+    """Algorithmic HBM bytes of one pass of a stage (ideal one-pass traffic); N = uncompressed bytes
+    of the batch, Cc = compressed bytes. Stages between BWT and the entropy coder see N-sized data up to ZRLT."""
+    if stage in ("bwt_forward", "bwt_inverse"):
+        return 2 * N + 32 * nblocks
+    if stage in ("mtft_forward", "mtft_inverse", "srt_forward", "srt_inverse"):
+        return 2 * N
+    if stage in ("bit_assembly",):
+        return 2 * Cc
+    return N + Cc          # entropy coders, ZRLT, LZ: N + C per direction
+
+
+def cpu_baseline(data, n_sample, cfg, cores):
+    """Reference kanzi (oracle/_ref, the unmodified sources) on the host cores: compress + decompress a bounded
+    sample through CompressedOutputStream/InputStream with -j min(cores, 64, #blocks). The clock runs INSIDE the C
+    harness (oracle/ref_harness.cpp:ref_time_roundtrip) around the stream objects only; buffers are numpy arrays
+    handed over by pointer, nothing is marshalled in the timed region."""
+    import numpy as np
     import knzlib
-    nblocks = max(1, (len(sample) + cfg["block"] - 1) // cfg["block"])
+    bs = cfg["block"]
+    nblocks = max(1, (n_sample + bs - 1) // bs)
+    src = np.frombuffer(data, dtype=np.uint8, count=n_sample)
+    comp = np.empty(n_sample + n_sample // 2 + (1 << 20), dtype=np.uint8)
+    back = np.empty(max(1, n_sample), dtype=np.uint8)
+    u8p = C.POINTER(C.c_uint8)
+    info = ""
     try:
-        ref = knzlib.Ref()
-        kind = "reference"
+        cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        cpu_model = "unknown"
+    so = knzlib.ensure_ref()
+    if so is not None:
+        L = C.CDLL(so)
+        L.ref_time_roundtrip.restype = C.c_int
+        L.ref_time_roundtrip.argtypes = [u8p, C.c_size_t, C.c_char_p, C.c_char_p, C.c_int, C.c_int, u8p, C.c_size_t,
+                                         C.POINTER(C.c_size_t), u8p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         jobs = max(1, min(cores, 64, nblocks))
-        t0 = time.perf_counter()
-        rc, enc = ref.compress(sample, cfg["transform"], cfg["entropy"], cfg["block"], jobs=jobs)
-        t1 = time.perf_counter()
-        rc2, dec = ref.decompress(enc, len(sample), jobs=jobs)
-        t2 = time.perf_counter()
-        assert rc == 0 and rc2 == 0 and dec == sample
-    except (RuntimeError, OSError):
+        clen, te, td = C.c_size_t(0), C.c_double(0), C.c_double(0)
+        rc = L.ref_time_roundtrip(src.ctypes.data_as(u8p), n_sample, cfg["transform"].encode(), cfg["entropy"].encode(), bs, jobs,
+                                  comp.ctypes.data_as(u8p), comp.size, C.byref(clen), back.ctypes.data_as(u8p), C.byref(te), C.byref(td))
+        if rc != 0:
+            raise RuntimeError("reference round trip failed: %d" % rc)
+        kind, t_enc, t_dec = "reference", te.value, td.value
+        enc = comp[:clen.value].tobytes()
+    else:
+        # Clean checkout without the reference build: the C restatement (oracle/), one independent stream per block on
+        # every host core (ctypes releases the GIL), so that the figure is a multi-core one like the reference's.
+        from concurrent.futures import ThreadPoolExecutor
         ora = knzlib.Oracle()
-        kind = "port"
-        jobs = 1
-        t0 = time.perf_counter()
-        rc, enc = ora.compress(sample, cfg["transform"], cfg["entropy"], cfg["block"])
-        t1 = time.perf_counter()
-        rc2, dec = ora.decompress(enc, len(sample))
-        t2 = time.perf_counter()
-        assert rc == 0 and rc2 == 0 and dec == sample
-    mbps = len(sample) / (t2 - t0) / 1e6
-    return dict(value=round(mbps, 2), unit="MB/s", cores=jobs, kind=kind,
-                sample="first %d bytes of the workload, %d blocks, encode %.3f s + decode %.3f s" % (
-                    len(sample), nblocks, t1 - t0, t2 - t1),
-                enc_MBps=round(len(sample) / (t1 - t0) / 1e6, 2), dec_MBps=round(len(sample) / (t2 - t1) / 1e6, 2)), enc
+        jobs = max(1, min(cores, 64, nblocks))
+        blocks = [bytes(src[i * bs:min(n_sample, (i + 1) * bs)]) for i in range(nblocks)]
+        with ThreadPoolExecutor(jobs) as ex:
+            t0 = time.perf_counter()
+            encs = list(ex.map(lambda b: ora.compress(b, cfg["transform"], cfg["entropy"], bs)[1], blocks))
+            t1 = time.perf_counter()
+            decs = list(ex.map(lambda eb: ora.decompress(eb[0], len(eb[1]))[1], zip(encs, blocks)))
+            t2 = time.perf_counter()
+        assert decs == blocks
+        kind, t_enc, t_dec, enc = "port", t1 - t0, t2 - t1, None
+        info = "; oracle/_ref absent: C restatement, one stream per block on %d threads (marshalling included)" % jobs
+    mbps = n_sample / (t_enc + t_dec) / 1e6
+    return dict(value=round(mbps, 2), unit="MB/s", cores=jobs, kind=kind, cpu=cpu_model, host_cores=cores,
+                sample="first %d bytes of the workload, %d blocks, -j %d, timed inside C: encode %.3f s + decode %.3f s%s" % (
+                    n_sample, nblocks, jobs, t_enc, t_dec, info),
+                enc_MBps=round(n_sample / t_enc / 1e6, 2), dec_MBps=round(n_sample / t_dec / 1e6, 2)), enc
+
+
+def end_to_end(data, cfg):
+    """What a caller of the drop-in C API gets (src/api/Compressor.hpp:92-116): host bytes -> initCompressor/compress
+    -> .knz file on tmpfs -> initDecompressor/decompress -> host bytes, PCIe and every host copy included."""
+    kz = importlib.import_module("kanzi_amd.kanzi")
+    bs = cfg["block"]
+    n = len(data)
+    path = ("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp") + "/knz_bench_%d.knz" % os.getpid()
+    mv = memoryview(data)
+    best = None
+    try:
+        for _ in range(2):
+            t0 = time.perf_counter()
+            c = kz.Compressor(path, cfg["transform"], cfg["entropy"], bs, jobs=8)
+            for off in range(0, n, bs):
+                c.compress(mv[off:off + bs])
+            written = c.close()
+            t1 = time.perf_counter()
+            d = kz.Decompressor(path, bs, jobs=8)
+            total, ok = 0, True
+            while True:
+                part = d.decompress(bs)
+                if not part:
+                    break
+                ok = ok and (part == mv[total:total + len(part)])
+                total += len(part)
+            d.close()
+            t2 = time.perf_counter()
+            if not ok or total != n:
+                raise RuntimeError("end-to-end round trip mismatch")
+            cur = dict(value=round(n / (t2 - t0) / 1e6, 2), unit="MB/s", compress_MBps=round(n / (t1 - t0) / 1e6, 2),
+                       decompress_MBps=round(n / (t2 - t1) / 1e6, 2), compressed_bytes=written,
+                       path="host bytes -> libkanzi_amd.so C API (initCompressor/compress, initDecompressor/decompress) -> .knz on tmpfs -> host bytes")
+            if best is None or cur["value"] > best["value"]:
+                best = cur
+    finally:
+        if os.path.exists(path):
+            os.remove(path)
+    return best
 
 
 def main():
@@ -84,10 +182,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=2)
+    ap.add_argument("--config", type=int, default=3)
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--limit", type=int, default=0, help="use only the first LIMIT bytes of the corpus")
     ap.add_argument("--cpu-sample", type=int, default=64 << 20)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
     args = ap.parse_args()
 
     import numpy as np
@@ -109,37 +209,50 @@ def main():
     hipapi = importlib.import_module("kanzi_amd.hipapi")
     corpus = importlib.import_module("kanzi_amd.corpus")
     framing = importlib.import_module("kanzi_amd.framing")
+    sharded = importlib.import_module("kanzi_amd.sharded")
 
     cfg = CONFIGS[args.config]
     data, desc = corpus.load(cfg["corpus"], args.limit or None)
-    n = len(data)
+    n_total = len(data)
     bs = cfg["block"]
+    nblocks_total = (n_total + bs - 1) // bs
+    # this rank's share of the corpus
+    if world > 1 and args.scaling == "strong":
+        first_block, cnt = sharded.block_ranges(n_total, bs, world)[rank]
+    else:
+        first_block, cnt = 0, nblocks_total
+    lo = first_block * bs
+    hi = min(n_total, (first_block + cnt) * bs)
+    n = hi - lo
     dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
     stream = torch.cuda.Stream(device=dev)  # the library launches (and HIP-event-times) on this stream
     ctx = hipapi.Context(local_rank, stream=stream.cuda_stream)
 
-    h_in = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy())
+    h_in = torch.from_numpy(np.frombuffer(data, dtype=np.uint8, count=n, offset=lo).copy())
     d_in = torch.empty(n + 64, dtype=torch.uint8, device=dev)
     d_in[:n].copy_(h_in)
     p = ctx.params(cfg["transform"], cfg["entropy"], bs)
     cap = ctx.encode_bound(p, n)
     d_enc = torch.zeros(cap, dtype=torch.uint8, device=dev)
     d_dec = torch.empty(n + bs + 64, dtype=torch.uint8, device=dev)
-    hdr, hdr_bits = framing.make_header(p.entropy_type, p.transform_type, bs, 0, n)
+    # rank 0 carries the stream header, the last rank with blocks the end marker: the runs concatenate to one stream
+    hdr, hdr_bits = framing.make_header(p.entropy_type, p.transform_type, bs, 0, n_total) if first_block == 0 else (b"", 0)
+    finish = 1 if (first_block + cnt == nblocks_total) else 0
 
-    state = {}
+    state = {"bits": 0, "out_bytes": 0}
 
     def encode():
-        state["bits"] = ctx.encode_blocks(p, d_in.data_ptr(), n, d_enc.data_ptr(), cap, prologue=hdr, prologue_bits=hdr_bits)
+        state["bits"] = ctx.encode_blocks(p, d_in.data_ptr(), n, d_enc.data_ptr(), cap, prologue=hdr, prologue_bits=hdr_bits,
+                                          first_block=first_block, finish=finish)
 
     def decode():
-        ob, eb, nb = ctx.decode_blocks(p, d_enc.data_ptr(), state["bits"], hdr_bits, d_dec.data_ptr(), n + bs)
+        ob, eb, nb = ctx.decode_blocks(p, d_enc.data_ptr(), state["bits"], hdr_bits, d_dec.data_ptr(), n + bs, max_blocks=max(cnt, 1))
         state["out_bytes"] = ob
 
     def step():
-        encode()
-        decode()
+        if cnt:
+            encode()
+            decode()
 
     for _ in range(args.warmup):
         step()
@@ -161,74 +274,118 @@ def main():
         elapsed = float(t.item())
 
     # ---- correctness of what was timed (outside the timed region)
-    assert state["out_bytes"] == n, "decoded %d of %d bytes" % (state["out_bytes"], n)
-    assert torch.equal(d_dec[:n], d_in[:n]), "round trip mismatch"
+    if cnt:
+        assert state["out_bytes"] == n, "decoded %d of %d bytes" % (state["out_bytes"], n)
+        assert torch.equal(d_dec[:n], d_in[:n]), "round trip mismatch"
     comp_bytes = (state["bits"] + 7) // 8
-
-    # ---- separate encode / decode timing + per-kernel HIP-event timing (same stream)
-    def timed(fn, reps):
-        torch.cuda.synchronize()
-        a = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - a) / reps
-
-    reps = max(2, min(args.steps, 5))
-    t_enc = timed(encode, reps)
-    t_dec = timed(decode, reps)
-    ctx.set_profiling(True)
-    for _ in range(reps):
-        step()
-    ktimes = ctx.kernel_times()
-    ctx.set_profiling(False)
-    kern = {nm: (ms / cnt, cnt) for nm, ms, cnt in ktimes if cnt}
-    dom = max(kern.items(), key=lambda kv: kv[1][0])
-    dom_name, (dom_ms, _) = dom
-    alg = KERNEL_BYTES.get(dom_name, lambda N, Cc: N + Cc)(n, comp_bytes)
-    achieved = alg / (dom_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath)).get("config%d" % args.config, {})
-            # measured with rocprofv3 --pmc on the same workload; only valid for the same input size
-            traffic = tj.get(dom_name) if tj.get("n_bytes") == n else None
-        except Exception:
-            traffic = None
-    roofline = dict(bound="hbm", kernel=dom_name, achieved=round(achieved, 2), peak=8000.0, unit="GB/s",
-                    frac=round(achieved / 8000.0, 5), traffic=traffic, algorithmic_bytes=alg,
-                    kernel_ms=round(dom_ms, 4),
-                    kernels_ms={k: round(v[0], 4) for k, v in kern.items()})
+    if world > 1:
+        t = torch.tensor([comp_bytes], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        comp_total = int(t.item())
+    else:
+        comp_total = comp_bytes
 
     result = None
     if rank == 0:
+        # ---- separate encode / decode timing + per-kernel HIP-event timing (same stream), rank 0's share
+        def timed(fn, reps):
+            torch.cuda.synchronize()
+            a = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - a) / reps
+
+        reps = max(2, min(args.steps, 5))
+        t_enc = timed(encode, reps)
+        t_dec = timed(decode, reps)
+        kern, stages = {}, {}
+        ctx.set_profiling(True)
+        for direction, fn in (("encode", encode), ("decode", decode)):
+            for _ in range(reps):
+                fn()
+            for nm, ms, launches in ctx.kernel_times():
+                if not launches:
+                    continue
+                key = nm if nm not in kern else nm + "@" + direction
+                kern[key] = dict(ms_per_step=ms / reps, launches_per_step=launches / reps, stage=stage_of(nm, direction))
+                st = stages.setdefault(stage_of(nm, direction), dict(ms=0.0, launches=0.0, kernels=[]))
+                st["ms"] += ms / reps
+                st["launches"] += launches / reps
+                st["kernels"].append(nm)
+        ctx.set_profiling(False)
+        nb_rank = max(cnt, 1)
+        dom_stage = max(stages.items(), key=lambda kv: kv[1]["ms"])[0]
+        dom = stages[dom_stage]
+        alg = stage_bytes(dom_stage, n, comp_bytes, nb_rank)
+        achieved = alg / (dom["ms"] * 1e-3) / 1e9
+        dk_name, dk = max(((k, v) for k, v in kern.items() if v["stage"] == dom_stage), key=lambda kv: kv[1]["ms_per_step"])
+        traffic, traffic_source = None, None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath)).get("config%d" % args.config, {})
+                # measured with rocprofv3 --pmc on the same workload (tools/pmc_summary.py); only valid for the same input size
+                if tj.get("n_bytes") == n and dom_stage in tj.get("stages", {}):
+                    traffic = tj["stages"][dom_stage]
+                    traffic_source = "profiles/pmc_traffic.json (%s)" % tj.get("source", "rocprofv3 --pmc")
+            except Exception:
+                traffic = None
+        pipe_bytes = 2 * (n + comp_bytes)
+        step_ms = (t_enc + t_dec) * 1e3
+        roofline = dict(
+            bound="hbm", stage=dom_stage, kernel=dk_name.split("@")[0], achieved=round(achieved, 2), peak=8000.0, unit="GB/s",
+            frac=round(achieved / 8000.0, 5), traffic=traffic, traffic_source=traffic_source, algorithmic_bytes=alg,
+            stage_ms=round(dom["ms"], 4), stage_launches_per_step=round(dom["launches"], 1),
+            note="dominant STAGE: algorithmic bytes of one pass of the stage / summed HIP-event time of all its launches in one step",
+            dominant_kernel=dict(name=dk_name.split("@")[0], avg_ms=round(dk["ms_per_step"] / dk["launches_per_step"], 4),
+                                 launches_per_step=round(dk["launches_per_step"], 1), ms_per_step=round(dk["ms_per_step"], 4)),
+            pipeline=dict(algorithmic_bytes=pipe_bytes, ms=round(step_ms, 4), achieved=round(pipe_bytes / (step_ms * 1e-3) / 1e9, 2),
+                          frac=round(pipe_bytes / (step_ms * 1e-3) / 1e9 / 8000.0, 5),
+                          note="2*(N + C): uncompressed read + compressed write per direction, over encode + decode"),
+            stages_ms={k: round(v["ms"], 4) for k, v in sorted(stages.items(), key=lambda kv: -kv[1]["ms"])},
+            kernels_ms={k: round(v["ms_per_step"], 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms_per_step"])})
+
         cpu = None
         bit_exact = None
-        if not args.no_cpu and world == 1:       # the CPU baseline is a single-GPU report line
-            sample_n = min(n, args.cpu_sample)
-            sample_n -= sample_n % bs if sample_n >= bs else 0
-            sample = data[:sample_n]
-            cpu, ref_enc = cpu_baseline(sample, cfg, os.cpu_count() or 1)
-            # bit-exactness of the device stream against the reference on the same sample
-            hdr2, hb2 = framing.make_header(p.entropy_type, p.transform_type, bs, 0, 0)
-            bits2 = ctx.encode_blocks(p, d_in.data_ptr(), sample_n, d_enc.data_ptr(), cap, prologue=hdr2, prologue_bits=hb2)
-            got = bytes(d_enc[:(bits2 + 7) // 8].cpu().numpy())
-            bit_exact = (got == ref_enc)
+        e2e = None
+        if world == 1:                           # the CPU baseline and the host-buffer path are single-GPU report lines
+            if not args.no_cpu:
+                sample_n = min(n, args.cpu_sample)
+                sample_n -= sample_n % bs if sample_n >= bs else 0
+                cpu, ref_enc = cpu_baseline(data, sample_n, cfg, os.cpu_count() or 1)
+                if ref_enc is not None:
+                    # bit-exactness of the device stream against the reference on the same sample
+                    hdr2, hb2 = framing.make_header(p.entropy_type, p.transform_type, bs, 0, 0)
+                    bits2 = ctx.encode_blocks(p, d_in.data_ptr(), sample_n, d_enc.data_ptr(), cap, prologue=hdr2, prologue_bits=hb2)
+                    got = bytes(d_enc[:(bits2 + 7) // 8].cpu().numpy())
+                    bit_exact = (got == ref_enc)
+            if not args.no_e2e:
+                try:
+                    e2e = end_to_end(data, cfg)
+                except Exception as ex:      # the host library is a separate .so; its absence must not hide the device line
+                    e2e = dict(error=str(ex))
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * n / (elapsed / args.steps) / 1e6
+        job_bytes = n_total if (world == 1 or args.scaling == "strong") else world * n_total
+        value = job_bytes / (elapsed / args.steps) / 1e6
+        real = "stand-in" not in desc
         result = {
-            "metric": "encode+decode MB/s on silesia.tar (bit-exact)",
+            "metric": "encode+decode MB/s on %s (bit-exact)" % ("silesia.tar" if real and cfg["corpus"] == "silesia" else desc.split(",")[0] if real else "the synthetic stand-in for %s" % ("silesia.tar" if cfg["corpus"] == "silesia" else cfg["corpus"])),
             "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic" if "stand-in" in desc else "real",
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak" if (world > 1 and args.scaling == "weak") else ("strong" if world > 1 else "weak"),
+            "vs_baseline": None, "dtype": "u8", "data": "real" if real else "synthetic",
             "config": {"workload": "-t %s -e %s -b %dm, %s" % (cfg["transform"], cfg["entropy"], bs >> 20, desc),
-                       "bytes_per_gpu": n, "blocks_per_gpu": (n + bs - 1) // bs, "compressed_bytes": comp_bytes,
-                       "parallelism": "blocks sharded by rank, no collective"},
-            "enc_MBps": round(world * n / t_enc / 1e6, 2), "dec_MBps": round(world * n / t_dec / 1e6, 2),
+                       "corpus_bytes": n_total, "blocks": nblocks_total, "compressed_bytes": comp_total,
+                       "bytes_rank0": n, "blocks_rank0": cnt,
+                       "parallelism": ("1 GPU" if world == 1 else
+                                       "blocks of one corpus sharded over %d ranks in contiguous ranges, no collective" % world if args.scaling == "strong"
+                                       else "%d replicas of the corpus, no collective" % world)},
+            "enc_MBps": round(n / t_enc / 1e6, 2), "dec_MBps": round(n / t_dec / 1e6, 2),
             "bit_exact_vs_reference": bit_exact,
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "end_to_end": e2e,
         }
         print(json.dumps(result))
     if world > 1:

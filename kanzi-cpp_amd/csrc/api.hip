@@ -397,6 +397,7 @@ static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t 
     // device-side positions of a batch are 32-bit (suffix array slots, bit offsets inside staging areas): a batch
     // is limited to 2 GiB of input; the host layers split larger inputs into several calls
     if (n > (size_t)0x7FFFFFFF - 8ull * (size_t)(nBlocks + 1) * 1056) return fail(c, KNZ_ERR_INVALID_PARAM, "batch of %zu bytes exceeds the 2 GiB per-call limit", n);
+    if ((prologueBits + 7) / 8 > 200) return fail(c, KNZ_ERR_INVALID_PARAM, "prologue too long");
     const size_t needOut = ((size_t)prologueBits + 7) / 8 + 16;
     if (outCap < needOut) return fail(c, KNZ_ERR_WRITE_FILE, "output buffer too small");
     u64* d_total;
@@ -536,7 +537,7 @@ static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t 
     HIPCHK(c, hipStreamSynchronize(s));
     const u64 totalBits = *h_total;
     const size_t outBytes = (size_t)((totalBits + 7) >> 3);
-    if (outBytes + 8 > outCap) return fail(c, KNZ_ERR_WRITE_FILE, "output buffer too small: need %zu have %zu", outBytes + 8, outCap);
+    if (((outBytes + 8 + 3) & ~(size_t)3) > outCap) return fail(c, KNZ_ERR_WRITE_FILE, "output buffer too small: need %zu have %zu", (outBytes + 8 + 3) & ~(size_t)3, outCap);
     {
         ProfScope ps(c, "memset_out");
         HIPCHK(c, hipMemsetAsync(d_out, 0, (outBytes + 8 + 3) & ~(size_t)3, s));
@@ -544,7 +545,6 @@ static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t 
     if (prologueBits) {
         u8* d_pro;
         if (int r = ws_get(c, "prologue", 256, (void**)&d_pro)) return r;
-        if ((prologueBits + 7) / 8 > 200) return fail(c, KNZ_ERR_INVALID_PARAM, "prologue too long");
         HIPCHK(c, hipMemcpyAsync(d_pro, prologue, (prologueBits + 7) / 8, hipMemcpyHostToDevice, s));
         launch_put_prologue(s, reinterpret_cast<u32*>(d_out), d_pro, prologueBits);
     }
@@ -581,6 +581,7 @@ static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_
     if ((reinterpret_cast<uintptr_t>(d_in) & 15) || (reinterpret_cast<uintptr_t>(d_out) & 15))
         return fail(c, KNZ_ERR_INVALID_PARAM, "device buffers must be 16-byte aligned");
     const u32 bs = (u32)p->block_size;
+    if (framing && (bs < 1024 || bs > (1u << 30) || (bs & 15))) return fail(c, KNZ_ERR_INVALID_PARAM, "invalid block size %u", bs);
     int tok[8];
     const int nTok = count_transforms(p->transform_type, tok);
     for (int i = 0; i < nTok; i++)
@@ -633,7 +634,7 @@ static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_
     launch_check_prelen(s, d_blocks, nBlocks, realStages ? maxPre : unit, realStages ? ~0ull : (u64)outCap, outStride);
     u32 realMask = 0;
     for (int i = 0; i < nTok; i++) if (tok[i] != KNZ_T_NONE) realMask |= 1u << (7 - i);
-    launch_seq_inv_entropy_dst(s, w.a, d_blocks, nBlocks, d_out, outStride, w.A, S, w.d_entDst, realMask);
+    launch_seq_inv_entropy_dst(s, w.a, d_blocks, nBlocks, d_out, outStride, w.A, S, w.d_entDst, realMask, unit, (u64)outCap);
     if (p->entropy_type == KNZ_E_ANS0) {
         void* d_meta;
         if (int r = ws_get(c, "ansDecChunks", ans0_dec_chunk_bytes() * nSlots, &d_meta)) return r;

@@ -233,7 +233,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     const size_t maxTotal = (size_t)st.nBlocks * v.VS;
     BwtScratch w;
     carve(reinterpret_cast<u8*>(scratch), st.nBlocks, v.VS, maxTotal, scratchBytes, &w);
-    { KScope ks_("k_bwt_bases"); hipLaunchKernelGGL(k_bwt_bases, dim3(1), dim3(64), 0, s, v, w.base, st.ok); }
+    { KScope ks_("k_bwt_f_bases"); hipLaunchKernelGGL(k_bwt_bases, dim3(1), dim3(64), 0, s, v, w.base, st.ok); }
     hipMemsetAsync(st.newLen, 0, sizeof(u32) * st.nBlocks, s);
     if (hipMemcpyAsync(h_pinned, w.base + st.nBlocks, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
     if (hipStreamSynchronize(s) != hipSuccess) return -1;
@@ -245,18 +245,18 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     const dim3 gridB((unsigned)std::min<size_t>(((size_t)v.VS + 255) / 256, 4096), st.nBlocks);
     { KScope ks_("k_bwt_f_init"); hipLaunchKernelGGL(k_bwt_f_init, gridB, dim3(256), 0, s, v, w.base, st.ok, bbits, nsym, w.keysA, w.valsA); }
     size_t pb = w.primBytes;
-    { KScope ks_("rocprim_sort_round0");
+    { KScope ks_("bwt_f_sort_round0");
       if (rocprim::radix_sort_pairs(w.prim, pb, w.keysA, w.keysB, w.valsA, w.valsB, (size_t)total, 0u, (unsigned)(bbits + 9 * nsym), s) != hipSuccess) return -1; }
-    { KScope ks_("k_bwt_flags"); hipLaunchKernelGGL(k_bwt_flags, GRID1(total), w.keysB, total, w.t0); }
+    { KScope ks_("k_bwt_f_flags"); hipLaunchKernelGGL(k_bwt_flags, GRID1(total), w.keysB, total, w.t0); }
     pb = w.primBytes;
-    { KScope ks_("rocprim_scan_max"); if (rocprim::inclusive_scan(w.prim, pb, w.t0, w.t1, (size_t)total, rocprim::maximum<u32>(), s) != hipSuccess) return -1; }
-    { KScope ks_("k_bwt_round0"); hipLaunchKernelGGL(k_bwt_round0, GRID1(total), w.keysB, w.valsB, w.t1, total, w.SA, w.rank, w.t0); }
+    { KScope ks_("bwt_f_scan_max"); if (rocprim::inclusive_scan(w.prim, pb, w.t0, w.t1, (size_t)total, rocprim::maximum<u32>(), s) != hipSuccess) return -1; }
+    { KScope ks_("k_bwt_f_round0"); hipLaunchKernelGGL(k_bwt_round0, GRID1(total), w.keysB, w.valsB, w.t1, total, w.SA, w.rank, w.t0); }
     // active slots = members of groups with more than one element
     u32 nAct = total;
     auto compact = [&](u32 n, const u32* value, u32* out) -> int {
         size_t pbs = w.primBytes;
-        { KScope ks_("rocprim_scan_sum"); if (rocprim::exclusive_scan(w.prim, pbs, w.t0, w.t1, 0u, (size_t)n, rocprim::plus<u32>(), s) != hipSuccess) return -1; }
-        { KScope ks_("k_compact"); hipLaunchKernelGGL(k_compact, GRID1(n), w.t0, w.t1, value, n, out); }
+        { KScope ks_("bwt_f_scan_sum"); if (rocprim::exclusive_scan(w.prim, pbs, w.t0, w.t1, 0u, (size_t)n, rocprim::plus<u32>(), s) != hipSuccess) return -1; }
+        { KScope ks_("k_bwt_f_compact"); hipLaunchKernelGGL(k_compact, GRID1(n), w.t0, w.t1, value, n, out); }
         // count = scan[n-1] + keep[n-1]
         hipMemcpyAsync(h_pinned, w.t1 + (n - 1), 4, hipMemcpyDeviceToHost, s);
         hipMemcpyAsync(h_pinned + 1, w.t0 + (n - 1), 4, hipMemcpyDeviceToHost, s);
@@ -271,13 +271,13 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     u32 h = (u32)nsym;
     u32* act = w.act; u32* act2 = w.act2;
     while (nAct > 0) {
-        { KScope ks_("k_bwt_keys"); hipLaunchKernelGGL(k_bwt_keys, GRID1(nAct), v, act, nAct, w.SA, w.rank, h, rbits, w.keysA, w.valsA); }
+        { KScope ks_("k_bwt_f_keys"); hipLaunchKernelGGL(k_bwt_keys, GRID1(nAct), v, act, nAct, w.SA, w.rank, h, rbits, w.keysA, w.valsA); }
         pb = w.primBytes;
-        { KScope ks_("rocprim_sort_round"); if (rocprim::radix_sort_pairs(w.prim, pb, w.keysA, w.keysB, w.valsA, w.valsB, (size_t)nAct, 0u, (unsigned)(2 * rbits), s) != hipSuccess) return -1; }
-        { KScope ks_("k_bwt_flags"); hipLaunchKernelGGL(k_bwt_flags, GRID1(nAct), w.keysB, nAct, w.t0); }
+        { KScope ks_("bwt_f_sort_round"); if (rocprim::radix_sort_pairs(w.prim, pb, w.keysA, w.keysB, w.valsA, w.valsB, (size_t)nAct, 0u, (unsigned)(2 * rbits), s) != hipSuccess) return -1; }
+        { KScope ks_("k_bwt_f_flags"); hipLaunchKernelGGL(k_bwt_flags, GRID1(nAct), w.keysB, nAct, w.t0); }
         pb = w.primBytes;
-        { KScope ks_("rocprim_scan_max"); if (rocprim::inclusive_scan(w.prim, pb, w.t0, w.t1, (size_t)nAct, rocprim::maximum<u32>(), s) != hipSuccess) return -1; }
-        { KScope ks_("k_bwt_place"); hipLaunchKernelGGL(k_bwt_place, GRID1(nAct), act, nAct, w.keysB, w.valsB, w.t1, w.SA, w.rank, w.t0); }
+        { KScope ks_("bwt_f_scan_max"); if (rocprim::inclusive_scan(w.prim, pb, w.t0, w.t1, (size_t)nAct, rocprim::maximum<u32>(), s) != hipSuccess) return -1; }
+        { KScope ks_("k_bwt_f_place"); hipLaunchKernelGGL(k_bwt_place, GRID1(nAct), act, nAct, w.keysB, w.valsB, w.t1, w.SA, w.rank, w.t0); }
         cnt = compact(nAct, act, act2);
         if (cnt < 0) return -1;
         nAct = (u32)cnt;
@@ -495,12 +495,12 @@ int launch_bwt_inverse(hipStream_t s, const XfStage& st, void* scratch, size_t s
     size_t pb = primBytes;
     int bbits = 0;
     while ((1 << bbits) < st.nBlocks) bbits++;
-    { KScope ks_("rocprim_sort_symbols"); if (rocprim::radix_sort_pairs(prim, pb, keysA, keysB, valsA, valsB, (size_t)total, 0u, (unsigned)(8 + bbits), s) != hipSuccess) return -1; }
+    { KScope ks_("bwt_i_sort_symbols"); if (rocprim::radix_sort_pairs(prim, pb, keysA, keysB, valsA, valsB, (size_t)total, 0u, (unsigned)(8 + bbits), s) != hipSuccess) return -1; }
     { KScope ks_("k_bwt_i_links"); hipLaunchKernelGGL(k_bwt_i_links, GRID1(total), hd, base, total, keysB, valsB, rec, flags); }
     { KScope ks_("k_bwt_i_fold"); hipLaunchKernelGGL(k_bwt_i_fold, GRID1(total), rec, flags, total); }
     pb = primBytes;
-    { KScope ks_("rocprim_scan_sum"); if (rocprim::exclusive_scan(prim, pb, flags, scanIdx, 0u, (size_t)total, rocprim::plus<u32>(), s) != hipSuccess) return -1; }
-    { KScope ks_("k_compact"); hipLaunchKernelGGL(k_compact, GRID1(total), flags, scanIdx, (const u32*)nullptr, total, splitNode); }
+    { KScope ks_("bwt_i_scan_sum"); if (rocprim::exclusive_scan(prim, pb, flags, scanIdx, 0u, (size_t)total, rocprim::plus<u32>(), s) != hipSuccess) return -1; }
+    { KScope ks_("k_bwt_i_compact"); hipLaunchKernelGGL(k_compact, GRID1(total), flags, scanIdx, (const u32*)nullptr, total, splitNode); }
     hipMemcpyAsync(h_pinned, scanIdx + (total - 1), 4, hipMemcpyDeviceToHost, s);
     hipMemcpyAsync(h_pinned + 1, flags + (total - 1), 4, hipMemcpyDeviceToHost, s);
     if (hipStreamSynchronize(s) != hipSuccess) return -1;

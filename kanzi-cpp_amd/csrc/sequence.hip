@@ -89,13 +89,21 @@ __global__ void k_seq_fwd_direct(SeqArrays a, u32* origLen, u64 n, u32 blockSize
 }
 
 // ---- inverse
-__global__ void k_seq_inv_entropy_dst(SeqArrays a, DecBlock* blocks, int nBlocks, u8* out, u64 outStride, u8* A, u64 S, u8** entDst, u32 realMask)
+__global__ void k_seq_inv_entropy_dst(SeqArrays a, DecBlock* blocks, int nBlocks, u8* out, u64 outStride, u8* A, u64 S, u8** entDst, u32 realMask,
+                                      u32 unit, u64 outCap)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nBlocks) return;
-    const DecBlock& db = blocks[b];
+    DecBlock& db = blocks[b];
     // realMask: bit (7-i) set for every non-NONE stage i of the sequence
     const bool any = !db.copyBlock && ((~db.skipFlags) & realMask & 0xFF) != 0;
+    // A block no inverse stage will touch is entropy-decoded straight into the caller's buffer: it has to fit its
+    // own slot there (TransformSequence::inverse refuses count > output room, TransformSequence.hpp:165-247).
+    if (!any && !db.error) {
+        const u64 at = (u64)b * outStride;
+        const u64 room = at < outCap ? outCap - at : 0;
+        if (db.preLen > unit || (u64)db.preLen > room) db.error = KNZ_ERR_PROCESS_BLOCK;
+    }
     a.skip[b] = db.copyBlock ? 0xFF : (u8)db.skipFlags;
     a.where[b] = any ? 1 : 0;
     a.len[b] = db.preLen;
@@ -152,8 +160,9 @@ void launch_seq_fwd_null(hipStream_t s, const SeqArrays& a, int nBlocks, int sta
 { KScope ks_("k_seq_fwd_null"); L1D(k_seq_fwd_null, a, nBlocks, stage); }
 void launch_seq_fwd_finish(hipStream_t s, const SeqArrays& a, int nBlocks, const u8* in, u64 inStride, u8* A, u8* B, u64 S, const u8** viewPtr)
 { KScope ks_("k_seq_fwd_finish"); L1D(k_seq_fwd_finish, a, nBlocks, in, inStride, A, B, S, viewPtr); }
-void launch_seq_inv_entropy_dst(hipStream_t s, const SeqArrays& a, DecBlock* blocks, int nBlocks, u8* out, u64 outStride, u8* A, u64 S, u8** entDst, u32 realMask)
-{ KScope ks_("k_seq_inv_entropy_dst"); L1D(k_seq_inv_entropy_dst, a, blocks, nBlocks, out, outStride, A, S, entDst, realMask); }
+void launch_seq_inv_entropy_dst(hipStream_t s, const SeqArrays& a, DecBlock* blocks, int nBlocks, u8* out, u64 outStride, u8* A, u64 S, u8** entDst, u32 realMask,
+                                u32 unit, u64 outCap)
+{ KScope ks_("k_seq_inv_entropy_dst"); L1D(k_seq_inv_entropy_dst, a, blocks, nBlocks, out, outStride, A, S, entDst, realMask, unit, outCap); }
 void launch_seq_inv_prepare(hipStream_t s, const SeqArrays& a, DecBlock* blocks, int nBlocks, int stage, u8* out, u64 outStride, u8* A, u8* B, u64 S, u32 capMid, u32 capFinal, u32 realMask, u64 outCap)
 { KScope ks_("k_seq_inv_prepare"); L1D(k_seq_inv_prepare, a, blocks, nBlocks, stage, out, outStride, A, B, S, capMid, capFinal, realMask, outCap); }
 void launch_seq_inv_commit(hipStream_t s, const SeqArrays& a, DecBlock* blocks, int nBlocks, int stage, int ttype)

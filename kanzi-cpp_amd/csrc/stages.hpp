@@ -119,7 +119,7 @@ void launch_seq_fwd_prepare(hipStream_t s, const SeqArrays& a, int nBlocks, int 
 void launch_seq_fwd_null(hipStream_t s, const SeqArrays& a, int nBlocks, int stage);
 void launch_seq_fwd_commit(hipStream_t s, const SeqArrays& a, int nBlocks, int stage);
 void launch_seq_fwd_finish(hipStream_t s, const SeqArrays& a, int nBlocks, const u8* in, u64 inStride, u8* A, u8* B, u64 S, const u8** viewPtr);
-void launch_seq_inv_entropy_dst(hipStream_t s, const SeqArrays& a, DecBlock* blocks, int nBlocks, u8* out, u64 outStride, u8* A, u64 S, u8** entDst, u32 realMask);
+void launch_seq_inv_entropy_dst(hipStream_t s, const SeqArrays& a, DecBlock* blocks, int nBlocks, u8* out, u64 outStride, u8* A, u64 S, u8** entDst, u32 realMask, u32 unit, u64 outCap);
 void launch_seq_inv_prepare(hipStream_t s, const SeqArrays& a, DecBlock* blocks, int nBlocks, int stage, u8* out, u64 outStride, u8* A, u8* B, u64 S, u32 capMid, u32 capFinal, u32 realMask, u64 outCap);
 void launch_seq_inv_commit(hipStream_t s, const SeqArrays& a, DecBlock* blocks, int nBlocks, int stage, int ttype);
 

@@ -132,7 +132,7 @@ class Context:
     def d2h(self, dptr, n):
         buf = (C.c_uint8 * max(1, n))()
         self._chk(self.L.knz_hip_memcpy_d2h(self.h, buf, C.c_void_p(dptr), n))
-        return bytes(buf[:n])
+        return C.string_at(buf, n)
 
     def sync(self):
         self._chk(self.L.knz_hip_sync(self.h))
@@ -169,7 +169,7 @@ class Context:
         out = (C.c_uint8 * cap)()
         bits = C.c_uint64(0)
         self._chk(self.L.knz_hip_entropy_encode(self.h, e, data, len(data), out, cap, C.byref(bits)))
-        return bytes(out[:(bits.value + 7) // 8]), bits.value
+        return C.string_at(out, (bits.value + 7) // 8), bits.value
 
     def entropy_decode(self, entropy, enc, n, start_bit=0, in_bits=None):
         e = ENTROPY_IDS[entropy.upper()]
@@ -178,7 +178,7 @@ class Context:
         if in_bits is None:
             in_bits = 8 * len(enc)
         self._chk(self.L.knz_hip_entropy_decode(self.h, e, enc, in_bits, start_bit, out, n, C.byref(dec), C.byref(used)))
-        return dec.value, bytes(out[:n]), used.value
+        return dec.value, C.string_at(out, n), used.value
 
     def transform_forward(self, transform, data, dst_cap, entropy=None):
         t = TRANSFORM_IDS[transform.upper()]
@@ -186,20 +186,20 @@ class Context:
         ol, ok = C.c_int32(0), C.c_int32(0)
         e = ENTROPY_IDS[entropy.upper()] if entropy else -1
         self._chk(self.L.knz_hip_transform_forward(self.h, t, data, len(data), out, dst_cap, e, C.byref(ol), C.byref(ok)))
-        return ok.value, bytes(out[:ol.value])
+        return ok.value, C.string_at(out, ol.value)
 
     def transform_inverse(self, transform, data, dst_cap):
         t = TRANSFORM_IDS[transform.upper()]
         out = (C.c_uint8 * (dst_cap + 64))()
         ol, ok = C.c_int32(0), C.c_int32(0)
         self._chk(self.L.knz_hip_transform_inverse(self.h, t, data, len(data), out, dst_cap, C.byref(ol), C.byref(ok)))
-        return ok.value, bytes(out[:ol.value])
+        return ok.value, C.string_at(out, ol.value)
 
     # ---- profiling
     def set_profiling(self, on):
         self.L.knz_hip_set_profiling(self.h, 1 if on else 0)
 
     def kernel_times(self):
-        arr = (KernelTime * 64)()
-        n = self.L.knz_hip_get_kernel_times(self.h, arr, 64)
+        arr = (KernelTime * 256)()
+        n = self.L.knz_hip_get_kernel_times(self.h, arr, 256)
         return [(arr[i].name.decode(), arr[i].ms, arr[i].launches) for i in range(n)]

@@ -806,12 +806,6 @@ bool CompressedInputStream::fetch(size_t minBytes)
     const size_t have = _comp.size() - size_t(_compBit >> 3);
     if (have >= minBytes) return true;
     if (_srcEof) return false;
-    if ((_compBit >> 3) > (size_t(1) << 24)) {   // drop consumed bytes, keep 16-byte alignment of the remainder
-        const size_t drop = size_t(_compBit >> 3) & ~size_t(15);
-        _comp.erase(_comp.begin(), _comp.begin() + drop);
-        _compBit -= uint64(drop) * 8;
-        _originBit += int64(drop) * 8;
-    }
     size_t want = std::max<size_t>(minBytes - have, size_t(1) << 20);
     const size_t old = _comp.size();
     _comp.resize(old + want);
@@ -861,6 +855,14 @@ bool CompressedInputStream::decodeBatch()
 {
     if (_ended) return false;
     readHeader();
+    // Drop the consumed prefix of the fetched bytes here, once per batch, before any bit cursor of the walk below
+    // is taken: the walk keeps positions relative to _comp, so nothing may rebase them while it runs.
+    if ((_compBit >> 3) > (size_t(1) << 20)) {   // keep 16-byte alignment of the remainder
+        const size_t drop = size_t(_compBit >> 3) & ~size_t(15);
+        _comp.erase(_comp.begin(), _comp.begin() + drop);
+        _compBit -= uint64(drop) * 8;
+        _originBit += int64(drop) * 8;
+    }
     // walk the block length prefixes on the host (framing only) to find complete blocks
     uint64 pos = _compBit;
     int nb = 0;

@@ -9,6 +9,7 @@
 //   * whole stream           -> CompressedOutputStream / CompressedInputStream (src/io/*.hpp)
 // Built only where /root/reference exists (this container); the resulting .so lives in
 // oracle/_ref/ (git-ignored, travels with gpurun) and is used as cpu_baseline "reference".
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <sstream>
@@ -213,6 +214,26 @@ int ref_decompress_stream(const uint8_t* in, size_t inLen, int jobs, uint8_t* ou
     } catch (const std::exception&) {
         return -1;
     }
+}
+
+// Compress + decompress one buffer, timed inside C with a steady clock around the stream objects only
+// (construction .. close), so that no caller-side marshalling is inside the figures bench.py reports as
+// cpu_baseline. Buffers are the caller's; `back` must hold n bytes. Returns 0, an error code, or -4 when
+// the round trip does not reproduce the input.
+int ref_time_roundtrip(const uint8_t* in, size_t n, const char* transform, const char* entropy, int blockSize, int jobs,
+                       uint8_t* comp, size_t compCap, size_t* compLen, uint8_t* back, double* encSec, double* decSec)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = ref_compress_stream(in, n, transform, entropy, blockSize, jobs, 0, 0ull, 0, comp, compCap, compLen);
+    const auto t1 = std::chrono::steady_clock::now();
+    if (rc != 0) return rc;
+    size_t got = 0;
+    rc = ref_decompress_stream(comp, *compLen, jobs, back, n, &got);
+    const auto t2 = std::chrono::steady_clock::now();
+    if (rc != 0) return rc;
+    *encSec = std::chrono::duration<double>(t1 - t0).count();
+    *decSec = std::chrono::duration<double>(t2 - t1).count();
+    return (got == n && memcmp(in, back, n) == 0) ? 0 : -4;
 }
 
 }

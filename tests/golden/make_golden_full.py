@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/golden_full.json: md5 + length of the UNMODIFIED reference's .knz (oracle/_ref) for the
+BASELINE.json configurations at their own block sizes (vectors.FULL_CASES), 64 MiB inputs, -j 1.
+
+    make -C oracle ref && python tests/golden/make_golden_full.py
+
+Data only (input specs + digests of the reference's output); nothing of the reference's sources is stored.
+"""
+import hashlib
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import knzlib  # noqa: E402
+import vectors  # noqa: E402
+
+
+def main():
+    R = knzlib.Ref()
+    out = []
+    for cfg, spec, t, e, bs in vectors.FULL_CASES:
+        d = vectors.make(spec)
+        rc, o = R.compress(d, t, e, bs, jobs=1, orig_size=len(d))
+        assert rc == 0, (cfg, rc)
+        rc, back = R.decompress(o, len(d))
+        assert rc == 0 and back == d, cfg
+        out.append({"config": cfg, "input": list(spec), "input_md5": hashlib.md5(d).hexdigest(), "transform": t, "entropy": e,
+                    "block": bs, "orig_size": len(d), "out": {"len": len(o), "md5": hashlib.md5(o).hexdigest()}})
+        print(out[-1], flush=True)
+    json.dump(out, open(os.path.join(HERE, "golden_full.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -98,12 +98,12 @@ class Oracle:
         bits = self.L.knzo_entropy_encode(ETYPE[name], _buf(data), len(data), out, cap)
         if bits < 0:
             return None, bits
-        return bytes(out[:(bits + 7) // 8]), bits
+        return C.string_at(out, (bits + 7) // 8), bits
 
     def entropy_decode(self, name, enc, n):
         out = (C.c_uint8 * max(1, n))()
         r = self.L.knzo_entropy_decode(ETYPE[name], _buf(enc), len(enc), out, n)
-        return r, bytes(out[:n])
+        return r, C.string_at(out, n)
 
     def forward(self, name, data, dst_cap=None, entropy=None):
         cap = dst_cap if dst_cap is not None else len(data) + 2048
@@ -111,19 +111,19 @@ class Oracle:
         ol = C.c_int(0)
         e = ETYPE[entropy] if entropy else -1
         ok = self.L.knzo_transform_forward(TTYPE[name], _buf(data), len(data), out, cap, e, C.byref(ol))
-        return ok, bytes(out[:ol.value])
+        return ok, C.string_at(out, ol.value)
 
     def inverse(self, name, data, dst_cap):
         out = (C.c_uint8 * (dst_cap + 64))()
         ol = C.c_int(0)
         ok = self.L.knzo_transform_inverse(TTYPE[name], _buf(data), len(data), out, dst_cap, C.byref(ol))
-        return ok, bytes(out[:ol.value])
+        return ok, C.string_at(out, ol.value)
 
     def bwt_raw(self, data):
         out = (C.c_uint8 * max(1, len(data)))()
         prim = (C.c_int * 8)()
         ok = self.L.knzo_bwt_forward_raw(_buf(data), len(data), out, prim)
-        return ok, bytes(out[:len(data)]), list(prim)
+        return ok, C.string_at(out, len(data)), list(prim)
 
     def compress(self, data, transform, entropy, block_size, checksum=0, orig_size=0, headerless=0, jobs=1):
         cap = len(data) + len(data) // 2 + (1 << 20)
@@ -131,7 +131,7 @@ class Oracle:
         ol = C.c_size_t(0)
         rc = self.L.knzo_compress_jobs(_buf(data), len(data), transform.encode(), entropy.encode(), block_size,
                                        checksum, orig_size, headerless, jobs, out, cap, C.byref(ol))
-        return rc, bytes(out[:ol.value])
+        return rc, C.string_at(out, ol.value)
 
     def compress_run(self, data, transform, entropy, block_size, first_block, finish, jobs=1, headerless=1, orig_size=0):
         """Blocks [first_block, ...) of a stream as a bit run: returns (rc, bytes, nbits)."""
@@ -140,13 +140,13 @@ class Oracle:
         ol, ob = C.c_size_t(0), C.c_uint64(0)
         rc = self.L.knzo_compress_run(_buf(data), len(data), transform.encode(), entropy.encode(), block_size, 0, orig_size,
                                       headerless, jobs, first_block, 1 if finish else 0, out, cap, C.byref(ol), C.byref(ob))
-        return rc, bytes(out[:ol.value]), ob.value
+        return rc, C.string_at(out, ol.value), ob.value
 
     def decompress(self, enc, cap):
         out = (C.c_uint8 * max(1, cap))()
         ol = C.c_size_t(0)
         rc = self.L.knzo_decompress(_buf(enc), len(enc), out, cap, C.byref(ol))
-        return rc, bytes(out[:ol.value])
+        return rc, C.string_at(out, ol.value)
 
 
 class Ref:
@@ -176,12 +176,12 @@ class Ref:
         bits = self.L.ref_entropy_encode(name.encode(), _buf(data), len(data), out, cap)
         if bits < 0:
             return None, bits
-        return bytes(out[:(bits + 7) // 8]), bits
+        return C.string_at(out, (bits + 7) // 8), bits
 
     def entropy_decode(self, name, enc, n):
         out = (C.c_uint8 * max(1, n))()
         r = self.L.ref_entropy_decode(name.encode(), _buf(enc), len(enc), out, n)
-        return r, bytes(out[:n])
+        return r, C.string_at(out, n)
 
     def forward(self, name, data, dst_cap=None, entropy=None, src_cap=0):
         cap = dst_cap if dst_cap is not None else len(data) + 2048
@@ -190,7 +190,7 @@ class Ref:
         sk = C.c_int(0)
         ok = self.L.ref_transform(name.encode(), 1, _buf(data), len(data), src_cap, out, cap,
                                   (entropy or "").encode(), C.byref(ol), C.byref(sk))
-        return ok, bytes(out[:ol.value]), sk.value
+        return ok, C.string_at(out, ol.value), sk.value
 
     def inverse(self, name, data, dst_cap, skip=0, src_cap=0):
         out = (C.c_uint8 * (dst_cap + 64))()
@@ -198,14 +198,14 @@ class Ref:
         sk = C.c_int(skip)
         ok = self.L.ref_transform(name.encode(), 0, _buf(data), len(data), src_cap, out, dst_cap, b"",
                                   C.byref(ol), C.byref(sk))
-        return ok, bytes(out[:ol.value])
+        return ok, C.string_at(out, ol.value)
 
     def sbrt(self, mode, forward, data):
         """SBRT(mode) constructed directly (mode 3, TIMESTAMP, has no transform id)."""
         out = (C.c_uint8 * max(1, len(data)))()
         ol = C.c_int(0)
         ok = self.L.ref_sbrt(mode, 1 if forward else 0, _buf(data), len(data), out, len(data), C.byref(ol))
-        return ok, bytes(out[:ol.value])
+        return ok, C.string_at(out, ol.value)
 
     def compress(self, data, transform, entropy, block_size, jobs=1, checksum=0, orig_size=0, headerless=0):
         cap = len(data) + len(data) // 2 + (1 << 20)
@@ -213,10 +213,10 @@ class Ref:
         ol = C.c_size_t(0)
         rc = self.L.ref_compress_stream(_buf(data), len(data), transform.encode(), entropy.encode(), block_size,
                                         jobs, checksum, orig_size, headerless, out, cap, C.byref(ol))
-        return rc, bytes(out[:ol.value])
+        return rc, C.string_at(out, ol.value)
 
     def decompress(self, enc, cap, jobs=1):
         out = (C.c_uint8 * max(1, cap))()
         ol = C.c_size_t(0)
         rc = self.L.ref_decompress_stream(_buf(enc), len(enc), jobs, out, cap, C.byref(ol))
-        return rc, bytes(out[:ol.value])
+        return rc, C.string_at(out, ol.value)

@@ -154,3 +154,28 @@ def test_threads_share_the_device(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_threads.py")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_multi_batch_stream_beyond_compaction_threshold(tmp_path, monkeypatch):
+    # Regression (round-1 advisor finding): the input stream drops the consumed prefix of its fetch buffer; that must
+    # never happen while the host walk holds bit cursors into it. 40 incompressible 1 MiB blocks = 40 MiB of
+    # compressed data, decoded in batches of 3 blocks, so many batches start beyond the compaction threshold.
+    import numpy as np
+    monkeypatch.setenv("KNZ_BATCH_BLOCKS", "3")
+    kz = _kanzi()
+    bs = 1 << 20
+    data = np.random.default_rng(5).integers(0, 256, 40 * bs + 12345, dtype=np.uint8).tobytes()
+    path = str(tmp_path / "big.knz")
+    with kz.Compressor(path, "NONE", "NONE", bs, 1) as c:
+        for off in range(0, len(data), bs):
+            c.compress(data[off:off + bs])
+    assert os.path.getsize(path) > 40 * bs
+    d = kz.Decompressor(path, buffer_size=bs, jobs=1)
+    out = bytearray()
+    while True:
+        chunk = d.decompress(bs)
+        out += chunk
+        if len(chunk) < bs:
+            break
+    d.close()
+    assert bytes(out) == data

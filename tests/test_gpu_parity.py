@@ -268,15 +268,47 @@ def test_lz_block_groups_and_long_matches(hip, oracle):
         assert k == 1 and back == d, t
 
 
-def test_full_size_roundtrip_properties(hip):
-    # BASELINE config 2 geometry (4 MiB blocks): round trip + determinism on 32 MiB, checked on the device side
+def _full_case(hip, config):
+    """BASELINE config `config` at its own block size on 64 MiB: the device stream must be the reference's .knz
+    (md5 + length from oracle/_ref, tests/golden/golden_full.json), and must decode back to the input."""
+    import json
+    recs = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_full.json")))
+    rec = [r for r in recs if r["config"] == config][0]
+    d = vectors.make(tuple(rec["input"]))
+    assert hashlib.md5(d).hexdigest() == rec["input_md5"]
+    out, bits, hb = gpu_compress(hip, d, rec["transform"], rec["entropy"], rec["block"], orig_size=rec["orig_size"])
+    assert len(out) == rec["out"]["len"], (config, len(out), rec["out"]["len"])
+    assert hashlib.md5(out).hexdigest() == rec["out"]["md5"], config
+    assert gpu_decompress(hip, out, rec["transform"], rec["entropy"], rec["block"], len(d), hb) == d, config
+
+
+def test_full_size_reference_stream_config1_huffman_4m(hip):
+    _full_case(hip, 1)
+
+
+def test_full_size_reference_stream_config2_ans0_4m(hip):
+    _full_case(hip, 2)
+
+
+def test_full_size_reference_stream_config3_bwt_mtft_zrlt_ans0_8m(hip):
+    _full_case(hip, 3)
+
+
+def test_full_size_reference_stream_config4_bwt_srt_zrlt_fpaq_32m(hip):
+    _full_case(hip, 4)
+
+
+def test_full_size_reference_stream_config5_lzx_ans1_16m(hip):
+    _full_case(hip, 5)
+
+
+def test_full_size_determinism(hip):
+    # two encodes of the same batch give the same bytes (no dependence on what earlier calls left in the workspaces)
     d = vectors.make(("mixed", 32 << 20, 2))
-    for t, e, bs in [("NONE", "ANS0", 4 << 20), ("NONE", "HUFFMAN", 4 << 20), ("BWT+MTFT+ZRLT", "ANS0", 8 << 20),
-                     ("BWT+SRT+ZRLT", "FPAQ", 32 << 20), ("NONE", "ANS1", 16 << 20)]:
+    for t, e, bs in [("NONE", "ANS0", 4 << 20), ("BWT+MTFT+ZRLT", "ANS0", 8 << 20), ("NONE", "ANS1", 16 << 20)]:
         out1, bits1, _ = gpu_compress(hip, d, t, e, bs, headerless=1)
         out2, bits2, _ = gpu_compress(hip, d, t, e, bs, headerless=1)
         assert out1 == out2, (t, e)
-        assert gpu_decompress(hip, out1, t, e, bs, len(d), 0) == d, (t, e)
 
 
 def test_sharded_runs_concatenate_to_single_stream(hip, oracle):
@@ -294,6 +326,24 @@ def test_sharded_runs_concatenate_to_single_stream(hip, oracle):
         got = sh.concat_bit_runs(runs)[0]
         rc, ref = oracle.compress(d, t, e, bs, orig_size=len(d), jobs=jobs)
         assert got == ref, (t, e, jobs)
+
+
+def test_sharded_decode_ranges(hip, oracle):
+    # decode side of the multi-GPU path on one device: the host walks the length prefixes, each "rank" decodes its own
+    # contiguous range of blocks from its own slice of the stream, the ranges are placed in order
+    sh = importlib.import_module("kanzi_amd.sharded")
+    d = vectors.make(("mixed", 700001, 11))
+    for t, e, bs, world in [("BWT+MTFT+ZRLT", "ANS0", 65536, 3), ("NONE", "HUFFMAN", 16384, 2), ("BWT+SRT+ZRLT", "ANS0", 262144, 4)]:
+        rc, ref = oracle.compress(d, t, e, bs, orig_size=len(d))
+        assert rc == 0
+        dec = sh.DeviceRunDecoder(0)
+        parts = [None] * world
+        for r in range(world):
+            def gather(obj, r=r):
+                parts[r] = obj
+                return None
+            sh.decompress_sharded(ref, r, world, dec, gather)
+        assert b"".join(parts) == d, (t, e, world)
 
 
 def test_block_checksums(hip, oracle):

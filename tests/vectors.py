@@ -101,3 +101,14 @@ STREAM_CASES = [
     (("const", 100000, 0), "LZ", "NONE", 65536, 0, 0),
     (("mixed", 1 << 20, 3), "BWT+RANK+ZRLT", "ANS0", 1 << 18, 0, 0),
 ]
+
+# BASELINE.json configurations at their own block sizes on 64 MiB of the stand-in corpora: the reference's .knz is
+# pinned by md5 + length in tests/golden/golden_full.json (tests/golden/make_golden_full.py, run where oracle/_ref exists).
+FULL_CASES = [
+    # (config number, input spec, transform, entropy, block size)
+    (1, ("mixed", 64 << 20, 2), "NONE", "HUFFMAN", 4 << 20),
+    (2, ("mixed", 64 << 20, 2), "NONE", "ANS0", 4 << 20),
+    (3, ("mixed", 64 << 20, 2), "BWT+MTFT+ZRLT", "ANS0", 8 << 20),
+    (4, ("text", 64 << 20, 1), "BWT+SRT+ZRLT", "FPAQ", 32 << 20),
+    (5, ("mixed", 64 << 20, 2), "LZX", "ANS1", 16 << 20),
+]
