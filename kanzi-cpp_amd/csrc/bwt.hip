@@ -1,4 +1,4 @@
-// Burrows-Wheeler transform (block codec) on gfx950, all blocks of a batch at once.
+// Inverse Burrows-Wheeler transform (block codec) on gfx950, all blocks of a batch at once (forward: bwt_fwd.hip).
 //
 // Reference being replaced (bit-identical results; the suffix array of a block is unique, so any
 // correct construction matches divsufsort):
@@ -10,106 +10,17 @@
 //            :295-492 (biPSIv2): both walk the psi permutation from the primary indexes
 //
 // GPU formulation
-//   forward  one suffix sort for the whole batch: the sort key carries the block id, suffix
-//            comparisons stop at the block end (rank 0 past the end = "shorter sorts first").
-//            Prefix doubling with group discarding (Larsson-Sadakane order refinement): round 0
-//            sorts 9-bit symbols packed in a 64-bit key, later rounds sort only the members of still
-//            unsorted groups on (group head, rank[i+h]). The two device-wide primitives (LSD radix
-//            sort of 64-bit keys, scans) come from rocPRIM; everything else is hand-written.
-//            (Measured alternative, rejected: rocprim::segmented_radix_sort_pairs on 32-bit rank[i+h] keys
-//            per group is 2.4x slower per round here -- tens of millions of tiny segments.)
-//   inverse  psi by a stable 8-bit counting sort of the BWT symbols, then list ranking by pointer
-//            jumping (log2 n rounds of next[next[j]]) gives every F-position its text offset; the
-//            8 chains the reference walks serially become one data-parallel scatter.
+//   inverse  psi by a stable 8-bit counting sort of the BWT symbols, then splitter-based list ranking (Helman-JaJa):
+//            the 8 chains the reference walks serially become ~n/64 independent ones.
 #include "common.hpp"
 #include "stages.hpp"
+#include "bwt_common.hpp"
 
 #include <cstring>
 #include <algorithm>
 #include <rocprim/rocprim.hpp>
 
 namespace knz {
-
-struct BwtView {
-    const u8* const* src;
-    u8* const* dst;
-    const u32* len;
-    const u32* cap;
-    u32 VS;                // virtual stride: position id = b * VS + offset
-    int nBlocks;
-};
-
-__device__ __forceinline__ int bwt_chunks(u32 n) { return n < 256 ? 1 : 8; }
-
-__device__ __forceinline__ bool bwt_fwd_applies(u32 n, u32 cap, u32* pIdxSizeOut)
-{
-    if (n == 0) return false;
-    if (cap < n + 33) return false;                       // getMaxEncodedLength, BWTBlockCodec.hpp:47-50
-    u32 logBlockSize = (u32)ilog2_u32(n);
-    if ((n & (n - 1)) != 0) logBlockSize++;
-    const u32 pIndexSize = (logBlockSize + 7) >> 3;
-    if (pIndexSize == 0 || pIndexSize >= 5) return false; // n == 1 -> 0 bytes -> refused (BWTBlockCodec.cpp:53-56)
-    *pIdxSizeOut = pIndexSize;
-    return true;
-}
-
-// base[b] = sum of active lengths of the blocks before b ; total in base[nBlocks]
-__global__ void k_bwt_bases(BwtView v, u32* __restrict__ base, u8* __restrict__ ok)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    u32 sum = 0;
-    for (int b = 0; b < v.nBlocks; b++) {
-        base[b] = sum;
-        u32 ps;
-        const bool a = bwt_fwd_applies(v.len[b], v.cap[b], &ps);
-        ok[b] = a ? 1 : 0;
-        if (a) sum += v.len[b];
-    }
-    base[v.nBlocks] = sum;
-}
-
-// round 0 keys: [block id | symbols as 9-bit values (byte + 1, 0 past the block end)]
-__global__ __launch_bounds__(256) void k_bwt_f_init(BwtView v, const u32* __restrict__ base, const u8* __restrict__ ok, int bbits, int nsym,
-                                                    u64* __restrict__ keys, u32* __restrict__ vals)
-{
-    const int b = blockIdx.y;
-    if (!ok[b]) return;
-    const u32 n = v.len[b];
-    const u8* s = v.src[b];
-    for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        u64 k = (u64)b;
-        for (int q = 0; q < nsym; q++) {
-            const u32 j = i + (u32)q;
-            k = (k << 9) | (j < n ? (u64)s[j] + 1 : 0ull);
-        }
-        (void)bbits;
-        keys[base[b] + i] = k;
-        vals[base[b] + i] = (u32)b * v.VS + i;
-    }
-}
-
-// flags[a] = 1 when element a starts a new group (differs from its predecessor)
-__global__ __launch_bounds__(256) void k_bwt_flags(const u64* __restrict__ keys, u32 n, u32* __restrict__ headIdx)
-{
-    const u32 a = blockIdx.x * 256 + threadIdx.x;
-    if (a >= n) return;
-    const bool f = (a == 0) || (keys[a] != keys[a - 1]);
-    headIdx[a] = f ? a : 0;
-}
-
-// first round: SA = sorted values; rank[pos] = group head slot; keep[a] = member of a group of size > 1
-__global__ __launch_bounds__(256) void k_bwt_round0(const u64* __restrict__ keys, const u32* __restrict__ vals, const u32* __restrict__ head, u32 n,
-                                                    u32* __restrict__ SA, u32* __restrict__ rank, u32* __restrict__ keep)
-{
-    const u32 a = blockIdx.x * 256 + threadIdx.x;
-    if (a >= n) return;
-    const u32 p = vals[a];
-    SA[a] = p;
-    rank[p] = head[a];
-    const bool startsHere = (a == 0) || (keys[a] != keys[a - 1]);
-    const bool nextStarts = (a + 1 >= n) || (keys[a + 1] != keys[a]);
-    keep[a] = (startsHere && nextStarts) ? 0u : 1u;
-}
 
 // compaction: act[out] = value[a] for kept elements, given the exclusive scan of keep
 __global__ __launch_bounds__(256) void k_compact(const u32* __restrict__ keep, const u32* __restrict__ scan, const u32* __restrict__ value, u32 n,
@@ -120,174 +31,9 @@ __global__ __launch_bounds__(256) void k_compact(const u32* __restrict__ keep, c
     if (keep[a]) out[scan[a]] = value ? value[a] : a;
 }
 
-// keys of the active elements for offset h: (head slot of the group, rank[pos + h] + 1 or 0 past the block end)
-__global__ __launch_bounds__(256) void k_bwt_keys(BwtView v, const u32* __restrict__ act, u32 nAct, const u32* __restrict__ SA,
-                                                  const u32* __restrict__ rank, u32 h, int rbits, u64* __restrict__ keys, u32* __restrict__ vals)
-{
-    const u32 a = blockIdx.x * 256 + threadIdx.x;
-    if (a >= nAct) return;
-    const u32 slot = act[a];
-    const u32 p = SA[slot];
-    const u32 b = p / v.VS;
-    const u32 off = p - b * v.VS;
-    const u32 n = v.len[b];
-    const u64 r2 = (off + h < n && off + h >= off) ? (u64)rank[p + h] + 1 : 0ull;
-    keys[a] = ((u64)rank[p] << rbits) | r2;
-    vals[a] = p;
-}
-
-// after sorting the active elements: write them back to their slots, new group heads, who stays active
-__global__ __launch_bounds__(256) void k_bwt_place(const u32* __restrict__ act, u32 nAct, const u64* __restrict__ keys, const u32* __restrict__ vals,
-                                                   const u32* __restrict__ headIdx, u32* __restrict__ SA, u32* __restrict__ rank, u32* __restrict__ keep)
-{
-    const u32 a = blockIdx.x * 256 + threadIdx.x;
-    if (a >= nAct) return;
-    const u32 p = vals[a];
-    SA[act[a]] = p;
-    rank[p] = act[headIdx[a]];
-    const bool startsHere = (a == 0) || (keys[a] != keys[a - 1]);
-    const bool nextStarts = (a + 1 >= nAct) || (keys[a + 1] != keys[a]);
-    keep[a] = (startsHere && nextStarts) ? 0u : 1u;
-}
-
-// final: BWT bytes + header (BWTBlockCodec.cpp:58-86)
-__global__ __launch_bounds__(256) void k_bwt_f_emit(BwtView v, const u32* __restrict__ base, const u8* __restrict__ ok, const u32* __restrict__ SA,
-                                                    const u32* __restrict__ rank, u32* __restrict__ newLen)
-{
-    const int b = blockIdx.y;
-    if (!ok[b]) return;
-    const u32 n = v.len[b];
-    u32 pIndexSize = 0;
-    bwt_fwd_applies(n, v.cap[b], &pIndexSize);
-    const int chunks = bwt_chunks(n);
-    const u32 hdr = 1 + (u32)chunks * pIndexSize;
-    const u8* s = v.src[b];
-    u8* d = v.dst[b];
-    const u32 vb = (u32)b * v.VS;
-    const u32 r0 = rank[vb] - base[b];                     // rank of suffix 0
-    for (u32 r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) {
-        const u32 p = SA[base[b] + r] - vb;
-        if (p != 0) d[hdr + 1 + r - (r > r0 ? 1u : 0u)] = s[p - 1];
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        d[hdr] = s[n - 1];
-        const u32 st = n / (u32)chunks;
-        const u32 step = ((u32)chunks * st == n) ? st : st + 1;
-        const u32 logNbChunks = (u32)ilog2_u32((u32)chunks);
-        d[0] = (u8)((logNbChunks << 2) | (pIndexSize - 1));
-        u32 idx = 1;
-        for (int k = 0; k < chunks; k++) {
-            const u32 prim = rank[vb + (u32)k * step] - base[b];   // primaryIndex - 1
-            for (int sh = (int)(pIndexSize - 1) * 8; sh >= 0; sh -= 8) d[idx++] = (u8)(prim >> sh);
-        }
-        newLen[b] = hdr + n;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-struct BwtScratch {
-    u64* keysA; u64* keysB;
-    u32* valsA; u32* valsB;
-    u32* SA; u32* rank;
-    u32* t0; u32* t1; u32* act; u32* act2;
-    u32* base;
-    void* prim; size_t primBytes;
-    u32* d_count;
-};
-
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-size_t bwt_forward_scratch_bytes(int nBlocks, u32 VS, size_t total)
-{
-    size_t primSort = 0, primScan = 0;
-    rocprim::radix_sort_pairs(nullptr, primSort, (u64*)nullptr, (u64*)nullptr, (u32*)nullptr, (u32*)nullptr, total, 0u, 64u, (hipStream_t)0);
-    rocprim::inclusive_scan(nullptr, primScan, (u32*)nullptr, (u32*)nullptr, total, rocprim::maximum<u32>(), (hipStream_t)0);
-    const size_t prim = align256(primSort > primScan ? primSort : primScan) + 4096;
-    return 2 * align256(8 * total) + 6 * align256(4 * total) + 2 * align256(4 * total) + align256(4ull * nBlocks * VS) +
-           align256(4ull * (nBlocks + 2)) + prim + 4096;
-}
-
-static void carve(u8* p, int nBlocks, u32 VS, size_t total, size_t bytes, BwtScratch* w)
-{
-    u8* q = p;
-    auto take = [&](size_t sz) { u8* r = q; q += align256(sz); return r; };
-    w->keysA = (u64*)take(8 * total); w->keysB = (u64*)take(8 * total);
-    w->valsA = (u32*)take(4 * total); w->valsB = (u32*)take(4 * total);
-    w->SA = (u32*)take(4 * total);
-    w->t0 = (u32*)take(4 * total); w->t1 = (u32*)take(4 * total);
-    w->act = (u32*)take(4 * total); w->act2 = (u32*)take(4 * total);
-    w->rank = (u32*)take(4ull * nBlocks * VS);
-    w->base = (u32*)take(4ull * (nBlocks + 2));
-    w->d_count = (u32*)take(256);
-    w->prim = q;
-    w->primBytes = bytes - (size_t)(q - p);
-}
-
 #define GRID1(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256), 0, s
-
-// Returns 0 or a negative HIP error. Synchronises the stream (active-set sizes are read back per round).
-int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t scratchBytes, u32* h_pinned)
-{
-    BwtView v; v.src = st.src; v.dst = st.dst; v.len = st.len; v.cap = st.cap; v.VS = st.maxLen; v.nBlocks = st.nBlocks;
-    // worst-case total = nBlocks * VS ; carve for that
-    const size_t maxTotal = (size_t)st.nBlocks * v.VS;
-    BwtScratch w;
-    carve(reinterpret_cast<u8*>(scratch), st.nBlocks, v.VS, maxTotal, scratchBytes, &w);
-    { KScope ks_("k_bwt_f_bases"); hipLaunchKernelGGL(k_bwt_bases, dim3(1), dim3(64), 0, s, v, w.base, st.ok); }
-    hipMemsetAsync(st.newLen, 0, sizeof(u32) * st.nBlocks, s);
-    if (hipMemcpyAsync(h_pinned, w.base + st.nBlocks, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
-    if (hipStreamSynchronize(s) != hipSuccess) return -1;
-    const u32 total = h_pinned[0];
-    if (total == 0) return 0;
-    int bbits = 0;
-    while ((1 << bbits) < st.nBlocks) bbits++;
-    const int nsym = (64 - bbits) / 9;
-    const dim3 gridB((unsigned)std::min<size_t>(((size_t)v.VS + 255) / 256, 4096), st.nBlocks);
-    { KScope ks_("k_bwt_f_init"); hipLaunchKernelGGL(k_bwt_f_init, gridB, dim3(256), 0, s, v, w.base, st.ok, bbits, nsym, w.keysA, w.valsA); }
-    size_t pb = w.primBytes;
-    { KScope ks_("bwt_f_sort_round0");
-      if (rocprim::radix_sort_pairs(w.prim, pb, w.keysA, w.keysB, w.valsA, w.valsB, (size_t)total, 0u, (unsigned)(bbits + 9 * nsym), s) != hipSuccess) return -1; }
-    { KScope ks_("k_bwt_f_flags"); hipLaunchKernelGGL(k_bwt_flags, GRID1(total), w.keysB, total, w.t0); }
-    pb = w.primBytes;
-    { KScope ks_("bwt_f_scan_max"); if (rocprim::inclusive_scan(w.prim, pb, w.t0, w.t1, (size_t)total, rocprim::maximum<u32>(), s) != hipSuccess) return -1; }
-    { KScope ks_("k_bwt_f_round0"); hipLaunchKernelGGL(k_bwt_round0, GRID1(total), w.keysB, w.valsB, w.t1, total, w.SA, w.rank, w.t0); }
-    // active slots = members of groups with more than one element
-    u32 nAct = total;
-    auto compact = [&](u32 n, const u32* value, u32* out) -> int {
-        size_t pbs = w.primBytes;
-        { KScope ks_("bwt_f_scan_sum"); if (rocprim::exclusive_scan(w.prim, pbs, w.t0, w.t1, 0u, (size_t)n, rocprim::plus<u32>(), s) != hipSuccess) return -1; }
-        { KScope ks_("k_bwt_f_compact"); hipLaunchKernelGGL(k_compact, GRID1(n), w.t0, w.t1, value, n, out); }
-        // count = scan[n-1] + keep[n-1]
-        hipMemcpyAsync(h_pinned, w.t1 + (n - 1), 4, hipMemcpyDeviceToHost, s);
-        hipMemcpyAsync(h_pinned + 1, w.t0 + (n - 1), 4, hipMemcpyDeviceToHost, s);
-        if (hipStreamSynchronize(s) != hipSuccess) return -1;
-        return (int)(h_pinned[0] + h_pinned[1]);
-    };
-    int cnt = compact(total, nullptr, w.act);
-    if (cnt < 0) return -1;
-    nAct = (u32)cnt;
-    int rbits = 1;
-    while ((1ull << rbits) < (u64)total + 2) rbits++;
-    u32 h = (u32)nsym;
-    u32* act = w.act; u32* act2 = w.act2;
-    while (nAct > 0) {
-        { KScope ks_("k_bwt_f_keys"); hipLaunchKernelGGL(k_bwt_keys, GRID1(nAct), v, act, nAct, w.SA, w.rank, h, rbits, w.keysA, w.valsA); }
-        pb = w.primBytes;
-        { KScope ks_("bwt_f_sort_round"); if (rocprim::radix_sort_pairs(w.prim, pb, w.keysA, w.keysB, w.valsA, w.valsB, (size_t)nAct, 0u, (unsigned)(2 * rbits), s) != hipSuccess) return -1; }
-        { KScope ks_("k_bwt_f_flags"); hipLaunchKernelGGL(k_bwt_flags, GRID1(nAct), w.keysB, nAct, w.t0); }
-        pb = w.primBytes;
-        { KScope ks_("bwt_f_scan_max"); if (rocprim::inclusive_scan(w.prim, pb, w.t0, w.t1, (size_t)nAct, rocprim::maximum<u32>(), s) != hipSuccess) return -1; }
-        { KScope ks_("k_bwt_f_place"); hipLaunchKernelGGL(k_bwt_place, GRID1(nAct), act, nAct, w.keysB, w.valsB, w.t1, w.SA, w.rank, w.t0); }
-        cnt = compact(nAct, act, act2);
-        if (cnt < 0) return -1;
-        nAct = (u32)cnt;
-        std::swap(act, act2);
-        if (h >= 0x80000000u) break;
-        h <<= 1;
-    }
-    { KScope ks_("k_bwt_f_emit"); hipLaunchKernelGGL(k_bwt_f_emit, gridB, dim3(256), 0, s, v, w.base, st.ok, w.SA, w.rank, st.newLen); }
-    return hipGetLastError() == hipSuccess ? 0 : -1;
-}
 
 // ------------------------------------------------------------------------------------------------
 // inverse

@@ -1,0 +1,695 @@
+// Forward Burrows-Wheeler transform (block codec) on gfx950: suffix sorting of all blocks of a batch at once.
+//
+// Reference being replaced (results are bit-identical; the suffix array of a block is unique, so any correct
+// construction matches divsufsort):
+//   transform/BWTBlockCodec.cpp:32-87 (header), transform/BWT.cpp:92-134, transform/DivSufSort.cpp:171-295
+//   (computeBWT / constructBWT): "proper prefix sorts first", out[0] = in[n-1], then in[SA[r]-1] for ranks with
+//   SA[r] != 0, 8 primary indexes rank(suffix k*ceil(n/8)) + 1 (BWT.hpp:40-61).
+//
+// GPU formulation: prefix doubling with group refinement (Larsson-Sadakane order refinement, made data parallel).
+//   State in HBM: SA[slot] (global position ids), ISA[position] = first slot of the position's group, and one bit per
+//   slot, gbits, set where a group starts. A position is resolved when its group has one member. Unresolved groups
+//   are refined every round on the key ISA[p + h] (0 past the block end: "shorter sorts first"), h doubling:
+//     * small groups (2..256 members) need no list at all: a kernel sweeps the bit map in windows of 2048 slots, finds
+//       the groups that start in its window and ranks every member by counting inside LDS (less / equal / equal-before),
+//     * medium groups (257..16384) are kept as (start, length) descriptors; one workgroup sorts a group in LDS with a
+//       stable LSD radix sort (8-bit digits, ranking by ballot matching inside a wave, per-wave digit counters),
+//     * large groups go through one global radix sort of (descriptor index, key) pairs (rocPRIM) -- runs of one
+//       symbol are what produces them.
+//   Keys are gathered by separate kernels before any kernel of the round moves a position or changes ISA (a refined
+//   head read beside an unrefined one would order two suffixes that are still equal).
+//   Round 0 sorts 9-bit symbols packed in 64-bit keys (block id on top) with rocPRIM's LSD sort.
+#include "common.hpp"
+#include "stages.hpp"
+#include "bwt_common.hpp"
+
+#include <cstring>
+#include <algorithm>
+#include <rocprim/rocprim.hpp>
+
+namespace knz {
+
+constexpr u32 SM_TS = 1792;        // slots owned by one window
+constexpr u32 SM_WIN = 2048;       // slots a window looks at (owned + halo)
+constexpr u32 SM_G = 256;          // largest "small" group
+constexpr u32 MED_CAP = 16384;     // largest "medium" group (one workgroup, LDS resident)
+constexpr int MED_THREADS = 1024;
+constexpr int MED_WAVES = 16;
+constexpr u32 NO_BIT = 0x7FFFFFFFu;
+
+struct FwdView {
+    const u32* base;     // [nBlocks + 1] slot / position base of every block (dense), base[nBlocks] = total
+    int nBlocks;
+    u32 total;
+    u32* SA;             // [total]
+    u32* ISA;            // [total]
+    u32* K;              // [total] keys of the round, by slot
+    u32* gbits;          // group-start bit per slot (bit k of word w = slot 32 w + k); set for every slot >= total
+    u32* counters;       // [0] members of small groups left, [1] medium descriptors, [2] large descriptors, [3] members of large groups
+};
+
+__device__ __forceinline__ int find_block(const u32* __restrict__ base, int nBlocks, u32 s)
+{
+    int lo = 0, hi = nBlocks;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (base[mid] <= s) lo = mid; else hi = mid; }
+    return lo;
+}
+
+__device__ __forceinline__ u32 gather_key(const u32* __restrict__ ISA, u32 gp, u32 h, u32 blkBase, u32 blkEnd)
+{
+    const u32 q = gp + h;
+    return (q < blkEnd) ? ISA[q] - blkBase + 1u : 0u;
+}
+
+__device__ __forceinline__ void classify_child(const FwdView& v, uint2* __restrict__ medNext, uint2* __restrict__ largeNext, u32 start, u32 size, u32& surv)
+{
+    if (size > MED_CAP) {
+        const u32 at = atomicAdd(&v.counters[2], 1u);
+        largeNext[at] = make_uint2(start, size);
+        atomicAdd(&v.counters[3], size);
+    } else if (size > SM_G) {
+        const u32 at = atomicAdd(&v.counters[1], 1u);
+        medNext[at] = make_uint2(start, size);
+    } else if (size > 1) {
+        surv += size;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// round 0
+// ------------------------------------------------------------------------------------------------
+// base[b] = sum of active lengths of the blocks before b ; total in base[nBlocks]
+__global__ void k_bwt_bases(BwtView v, u32* __restrict__ base, u8* __restrict__ ok)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    u32 sum = 0;
+    for (int b = 0; b < v.nBlocks; b++) {
+        base[b] = sum;
+        u32 ps;
+        const bool a = bwt_fwd_applies(v.len[b], v.cap[b], &ps);
+        ok[b] = a ? 1 : 0;
+        if (a) sum += v.len[b];
+    }
+    base[v.nBlocks] = sum;
+}
+
+// keys: [block id | symbols as 9-bit values (byte + 1, 0 past the block end)], values: global position ids
+__global__ __launch_bounds__(256) void k_bwt_f_init(BwtView v, const u32* __restrict__ base, const u8* __restrict__ ok, int nsym,
+                                                    u64* __restrict__ keys, u32* __restrict__ vals)
+{
+    const int b = blockIdx.y;
+    if (!ok[b]) return;
+    const u32 n = v.len[b];
+    const u8* s = v.src[b];
+    for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        u64 k = (u64)b;
+        for (int q = 0; q < nsym; q++) {
+            const u32 j = i + (u32)q;
+            k = (k << 9) | (j < n ? (u64)s[j] + 1 : 0ull);
+        }
+        keys[base[b] + i] = k;
+        vals[base[b] + i] = base[b] + i;
+    }
+}
+
+// group-start flags of the sorted keys: bit map (one ballot per wave), index arrays for the two scans
+__global__ __launch_bounds__(256) void k_bwt_f_r0_flags(const u64* __restrict__ keys, u32 total, unsigned long long* __restrict__ gbits64,
+                                                        u32* __restrict__ headIdx, u32* __restrict__ nextIdxRev)
+{
+    const u32 a = blockIdx.x * 256 + threadIdx.x;
+    bool f = true;
+    if (a < total) {
+        f = (a == 0) || (keys[a] != keys[a - 1]);
+        headIdx[a] = f ? a : 0u;
+        nextIdxRev[total - 1 - a] = f ? a : total;
+    }
+    const unsigned long long m = __ballot(f);
+    if ((threadIdx.x & 63) == 0) gbits64[a >> 6] = m;
+}
+
+// SA, ISA and the descriptors of the groups that are not small
+__global__ __launch_bounds__(256) void k_bwt_f_r0_place(FwdView v, const u32* __restrict__ vals, const u32* __restrict__ head,
+                                                        const u32* __restrict__ nextRev, uint2* __restrict__ medNext, uint2* __restrict__ largeNext)
+{
+    const u32 a = blockIdx.x * 256 + threadIdx.x;
+    u32 surv = 0;
+    if (a < v.total) {
+        const u32 gp = vals[a];
+        v.SA[a] = gp;
+        const u32 hd = head[a];
+        v.ISA[gp] = hd;
+        if (hd == a) {
+            const u32 nxt = (a + 1 < v.total) ? nextRev[v.total - 2 - a] : v.total;
+            classify_child(v, medNext, largeNext, a, nxt - a, surv);
+        }
+    }
+    surv = wave_sum(surv);
+    if ((threadIdx.x & 63) == 0 && surv) atomicAdd(&v.counters[0], surv);
+}
+
+// ------------------------------------------------------------------------------------------------
+// small groups: bit-map driven windows
+// ------------------------------------------------------------------------------------------------
+struct SmWindow {
+    u32 bw[64];
+    int prevSet[64];     // last set bit in the words before w (-1: none)
+    u32 nextSet[64];     // first set bit in the words after w (NO_BIT: none)
+};
+
+// wave 0 of the workgroup loads the 64 bit-map words of the window and the two per-word summaries; returns false
+// (to every thread) when no group that starts in the window is unresolved
+__device__ __forceinline__ bool sm_load_window(const FwdView& v, u32 slot0, SmWindow& W, int* sAny)
+{
+    const int tid = (int)threadIdx.x;
+    if (tid < 64) {
+        const u32 w = v.gbits[(slot0 >> 5) + (u32)tid];
+        W.bw[tid] = w;
+        int last = w ? (tid * 32 + 31 - __clz((int)w)) : -1;
+        u32 first = w ? (u32)(tid * 32 + __ffs((int)w) - 1) : NO_BIT;
+        // exclusive prefix max / suffix min over the 64 words
+        int pm = last;
+        u32 sm = first;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(pm, o, 64);
+            if (tid >= o) pm = t > pm ? t : pm;
+            const u32 u = (u32)__shfl_down((int)sm, o, 64);
+            if (tid + o < 64) sm = u < sm ? u : sm;
+        }
+        int pex = __shfl_up(pm, 1, 64);
+        if (tid == 0) pex = -1;
+        u32 sex = (u32)__shfl_down((int)sm, 1, 64);
+        if (tid == 63) sex = NO_BIT;
+        W.prevSet[tid] = pex;
+        W.nextSet[tid] = sex;
+        // anything to do? a zero bit among the owned slots, or right behind them (a group that starts at the last owned slot)
+        const bool zero = (tid < (int)(SM_TS / 32)) ? (w != 0xFFFFFFFFu) : (tid == (int)(SM_TS / 32) ? ((w & 1u) == 0) : false);
+        const unsigned long long anyz = __ballot(zero);
+        if (tid == 0) *sAny = anyz != 0 ? 1 : 0;
+    }
+    __syncthreads();
+    return *sAny != 0;
+}
+
+// group [s, e) of window element i; false when i is not a member of a small unresolved group owned by this window
+__device__ __forceinline__ bool sm_group_of(const SmWindow& W, u32 i, u32& s, u32& e)
+{
+    const u32 w = i >> 5, bit = i & 31;
+    const u32 lowmask = (bit == 31) ? 0xFFFFFFFFu : ((2u << bit) - 1u);
+    const u32 word = W.bw[w];
+    const u32 m = word & lowmask;
+    int si = m ? (int)(w * 32 + 31 - __clz((int)m)) : W.prevSet[w];
+    if (si < 0 || (u32)si >= SM_TS) return false;
+    const u32 m2 = word & ~lowmask;
+    const u32 ei = m2 ? (w * 32 + (u32)__ffs((int)m2) - 1) : W.nextSet[w];
+    if (ei == NO_BIT) return false;
+    const u32 len = ei - (u32)si;
+    if (len < 2 || len > SM_G) return false;
+    s = (u32)si; e = ei;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_bwt_f_gather_small(FwdView v, u32 h)
+{
+    __shared__ SmWindow W;
+    __shared__ int sAny;
+    __shared__ int sBlk;
+    const u32 slot0 = blockIdx.x * SM_TS;
+    if (!sm_load_window(v, slot0, W, &sAny)) return;
+    if (threadIdx.x == 0) sBlk = find_block(v.base, v.nBlocks, slot0 < v.total ? slot0 : v.total - 1);
+    __syncthreads();
+    const int b0 = sBlk;
+#pragma unroll
+    for (int k = 0; k < (int)(SM_WIN / 256); k++) {
+        const u32 i = threadIdx.x + 256u * k;
+        u32 s, e;
+        if (!sm_group_of(W, i, s, e)) continue;
+        const u32 slot = slot0 + i;
+        int b = b0;
+        while (slot >= v.base[b + 1]) b++;
+        v.K[slot] = gather_key(v.ISA, v.SA[slot], h, v.base[b], v.base[b + 1]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bwt_f_sort_small(FwdView v)
+{
+    __shared__ SmWindow W;
+    __shared__ int sAny;
+    __shared__ u32 sSA[SM_WIN];
+    __shared__ u32 sK[SM_WIN];
+    __shared__ u32 sNew[64];
+    const u32 slot0 = blockIdx.x * SM_TS;
+    if (!sm_load_window(v, slot0, W, &sAny)) return;
+    if (threadIdx.x < 64) sNew[threadIdx.x] = 0;
+    u32 gs[SM_WIN / 256], ge[SM_WIN / 256];
+    bool act[SM_WIN / 256];
+#pragma unroll
+    for (int k = 0; k < (int)(SM_WIN / 256); k++) {
+        const u32 i = threadIdx.x + 256u * k;
+        act[k] = sm_group_of(W, i, gs[k], ge[k]);
+        if (act[k]) { sSA[i] = v.SA[slot0 + i]; sK[i] = v.K[slot0 + i]; }
+    }
+    __syncthreads();
+    u32 surv = 0;
+#pragma unroll
+    for (int k = 0; k < (int)(SM_WIN / 256); k++) {
+        if (!act[k]) continue;
+        const u32 i = threadIdx.x + 256u * k;
+        const u32 ki = sK[i];
+        u32 less = 0, eq = 0, eqBefore = 0;
+        for (u32 j = gs[k]; j < ge[k]; j++) {
+            const u32 kj = sK[j];
+            less += (kj < ki) ? 1u : 0u;
+            const u32 same = (kj == ki) ? 1u : 0u;
+            eq += same;
+            eqBefore += (j < i) ? same : 0u;
+        }
+        const u32 gp = sSA[i];
+        const u32 headIdx = gs[k] + less;
+        v.SA[slot0 + headIdx + eqBefore] = gp;
+        if (less != 0) {
+            v.ISA[gp] = slot0 + headIdx;
+            if (eqBefore == 0) atomicOr(&sNew[headIdx >> 5], 1u << (headIdx & 31));
+        }
+        if (eq > 1) surv++;
+    }
+    surv = wave_sum(surv);
+    if ((threadIdx.x & 63) == 0 && surv) atomicAdd(&v.counters[0], surv);
+    __syncthreads();
+    if (threadIdx.x < 64 && sNew[threadIdx.x]) atomicOr(&v.gbits[(slot0 >> 5) + threadIdx.x], sNew[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// medium groups: one workgroup per descriptor
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bwt_f_gather_desc(FwdView v, const uint2* __restrict__ desc, u32 nDesc, u32 h)
+{
+    __shared__ int sBlk;
+    for (u32 g = blockIdx.x; g < nDesc; g += gridDim.x) {
+        const uint2 d = desc[g];
+        if (threadIdx.x == 0) sBlk = find_block(v.base, v.nBlocks, d.x);
+        __syncthreads();
+        const u32 bb = v.base[sBlk], be = v.base[sBlk + 1];
+        for (u32 i = threadIdx.x; i < d.y; i += 256) {
+            const u32 slot = d.x + i;
+            v.K[slot] = gather_key(v.ISA, v.SA[slot], h, bb, be);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(MED_THREADS) void k_bwt_f_sort_medium(FwdView v, const uint2* __restrict__ desc, u32 nDesc, int npass,
+                                                                   uint2* __restrict__ medNext, uint2* __restrict__ largeNext)
+{
+    __shared__ u32 oK[MED_CAP];
+    __shared__ u32 oV[MED_CAP];
+    __shared__ u32 cnt[MED_WAVES * 256];
+    __shared__ u32 fb[MED_CAP / 32];
+    __shared__ int pm[MED_CAP / 32];
+    __shared__ u32 pn[MED_CAP / 32];
+    __shared__ u32 wtot[MED_WAVES];
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const unsigned long long ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    u32* cntw = cnt + wave * 256;
+
+    for (u32 g = blockIdx.x; g < nDesc; g += gridDim.x) {
+        const uint2 d = desc[g];
+        const u32 gs = d.x, n = d.y;
+        const int R = (int)((n + 1023) >> 10);                 // rows of 64 per wave
+        const u32 waveBase = (u32)wave * (u32)R * 64u;
+        u32 key[16], val[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            key[r] = 0xFFFFFFFFu; val[r] = 0;
+            if (r < R) {
+                const u32 idx = waveBase + (u32)r * 64u + (u32)lane;
+                if (idx < n) { key[r] = v.K[gs + idx]; val[r] = v.SA[gs + idx]; }
+            }
+        }
+        for (int pass = 0; pass < npass; pass++) {
+            const int shift = 8 * pass;
+            for (int q = lane; q < 256; q += 64) cntw[q] = 0;
+            u32 pre[16];
+            // stable rank of every element among the elements of its wave with the same digit
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                pre[r] = 0;
+                if (r < R) {
+                    const u32 dg = (key[r] >> shift) & 255u;
+                    unsigned long long peers = ~0ull;
+#pragma unroll
+                    for (int bit = 0; bit < 8; bit++) {
+                        const bool one = (dg >> bit) & 1u;
+                        const unsigned long long bal = __ballot(one);
+                        peers &= one ? bal : ~bal;
+                    }
+                    const u32 pop = (u32)__popcll(peers);
+                    const u32 rnk = (u32)__popcll(peers & ltMask);
+                    const int leader = __ffsll((long long)peers) - 1;
+                    u32 old = 0;
+                    if (lane == leader) { old = cntw[dg]; cntw[dg] = old + pop; }
+                    old = (u32)__shfl((int)old, leader, 64);
+                    pre[r] = old + rnk;
+                }
+            }
+            __syncthreads();
+            // exclusive scan of the counters in (digit, wave) order: thread t owns digit t >> 2, waves 4 (t & 3) .. + 3
+            {
+                const int dg = tid >> 2, w0 = (tid & 3) * 4;
+                const u32 c0 = cnt[(w0 + 0) * 256 + dg], c1 = cnt[(w0 + 1) * 256 + dg], c2 = cnt[(w0 + 2) * 256 + dg], c3 = cnt[(w0 + 3) * 256 + dg];
+                const u32 sum = c0 + c1 + c2 + c3;
+                const u32 incl = wave_incl_scan(sum);
+                if (lane == 63) wtot[wave] = incl;
+                __syncthreads();
+                u32 wbase = 0;
+                for (int w = 0; w < wave; w++) wbase += wtot[w];
+                const u32 excl = wbase + incl - sum;
+                cnt[(w0 + 0) * 256 + dg] = excl;
+                cnt[(w0 + 1) * 256 + dg] = excl + c0;
+                cnt[(w0 + 2) * 256 + dg] = excl + c0 + c1;
+                cnt[(w0 + 3) * 256 + dg] = excl + c0 + c1 + c2;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                if (r < R) {
+                    const u32 dg = (key[r] >> shift) & 255u;
+                    const u32 pos = cntw[dg] + pre[r];
+                    oK[pos] = key[r];
+                    oV[pos] = val[r];
+                }
+            }
+            __syncthreads();
+            if (pass + 1 < npass) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    if (r < R) {
+                        const u32 idx = waveBase + (u32)r * 64u + (u32)lane;
+                        key[r] = oK[idx]; val[r] = oV[idx];
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // ---- subgroup boundaries of the sorted keys as a bit map in LDS + per-word summaries
+        const int nWords = (int)((n + 31) >> 5);
+        if (tid < (int)(MED_CAP / 32)) {
+            u32 bits = 0;
+            if (tid < nWords) {
+                const u32 i0 = (u32)tid * 32u;
+                u32 prev = (i0 == 0) ? 0u : oK[i0 - 1];
+                for (u32 k = 0; k < 32; k++) {
+                    const u32 i = i0 + k;
+                    if (i >= n) break;
+                    const u32 cur = oK[i];
+                    if (i == 0 || cur != prev) bits |= 1u << k;
+                    prev = cur;
+                }
+            }
+            fb[tid] = bits;
+            pm[tid] = bits ? (tid * 32 + 31 - __clz((int)bits)) : -1;
+            pn[tid] = bits ? (u32)(tid * 32 + __ffs((int)bits) - 1) : n;
+        }
+        __syncthreads();
+        for (int o = 1; o < (int)(MED_CAP / 32); o <<= 1) {
+            int a = -1; u32 c = n;
+            if (tid < (int)(MED_CAP / 32)) {
+                if (tid >= o) a = pm[tid - o];
+                if (tid + o < (int)(MED_CAP / 32)) c = pn[tid + o];
+            }
+            __syncthreads();
+            if (tid < (int)(MED_CAP / 32)) {
+                if (a > pm[tid]) pm[tid] = a;
+                if (c < pn[tid]) pn[tid] = c;
+            }
+            __syncthreads();
+        }
+        // pm[w] = last boundary at or before the end of word w, pn[w] = first boundary at or after the start of word w
+        u32 surv = 0;
+        for (u32 i = (u32)tid; i < n; i += MED_THREADS) {
+            const u32 w = i >> 5, bit = i & 31;
+            const u32 lowmask = (bit == 31) ? 0xFFFFFFFFu : ((2u << bit) - 1u);
+            const u32 word = fb[w];
+            const u32 m = word & lowmask;
+            const u32 hd = m ? (w * 32 + 31 - (u32)__clz((int)m)) : (u32)pm[w - 1];      // word 0 always has bit 0
+            const u32 gp = oV[i];
+            v.SA[gs + i] = gp;
+            if (hd != 0) v.ISA[gp] = gs + hd;
+            if (hd == i) {
+                const u32 m2 = word & ~lowmask;
+                const u32 e = m2 ? (w * 32 + (u32)__ffs((int)m2) - 1) : ((w + 1 < (u32)(MED_CAP / 32)) ? pn[w + 1] : n);
+                classify_child(v, medNext, largeNext, gs + i, e - i, surv);
+            }
+        }
+        surv = wave_sum(surv);
+        if (lane == 0 && surv) atomicAdd(&v.counters[0], surv);
+        // new group starts into the global bit map (bit 0 of the group is set already)
+        if (tid < nWords && fb[tid]) {
+            const u32 off = gs + (u32)tid * 32u;
+            const u32 sh = off & 31;
+            atomicOr(&v.gbits[off >> 5], fb[tid] << sh);
+            if (sh && (fb[tid] >> (32 - sh))) atomicOr(&v.gbits[(off >> 5) + 1], fb[tid] >> (32 - sh));
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// large groups: one global sort of (descriptor index, key) pairs
+// ------------------------------------------------------------------------------------------------
+// loff[i] = sum of the lengths of the descriptors before i; loff[n] = total
+__global__ __launch_bounds__(1024) void k_bwt_f_large_prefix(const uint2* __restrict__ desc, u32 nDesc, u32* __restrict__ loff)
+{
+    __shared__ u32 part[1024];
+    const u32 per = (nDesc + 1023) / 1024;
+    const u32 lo = threadIdx.x * per, hi = (lo + per < nDesc) ? lo + per : nDesc;
+    u32 sum = 0;
+    for (u32 i = lo; i < hi; i++) sum += desc[i].y;
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) { u32 run = 0; for (int t = 0; t < 1024; t++) { const u32 x = part[t]; part[t] = run; run += x; } loff[nDesc] = run; }
+    __syncthreads();
+    u32 run = part[threadIdx.x];
+    for (u32 i = lo; i < hi; i++) { loff[i] = run; run += desc[i].y; }
+}
+
+__global__ __launch_bounds__(256) void k_bwt_f_large_keys(FwdView v, const uint2* __restrict__ desc, u32 nDesc, const u32* __restrict__ loff,
+                                                          u32 L, u32 h, int kbits, u64* __restrict__ keys, u32* __restrict__ vals)
+{
+    const u32 j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= L) return;
+    u32 lo = 0, hi = nDesc;
+    while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (loff[mid] <= j) lo = mid; else hi = mid; }
+    const uint2 d = desc[lo];
+    const u32 slot = d.x + (j - loff[lo]);
+    const int b = find_block(v.base, v.nBlocks, d.x);
+    const u32 gp = v.SA[slot];
+    const u32 key = gather_key(v.ISA, gp, h, v.base[b], v.base[b + 1]);
+    keys[j] = ((u64)lo << kbits) | (u64)key;
+    vals[j] = gp;
+}
+
+__global__ __launch_bounds__(256) void k_bwt_f_large_flags(const u64* __restrict__ keys, u32 L, u32* __restrict__ headIdx, u32* __restrict__ nextIdxRev)
+{
+    const u32 j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= L) return;
+    const bool f = (j == 0) || (keys[j] != keys[j - 1]);
+    headIdx[j] = f ? j : 0u;
+    nextIdxRev[L - 1 - j] = f ? j : L;
+}
+
+__global__ __launch_bounds__(256) void k_bwt_f_large_place(FwdView v, const uint2* __restrict__ desc, const u32* __restrict__ loff, u32 L, int kbits,
+                                                           const u64* __restrict__ keys, const u32* __restrict__ vals, const u32* __restrict__ head,
+                                                           const u32* __restrict__ nextRev, uint2* __restrict__ medNext, uint2* __restrict__ largeNext)
+{
+    const u32 j = blockIdx.x * 256 + threadIdx.x;
+    u32 surv = 0;
+    if (j < L) {
+        const u32 di = (u32)(keys[j] >> kbits);
+        const u32 gs = desc[di].x, off = loff[di];
+        const u32 gp = vals[j];
+        const u32 nh = head[j];
+        v.SA[gs + (j - off)] = gp;
+        if (nh != off) v.ISA[gp] = gs + (nh - off);
+        if (nh == j) {
+            const u32 nxt = (j + 1 < L) ? nextRev[L - 2 - j] : L;
+            const u32 slot = gs + (j - off);
+            if (j != off) atomicOr(&v.gbits[slot >> 5], 1u << (slot & 31));
+            classify_child(v, medNext, largeNext, slot, nxt - j, surv);
+        }
+    }
+    surv = wave_sum(surv);
+    if ((threadIdx.x & 63) == 0 && surv) atomicAdd(&v.counters[0], surv);
+}
+
+// ------------------------------------------------------------------------------------------------
+// final: BWT bytes + header (BWTBlockCodec.cpp:58-86)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bwt_f_emit(BwtView v, const u32* __restrict__ base, const u8* __restrict__ ok, const u32* __restrict__ SA,
+                                                    const u32* __restrict__ ISA, u32* __restrict__ newLen)
+{
+    const int b = blockIdx.y;
+    if (!ok[b]) return;
+    const u32 n = v.len[b];
+    u32 pIndexSize = 0;
+    bwt_fwd_applies(n, v.cap[b], &pIndexSize);
+    const int chunks = bwt_chunks(n);
+    const u32 hdr = 1 + (u32)chunks * pIndexSize;
+    const u8* s = v.src[b];
+    u8* d = v.dst[b];
+    const u32 bb = base[b];
+    const u32 r0 = ISA[bb] - bb;                           // rank of suffix 0
+    for (u32 r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) {
+        const u32 p = SA[bb + r] - bb;
+        if (p != 0) d[hdr + 1 + r - (r > r0 ? 1u : 0u)] = s[p - 1];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        d[hdr] = s[n - 1];
+        const u32 st = n / (u32)chunks;
+        const u32 step = ((u32)chunks * st == n) ? st : st + 1;
+        const u32 logNbChunks = (u32)ilog2_u32((u32)chunks);
+        d[0] = (u8)((logNbChunks << 2) | (pIndexSize - 1));
+        u32 idx = 1;
+        for (int k = 0; k < chunks; k++) {
+            const u32 prim = ISA[bb + (u32)k * step] - bb;   // primaryIndex - 1
+            for (int sh = (int)(pIndexSize - 1) * 8; sh >= 0; sh -= 8) d[idx++] = (u8)(prim >> sh);
+        }
+        newLen[b] = hdr + n;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct FwdScratch {
+    u64* keysA; u64* keysB;
+    u32* valsA; u32* valsB;
+    u32* SA; u32* ISA; u32* K;
+    u32* t0; u32* t1; u32* t2; u32* t3;
+    u32* gbits; size_t gbitsWords;
+    uint2* med[2]; uint2* large[2];
+    u32* loff;
+    u32* base;
+    u32* counters;
+    void* prim; size_t primBytes;
+};
+
+static size_t fwd_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static size_t fwd_carve(u8* p, int nBlocks, size_t total, size_t bytes, FwdScratch* w)
+{
+    u8* q = p;
+    auto take = [&](size_t sz) { u8* r = q; q += fwd_align(sz); return r; };
+    const size_t maxMed = total / (SM_G + 1) + 2, maxLarge = total / (MED_CAP + 1) + 2;
+    w->gbitsWords = ((total + 64) / 64 + SM_WIN / 64 + 4) * 2;
+    w->keysA = (u64*)take(8 * total); w->keysB = (u64*)take(8 * total);
+    w->valsA = (u32*)take(4 * total); w->valsB = (u32*)take(4 * total);
+    w->SA = (u32*)take(4 * total); w->ISA = (u32*)take(4 * total); w->K = (u32*)take(4 * total);
+    w->t0 = (u32*)take(4 * total); w->t1 = (u32*)take(4 * total); w->t2 = (u32*)take(4 * total); w->t3 = (u32*)take(4 * total);
+    w->gbits = (u32*)take(4 * w->gbitsWords);
+    w->med[0] = (uint2*)take(8 * maxMed); w->med[1] = (uint2*)take(8 * maxMed);
+    w->large[0] = (uint2*)take(8 * maxLarge); w->large[1] = (uint2*)take(8 * maxLarge);
+    w->loff = (u32*)take(4 * (maxLarge + 1));
+    w->base = (u32*)take(4ull * (nBlocks + 2));
+    w->counters = (u32*)take(256);
+    w->prim = q;
+    w->primBytes = (p && bytes > (size_t)(q - p)) ? bytes - (size_t)(q - p) : 0;
+    return (size_t)(q - p);
+}
+
+size_t bwt_forward_scratch_bytes(int nBlocks, u32 VS, size_t total)
+{
+    (void)VS;
+    size_t primSort = 0, primScan = 0;
+    rocprim::radix_sort_pairs(nullptr, primSort, (u64*)nullptr, (u64*)nullptr, (u32*)nullptr, (u32*)nullptr, total, 0u, 64u, (hipStream_t)0);
+    rocprim::inclusive_scan(nullptr, primScan, (u32*)nullptr, (u32*)nullptr, total, rocprim::maximum<u32>(), (hipStream_t)0);
+    const size_t prim = fwd_align(primSort > primScan ? primSort : primScan) + 4096;
+    FwdScratch w;
+    return fwd_carve(nullptr, nBlocks, total, 0, &w) + prim + 4096;
+}
+
+#define GRID1(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256), 0, s
+
+// Returns 0 or a negative HIP error. Synchronises the stream (the sizes of the work lists are read back per round).
+int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t scratchBytes, u32* h_pinned)
+{
+    BwtView bv; bv.src = st.src; bv.dst = st.dst; bv.len = st.len; bv.cap = st.cap; bv.VS = st.maxLen; bv.nBlocks = st.nBlocks;
+    const size_t maxTotal = (size_t)st.nBlocks * bv.VS;
+    FwdScratch w;
+    fwd_carve(reinterpret_cast<u8*>(scratch), st.nBlocks, maxTotal, scratchBytes, &w);
+    { KScope ks_("k_bwt_f_bases"); hipLaunchKernelGGL(k_bwt_bases, dim3(1), dim3(64), 0, s, bv, w.base, st.ok); }
+    hipMemsetAsync(st.newLen, 0, sizeof(u32) * st.nBlocks, s);
+    if (hipMemcpyAsync(h_pinned, w.base + st.nBlocks, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+    if (hipStreamSynchronize(s) != hipSuccess) return -1;
+    const u32 total = h_pinned[0];
+    if (total == 0) return 0;
+    FwdView v; v.base = w.base; v.nBlocks = st.nBlocks; v.total = total; v.SA = w.SA; v.ISA = w.ISA; v.K = w.K; v.gbits = w.gbits; v.counters = w.counters;
+
+    // ---- round 0: sort by the first nsym symbols
+    int bbits = 0;
+    while ((1 << bbits) < st.nBlocks) bbits++;
+    const int nsym = (64 - bbits) / 9;
+    if (nsym < 1) return -4;
+    const dim3 gridB((unsigned)std::min<size_t>(((size_t)bv.VS + 255) / 256, 4096), st.nBlocks);
+    { KScope ks_("k_bwt_f_init"); hipLaunchKernelGGL(k_bwt_f_init, gridB, dim3(256), 0, s, bv, w.base, st.ok, nsym, w.keysA, w.valsA); }
+    size_t pb = w.primBytes;
+    { KScope ks_("bwt_f_sort_round0");
+      if (rocprim::radix_sort_pairs(w.prim, pb, w.keysA, w.keysB, w.valsA, w.valsB, (size_t)total, 0u, (unsigned)(bbits + 9 * nsym), s) != hipSuccess) return -1; }
+    // every bit from `total` on is set (end sentinel, and windows may look past the end)
+    hipMemsetAsync(w.gbits, 0xFF, 4 * w.gbitsWords, s);
+    hipMemsetAsync(w.counters, 0, 64, s);
+    { KScope ks_("k_bwt_f_r0_flags"); hipLaunchKernelGGL(k_bwt_f_r0_flags, dim3((total + 255) / 256), dim3(256), 0, s, w.keysB, total,
+                                                         reinterpret_cast<unsigned long long*>(w.gbits), w.t0, w.t2); }
+    pb = w.primBytes;
+    { KScope ks_("bwt_f_scan_max"); if (rocprim::inclusive_scan(w.prim, pb, w.t0, w.t1, (size_t)total, rocprim::maximum<u32>(), s) != hipSuccess) return -1; }
+    pb = w.primBytes;
+    { KScope ks_("bwt_f_scan_min"); if (rocprim::inclusive_scan(w.prim, pb, w.t2, w.t3, (size_t)total, rocprim::minimum<u32>(), s) != hipSuccess) return -1; }
+    int cur = 0;
+    { KScope ks_("k_bwt_f_r0_place"); hipLaunchKernelGGL(k_bwt_f_r0_place, GRID1(total), v, w.valsB, w.t1, w.t3, w.med[cur], w.large[cur]); }
+    if (hipMemcpyAsync(h_pinned, w.counters, 16, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+    if (hipStreamSynchronize(s) != hipSuccess) return -1;
+    u32 surv = h_pinned[0], nMed = h_pinned[1], nLarge = h_pinned[2], largeElems = h_pinned[3];
+
+    int kbits = 1;
+    while ((1ull << kbits) < (u64)bv.VS + 2) kbits++;
+    const int npass = (kbits + 7) / 8;
+    const u32 nTiles = (total + SM_TS - 1) / SM_TS;
+    u32 h = (u32)nsym;
+    while (surv || nMed || nLarge) {
+        if (h > bv.VS) return -5;                                    // cannot happen: suffixes of one block differ in length
+        hipMemsetAsync(w.counters, 0, 64, s);
+        const int nxt = cur ^ 1;
+        // -- all keys first
+        if (surv) { KScope ks_("k_bwt_f_gather_small"); hipLaunchKernelGGL(k_bwt_f_gather_small, dim3(nTiles), dim3(256), 0, s, v, h); }
+        if (nMed) { KScope ks_("k_bwt_f_gather_desc"); hipLaunchKernelGGL(k_bwt_f_gather_desc, dim3(std::min<u32>(nMed, 8192)), dim3(256), 0, s, v, w.med[cur], nMed, h); }
+        int lbits = 0;
+        if (nLarge) {
+            while ((1u << lbits) < nLarge) lbits++;
+            { KScope ks_("k_bwt_f_large_prefix"); hipLaunchKernelGGL(k_bwt_f_large_prefix, dim3(1), dim3(1024), 0, s, w.large[cur], nLarge, w.loff); }
+            { KScope ks_("k_bwt_f_large_keys"); hipLaunchKernelGGL(k_bwt_f_large_keys, GRID1(largeElems), v, w.large[cur], nLarge, w.loff, largeElems, h, kbits, w.keysA, w.valsA); }
+        }
+        // -- then the refinements
+        if (surv) { KScope ks_("k_bwt_f_sort_small"); hipLaunchKernelGGL(k_bwt_f_sort_small, dim3(nTiles), dim3(256), 0, s, v); }
+        if (nMed) { KScope ks_("k_bwt_f_sort_medium"); hipLaunchKernelGGL(k_bwt_f_sort_medium, dim3(std::min<u32>(nMed, 4096)), dim3(MED_THREADS), 0, s, v, w.med[cur], nMed, npass, w.med[nxt], w.large[nxt]); }
+        if (nLarge) {
+            pb = w.primBytes;
+            { KScope ks_("bwt_f_sort_large");
+              if (rocprim::radix_sort_pairs(w.prim, pb, w.keysA, w.keysB, w.valsA, w.valsB, (size_t)largeElems, 0u, (unsigned)(kbits + lbits), s) != hipSuccess) return -1; }
+            { KScope ks_("k_bwt_f_large_flags"); hipLaunchKernelGGL(k_bwt_f_large_flags, GRID1(largeElems), w.keysB, largeElems, w.t0, w.t2); }
+            pb = w.primBytes;
+            { KScope ks_("bwt_f_scan_max"); if (rocprim::inclusive_scan(w.prim, pb, w.t0, w.t1, (size_t)largeElems, rocprim::maximum<u32>(), s) != hipSuccess) return -1; }
+            pb = w.primBytes;
+            { KScope ks_("bwt_f_scan_min"); if (rocprim::inclusive_scan(w.prim, pb, w.t2, w.t3, (size_t)largeElems, rocprim::minimum<u32>(), s) != hipSuccess) return -1; }
+            { KScope ks_("k_bwt_f_large_place"); hipLaunchKernelGGL(k_bwt_f_large_place, GRID1(largeElems), v, w.large[cur], w.loff, largeElems, kbits, w.keysB, w.valsB,
+                                                                    w.t1, w.t3, w.med[nxt], w.large[nxt]); }
+        }
+        if (hipMemcpyAsync(h_pinned, w.counters, 16, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+        if (hipStreamSynchronize(s) != hipSuccess) return -1;
+        surv = h_pinned[0]; nMed = h_pinned[1]; nLarge = h_pinned[2]; largeElems = h_pinned[3];
+        cur = nxt;
+        h <<= 1;
+    }
+    { KScope ks_("k_bwt_f_emit"); hipLaunchKernelGGL(k_bwt_f_emit, gridB, dim3(256), 0, s, bv, w.base, st.ok, w.SA, w.ISA, st.newLen); }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace knz

@@ -1,0 +1,54 @@
+"""Kernel logic on the CPU: selected .hip files are compiled as plain C++ against the fiber emulation in tools/hipemu
+(threads of a workgroup = cooperative fibers, wave intrinsics = 64-lane rendezvous) and their results are compared with
+the oracle. This exercises index arithmetic, LDS protocols and wave-level ranking where no GPU exists; it is test
+infrastructure only -- the product path never runs this way (the `-m gpu` tests run the real kernels through the C ABI)."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import knzlib
+
+ROOT = knzlib.ROOT
+EMU = os.path.join(ROOT, "tests", "emu")
+
+
+def build(name, tmp_path):
+    knzlib.ensure_oracle()
+    exe = str(tmp_path / name)
+    cmd = ["g++", "-O1", "-std=c++17", "-x", "c++", "-I" + os.path.join(ROOT, "tools", "hipemu"), "-I" + os.path.join(ROOT, "include"),
+           "-Wno-unused-value", "-Wno-attributes", "-Wno-format-extra-args", os.path.join(EMU, name + ".cpp"),
+           os.path.join(ROOT, "tools", "hipemu", "hipemu.cpp"), "-x", "none", "-L" + os.path.join(ROOT, "oracle"), "-lknz_oracle",
+           "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-o", exe]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def write_case(path, blocks):
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", len(blocks)))
+        for b in blocks:
+            f.write(struct.pack("<I", len(b)))
+            f.write(b)
+
+
+def test_bwt_forward_kernels_emulated(tmp_path):
+    exe = build("bwt_fwd_emu", tmp_path)
+    c = knzlib.corpus()
+    rng = np.random.default_rng(1)
+    ramp = bytes((np.arange(20000) % 64).astype(np.uint8))          # period 64: groups of ~312 -> the medium (LDS radix) path
+    z = bytearray(24000)                                             # long zero runs: a group above 16384 -> the large path
+    for p in rng.integers(0, 24000, 40):
+        z[p] = int(rng.integers(1, 256))
+    cases = [
+        [b"mississippi", b"abcabcabcabcabcabcab", bytes(5), b"a", b"ab", c.text(3000, 1), bytes((np.arange(1000) & 255).astype(np.uint8))],
+        [c.text(30000, 2), bytes(3000) + c.text(500, 3), ramp, rng.integers(0, 4, 20000, dtype=np.uint8).tobytes()],
+        [bytes(z), c.mixed(300000, 2)[250000:290000]],
+    ]
+    for i, blocks in enumerate(cases):
+        path = str(tmp_path / ("case%d.bin" % i))
+        write_case(path, blocks)
+        r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -1,0 +1,32 @@
+#!/bin/bash
+# One GPU-box visit: parity suite, bench lines, rocprofv3 kernel stats (developer tool; run through gpurun).
+# usage: tools/gpu_round.sh <tag> [steps...]   steps: tests bench3 bench2 prof3 pmc3
+set -u
+TAG=${1:-run}; shift || true
+STEPS=${@:-tests bench3}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+for s in $STEPS; do
+  case $s in
+    tests) timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "tests rc=$?" >> $OUT/summary.txt; tail -5 $OUT/pytest.log ;;
+    tests_fast) timeout 900 python -m pytest tests -m gpu -x -q -k "not full_size and not soak and not fpaq" > $OUT/pytest_fast.log 2>&1; echo "tests_fast rc=$?" >> $OUT/summary.txt; tail -5 $OUT/pytest_fast.log ;;
+    bench3) timeout 600 python bench.py --steps 5 --warmup 2 > $OUT/bench3.json 2> $OUT/bench3.err; echo "bench3 rc=$?" >> $OUT/summary.txt; cat $OUT/bench3.json ;;
+    bench3q) timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu --no-e2e > $OUT/bench3q.json 2> $OUT/bench3q.err; echo "bench3q rc=$?" >> $OUT/summary.txt; cat $OUT/bench3q.json ;;
+    bench2) timeout 600 python bench.py --config 2 --steps 10 --warmup 3 > $OUT/bench2.json 2> $OUT/bench2.err; echo "bench2 rc=$?" >> $OUT/summary.txt; cat $OUT/bench2.json ;;
+    bench1) timeout 600 python bench.py --config 1 --steps 10 --warmup 3 --no-e2e > $OUT/bench1.json 2> $OUT/bench1.err; echo "bench1 rc=$?" >> $OUT/summary.txt; cat $OUT/bench1.json ;;
+    bench4) timeout 900 python bench.py --config 4 --limit 134217728 --steps 1 --warmup 1 --no-e2e > $OUT/bench4.json 2> $OUT/bench4.err; echo "bench4 rc=$?" >> $OUT/summary.txt; cat $OUT/bench4.json ;;
+    bench5) timeout 900 python bench.py --config 5 --steps 2 --warmup 1 --no-e2e > $OUT/bench5.json 2> $OUT/bench5.err; echo "bench5 rc=$?" >> $OUT/summary.txt; cat $OUT/bench5.json ;;
+    prof3) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof3 -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-e2e > $GRAFT_REPO_ROOT/$OUT/prof3.log 2>&1); echo "prof3 rc=$?" >> $OUT/summary.txt
+           f=$(find $OUT/prof3 -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && python tools/rocprof_csv_summary.py $f > $OUT/prof3_kernel_stats.txt && cp $f $OUT/prof3_kernel_stats.csv && head -30 $OUT/prof3_kernel_stats.txt ;;
+    prof2) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof2 -- python $GRAFT_REPO_ROOT/bench.py --config 2 --steps 5 --warmup 2 --no-cpu --no-e2e > $GRAFT_REPO_ROOT/$OUT/prof2.log 2>&1); echo "prof2 rc=$?" >> $OUT/summary.txt
+           f=$(find $OUT/prof2 -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && python tools/rocprof_csv_summary.py $f > $OUT/prof2_kernel_stats.txt && cp $f $OUT/prof2_kernel_stats.csv && head -20 $OUT/prof2_kernel_stats.txt ;;
+    pmc3) for c in FETCH_SIZE WRITE_SIZE; do (cd /tmp && timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc3_$c -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu --no-e2e > $GRAFT_REPO_ROOT/$OUT/pmc3_$c.log 2>&1); echo "pmc3 $c rc=$?" >> $OUT/summary.txt; done
+          ff=$(find $OUT/pmc3_FETCH_SIZE -name '*counter_collection.csv' | head -1); fw=$(find $OUT/pmc3_WRITE_SIZE -name '*counter_collection.csv' | head -1)
+          [ -n "$ff" ] && [ -n "$fw" ] && python tools/pmc_stage_summary.py $ff $fw 3 $OUT/pmc3_traffic.json $OUT/pmc3_traffic.txt && cat $OUT/pmc3_traffic.txt | head -40 ;;
+    *) echo "running custom: $s"; timeout 900 bash -c "$s" > $OUT/custom.log 2>&1; echo "custom rc=$?" >> $OUT/summary.txt; tail -40 $OUT/custom.log ;;
+  esac
+done
+# rocprof output directories are large: keep only the summaries
+find $OUT -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +
+cat $OUT/summary.txt

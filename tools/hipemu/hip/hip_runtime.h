@@ -1,0 +1,133 @@
+// TEST INFRASTRUCTURE ONLY -- a small CPU emulation of the HIP constructs the kernels in kanzi-cpp_amd/csrc use,
+// so that kernel logic (index arithmetic, wave-level ranking, LDS protocols) can be exercised in the CPU-only test
+// suite, where no GPU exists. A kernel's threads run as cooperative fibers on one OS thread: a workgroup is run to
+// completion before the next one starts, __syncthreads() and the wave intrinsics (64 lanes) are rendezvous points.
+// Nothing here is part of the product; the product path has no CPU fallback (the GPU build never sees this file:
+// it is only on the include path of tests/emu/*.cpp, ahead of /opt/rocm/include).
+#pragma once
+#define KNZ_EMU 1
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
+};
+struct uint2 { unsigned x, y; };
+static inline uint2 make_uint2(unsigned a, unsigned b) { uint2 r; r.x = a; r.y = b; return r; }
+struct uint4 { unsigned x, y, z, w; };
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+enum { hipSuccess = 0 };
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+
+namespace hipemu {
+
+struct Fiber {
+    void* sp;
+    char* stack;
+    dim3 tid;
+    int state;          // 0 runnable, 1 waiting at block barrier, 2 waiting at wave rendezvous, 3 done
+    unsigned long long xval;
+};
+
+struct Block {
+    dim3 bIdx, bDim, gDim;
+    std::vector<Fiber> fibers;
+    std::function<void()> body;
+    void* schedSp;
+    Fiber* cur;
+    int nLive;
+};
+
+Block& blk();
+void yield_to_scheduler();
+void launch(const std::function<void()>& body, dim3 grid, dim3 block);
+void block_barrier();
+// rendezvous of the (live) lanes of the calling fiber's wave: every lane deposits v, gets the array of all 64
+void wave_exchange(unsigned long long v, unsigned long long out[64], unsigned long long* activeMask);
+
+}  // namespace hipemu
+
+#define threadIdx (hipemu::blk().cur->tid)
+#define blockIdx (hipemu::blk().bIdx)
+#define blockDim (hipemu::blk().bDim)
+#define gridDim (hipemu::blk().gDim)
+
+namespace hipemu {
+template <class F, class... A>
+static inline void launch_k(F f, dim3 grid, dim3 block, size_t, hipStream_t, A... args) { launch([=]() { f(args...); }, grid, block); }
+}
+#define hipLaunchKernelGGL(kernel, ...) hipemu::launch_k(kernel, __VA_ARGS__)
+
+static inline void __syncthreads() { hipemu::block_barrier(); }
+
+static inline unsigned long long __ballot(int pred)
+{
+    unsigned long long v[64], act;
+    hipemu::wave_exchange(pred ? 1ull : 0ull, v, &act);
+    unsigned long long m = 0;
+    for (int i = 0; i < 64; i++) if (((act >> i) & 1) && v[i]) m |= 1ull << i;
+    return m;
+}
+static inline int __shfl(int var, int src, int width = 64)
+{
+    unsigned long long v[64], act;
+    hipemu::wave_exchange((unsigned long long)(unsigned)var, v, &act);
+    const int lane = (int)(threadIdx.x & 63);
+    const int s = (lane & ~(width - 1)) | (src & (width - 1));
+    return (int)(unsigned)v[s];
+}
+static inline int __shfl_up(int var, unsigned delta, int width = 64)
+{
+    unsigned long long v[64], act;
+    hipemu::wave_exchange((unsigned long long)(unsigned)var, v, &act);
+    const int lane = (int)(threadIdx.x & 63);
+    const int s = lane - (int)delta;
+    return ((s >= (lane & ~(width - 1))) ? (int)(unsigned)v[s] : var);
+}
+static inline int __shfl_down(int var, unsigned delta, int width = 64)
+{
+    unsigned long long v[64], act;
+    hipemu::wave_exchange((unsigned long long)(unsigned)var, v, &act);
+    const int lane = (int)(threadIdx.x & 63);
+    const int s = lane + (int)delta;
+    return ((s < ((lane & ~(width - 1)) + width)) ? (int)(unsigned)v[s] : var);
+}
+static inline int __shfl_xor(int var, int mask, int width = 64)
+{
+    unsigned long long v[64], act;
+    hipemu::wave_exchange((unsigned long long)(unsigned)var, v, &act);
+    const int lane = (int)(threadIdx.x & 63);
+    (void)width;
+    return (int)(unsigned)v[lane ^ mask];
+}
+static inline unsigned long long __lanemask_lt() { const int lane = (int)(threadIdx.x & 63); return lane ? (~0ull >> (64 - lane)) : 0ull; }
+static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline int __popc(unsigned x) { return __builtin_popcount(x); }
+static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
+static inline int __ffs(int x) { return __builtin_ffs(x); }
+static inline int __clz(int x) { return x == 0 ? 32 : __builtin_clz((unsigned)x); }
+static inline int __clzll(long long x) { return x == 0 ? 64 : __builtin_clzll((unsigned long long)x); }
+
+template <class T> static inline T atomicAdd(T* p, T v) { const T o = *p; *p = o + v; return o; }
+template <class T> static inline T atomicOr(T* p, T v) { const T o = *p; *p = o | v; return o; }
+template <class T> static inline T atomicMax(T* p, T v) { const T o = *p; if (v > o) *p = v; return o; }
+template <class T> static inline T atomicMin(T* p, T v) { const T o = *p; if (v < o) *p = v; return o; }
