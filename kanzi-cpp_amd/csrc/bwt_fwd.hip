@@ -45,7 +45,9 @@ struct FwdView {
     u32* ISA;            // [total]
     u32* K;              // [total] keys of the round, by slot
     u32* gbits;          // group-start bit per slot (bit k of word w = slot 32 w + k); set for every slot >= total
-    u32* counters;       // [0] members of small groups left, [1] medium descriptors, [2] large descriptors, [3] members of large groups
+    u32* gnew;           // group starts found in the current round; merged into gbits when the round is over (a window must
+                         // not see the subgroups a neighbouring window has just made: their keys belong to the old order)
+    u32* counters;       // [0] != 0: small groups are left, [1] medium descriptors, [2] large descriptors, [3] members of large groups
 };
 
 __device__ __forceinline__ int find_block(const u32* __restrict__ base, int nBlocks, u32 s)
@@ -71,7 +73,7 @@ __device__ __forceinline__ void classify_child(const FwdView& v, uint2* __restri
         const u32 at = atomicAdd(&v.counters[1], 1u);
         medNext[at] = make_uint2(start, size);
     } else if (size > 1) {
-        surv += size;
+        surv = 1;
     }
 }
 
@@ -143,8 +145,7 @@ __global__ __launch_bounds__(256) void k_bwt_f_r0_place(FwdView v, const u32* __
             classify_child(v, medNext, largeNext, a, nxt - a, surv);
         }
     }
-    surv = wave_sum(surv);
-    if ((threadIdx.x & 63) == 0 && surv) atomicAdd(&v.counters[0], surv);
+    if (__ballot(surv != 0) != 0 && (threadIdx.x & 63) == 0) v.counters[0] = 1;      // a flag: plain store, no atomic traffic
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -270,12 +271,11 @@ __global__ __launch_bounds__(256) void k_bwt_f_sort_small(FwdView v)
             v.ISA[gp] = slot0 + headIdx;
             if (eqBefore == 0) atomicOr(&sNew[headIdx >> 5], 1u << (headIdx & 31));
         }
-        if (eq > 1) surv++;
+        if (eq > 1) surv = 1;
     }
-    surv = wave_sum(surv);
-    if ((threadIdx.x & 63) == 0 && surv) atomicAdd(&v.counters[0], surv);
+    if (__ballot(surv != 0) != 0 && (threadIdx.x & 63) == 0) v.counters[0] = 1;
     __syncthreads();
-    if (threadIdx.x < 64 && sNew[threadIdx.x]) atomicOr(&v.gbits[(slot0 >> 5) + threadIdx.x], sNew[threadIdx.x]);
+    if (threadIdx.x < 64 && sNew[threadIdx.x]) atomicOr(&v.gnew[(slot0 >> 5) + threadIdx.x], sNew[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -442,14 +442,13 @@ __global__ __launch_bounds__(MED_THREADS) void k_bwt_f_sort_medium(FwdView v, co
                 classify_child(v, medNext, largeNext, gs + i, e - i, surv);
             }
         }
-        surv = wave_sum(surv);
-        if (lane == 0 && surv) atomicAdd(&v.counters[0], surv);
-        // new group starts into the global bit map (bit 0 of the group is set already)
+        if (__ballot(surv != 0) != 0 && lane == 0) v.counters[0] = 1;
+        // new group starts into the round's bit map (bit 0 of the group is set already)
         if (tid < nWords && fb[tid]) {
             const u32 off = gs + (u32)tid * 32u;
             const u32 sh = off & 31;
-            atomicOr(&v.gbits[off >> 5], fb[tid] << sh);
-            if (sh && (fb[tid] >> (32 - sh))) atomicOr(&v.gbits[(off >> 5) + 1], fb[tid] >> (32 - sh));
+            atomicOr(&v.gnew[off >> 5], fb[tid] << sh);
+            if (sh && (fb[tid] >> (32 - sh))) atomicOr(&v.gnew[(off >> 5) + 1], fb[tid] >> (32 - sh));
         }
         __syncthreads();
     }
@@ -515,12 +514,20 @@ __global__ __launch_bounds__(256) void k_bwt_f_large_place(FwdView v, const uint
         if (nh == j) {
             const u32 nxt = (j + 1 < L) ? nextRev[L - 2 - j] : L;
             const u32 slot = gs + (j - off);
-            if (j != off) atomicOr(&v.gbits[slot >> 5], 1u << (slot & 31));
+            if (j != off) atomicOr(&v.gnew[slot >> 5], 1u << (slot & 31));
             classify_child(v, medNext, largeNext, slot, nxt - j, surv);
         }
     }
-    surv = wave_sum(surv);
-    if ((threadIdx.x & 63) == 0 && surv) atomicAdd(&v.counters[0], surv);
+    if (__ballot(surv != 0) != 0 && (threadIdx.x & 63) == 0) v.counters[0] = 1;
+}
+
+// end of a round: the group starts found in it become visible
+__global__ __launch_bounds__(256) void k_bwt_f_merge_bits(u32* __restrict__ gbits, u32* __restrict__ gnew, u32 nWords)
+{
+    const u32 w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= nWords) return;
+    const u32 x = gnew[w];
+    if (x) { gbits[w] |= x; gnew[w] = 0; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -565,7 +572,7 @@ struct FwdScratch {
     u32* valsA; u32* valsB;
     u32* SA; u32* ISA; u32* K;
     u32* t0; u32* t1; u32* t2; u32* t3;
-    u32* gbits; size_t gbitsWords;
+    u32* gbits; u32* gnew; size_t gbitsWords;
     uint2* med[2]; uint2* large[2];
     u32* loff;
     u32* base;
@@ -586,6 +593,7 @@ static size_t fwd_carve(u8* p, int nBlocks, size_t total, size_t bytes, FwdScrat
     w->SA = (u32*)take(4 * total); w->ISA = (u32*)take(4 * total); w->K = (u32*)take(4 * total);
     w->t0 = (u32*)take(4 * total); w->t1 = (u32*)take(4 * total); w->t2 = (u32*)take(4 * total); w->t3 = (u32*)take(4 * total);
     w->gbits = (u32*)take(4 * w->gbitsWords);
+    w->gnew = (u32*)take(4 * w->gbitsWords);
     w->med[0] = (uint2*)take(8 * maxMed); w->med[1] = (uint2*)take(8 * maxMed);
     w->large[0] = (uint2*)take(8 * maxLarge); w->large[1] = (uint2*)take(8 * maxLarge);
     w->loff = (u32*)take(4 * (maxLarge + 1));
@@ -622,7 +630,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     if (hipStreamSynchronize(s) != hipSuccess) return -1;
     const u32 total = h_pinned[0];
     if (total == 0) return 0;
-    FwdView v; v.base = w.base; v.nBlocks = st.nBlocks; v.total = total; v.SA = w.SA; v.ISA = w.ISA; v.K = w.K; v.gbits = w.gbits; v.counters = w.counters;
+    FwdView v; v.base = w.base; v.nBlocks = st.nBlocks; v.total = total; v.SA = w.SA; v.ISA = w.ISA; v.K = w.K; v.gbits = w.gbits; v.gnew = w.gnew; v.counters = w.counters;
 
     // ---- round 0: sort by the first nsym symbols
     int bbits = 0;
@@ -636,6 +644,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
       if (rocprim::radix_sort_pairs(w.prim, pb, w.keysA, w.keysB, w.valsA, w.valsB, (size_t)total, 0u, (unsigned)(bbits + 9 * nsym), s) != hipSuccess) return -1; }
     // every bit from `total` on is set (end sentinel, and windows may look past the end)
     hipMemsetAsync(w.gbits, 0xFF, 4 * w.gbitsWords, s);
+    hipMemsetAsync(w.gnew, 0, 4 * w.gbitsWords, s);
     hipMemsetAsync(w.counters, 0, 64, s);
     { KScope ks_("k_bwt_f_r0_flags"); hipLaunchKernelGGL(k_bwt_f_r0_flags, dim3((total + 255) / 256), dim3(256), 0, s, w.keysB, total,
                                                          reinterpret_cast<unsigned long long*>(w.gbits), w.t0, w.t2); }
@@ -682,6 +691,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
             { KScope ks_("k_bwt_f_large_place"); hipLaunchKernelGGL(k_bwt_f_large_place, GRID1(largeElems), v, w.large[cur], w.loff, largeElems, kbits, w.keysB, w.valsB,
                                                                     w.t1, w.t3, w.med[nxt], w.large[nxt]); }
         }
+        { KScope ks_("k_bwt_f_merge_bits"); hipLaunchKernelGGL(k_bwt_f_merge_bits, GRID1(total / 32 + 2), w.gbits, w.gnew, total / 32 + 2); }
         if (hipMemcpyAsync(h_pinned, w.counters, 16, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
         if (hipStreamSynchronize(s) != hipSuccess) return -1;
         surv = h_pinned[0]; nMed = h_pinned[1]; nLarge = h_pinned[2]; largeElems = h_pinned[3];

@@ -42,7 +42,10 @@ def test_bwt_forward_kernels_emulated(tmp_path):
     z = bytearray(24000)                                             # long zero runs: a group above 16384 -> the large path
     for p in rng.integers(0, 24000, 40):
         z[p] = int(rng.integers(1, 256))
+    words = [bytes(rng.integers(97, 101, int(rng.integers(2, 6)), dtype=np.uint8)) for _ in range(40)]
+    babble = b" ".join(words[int(i)] for i in rng.integers(0, 40, 40000))[:150000]   # many groups that straddle window borders
     cases = [
+        [babble],
         [b"mississippi", b"abcabcabcabcabcabcab", bytes(5), b"a", b"ab", c.text(3000, 1), bytes((np.arange(1000) & 255).astype(np.uint8))],
         [c.text(30000, 2), bytes(3000) + c.text(500, 3), ramp, rng.integers(0, 4, 20000, dtype=np.uint8).tobytes()],
         [bytes(z), c.mixed(300000, 2)[250000:290000]],
@@ -50,5 +53,6 @@ def test_bwt_forward_kernels_emulated(tmp_path):
     for i, blocks in enumerate(cases):
         path = str(tmp_path / ("case%d.bin" % i))
         write_case(path, blocks)
-        r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        for order in ("0", "1", "2"):       # workgroup dispatch order is not defined: forward, reverse, shuffled
+            r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900, env=dict(os.environ, HIPEMU_ORDER=order))
+            assert r.returncode == 0, (i, order, r.stdout[-2000:] + r.stderr[-2000:])

@@ -3,13 +3,15 @@
 # usage: tools/gpu_round.sh <tag> [steps...]   steps: tests bench3 bench2 prof3 pmc3
 set -u
 TAG=${1:-run}; shift || true
-STEPS=${@:-tests bench3}
+[ $# -eq 0 ] && set -- tests bench3
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-for s in $STEPS; do
-  case $s in
-    tests) timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "tests rc=$?" >> $OUT/summary.txt; tail -5 $OUT/pytest.log ;;
+for s in "$@"; do
+  [ -n "${DRY:-}" ] && { echo "step: [$s]"; continue; }
+  case "$s" in
+    tests_bwt) timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "bwt or transform or stream_golden or ragged or config3 or soak or jobs" < /dev/null > $OUT/pytest_bwt.log 2>&1; echo "tests_bwt rc=$?" >> $OUT/summary.txt; tail -15 $OUT/pytest_bwt.log ;;
+    tests) timeout 1500 python -m pytest tests -m gpu -x -q < /dev/null > $OUT/pytest.log 2>&1; echo "tests rc=$?" >> $OUT/summary.txt; tail -5 $OUT/pytest.log ;;
     tests_fast) timeout 900 python -m pytest tests -m gpu -x -q -k "not full_size and not soak and not fpaq" > $OUT/pytest_fast.log 2>&1; echo "tests_fast rc=$?" >> $OUT/summary.txt; tail -5 $OUT/pytest_fast.log ;;
     bench3) timeout 600 python bench.py --steps 5 --warmup 2 > $OUT/bench3.json 2> $OUT/bench3.err; echo "bench3 rc=$?" >> $OUT/summary.txt; cat $OUT/bench3.json ;;
     bench3q) timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu --no-e2e > $OUT/bench3q.json 2> $OUT/bench3q.err; echo "bench3q rc=$?" >> $OUT/summary.txt; cat $OUT/bench3q.json ;;
@@ -24,7 +26,8 @@ for s in $STEPS; do
     pmc3) for c in FETCH_SIZE WRITE_SIZE; do (cd /tmp && timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc3_$c -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu --no-e2e > $GRAFT_REPO_ROOT/$OUT/pmc3_$c.log 2>&1); echo "pmc3 $c rc=$?" >> $OUT/summary.txt; done
           ff=$(find $OUT/pmc3_FETCH_SIZE -name '*counter_collection.csv' | head -1); fw=$(find $OUT/pmc3_WRITE_SIZE -name '*counter_collection.csv' | head -1)
           [ -n "$ff" ] && [ -n "$fw" ] && python tools/pmc_stage_summary.py $ff $fw 3 $OUT/pmc3_traffic.json $OUT/pmc3_traffic.txt && cat $OUT/pmc3_traffic.txt | head -40 ;;
-    *) echo "running custom: $s"; timeout 900 bash -c "$s" > $OUT/custom.log 2>&1; echo "custom rc=$?" >> $OUT/summary.txt; tail -40 $OUT/custom.log ;;
+    cmd:*) echo "running custom: ${s#cmd:}"; timeout 600 bash -c "${s#cmd:}" < /dev/null > $OUT/custom.log 2>&1; echo "custom rc=$?" >> $OUT/summary.txt; tail -40 $OUT/custom.log ;;
+    *) echo "unknown step: $s" ;;
   esac
 done
 # rocprof output directories are large: keep only the summaries

@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE ONLY -- fiber scheduler behind tools/hipemu/hip/hip_runtime.h (see there).
 #include "hip/hip_runtime.h"
 #include <sys/mman.h>
+#include <algorithm>
 
 extern "C" void hipemu_switch(void** fromSp, void* toSp);
 asm(R"(
@@ -158,12 +159,18 @@ void launch(const std::function<void()>& body, dim3 grid, dim3 block)
     }
     g_blk.body = body;
     g_blk.bDim = block; g_blk.gDim = grid;
-    for (unsigned z = 0; z < grid.z; z++)
-        for (unsigned y = 0; y < grid.y; y++)
-            for (unsigned x = 0; x < grid.x; x++) {
-                g_blk.bIdx = dim3(x, y, z);
-                run_block();
-            }
+    // HIPEMU_ORDER: 0 = workgroups in index order, 1 = reverse, 2 = a fixed pseudo-random permutation. HIP promises no
+    // dispatch order; running a test under several orders exposes kernels that depend on one.
+    static const int order = getenv("HIPEMU_ORDER") ? atoi(getenv("HIPEMU_ORDER")) : 0;
+    const size_t nb = (size_t)grid.x * grid.y * grid.z;
+    std::vector<size_t> seq(nb);
+    for (size_t i = 0; i < nb; i++) seq[i] = (order == 1) ? nb - 1 - i : i;
+    if (order == 2) { unsigned long long st = 0x9E3779B97F4A7C15ull; for (size_t i = nb; i > 1; i--) { st = st * 6364136223846793005ull + 1442695040888963407ull; std::swap(seq[i - 1], seq[(size_t)((st >> 33) % i)]); } }
+    for (size_t i = 0; i < nb; i++) {
+        const size_t q = seq[i];
+        g_blk.bIdx = dim3((unsigned)(q % grid.x), (unsigned)((q / grid.x) % grid.y), (unsigned)(q / ((size_t)grid.x * grid.y)));
+        run_block();
+    }
 }
 
 }  // namespace hipemu
