@@ -12,7 +12,7 @@
 //   are refined every round on the key ISA[p + h] (0 past the block end: "shorter sorts first"), h doubling:
 //     * small groups (2..256 members) need no list at all: a kernel sweeps the bit map in windows of 2048 slots, finds
 //       the groups that start in its window and ranks every member by counting inside LDS (less / equal / equal-before),
-//     * medium groups (257..16384) are kept as (start, length) descriptors; one workgroup sorts a group in LDS with a
+//     * medium groups (257..8192) are kept as (start, length) descriptors; one workgroup sorts a group in LDS with a
 //       stable LSD radix sort (8-bit digits, ranking by ballot matching inside a wave, per-wave digit counters),
 //     * large groups go through one global radix sort of (descriptor index, key) pairs (rocPRIM) -- runs of one
 //       symbol are what produces them.
@@ -32,9 +32,8 @@ namespace knz {
 constexpr u32 SM_TS = 1792;        // slots owned by one window
 constexpr u32 SM_WIN = 2048;       // slots a window looks at (owned + halo)
 constexpr u32 SM_G = 256;          // largest "small" group
-constexpr u32 MED_CAP = 16384;     // largest "medium" group (one workgroup, LDS resident)
-constexpr int MED_THREADS = 1024;
-constexpr int MED_WAVES = 16;
+constexpr u32 MED_CAP = 8192;      // largest "medium" group (one workgroup of 1024 threads, LDS resident)
+constexpr int MED_ROWS = 8;        // elements per thread in the LDS sort
 constexpr u32 NO_BIT = 0x7FFFFFFFu;
 
 struct FwdView {
@@ -284,7 +283,11 @@ __global__ __launch_bounds__(256) void k_bwt_f_sort_small(FwdView v)
 __global__ __launch_bounds__(256) void k_bwt_f_gather_desc(FwdView v, const uint2* __restrict__ desc, u32 nDesc, u32 h)
 {
     __shared__ int sBlk;
-    for (u32 g = blockIdx.x; g < nDesc; g += gridDim.x) {
+    // Neighbouring descriptors are neighbouring groups (the list is filled roughly in slot order), and in periodic data their
+    // members look at neighbouring words of ISA: workgroups that run on one XCD (index mod 8) take consecutive descriptors, so
+    // that those lines are found in that XCD's L2. Placement only changes speed.
+    const u32 per = (gridDim.x + 7) / 8;
+    for (u32 g = (blockIdx.x & 7) * per + (blockIdx.x >> 3); g < nDesc; g += per * 8) {
         const uint2 d = desc[g];
         if (threadIdx.x == 0) sBlk = find_block(v.base, v.nBlocks, d.x);
         __syncthreads();
@@ -297,158 +300,270 @@ __global__ __launch_bounds__(256) void k_bwt_f_gather_desc(FwdView v, const uint
     }
 }
 
-__global__ __launch_bounds__(MED_THREADS) void k_bwt_f_sort_medium(FwdView v, const uint2* __restrict__ desc, u32 nDesc, int npass,
-                                                                   uint2* __restrict__ medNext, uint2* __restrict__ largeNext)
+// LDS of one sorting workgroup of THREADS threads: up to MED_ROWS elements per thread
+template <int THREADS>
+struct MedLds {
+    static constexpr int WAVES = THREADS / 64;
+    static constexpr u32 CAP = (u32)MED_ROWS * THREADS;
+    u32 oK[CAP];
+    u32 oV[CAP];
+    u32 cnt[WAVES * 256];
+    u32 fb[CAP / 32];
+    int pm[CAP / 32];
+    u32 pn[CAP / 32];
+    u32 wtot[WAVES];
+    u32 wtot2[WAVES];
+};
+
+template <int THREADS>
+__device__ __forceinline__ u32 med_block_sum(MedLds<THREADS>& L, u32 x)
 {
-    __shared__ u32 oK[MED_CAP];
-    __shared__ u32 oV[MED_CAP];
-    __shared__ u32 cnt[MED_WAVES * 256];
-    __shared__ u32 fb[MED_CAP / 32];
-    __shared__ int pm[MED_CAP / 32];
-    __shared__ u32 pn[MED_CAP / 32];
-    __shared__ u32 wtot[MED_WAVES];
-    const int tid = (int)threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const u32 s = wave_sum(x);
+    if ((threadIdx.x & 63) == 0) L.wtot[threadIdx.x >> 6] = s;
+    __syncthreads();
+    u32 tot = 0;
+    for (int w = 0; w < MedLds<THREADS>::WAVES; w++) tot += L.wtot[w];
+    __syncthreads();
+    return tot;
+}
+
+// Stable LSD radix sort of the pairs (oK, oV)[0, n) in LDS, 8-bit digits. Wave w owns the R*64 consecutive elements from
+// w*R*64 (R = rows of 64 per wave); the rank of an element among the elements of its wave with the same digit comes from
+// ballot matching (the lanes of a row that agree on all 8 digit bits), rows in order; per-wave digit counters are then
+// scanned in (digit, wave) order. Entered and left with the workgroup in step.
+template <int THREADS>
+__device__ __forceinline__ void med_radix_sort(MedLds<THREADS>& L, u32 n, int npass)
+{
+    constexpr int WAVES = THREADS / 64;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    u32* cntw = cnt + wave * 256;
+    u32* cntw = L.cnt + wave * 256;
+    const int R = (int)((n + THREADS - 1) / THREADS);
+    const u32 waveBase = (u32)wave * (u32)R * 64u;
+    for (int pass = 0; pass < npass; pass++) {
+        const int shift = 8 * pass;
+        for (int q = lane; q < 256; q += 64) cntw[q] = 0;
+        u32 key[MED_ROWS], val[MED_ROWS], pre[MED_ROWS];
+#pragma unroll
+        for (int r = 0; r < MED_ROWS; r++) {
+            key[r] = 0xFFFFFFFFu; val[r] = 0; pre[r] = 0;
+            if (r < R) {
+                const u32 idx = waveBase + (u32)r * 64u + (u32)lane;
+                if (idx < n) { key[r] = L.oK[idx]; val[r] = L.oV[idx]; }
+                const u32 dg = (key[r] >> shift) & 255u;
+                unsigned long long peers = ~0ull;
+#pragma unroll
+                for (int bit = 0; bit < 8; bit++) {
+                    const bool one = (dg >> bit) & 1u;
+                    const unsigned long long bal = __ballot(one);
+                    peers &= one ? bal : ~bal;
+                }
+                const u32 pop = (u32)__popcll(peers);
+                const u32 rnk = (u32)__popcll(peers & ltMask);
+                const int leader = __ffsll((long long)peers) - 1;
+                u32 old = 0;
+                if (lane == leader) { old = cntw[dg]; cntw[dg] = old + pop; }
+                old = (u32)__shfl((int)old, leader, 64);
+                pre[r] = old + rnk;
+            }
+        }
+        __syncthreads();
+        // exclusive scan of the counters in (digit, wave) order: a thread owns one digit and four consecutive waves
+        {
+            constexpr int TPD = THREADS / 256;
+            const int dg = tid / TPD, w0 = (tid % TPD) * 4;
+            const u32 c0 = L.cnt[(w0 + 0) * 256 + dg], c1 = L.cnt[(w0 + 1) * 256 + dg], c2 = L.cnt[(w0 + 2) * 256 + dg], c3 = L.cnt[(w0 + 3) * 256 + dg];
+            const u32 sum = c0 + c1 + c2 + c3;
+            const u32 incl = wave_incl_scan(sum);
+            if (lane == 63) L.wtot[wave] = incl;
+            __syncthreads();
+            u32 wbase = 0;
+            for (int w = 0; w < wave; w++) wbase += L.wtot[w];
+            const u32 excl = wbase + incl - sum;
+            L.cnt[(w0 + 0) * 256 + dg] = excl;
+            L.cnt[(w0 + 1) * 256 + dg] = excl + c0;
+            L.cnt[(w0 + 2) * 256 + dg] = excl + c0 + c1;
+            L.cnt[(w0 + 3) * 256 + dg] = excl + c0 + c1 + c2;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < MED_ROWS; r++) {
+            if (r < R) {
+                const u32 dg = (key[r] >> shift) & 255u;
+                const u32 pos = cntw[dg] + pre[r];
+                if (pos < n) {                         // the padding of the last row sorts behind everything: not stored
+                    L.oK[pos] = key[r];
+                    L.oV[pos] = val[r];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    (void)WAVES;
+}
+
+// One workgroup refines one group of 257..MED_ROWS*THREADS members (descriptors of other sizes are left to the other
+// instantiations of the kernel): keys and positions into LDS, sort, subgroup boundaries, SA / ISA / bit map / children.
+// A group in which one key holds the majority (periodic stretches and runs: every member but the ones near the end of the
+// stretch looks at the same group h further on) is first split, stably, into "that key" and "the others"; only the
+// others are sorted.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_bwt_f_sort_medium(FwdView v, const uint2* __restrict__ desc, u32 nDesc, int npass, u32 minLen,
+                                                               uint2* __restrict__ medNext, uint2* __restrict__ largeNext)
+{
+    constexpr int WAVES = THREADS / 64;
+    constexpr u32 CAP = (u32)MED_ROWS * THREADS;
+    __shared__ MedLds<THREADS> L;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
     for (u32 g = blockIdx.x; g < nDesc; g += gridDim.x) {
         const uint2 d = desc[g];
         const u32 gs = d.x, n = d.y;
-        const int R = (int)((n + 1023) >> 10);                 // rows of 64 per wave
-        const u32 waveBase = (u32)wave * (u32)R * 64u;
-        u32 key[16], val[16];
+        if (n <= minLen || n > CAP) continue;               // uniform for the workgroup
+        for (u32 i = (u32)tid; i < n; i += THREADS) { L.oK[i] = v.K[gs + i]; L.oV[i] = v.SA[gs + i]; }
+        __syncthreads();
+        // majority candidate: the key two of three probes agree on, else the middle one
+        const u32 ka = L.oK[n >> 2], kb = L.oK[n >> 1], kc = L.oK[(n >> 2) * 3];
+        const u32 m = (ka == kc) ? ka : kb;
+        u32 c = 0;
+        for (u32 i = (u32)tid; i < n; i += THREADS) c += (L.oK[i] == m) ? 1u : 0u;
+        c = med_block_sum(L, c);
+        if (c < n) {
+            if (2 * c >= n) {
+                // ---- stable split: [others (nOth)][members with key m (c)]
+                const int R = (int)((n + THREADS - 1) / THREADS);
+                const u32 waveBase = (u32)wave * (u32)R * 64u;
+                u32 key[MED_ROWS], val[MED_ROWS], pos[MED_ROWS];
+                u32 runO = 0, runE = 0;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            key[r] = 0xFFFFFFFFu; val[r] = 0;
-            if (r < R) {
-                const u32 idx = waveBase + (u32)r * 64u + (u32)lane;
-                if (idx < n) { key[r] = v.K[gs + idx]; val[r] = v.SA[gs + idx]; }
-            }
-        }
-        for (int pass = 0; pass < npass; pass++) {
-            const int shift = 8 * pass;
-            for (int q = lane; q < 256; q += 64) cntw[q] = 0;
-            u32 pre[16];
-            // stable rank of every element among the elements of its wave with the same digit
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                pre[r] = 0;
-                if (r < R) {
-                    const u32 dg = (key[r] >> shift) & 255u;
-                    unsigned long long peers = ~0ull;
-#pragma unroll
-                    for (int bit = 0; bit < 8; bit++) {
-                        const bool one = (dg >> bit) & 1u;
-                        const unsigned long long bal = __ballot(one);
-                        peers &= one ? bal : ~bal;
-                    }
-                    const u32 pop = (u32)__popcll(peers);
-                    const u32 rnk = (u32)__popcll(peers & ltMask);
-                    const int leader = __ffsll((long long)peers) - 1;
-                    u32 old = 0;
-                    if (lane == leader) { old = cntw[dg]; cntw[dg] = old + pop; }
-                    old = (u32)__shfl((int)old, leader, 64);
-                    pre[r] = old + rnk;
-                }
-            }
-            __syncthreads();
-            // exclusive scan of the counters in (digit, wave) order: thread t owns digit t >> 2, waves 4 (t & 3) .. + 3
-            {
-                const int dg = tid >> 2, w0 = (tid & 3) * 4;
-                const u32 c0 = cnt[(w0 + 0) * 256 + dg], c1 = cnt[(w0 + 1) * 256 + dg], c2 = cnt[(w0 + 2) * 256 + dg], c3 = cnt[(w0 + 3) * 256 + dg];
-                const u32 sum = c0 + c1 + c2 + c3;
-                const u32 incl = wave_incl_scan(sum);
-                if (lane == 63) wtot[wave] = incl;
-                __syncthreads();
-                u32 wbase = 0;
-                for (int w = 0; w < wave; w++) wbase += wtot[w];
-                const u32 excl = wbase + incl - sum;
-                cnt[(w0 + 0) * 256 + dg] = excl;
-                cnt[(w0 + 1) * 256 + dg] = excl + c0;
-                cnt[(w0 + 2) * 256 + dg] = excl + c0 + c1;
-                cnt[(w0 + 3) * 256 + dg] = excl + c0 + c1 + c2;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                if (r < R) {
-                    const u32 dg = (key[r] >> shift) & 255u;
-                    const u32 pos = cntw[dg] + pre[r];
-                    oK[pos] = key[r];
-                    oV[pos] = val[r];
-                }
-            }
-            __syncthreads();
-            if (pass + 1 < npass) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
+                for (int r = 0; r < MED_ROWS; r++) {
+                    key[r] = m; val[r] = 0; pos[r] = 0xFFFFFFFFu;
                     if (r < R) {
                         const u32 idx = waveBase + (u32)r * 64u + (u32)lane;
-                        key[r] = oK[idx]; val[r] = oV[idx];
+                        const bool valid = idx < n;
+                        if (valid) { key[r] = L.oK[idx]; val[r] = L.oV[idx]; }
+                        const bool oth = valid && key[r] != m, same = valid && key[r] == m;
+                        const unsigned long long bo = __ballot(oth), be = __ballot(same);
+                        if (oth) pos[r] = runO + (u32)__popcll(bo & ltMask);
+                        if (same) pos[r] = 0x80000000u | (runE + (u32)__popcll(be & ltMask));
+                        runO += (u32)__popcll(bo);
+                        runE += (u32)__popcll(be);
+                    }
+                }
+                if (lane == 0) { L.wtot[wave] = runO; L.wtot2[wave] = runE; }
+                __syncthreads();
+                u32 baseO = 0, baseE = 0, nOth = 0;
+                for (int w = 0; w < WAVES; w++) { if (w < wave) { baseO += L.wtot[w]; baseE += L.wtot2[w]; } nOth += L.wtot[w]; }
+#pragma unroll
+                for (int r = 0; r < MED_ROWS; r++) {
+                    if (r < R && pos[r] != 0xFFFFFFFFu) {
+                        const u32 at = (pos[r] & 0x80000000u) ? (nOth + baseE + (pos[r] & 0x7FFFFFFFu)) : (baseO + pos[r]);
+                        L.oK[at] = key[r];
+                        L.oV[at] = val[r];
                     }
                 }
                 __syncthreads();
+                if (nOth <= (u32)THREADS) {
+                    // few others: rank by counting (stable: smaller keys, then equal keys that come earlier)
+                    u32 kk = 0, vv = 0, at = 0;
+                    if ((u32)tid < nOth) {
+                        kk = L.oK[tid]; vv = L.oV[tid];
+                        for (u32 j = 0; j < nOth; j++) { const u32 kj = L.oK[j]; at += (kj < kk || (kj == kk && j < (u32)tid)) ? 1u : 0u; }
+                    }
+                    __syncthreads();
+                    if ((u32)tid < nOth) { L.oK[at] = kk; L.oV[at] = vv; }
+                    __syncthreads();
+                } else {
+                    med_radix_sort<THREADS>(L, nOth, npass);
+                }
+                u32 less = 0;
+                for (u32 i = (u32)tid; i < nOth; i += THREADS) less += (L.oK[i] < m) ? 1u : 0u;
+                less = med_block_sum(L, less);
+                // ---- [others < m][key m][others > m]
+#pragma unroll
+                for (int k = 0; k < MED_ROWS; k++) {
+                    const u32 i = (u32)tid + (u32)k * THREADS;
+                    if (i < n) { key[k] = L.oK[i]; val[k] = L.oV[i]; }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < MED_ROWS; k++) {
+                    const u32 i = (u32)tid + (u32)k * THREADS;
+                    if (i < n) {
+                        const u32 at = (i < less) ? i : (i < nOth ? i + c : less + (i - nOth));
+                        L.oK[at] = key[k];
+                        L.oV[at] = val[k];
+                    }
+                }
+                __syncthreads();
+            } else {
+                med_radix_sort<THREADS>(L, n, npass);
             }
         }
         // ---- subgroup boundaries of the sorted keys as a bit map in LDS + per-word summaries
         const int nWords = (int)((n + 31) >> 5);
-        if (tid < (int)(MED_CAP / 32)) {
+        if (tid < (int)(CAP / 32)) {
             u32 bits = 0;
             if (tid < nWords) {
                 const u32 i0 = (u32)tid * 32u;
-                u32 prev = (i0 == 0) ? 0u : oK[i0 - 1];
+                u32 prev = (i0 == 0) ? 0u : L.oK[i0 - 1];
                 for (u32 k = 0; k < 32; k++) {
                     const u32 i = i0 + k;
                     if (i >= n) break;
-                    const u32 cur = oK[i];
+                    const u32 cur = L.oK[i];
                     if (i == 0 || cur != prev) bits |= 1u << k;
                     prev = cur;
                 }
             }
-            fb[tid] = bits;
-            pm[tid] = bits ? (tid * 32 + 31 - __clz((int)bits)) : -1;
-            pn[tid] = bits ? (u32)(tid * 32 + __ffs((int)bits) - 1) : n;
+            L.fb[tid] = bits;
+            L.pm[tid] = bits ? (tid * 32 + 31 - __clz((int)bits)) : -1;
+            L.pn[tid] = bits ? (u32)(tid * 32 + __ffs((int)bits) - 1) : n;
         }
         __syncthreads();
-        for (int o = 1; o < (int)(MED_CAP / 32); o <<= 1) {
-            int a = -1; u32 c = n;
-            if (tid < (int)(MED_CAP / 32)) {
-                if (tid >= o) a = pm[tid - o];
-                if (tid + o < (int)(MED_CAP / 32)) c = pn[tid + o];
-            }
-            __syncthreads();
-            if (tid < (int)(MED_CAP / 32)) {
-                if (a > pm[tid]) pm[tid] = a;
-                if (c < pn[tid]) pn[tid] = c;
-            }
-            __syncthreads();
+        // inclusive prefix max of pm / suffix min of pn over the words, by the first wave (WPL consecutive words per lane)
+        if (tid < 64) {
+            constexpr int WPL = (int)(CAP / 32) / 64;
+            int run = -1;
+            for (int k = 0; k < WPL; k++) { const int x = L.pm[tid * WPL + k]; run = x > run ? x : run; }
+            int incl = run;
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, (unsigned)o, 64); if (tid >= o) incl = t > incl ? t : incl; }
+            int carry = __shfl_up(incl, 1u, 64);
+            if (tid == 0) carry = -1;
+            for (int k = 0; k < WPL; k++) { const int x = L.pm[tid * WPL + k]; carry = x > carry ? x : carry; L.pm[tid * WPL + k] = carry; }
+            u32 runn = n;
+            for (int k = WPL - 1; k >= 0; k--) { const u32 x = L.pn[tid * WPL + k]; runn = x < runn ? x : runn; }
+            u32 incn = runn;
+            for (int o = 1; o < 64; o <<= 1) { const u32 t = (u32)__shfl_down((int)incn, (unsigned)o, 64); if (tid + o < 64) incn = t < incn ? t : incn; }
+            u32 carn = (u32)__shfl_down((int)incn, 1u, 64);
+            if (tid == 63) carn = n;
+            for (int k = WPL - 1; k >= 0; k--) { const u32 x = L.pn[tid * WPL + k]; carn = x < carn ? x : carn; L.pn[tid * WPL + k] = carn; }
         }
+        __syncthreads();
         // pm[w] = last boundary at or before the end of word w, pn[w] = first boundary at or after the start of word w
         u32 surv = 0;
-        for (u32 i = (u32)tid; i < n; i += MED_THREADS) {
+        for (u32 i = (u32)tid; i < n; i += THREADS) {
             const u32 w = i >> 5, bit = i & 31;
             const u32 lowmask = (bit == 31) ? 0xFFFFFFFFu : ((2u << bit) - 1u);
-            const u32 word = fb[w];
-            const u32 m = word & lowmask;
-            const u32 hd = m ? (w * 32 + 31 - (u32)__clz((int)m)) : (u32)pm[w - 1];      // word 0 always has bit 0
-            const u32 gp = oV[i];
+            const u32 word = L.fb[w];
+            const u32 mm = word & lowmask;
+            const u32 hd = mm ? (w * 32 + 31 - (u32)__clz((int)mm)) : (u32)L.pm[w - 1];      // word 0 always has bit 0
+            const u32 gp = L.oV[i];
             v.SA[gs + i] = gp;
             if (hd != 0) v.ISA[gp] = gs + hd;
             if (hd == i) {
                 const u32 m2 = word & ~lowmask;
-                const u32 e = m2 ? (w * 32 + (u32)__ffs((int)m2) - 1) : ((w + 1 < (u32)(MED_CAP / 32)) ? pn[w + 1] : n);
+                const u32 e = m2 ? (w * 32 + (u32)__ffs((int)m2) - 1) : ((w + 1 < (u32)(CAP / 32)) ? L.pn[w + 1] : n);
                 classify_child(v, medNext, largeNext, gs + i, e - i, surv);
             }
         }
         if (__ballot(surv != 0) != 0 && lane == 0) v.counters[0] = 1;
         // new group starts into the round's bit map (bit 0 of the group is set already)
-        if (tid < nWords && fb[tid]) {
+        if (tid < nWords && L.fb[tid]) {
             const u32 off = gs + (u32)tid * 32u;
             const u32 sh = off & 31;
-            atomicOr(&v.gnew[off >> 5], fb[tid] << sh);
-            if (sh && (fb[tid] >> (32 - sh))) atomicOr(&v.gnew[(off >> 5) + 1], fb[tid] >> (32 - sh));
+            atomicOr(&v.gnew[off >> 5], L.fb[tid] << sh);
+            if (sh && (L.fb[tid] >> (32 - sh))) atomicOr(&v.gnew[(off >> 5) + 1], L.fb[tid] >> (32 - sh));
         }
         __syncthreads();
     }
@@ -678,7 +793,14 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
         }
         // -- then the refinements
         if (surv) { KScope ks_("k_bwt_f_sort_small"); hipLaunchKernelGGL(k_bwt_f_sort_small, dim3(nTiles), dim3(256), 0, s, v); }
-        if (nMed) { KScope ks_("k_bwt_f_sort_medium"); hipLaunchKernelGGL(k_bwt_f_sort_medium, dim3(std::min<u32>(nMed, 4096)), dim3(MED_THREADS), 0, s, v, w.med[cur], nMed, npass, w.med[nxt], w.large[nxt]); }
+        if (nMed) {
+            // three workgroup sizes over the same list, each takes the groups of its size class (LDS per group: 21 / 42 / 84 KB)
+            KScope ks_("k_bwt_f_sort_medium");
+            const dim3 gridM(std::min<u32>(nMed, 8192));
+            hipLaunchKernelGGL(k_bwt_f_sort_medium<256>, gridM, dim3(256), 0, s, v, w.med[cur], nMed, npass, SM_G, w.med[nxt], w.large[nxt]);
+            hipLaunchKernelGGL(k_bwt_f_sort_medium<512>, gridM, dim3(512), 0, s, v, w.med[cur], nMed, npass, 2048u, w.med[nxt], w.large[nxt]);
+            hipLaunchKernelGGL(k_bwt_f_sort_medium<1024>, gridM, dim3(1024), 0, s, v, w.med[cur], nMed, npass, 4096u, w.med[nxt], w.large[nxt]);
+        }
         if (nLarge) {
             pb = w.primBytes;
             { KScope ks_("bwt_f_sort_large");
@@ -695,6 +817,10 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
         if (hipMemcpyAsync(h_pinned, w.counters, 16, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
         if (hipStreamSynchronize(s) != hipSuccess) return -1;
         surv = h_pinned[0]; nMed = h_pinned[1]; nLarge = h_pinned[2]; largeElems = h_pinned[3];
+#ifdef KNZ_FWD_DEBUG
+        fprintf(stderr, "round h=%u: small left %u, medium %u, large %u (%u members)\n", h, surv, nMed, nLarge, largeElems);
+        for (u32 q = 0; q < nMed && q < 8; q++) fprintf(stderr, "   med[%u] = (%u, %u)\n", q, w.med[nxt][q].x, w.med[nxt][q].y);
+#endif
         cur = nxt;
         h <<= 1;
     }

@@ -44,8 +44,15 @@ def test_bwt_forward_kernels_emulated(tmp_path):
         z[p] = int(rng.integers(1, 256))
     words = [bytes(rng.integers(97, 101, int(rng.integers(2, 6)), dtype=np.uint8)) for _ in range(40)]
     babble = b" ".join(words[int(i)] for i in rng.integers(0, 40, 40000))[:150000]   # many groups that straddle window borders
+    # "abcdefg" + 2 random bytes, 3000 times: a group of 3000 whose members all look at different groups (plain LDS radix sort);
+    # period-4 and period-700 stretches: groups of ~5000 / ~1000 in which one key holds the majority (split + sort of the rest)
+    marked = b"".join(b"abcdefg" + rng.integers(0, 256, 2, dtype=np.uint8).tobytes() for _ in range(3000))
+    per4 = bytes((np.arange(20000) % 4).astype(np.uint8)) + c.text(3000, 5)
+    unit = rng.integers(0, 256, 700, dtype=np.uint8).tobytes()
+    per700 = unit * 12 + c.text(2000, 6) + unit * 9
     cases = [
         [babble],
+        [marked, per4, per700],
         [b"mississippi", b"abcabcabcabcabcabcab", bytes(5), b"a", b"ab", c.text(3000, 1), bytes((np.arange(1000) & 255).astype(np.uint8))],
         [c.text(30000, 2), bytes(3000) + c.text(500, 3), ramp, rng.integers(0, 4, 20000, dtype=np.uint8).tobytes()],
         [bytes(z), c.mixed(300000, 2)[250000:290000]],
