@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void k_bwt_f_gather_desc(FwdView v, const uint
     // Neighbouring descriptors are neighbouring groups (the list is filled roughly in slot order), and in periodic data their
     // members look at neighbouring words of ISA: workgroups that run on one XCD (index mod 8) take consecutive descriptors, so
     // that those lines are found in that XCD's L2. Placement only changes speed.
-    const u32 per = (gridDim.x + 7) / 8;
+    const u32 per = gridDim.x / 8;                        // the grid is a multiple of 8 workgroups
     for (u32 g = (blockIdx.x & 7) * per + (blockIdx.x >> 3); g < nDesc; g += per * 8) {
         const uint2 d = desc[g];
         if (threadIdx.x == 0) sBlk = find_block(v.base, v.nBlocks, d.x);
@@ -784,7 +784,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
         const int nxt = cur ^ 1;
         // -- all keys first
         if (surv) { KScope ks_("k_bwt_f_gather_small"); hipLaunchKernelGGL(k_bwt_f_gather_small, dim3(nTiles), dim3(256), 0, s, v, h); }
-        if (nMed) { KScope ks_("k_bwt_f_gather_desc"); hipLaunchKernelGGL(k_bwt_f_gather_desc, dim3(std::min<u32>(nMed, 8192)), dim3(256), 0, s, v, w.med[cur], nMed, h); }
+        if (nMed) { KScope ks_("k_bwt_f_gather_desc"); hipLaunchKernelGGL(k_bwt_f_gather_desc, dim3((std::min<u32>(nMed, 8192) + 7) & ~7u), dim3(256), 0, s, v, w.med[cur], nMed, h); }
         int lbits = 0;
         if (nLarge) {
             while ((1u << lbits) < nLarge) lbits++;
