@@ -33,7 +33,7 @@ constexpr u32 SM_TS = 1792;        // slots owned by one window
 constexpr u32 SM_WIN = 2048;       // slots a window looks at (owned + halo)
 constexpr u32 SM_G = 256;          // largest "small" group
 constexpr u32 MED_CAP = 8192;      // largest "medium" group (one workgroup of 1024 threads, LDS resident)
-constexpr int MED_ROWS = 8;        // elements per thread in the LDS sort
+constexpr int MED_ROWS = 16;       // most elements per thread in the LDS sort
 constexpr u32 NO_BIT = 0x7FFFFFFFu;
 
 struct FwdView {
@@ -301,10 +301,10 @@ __global__ __launch_bounds__(256) void k_bwt_f_gather_desc(FwdView v, const uint
 }
 
 // LDS of one sorting workgroup of THREADS threads: up to MED_ROWS elements per thread
-template <int THREADS>
+template <int THREADS, int ROWS>
 struct MedLds {
     static constexpr int WAVES = THREADS / 64;
-    static constexpr u32 CAP = (u32)MED_ROWS * THREADS;
+    static constexpr u32 CAP = (u32)ROWS * THREADS;
     u32 oK[CAP];
     u32 oV[CAP];
     u32 cnt[WAVES * 256];
@@ -315,14 +315,14 @@ struct MedLds {
     u32 wtot2[WAVES];
 };
 
-template <int THREADS>
-__device__ __forceinline__ u32 med_block_sum(MedLds<THREADS>& L, u32 x)
+template <int THREADS, int ROWS>
+__device__ __forceinline__ u32 med_block_sum(MedLds<THREADS, ROWS>& L, u32 x)
 {
     const u32 s = wave_sum(x);
     if ((threadIdx.x & 63) == 0) L.wtot[threadIdx.x >> 6] = s;
     __syncthreads();
     u32 tot = 0;
-    for (int w = 0; w < MedLds<THREADS>::WAVES; w++) tot += L.wtot[w];
+    for (int w = 0; w < THREADS / 64; w++) tot += L.wtot[w];
     __syncthreads();
     return tot;
 }
@@ -331,8 +331,8 @@ __device__ __forceinline__ u32 med_block_sum(MedLds<THREADS>& L, u32 x)
 // w*R*64 (R = rows of 64 per wave); the rank of an element among the elements of its wave with the same digit comes from
 // ballot matching (the lanes of a row that agree on all 8 digit bits), rows in order; per-wave digit counters are then
 // scanned in (digit, wave) order. Entered and left with the workgroup in step.
-template <int THREADS>
-__device__ __forceinline__ void med_radix_sort(MedLds<THREADS>& L, u32 n, int npass)
+template <int THREADS, int ROWS>
+__device__ __forceinline__ void med_radix_sort(MedLds<THREADS, ROWS>& L, u32 n, int npass)
 {
     constexpr int WAVES = THREADS / 64;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -343,9 +343,9 @@ __device__ __forceinline__ void med_radix_sort(MedLds<THREADS>& L, u32 n, int np
     for (int pass = 0; pass < npass; pass++) {
         const int shift = 8 * pass;
         for (int q = lane; q < 256; q += 64) cntw[q] = 0;
-        u32 key[MED_ROWS], val[MED_ROWS], pre[MED_ROWS];
+        u32 key[ROWS], val[ROWS], pre[ROWS];
 #pragma unroll
-        for (int r = 0; r < MED_ROWS; r++) {
+        for (int r = 0; r < ROWS; r++) {
             key[r] = 0xFFFFFFFFu; val[r] = 0; pre[r] = 0;
             if (r < R) {
                 const u32 idx = waveBase + (u32)r * 64u + (u32)lane;
@@ -387,7 +387,7 @@ __device__ __forceinline__ void med_radix_sort(MedLds<THREADS>& L, u32 n, int np
         }
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < MED_ROWS; r++) {
+        for (int r = 0; r < ROWS; r++) {
             if (r < R) {
                 const u32 dg = (key[r] >> shift) & 255u;
                 const u32 pos = cntw[dg] + pre[r];
@@ -402,18 +402,18 @@ __device__ __forceinline__ void med_radix_sort(MedLds<THREADS>& L, u32 n, int np
     (void)WAVES;
 }
 
-// One workgroup refines one group of 257..MED_ROWS*THREADS members (descriptors of other sizes are left to the other
+// One workgroup refines one group of 257..ROWS*THREADS members (descriptors of other sizes are left to the other
 // instantiations of the kernel): keys and positions into LDS, sort, subgroup boundaries, SA / ISA / bit map / children.
 // A group in which one key holds the majority (periodic stretches and runs: every member but the ones near the end of the
 // stretch looks at the same group h further on) is first split, stably, into "that key" and "the others"; only the
 // others are sorted.
-template <int THREADS>
-__global__ __launch_bounds__(THREADS) void k_bwt_f_sort_medium(FwdView v, const uint2* __restrict__ desc, u32 nDesc, int npass, u32 minLen,
+template <int THREADS, int ROWS>
+__global__ __launch_bounds__(THREADS, THREADS / 128) void k_bwt_f_sort_medium(FwdView v, const uint2* __restrict__ desc, u32 nDesc, int npass, u32 minLen,
                                                                uint2* __restrict__ medNext, uint2* __restrict__ largeNext)
 {
     constexpr int WAVES = THREADS / 64;
-    constexpr u32 CAP = (u32)MED_ROWS * THREADS;
-    __shared__ MedLds<THREADS> L;
+    constexpr u32 CAP = (u32)ROWS * THREADS;
+    __shared__ MedLds<THREADS, ROWS> L;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
@@ -434,10 +434,10 @@ __global__ __launch_bounds__(THREADS) void k_bwt_f_sort_medium(FwdView v, const 
                 // ---- stable split: [others (nOth)][members with key m (c)]
                 const int R = (int)((n + THREADS - 1) / THREADS);
                 const u32 waveBase = (u32)wave * (u32)R * 64u;
-                u32 key[MED_ROWS], val[MED_ROWS], pos[MED_ROWS];
+                u32 key[ROWS], val[ROWS], pos[ROWS];
                 u32 runO = 0, runE = 0;
 #pragma unroll
-                for (int r = 0; r < MED_ROWS; r++) {
+                for (int r = 0; r < ROWS; r++) {
                     key[r] = m; val[r] = 0; pos[r] = 0xFFFFFFFFu;
                     if (r < R) {
                         const u32 idx = waveBase + (u32)r * 64u + (u32)lane;
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(THREADS) void k_bwt_f_sort_medium(FwdView v, const 
                 u32 baseO = 0, baseE = 0, nOth = 0;
                 for (int w = 0; w < WAVES; w++) { if (w < wave) { baseO += L.wtot[w]; baseE += L.wtot2[w]; } nOth += L.wtot[w]; }
 #pragma unroll
-                for (int r = 0; r < MED_ROWS; r++) {
+                for (int r = 0; r < ROWS; r++) {
                     if (r < R && pos[r] != 0xFFFFFFFFu) {
                         const u32 at = (pos[r] & 0x80000000u) ? (nOth + baseE + (pos[r] & 0x7FFFFFFFu)) : (baseO + pos[r]);
                         L.oK[at] = key[r];
@@ -475,20 +475,20 @@ __global__ __launch_bounds__(THREADS) void k_bwt_f_sort_medium(FwdView v, const 
                     if ((u32)tid < nOth) { L.oK[at] = kk; L.oV[at] = vv; }
                     __syncthreads();
                 } else {
-                    med_radix_sort<THREADS>(L, nOth, npass);
+                    med_radix_sort<THREADS, ROWS>(L, nOth, npass);
                 }
                 u32 less = 0;
                 for (u32 i = (u32)tid; i < nOth; i += THREADS) less += (L.oK[i] < m) ? 1u : 0u;
                 less = med_block_sum(L, less);
                 // ---- [others < m][key m][others > m]
 #pragma unroll
-                for (int k = 0; k < MED_ROWS; k++) {
+                for (int k = 0; k < ROWS; k++) {
                     const u32 i = (u32)tid + (u32)k * THREADS;
                     if (i < n) { key[k] = L.oK[i]; val[k] = L.oV[i]; }
                 }
                 __syncthreads();
 #pragma unroll
-                for (int k = 0; k < MED_ROWS; k++) {
+                for (int k = 0; k < ROWS; k++) {
                     const u32 i = (u32)tid + (u32)k * THREADS;
                     if (i < n) {
                         const u32 at = (i < less) ? i : (i < nOth ? i + c : less + (i - nOth));
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(THREADS) void k_bwt_f_sort_medium(FwdView v, const 
                 }
                 __syncthreads();
             } else {
-                med_radix_sort<THREADS>(L, n, npass);
+                med_radix_sort<THREADS, ROWS>(L, n, npass);
             }
         }
         // ---- subgroup boundaries of the sorted keys as a bit map in LDS + per-word summaries
@@ -794,12 +794,12 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
         // -- then the refinements
         if (surv) { KScope ks_("k_bwt_f_sort_small"); hipLaunchKernelGGL(k_bwt_f_sort_small, dim3(nTiles), dim3(256), 0, s, v); }
         if (nMed) {
-            // three workgroup sizes over the same list, each takes the groups of its size class (LDS per group: 21 / 42 / 84 KB)
+            // two workgroup shapes over the same list, each takes the groups of its size class: 256 threads x 8 elements (21 KB of LDS,
+            // groups up to 2048) and 512 threads x 16 elements (76 KB: two groups per CU in flight)
             KScope ks_("k_bwt_f_sort_medium");
             const dim3 gridM(std::min<u32>(nMed, 8192));
-            hipLaunchKernelGGL(k_bwt_f_sort_medium<256>, gridM, dim3(256), 0, s, v, w.med[cur], nMed, npass, SM_G, w.med[nxt], w.large[nxt]);
-            hipLaunchKernelGGL(k_bwt_f_sort_medium<512>, gridM, dim3(512), 0, s, v, w.med[cur], nMed, npass, 2048u, w.med[nxt], w.large[nxt]);
-            hipLaunchKernelGGL(k_bwt_f_sort_medium<1024>, gridM, dim3(1024), 0, s, v, w.med[cur], nMed, npass, 4096u, w.med[nxt], w.large[nxt]);
+            hipLaunchKernelGGL((k_bwt_f_sort_medium<256, 8>), gridM, dim3(256), 0, s, v, w.med[cur], nMed, npass, SM_G, w.med[nxt], w.large[nxt]);
+            hipLaunchKernelGGL((k_bwt_f_sort_medium<512, 16>), gridM, dim3(512), 0, s, v, w.med[cur], nMed, npass, 2048u, w.med[nxt], w.large[nxt]);
         }
         if (nLarge) {
             pb = w.primBytes;
