@@ -18,8 +18,13 @@
 #ifndef KANZI_AMD_HPP
 #define KANZI_AMD_HPP
 
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
+#include <exception>
 #include <istream>
+#include <mutex>
+#include <thread>
 #include <map>
 #include <ostream>
 #include <stdexcept>
@@ -316,7 +321,7 @@ public:
     std::ostream& write(const char* s, std::streamsize n);
     std::ostream& put(char c);
     void close();
-    uint64 getWritten() const { return _written; }
+    uint64 getWritten() const { return _written.load(); }
     // number of blocks handed to the device per call (default: jobs, like the reference keeps `jobs` blocks in flight)
     void setBatchBlocks(int n) { if (n > 0) _batchBlocks = n; }
 private:
@@ -328,12 +333,24 @@ private:
     bool _headless, _closed, _headerDone;
     int _batchBlocks;
     int64 _blockId;               // blocks submitted so far
-    std::vector<byte> _buffer;    // pending uncompressed bytes
     byte _pendingByte;            // partial last byte of the stream written so far
     uint _pendingBits;
-    uint64 _written;              // bytes that reached the sink
+    std::atomic<uint64_t> _written;   // bytes that reached the sink (advanced by the worker thread)
     void* _dIn; size_t _dInCap; void* _dOut; size_t _dOutCap;
-    std::vector<byte> _host;
+    // Two page-locked input slots: write() fills one while a worker thread moves the other through the device
+    // (H2D, kernels, D2H into a page-locked output buffer, sink write), so that the caller's copies overlap the GPU.
+    struct Slot { byte* buf; size_t cap; size_t n; bool last; int state; };   // state: 0 free, 1 queued
+    Slot _slot[2];
+    int _fill, _proc;
+    byte* _hostOut; size_t _hostOutCap;
+    std::thread _worker;
+    std::mutex _mu;
+    std::condition_variable _cv;
+    bool _stop;
+    std::exception_ptr _err;
+    void enqueue(bool last);
+    void workerLoop();
+    void rethrow();
     void submit(bool last);
 };
 
@@ -369,7 +386,8 @@ private:
     uint64 _compBit;              // next unread bit in _comp
     uint64 _consumedBits;
     int64 _originBit;             // bit position in the underlying stream that _compBit == 0 corresponds to
-    std::vector<byte> _plain;     // decoded bytes not yet delivered
+    byte* _plain; size_t _plainCap, _plainLen;   // decoded bytes not yet delivered (page-locked)
+    byte* _stage; size_t _stageCap;              // page-locked staging of the compressed bytes of a batch
     size_t _plainPos;
     std::streamsize _gcount;
     bool _srcEof;

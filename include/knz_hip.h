@@ -129,6 +129,9 @@ KNZ_API int knz_hip_free(knz_ctx* ctx, void* d_ptr);
 KNZ_API int knz_hip_memcpy_h2d(knz_ctx* ctx, void* d_dst, const void* src, size_t bytes);
 KNZ_API int knz_hip_memcpy_d2h(knz_ctx* ctx, void* dst, const void* d_src, size_t bytes);
 KNZ_API int knz_hip_sync(knz_ctx* ctx);
+/* Page-locked host memory for staging buffers (what knz_hip_memcpy_h2d / _d2h move at full PCIe rate). */
+KNZ_API int knz_hip_host_alloc(size_t bytes, void** ptr);
+KNZ_API int knz_hip_host_free(void* ptr);
 
 /* Timing of the kernels of the last encode/decode call, measured with HIP events on the context's
  * stream: name/ms pairs. Returns the number of entries written (<= cap). */

@@ -247,6 +247,14 @@ int knz_hip_memcpy_d2h(knz_ctx* ctx, void* dst, const void* d_src, size_t bytes)
     return 0;
 }
 
+int knz_hip_host_alloc(size_t bytes, void** ptr)
+{
+    *ptr = nullptr;
+    return hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? 0 : -1;
+}
+
+int knz_hip_host_free(void* ptr) { return (ptr == nullptr || hipHostFree(ptr) == hipSuccess) ? 0 : -1; }
+
 int knz_hip_sync(knz_ctx* ctx)
 {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);

@@ -33,7 +33,6 @@ constexpr u32 SM_TS = 1792;        // slots owned by one window
 constexpr u32 SM_WIN = 2048;       // slots a window looks at (owned + halo)
 constexpr u32 SM_G = 256;          // largest "small" group
 constexpr u32 MED_CAP = 8192;      // largest "medium" group (one workgroup of 1024 threads, LDS resident)
-constexpr int MED_ROWS = 16;       // most elements per thread in the LDS sort
 constexpr u32 NO_BIT = 0x7FFFFFFFu;
 
 struct FwdView {
@@ -300,7 +299,7 @@ __global__ __launch_bounds__(256) void k_bwt_f_gather_desc(FwdView v, const uint
     }
 }
 
-// LDS of one sorting workgroup of THREADS threads: up to MED_ROWS elements per thread
+// LDS of one sorting workgroup of THREADS threads: up to ROWS elements per thread
 template <int THREADS, int ROWS>
 struct MedLds {
     static constexpr int WAVES = THREADS / 64;

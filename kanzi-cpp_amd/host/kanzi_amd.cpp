@@ -654,6 +654,38 @@ static uint64 getBitsAt(const std::vector<byte>& d, uint64 pos, uint n)
 // ------------------------------------------------------------------------------------------------
 // CompressedOutputStream
 // ------------------------------------------------------------------------------------------------
+// Page-locked staging memory is expensive to create (the pages are pinned one by one) and cheap to keep: buffers go
+// back to a process-wide pool when a stream is done with them.
+namespace {
+struct PinnedPool {
+    std::mutex mu;
+    std::vector<std::pair<void*, size_t>> idle;
+    byte* get(size_t bytes, size_t* cap)
+    {
+        {
+            std::lock_guard<std::mutex> l(mu);
+            size_t best = idle.size();
+            for (size_t i = 0; i < idle.size(); i++)
+                if (idle[i].second >= bytes && (best == idle.size() || idle[i].second < idle[best].second)) best = i;
+            if (best != idle.size()) { void* p = idle[best].first; *cap = idle[best].second; idle.erase(idle.begin() + long(best)); return static_cast<byte*>(p); }
+        }
+        void* p = nullptr;
+        const size_t want = bytes + (bytes >> 3) + 4096;
+        if (knz_hip_host_alloc(want, &p) != 0 || p == nullptr) throw IOException("cannot allocate page-locked staging memory", Error::ERR_CREATE_STREAM);
+        *cap = want;
+        return static_cast<byte*>(p);
+    }
+    void put(byte* p, size_t cap)
+    {
+        if (!p) return;
+        std::lock_guard<std::mutex> l(mu);
+        if (idle.size() >= 8) { knz_hip_host_free(p); return; }
+        idle.push_back(std::make_pair(static_cast<void*>(p), cap));
+    }
+};
+PinnedPool g_pinned;
+}
+
 CompressedOutputStream::CompressedOutputStream(std::ostream& os, int tasks, const std::string& entropy, const std::string& transform,
                                                int blockSize, int checksum, uint64 fileSize, bool headerless)
     : std::ostream(os.rdbuf()), _os(os)
@@ -669,8 +701,9 @@ CompressedOutputStream::CompressedOutputStream(std::ostream& os, int tasks, cons
     _inputSize = fileSize;
     _headless = headerless; _closed = false; _headerDone = false;
     // Blocks per device call.  `jobs` only selects the reference's buffer-slot capacities in the bitstream; the
-    // GPU wants many blocks per launch, so by default up to 256 MiB (at most 64 blocks) are gathered per call.
-    { const int64_t want = (int64_t(256) << 20) / int64_t(blockSize); _batchBlocks = std::max(tasks, int(std::min<int64_t>(64, std::max<int64_t>(1, want)))); }
+    // GPU wants many blocks per launch and the host wants several batches in flight (the caller fills one staging
+    // slot while the device works on the other), so by default a batch is 64 MiB (at least `jobs` blocks, at most 64).
+    { const int64_t want = (int64_t(64) << 20) / int64_t(blockSize); _batchBlocks = std::max(tasks, int(std::min<int64_t>(64, std::max<int64_t>(1, want)))); }
     const char* e = getenv("KNZ_BATCH_BLOCKS");
     if (e && atoi(e) > 0) _batchBlocks = atoi(e);
     // one device call takes at most 2 GiB of input (32-bit positions on the device side)
@@ -678,34 +711,101 @@ CompressedOutputStream::CompressedOutputStream(std::ostream& os, int tasks, cons
     _blockId = 0;
     _pendingByte = 0; _pendingBits = 0; _written = 0;
     _dIn = _dOut = nullptr; _dInCap = _dOutCap = 0;
+    for (int i = 0; i < 2; i++) { _slot[i].buf = nullptr; _slot[i].cap = 0; _slot[i].n = 0; _slot[i].last = false; _slot[i].state = 0; }
+    _fill = 0; _proc = 0; _hostOut = nullptr; _hostOutCap = 0; _stop = false;
     deviceContext();
 }
 
 CompressedOutputStream::~CompressedOutputStream()
 {
     try { close(); } catch (...) {}
+    if (_worker.joinable()) {
+        { std::lock_guard<std::mutex> l(_mu); _stop = true; }
+        _cv.notify_all();
+        _worker.join();
+    }
     knz_ctx* c = nullptr;
     try { c = deviceContext(); } catch (...) {}
     if (c) { if (_dIn) knz_hip_free(c, _dIn); if (_dOut) knz_hip_free(c, _dOut); }
+    for (int i = 0; i < 2; i++) g_pinned.put(_slot[i].buf, _slot[i].cap);
+    g_pinned.put(_hostOut, _hostOutCap);
+}
+
+void CompressedOutputStream::rethrow()
+{
+    std::exception_ptr e;
+    { std::lock_guard<std::mutex> l(_mu); e = _err; _err = nullptr; }
+    if (e) std::rethrow_exception(e);
 }
 
 std::ostream& CompressedOutputStream::write(const char* data, std::streamsize length)
 {
     if (length < 0) throw IOException("Invalid buffer size");
     if (_closed) throw IOException("Stream closed", Error::ERR_WRITE_FILE);
-    _buffer.insert(_buffer.end(), reinterpret_cast<const byte*>(data), reinterpret_cast<const byte*>(data) + length);
+    rethrow();
     const size_t batchBytes = size_t(_batchBlocks) * size_t(_blockSize);
-    while (_buffer.size() >= batchBytes) submit(false);
+    size_t off = 0;
+    while (off < size_t(length)) {
+        Slot& sl = _slot[_fill];
+        if (sl.buf == nullptr) sl.buf = g_pinned.get(batchBytes + 64, &sl.cap);
+        const size_t take = std::min(size_t(length) - off, batchBytes - sl.n);
+        memcpy(sl.buf + sl.n, data + off, take);
+        sl.n += take;
+        off += take;
+        if (sl.n == batchBytes) enqueue(false);
+    }
     return *this;
 }
 
 std::ostream& CompressedOutputStream::put(char c) { return write(&c, 1); }
 
+// hand the slot being filled to the worker and wait until the other slot is free
+void CompressedOutputStream::enqueue(bool last)
+{
+    if (!_worker.joinable()) _worker = std::thread(&CompressedOutputStream::workerLoop, this);
+    {
+        std::unique_lock<std::mutex> l(_mu);
+        _slot[_fill].last = last;
+        _slot[_fill].state = 1;
+        _fill ^= 1;
+        _cv.notify_all();
+        _cv.wait(l, [&] { return _slot[_fill].state == 0 || _err; });
+    }
+    rethrow();
+}
+
+void CompressedOutputStream::workerLoop()
+{
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> l(_mu);
+            _cv.wait(l, [&] { return _stop || _slot[_proc].state == 1; });
+            if (_slot[_proc].state != 1) return;
+        }
+        bool last = _slot[_proc].last;
+        try {
+            submit(last);
+        } catch (...) {
+            std::lock_guard<std::mutex> l(_mu);
+            if (!_err) _err = std::current_exception();
+        }
+        {
+            std::lock_guard<std::mutex> l(_mu);
+            _slot[_proc].n = 0;
+            _slot[_proc].state = 0;
+            _proc ^= 1;
+        }
+        _cv.notify_all();
+        if (last) return;
+    }
+}
+
+// worker thread: one batch through the device and into the sink
 void CompressedOutputStream::submit(bool last)
 {
     knz_ctx* c = deviceContext();
-    const size_t batchBytes = size_t(_batchBlocks) * size_t(_blockSize);
-    const size_t n = last ? _buffer.size() : batchBytes;
+    Slot& sl = _slot[_proc];
+    const size_t n = sl.n;
     knz_params p;
     memset(&p, 0, sizeof(p));
     p.transform_type = _transformType; p.entropy_type = _entropyType; p.block_size = _blockSize; p.checksum_bits = _checksum; p.jobs = _jobs;
@@ -730,26 +830,25 @@ void CompressedOutputStream::submit(bool last)
     const size_t cap = knz_hip_encode_bound(&p, n) + pro.bytes.size() + 256;
     if (_dInCap < n + 64) { if (_dIn) knz_hip_free(c, _dIn); devCheck(c, knz_hip_malloc(c, n + 64 + (n >> 2), &_dIn), "malloc"); _dInCap = n + 64 + (n >> 2); }
     if (_dOutCap < cap) { if (_dOut) knz_hip_free(c, _dOut); devCheck(c, knz_hip_malloc(c, cap + (cap >> 2), &_dOut), "malloc"); _dOutCap = cap + (cap >> 2); }
-    if (n) devCheck(c, knz_hip_memcpy_h2d(c, _dIn, _buffer.data(), n), "h2d");
+    if (n) devCheck(c, knz_hip_memcpy_h2d(c, _dIn, sl.buf, n), "h2d");
     uint64_t bits = 0;
     devCheck(c, knz_hip_encode_blocks(c, &p, static_cast<const uint8_t*>(_dIn), n, pro.bytes.empty() ? nullptr : pro.bytes.data(), uint32_t(pro.nbits),
                                       _blockId, last ? 1 : 0, static_cast<uint8_t*>(_dOut), _dOutCap, &bits), "encode blocks");
     const size_t bytes = size_t((bits + 7) >> 3);
-    _host.resize(bytes + 8);
-    if (bytes) devCheck(c, knz_hip_memcpy_d2h(c, _host.data(), _dOut, bytes), "d2h");
+    if (_hostOutCap < bytes + 8) { g_pinned.put(_hostOut, _hostOutCap); _hostOut = nullptr; _hostOutCap = 0; _hostOut = g_pinned.get(std::max(bytes + 8, cap / 2), &_hostOutCap); }
+    if (bytes) devCheck(c, knz_hip_memcpy_d2h(c, _hostOut, _dOut, bytes), "d2h");
     const size_t full = size_t(bits >> 3);
     const uint rem = uint(bits & 7);
     size_t toWrite = full;
     if (last && rem) toWrite = full + 1;          // close(): the last byte is zero padded
     if (toWrite) {
-        _os.write(reinterpret_cast<const char*>(_host.data()), std::streamsize(toWrite));
+        _os.write(reinterpret_cast<const char*>(_hostOut), std::streamsize(toWrite));
         if (_os.fail()) throw IOException("Write to bitstream failed", Error::ERR_WRITE_FILE);
         _written += toWrite;
     }
     _pendingBits = last ? 0 : rem;
-    _pendingByte = (rem && !last) ? _host[full] : 0;
+    _pendingByte = (rem && !last) ? _hostOut[full] : 0;
     _blockId += int64((n + size_t(_blockSize) - 1) / size_t(_blockSize));
-    _buffer.erase(_buffer.begin(), _buffer.begin() + n);
 }
 
 void CompressedOutputStream::close()
@@ -757,8 +856,17 @@ void CompressedOutputStream::close()
     if (_closed) return;
     _closed = true;
     try {
-        submit(true);
+        enqueue(true);                      // the last batch (possibly empty) carries the end marker
+        {
+            std::unique_lock<std::mutex> l(_mu);
+            _cv.wait(l, [&] { return (_slot[0].state == 0 && _slot[1].state == 0) || _err; });
+        }
+        if (_worker.joinable()) _worker.join();
+        rethrow();
         _os.flush();
+    } catch (const IOException&) {
+        setstate(std::ios::badbit);
+        throw;
     } catch (const std::exception& e) {
         setstate(std::ios::badbit);
         throw IOException(e.what(), Error::ERR_WRITE_FILE);
@@ -788,6 +896,7 @@ CompressedInputStream::CompressedInputStream(std::istream& is, int tasks, const 
     _batchFromEnv = false;
     if (e && atoi(e) > 0) { _batchBlocks = atoi(e); _batchFromEnv = true; }
     _compBit = 0; _consumedBits = 0; _plainPos = 0; _gcount = 0; _srcEof = false;
+    _plain = nullptr; _plainCap = 0; _plainLen = 0; _stage = nullptr; _stageCap = 0;
     { _is.clear(); const std::streamoff at = std::streamoff(_is.tellg()); _originBit = (at < 0) ? 0 : 8 * int64(at); _is.clear(); }
     _dIn = _dOut = nullptr; _dInCap = _dOutCap = 0;
     deviceContext();
@@ -798,6 +907,8 @@ CompressedInputStream::~CompressedInputStream()
     knz_ctx* c = nullptr;
     try { c = deviceContext(); } catch (...) {}
     if (c) { if (_dIn) knz_hip_free(c, _dIn); if (_dOut) knz_hip_free(c, _dOut); }
+    g_pinned.put(_plain, _plainCap);
+    g_pinned.put(_stage, _stageCap);
 }
 
 bool CompressedInputStream::fetch(size_t minBytes)
@@ -899,15 +1010,19 @@ bool CompressedInputStream::decodeBatch()
         const size_t outCap = size_t(nb) * size_t(_blockSize) + 64;
         if (_dInCap < inBytes + 64) { if (_dIn) knz_hip_free(c, _dIn); devCheck(c, knz_hip_malloc(c, inBytes + 64 + (inBytes >> 2), &_dIn), "malloc"); _dInCap = inBytes + 64 + (inBytes >> 2); }
         if (_dOutCap < outCap) { if (_dOut) knz_hip_free(c, _dOut); devCheck(c, knz_hip_malloc(c, outCap + (outCap >> 2), &_dOut), "malloc"); _dOutCap = outCap + (outCap >> 2); }
-        devCheck(c, knz_hip_memcpy_h2d(c, _dIn, &_comp[firstByte], inBytes), "h2d");
+        // through page-locked staging: the pageable vector would be bounced by the runtime at a fraction of the PCIe rate
+        if (_stageCap < inBytes) { g_pinned.put(_stage, _stageCap); _stage = nullptr; _stageCap = 0; _stage = g_pinned.get(inBytes, &_stageCap); }
+        memcpy(_stage, &_comp[firstByte], inBytes);
+        devCheck(c, knz_hip_memcpy_h2d(c, _dIn, _stage, inBytes), "h2d");
         uint64_t outBytes = 0, endBit = 0;
         int64_t done = 0;
         const uint64 startBit = _compBit - uint64(firstByte) * 8;
         devCheck(c, knz_hip_decode_blocks(c, &p, static_cast<const uint8_t*>(_dIn), uint64(inBytes) * 8, startBit, nb,
                                           static_cast<uint8_t*>(_dOut), outCap, &outBytes, &endBit, &done), "decode blocks");
-        _plain.resize(size_t(outBytes));
+        if (_plainCap < size_t(outBytes)) { g_pinned.put(_plain, _plainCap); _plain = nullptr; _plainCap = 0; _plain = g_pinned.get(std::max(size_t(outBytes), outCap), &_plainCap); }
+        _plainLen = size_t(outBytes);
         _plainPos = 0;
-        if (outBytes) devCheck(c, knz_hip_memcpy_d2h(c, _plain.data(), _dOut, size_t(outBytes)), "d2h");
+        if (outBytes) devCheck(c, knz_hip_memcpy_d2h(c, _plain, _dOut, size_t(outBytes)), "d2h");
     }
     _consumedBits += pos - _compBit;
     _compBit = pos;
@@ -921,12 +1036,12 @@ std::istream& CompressedInputStream::read(char* data, std::streamsize length)
     if (_closed) throw IOException("Stream closed", Error::ERR_READ_FILE);
     std::streamsize remaining = length;
     while (remaining > 0) {
-        if (_plainPos >= _plain.size()) {
-            _plain.clear(); _plainPos = 0;
+        if (_plainPos >= _plainLen) {
+            _plainLen = 0; _plainPos = 0;
             if (!decodeBatch()) { setstate(std::ios::eofbit); break; }
-            if (_plain.empty()) continue;
+            if (_plainLen == 0) continue;
         }
-        const size_t take = std::min<size_t>(size_t(remaining), _plain.size() - _plainPos);
+        const size_t take = std::min<size_t>(size_t(remaining), _plainLen - _plainPos);
         memcpy(data + _gcount, &_plain[_plainPos], take);
         _plainPos += take;
         _gcount += std::streamsize(take);
@@ -937,9 +1052,9 @@ std::istream& CompressedInputStream::read(char* data, std::streamsize length)
 
 int CompressedInputStream::peek()
 {
-    if (_plainPos >= _plain.size()) {
-        _plain.clear(); _plainPos = 0;
-        while (_plain.empty()) if (!decodeBatch()) { setstate(std::ios::eofbit); return EOF; }
+    if (_plainPos >= _plainLen) {
+        _plainLen = 0; _plainPos = 0;
+        while (_plainLen == 0) if (!decodeBatch()) { setstate(std::ios::eofbit); return EOF; }
     }
     return int(_plain[_plainPos]);
 }
@@ -968,7 +1083,7 @@ bool CompressedInputStream::seek(int64 bitPos)
     if (_is.fail()) return false;
     // forget everything fetched or decoded; the stream parameters (header) stay
     _comp.clear();
-    _plain.clear(); _plainPos = 0;
+    _plainLen = 0; _plainPos = 0;
     _gcount = 0;
     _srcEof = false; _ended = false;
     _originBit = (bitPos >> 3) * 8;

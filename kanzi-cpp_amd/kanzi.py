@@ -147,7 +147,9 @@ class Decompressor:
         return self.decompress(max_output)
 
     def decompress(self, n):
-        buf = C.create_string_buffer(max(1, n))
+        if getattr(self, "_buf", None) is None or len(self._buf) < max(1, n):
+            self._buf = C.create_string_buffer(max(1, n))      # kept across calls: no zero fill per block
+        buf = self._buf
         ins, outs = C.c_size_t(0), C.c_size_t(n)
         rc = lib().decompress(self._ctx, buf, C.byref(ins), C.byref(outs))
         if rc != 0:
