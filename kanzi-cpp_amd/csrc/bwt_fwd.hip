@@ -18,7 +18,7 @@
 //       symbol are what produces them.
 //   Keys are gathered by separate kernels before any kernel of the round moves a position or changes ISA (a refined
 //   head read beside an unrefined one would order two suffixes that are still equal).
-//   Round 0 sorts 9-bit symbols packed in 64-bit keys (block id on top) with rocPRIM's LSD sort.
+//   Round 0 sorts the first 6 bytes (block id on top, suffix length below) as one 64-bit key with rocPRIM's LSD sort.
 #include "common.hpp"
 #include "stages.hpp"
 #include "bwt_common.hpp"
@@ -93,7 +93,10 @@ __global__ void k_bwt_bases(BwtView v, u32* __restrict__ base, u8* __restrict__ 
     base[v.nBlocks] = sum;
 }
 
-// keys: [block id | symbols as 9-bit values (byte + 1, 0 past the block end)], values: global position ids
+// keys: [block id | nsym bytes, zero past the block end | min(suffix length, nsym) in 3 bits], values: global position ids.
+// Padding with the smallest byte and breaking ties by length puts a suffix that ends inside the prefix in front of every
+// longer suffix that continues with zero bytes ("shorter sorts first"); suffixes of at least nsym bytes with equal keys share
+// their first nsym symbols.
 __global__ __launch_bounds__(256) void k_bwt_f_init(BwtView v, const u32* __restrict__ base, const u8* __restrict__ ok, int nsym,
                                                     u64* __restrict__ keys, u32* __restrict__ vals)
 {
@@ -105,8 +108,10 @@ __global__ __launch_bounds__(256) void k_bwt_f_init(BwtView v, const u32* __rest
         u64 k = (u64)b;
         for (int q = 0; q < nsym; q++) {
             const u32 j = i + (u32)q;
-            k = (k << 9) | (j < n ? (u64)s[j] + 1 : 0ull);
+            k = (k << 8) | (j < n ? (u64)s[j] : 0ull);
         }
+        const u32 left = n - i;
+        k = (k << 3) | (u64)(left < (u32)nsym ? left : (u32)nsym);
         keys[base[b] + i] = k;
         vals[base[b] + i] = base[b] + i;
     }
@@ -279,21 +284,25 @@ __global__ __launch_bounds__(256) void k_bwt_f_sort_small(FwdView v)
 // ------------------------------------------------------------------------------------------------
 // medium groups: one workgroup per descriptor
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_bwt_f_gather_desc(FwdView v, const uint2* __restrict__ desc, u32 nDesc, u32 h)
+// The descriptors arrive sorted by start slot: neighbours in the list are neighbouring groups, and in periodic data (the
+// members of group v+1 are the members of group v moved by one position) their members look at neighbouring words of ISA.
+// The 32 workgroups that run on one XCD (workgroup index mod 8 -- an observed placement, used for speed only) walk through one
+// contiguous eighth of the list side by side, so that a line of ISA fetched for one group is found in that XCD's L2 by the
+// 31 groups next to it, instead of being fetched from memory once per group.
+__global__ __launch_bounds__(1024) void k_bwt_f_gather_desc(FwdView v, const uint2* __restrict__ desc, u32 nDesc, u32 h)
 {
     __shared__ int sBlk;
-    // Neighbouring descriptors are neighbouring groups (the list is filled roughly in slot order), and in periodic data their
-    // members look at neighbouring words of ISA: workgroups that run on one XCD (index mod 8) take consecutive descriptors, so
-    // that those lines are found in that XCD's L2. Placement only changes speed.
-    const u32 per = gridDim.x / 8;                        // the grid is a multiple of 8 workgroups
-    for (u32 g = (blockIdx.x & 7) * per + (blockIdx.x >> 3); g < nDesc; g += per * 8) {
+    const u32 xcd = blockIdx.x & 7, lanesPerXcd = gridDim.x >> 3, slot = blockIdx.x >> 3;      // the grid is a multiple of 8 workgroups
+    const u32 per = (nDesc + 7) / 8;
+    const u32 lo = xcd * per, hi = (lo + per < nDesc) ? lo + per : nDesc;
+    for (u32 g = lo + slot; g < hi; g += lanesPerXcd) {
         const uint2 d = desc[g];
         if (threadIdx.x == 0) sBlk = find_block(v.base, v.nBlocks, d.x);
         __syncthreads();
         const u32 bb = v.base[sBlk], be = v.base[sBlk + 1];
-        for (u32 i = threadIdx.x; i < d.y; i += 256) {
-            const u32 slot = d.x + i;
-            v.K[slot] = gather_key(v.ISA, v.SA[slot], h, bb, be);
+        for (u32 i = threadIdx.x; i < d.y; i += 1024) {
+            const u32 sl = d.x + i;
+            v.K[sl] = gather_key(v.ISA, v.SA[sl], h, bb, be);
         }
         __syncthreads();
     }
@@ -687,7 +696,7 @@ struct FwdScratch {
     u32* SA; u32* ISA; u32* K;
     u32* t0; u32* t1; u32* t2; u32* t3;
     u32* gbits; u32* gnew; size_t gbitsWords;
-    uint2* med[2]; uint2* large[2];
+    uint2* med[2]; uint2* medSorted; uint2* large[2];
     u32* loff;
     u32* base;
     u32* counters;
@@ -708,7 +717,7 @@ static size_t fwd_carve(u8* p, int nBlocks, size_t total, size_t bytes, FwdScrat
     w->t0 = (u32*)take(4 * total); w->t1 = (u32*)take(4 * total); w->t2 = (u32*)take(4 * total); w->t3 = (u32*)take(4 * total);
     w->gbits = (u32*)take(4 * w->gbitsWords);
     w->gnew = (u32*)take(4 * w->gbitsWords);
-    w->med[0] = (uint2*)take(8 * maxMed); w->med[1] = (uint2*)take(8 * maxMed);
+    w->med[0] = (uint2*)take(8 * maxMed); w->med[1] = (uint2*)take(8 * maxMed); w->medSorted = (uint2*)take(8 * maxMed);
     w->large[0] = (uint2*)take(8 * maxLarge); w->large[1] = (uint2*)take(8 * maxLarge);
     w->loff = (u32*)take(4 * (maxLarge + 1));
     w->base = (u32*)take(4ull * (nBlocks + 2));
@@ -749,13 +758,16 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     // ---- round 0: sort by the first nsym symbols
     int bbits = 0;
     while ((1 << bbits) < st.nBlocks) bbits++;
-    const int nsym = (64 - bbits) / 9;
+    // 56 key bits = 7 passes of the LSD sort where the block count allows it
+    int nsym = (53 - bbits) / 8;
+    if (nsym < 4) nsym = (61 - bbits) / 8;
+    if (nsym > 7) nsym = 7;
     if (nsym < 1) return -4;
     const dim3 gridB((unsigned)std::min<size_t>(((size_t)bv.VS + 255) / 256, 4096), st.nBlocks);
     { KScope ks_("k_bwt_f_init"); hipLaunchKernelGGL(k_bwt_f_init, gridB, dim3(256), 0, s, bv, w.base, st.ok, nsym, w.keysA, w.valsA); }
     size_t pb = w.primBytes;
     { KScope ks_("bwt_f_sort_round0");
-      if (rocprim::radix_sort_pairs(w.prim, pb, w.keysA, w.keysB, w.valsA, w.valsB, (size_t)total, 0u, (unsigned)(bbits + 9 * nsym), s) != hipSuccess) return -1; }
+      if (rocprim::radix_sort_pairs(w.prim, pb, w.keysA, w.keysB, w.valsA, w.valsB, (size_t)total, 0u, (unsigned)(bbits + 8 * nsym + 3), s) != hipSuccess) return -1; }
     // every bit from `total` on is set (end sentinel, and windows may look past the end)
     hipMemsetAsync(w.gbits, 0xFF, 4 * w.gbitsWords, s);
     hipMemsetAsync(w.gnew, 0, 4 * w.gbitsWords, s);
@@ -783,7 +795,14 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
         const int nxt = cur ^ 1;
         // -- all keys first
         if (surv) { KScope ks_("k_bwt_f_gather_small"); hipLaunchKernelGGL(k_bwt_f_gather_small, dim3(nTiles), dim3(256), 0, s, v, h); }
-        if (nMed) { KScope ks_("k_bwt_f_gather_desc"); hipLaunchKernelGGL(k_bwt_f_gather_desc, dim3((std::min<u32>(nMed, 8192) + 7) & ~7u), dim3(256), 0, s, v, w.med[cur], nMed, h); }
+        if (nMed) {
+            // sorted by start slot (bits 0..31 of the (start, length) pair read as one 64-bit key)
+            pb = w.primBytes;
+            { KScope ks_("bwt_f_sort_desc");
+              if (rocprim::radix_sort_keys(w.prim, pb, reinterpret_cast<u64*>(w.med[cur]), reinterpret_cast<u64*>(w.medSorted), (size_t)nMed, 0u, 32u, s) != hipSuccess) return -1; }
+            KScope ks_("k_bwt_f_gather_desc");
+            hipLaunchKernelGGL(k_bwt_f_gather_desc, dim3(256), dim3(1024), 0, s, v, w.medSorted, nMed, h);
+        }
         int lbits = 0;
         if (nLarge) {
             while ((1u << lbits) < nLarge) lbits++;
@@ -797,8 +816,8 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
             // groups up to 2048) and 512 threads x 16 elements (76 KB: two groups per CU in flight)
             KScope ks_("k_bwt_f_sort_medium");
             const dim3 gridM(std::min<u32>(nMed, 8192));
-            hipLaunchKernelGGL((k_bwt_f_sort_medium<256, 8>), gridM, dim3(256), 0, s, v, w.med[cur], nMed, npass, SM_G, w.med[nxt], w.large[nxt]);
-            hipLaunchKernelGGL((k_bwt_f_sort_medium<512, 16>), gridM, dim3(512), 0, s, v, w.med[cur], nMed, npass, 2048u, w.med[nxt], w.large[nxt]);
+            hipLaunchKernelGGL((k_bwt_f_sort_medium<256, 8>), gridM, dim3(256), 0, s, v, w.medSorted, nMed, npass, SM_G, w.med[nxt], w.large[nxt]);
+            hipLaunchKernelGGL((k_bwt_f_sort_medium<512, 16>), gridM, dim3(512), 0, s, v, w.medSorted, nMed, npass, 2048u, w.med[nxt], w.large[nxt]);
         }
         if (nLarge) {
             pb = w.primBytes;

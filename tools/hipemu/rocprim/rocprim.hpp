@@ -23,6 +23,17 @@ hipError_t radix_sort_pairs(void* tmp, size_t& bytes, const K* kin, K* kout, con
     for (size_t i = 0; i < n; i++) { kout[i] = kin[idx[i]]; vout[i] = vin[idx[i]]; }
     return hipSuccess;
 }
+template <class K>
+hipError_t radix_sort_keys(void* tmp, size_t& bytes, const K* kin, K* kout, size_t n, unsigned beginBit, unsigned endBit, hipStream_t)
+{
+    if (!tmp) { bytes = 16; return hipSuccess; }
+    std::vector<K> v(kin, kin + n);
+    const unsigned nb = endBit - beginBit;
+    const K mask = (nb >= 8 * sizeof(K)) ? (K)~(K)0 : (K)((((K)1) << nb) - 1);
+    std::stable_sort(v.begin(), v.end(), [&](const K& a, const K& b) { return ((a >> beginBit) & mask) < ((b >> beginBit) & mask); });
+    for (size_t i = 0; i < n; i++) kout[i] = v[i];
+    return hipSuccess;
+}
 template <class T, class Op>
 hipError_t inclusive_scan(void* tmp, size_t& bytes, const T* in, T* out, size_t n, Op op, hipStream_t)
 {
