@@ -117,38 +117,34 @@ __global__ __launch_bounds__(256) void k_bwt_f_init(BwtView v, const u32* __rest
     }
 }
 
-// group-start flags of the sorted keys: bit map (one ballot per wave), index arrays for the two scans
-__global__ __launch_bounds__(256) void k_bwt_f_r0_flags(const u64* __restrict__ keys, u32 total, unsigned long long* __restrict__ gbits64,
-                                                        u32* __restrict__ headIdx, u32* __restrict__ nextIdxRev)
+// group-start flags of the sorted keys as a bit map (one ballot per wave)
+__global__ __launch_bounds__(256) void k_bwt_f_r0_flags(const u64* __restrict__ keys, u32 total, unsigned long long* __restrict__ gbits64)
 {
     const u32 a = blockIdx.x * 256 + threadIdx.x;
     bool f = true;
-    if (a < total) {
-        f = (a == 0) || (keys[a] != keys[a - 1]);
-        headIdx[a] = f ? a : 0u;
-        nextIdxRev[total - 1 - a] = f ? a : total;
-    }
+    if (a < total) f = (a == 0) || (keys[a] != keys[a - 1]);
     const unsigned long long m = __ballot(f);
     if ((threadIdx.x & 63) == 0) gbits64[a >> 6] = m;
 }
 
-// SA, ISA and the descriptors of the groups that are not small
-__global__ __launch_bounds__(256) void k_bwt_f_r0_place(FwdView v, const u32* __restrict__ vals, const u32* __restrict__ head,
-                                                        const u32* __restrict__ nextRev, uint2* __restrict__ medNext, uint2* __restrict__ largeNext)
+// per window of 2048 slots: the last group start in it (0 when it has none: slot 0 always starts a group, so 0 is neutral
+// for the running maximum) and, mirrored for a running minimum from the right, the first one (`total` when none)
+__global__ __launch_bounds__(256) void k_bwt_f_r0_winsum(const u32* __restrict__ gbits, u32 total, u32 nWin, u32* __restrict__ winLast, u32* __restrict__ winFirstRev)
 {
-    const u32 a = blockIdx.x * 256 + threadIdx.x;
-    u32 surv = 0;
-    if (a < v.total) {
-        const u32 gp = vals[a];
-        v.SA[a] = gp;
-        const u32 hd = head[a];
-        v.ISA[gp] = hd;
-        if (hd == a) {
-            const u32 nxt = (a + 1 < v.total) ? nextRev[v.total - 2 - a] : v.total;
-            classify_child(v, medNext, largeNext, a, nxt - a, surv);
+    const u32 w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= nWin) return;
+    u32 last = 0, first = total;
+    bool seen = false;
+    for (u32 k = 0; k < SM_WIN / 32; k++) {
+        const u32 x = gbits[w * (SM_WIN / 32) + k];
+        if (x) {
+            const u32 b0 = (w * (SM_WIN / 32) + k) * 32;
+            if (!seen) { first = b0 + (u32)__ffs((int)x) - 1; seen = true; }
+            last = b0 + 31 - (u32)__clz((int)x);
         }
     }
-    if (__ballot(surv != 0) != 0 && (threadIdx.x & 63) == 0) v.counters[0] = 1;      // a flag: plain store, no atomic traffic
+    winLast[w] = last < total ? last : (total ? total - 1 : 0);
+    winFirstRev[nWin - 1 - w] = first < total ? first : total;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -210,6 +206,63 @@ __device__ __forceinline__ bool sm_group_of(const SmWindow& W, u32 i, u32& s, u3
     if (len < 2 || len > SM_G) return false;
     s = (u32)si; e = ei;
     return true;
+}
+
+// Round 0: SA, ISA and the descriptors of the groups that are not small, one workgroup per window of 2048 slots. The group
+// of a slot starts at the last set bit at or before it: found in the window's 64 bit-map words, else in the running
+// maximum over the windows before it (winLastIncl); the length of a group (needed where it starts) ends at the next set bit.
+__global__ __launch_bounds__(256) void k_bwt_f_r0_place(FwdView v, const u32* __restrict__ vals, const u32* __restrict__ winLastIncl,
+                                                        const u32* __restrict__ winFirstInclRev, u32 nWin, uint2* __restrict__ medNext, uint2* __restrict__ largeNext)
+{
+    __shared__ SmWindow W;
+    const int tid = (int)threadIdx.x;
+    const u32 win = blockIdx.x;
+    const u32 slot0 = win * SM_WIN;
+    if (tid < 64) {
+        const u32 w = v.gbits[(slot0 >> 5) + (u32)tid];
+        W.bw[tid] = w;
+        int pm = w ? (tid * 32 + 31 - __clz((int)w)) : -1;
+        u32 sm = w ? (u32)(tid * 32 + __ffs((int)w) - 1) : NO_BIT;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(pm, (unsigned)o, 64);
+            if (tid >= o) pm = t > pm ? t : pm;
+            const u32 u = (u32)__shfl_down((int)sm, (unsigned)o, 64);
+            if (tid + o < 64) sm = u < sm ? u : sm;
+        }
+        int pex = __shfl_up(pm, 1u, 64);
+        if (tid == 0) pex = -1;
+        u32 sex = (u32)__shfl_down((int)sm, 1u, 64);
+        if (tid == 63) sex = NO_BIT;
+        W.prevSet[tid] = pex;
+        W.nextSet[tid] = sex;
+    }
+    __syncthreads();
+    const u32 before = win ? winLastIncl[win - 1] : 0u;
+    const u32 after = (win + 1 < nWin) ? winFirstInclRev[nWin - 2 - win] : v.total;
+    u32 surv = 0;
+#pragma unroll
+    for (int k = 0; k < (int)(SM_WIN / 256); k++) {
+        const u32 i = (u32)tid + 256u * (u32)k;
+        const u32 a = slot0 + i;
+        if (a >= v.total) continue;
+        const u32 w = i >> 5, bit = i & 31;
+        const u32 lowmask = (bit == 31) ? 0xFFFFFFFFu : ((2u << bit) - 1u);
+        const u32 word = W.bw[w];
+        const u32 m = word & lowmask;
+        const int si = m ? (int)(w * 32 + 31 - (u32)__clz((int)m)) : W.prevSet[w];
+        const u32 hd = (si >= 0) ? slot0 + (u32)si : before;
+        const u32 gp = vals[a];
+        v.SA[a] = gp;
+        v.ISA[gp] = hd;
+        if (hd == a) {
+            const u32 m2 = word & ~lowmask;
+            const u32 ei = m2 ? (w * 32 + (u32)__ffs((int)m2) - 1) : W.nextSet[w];
+            u32 nxt = (ei != NO_BIT) ? slot0 + ei : after;
+            if (nxt > v.total) nxt = v.total;
+            classify_child(v, medNext, largeNext, a, nxt - a, surv);
+        }
+    }
+    if (__ballot(surv != 0) != 0 && (tid & 63) == 0) v.counters[0] = 1;
 }
 
 __global__ __launch_bounds__(256) void k_bwt_f_gather_small(FwdView v, u32 h)
@@ -300,9 +353,16 @@ __global__ __launch_bounds__(1024) void k_bwt_f_gather_desc(FwdView v, const uin
         if (threadIdx.x == 0) sBlk = find_block(v.base, v.nBlocks, d.x);
         __syncthreads();
         const u32 bb = v.base[sBlk], be = v.base[sBlk + 1];
-        for (u32 i = threadIdx.x; i < d.y; i += 1024) {
-            const u32 sl = d.x + i;
-            v.K[sl] = gather_key(v.ISA, v.SA[sl], h, bb, be);
+        // eight members per thread at a time: all position loads, then all key loads, then the stores -- two memory
+        // latencies per batch instead of two per member
+        for (u32 i0 = 0; i0 < d.y; i0 += 8 * 1024) {
+            u32 gp[8], key[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const u32 i = i0 + (u32)k * 1024u + threadIdx.x; gp[k] = (i < d.y) ? v.SA[d.x + i] : bb; }
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const u32 i = i0 + (u32)k * 1024u + threadIdx.x; key[k] = (i < d.y) ? gather_key(v.ISA, gp[k], h, bb, be) : 0u; }
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const u32 i = i0 + (u32)k * 1024u + threadIdx.x; if (i < d.y) v.K[d.x + i] = key[k]; }
         }
         __syncthreads();
     }
@@ -429,7 +489,14 @@ __global__ __launch_bounds__(THREADS, THREADS / 128) void k_bwt_f_sort_medium(Fw
         const uint2 d = desc[g];
         const u32 gs = d.x, n = d.y;
         if (n <= minLen || n > CAP) continue;               // uniform for the workgroup
-        for (u32 i = (u32)tid; i < n; i += THREADS) { L.oK[i] = v.K[gs + i]; L.oV[i] = v.SA[gs + i]; }
+        {
+            // all loads of the group in flight before the first one is used
+            u32 k[ROWS], p[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) { const u32 i = (u32)tid + (u32)r * THREADS; k[r] = 0; p[r] = 0; if (i < n) { k[r] = v.K[gs + i]; p[r] = v.SA[gs + i]; } }
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) { const u32 i = (u32)tid + (u32)r * THREADS; if (i < n) { L.oK[i] = k[r]; L.oV[i] = p[r]; } }
+        }
         __syncthreads();
         // majority candidate: the key two of three probes agree on, else the middle one
         const u32 ka = L.oK[n >> 2], kb = L.oK[n >> 1], kc = L.oK[(n >> 2) * 3];
@@ -773,13 +840,16 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     hipMemsetAsync(w.gnew, 0, 4 * w.gbitsWords, s);
     hipMemsetAsync(w.counters, 0, 64, s);
     { KScope ks_("k_bwt_f_r0_flags"); hipLaunchKernelGGL(k_bwt_f_r0_flags, dim3((total + 255) / 256), dim3(256), 0, s, w.keysB, total,
-                                                         reinterpret_cast<unsigned long long*>(w.gbits), w.t0, w.t2); }
+                                                         reinterpret_cast<unsigned long long*>(w.gbits)); }
+    // group starts before / after every window of 2048 slots: two scans over ~total/2048 values
+    const u32 nWin = (total + SM_WIN - 1) / SM_WIN;
+    { KScope ks_("k_bwt_f_r0_winsum"); hipLaunchKernelGGL(k_bwt_f_r0_winsum, GRID1(nWin), w.gbits, total, nWin, w.t0, w.t2); }
     pb = w.primBytes;
-    { KScope ks_("bwt_f_scan_max"); if (rocprim::inclusive_scan(w.prim, pb, w.t0, w.t1, (size_t)total, rocprim::maximum<u32>(), s) != hipSuccess) return -1; }
+    { KScope ks_("bwt_f_scan_max"); if (rocprim::inclusive_scan(w.prim, pb, w.t0, w.t1, (size_t)nWin, rocprim::maximum<u32>(), s) != hipSuccess) return -1; }
     pb = w.primBytes;
-    { KScope ks_("bwt_f_scan_min"); if (rocprim::inclusive_scan(w.prim, pb, w.t2, w.t3, (size_t)total, rocprim::minimum<u32>(), s) != hipSuccess) return -1; }
+    { KScope ks_("bwt_f_scan_min"); if (rocprim::inclusive_scan(w.prim, pb, w.t2, w.t3, (size_t)nWin, rocprim::minimum<u32>(), s) != hipSuccess) return -1; }
     int cur = 0;
-    { KScope ks_("k_bwt_f_r0_place"); hipLaunchKernelGGL(k_bwt_f_r0_place, GRID1(total), v, w.valsB, w.t1, w.t3, w.med[cur], w.large[cur]); }
+    { KScope ks_("k_bwt_f_r0_place"); hipLaunchKernelGGL(k_bwt_f_r0_place, dim3(nWin), dim3(256), 0, s, v, w.valsB, w.t1, w.t3, nWin, w.med[cur], w.large[cur]); }
     if (hipMemcpyAsync(h_pinned, w.counters, 16, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
     if (hipStreamSynchronize(s) != hipSuccess) return -1;
     u32 surv = h_pinned[0], nMed = h_pinned[1], nLarge = h_pinned[2], largeElems = h_pinned[3];
