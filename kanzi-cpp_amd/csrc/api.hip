@@ -527,7 +527,9 @@ static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t 
     } else if (p->entropy_type == KNZ_E_FPAQ) {
         const u64 fStride = (4u << 20) + (4u << 17) + 256;      // FPAQEncoder.cpp:65-68 buffer size (+ slack)
         if (int r = ws_get(c, "chunkTmp", (size_t)fStride * nSlots, (void**)&d_tmp)) return r;
-        launch_fpaq_encode(s, view, d_origLen, framing ? 15u : 0u, nBlocks, maxChunks, d_desc, d_tmp, fStride);
+        u16* d_fprobs;
+        if (int r = ws_get(c, "fpaqProbs", fpaq_probs_bytes(nBlocks, S), (void**)&d_fprobs)) return r;
+        launch_fpaq_encode(s, view, d_origLen, framing ? 15u : 0u, nBlocks, maxChunks, d_desc, d_tmp, fStride, d_fprobs, S);
     } else {
         if (int r = ws_get(c, "chunkTmp", 64, (void**)&d_tmp)) return r;
         launch_none_encode(s, view, nBlocks, maxChunks, d_desc);

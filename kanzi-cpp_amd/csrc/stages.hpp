@@ -74,8 +74,10 @@ int launch_bwt_inverse(hipStream_t s, const XfStage& st, void* scratch, size_t s
 size_t bwt_forward_scratch_bytes(int nBlocks, u32 VS, size_t total);
 size_t bwt_inverse_scratch_bytes(int nBlocks, u32 VS, size_t total);
 
-// serial.hip (one lane per block: FPAQ, SRT, RLT)
-void launch_fpaq_encode(hipStream_t s, BlockView view, const u32* origLen, u32 copyThreshold, int nBlocks, int maxChunks, ChunkDesc* desc, u8* tmp, u64 tmpStride);
+// fpaq.hip (probs: fpaq_probs_bytes(nBlocks, S) bytes of scratch, S = upper bound of the block lengths)
+void launch_fpaq_encode(hipStream_t s, BlockView view, const u32* origLen, u32 copyThreshold, int nBlocks, int maxChunks, ChunkDesc* desc, u8* tmp, u64 tmpStride,
+                        u16* probs, u64 S);
+size_t fpaq_probs_bytes(int nBlocks, u64 S);
 void launch_fpaq_decode(hipStream_t s, BitSrc src, DecBlock* blocks, int nBlocks, u8* const* outPtr);
 void launch_srt_forward(hipStream_t s, const XfStage& st);
 void launch_srt_inverse(hipStream_t s, const XfStage& st);

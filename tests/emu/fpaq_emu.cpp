@@ -1,0 +1,86 @@
+// CPU-only check of the FPAQ kernels' logic (kanzi-cpp_amd/csrc/fpaq.hip compiled as plain C++ against tools/hipemu):
+// the encoder's two phases and the decoder against the oracle's FPAQ codec (oracle/fpaq.c). Test infrastructure only.
+//   usage: fpaq_emu <case file>    (binary: u32 nBlocks, then per block u32 len + bytes)
+#include "hip/hip_runtime.h"
+#include "../../kanzi-cpp_amd/csrc/fpaq.hip"
+
+#include <stdio.h>
+#include <vector>
+
+extern "C" int64_t knzo_entropy_encode(int etype, const uint8_t* in, uint32_t n, uint8_t* out, size_t cap);
+
+namespace knz { thread_local ProfHook* g_prof = nullptr; }
+
+int main(int argc, char** argv)
+{
+    using namespace knz;
+    if (argc < 2) return 2;
+    FILE* f = fopen(argv[1], "rb");
+    if (!f) return 2;
+    u32 nBlocks = 0;
+    if (fread(&nBlocks, 4, 1, f) != 1) return 2;
+    std::vector<std::vector<u8>> in(nBlocks);
+    u32 maxLen = 1;
+    for (u32 b = 0; b < nBlocks; b++) {
+        u32 n = 0;
+        if (fread(&n, 4, 1, f) != 1) return 2;
+        in[b].resize(n + 64);
+        if (n && fread(in[b].data(), 1, n, f) != n) return 2;
+        in[b].resize(n);
+        maxLen = std::max(maxLen, n);
+    }
+    fclose(f);
+    const u64 S = (maxLen + 255) & ~255u;
+    const int maxChunks = (int)((S + FPAQ_CHUNK - 1) / FPAQ_CHUNK);
+    std::vector<const u8*> ptr(nBlocks);
+    std::vector<u32> len(nBlocks), origLen(nBlocks);
+    for (u32 b = 0; b < nBlocks; b++) { in[b].reserve(in[b].size() + 64); ptr[b] = in[b].data(); len[b] = origLen[b] = (u32)in[b].size(); }
+    BlockView view; view.ptr = ptr.data(); view.len = len.data();
+    std::vector<ChunkDesc> desc((size_t)nBlocks * maxChunks);
+    const u64 tmpStride = (4u << 20) + (4u << 17) + 256;
+    std::vector<u8> tmp((size_t)nBlocks * maxChunks * tmpStride + 256);
+    std::vector<u8> probs(fpaq_probs_bytes((int)nBlocks, S) + 256);
+    u8* pb = reinterpret_cast<u8*>((reinterpret_cast<uintptr_t>(probs.data()) + 255) & ~(uintptr_t)255);
+    u8* tb = reinterpret_cast<u8*>((reinterpret_cast<uintptr_t>(tmp.data()) + 255) & ~(uintptr_t)255);
+    launch_fpaq_encode(nullptr, view, origLen.data(), 0u, (int)nBlocks, maxChunks, desc.data(), tb, tmpStride, reinterpret_cast<u16*>(pb), S);
+    int bad = 0;
+    for (u32 b = 0; b < nBlocks; b++) {
+        // the block's entropy bits: per sub-chunk var-int, payload, 56-bit tail
+        std::vector<u8> got;
+        const u32 n = len[b];
+        const int nCh = (int)((n + FPAQ_CHUNK - 1) / FPAQ_CHUNK);
+        for (int ci = 0; ci < nCh; ci++) {
+            const ChunkDesc& cd = desc[(size_t)b * maxChunks + ci];
+            for (u32 i = 0; i < cd.midLen; i++) got.push_back((u8)(cd.mid[i >> 2] >> (8 * (i & 3))));
+            if (cd.nPieces) got.insert(got.end(), cd.piecePtr[0], cd.piecePtr[0] + cd.pieceBits[0] / 8);
+            for (u32 i = 0; i < cd.trailerLen; i++) got.push_back((u8)(cd.trailer[i >> 2] >> (8 * (i & 3))));
+        }
+        std::vector<u8> ref(2 * (size_t)n + 65536);
+        const int64_t bits = knzo_entropy_encode(2, in[b].data(), n, ref.data(), ref.size());
+        if (bits < 0 || (size_t)((bits + 7) / 8) != got.size() || memcmp(ref.data(), got.data(), got.size()) != 0) {
+            size_t at = 0;
+            while (at < got.size() && at < (size_t)((bits + 7) / 8) && ref[at] == got[at]) at++;
+            printf("FAIL encode block %u (n=%u): %zu bytes vs %lld bits, first difference at byte %zu\n", b, n, got.size(), (long long)bits, at);
+            bad++;
+            continue;
+        }
+        // decode the oracle's stream
+        std::vector<u8> stream(ref.begin(), ref.begin() + (bits + 7) / 8);
+        stream.resize(stream.size() + 64, 0);
+        BitSrc src; src.words = reinterpret_cast<const u32*>(stream.data()); src.nBytes = (u64)((bits + 7) / 8); src.nWords = src.nBytes >> 2; src.limitBits = (u64)bits;
+        DecBlock db; memset(&db, 0, sizeof(db));
+        db.payloadBit = 0; db.bits = (u64)bits; db.entropyBit = 0; db.preLen = n;
+        std::vector<u8> out(n + 64, 0xEE);
+        u8* op = out.data();
+        u8* const* outPtr = &op;
+        launch_fpaq_decode(nullptr, src, &db, 1, outPtr);
+        if (db.error || memcmp(out.data(), in[b].data(), n) != 0 || db.usedBits != (u64)bits) {
+            u32 at = 0;
+            while (at < n && out[at] == in[b][at]) at++;
+            printf("FAIL decode block %u (n=%u): error %d, used %llu of %lld bits, first difference at %u\n", b, n, db.error, (unsigned long long)db.usedBits, (long long)bits, at);
+            bad++;
+        }
+    }
+    printf(bad ? "FAILED %d blocks\n" : "OK %u blocks\n", bad ? bad : nBlocks, nBlocks);
+    return bad ? 1 : 0;
+}

@@ -63,3 +63,16 @@ def test_bwt_forward_kernels_emulated(tmp_path):
         for order in ("0", "1", "2"):       # workgroup dispatch order is not defined: forward, reverse, shuffled
             r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900, env=dict(os.environ, HIPEMU_ORDER=order))
             assert r.returncode == 0, (i, order, r.stdout[-2000:] + r.stderr[-2000:])
+
+
+def test_fpaq_kernels_emulated(tmp_path):
+    # encoder phase 1 (probability chains per context family), phase 2 (interval recurrence) and the decoder against oracle/fpaq.c
+    exe = build("fpaq_emu", tmp_path)
+    c = knzlib.corpus()
+    rng = np.random.default_rng(3)
+    blocks = [c.text(5000, 1), bytes(3000), rng.integers(0, 256, 4000, dtype=np.uint8).tobytes(), b"a", b"ab" * 40,
+              c.mixed(300000, 2)[250000:258000], bytes([255]) * 700 + bytes(range(256)) * 3]
+    path = str(tmp_path / "fpaq.bin")
+    write_case(path, blocks)
+    r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

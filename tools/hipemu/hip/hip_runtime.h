@@ -119,6 +119,13 @@ static inline int __shfl_xor(int var, int mask, int width = 64)
     (void)width;
     return (int)(unsigned)v[lane ^ mask];
 }
+static inline int __builtin_amdgcn_readlane(int var, int src) { return __shfl(var, src & 63, 64); }
+static inline int __builtin_amdgcn_readfirstlane(int var)
+{
+    unsigned long long v[64], act;
+    hipemu::wave_exchange((unsigned long long)(unsigned)var, v, &act);
+    return (int)(unsigned)v[__builtin_ctzll(act)];
+}
 static inline unsigned long long __lanemask_lt() { const int lane = (int)(threadIdx.x & 63); return lane ? (~0ull >> (64 - lane)) : 0ull; }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
