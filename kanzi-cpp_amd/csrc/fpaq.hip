@@ -25,7 +25,11 @@
 
 namespace knz {
 
+#ifdef KNZ_EMU_FPAQ_CHUNK          // CPU emulation tests only: a small sub-chunk, to cross sub-chunk borders with small inputs
+constexpr u32 FPAQ_CHUNK = KNZ_EMU_FPAQ_CHUNK;
+#else
 constexpr u32 FPAQ_CHUNK = 4u << 20;
+#endif
 constexpr u64 FPAQ_TOP = 0x00FFFFFFFFFFFFFFull;
 constexpr u64 FPAQ_MASK24 = 0x0000000000FFFFFFull;
 constexpr u64 FPAQ_MASK32 = 0x00000000FFFFFFFFull;
@@ -206,7 +210,10 @@ __global__ __launch_bounds__(64) void k_fpaq_decode(BitSrc src, DecBlock* __rest
     const int lane = lane_id();
     // probabilities as 16-bit values, read as pairs: word c2 * 128 + node holds the children 2 node (low half) and 2 node + 1
     __shared__ u32 pr32[512];
-    u16* pr16 = reinterpret_cast<u16*>(pr32);
+    // the 16-bit stores below go to the words the 32-bit loads read: say so, or type-based alias analysis lets the compiler keep
+    // a loaded pair across a store (it hoisted the read of the root pair out of the sub-chunk loop)
+    typedef u16 __attribute__((may_alias)) u16_alias;
+    u16_alias* pr16 = reinterpret_cast<u16_alias*>(pr32);
     for (int i = lane; i < 512; i += 64) pr32[i] = 0x80008000u;
     __syncthreads();
     DecBlock& db = blocks[b];

@@ -13,7 +13,9 @@
 #define MASK_0_24 0x0000000000FFFFFFull
 #define MASK_0_32 0x00000000FFFFFFFFull
 #define MASK_0_56 0x00FFFFFFFFFFFFFFull
+#ifndef FPAQ_CHUNK            /* tests/test_emu_kernels.py builds a copy with a small value to cross sub-chunk borders quickly */
 #define FPAQ_CHUNK (4u * 1024 * 1024)
+#endif
 #define PSCALE 65536
 
 typedef struct {
