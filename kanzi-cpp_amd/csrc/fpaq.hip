@@ -61,11 +61,15 @@ __global__ __launch_bounds__(64) void k_fpaq_probs(BlockView view, const u32* __
     __shared__ u16 pr[128];
     for (int q = lane; q < 128; q += 64) pr[q] = 32768;
     u32 p0 = 32768, p1 = 32768, p2 = 32768, p3 = 32768;
+    // the bytes of the next tile (and the byte before each) are loaded while this tile is worked on
+    u32 nByte = 0, nPrev = 0;
+    if ((u32)lane < count) { nByte = blk[lane]; nPrev = lane ? blk[lane - 1] : 0u; }
     for (u32 i0 = 0; i0 < count; i0 += 64) {
         const u32 i = i0 + (u32)lane;
         const bool valid = i < count;
-        const u32 byte = valid ? blk[i] : 0u;
-        const u32 prev2 = (valid && (i % FPAQ_CHUNK) != 0) ? (u32)(blk[i - 1] >> 6) : 0u;     // every sub-chunk starts in class 0
+        const u32 byte = nByte;
+        const u32 prev2 = (valid && (i % FPAQ_CHUNK) != 0) ? (nPrev >> 6) : 0u;     // every sub-chunk starts in class 0
+        { const u32 j = i + 64; nByte = 0; nPrev = 0; if (j < count) { nByte = blk[j]; nPrev = blk[j - 1]; } }
         const bool match = valid && prev2 == c2;
         const u32 node = ((byte | 256u) >> (8 - level)) - (1u << level);
         const u32 bit = (byte >> (7 - level)) & 1u;
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(64) void k_fpaq_decode(BitSrc src, DecBlock* __rest
                     const u64 split = ((((high - low) >> 8) * (u64)p) >> 8) + low;
                     const bool one = split >= current;
                     const u32 np = fpaq_update(p, one ? 1u : 0u);
-                    if (lane == 0) pr16[c2 * 256 + ctx] = (u16)np;
+                    pr16[c2 * 256 + ctx] = (u16)np;                 // every lane stores the same value: no exec-mask detour on the chain
                     high = one ? split : high;
                     low = one ? low : split + 1;
                     ctx = 2 * ctx + (one ? 1u : 0u);

@@ -76,3 +76,19 @@ def test_fpaq_kernels_emulated(tmp_path):
     write_case(path, blocks)
     r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    # sub-chunk borders (the coder state carries over, the context class restarts): kernels and a private copy of the oracle's
+    # sources built with 4 KiB sub-chunks instead of 4 MiB
+    objs = []
+    for src in sorted(os.listdir(os.path.join(ROOT, "oracle"))):
+        if src.endswith(".c"):
+            obj = str(tmp_path / (src[:-2] + ".o"))
+            subprocess.check_call(["gcc", "-O2", "-std=c99", "-fPIC", "-DFPAQ_CHUNK=4096u", "-c", os.path.join(ROOT, "oracle", src), "-o", obj])
+            objs.append(obj)
+    exe2 = str(tmp_path / "fpaq_emu_small")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-x", "c++", "-DKNZ_EMU_FPAQ_CHUNK=4096u", "-I" + os.path.join(ROOT, "tools", "hipemu"),
+                           "-I" + os.path.join(ROOT, "include"), "-Wno-unused-value", "-Wno-attributes", "-Wno-format-extra-args",
+                           os.path.join(EMU, "fpaq_emu.cpp"), os.path.join(ROOT, "tools", "hipemu", "hipemu.cpp"), "-x", "none"] + objs + ["-o", exe2])
+    path2 = str(tmp_path / "fpaq2.bin")
+    write_case(path2, [c.text(20000, 1), c.mixed(300000, 2)[250000:262000], bytes(9000)])
+    r = subprocess.run([exe2, path2], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
