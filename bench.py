@@ -155,17 +155,18 @@ def end_to_end(data, cfg):
             written = c.close()
             t1 = time.perf_counter()
             d = kz.Decompressor(path, bs, jobs=8)
-            total, ok = 0, True
+            parts, total = [], 0
             while True:
                 part = d.decompress(bs)
                 if not part:
                     break
-                ok = ok and (part == mv[total:total + len(part)])
+                parts.append(part)
                 total += len(part)
             d.close()
             t2 = time.perf_counter()
-            if not ok or total != n:
+            if total != n or b"".join(parts) != data:      # checked outside the timed region
                 raise RuntimeError("end-to-end round trip mismatch")
+            del parts
             cur = dict(value=round(n / (t2 - t0) / 1e6, 2), unit="MB/s", compress_MBps=round(n / (t1 - t0) / 1e6, 2),
                        decompress_MBps=round(n / (t2 - t1) / 1e6, 2), compressed_bytes=written,
                        path="host bytes -> libkanzi_amd.so C API (initCompressor/compress, initDecompressor/decompress) -> .knz on tmpfs -> host bytes")
@@ -185,9 +186,11 @@ def main():
     ap.add_argument("--config", type=int, default=3)
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--limit", type=int, default=0, help="use only the first LIMIT bytes of the corpus")
-    ap.add_argument("--cpu-sample", type=int, default=64 << 20)
+    ap.add_argument("--cpu-sample", type=int, default=256 << 20, help="bytes of the workload the CPU reference is timed on (the whole silesia corpus fits)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="gloo + --share-device: the N-rank code path on a 1-GPU box (developer check)")
+    ap.add_argument("--share-device", action="store_true", help="every rank uses cuda:0")
     args = ap.parse_args()
 
     import numpy as np
@@ -199,10 +202,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
 
     import __graft_entry__ as ge
     ge.load_package()
@@ -269,7 +277,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -279,7 +287,7 @@ def main():
         assert torch.equal(d_dec[:n], d_in[:n]), "round trip mismatch"
     comp_bytes = (state["bits"] + 7) // 8
     if world > 1:
-        t = torch.tensor([comp_bytes], dtype=torch.int64, device=dev)
+        t = torch.tensor([comp_bytes], dtype=torch.int64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         comp_total = int(t.item())
     else:
