@@ -10,7 +10,7 @@
 //            :295-492 (biPSIv2): both walk the psi permutation from the primary indexes
 //
 // GPU formulation
-//   inverse  psi by a stable 8-bit counting sort of the BWT symbols, then splitter-based list ranking (Helman-JaJa):
+//   inverse  psi by a stable counting sort of the BWT symbols (tile histograms + ballot ranks), then splitter-based list ranking (Helman-JaJa):
 //            the 8 chains the reference walks serially become ~n/64 independent ones.
 #include "common.hpp"
 #include "stages.hpp"
@@ -88,55 +88,144 @@ __global__ void k_bwt_i_header(BwtView v, BwtHdr* __restrict__ hd, u32* __restri
     base[v.nBlocks] = sum;
 }
 
-__global__ __launch_bounds__(256) void k_bwt_i_keys(BwtView v, const BwtHdr* __restrict__ hd, const u32* __restrict__ base,
-                                                    u32* __restrict__ keys, u32* __restrict__ vals)
-{
-    const int b = blockIdx.y;
-    const BwtHdr h = hd[b];
-    if (!h.okFlag || h.n < 2) return;
-    const u8* s = v.src[b] + h.hdr;
-    for (u32 i = blockIdx.x * 256 + threadIdx.x; i < h.n; i += gridDim.x * 256) {
-        keys[base[b] + i] = ((u32)b << 8) | s[i];              // stable sort by (block, symbol)
-        vals[base[b] + i] = i;
-    }
-}
-
 // ---- list ranking with random splitters (Helman-JaJa style) ------------------------------------
 // Node j = F-position (global slot). rec[j] = next node (31 bits) | "next is a splitter" (bit 31) | symbol << 32.
 // The node holding BWT index 0 is the end of the text (self loop). Splitters: a pseudo-random 1/64 of the
 // nodes + every block's chain head + the terminals. Each splitter walks to the next splitter (sub-list
 // length), the short splitter list is ranked by pointer jumping, then each splitter walks its sub-list
 // again and writes the text. Two O(n) random-access passes instead of log2(n) of them.
+//
+// The F-position of BWT index i is C[symbol] + (number of equal symbols before i): a stable counting sort, done per tile
+// of 4096 symbols (histogram, scan over tiles and symbols, rank by ballot matching inside a wave) and written straight
+// into rec -- no sorted copy of (symbol, index) pairs is ever materialised.
 constexpr int SPLIT_LOG = 6;
+constexpr u32 IT = 4096;             // symbols per tile: 4 waves x 16 rows of 64
 
 __device__ __forceinline__ bool hash_split(u32 j) { return ((j * 2654435761u) >> (32 - SPLIT_LOG)) == 0; }
 
-__global__ __launch_bounds__(256) void k_bwt_i_links(const BwtHdr* __restrict__ hd, const u32* __restrict__ base, u32 total,
-                                                     const u32* __restrict__ keysSorted, const u32* __restrict__ valsSorted,
-                                                     u64* __restrict__ rec, u32* __restrict__ flags)
+// lanes of the wave whose (valid) symbol equals mine
+__device__ __forceinline__ unsigned long long sym_peers(bool valid, u32 sym)
 {
-    const u32 j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= total) return;
-    const u32 key = keysSorted[j];
-    const u32 b = key >> 8;
-    const u32 i = valsSorted[j];
-    const u32 pIdx = hd[b].pIdx;
-    u32 nx;
-    if (i == 0) nx = j;                                       // end of text
-    else nx = base[b] + ((i < pIdx) ? i - 1 : i);            // BWT.cpp:203-215
-    rec[j] = (u64)nx | ((u64)(key & 0xFF) << 32);
-    u32 f = (hash_split(j) || i == 0) ? 1u : 0u;
-    if (j == base[b] + pIdx - 1) f = 1;                      // chain head of the block
-    flags[j] = f;
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 8; bit++) {
+        const bool one = (sym >> bit) & 1u;
+        const unsigned long long bal = __ballot(valid && one);
+        peers &= one ? bal : ~bal;
+    }
+    return peers;
 }
 
-__global__ __launch_bounds__(256) void k_bwt_i_fold(u64* __restrict__ rec, const u32* __restrict__ flags, u32 total)
+__global__ __launch_bounds__(256) void k_bwt_i_hist(BwtView v, const BwtHdr* __restrict__ hd, int perTiles, u32* __restrict__ tileHist)
+{
+    const int b = blockIdx.y;
+    const BwtHdr h = hd[b];
+    if (!h.okFlag || h.n < 2) return;
+    const u32 t0 = blockIdx.x * IT;
+    if (t0 >= h.n) return;
+    __shared__ u32 cnt[256];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    cnt[tid] = 0;
+    __syncthreads();
+    const u8* s = v.src[b] + h.hdr;
+#pragma unroll 4
+    for (int r = 0; r < 16; r++) {
+        const u32 i = t0 + (u32)wave * 1024u + (u32)r * 64u + (u32)lane;
+        const bool valid = i < h.n;
+        const u32 sym = valid ? s[i] : 0u;
+        const unsigned long long peers = sym_peers(valid, sym);
+        if (valid && lane == __ffsll((long long)peers) - 1) atomicAdd(&cnt[sym], (u32)__popcll(peers));
+    }
+    __syncthreads();
+    tileHist[((size_t)b * perTiles + blockIdx.x) * 256 + tid] = cnt[tid];
+}
+
+// per block: tileHist[t][sym] := number of sym in the tiles before t; C[b][sym] = number of smaller symbols in the block;
+// term[b] = node of BWT index 0 (first occurrence of its symbol)
+__global__ __launch_bounds__(256) void k_bwt_i_scan(BwtView v, const BwtHdr* __restrict__ hd, const u32* __restrict__ base, int perTiles,
+                                                    u32* __restrict__ tileHist, u32* __restrict__ Cb, u32* __restrict__ term)
+{
+    const int b = blockIdx.x;
+    const BwtHdr h = hd[b];
+    const int tid = (int)threadIdx.x;
+    __shared__ u32 tot[256];
+    u32 run = 0;
+    if (h.okFlag && h.n >= 2) {
+        const u32 nT = (h.n + IT - 1) / IT;
+        u32* p = tileHist + (size_t)b * perTiles * 256 + tid;
+        for (u32 t = 0; t < nT; t++) { const u32 x = p[(size_t)t * 256]; p[(size_t)t * 256] = run; run += x; }
+    }
+    tot[tid] = run;
+    __syncthreads();
+    if (tid == 0) { u32 acc = 0; for (int c = 0; c < 256; c++) { const u32 x = tot[c]; tot[c] = acc; acc += x; } }
+    __syncthreads();
+    Cb[b * 256 + tid] = tot[tid];
+    if (tid == 0) term[b] = (h.okFlag && h.n >= 2) ? base[b] + tot[v.src[b][h.hdr]] : 0xFFFFFFFFu;
+}
+
+__device__ __forceinline__ bool is_splitter(u32 node, u32 head, u32 term) { return hash_split(node) || node == head || node == term; }
+
+__global__ __launch_bounds__(256) void k_bwt_i_links(BwtView v, const BwtHdr* __restrict__ hd, const u32* __restrict__ base, int perTiles,
+                                                     const u32* __restrict__ tileHist, const u32* __restrict__ Cb, const u32* __restrict__ term,
+                                                     u64* __restrict__ rec)
+{
+    const int b = blockIdx.y;
+    const BwtHdr h = hd[b];
+    if (!h.okFlag || h.n < 2) return;
+    const u32 t0 = blockIdx.x * IT;
+    if (t0 >= h.n) return;
+    __shared__ u32 cntw[4][256];
+    __shared__ u32 start[256];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int w = 0; w < 4; w++) cntw[w][tid] = 0;
+    start[tid] = base[b] + Cb[b * 256 + tid] + tileHist[((size_t)b * perTiles + blockIdx.x) * 256 + tid];
+    __syncthreads();
+    const u8* s = v.src[b] + h.hdr;
+    u32 sym[16], pre[16];
+    // rank among the equal symbols of my wave's 1024-symbol stretch, rows in order
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const u32 i = t0 + (u32)wave * 1024u + (u32)r * 64u + (u32)lane;
+        const bool valid = i < h.n;
+        sym[r] = valid ? s[i] : 0u;
+        const unsigned long long peers = sym_peers(valid, sym[r]);
+        const int leader = __ffsll((long long)peers) - 1;
+        u32 old = 0;
+        if (valid && lane == leader) { old = cntw[wave][sym[r]]; cntw[wave][sym[r]] = old + (u32)__popcll(peers); }
+        old = (u32)__shfl((int)old, leader < 0 ? 0 : leader, 64);
+        pre[r] = old + (u32)__popcll(peers & ltMask);
+    }
+    __syncthreads();
+    // symbols of earlier waves of the tile come first
+    {
+        const u32 c0 = cntw[0][tid], c1 = cntw[1][tid], c2 = cntw[2][tid];
+        const u32 st = start[tid];
+        cntw[0][tid] = st; cntw[1][tid] = st + c0; cntw[2][tid] = st + c0 + c1; cntw[3][tid] = st + c0 + c1 + c2;
+    }
+    __syncthreads();
+    const u32 bb = base[b], pIdx = h.pIdx;
+    const u32 head = bb + pIdx - 1, tm = term[b];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const u32 i = t0 + (u32)wave * 1024u + (u32)r * 64u + (u32)lane;
+        if (i >= h.n) continue;
+        const u32 j = cntw[wave][sym[r]] + pre[r];
+        u32 nx;
+        if (i == 0) nx = j;                                       // end of text
+        else nx = bb + ((i < pIdx) ? i - 1 : i);                  // BWT.cpp:203-215
+        rec[j] = (u64)nx | (is_splitter(nx, head, tm) ? 0x80000000ull : 0ull) | ((u64)sym[r] << 32);
+    }
+}
+
+// splitter flags from the node number alone
+__global__ __launch_bounds__(256) void k_bwt_i_flags(const BwtHdr* __restrict__ hd, const u32* __restrict__ base, const u32* __restrict__ term, int nBlocks,
+                                                     u32 total, u32* __restrict__ flags)
 {
     const u32 j = blockIdx.x * 256 + threadIdx.x;
     if (j >= total) return;
-    const u64 r = rec[j];
-    const u32 nx = (u32)r & 0x7FFFFFFFu;
-    if (flags[nx]) rec[j] = r | 0x80000000ull;
+    const int b = find_block(base, nBlocks, j);
+    flags[j] = is_splitter(j, base[b] + hd[b].pIdx - 1, term[b]) ? 1u : 0u;
 }
 
 // walk 1: sub-list length and successor splitter (compact indices)
@@ -170,26 +259,37 @@ __global__ __launch_bounds__(256) void k_bwt_i_jump(const u32* __restrict__ next
     nextOut[j] = nextIn[nx];
 }
 
-// walk 2: every splitter writes the text bytes of its sub-list
-__global__ __launch_bounds__(256) void k_bwt_i_walk2(BwtView v, const BwtHdr* __restrict__ hd, const u64* __restrict__ rec,
-                                                     const u32* __restrict__ splitNode, const u32* __restrict__ keysSorted,
-                                                     const u32* __restrict__ dEnd, u32 count, u32 limit)
+// walk 2: every splitter writes the text bytes of its sub-list (ascending addresses: four bytes are gathered per store)
+__global__ __launch_bounds__(256) void k_bwt_i_walk2(BwtView v, const BwtHdr* __restrict__ hd, const u32* __restrict__ base, const u64* __restrict__ rec,
+                                                     const u32* __restrict__ splitNode, const u32* __restrict__ dEnd, u32 count, u32 limit)
 {
     const u32 c = blockIdx.x * 256 + threadIdx.x;
     if (c >= count) return;
     u32 node = splitNode[c];
-    const u32 b = keysSorted[node] >> 8;
+    const int b = find_block(base, v.nBlocks, node);
     const u32 n = hd[b].n;
     u8* dst = v.dst[b];
+    const bool al = (reinterpret_cast<uintptr_t>(dst) & 3) == 0;
     u32 d = dEnd[c];
     u32 steps = 0;
+    u32 curW = 0xFFFFFFFFu, acc = 0, mask = 0;
+    auto flush = [&]() {
+        if (mask == 0xF && al) { reinterpret_cast<u32*>(dst)[curW] = acc; }
+        else { for (u32 k = 0; k < 4; k++) if ((mask >> k) & 1) dst[4 * curW + k] = (u8)(acc >> (8 * k)); }
+    };
     while (true) {
         const u64 r = rec[node];
-        if (d < n) dst[n - 1 - d] = (u8)(r >> 32);
+        if (d < n) {
+            const u32 pos = n - 1 - d;
+            if ((pos >> 2) != curW) { if (mask) flush(); curW = pos >> 2; acc = 0; mask = 0; }
+            acc |= (u32)((r >> 32) & 0xFF) << (8 * (pos & 3));
+            mask |= 1u << (pos & 3);
+        }
         if (((r >> 31) & 1) || d == 0 || ++steps > limit) break;
         node = (u32)r & 0x7FFFFFFFu;
         d--;
     }
+    if (mask) flush();
 }
 
 __global__ void k_bwt_i_tiny(BwtView v, const BwtHdr* __restrict__ hd)
@@ -206,7 +306,8 @@ size_t bwt_inverse_scratch_bytes(int nBlocks, u32 VS, size_t total)
     rocprim::radix_sort_pairs(nullptr, primSort, (u32*)nullptr, (u32*)nullptr, (u32*)nullptr, (u32*)nullptr, total, 0u, 32u, (hipStream_t)0);
     rocprim::exclusive_scan(nullptr, primScan, (u32*)nullptr, (u32*)nullptr, 0u, total, rocprim::plus<u32>(), (hipStream_t)0);
     const size_t prim = primSort > primScan ? primSort : primScan;
-    return 4 * align256(4 * total) + align256(8 * total) + 2 * align256(4 * total) + 6 * align256(4 * (total / 8 + 4096 + 3 * (size_t)nBlocks)) +
+    const size_t perTiles = ((size_t)VS + IT - 1) / IT;
+    return align256(1024 * perTiles * (size_t)nBlocks) + align256(1024 * (size_t)nBlocks) + align256(8 * total) + 2 * align256(4 * total) + 6 * align256(4 * (total / 8 + 4096 + 3 * (size_t)nBlocks)) +
            align256(sizeof(BwtHdr) * (size_t)nBlocks) + align256(4ull * (nBlocks + 2)) + align256(prim) + 16384;
 }
 
@@ -218,8 +319,10 @@ int launch_bwt_inverse(hipStream_t s, const XfStage& st, void* scratch, size_t s
     const size_t maxSplit = maxTotal / 8 + 4096 + 3 * (size_t)st.nBlocks;
     u8* q = reinterpret_cast<u8*>(scratch);
     auto take = [&](size_t sz) { u8* r = q; q += align256(sz); return r; };
-    u32* keysA = (u32*)take(4 * maxTotal); u32* keysB = (u32*)take(4 * maxTotal);
-    u32* valsA = (u32*)take(4 * maxTotal); u32* valsB = (u32*)take(4 * maxTotal);
+    const int perTiles = (int)((v.VS + IT - 1) / IT);
+    u32* tileHist = (u32*)take(4ull * 256 * (size_t)perTiles * st.nBlocks);
+    u32* Cb = (u32*)take(4ull * 256 * st.nBlocks);
+    u32* term = (u32*)take(4ull * (st.nBlocks + 1));
     u64* rec = (u64*)take(8 * maxTotal);
     u32* flags = (u32*)take(4 * maxTotal); u32* scanIdx = (u32*)take(4 * maxTotal);
     u32* splitNode = (u32*)take(4 * maxSplit);
@@ -236,14 +339,12 @@ int launch_bwt_inverse(hipStream_t s, const XfStage& st, void* scratch, size_t s
     const u32 total = h_pinned[0];
     { KScope ks_("k_bwt_i_tiny"); hipLaunchKernelGGL(k_bwt_i_tiny, dim3((st.nBlocks + 63) / 64), dim3(64), 0, s, v, hd); }
     if (total == 0) return 0;
-    const dim3 gridB((unsigned)std::min<size_t>(((size_t)v.VS + 255) / 256, 4096), st.nBlocks);
-    { KScope ks_("k_bwt_i_keys"); hipLaunchKernelGGL(k_bwt_i_keys, gridB, dim3(256), 0, s, v, hd, base, keysA, valsA); }
-    size_t pb = primBytes;
-    int bbits = 0;
-    while ((1 << bbits) < st.nBlocks) bbits++;
-    { KScope ks_("bwt_i_sort_symbols"); if (rocprim::radix_sort_pairs(prim, pb, keysA, keysB, valsA, valsB, (size_t)total, 0u, (unsigned)(8 + bbits), s) != hipSuccess) return -1; }
-    { KScope ks_("k_bwt_i_links"); hipLaunchKernelGGL(k_bwt_i_links, GRID1(total), hd, base, total, keysB, valsB, rec, flags); }
-    { KScope ks_("k_bwt_i_fold"); hipLaunchKernelGGL(k_bwt_i_fold, GRID1(total), rec, flags, total); }
+    const dim3 gridT((unsigned)perTiles, st.nBlocks);
+    { KScope ks_("k_bwt_i_hist"); hipLaunchKernelGGL(k_bwt_i_hist, gridT, dim3(256), 0, s, v, hd, perTiles, tileHist); }
+    { KScope ks_("k_bwt_i_scan"); hipLaunchKernelGGL(k_bwt_i_scan, dim3(st.nBlocks), dim3(256), 0, s, v, hd, base, perTiles, tileHist, Cb, term); }
+    { KScope ks_("k_bwt_i_links"); hipLaunchKernelGGL(k_bwt_i_links, gridT, dim3(256), 0, s, v, hd, base, perTiles, tileHist, Cb, term, rec); }
+    { KScope ks_("k_bwt_i_flags"); hipLaunchKernelGGL(k_bwt_i_flags, GRID1(total), hd, base, term, st.nBlocks, total, flags); }
+    size_t pb;
     pb = primBytes;
     { KScope ks_("bwt_i_scan_sum"); if (rocprim::exclusive_scan(prim, pb, flags, scanIdx, 0u, (size_t)total, rocprim::plus<u32>(), s) != hipSuccess) return -1; }
     { KScope ks_("k_bwt_i_compact"); hipLaunchKernelGGL(k_compact, GRID1(total), flags, scanIdx, (const u32*)nullptr, total, splitNode); }
@@ -258,7 +359,7 @@ int launch_bwt_inverse(hipStream_t s, const XfStage& st, void* scratch, size_t s
         { KScope ks_("k_bwt_i_jump"); hipLaunchKernelGGL(k_bwt_i_jump, GRID1(count), nA, dA, count, nB, dB); }
         std::swap(nA, nB); std::swap(dA, dB);
     }
-    { KScope ks_("k_bwt_i_walk2"); hipLaunchKernelGGL(k_bwt_i_walk2, GRID1(count), v, hd, rec, splitNode, keysB, dA, count, limit); }
+    { KScope ks_("k_bwt_i_walk2"); hipLaunchKernelGGL(k_bwt_i_walk2, GRID1(count), v, hd, base, rec, splitNode, dA, count, limit); }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

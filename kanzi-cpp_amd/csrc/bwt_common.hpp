@@ -27,4 +27,12 @@ __device__ __forceinline__ bool bwt_fwd_applies(u32 n, u32 cap, u32* pIdxSizeOut
     return true;
 }
 
+// block that holds dense slot / position s: the last b with base[b] <= s (empty blocks repeat the base of their successor)
+__device__ __forceinline__ int find_block(const u32* __restrict__ base, int nBlocks, u32 s)
+{
+    int lo = 0, hi = nBlocks;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (base[mid] <= s) lo = mid; else hi = mid; }
+    return lo;
+}
+
 }  // namespace knz

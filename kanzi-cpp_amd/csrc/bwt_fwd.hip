@@ -48,13 +48,6 @@ struct FwdView {
     u32* counters;       // [0] != 0: small groups are left, [1] medium descriptors, [2] large descriptors, [3] members of large groups
 };
 
-__device__ __forceinline__ int find_block(const u32* __restrict__ base, int nBlocks, u32 s)
-{
-    int lo = 0, hi = nBlocks;
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (base[mid] <= s) lo = mid; else hi = mid; }
-    return lo;
-}
-
 __device__ __forceinline__ u32 gather_key(const u32* __restrict__ ISA, u32 gp, u32 h, u32 blkBase, u32 blkEnd)
 {
     const u32 q = gp + h;
@@ -663,8 +656,10 @@ __global__ __launch_bounds__(1024) void k_bwt_f_large_prefix(const uint2* __rest
     for (u32 i = lo; i < hi; i++) { loff[i] = run; run += desc[i].y; }
 }
 
+// KEY = u32 when descriptor index and key fit 32 bits together (two thirds of the sort's traffic), else u64
+template <class KEY>
 __global__ __launch_bounds__(256) void k_bwt_f_large_keys(FwdView v, const uint2* __restrict__ desc, u32 nDesc, const u32* __restrict__ loff,
-                                                          u32 L, u32 h, int kbits, u64* __restrict__ keys, u32* __restrict__ vals)
+                                                          u32 L, u32 h, int kbits, KEY* __restrict__ keys, u32* __restrict__ vals)
 {
     const u32 j = blockIdx.x * 256 + threadIdx.x;
     if (j >= L) return;
@@ -675,11 +670,12 @@ __global__ __launch_bounds__(256) void k_bwt_f_large_keys(FwdView v, const uint2
     const int b = find_block(v.base, v.nBlocks, d.x);
     const u32 gp = v.SA[slot];
     const u32 key = gather_key(v.ISA, gp, h, v.base[b], v.base[b + 1]);
-    keys[j] = ((u64)lo << kbits) | (u64)key;
+    keys[j] = (KEY)(((u64)lo << kbits) | (u64)key);
     vals[j] = gp;
 }
 
-__global__ __launch_bounds__(256) void k_bwt_f_large_flags(const u64* __restrict__ keys, u32 L, u32* __restrict__ headIdx, u32* __restrict__ nextIdxRev)
+template <class KEY>
+__global__ __launch_bounds__(256) void k_bwt_f_large_flags(const KEY* __restrict__ keys, u32 L, u32* __restrict__ headIdx, u32* __restrict__ nextIdxRev)
 {
     const u32 j = blockIdx.x * 256 + threadIdx.x;
     if (j >= L) return;
@@ -688,8 +684,9 @@ __global__ __launch_bounds__(256) void k_bwt_f_large_flags(const u64* __restrict
     nextIdxRev[L - 1 - j] = f ? j : L;
 }
 
+template <class KEY>
 __global__ __launch_bounds__(256) void k_bwt_f_large_place(FwdView v, const uint2* __restrict__ desc, const u32* __restrict__ loff, u32 L, int kbits,
-                                                           const u64* __restrict__ keys, const u32* __restrict__ vals, const u32* __restrict__ head,
+                                                           const KEY* __restrict__ keys, const u32* __restrict__ vals, const u32* __restrict__ head,
                                                            const u32* __restrict__ nextRev, uint2* __restrict__ medNext, uint2* __restrict__ largeNext)
 {
     const u32 j = blockIdx.x * 256 + threadIdx.x;
@@ -874,10 +871,14 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
             hipLaunchKernelGGL(k_bwt_f_gather_desc, dim3(256), dim3(1024), 0, s, v, w.medSorted, nMed, h);
         }
         int lbits = 0;
+        bool small32 = false;
         if (nLarge) {
             while ((1u << lbits) < nLarge) lbits++;
+            small32 = (kbits + lbits) <= 32;
             { KScope ks_("k_bwt_f_large_prefix"); hipLaunchKernelGGL(k_bwt_f_large_prefix, dim3(1), dim3(1024), 0, s, w.large[cur], nLarge, w.loff); }
-            { KScope ks_("k_bwt_f_large_keys"); hipLaunchKernelGGL(k_bwt_f_large_keys, GRID1(largeElems), v, w.large[cur], nLarge, w.loff, largeElems, h, kbits, w.keysA, w.valsA); }
+            KScope ks_("k_bwt_f_large_keys");
+            if (small32) hipLaunchKernelGGL(k_bwt_f_large_keys<u32>, GRID1(largeElems), v, w.large[cur], nLarge, w.loff, largeElems, h, kbits, reinterpret_cast<u32*>(w.keysA), w.valsA);
+            else hipLaunchKernelGGL(k_bwt_f_large_keys<u64>, GRID1(largeElems), v, w.large[cur], nLarge, w.loff, largeElems, h, kbits, w.keysA, w.valsA);
         }
         // -- then the refinements
         if (surv) { KScope ks_("k_bwt_f_sort_small"); hipLaunchKernelGGL(k_bwt_f_sort_small, dim3(nTiles), dim3(256), 0, s, v); }
@@ -890,16 +891,22 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
             hipLaunchKernelGGL((k_bwt_f_sort_medium<512, 16>), gridM, dim3(512), 0, s, v, w.medSorted, nMed, npass, 2048u, w.med[nxt], w.large[nxt]);
         }
         if (nLarge) {
+            u32* k32a = reinterpret_cast<u32*>(w.keysA); u32* k32b = reinterpret_cast<u32*>(w.keysB);
             pb = w.primBytes;
             { KScope ks_("bwt_f_sort_large");
-              if (rocprim::radix_sort_pairs(w.prim, pb, w.keysA, w.keysB, w.valsA, w.valsB, (size_t)largeElems, 0u, (unsigned)(kbits + lbits), s) != hipSuccess) return -1; }
-            { KScope ks_("k_bwt_f_large_flags"); hipLaunchKernelGGL(k_bwt_f_large_flags, GRID1(largeElems), w.keysB, largeElems, w.t0, w.t2); }
+              const hipError_t e = small32 ? rocprim::radix_sort_pairs(w.prim, pb, k32a, k32b, w.valsA, w.valsB, (size_t)largeElems, 0u, (unsigned)(kbits + lbits), s)
+                                           : rocprim::radix_sort_pairs(w.prim, pb, w.keysA, w.keysB, w.valsA, w.valsB, (size_t)largeElems, 0u, (unsigned)(kbits + lbits), s);
+              if (e != hipSuccess) return -1; }
+            { KScope ks_("k_bwt_f_large_flags");
+              if (small32) hipLaunchKernelGGL(k_bwt_f_large_flags<u32>, GRID1(largeElems), k32b, largeElems, w.t0, w.t2);
+              else hipLaunchKernelGGL(k_bwt_f_large_flags<u64>, GRID1(largeElems), w.keysB, largeElems, w.t0, w.t2); }
             pb = w.primBytes;
             { KScope ks_("bwt_f_scan_max"); if (rocprim::inclusive_scan(w.prim, pb, w.t0, w.t1, (size_t)largeElems, rocprim::maximum<u32>(), s) != hipSuccess) return -1; }
             pb = w.primBytes;
             { KScope ks_("bwt_f_scan_min"); if (rocprim::inclusive_scan(w.prim, pb, w.t2, w.t3, (size_t)largeElems, rocprim::minimum<u32>(), s) != hipSuccess) return -1; }
-            { KScope ks_("k_bwt_f_large_place"); hipLaunchKernelGGL(k_bwt_f_large_place, GRID1(largeElems), v, w.large[cur], w.loff, largeElems, kbits, w.keysB, w.valsB,
-                                                                    w.t1, w.t3, w.med[nxt], w.large[nxt]); }
+            { KScope ks_("k_bwt_f_large_place");
+              if (small32) hipLaunchKernelGGL(k_bwt_f_large_place<u32>, GRID1(largeElems), v, w.large[cur], w.loff, largeElems, kbits, k32b, w.valsB, w.t1, w.t3, w.med[nxt], w.large[nxt]);
+              else hipLaunchKernelGGL(k_bwt_f_large_place<u64>, GRID1(largeElems), v, w.large[cur], w.loff, largeElems, kbits, w.keysB, w.valsB, w.t1, w.t3, w.med[nxt], w.large[nxt]); }
         }
         { KScope ks_("k_bwt_f_merge_bits"); hipLaunchKernelGGL(k_bwt_f_merge_bits, GRID1(total / 32 + 2), w.gbits, w.gnew, total / 32 + 2); }
         if (hipMemcpyAsync(h_pinned, w.counters, 16, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;

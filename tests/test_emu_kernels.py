@@ -92,3 +92,20 @@ def test_fpaq_kernels_emulated(tmp_path):
     write_case(path2, [c.text(20000, 1), c.mixed(300000, 2)[250000:262000], bytes(9000)])
     r = subprocess.run([exe2, path2], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_bwt_inverse_kernels_emulated(tmp_path):
+    # tile histograms + ballot ranks -> links, splitter walks, dword-gathered stores, against the oracle's forward transform
+    exe = build("bwt_inv_emu", tmp_path)
+    c = knzlib.corpus()
+    rng = np.random.default_rng(2)
+    cases = [
+        [b"ab", b"mississippi", bytes(255), bytes(range(256)), bytes(257), c.text(5000, 1), b"abcabcabcabcabcabcab"],
+        [c.text(30000, 2), c.mixed(300000, 2)[250000:262345], rng.integers(0, 4, 9000, dtype=np.uint8).tobytes(), bytes(3000) + c.text(500, 3)],
+    ]
+    for i, blocks in enumerate(cases):
+        path = str(tmp_path / ("inv%d.bin" % i))
+        write_case(path, blocks)
+        for order in ("0", "2"):
+            r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900, env=dict(os.environ, HIPEMU_ORDER=order))
+            assert r.returncode == 0, (i, order, r.stdout[-2000:] + r.stderr[-2000:])
