@@ -23,6 +23,7 @@
 #include "stages.hpp"
 #include "bwt_common.hpp"
 
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <rocprim/rocprim.hpp>
@@ -205,7 +206,8 @@ __device__ __forceinline__ bool sm_group_of(const SmWindow& W, u32 i, u32& s, u3
 // of a slot starts at the last set bit at or before it: found in the window's 64 bit-map words, else in the running
 // maximum over the windows before it (winLastIncl); the length of a group (needed where it starts) ends at the next set bit.
 __global__ __launch_bounds__(256) void k_bwt_f_r0_place(FwdView v, const u32* __restrict__ vals, const u32* __restrict__ winLastIncl,
-                                                        const u32* __restrict__ winFirstInclRev, u32 nWin, uint2* __restrict__ medNext, uint2* __restrict__ largeNext)
+                                                        const u32* __restrict__ winFirstInclRev, u32 nWin, uint2* __restrict__ medNext, uint2* __restrict__ largeNext,
+                                                        const u64* __restrict__ keys, int nsym, uint2* __restrict__ runList)
 {
     __shared__ SmWindow W;
     const int tid = (int)threadIdx.x;
@@ -252,7 +254,24 @@ __global__ __launch_bounds__(256) void k_bwt_f_r0_place(FwdView v, const u32* __
             const u32 ei = m2 ? (w * 32 + (u32)__ffs((int)m2) - 1) : W.nextSet[w];
             u32 nxt = (ei != NO_BIT) ? slot0 + ei : after;
             if (nxt > v.total) nxt = v.total;
-            classify_child(v, medNext, largeNext, a, nxt - a, surv);
+            const u32 size = nxt - a;
+            // a group whose nsym key bytes are one and the same byte (and whose suffixes are at least nsym long) sits inside runs
+            // of that byte: above the small size it is finished by the run-length round instead of log2(run length) doublings
+            bool runGroup = false;
+            if (runList != nullptr && size > SM_G) {
+                const u64 k = keys[a];
+                const u64 bytes = (k >> 3) & ((1ull << (8 * nsym)) - 1ull);
+                u64 rep = 0;
+                for (int q = 0; q < nsym; q++) rep = (rep << 8) | (bytes & 0xFF);
+                runGroup = ((k & 7) == (u64)nsym) && bytes == rep;
+            }
+            if (runGroup) {
+                const u32 at = atomicAdd(&v.counters[4], 1u);
+                runList[at] = make_uint2(a, size);
+                atomicAdd(&v.counters[5], size);
+            } else {
+                classify_child(v, medNext, largeNext, a, size, surv);
+            }
         }
     }
     if (__ballot(surv != 0) != 0 && (tid & 63) == 0) v.counters[0] = 1;
@@ -708,6 +727,95 @@ __global__ __launch_bounds__(256) void k_bwt_f_large_place(FwdView v, const uint
     if (__ballot(surv != 0) != 0 && (threadIdx.x & 63) == 0) v.counters[0] = 1;
 }
 
+// ------------------------------------------------------------------------------------------------
+// runs of one byte: finished in one round by their length
+// ------------------------------------------------------------------------------------------------
+// Members of a run group all start with nsym copies of a byte c. With R = length of the run of c that starts at the position, a =
+// the byte behind the run (or the block end, which sorts first), two members compare like (R, a): the one whose run ends first
+// is smaller when its a is below c, larger when above; equal (R, a) leave the suffixes behind the runs to decide. So ONE sort on
+//   hi = (a < c) ? R : 2^(kbits+1) - 1 - R,   lo = ISA[p + R] (rank of the suffix behind the run, 0 at the block end)
+// replaces the log2(R / nsym) doubling rounds such a group would otherwise take; members that still tie share R + nsym symbols.
+
+// run-end flags in position order: bit set where the next byte differs or the block ends
+__global__ __launch_bounds__(256) void k_bwt_f_run_ends(BwtView bv, FwdView v, unsigned long long* __restrict__ ebits64)
+{
+    const u32 gp = blockIdx.x * 256 + threadIdx.x;
+    bool f = true;
+    if (gp < v.total) {
+        const int b = find_block(v.base, v.nBlocks, gp);
+        const u32 off = gp - v.base[b], n = v.base[b + 1] - v.base[b];
+        const u8* t = bv.src[b];
+        f = (off + 1 >= n) || (t[off] != t[off + 1]);
+    }
+    const unsigned long long m = __ballot(f);
+    if ((threadIdx.x & 63) == 0) ebits64[gp >> 6] = m;
+}
+
+// R[gp] = distance to the end of the run that holds gp (1 = the run ends here); one workgroup per window of 2048 positions
+__global__ __launch_bounds__(256) void k_bwt_f_run_len(FwdView v, const u32* __restrict__ ebits, const u32* __restrict__ winFirstInclRev, u32 nWin, u32* __restrict__ R)
+{
+    __shared__ u32 bw[64];
+    __shared__ u32 nextSet[64];
+    const int tid = (int)threadIdx.x;
+    const u32 win = blockIdx.x, pos0 = win * SM_WIN;
+    if (tid < 64) {
+        const u32 w = ebits[(pos0 >> 5) + (u32)tid];
+        bw[tid] = w;
+        u32 sm = w ? (u32)(tid * 32 + __ffs((int)w) - 1) : NO_BIT;
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 u = (u32)__shfl_down((int)sm, (unsigned)o, 64);
+            if (tid + o < 64) sm = u < sm ? u : sm;
+        }
+        u32 sex = (u32)__shfl_down((int)sm, 1u, 64);
+        if (tid == 63) sex = NO_BIT;
+        nextSet[tid] = sex;
+    }
+    __syncthreads();
+    const u32 after = (win + 1 < nWin) ? winFirstInclRev[nWin - 2 - win] : v.total - 1;
+#pragma unroll
+    for (int k = 0; k < (int)(SM_WIN / 256); k++) {
+        const u32 i = (u32)tid + 256u * (u32)k;
+        const u32 gp = pos0 + i;
+        if (gp >= v.total) continue;
+        const u32 w = i >> 5, bit = i & 31;
+        const u32 m = bw[w] & (0xFFFFFFFFu << bit);              // this position or later
+        const u32 ei = m ? (w * 32 + (u32)__ffs((int)m) - 1) : nextSet[w];
+        const u32 e = (ei != NO_BIT) ? pos0 + ei : after;
+        R[gp] = e - gp + 1;
+    }
+}
+
+// the run groups as ordinary groups (when the run-length round cannot take them)
+__global__ __launch_bounds__(256) void k_bwt_f_run_fallback(FwdView v, const uint2* __restrict__ runList, u32 nRun, uint2* __restrict__ medNext, uint2* __restrict__ largeNext)
+{
+    const u32 g = blockIdx.x * 256 + threadIdx.x;
+    u32 surv = 0;
+    if (g < nRun) classify_child(v, medNext, largeNext, runList[g].x, runList[g].y, surv);
+}
+
+__global__ __launch_bounds__(256) void k_bwt_f_run_keys(BwtView bv, FwdView v, const uint2* __restrict__ desc, u32 nDesc, const u32* __restrict__ loff,
+                                                        u32 L, const u32* __restrict__ R, int kbits, u64* __restrict__ keys, u32* __restrict__ vals)
+{
+    const u32 j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= L) return;
+    u32 lo = 0, hi = nDesc;
+    while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (loff[mid] <= j) lo = mid; else hi = mid; }
+    const uint2 d = desc[lo];
+    const u32 slot = d.x + (j - loff[lo]);
+    const int b = find_block(v.base, v.nBlocks, d.x);
+    const u32 bb = v.base[b], be = v.base[b + 1];
+    const u32 gp = v.SA[slot];
+    const u32 r = R[gp];
+    const u32 q = gp + r;
+    const u8* t = bv.src[b];
+    const u32 c = t[gp - bb];
+    const bool below = (q >= be) || (t[q - bb] < c);                 // the block end sorts in front of every byte
+    const u64 khi = below ? (u64)r : ((1ull << (kbits + 1)) - 1ull - (u64)r);
+    const u64 klo = (q < be) ? (u64)(v.ISA[q] - bb + 1u) : 0ull;
+    keys[j] = ((u64)lo << (2 * kbits + 1)) | (khi << kbits) | klo;
+    vals[j] = gp;
+}
+
 // end of a round: the group starts found in it become visible
 __global__ __launch_bounds__(256) void k_bwt_f_merge_bits(u32* __restrict__ gbits, u32* __restrict__ gnew, u32 nWords)
 {
@@ -760,7 +868,7 @@ struct FwdScratch {
     u32* SA; u32* ISA; u32* K;
     u32* t0; u32* t1; u32* t2; u32* t3;
     u32* gbits; u32* gnew; size_t gbitsWords;
-    uint2* med[2]; uint2* medSorted; uint2* large[2];
+    uint2* med[2]; uint2* medSorted; uint2* large[2]; uint2* runList; u32* ebits;
     u32* loff;
     u32* base;
     u32* counters;
@@ -783,7 +891,9 @@ static size_t fwd_carve(u8* p, int nBlocks, size_t total, size_t bytes, FwdScrat
     w->gnew = (u32*)take(4 * w->gbitsWords);
     w->med[0] = (uint2*)take(8 * maxMed); w->med[1] = (uint2*)take(8 * maxMed); w->medSorted = (uint2*)take(8 * maxMed);
     w->large[0] = (uint2*)take(8 * maxLarge); w->large[1] = (uint2*)take(8 * maxLarge);
-    w->loff = (u32*)take(4 * (maxLarge + 1));
+    w->runList = (uint2*)take(8 * maxMed);
+    w->ebits = (u32*)take(4 * w->gbitsWords);
+    w->loff = (u32*)take(4 * (maxMed + 1));
     w->base = (u32*)take(4ull * (nBlocks + 2));
     w->counters = (u32*)take(256);
     w->prim = q;
@@ -846,13 +956,53 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     pb = w.primBytes;
     { KScope ks_("bwt_f_scan_min"); if (rocprim::inclusive_scan(w.prim, pb, w.t2, w.t3, (size_t)nWin, rocprim::minimum<u32>(), s) != hipSuccess) return -1; }
     int cur = 0;
-    { KScope ks_("k_bwt_f_r0_place"); hipLaunchKernelGGL(k_bwt_f_r0_place, dim3(nWin), dim3(256), 0, s, v, w.valsB, w.t1, w.t3, nWin, w.med[cur], w.large[cur]); }
-    if (hipMemcpyAsync(h_pinned, w.counters, 16, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
-    if (hipStreamSynchronize(s) != hipSuccess) return -1;
-    u32 surv = h_pinned[0], nMed = h_pinned[1], nLarge = h_pinned[2], largeElems = h_pinned[3];
-
     int kbits = 1;
     while ((1ull << kbits) < (u64)bv.VS + 2) kbits++;
+    // the run-length round needs descriptor index + (kbits + 1) + kbits bits in one 64-bit key
+    const bool runRound = (2 * kbits + 1) < 64 && getenv("KNZ_BWT_NO_RUN_ROUND") == nullptr;
+    { KScope ks_("k_bwt_f_r0_place"); hipLaunchKernelGGL(k_bwt_f_r0_place, dim3(nWin), dim3(256), 0, s, v, w.valsB, w.t1, w.t3, nWin, w.med[cur], w.large[cur],
+                                                         w.keysB, nsym, runRound ? w.runList : (uint2*)nullptr); }
+    if (hipMemcpyAsync(h_pinned, w.counters, 32, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+    if (hipStreamSynchronize(s) != hipSuccess) return -1;
+    u32 nRun = h_pinned[4], runElems = h_pinned[5];
+    const int keyBits = 2 * kbits + 1;
+    if (nRun && ((u64)nRun > (1ull << (64 - keyBits)))) {
+        // more run groups than the key has index bits left for (thousands of blocks in one batch): they go the ordinary way
+        { KScope ks_("k_bwt_f_run_fallback"); hipLaunchKernelGGL(k_bwt_f_run_fallback, GRID1(nRun), v, w.runList, nRun, w.med[cur], w.large[cur]); }
+        if (hipMemcpyAsync(h_pinned, w.counters, 32, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+        if (hipStreamSynchronize(s) != hipSuccess) return -1;
+        nRun = 0;
+    }
+    if (nRun) {
+        // run lengths of every position (text order), then one sort of the run groups' members on (run length, what follows)
+        { KScope ks_("k_bwt_f_run_ends"); hipLaunchKernelGGL(k_bwt_f_run_ends, dim3((total + 255) / 256), dim3(256), 0, s, bv, v, reinterpret_cast<unsigned long long*>(w.ebits)); }
+        { KScope ks_("k_bwt_f_r0_winsum"); hipLaunchKernelGGL(k_bwt_f_r0_winsum, GRID1(nWin), w.ebits, total, nWin, w.t0, w.t2); }
+        pb = w.primBytes;
+        { KScope ks_("bwt_f_scan_min"); if (rocprim::inclusive_scan(w.prim, pb, w.t2, w.t3, (size_t)nWin, rocprim::minimum<u32>(), s) != hipSuccess) return -1; }
+        { KScope ks_("k_bwt_f_run_len"); hipLaunchKernelGGL(k_bwt_f_run_len, dim3(nWin), dim3(256), 0, s, v, w.ebits, w.t3, nWin, w.K); }
+        int rbits = 0;
+        while ((1u << rbits) < nRun) rbits++;
+        { KScope ks_("k_bwt_f_large_prefix"); hipLaunchKernelGGL(k_bwt_f_large_prefix, dim3(1), dim3(1024), 0, s, w.runList, nRun, w.loff); }
+        { KScope ks_("k_bwt_f_run_keys"); hipLaunchKernelGGL(k_bwt_f_run_keys, GRID1(runElems), bv, v, w.runList, nRun, w.loff, runElems, w.K, kbits, w.keysA, w.valsA); }
+        pb = w.primBytes;
+        { KScope ks_("bwt_f_sort_runs");
+          if (rocprim::radix_sort_pairs(w.prim, pb, w.keysA, w.keysB, w.valsA, w.valsB, (size_t)runElems, 0u, (unsigned)(keyBits + rbits), s) != hipSuccess) return -1; }
+        { KScope ks_("k_bwt_f_large_flags"); hipLaunchKernelGGL(k_bwt_f_large_flags<u64>, GRID1(runElems), w.keysB, runElems, w.t0, w.t2); }
+        pb = w.primBytes;
+        { KScope ks_("bwt_f_scan_max"); if (rocprim::inclusive_scan(w.prim, pb, w.t0, w.t1, (size_t)runElems, rocprim::maximum<u32>(), s) != hipSuccess) return -1; }
+        pb = w.primBytes;
+        { KScope ks_("bwt_f_scan_min"); if (rocprim::inclusive_scan(w.prim, pb, w.t2, w.t3, (size_t)runElems, rocprim::minimum<u32>(), s) != hipSuccess) return -1; }
+        { KScope ks_("k_bwt_f_large_place"); hipLaunchKernelGGL(k_bwt_f_large_place<u64>, GRID1(runElems), v, w.runList, w.loff, runElems, keyBits, w.keysB, w.valsB, w.t1, w.t3,
+                                                                w.med[cur], w.large[cur]); }
+        { KScope ks_("k_bwt_f_merge_bits"); hipLaunchKernelGGL(k_bwt_f_merge_bits, GRID1(total / 32 + 2), w.gbits, w.gnew, total / 32 + 2); }
+        if (hipMemcpyAsync(h_pinned, w.counters, 32, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+        if (hipStreamSynchronize(s) != hipSuccess) return -1;
+    }
+    u32 surv = h_pinned[0], nMed = h_pinned[1], nLarge = h_pinned[2], largeElems = h_pinned[3];
+#ifdef KNZ_FWD_DEBUG
+    fprintf(stderr, "after round 0: run groups %u (%u members), small left %u, medium %u, large %u (%u members)\n", nRun, runElems, surv, nMed, nLarge, largeElems);
+#endif
+
     const int npass = (kbits + 7) / 8;
     const u32 nTiles = (total + SM_TS - 1) / SM_TS;
     u32 h = (u32)nsym;
