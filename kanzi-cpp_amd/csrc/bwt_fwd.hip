@@ -966,7 +966,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     if (hipStreamSynchronize(s) != hipSuccess) return -1;
     u32 nRun = h_pinned[4], runElems = h_pinned[5];
     const int keyBits = 2 * kbits + 1;
-    if (nRun && ((u64)nRun > (1ull << (64 - keyBits)))) {
+    if (nRun && ((u64)nRun > (1ull << (64 - keyBits)) || getenv("KNZ_BWT_RUN_FALLBACK") != nullptr)) {     // (the variable: tests force this path)
         // more run groups than the key has index bits left for (thousands of blocks in one batch): they go the ordinary way
         { KScope ks_("k_bwt_f_run_fallback"); hipLaunchKernelGGL(k_bwt_f_run_fallback, GRID1(nRun), v, w.runList, nRun, w.med[cur], w.large[cur]); }
         if (hipMemcpyAsync(h_pinned, w.counters, 32, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;

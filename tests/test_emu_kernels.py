@@ -63,6 +63,11 @@ def test_bwt_forward_kernels_emulated(tmp_path):
         for order in ("0", "1", "2"):       # workgroup dispatch order is not defined: forward, reverse, shuffled
             r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900, env=dict(os.environ, HIPEMU_ORDER=order))
             assert r.returncode == 0, (i, order, r.stdout[-2000:] + r.stderr[-2000:])
+        # the same without the run-length round (run groups refined by doubling like any other group), and with the run groups
+        # handed back to the ordinary lists (the path taken when a batch has more run groups than the sort key has index bits)
+        for var in ("KNZ_BWT_NO_RUN_ROUND", "KNZ_BWT_RUN_FALLBACK"):
+            r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900, env=dict(os.environ, **{var: "1"}))
+            assert r.returncode == 0, (i, var, r.stdout[-2000:] + r.stderr[-2000:])
 
 
 def test_fpaq_kernels_emulated(tmp_path):
