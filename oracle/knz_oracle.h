@@ -102,6 +102,11 @@ int knzo_compress_run(const uint8_t* in, size_t n, const char* transform, const 
                       int blockSize, int checksum, uint64_t origSize, int headerless, int jobs,
                       uint64_t firstBlock, int finish, uint8_t* out, size_t cap, size_t* outLen, uint64_t* outBits);
 int knzo_decompress(const uint8_t* in, size_t inLen, uint8_t* out, size_t cap, size_t* outLen);
+/* the same with codec ids and an open bit writer / a start bit (tests/stub: a CPU stand-in for the device library) */
+int knzo_compress_run_ids(const uint8_t* in, size_t n, uint64_t ttype, int etype, int blockSize, int checksum, int jobs,
+                          uint64_t firstBlock, int finish, knzo_bw* w);
+int knzo_decode_run(const uint8_t* in, uint64_t inBits, uint64_t startBit, uint64_t ttype, int etype, int checksumBits, int blockSize,
+                    int64_t maxBlocks, uint8_t* out, size_t cap, size_t* outLen, uint64_t* endBit, int64_t* blocksDone);
 
 /* XXHash32/64 as used for block checksums (util/XXHash.hpp:61-115,153-230), seed 0x4B414E5A */
 uint32_t knzo_xxhash32(const uint8_t* p, size_t n, uint32_t seed);

@@ -394,34 +394,10 @@ int knzo_compress_jobs(const uint8_t* in, size_t n, const char* transform, const
     return knzo_compress_run(in, n, transform, entropy, blockSize, checksum, origSize, headerless, jobs, 0, 1, out, cap, outLen, &bits);
 }
 
-/* A run of consecutive blocks of a larger stream: firstBlock = index of the first block (selects the
- * buffer slots), finish = append the end marker. *outBits = exact bit count (multi-GPU sharding tests). */
-int knzo_compress_run(const uint8_t* in, size_t n, const char* transform, const char* entropy,
-                      int blockSize, int checksum, uint64_t origSize, int headerless, int jobs,
-                      uint64_t firstBlock, int finish, uint8_t* out, size_t cap, size_t* outLen, uint64_t* outBits)
+/* The blocks of a run (length prefixes + private streams, optional end marker) appended to an open bit writer; codecs by id. */
+int knzo_compress_run_ids(const uint8_t* in, size_t n, uint64_t ttype, int etype, int blockSize, int checksum, int jobs,
+                          uint64_t firstBlock, int finish, knzo_bw* w)
 {
-    *outLen = 0;
-    const uint64_t ttype = knzo_transform_type(transform);
-    const int etype = knzo_entropy_type(entropy);
-    if (ttype == ~0ull || etype < 0) return ERR_INVALID_PARAM;
-    if (blockSize < 1024 || blockSize > (1 << 30) || (blockSize & -16) != blockSize) return ERR_INVALID_PARAM;
-    if (checksum != 0 && checksum != 32 && checksum != 64) return ERR_INVALID_PARAM;
-    knzo_bw w;
-    knzo_bw_init(&w, out, cap);
-    if (!headerless) {
-        const uint32_t ckSize = checksum == 32 ? 1 : (checksum == 64 ? 2 : 0);
-        knzo_bw_bits(&w, KNZ_MAGIC, 32);
-        knzo_bw_bits(&w, KNZ_VERSION, 4);
-        knzo_bw_bits(&w, ckSize, 2);
-        knzo_bw_bits(&w, (uint64_t)etype, 5);
-        knzo_bw_bits(&w, ttype, 48);
-        knzo_bw_bits(&w, (uint64_t)(blockSize >> 4), 28);
-        const int szMask = (origSize == 0 || origSize >= (1ull << 48)) ? 0 : (ilog2_64(origSize) >> 4) + 1;
-        knzo_bw_bits(&w, (uint64_t)szMask, 2);
-        if (szMask) knzo_bw_bits(&w, origSize, 16u * (unsigned)szMask);
-        knzo_bw_bits(&w, 0, 15);
-        knzo_bw_bits(&w, header_checksum(ckSize, (uint32_t)etype, ttype, (uint32_t)blockSize, szMask, origSize), 24);
-    }
     if (jobs < 1 || jobs > 64) return ERR_INVALID_PARAM;
     int dataCaps[64], bufCaps[64];
     for (int j = 0; j < jobs; j++) {
@@ -467,20 +443,95 @@ int knzo_compress_run(const uint8_t* in, size_t n, const char* transform, const 
         dataCaps[slot] = dataCap; bufCaps[slot] = bufCap;
         const uint64_t written = (uint64_t)bits;
         const unsigned lw = (written < 8) ? 3u : (unsigned)ilog2((uint32_t)(written >> 3)) + 4u;
-        knzo_bw_bits(&w, lw - 3, 5);
-        knzo_bw_bits(&w, written, lw);
-        knzo_bw_bytes(&w, tmp, written);
+        knzo_bw_bits(w, lw - 3, 5);
+        knzo_bw_bits(w, written, lw);
+        knzo_bw_bytes(w, tmp, written);
         off += (size_t)len;
     }
     free(tmp);
     if (finish) {
-        knzo_bw_bits(&w, 0, 5);
-        knzo_bw_bits(&w, 0, 3);
+        knzo_bw_bits(w, 0, 5);
+        knzo_bw_bits(w, 0, 3);
+    }
+    return 0;
+}
+
+/* A run of consecutive blocks of a larger stream: firstBlock = index of the first block (selects the
+ * buffer slots), finish = append the end marker. *outBits = exact bit count (multi-GPU sharding tests). */
+int knzo_compress_run(const uint8_t* in, size_t n, const char* transform, const char* entropy,
+                      int blockSize, int checksum, uint64_t origSize, int headerless, int jobs,
+                      uint64_t firstBlock, int finish, uint8_t* out, size_t cap, size_t* outLen, uint64_t* outBits)
+{
+    *outLen = 0;
+    const uint64_t ttype = knzo_transform_type(transform);
+    const int etype = knzo_entropy_type(entropy);
+    if (ttype == ~0ull || etype < 0) return ERR_INVALID_PARAM;
+    if (blockSize < 1024 || blockSize > (1 << 30) || (blockSize & -16) != blockSize) return ERR_INVALID_PARAM;
+    if (checksum != 0 && checksum != 32 && checksum != 64) return ERR_INVALID_PARAM;
+    knzo_bw w;
+    knzo_bw_init(&w, out, cap);
+    if (!headerless) {
+        const uint32_t ckSize = checksum == 32 ? 1 : (checksum == 64 ? 2 : 0);
+        knzo_bw_bits(&w, KNZ_MAGIC, 32);
+        knzo_bw_bits(&w, KNZ_VERSION, 4);
+        knzo_bw_bits(&w, ckSize, 2);
+        knzo_bw_bits(&w, (uint64_t)etype, 5);
+        knzo_bw_bits(&w, ttype, 48);
+        knzo_bw_bits(&w, (uint64_t)(blockSize >> 4), 28);
+        const int szMask = (origSize == 0 || origSize >= (1ull << 48)) ? 0 : (ilog2_64(origSize) >> 4) + 1;
+        knzo_bw_bits(&w, (uint64_t)szMask, 2);
+        if (szMask) knzo_bw_bits(&w, origSize, 16u * (unsigned)szMask);
+        knzo_bw_bits(&w, 0, 15);
+        knzo_bw_bits(&w, header_checksum(ckSize, (uint32_t)etype, ttype, (uint32_t)blockSize, szMask, origSize), 24);
+    }
+    {
+        const int rc = knzo_compress_run_ids(in, n, ttype, etype, blockSize, checksum, jobs, firstBlock, finish, &w);
+        if (rc) return rc;
     }
     if (w.overflow) return ERR_WRITE_FILE;
     *outLen = (size_t)((w.bits + 7) >> 3);
     *outBits = w.bits;
     return 0;
+}
+
+/* Blocks from bit `startBit` on: until the end marker, `maxBlocks` blocks (< 0: no limit) or the end of the data. */
+int knzo_decode_run(const uint8_t* in, uint64_t inBits, uint64_t startBit, uint64_t ttype, int etype, int checksumBits, int blockSize,
+                    int64_t maxBlocks, uint8_t* out, size_t cap, size_t* outLen, uint64_t* endBit, int64_t* blocksDone)
+{
+    knzo_br r;
+    knzo_br_init(&r, in, inBits);
+    r.pos = startBit;
+    uint8_t* tmp = NULL;
+    size_t tmpCap = 0;
+    size_t off = 0;
+    int err = 0;
+    int64_t done = 0;
+    *endBit = startBit;
+    while (maxBlocks < 0 || done < maxBlocks) {
+        if (r.pos + 8 > inBits) break;
+        const unsigned lr = 3 + (unsigned)knzo_br_bits(&r, 5);
+        const uint64_t bits = knzo_br_bits(&r, lr);
+        if (r.error) { err = ERR_READ_FILE; break; }
+        if (bits == 0) { *endBit = r.pos; break; }
+        if (bits > (1ull << 34)) { err = ERR_BLOCK_SIZE; break; }
+        const size_t nb = (size_t)((bits + 7) >> 3);
+        if (tmpCap < nb + 8) { free(tmp); tmpCap = nb + 8; tmp = (uint8_t*)malloc(tmpCap); }
+        memset(tmp, 0, nb + 8);
+        knzo_br_bytes(&r, tmp, bits);
+        if (r.error) { err = ERR_READ_FILE; break; }
+        int ol = 0;
+        const size_t room = cap - off;
+        const int outCap = room > (size_t)0x7FFFFFFF ? 0x7FFFFFFF : (int)room;
+        err = knzo_decode_block(tmp, bits, ttype, etype, checksumBits, blockSize, out + off, outCap, &ol);
+        if (err) break;
+        off += (size_t)ol;
+        done++;
+        *endBit = r.pos;
+    }
+    free(tmp);
+    *outLen = off;
+    *blocksDone = done;
+    return err;
 }
 
 int knzo_decompress(const uint8_t* in, size_t inLen, uint8_t* out, size_t cap, size_t* outLen)
@@ -505,29 +556,8 @@ int knzo_decompress(const uint8_t* in, size_t inLen, uint8_t* out, size_t cap, s
     if (r.error) return ERR_INVALID_FILE;
     if (ck1 != header_checksum(ckSize, (uint32_t)etype, ttype, (uint32_t)blockSize, szMask, size)) return ERR_CRC_CHECK;
     const int checksumBits = ckSize == 1 ? 32 : (ckSize == 2 ? 64 : 0);
-    uint8_t* tmp = NULL;
-    size_t tmpCap = 0;
-    size_t off = 0;
-    int err = 0;
-    while (1) {
-        const unsigned lr = 3 + (unsigned)knzo_br_bits(&r, 5);
-        const uint64_t bits = knzo_br_bits(&r, lr);
-        if (r.error) { err = ERR_READ_FILE; break; }
-        if (bits == 0) break;
-        if (bits > (1ull << 34)) { err = ERR_BLOCK_SIZE; break; }
-        const size_t nb = (size_t)((bits + 7) >> 3);
-        if (tmpCap < nb + 8) { free(tmp); tmpCap = nb + 8; tmp = (uint8_t*)malloc(tmpCap); }
-        memset(tmp, 0, nb + 8);
-        knzo_br_bytes(&r, tmp, bits);
-        if (r.error) { err = ERR_READ_FILE; break; }
-        int ol = 0;
-        const size_t room = cap - off;
-        const int outCap = room > (size_t)0x7FFFFFFF ? 0x7FFFFFFF : (int)room;
-        err = knzo_decode_block(tmp, bits, ttype, etype, checksumBits, blockSize, out + off, outCap, &ol);
-        if (err) break;
-        off += (size_t)ol;
-    }
-    free(tmp);
-    *outLen = off;
-    return err;
+    uint64_t endBit = 0;
+    int64_t done = 0;
+    return knzo_decode_run(in, 8ull * inLen, r.pos, ttype, etype, checksumBits, blockSize, -1, out, cap, outLen, &endBit, &done);
 }
+
