@@ -365,11 +365,11 @@ public:
     int peek();
     std::streamsize gcount() const { return _gcount; }
     void close();
-    uint64 getRead() const { return (_consumedBits + 7) >> 3; }
+    uint64 getRead() const { return (_readBits + 7) >> 3; }
     // io/CompressedInputStream.hpp:227-229,329-384. The only valid positions are block boundaries. tell() is the bit
-    // position (in the compressed stream) of the first block that has not been decoded yet, hence always a valid
-    // argument for seek(); with the default batching that is up to a batch of blocks ahead of what read() has
-    // delivered, call setBatchBlocks(1) to step block by block. seek() drops everything decoded and not yet read.
+    // position (in the compressed stream) behind the batch of blocks read() is currently delivering (before the first read:
+    // behind the stream header), hence always a valid argument for seek(); call setBatchBlocks(1) to step block by block.
+    // seek() drops everything decoded and not yet read. A reader thread decodes the next batch while this one is consumed.
     bool seek(int64 bitPos);
     int64 tell();
     void setBatchBlocks(int n) { if (n > 0) { _batchBlocks = n; _batchFromEnv = true; } }
@@ -380,21 +380,38 @@ private:
     uint64 _transformType;
     uint64 _outputSize;
     bool _headless, _closed, _headerDone, _ended;
-    int _batchBlocks;
-    bool _batchFromEnv;
+    std::atomic<int> _batchBlocks;
+    std::atomic<bool> _batchFromEnv;
+    // owned by the reader thread once it runs
     std::vector<byte> _comp;      // compressed bytes fetched and not yet decoded
     uint64 _compBit;              // next unread bit in _comp
     uint64 _consumedBits;
     int64 _originBit;             // bit position in the underlying stream that _compBit == 0 corresponds to
-    byte* _plain; size_t _plainCap, _plainLen;   // decoded bytes not yet delivered (page-locked)
     byte* _stage; size_t _stageCap;              // page-locked staging of the compressed bytes of a batch
-    size_t _plainPos;
-    std::streamsize _gcount;
     bool _srcEof;
     void* _dIn; size_t _dInCap; void* _dOut; size_t _dOutCap;
+    // two page-locked output slots: the reader thread fills one while read() drains the other
+    struct PSlot { byte* buf; size_t cap; size_t len; int64 endBit; uint64 consumedBits; bool last; std::exception_ptr err; int state; };   // state: 0 free, 2 ready
+    PSlot _ps[2];
+    int _prod, _cons;
+    std::thread _reader;
+    std::mutex _rmu;
+    std::condition_variable _rcv;
+    bool _rstop, _started;
+    // owned by the caller's thread
+    PSlot* _cur;                  // slot being delivered
+    size_t _plainPos;
+    bool _lastTaken;              // the final batch has been handed over: nothing more will come
+    int64 _tellBit;
+    uint64 _readBits;
+    std::streamsize _gcount;
+    void ensureStarted();
+    void stopReader();
+    void readerLoop();
+    bool advance();
     void readHeader();
     bool fetch(size_t minBytes);
-    bool decodeBatch();
+    void decodeBatch(PSlot& sl);
 };
 
 }  // namespace kanzi_amd

@@ -896,7 +896,9 @@ CompressedInputStream::CompressedInputStream(std::istream& is, int tasks, const 
     _batchFromEnv = false;
     if (e && atoi(e) > 0) { _batchBlocks = atoi(e); _batchFromEnv = true; }
     _compBit = 0; _consumedBits = 0; _plainPos = 0; _gcount = 0; _srcEof = false;
-    _plain = nullptr; _plainCap = 0; _plainLen = 0; _stage = nullptr; _stageCap = 0;
+    _stage = nullptr; _stageCap = 0;
+    for (int i = 0; i < 2; i++) { _ps[i].buf = nullptr; _ps[i].cap = 0; _ps[i].len = 0; _ps[i].endBit = 0; _ps[i].consumedBits = 0; _ps[i].last = false; _ps[i].state = 0; }
+    _prod = _cons = 0; _rstop = false; _started = false; _cur = nullptr; _lastTaken = false; _tellBit = 0; _readBits = 0;
     { _is.clear(); const std::streamoff at = std::streamoff(_is.tellg()); _originBit = (at < 0) ? 0 : 8 * int64(at); _is.clear(); }
     _dIn = _dOut = nullptr; _dInCap = _dOutCap = 0;
     deviceContext();
@@ -904,10 +906,11 @@ CompressedInputStream::CompressedInputStream(std::istream& is, int tasks, const 
 
 CompressedInputStream::~CompressedInputStream()
 {
+    stopReader();
     knz_ctx* c = nullptr;
     try { c = deviceContext(); } catch (...) {}
     if (c) { if (_dIn) knz_hip_free(c, _dIn); if (_dOut) knz_hip_free(c, _dOut); }
-    g_pinned.put(_plain, _plainCap);
+    for (int i = 0; i < 2; i++) g_pinned.put(_ps[i].buf, _ps[i].cap);
     g_pinned.put(_stage, _stageCap);
 }
 
@@ -962,9 +965,11 @@ void CompressedInputStream::readHeader()
     _compBit = pos;
 }
 
-bool CompressedInputStream::decodeBatch()
+// reader thread: the next batch of blocks into `sl` (sl.last: nothing behind it)
+void CompressedInputStream::decodeBatch(PSlot& sl)
 {
-    if (_ended) return false;
+    sl.len = 0;
+    if (_ended) { sl.last = true; sl.endBit = _originBit + int64(_compBit); sl.consumedBits = _consumedBits; return; }
     readHeader();
     // Drop the consumed prefix of the fetched bytes here, once per batch, before any bit cursor of the walk below
     // is taken: the walk keeps positions relative to _comp, so nothing may rebase them while it runs.
@@ -981,8 +986,9 @@ bool CompressedInputStream::decodeBatch()
     // one device call produces at most 2 GiB of output (32-bit positions on the device side)
     const int64_t bsz = int64_t(_blockSize > 0 ? _blockSize : 1);
     const int64_t lim = (int64_t(1) << 31) / bsz - 1;
-    int batch = (_batchBlocks > lim) ? int(lim < 1 ? 1 : lim) : _batchBlocks;
-    if (!_batchFromEnv) batch = std::max(_jobs, int(std::min<int64_t>(batch, std::max<int64_t>(1, (int64_t(256) << 20) / bsz))));
+    const int wantBatch = _batchBlocks.load();
+    int batch = (wantBatch > lim) ? int(lim < 1 ? 1 : lim) : wantBatch;
+    if (!_batchFromEnv.load()) batch = std::max(_jobs, int(std::min<int64_t>(batch, std::max<int64_t>(1, (int64_t(64) << 20) / bsz))));
     while (nb < batch) {
         if (!fetch(size_t(((pos + 40) >> 3) + 1 - (_compBit >> 3)))) {
             if (uint64(_comp.size()) * 8 < pos + 8) { if (nb == 0) throw IOException("Unexpected end of stream", Error::ERR_READ_FILE); break; }
@@ -1019,15 +1025,104 @@ bool CompressedInputStream::decodeBatch()
         const uint64 startBit = _compBit - uint64(firstByte) * 8;
         devCheck(c, knz_hip_decode_blocks(c, &p, static_cast<const uint8_t*>(_dIn), uint64(inBytes) * 8, startBit, nb,
                                           static_cast<uint8_t*>(_dOut), outCap, &outBytes, &endBit, &done), "decode blocks");
-        if (_plainCap < size_t(outBytes)) { g_pinned.put(_plain, _plainCap); _plain = nullptr; _plainCap = 0; _plain = g_pinned.get(std::max(size_t(outBytes), outCap), &_plainCap); }
-        _plainLen = size_t(outBytes);
-        _plainPos = 0;
-        if (outBytes) devCheck(c, knz_hip_memcpy_d2h(c, _plain, _dOut, size_t(outBytes)), "d2h");
+        if (sl.cap < size_t(outBytes)) { g_pinned.put(sl.buf, sl.cap); sl.buf = nullptr; sl.cap = 0; sl.buf = g_pinned.get(std::max(size_t(outBytes), outCap), &sl.cap); }
+        sl.len = size_t(outBytes);
+        if (outBytes) devCheck(c, knz_hip_memcpy_d2h(c, sl.buf, _dOut, size_t(outBytes)), "d2h");
     }
     _consumedBits += pos - _compBit;
     _compBit = pos;
     if (sawEnd) _ended = true;
-    return nb > 0;
+    sl.endBit = _originBit + int64(_compBit);
+    sl.consumedBits = _consumedBits;
+    sl.last = sawEnd || nb == 0;
+}
+
+void CompressedInputStream::readerLoop()
+{
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> l(_rmu);
+            _rcv.wait(l, [&] { return _rstop || _ps[_prod].state == 0; });
+            if (_rstop) return;
+        }
+        PSlot& sl = _ps[_prod];
+        sl.err = nullptr; sl.last = false; sl.len = 0;
+        try {
+            decodeBatch(sl);
+        } catch (...) {
+            sl.err = std::current_exception();
+            sl.last = true;
+        }
+        const bool last = sl.last;
+        {
+            std::lock_guard<std::mutex> l(_rmu);
+            sl.state = 2;
+            _prod ^= 1;
+        }
+        _rcv.notify_all();
+        if (last) return;
+    }
+}
+
+// caller's thread: header first (its errors belong to the caller), then the reader thread
+void CompressedInputStream::ensureStarted()
+{
+    if (_started) return;
+    readHeader();
+    _tellBit = _originBit + int64(_compBit);
+    _readBits = _consumedBits;
+    _rstop = false;
+    _started = true;
+    _reader = std::thread(&CompressedInputStream::readerLoop, this);
+}
+
+void CompressedInputStream::stopReader()
+{
+    if (_reader.joinable()) {
+        { std::lock_guard<std::mutex> l(_rmu); _rstop = true; }
+        _rcv.notify_all();
+        _reader.join();
+    }
+    _started = false;
+}
+
+// caller's thread: hand back the slot just drained and take the next batch; false at the end of the stream
+bool CompressedInputStream::advance()
+{
+    if (_cur) {
+        { std::lock_guard<std::mutex> l(_rmu); _cur->state = 0; }
+        _rcv.notify_all();
+        _cur = nullptr;
+    }
+    _plainPos = 0;
+    for (;;) {
+        if (_lastTaken) return false;
+        ensureStarted();
+        PSlot* sl;
+        {
+            std::unique_lock<std::mutex> l(_rmu);
+            _rcv.wait(l, [&] { return _ps[_cons].state == 2; });
+            sl = &_ps[_cons];
+            _cons ^= 1;
+        }
+        if (sl->last) _lastTaken = true;
+        if (sl->err) {
+            std::exception_ptr e = sl->err;
+            sl->err = nullptr;
+            { std::lock_guard<std::mutex> l(_rmu); sl->state = 0; }
+            _rcv.notify_all();
+            std::rethrow_exception(e);
+        }
+        _tellBit = sl->endBit;
+        _readBits = sl->consumedBits;
+        if (sl->len == 0) {
+            { std::lock_guard<std::mutex> l(_rmu); sl->state = 0; }
+            _rcv.notify_all();
+            continue;
+        }
+        _cur = sl;
+        return true;
+    }
 }
 
 std::istream& CompressedInputStream::read(char* data, std::streamsize length)
@@ -1036,13 +1131,11 @@ std::istream& CompressedInputStream::read(char* data, std::streamsize length)
     if (_closed) throw IOException("Stream closed", Error::ERR_READ_FILE);
     std::streamsize remaining = length;
     while (remaining > 0) {
-        if (_plainPos >= _plainLen) {
-            _plainLen = 0; _plainPos = 0;
-            if (!decodeBatch()) { setstate(std::ios::eofbit); break; }
-            if (_plainLen == 0) continue;
+        if (_cur == nullptr || _plainPos >= _cur->len) {
+            if (!advance()) { setstate(std::ios::eofbit); break; }
         }
-        const size_t take = std::min<size_t>(size_t(remaining), _plainLen - _plainPos);
-        memcpy(data + _gcount, &_plain[_plainPos], take);
+        const size_t take = std::min<size_t>(size_t(remaining), _cur->len - _plainPos);
+        memcpy(data + _gcount, _cur->buf + _plainPos, take);
         _plainPos += take;
         _gcount += std::streamsize(take);
         remaining -= std::streamsize(take);
@@ -1052,11 +1145,10 @@ std::istream& CompressedInputStream::read(char* data, std::streamsize length)
 
 int CompressedInputStream::peek()
 {
-    if (_plainPos >= _plainLen) {
-        _plainLen = 0; _plainPos = 0;
-        while (_plainLen == 0) if (!decodeBatch()) { setstate(std::ios::eofbit); return EOF; }
+    if (_cur == nullptr || _plainPos >= _cur->len) {
+        if (!advance()) { setstate(std::ios::eofbit); return EOF; }
     }
-    return int(_plain[_plainPos]);
+    return int(_cur->buf[_plainPos]);
 }
 
 int CompressedInputStream::get()
@@ -1069,25 +1161,29 @@ int CompressedInputStream::get()
 int64 CompressedInputStream::tell()
 {
     if (_closed) return -1;
-    if (!_ended && !_headerDone) {            // the first block starts behind the stream header
-        try { readHeader(); } catch (const IOException&) { _headerDone = false; return _originBit + int64(_compBit); }
+    if (!_started && !_lastTaken) {           // the first block starts behind the stream header
+        try { ensureStarted(); } catch (const IOException&) { _headerDone = false; return _originBit + int64(_compBit); }
     }
-    return _originBit + int64(_compBit);
+    return _tellBit;
 }
 
 bool CompressedInputStream::seek(int64 bitPos)
 {
     if (_closed || bitPos < 0) return false;
+    stopReader();
     _is.clear();
     _is.seekg(std::streampos(bitPos >> 3));
     if (_is.fail()) return false;
     // forget everything fetched or decoded; the stream parameters (header) stay
     _comp.clear();
-    _plainLen = 0; _plainPos = 0;
+    for (int i = 0; i < 2; i++) { _ps[i].state = 0; _ps[i].len = 0; _ps[i].err = nullptr; _ps[i].last = false; }
+    _prod = _cons = 0; _cur = nullptr; _lastTaken = false;
+    _plainPos = 0;
     _gcount = 0;
     _srcEof = false; _ended = false;
     _originBit = (bitPos >> 3) * 8;
     _compBit = uint64(bitPos & 7);
+    _tellBit = bitPos;
     this->clear();
     return true;
 }
@@ -1096,6 +1192,7 @@ void CompressedInputStream::close()
 {
     if (_closed) return;
     _closed = true;
+    stopReader();
     setstate(std::ios::eofbit);
 }
 
