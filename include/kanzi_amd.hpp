@@ -359,7 +359,12 @@ public:
     CompressedInputStream(std::istream& is, int jobs = 1, const std::string& entropy = "NONE", const std::string& transform = "NONE",
                           int blockSize = 4 * 1024 * 1024, int checksum = 0, uint64 originalSize = 0, bool headerless = false,
                           int bsVersion = 6);
+    // io/CompressedInputStream.hpp:189 / .cpp:121-212: parameters from a Context -- "jobs", for a headerless stream "entropy",
+    // "transform", "blockSize", "checksum", "outputSize", "bsVersion", and the block range "from" / "to" (1-based block ids, blocks
+    // from <= id < to are decoded, the ones before are skipped on the host, io/CompressedInputStream.cpp:836-868)
+    CompressedInputStream(std::istream& is, Context& ctx, bool headerless = false);
     ~CompressedInputStream();
+    void setBlockRange(int from, int to) { _from = from < 1 ? 1 : from; _to = to; }
     std::istream& read(char* s, std::streamsize n);
     int get();
     int peek();
@@ -380,6 +385,8 @@ private:
     uint64 _transformType;
     uint64 _outputSize;
     bool _headless, _closed, _headerDone, _ended;
+    int _from, _to;               // block range (1-based ids), default everything
+    int64 _nextBlockId;           // id of the next block the host walk will meet
     std::atomic<int> _batchBlocks;
     std::atomic<bool> _batchFromEnv;
     // owned by the reader thread once it runs

@@ -899,9 +899,18 @@ CompressedInputStream::CompressedInputStream(std::istream& is, int tasks, const 
     _stage = nullptr; _stageCap = 0;
     for (int i = 0; i < 2; i++) { _ps[i].buf = nullptr; _ps[i].cap = 0; _ps[i].len = 0; _ps[i].endBit = 0; _ps[i].consumedBits = 0; _ps[i].last = false; _ps[i].state = 0; }
     _prod = _cons = 0; _rstop = false; _started = false; _cur = nullptr; _lastTaken = false; _tellBit = 0; _readBits = 0;
+    _from = 1; _to = 0x7FFFFFFF; _nextBlockId = 1;
     { _is.clear(); const std::streamoff at = std::streamoff(_is.tellg()); _originBit = (at < 0) ? 0 : 8 * int64(at); _is.clear(); }
     _dIn = _dOut = nullptr; _dInCap = _dOutCap = 0;
     deviceContext();
+}
+
+CompressedInputStream::CompressedInputStream(std::istream& is, Context& ctx, bool headerless)
+    : CompressedInputStream(is, ctx.getInt("jobs", 1), ctx.getString("entropy", "NONE"), ctx.getString("transform", "NONE"),
+                            ctx.getInt("blockSize", 4 * 1024 * 1024), ctx.getInt("checksum", 0), uint64(ctx.getLong("outputSize", 0)), headerless,
+                            ctx.getInt("bsVersion", 6))
+{
+    setBlockRange(ctx.getInt("from", 1), ctx.getInt("to", 0x7FFFFFFF));
 }
 
 CompressedInputStream::~CompressedInputStream()
@@ -1000,10 +1009,21 @@ void CompressedInputStream::decodeBatch(PSlot& sl)
         if (uint64(_comp.size()) * 8 < pos + 5 + lr) throw IOException("Unexpected end of stream", Error::ERR_READ_FILE);
         if (len == 0) { sawEnd = true; pos += 5 + lr; break; }
         if (len > (uint64(1) << 34)) throw IOException("Invalid block size", Error::ERR_BLOCK_SIZE);
+        if (_nextBlockId >= int64(_to)) { sawEnd = true; break; }          // io/CompressedInputStream.cpp:866-868: the range is over
         const uint64 next = pos + 5 + lr + len;
         if (!fetch(size_t(((next + 7) >> 3) - (_compBit >> 3)))) throw IOException("Unexpected end of stream", Error::ERR_READ_FILE);
+        if (_nextBlockId < int64(_from)) {
+            // a block in front of the range: its bits are consumed, nothing is decoded (:843-865); only happens before the
+            // first block of a batch, so the batch simply starts behind it
+            _consumedBits += next - _compBit;
+            _compBit = next;
+            pos = next;
+            _nextBlockId++;
+            continue;
+        }
         pos = next;
         nb++;
+        _nextBlockId++;
     }
     if (nb > 0) {
         knz_ctx* c = deviceContext();
@@ -1181,6 +1201,7 @@ bool CompressedInputStream::seek(int64 bitPos)
     _plainPos = 0;
     _gcount = 0;
     _srcEof = false; _ended = false;
+    _nextBlockId = 1;
     _originBit = (bitPos >> 3) * 8;
     _compBit = uint64(bitPos & 7);
     _tellBit = bitPos;

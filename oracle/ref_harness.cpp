@@ -236,4 +236,33 @@ int ref_time_roundtrip(const uint8_t* in, size_t n, const char* transform, const
     return (got == n && memcmp(in, back, n) == 0) ? 0 : -4;
 }
 
+// Decompress with a block range ("from" / "to" in the Context, io/CompressedInputStream.cpp:836-868).
+int ref_decompress_range(const uint8_t* in, size_t inLen, int jobs, int from, int to, uint8_t* out, size_t outCap, size_t* outLen)
+{
+    try {
+        MemInBuf buf(reinterpret_cast<const char*>(in), inLen);
+        std::istream is(&buf);
+        Context ctx;
+        ctx.putInt("jobs", jobs);
+        ctx.putInt("from", from);
+        ctx.putInt("to", to);
+        CompressedInputStream cis(is, ctx);
+        size_t off = 0;
+        while (off < outCap) {
+            size_t c = outCap - off < (size_t(1) << 26) ? outCap - off : (size_t(1) << 26);
+            cis.read(reinterpret_cast<char*>(out) + off, std::streamsize(c));
+            size_t got = size_t(cis.gcount());
+            off += got;
+            if (got == 0) break;
+        }
+        cis.close();
+        *outLen = off;
+        return 0;
+    } catch (const IOException& e) {
+        return e.error();
+    } catch (const std::exception&) {
+        return -1;
+    }
+}
+
 }

@@ -220,6 +220,36 @@ static void testSeek()
     }
 }
 
+static void testBlockRange()
+{
+    // io/CompressedInputStream.cpp:836-868: with "from" / "to" in the Context only the blocks from <= id < to (1-based) come out
+    const int bs = 16384;
+    const size_t n = 7 * size_t(bs) + 777;       // 8 blocks
+    std::vector<byte> in = gen(4, n, 11);
+    std::stringstream ss;
+    {
+        CompressedOutputStream cos(ss, 1, "HUFFMAN", "BWT+MTFT+ZRLT", bs, 0, 0, false);
+        cos.write(reinterpret_cast<const char*>(in.data()), std::streamsize(n));
+        cos.close();
+    }
+    const std::string enc = ss.str();
+    const int ranges[][2] = { { 1, 0x7FFFFFFF }, { 3, 6 }, { 1, 2 }, { 8, 9 }, { 5, 100 }, { 9, 12 }, { 4, 4 } };
+    for (auto& r : ranges) {
+        for (int batch = 1; batch <= 3; batch += 2) {
+            std::stringstream is(enc);
+            Context ctx;
+            ctx.putInt("jobs", 2); ctx.putInt("from", r[0]); ctx.putInt("to", r[1]);
+            CompressedInputStream cis(is, ctx);
+            cis.setBatchBlocks(batch);
+            std::vector<byte> out(n + 16);
+            cis.read(reinterpret_cast<char*>(out.data()), std::streamsize(out.size()));
+            const size_t lo = std::min(n, size_t(r[0] - 1) * bs), hi = std::min(n, size_t(std::max(r[1], r[0]) - 1) * bs);
+            CHECK(size_t(cis.gcount()) == hi - lo);
+            CHECK(memcmp(out.data(), in.data() + lo, hi - lo) == 0);
+        }
+    }
+}
+
 int main(int argc, char** argv)
 {
     const std::string what = argc > 1 ? argv[1] : "all";
@@ -229,6 +259,7 @@ int main(int argc, char** argv)
         if (what == "all" || what == "entropy") testEntropy();
         if (what == "all" || what == "streams") testStreams();
         if (what == "all" || what == "seek") testSeek();
+        if (what == "all" || what == "range") testBlockRange();
     } catch (const std::exception& e) {
         printf("EXCEPTION %s\n", e.what());
         return 2;

@@ -3,6 +3,7 @@ build is absent). Randomised inputs beyond the committed golden vectors."""
 import numpy as np
 import pytest
 
+import knzlib
 import vectors
 
 
@@ -123,3 +124,28 @@ def test_checksums_match_reference(oracle, ref):
 def knz_buf(b):
     import ctypes as C
     return (C.c_uint8 * len(b)).from_buffer_copy(b)
+
+
+def test_reference_block_range_semantics():
+    """Pins what `from` / `to` mean in the reference (io/CompressedInputStream.cpp:836-868): 1-based block ids, blocks with
+    from <= id < to are delivered. The host layer's setBlockRange / Context constructor is tested against the same rule in
+    tests/cpp/host_mirror_test.cpp (testBlockRange)."""
+    import ctypes as C
+    so = knzlib.ensure_ref()
+    if so is None:
+        pytest.skip("reference build not available")
+    L = C.CDLL(so)
+    u8p = C.POINTER(C.c_uint8)
+    L.ref_decompress_range.restype = C.c_int
+    L.ref_decompress_range.argtypes = [u8p, C.c_size_t, C.c_int, C.c_int, C.c_int, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+    bs = 16384
+    d = vectors.make(("mixed", 7 * bs + 777, 4))
+    rc, enc = knzlib.Ref().compress(d, "BWT+MTFT+ZRLT", "HUFFMAN", bs, jobs=1)
+    assert rc == 0
+    src = (C.c_uint8 * len(enc)).from_buffer_copy(enc)
+    for lo_id, hi_id in [(1, 0x7FFFFFFF), (3, 6), (1, 2), (8, 9), (5, 100), (9, 12)]:
+        out = (C.c_uint8 * (len(d) + 16))()
+        ol = C.c_size_t(0)
+        rc = L.ref_decompress_range(src, len(enc), 1, lo_id, hi_id, out, len(d) + 16, C.byref(ol))
+        lo, hi = min(len(d), (lo_id - 1) * bs), min(len(d), (hi_id - 1) * bs)
+        assert rc == 0 and C.string_at(out, ol.value) == d[lo:hi], (lo_id, hi_id, rc, ol.value, hi - lo)
