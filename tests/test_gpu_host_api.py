@@ -185,3 +185,15 @@ def test_multi_batch_stream_beyond_compaction_threshold(tmp_path, monkeypatch):
             break
     d.close()
     assert bytes(out) == data
+
+
+def test_cli_interoperates_with_the_reference_cli_on_device(tmp_path):
+    # kanzi_amd_cli (reference option names) on the real device path: byte-identical files, cross decoding, --from/--to
+    import test_host_stub
+    cli = os.path.join(knzlib.ROOT, "kanzi-cpp_amd", "kanzi_amd_cli")
+    assert os.path.exists(cli), "run __graft_entry__.build()"
+    if os.environ.get("KNZ_TEST_KANZI_LIB"):
+        pytest.skip("covered by tests/test_host_stub.py in the stub run")
+    if knzlib.ensure_ref() is None or not os.path.exists(knzlib.REF_BIN):
+        pytest.skip("reference build not available")
+    test_host_stub.run_cli_interop(cli, knzlib.REF_BIN, tmp_path)

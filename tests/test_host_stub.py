@@ -26,13 +26,49 @@ def build_stub(tmp_path):
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-o", exe,
                            os.path.join(ROOT, "tests", "cpp", "host_mirror_test.cpp"), lib, "-Wl,-rpath," + str(tmp_path), "-L" + ora,
                            "-lknz_oracle", "-Wl,-rpath," + ora])
-    return lib, exe
+    cli = str(tmp_path / "kanzi_amd_cli_stub")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-o", cli,
+                           os.path.join(ROOT, "kanzi-cpp_amd", "host", "kanzi_cli.cpp"), lib, "-Wl,-rpath," + str(tmp_path), "-L" + ora,
+                           "-lknz_oracle", "-Wl,-rpath," + ora])
+    return lib, exe, cli
 
 
 def test_host_layer_against_stub_device(tmp_path):
-    lib, exe = build_stub(tmp_path)
+    lib, exe, _ = build_stub(tmp_path)
     env = dict(os.environ, KNZ_TEST_KANZI_LIB=lib, KNZ_TEST_HOST_MIRROR_EXE=exe)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_host_api.py"), "-m", "gpu", "-x", "-q",
                         "-p", "no:cacheprovider", "-k", "not threads_share_the_device"], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_cli_interoperates_with_the_reference_cli(tmp_path):
+    """kanzi-cpp_amd/host/kanzi_cli.cpp (option names of src/app/Kanzi.cpp) against the reference's own `kanzi` binary
+    (oracle/_ref/kanzi): same flags -> the same .knz bytes, each tool decodes the other's files, --from/--to select the
+    same blocks. Runs on the CPU with the stand-in device library; the GPU suite repeats it with the real one."""
+    import pytest
+    ref = knzlib.REF_BIN
+    if knzlib.ensure_ref() is None or not os.path.exists(ref):
+        pytest.skip("reference build not available")
+    _, _, cli = build_stub(tmp_path)
+    run_cli_interop(cli, ref, tmp_path)
+
+
+def run_cli_interop(cli, ref, tmp_path):
+    import vectors
+    data = vectors.make(("mixed", 5 * 65536 + 4321, 9))
+    src = str(tmp_path / "in.bin")
+    open(src, "wb").write(data)
+    for args in (["-t", "BWT+MTFT+ZRLT", "-e", "ANS0", "-b", "64k"], ["-t", "LZX", "-e", "HUFFMAN", "-b", "65536", "-x"],
+                 ["-l", "1", "-b", "1m"], ["--transform=RLT", "--entropy=FPAQ", "--block=32k", "-x64"]):
+        a, b = str(tmp_path / "a.knz"), str(tmp_path / "b.knz")
+        subprocess.check_call([ref, "-c", "-i", src, "-o", a, "-f", "-j", "1", "-v", "0"] + args)
+        subprocess.check_call([cli, "-c", "-i", src, "-o", b, "-f", "-j", "1"] + args, stderr=subprocess.DEVNULL)
+        assert open(a, "rb").read() == open(b, "rb").read(), args
+        oa, ob = str(tmp_path / "a.out"), str(tmp_path / "b.out")
+        subprocess.check_call([ref, "-d", "-i", b, "-o", oa, "-f", "-j", "1", "-v", "0"])
+        subprocess.check_call([cli, "-d", "-i", a, "-o", ob, "-f"], stderr=subprocess.DEVNULL)
+        assert open(oa, "rb").read() == data and open(ob, "rb").read() == data, args
+    subprocess.check_call([ref, "-d", "-i", a, "-o", oa, "-f", "-j", "1", "-v", "0", "--from=2", "--to=4"])
+    subprocess.check_call([cli, "-d", "-i", a, "-o", ob, "-f", "--from=2", "--to=4"], stderr=subprocess.DEVNULL)
+    assert open(oa, "rb").read() == open(ob, "rb").read() == data[32768:3 * 32768]
