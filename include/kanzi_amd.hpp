@@ -149,6 +149,8 @@ public:
     // consumed (bit 0 of the result = next unread bit) without consuming it, and lets the caller
     // advance afterwards.
     void peekRemaining(const byte** data, uint64* startBit, uint64* endBit);
+    // the same, but only as far as `wantBits` behind the read position (less at the end of the stream)
+    void peekAhead(uint64 wantBits, const byte** data, uint64* startBit, uint64* endBit);
     void skip(uint64 nbits);
 private:
     std::istream& _is;

@@ -212,6 +212,15 @@ void DefaultInputBitStream::peekRemaining(const byte** data, uint64* startBit, u
     *endBit = uint64(_data.size()) * 8;
 }
 
+void DefaultInputBitStream::peekAhead(uint64 wantBits, const byte** data, uint64* startBit, uint64* endBit)
+{
+    fill(wantBits);
+    *data = _data.data();
+    *startBit = _pos;
+    const uint64 have = uint64(_data.size()) * 8;
+    *endBit = (have - _pos > wantBits) ? _pos + wantBits : have;
+}
+
 void DefaultInputBitStream::skip(uint64 nbits)
 {
     if (!fill(nbits)) throw BitStreamException("No more data to read in the bitstream", BitStreamException::END_OF_STREAM);
@@ -559,13 +568,22 @@ int DeviceEntropyDecoder::decode(byte block[], uint blkptr, uint len)
     uint64_t used = 0;
     DefaultInputBitStream* dibs = dynamic_cast<DefaultInputBitStream*>(&_ibs);
     if (dibs != nullptr) {
+        // The device needs the block's bits in one buffer. Only as much of the stream as `len` symbols can occupy is handed
+        // over (16 bits per symbol, a header per 16 KiB chunk, 256 tables per 4 MiB for ANS1) -- not the whole rest of the
+        // stream on every call; should a valid block ever need more, the second try takes everything.
+        const uint64 bound = 8 * (2ull * len + (uint64(len) / 16384 + 2) * 640 + (_type == KNZ_E_ANS1 ? (uint64(len) / (4u << 20) + 1) * 256 * 576 : 0) + 4096);
         const byte* data; uint64 startBit, endBit;
-        dibs->peekRemaining(&data, &startBit, &endBit);
+        dibs->peekAhead(bound, &data, &startBit, &endBit);
         devCheck(c, knz_hip_entropy_decode(c, _type, data, endBit, startBit, &block[blkptr], len, &decoded, &used), "entropy decode");
+        if (decoded != int32_t(len) && endBit - startBit >= bound) {
+            dibs->peekRemaining(&data, &startBit, &endBit);
+            devCheck(c, knz_hip_entropy_decode(c, _type, data, endBit, startBit, &block[blkptr], len, &decoded, &used), "entropy decode");
+        }
         if (decoded == int32_t(len)) dibs->skip(used);
         return int(decoded);
     }
-    // generic InputBitStream: the device needs the bits in one buffer, so the rest of the stream is drained
+    // generic InputBitStream (no way to look ahead without consuming): the rest of the stream is drained into one buffer, so
+    // only ONE decode() per stream is possible through such an object; DefaultInputBitStream has no such limit
     std::vector<byte> rest;
     try { while (_ibs.hasMoreToRead()) rest.push_back(byte(_ibs.readBits(8))); } catch (const BitStreamException&) {}
     devCheck(c, knz_hip_entropy_decode(c, _type, rest.data(), uint64(rest.size()) * 8, 0, &block[blkptr], len, &decoded, &used), "entropy decode");
