@@ -40,6 +40,8 @@ CONFIGS = {
     # not BASELINE lines: config 1's codec on the device (BASELINE runs it on the CPU), config 5's entropy stage alone
     1: dict(transform="NONE", entropy="HUFFMAN", block=4 << 20, corpus="silesia"),
     6: dict(transform="NONE", entropy="ANS1", block=16 << 20, corpus="silesia"),
+    # config 3's chain on text (use with --limit 211957760): how the suffix sorter does without the stand-in's periodic segments
+    7: dict(transform="BWT+MTFT+ZRLT", entropy="ANS0", block=8 << 20, corpus="enwik9"),
 }
 
 # Kernel name (the KScope label of the launch) -> pipeline stage. First matching prefix wins.
