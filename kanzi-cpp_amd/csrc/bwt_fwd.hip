@@ -710,6 +710,8 @@ __global__ __launch_bounds__(256) void k_bwt_f_large_place(FwdView v, const uint
 {
     const u32 j = blockIdx.x * 256 + threadIdx.x;
     u32 surv = 0;
+    u32 mySlot = 0;
+    bool setBit = false;
     if (j < L) {
         const u32 di = (u32)(keys[j] >> kbits);
         const u32 gs = desc[di].x, off = loff[di];
@@ -717,14 +719,31 @@ __global__ __launch_bounds__(256) void k_bwt_f_large_place(FwdView v, const uint
         const u32 nh = head[j];
         v.SA[gs + (j - off)] = gp;
         if (nh != off) v.ISA[gp] = gs + (nh - off);
+        mySlot = gs + (j - off);
         if (nh == j) {
             const u32 nxt = (j + 1 < L) ? nextRev[L - 2 - j] : L;
-            const u32 slot = gs + (j - off);
-            if (j != off) atomicOr(&v.gnew[slot >> 5], 1u << (slot & 31));
-            classify_child(v, medNext, largeNext, slot, nxt - j, surv);
+            setBit = (j != off);
+            classify_child(v, medNext, largeNext, mySlot, nxt - j, surv);
         }
     }
     if (__ballot(surv != 0) != 0 && (threadIdx.x & 63) == 0) v.counters[0] = 1;
+    // new group starts: the lanes of a wave mostly hold consecutive slots (one group), so their bits are put together with a
+    // ballot and leave as at most three word-wide ORs per wave; lanes that are out of line (a group border inside the wave) OR
+    // their own bit
+    const int lane = (int)(threadIdx.x & 63);
+    const u32 s0 = (u32)__shfl((int)mySlot, 0, 64);
+    const bool inLine = (j < L) && (mySlot == s0 + (u32)lane);
+    const unsigned long long mask = __ballot(setBit && inLine);
+    if (setBit && !inLine) atomicOr(&v.gnew[mySlot >> 5], 1u << (mySlot & 31));
+    if (mask != 0 && lane == 0) {
+        const u32 w0 = s0 >> 5, sh = s0 & 31;
+        const u32 p0 = (u32)(mask << sh);
+        const u32 p1 = sh ? (u32)(mask >> (32 - sh)) : (u32)(mask >> 32);
+        const u32 p2 = sh ? (u32)(mask >> (64 - sh)) : 0u;
+        if (p0) atomicOr(&v.gnew[w0], p0);
+        if (p1) atomicOr(&v.gnew[w0 + 1], p1);
+        if (p2) atomicOr(&v.gnew[w0 + 2], p2);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -741,8 +760,11 @@ __global__ __launch_bounds__(256) void k_bwt_f_run_ends(BwtView bv, FwdView v, u
 {
     const u32 gp = blockIdx.x * 256 + threadIdx.x;
     bool f = true;
+    // one search per wave (uniform), then a short walk for the lanes behind a block border
+    const u32 gp0 = gp & ~63u;
+    int b = find_block(v.base, v.nBlocks, gp0 < v.total ? gp0 : v.total - 1);
     if (gp < v.total) {
-        const int b = find_block(v.base, v.nBlocks, gp);
+        while (gp >= v.base[b + 1]) b++;
         const u32 off = gp - v.base[b], n = v.base[b + 1] - v.base[b];
         const u8* t = bv.src[b];
         f = (off + 1 >= n) || (t[off] != t[off + 1]);
@@ -772,6 +794,7 @@ __global__ __launch_bounds__(256) void k_bwt_f_run_len(FwdView v, const u32* __r
     }
     __syncthreads();
     const u32 after = (win + 1 < nWin) ? winFirstInclRev[nWin - 2 - win] : v.total - 1;
+    u32 rmax = 0;
 #pragma unroll
     for (int k = 0; k < (int)(SM_WIN / 256); k++) {
         const u32 i = (u32)tid + 256u * (u32)k;
@@ -782,7 +805,10 @@ __global__ __launch_bounds__(256) void k_bwt_f_run_len(FwdView v, const u32* __r
         const u32 ei = m ? (w * 32 + (u32)__ffs((int)m) - 1) : nextSet[w];
         const u32 e = (ei != NO_BIT) ? pos0 + ei : after;
         R[gp] = e - gp + 1;
+        rmax = (e - gp + 1) > rmax ? (e - gp + 1) : rmax;
     }
+    rmax = wave_max(rmax);
+    if ((tid & 63) == 0) atomicMax(&v.counters[6], rmax);     // longest run: sizes the key of the run-length sort
 }
 
 // the run groups as ordinary groups (when the run-length round cannot take them)
@@ -794,7 +820,7 @@ __global__ __launch_bounds__(256) void k_bwt_f_run_fallback(FwdView v, const uin
 }
 
 __global__ __launch_bounds__(256) void k_bwt_f_run_keys(BwtView bv, FwdView v, const uint2* __restrict__ desc, u32 nDesc, const u32* __restrict__ loff,
-                                                        u32 L, const u32* __restrict__ R, int kbits, u64* __restrict__ keys, u32* __restrict__ vals)
+                                                        u32 L, const u32* __restrict__ R, int kbits, int hbits, u64* __restrict__ keys, u32* __restrict__ vals)
 {
     const u32 j = blockIdx.x * 256 + threadIdx.x;
     if (j >= L) return;
@@ -810,9 +836,9 @@ __global__ __launch_bounds__(256) void k_bwt_f_run_keys(BwtView bv, FwdView v, c
     const u8* t = bv.src[b];
     const u32 c = t[gp - bb];
     const bool below = (q >= be) || (t[q - bb] < c);                 // the block end sorts in front of every byte
-    const u64 khi = below ? (u64)r : ((1ull << (kbits + 1)) - 1ull - (u64)r);
+    const u64 khi = below ? (u64)r : ((1ull << hbits) - 1ull - (u64)r);      // hbits = bits of the longest run + 1
     const u64 klo = (q < be) ? (u64)(v.ISA[q] - bb + 1u) : 0ull;
-    keys[j] = ((u64)lo << (2 * kbits + 1)) | (khi << kbits) | klo;
+    keys[j] = ((u64)lo << (hbits + kbits)) | (khi << kbits) | klo;
     vals[j] = gp;
 }
 
@@ -842,9 +868,25 @@ __global__ __launch_bounds__(256) void k_bwt_f_emit(BwtView v, const u32* __rest
     u8* d = v.dst[b];
     const u32 bb = base[b];
     const u32 r0 = ISA[bb] - bb;                           // rank of suffix 0
-    for (u32 r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) {
-        const u32 p = SA[bb + r] - bb;
-        if (p != 0) d[hdr + 1 + r - (r > r0 ? 1u : 0u)] = s[p - 1];
+    // output byte q (hdr + 1 <= q < hdr + n) is the symbol in front of the suffix of rank r' = q - hdr - 1, ranks from r0 on moved
+    // up by one (suffix 0 has nothing in front of it); a thread gathers the four bytes of one aligned dword of the output
+    const u32 qLo = hdr + 1, qHi = hdr + n;
+    const bool al = (reinterpret_cast<uintptr_t>(d) & 3) == 0;
+    for (u32 w = (qLo >> 2) + blockIdx.x * 256 + threadIdx.x; 4 * w < qHi; w += gridDim.x * 256) {
+        u32 word = 0, have = 0;
+#pragma unroll
+        for (u32 k = 0; k < 4; k++) {
+            const u32 q = 4 * w + k;
+            if (q >= qLo && q < qHi) {
+                const u32 rr = q - qLo;
+                const u32 r = rr + (rr >= r0 ? 1u : 0u);
+                const u32 p = SA[bb + r] - bb;
+                word |= (u32)s[p - 1] << (8 * k);
+                have |= 1u << k;
+            }
+        }
+        if (have == 0xF && al) reinterpret_cast<u32*>(d)[w] = word;
+        else for (u32 k = 0; k < 4; k++) if ((have >> k) & 1) d[4 * w + k] = (u8)(word >> (8 * k));
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         d[hdr] = s[n - 1];
@@ -965,8 +1007,8 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     if (hipMemcpyAsync(h_pinned, w.counters, 32, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
     if (hipStreamSynchronize(s) != hipSuccess) return -1;
     u32 nRun = h_pinned[4], runElems = h_pinned[5];
-    const int keyBits = 2 * kbits + 1;
-    if (nRun && ((u64)nRun > (1ull << (64 - keyBits)) || getenv("KNZ_BWT_RUN_FALLBACK") != nullptr)) {     // (the variable: tests force this path)
+    const int maxKeyBits = 2 * kbits + 1;
+    if (nRun && ((u64)nRun > (1ull << (64 - maxKeyBits)) || getenv("KNZ_BWT_RUN_FALLBACK") != nullptr)) {     // (the variable: tests force this path)
         // more run groups than the key has index bits left for (thousands of blocks in one batch): they go the ordinary way
         { KScope ks_("k_bwt_f_run_fallback"); hipLaunchKernelGGL(k_bwt_f_run_fallback, GRID1(nRun), v, w.runList, nRun, w.med[cur], w.large[cur]); }
         if (hipMemcpyAsync(h_pinned, w.counters, 32, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
@@ -980,10 +1022,16 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
         pb = w.primBytes;
         { KScope ks_("bwt_f_scan_min"); if (rocprim::inclusive_scan(w.prim, pb, w.t2, w.t3, (size_t)nWin, rocprim::minimum<u32>(), s) != hipSuccess) return -1; }
         { KScope ks_("k_bwt_f_run_len"); hipLaunchKernelGGL(k_bwt_f_run_len, dim3(nWin), dim3(256), 0, s, v, w.ebits, w.t3, nWin, w.K); }
+        if (hipMemcpyAsync(h_pinned + 8, w.counters + 6, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+        if (hipStreamSynchronize(s) != hipSuccess) return -1;
+        int hbits = 1;
+        while ((1ull << hbits) < (u64)h_pinned[8] + 1) hbits++;
+        hbits++;                                                  // both halves of the order: R and 2^hbits - 1 - R
+        const int keyBits = hbits + kbits;
         int rbits = 0;
         while ((1u << rbits) < nRun) rbits++;
         { KScope ks_("k_bwt_f_large_prefix"); hipLaunchKernelGGL(k_bwt_f_large_prefix, dim3(1), dim3(1024), 0, s, w.runList, nRun, w.loff); }
-        { KScope ks_("k_bwt_f_run_keys"); hipLaunchKernelGGL(k_bwt_f_run_keys, GRID1(runElems), bv, v, w.runList, nRun, w.loff, runElems, w.K, kbits, w.keysA, w.valsA); }
+        { KScope ks_("k_bwt_f_run_keys"); hipLaunchKernelGGL(k_bwt_f_run_keys, GRID1(runElems), bv, v, w.runList, nRun, w.loff, runElems, w.K, kbits, hbits, w.keysA, w.valsA); }
         pb = w.primBytes;
         { KScope ks_("bwt_f_sort_runs");
           if (rocprim::radix_sort_pairs(w.prim, pb, w.keysA, w.keysB, w.valsA, w.valsB, (size_t)runElems, 0u, (unsigned)(keyBits + rbits), s) != hipSuccess) return -1; }
