@@ -808,7 +808,8 @@ __global__ __launch_bounds__(256) void k_bwt_f_run_len(FwdView v, const u32* __r
         rmax = (e - gp + 1) > rmax ? (e - gp + 1) : rmax;
     }
     rmax = wave_max(rmax);
-    if ((tid & 63) == 0) atomicMax(&v.counters[6], rmax);     // longest run: sizes the key of the run-length sort
+    // longest run: sizes the key of the run-length sort (read first: one atomic per wave on one address would serialise the launch)
+    if ((tid & 63) == 0 && rmax > __atomic_load_n(&v.counters[6], __ATOMIC_RELAXED)) atomicMax(&v.counters[6], rmax);
 }
 
 // the run groups as ordinary groups (when the run-length round cannot take them)
@@ -978,6 +979,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     int nsym = (53 - bbits) / 8;
     if (nsym < 4) nsym = (61 - bbits) / 8;
     if (nsym > 7) nsym = 7;
+    if (const char* e = getenv("KNZ_BWT_NSYM")) { const int o = atoi(e); if (o >= 1 && o < nsym) nsym = o; }   // tuning knob: shorter round-0 keys
     if (nsym < 1) return -4;
     const dim3 gridB((unsigned)std::min<size_t>(((size_t)bv.VS + 255) / 256, 4096), st.nBlocks);
     { KScope ks_("k_bwt_f_init"); hipLaunchKernelGGL(k_bwt_f_init, gridB, dim3(256), 0, s, bv, w.base, st.ok, nsym, w.keysA, w.valsA); }
