@@ -338,18 +338,23 @@ private:
     byte _pendingByte;            // partial last byte of the stream written so far
     uint _pendingBits;
     std::atomic<uint64_t> _written;   // bytes that reached the sink (advanced by the worker thread)
-    void* _dIn; size_t _dInCap; void* _dOut; size_t _dOutCap;
-    // Two page-locked input slots: write() fills one while a worker thread moves the other through the device
-    // (H2D, kernels, D2H into a page-locked output buffer, sink write), so that the caller's copies overlap the GPU.
-    struct Slot { byte* buf; size_t cap; size_t n; bool last; int state; };   // state: 0 free, 1 queued
+    // Two page-locked input slots, each with its own device input buffer: write() fills one and queues its host-to-device copy
+    // (copy stream) while a worker thread has the other one in the kernels. The worker brings the compressed bytes back into one
+    // of two page-locked output buffers; the caller's thread writes them to the sink (in order, from write()/close()) while the
+    // device is already busy with the next batch.
+    struct Slot { byte* buf; size_t cap; size_t n; bool last; int state; void* dIn; size_t dInCap; uint64 ticket; };   // state: 0 free, 1 queued
     Slot _slot[2];
     int _fill, _proc;
-    byte* _hostOut; size_t _hostOutCap;
+    struct Out { byte* buf; size_t cap; size_t bytes; int state; };   // state: 0 free, 1 waiting for the sink
+    Out _out[2];
+    int _outProd, _outCons;
+    void* _dOut; size_t _dOutCap;
     std::thread _worker;
     std::mutex _mu;
     std::condition_variable _cv;
     bool _stop;
     std::exception_ptr _err;
+    bool drainOne(std::unique_lock<std::mutex>& l);
     void enqueue(bool last);
     void workerLoop();
     void rethrow();
@@ -396,14 +401,20 @@ private:
     uint64 _compBit;              // next unread bit in _comp
     uint64 _consumedBits;
     int64 _originBit;             // bit position in the underlying stream that _compBit == 0 corresponds to
-    byte* _stage; size_t _stageCap;              // page-locked staging of the compressed bytes of a batch
     bool _srcEof;
-    void* _dIn; size_t _dInCap; void* _dOut; size_t _dOutCap;
-    // two page-locked output slots: the reader thread fills one while read() drains the other
-    struct PSlot { byte* buf; size_t cap; size_t len; int64 endBit; uint64 consumedBits; bool last; std::exception_ptr err; int state; };   // state: 0 free, 2 ready
+    // Three stages, two buffers between each pair. The reader thread fetches compressed bytes, walks the block length prefixes and
+    // copies the batch to the device (page-locked staging, copy stream); the decoder thread runs the kernels and queues the
+    // device-to-host copy of the result into a page-locked slot; read() waits for that copy and drains the slot. So the file reads
+    // and both PCIe directions of neighbouring batches run beside the kernels.
+    struct Prep { void* dIn; size_t dInCap; byte* stage; size_t stageCap; size_t inBytes; uint64 startBit; int nb; bool last;
+                  int64 endBit; uint64 consumedBits; std::exception_ptr err; uint64 ticket; int state; };                    // state: 0 free, 1 prepared
+    Prep _prep[2];
+    int _pprod, _pcons;
+    struct PSlot { byte* buf; size_t cap; size_t len; int64 endBit; uint64 consumedBits; bool last; std::exception_ptr err;
+                   void* dOut; size_t dOutCap; uint64 ticket; int state; };                                                    // state: 0 free, 2 ready
     PSlot _ps[2];
     int _prod, _cons;
-    std::thread _reader;
+    std::thread _reader, _decoder;
     std::mutex _rmu;
     std::condition_variable _rcv;
     bool _rstop, _started;
@@ -420,7 +431,9 @@ private:
     bool advance();
     void readHeader();
     bool fetch(size_t minBytes);
-    void decodeBatch(PSlot& sl);
+    void prepareBatch(Prep& pr);
+    void decodeBatch(Prep& pr, PSlot& sl);
+    void decoderLoop();
 };
 
 }  // namespace kanzi_amd

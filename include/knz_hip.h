@@ -129,6 +129,14 @@ KNZ_API int knz_hip_free(knz_ctx* ctx, void* d_ptr);
 KNZ_API int knz_hip_memcpy_h2d(knz_ctx* ctx, void* d_dst, const void* src, size_t bytes);
 KNZ_API int knz_hip_memcpy_d2h(knz_ctx* ctx, void* dst, const void* d_src, size_t bytes);
 KNZ_API int knz_hip_sync(knz_ctx* ctx);
+/* The same copies, queued on the context's copy streams (one per direction) and returning at once: they run beside the kernels
+ * of a knz_hip_encode_blocks / knz_hip_decode_blocks call that another host thread has in flight (no context lock is taken), which
+ * is how the stream classes overlap PCIe with compute. Host memory must be page-locked (knz_hip_host_alloc); the device buffer
+ * must not be in use by a call in flight. knz_hip_copy_wait blocks until the copy behind `ticket` is complete (a ticket can be
+ * waited for once; 0 and unknown tickets return at once). */
+KNZ_API int knz_hip_memcpy_h2d_async(knz_ctx* ctx, void* d_dst, const void* src, size_t bytes, uint64_t* ticket);
+KNZ_API int knz_hip_memcpy_d2h_async(knz_ctx* ctx, void* dst, const void* d_src, size_t bytes, uint64_t* ticket);
+KNZ_API int knz_hip_copy_wait(knz_ctx* ctx, uint64_t ticket);
 /* Page-locked host memory for staging buffers (what knz_hip_memcpy_h2d / _d2h move at full PCIe rate). */
 KNZ_API int knz_hip_host_alloc(size_t bytes, void** ptr);
 KNZ_API int knz_hip_host_free(void* ptr);

@@ -34,6 +34,13 @@ struct Ctx {
     void* pinned = nullptr;      // small pinned host scratch
     size_t pinnedCap = 0;
     std::recursive_mutex mu;     // a context is one stream + one set of workspaces: calls on it are serialised
+    // Copy engine beside the kernels: one stream per direction, outside the lock above, so that a host thread can move the next
+    // batch in (or the last one out) while another thread sits in knz_hip_encode_blocks / knz_hip_decode_blocks.
+    std::mutex copyMu;
+    hipStream_t copyIn = nullptr, copyOut = nullptr;
+    std::vector<hipEvent_t> copyIdle;
+    std::map<uint64_t, hipEvent_t> copyPending;
+    uint64_t copyNext = 1;
 };
 #define CTX_LOCK(c) std::lock_guard<std::recursive_mutex> ctx_lock_((c)->mu)
 
@@ -157,6 +164,10 @@ void knz_hip_destroy(knz_ctx* ctx)
     for (auto& kv : c->ws) if (kv.second.p) hipFree(kv.second.p);
     for (auto& e : c->prof) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     if (c->pinned) hipHostFree(c->pinned);
+    for (auto& kv : c->copyPending) { hipEventSynchronize(kv.second); hipEventDestroy(kv.second); }
+    for (auto& e : c->copyIdle) hipEventDestroy(e);
+    if (c->copyIn) hipStreamDestroy(c->copyIn);
+    if (c->copyOut) hipStreamDestroy(c->copyOut);
     if (c->ownStream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -244,6 +255,53 @@ int knz_hip_memcpy_d2h(knz_ctx* ctx, void* dst, const void* d_src, size_t bytes)
     CTX_LOCK(c);
     HIPCHK(c, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+static int copy_async(Ctx* c, void* dst, const void* src, size_t bytes, bool in, uint64_t* ticket)
+{
+    *ticket = 0;
+    std::lock_guard<std::mutex> l(c->copyMu);
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t& st = in ? c->copyIn : c->copyOut;
+    if (st == nullptr) HIPCHK(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    hipEvent_t ev;
+    if (!c->copyIdle.empty()) { ev = c->copyIdle.back(); c->copyIdle.pop_back(); }
+    else HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    if (bytes) HIPCHK(c, hipMemcpyAsync(dst, src, bytes, in ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipEventRecord(ev, st));
+    *ticket = c->copyNext++;
+    c->copyPending[*ticket] = ev;
+    return 0;
+}
+
+int knz_hip_memcpy_h2d_async(knz_ctx* ctx, void* d_dst, const void* src, size_t bytes, uint64_t* ticket)
+{
+    return copy_async(reinterpret_cast<Ctx*>(ctx), d_dst, src, bytes, true, ticket);
+}
+
+int knz_hip_memcpy_d2h_async(knz_ctx* ctx, void* dst, const void* d_src, size_t bytes, uint64_t* ticket)
+{
+    return copy_async(reinterpret_cast<Ctx*>(ctx), dst, d_src, bytes, false, ticket);
+}
+
+int knz_hip_copy_wait(knz_ctx* ctx, uint64_t ticket)
+{
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    hipEvent_t ev;
+    {
+        std::lock_guard<std::mutex> l(c->copyMu);
+        auto it = c->copyPending.find(ticket);
+        if (it == c->copyPending.end()) return 0;               // unknown or already waited for
+        ev = it->second;
+        c->copyPending.erase(it);
+    }
+    const hipError_t e = hipEventSynchronize(ev);
+    {
+        std::lock_guard<std::mutex> l(c->copyMu);
+        c->copyIdle.push_back(ev);
+    }
+    if (e != hipSuccess) return fail(c, -1, "copy failed: %s", hipGetErrorString(e));
     return 0;
 }
 

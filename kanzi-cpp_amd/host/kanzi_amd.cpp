@@ -728,9 +728,13 @@ CompressedOutputStream::CompressedOutputStream(std::ostream& os, int tasks, cons
     { const int64_t lim = (int64_t(1) << 31) / int64_t(blockSize) - 1; if (_batchBlocks > lim) _batchBlocks = int(lim < 1 ? 1 : lim); }
     _blockId = 0;
     _pendingByte = 0; _pendingBits = 0; _written = 0;
-    _dIn = _dOut = nullptr; _dInCap = _dOutCap = 0;
-    for (int i = 0; i < 2; i++) { _slot[i].buf = nullptr; _slot[i].cap = 0; _slot[i].n = 0; _slot[i].last = false; _slot[i].state = 0; }
-    _fill = 0; _proc = 0; _hostOut = nullptr; _hostOutCap = 0; _stop = false;
+    _dOut = nullptr; _dOutCap = 0;
+    for (int i = 0; i < 2; i++) {
+        _slot[i].buf = nullptr; _slot[i].cap = 0; _slot[i].n = 0; _slot[i].last = false; _slot[i].state = 0;
+        _slot[i].dIn = nullptr; _slot[i].dInCap = 0; _slot[i].ticket = 0;
+        _out[i].buf = nullptr; _out[i].cap = 0; _out[i].bytes = 0; _out[i].state = 0;
+    }
+    _fill = 0; _proc = 0; _outProd = 0; _outCons = 0; _stop = false;
     deviceContext();
 }
 
@@ -744,9 +748,11 @@ CompressedOutputStream::~CompressedOutputStream()
     }
     knz_ctx* c = nullptr;
     try { c = deviceContext(); } catch (...) {}
-    if (c) { if (_dIn) knz_hip_free(c, _dIn); if (_dOut) knz_hip_free(c, _dOut); }
-    for (int i = 0; i < 2; i++) g_pinned.put(_slot[i].buf, _slot[i].cap);
-    g_pinned.put(_hostOut, _hostOutCap);
+    if (c) {
+        for (int i = 0; i < 2; i++) { knz_hip_copy_wait(c, _slot[i].ticket); if (_slot[i].dIn) knz_hip_free(c, _slot[i].dIn); }
+        if (_dOut) knz_hip_free(c, _dOut);
+    }
+    for (int i = 0; i < 2; i++) { g_pinned.put(_slot[i].buf, _slot[i].cap); g_pinned.put(_out[i].buf, _out[i].cap); }
 }
 
 void CompressedOutputStream::rethrow()
@@ -777,17 +783,55 @@ std::ostream& CompressedOutputStream::write(const char* data, std::streamsize le
 
 std::ostream& CompressedOutputStream::put(char c) { return write(&c, 1); }
 
-// hand the slot being filled to the worker and wait until the other slot is free
+// caller's thread: the oldest finished batch goes to the sink (the lock is dropped around the write); false if none is waiting
+bool CompressedOutputStream::drainOne(std::unique_lock<std::mutex>& l)
+{
+    Out& o = _out[_outCons];
+    if (o.state != 1) return false;
+    l.unlock();
+    bool bad = false;
+    if (o.bytes) {
+        _os.write(reinterpret_cast<const char*>(o.buf), std::streamsize(o.bytes));
+        bad = _os.fail();
+        if (!bad) _written += o.bytes;
+    }
+    l.lock();
+    o.state = 0;
+    _outCons ^= 1;
+    if (bad && !_err) _err = std::make_exception_ptr(IOException("Write to bitstream failed", Error::ERR_WRITE_FILE));
+    _cv.notify_all();
+    return true;
+}
+
+// hand the slot being filled to the worker (its host-to-device copy starts right away, beside the kernels of the batch
+// in flight), write finished batches to the sink, and wait until the other slot is free
 void CompressedOutputStream::enqueue(bool last)
 {
     if (!_worker.joinable()) _worker = std::thread(&CompressedOutputStream::workerLoop, this);
+    {
+        // the device buffer of this slot was last read by the batch that freed the slot: safe to overwrite
+        knz_ctx* c = deviceContext();
+        Slot& sl = _slot[_fill];
+        if (sl.dInCap < sl.n + 64) {
+            if (sl.dIn) knz_hip_free(c, sl.dIn);
+            sl.dIn = nullptr; sl.dInCap = 0;
+            const size_t want = sl.n + 64;                  // a full batch, except for a stream shorter than one
+            devCheck(c, knz_hip_malloc(c, want, &sl.dIn), "malloc");
+            sl.dInCap = want;
+        }
+        sl.ticket = 0;
+        if (sl.n) devCheck(c, knz_hip_memcpy_h2d_async(c, sl.dIn, sl.buf, sl.n, &sl.ticket), "h2d");
+    }
     {
         std::unique_lock<std::mutex> l(_mu);
         _slot[_fill].last = last;
         _slot[_fill].state = 1;
         _fill ^= 1;
         _cv.notify_all();
-        _cv.wait(l, [&] { return _slot[_fill].state == 0 || _err; });
+        for (;;) {
+            _cv.wait(l, [&] { return _slot[_fill].state == 0 || _err || _out[_outCons].state == 1; });
+            if (!drainOne(l)) break;
+        }
     }
     rethrow();
 }
@@ -846,27 +890,34 @@ void CompressedOutputStream::submit(bool last)
         pro.put(uint64(_pendingByte >> (8 - _pendingBits)), _pendingBits);
     }
     const size_t cap = knz_hip_encode_bound(&p, n) + pro.bytes.size() + 256;
-    if (_dInCap < n + 64) { if (_dIn) knz_hip_free(c, _dIn); devCheck(c, knz_hip_malloc(c, n + 64 + (n >> 2), &_dIn), "malloc"); _dInCap = n + 64 + (n >> 2); }
     if (_dOutCap < cap) { if (_dOut) knz_hip_free(c, _dOut); devCheck(c, knz_hip_malloc(c, cap + (cap >> 2), &_dOut), "malloc"); _dOutCap = cap + (cap >> 2); }
-    if (n) devCheck(c, knz_hip_memcpy_h2d(c, _dIn, sl.buf, n), "h2d");
+    devCheck(c, knz_hip_copy_wait(c, sl.ticket), "h2d");           // queued by enqueue(), normally long complete
+    sl.ticket = 0;
     uint64_t bits = 0;
-    devCheck(c, knz_hip_encode_blocks(c, &p, static_cast<const uint8_t*>(_dIn), n, pro.bytes.empty() ? nullptr : pro.bytes.data(), uint32_t(pro.nbits),
+    devCheck(c, knz_hip_encode_blocks(c, &p, static_cast<const uint8_t*>(sl.dIn), n, pro.bytes.empty() ? nullptr : pro.bytes.data(), uint32_t(pro.nbits),
                                       _blockId, last ? 1 : 0, static_cast<uint8_t*>(_dOut), _dOutCap, &bits), "encode blocks");
     const size_t bytes = size_t((bits + 7) >> 3);
-    if (_hostOutCap < bytes + 8) { g_pinned.put(_hostOut, _hostOutCap); _hostOut = nullptr; _hostOutCap = 0; _hostOut = g_pinned.get(std::max(bytes + 8, cap / 2), &_hostOutCap); }
-    if (bytes) devCheck(c, knz_hip_memcpy_d2h(c, _hostOut, _dOut, bytes), "d2h");
+    // the output buffer the sink is not reading from
+    Out& o = _out[_outProd];
+    {
+        std::unique_lock<std::mutex> l(_mu);
+        _cv.wait(l, [&] { return o.state == 0 || _stop || _err; });
+        if (o.state != 0) return;
+    }
+    if (o.cap < bytes + 8) { g_pinned.put(o.buf, o.cap); o.buf = nullptr; o.cap = 0; o.buf = g_pinned.get(std::max(bytes + 8, cap / 2), &o.cap); }
+    if (bytes) devCheck(c, knz_hip_memcpy_d2h(c, o.buf, _dOut, bytes), "d2h");
     const size_t full = size_t(bits >> 3);
     const uint rem = uint(bits & 7);
-    size_t toWrite = full;
-    if (last && rem) toWrite = full + 1;          // close(): the last byte is zero padded
-    if (toWrite) {
-        _os.write(reinterpret_cast<const char*>(_hostOut), std::streamsize(toWrite));
-        if (_os.fail()) throw IOException("Write to bitstream failed", Error::ERR_WRITE_FILE);
-        _written += toWrite;
-    }
     _pendingBits = last ? 0 : rem;
-    _pendingByte = (rem && !last) ? _hostOut[full] : 0;
+    _pendingByte = (rem && !last) ? o.buf[full] : 0;
     _blockId += int64((n + size_t(_blockSize) - 1) / size_t(_blockSize));
+    {
+        std::lock_guard<std::mutex> l(_mu);
+        o.bytes = (last && rem) ? full + 1 : full;          // close(): the last byte is zero padded
+        o.state = 1;
+        _outProd ^= 1;
+    }
+    _cv.notify_all();
 }
 
 void CompressedOutputStream::close()
@@ -877,8 +928,13 @@ void CompressedOutputStream::close()
         enqueue(true);                      // the last batch (possibly empty) carries the end marker
         {
             std::unique_lock<std::mutex> l(_mu);
-            _cv.wait(l, [&] { return (_slot[0].state == 0 && _slot[1].state == 0) || _err; });
+            for (;;) {
+                _cv.wait(l, [&] { return (_slot[0].state == 0 && _slot[1].state == 0 && _out[0].state == 0 && _out[1].state == 0) || _err || _out[_outCons].state == 1; });
+                if (!drainOne(l)) break;
+            }
+            if (_err) _stop = true;           // releases a worker that waits for an output buffer
         }
+        _cv.notify_all();
         if (_worker.joinable()) _worker.join();
         rethrow();
         _os.flush();
@@ -914,12 +970,16 @@ CompressedInputStream::CompressedInputStream(std::istream& is, int tasks, const 
     _batchFromEnv = false;
     if (e && atoi(e) > 0) { _batchBlocks = atoi(e); _batchFromEnv = true; }
     _compBit = 0; _consumedBits = 0; _plainPos = 0; _gcount = 0; _srcEof = false;
-    _stage = nullptr; _stageCap = 0;
-    for (int i = 0; i < 2; i++) { _ps[i].buf = nullptr; _ps[i].cap = 0; _ps[i].len = 0; _ps[i].endBit = 0; _ps[i].consumedBits = 0; _ps[i].last = false; _ps[i].state = 0; }
+    for (int i = 0; i < 2; i++) {
+        _ps[i].buf = nullptr; _ps[i].cap = 0; _ps[i].len = 0; _ps[i].endBit = 0; _ps[i].consumedBits = 0; _ps[i].last = false; _ps[i].state = 0;
+        _ps[i].dOut = nullptr; _ps[i].dOutCap = 0; _ps[i].ticket = 0;
+        _prep[i].dIn = nullptr; _prep[i].dInCap = 0; _prep[i].stage = nullptr; _prep[i].stageCap = 0; _prep[i].inBytes = 0; _prep[i].startBit = 0;
+        _prep[i].nb = 0; _prep[i].last = false; _prep[i].endBit = 0; _prep[i].consumedBits = 0; _prep[i].ticket = 0; _prep[i].state = 0;
+    }
+    _pprod = _pcons = 0;
     _prod = _cons = 0; _rstop = false; _started = false; _cur = nullptr; _lastTaken = false; _tellBit = 0; _readBits = 0;
     _from = 1; _to = 0x7FFFFFFF; _nextBlockId = 1;
     { _is.clear(); const std::streamoff at = std::streamoff(_is.tellg()); _originBit = (at < 0) ? 0 : 8 * int64(at); _is.clear(); }
-    _dIn = _dOut = nullptr; _dInCap = _dOutCap = 0;
     deviceContext();
 }
 
@@ -936,9 +996,8 @@ CompressedInputStream::~CompressedInputStream()
     stopReader();
     knz_ctx* c = nullptr;
     try { c = deviceContext(); } catch (...) {}
-    if (c) { if (_dIn) knz_hip_free(c, _dIn); if (_dOut) knz_hip_free(c, _dOut); }
-    for (int i = 0; i < 2; i++) g_pinned.put(_ps[i].buf, _ps[i].cap);
-    g_pinned.put(_stage, _stageCap);
+    if (c) for (int i = 0; i < 2; i++) { if (_prep[i].dIn) knz_hip_free(c, _prep[i].dIn); if (_ps[i].dOut) knz_hip_free(c, _ps[i].dOut); }
+    for (int i = 0; i < 2; i++) { g_pinned.put(_ps[i].buf, _ps[i].cap); g_pinned.put(_prep[i].stage, _prep[i].stageCap); }
 }
 
 bool CompressedInputStream::fetch(size_t minBytes)
@@ -992,11 +1051,11 @@ void CompressedInputStream::readHeader()
     _compBit = pos;
 }
 
-// reader thread: the next batch of blocks into `sl` (sl.last: nothing behind it)
-void CompressedInputStream::decodeBatch(PSlot& sl)
+// reader thread: the compressed bytes of the next batch of blocks, on their way to the device (pr.last: nothing behind it)
+void CompressedInputStream::prepareBatch(Prep& pr)
 {
-    sl.len = 0;
-    if (_ended) { sl.last = true; sl.endBit = _originBit + int64(_compBit); sl.consumedBits = _consumedBits; return; }
+    pr.nb = 0; pr.inBytes = 0; pr.ticket = 0;
+    if (_ended) { pr.last = true; pr.endBit = _originBit + int64(_compBit); pr.consumedBits = _consumedBits; return; }
     readHeader();
     // Drop the consumed prefix of the fetched bytes here, once per batch, before any bit cursor of the walk below
     // is taken: the walk keeps positions relative to _comp, so nothing may rebase them while it runs.
@@ -1045,55 +1104,113 @@ void CompressedInputStream::decodeBatch(PSlot& sl)
     }
     if (nb > 0) {
         knz_ctx* c = deviceContext();
-        knz_params p;
-        memset(&p, 0, sizeof(p));
-        p.transform_type = _transformType; p.entropy_type = _entropyType; p.block_size = _blockSize; p.checksum_bits = _checksum; p.jobs = _jobs;
         const size_t firstByte = size_t(_compBit >> 3) & ~size_t(15);
         const size_t lastByte = size_t((pos + 7) >> 3);
         const size_t inBytes = lastByte - firstByte;
-        const size_t outCap = size_t(nb) * size_t(_blockSize) + 64;
-        if (_dInCap < inBytes + 64) { if (_dIn) knz_hip_free(c, _dIn); devCheck(c, knz_hip_malloc(c, inBytes + 64 + (inBytes >> 2), &_dIn), "malloc"); _dInCap = inBytes + 64 + (inBytes >> 2); }
-        if (_dOutCap < outCap) { if (_dOut) knz_hip_free(c, _dOut); devCheck(c, knz_hip_malloc(c, outCap + (outCap >> 2), &_dOut), "malloc"); _dOutCap = outCap + (outCap >> 2); }
+        if (pr.dInCap < inBytes + 64) {
+            if (pr.dIn) knz_hip_free(c, pr.dIn);
+            pr.dIn = nullptr; pr.dInCap = 0;
+            devCheck(c, knz_hip_malloc(c, inBytes + 64 + (inBytes >> 2), &pr.dIn), "malloc");
+            pr.dInCap = inBytes + 64 + (inBytes >> 2);
+        }
         // through page-locked staging: the pageable vector would be bounced by the runtime at a fraction of the PCIe rate
-        if (_stageCap < inBytes) { g_pinned.put(_stage, _stageCap); _stage = nullptr; _stageCap = 0; _stage = g_pinned.get(inBytes, &_stageCap); }
-        memcpy(_stage, &_comp[firstByte], inBytes);
-        devCheck(c, knz_hip_memcpy_h2d(c, _dIn, _stage, inBytes), "h2d");
-        uint64_t outBytes = 0, endBit = 0;
-        int64_t done = 0;
-        const uint64 startBit = _compBit - uint64(firstByte) * 8;
-        devCheck(c, knz_hip_decode_blocks(c, &p, static_cast<const uint8_t*>(_dIn), uint64(inBytes) * 8, startBit, nb,
-                                          static_cast<uint8_t*>(_dOut), outCap, &outBytes, &endBit, &done), "decode blocks");
-        if (sl.cap < size_t(outBytes)) { g_pinned.put(sl.buf, sl.cap); sl.buf = nullptr; sl.cap = 0; sl.buf = g_pinned.get(std::max(size_t(outBytes), outCap), &sl.cap); }
-        sl.len = size_t(outBytes);
-        if (outBytes) devCheck(c, knz_hip_memcpy_d2h(c, sl.buf, _dOut, size_t(outBytes)), "d2h");
+        if (pr.stageCap < inBytes) { g_pinned.put(pr.stage, pr.stageCap); pr.stage = nullptr; pr.stageCap = 0; pr.stage = g_pinned.get(inBytes, &pr.stageCap); }
+        memcpy(pr.stage, &_comp[firstByte], inBytes);
+        devCheck(c, knz_hip_memcpy_h2d_async(c, pr.dIn, pr.stage, inBytes, &pr.ticket), "h2d");
+        pr.inBytes = inBytes;
+        pr.startBit = _compBit - uint64(firstByte) * 8;
+        pr.nb = nb;
     }
     _consumedBits += pos - _compBit;
     _compBit = pos;
     if (sawEnd) _ended = true;
-    sl.endBit = _originBit + int64(_compBit);
-    sl.consumedBits = _consumedBits;
-    sl.last = sawEnd || nb == 0;
+    pr.endBit = _originBit + int64(_compBit);
+    pr.consumedBits = _consumedBits;
+    pr.last = sawEnd || nb == 0;
 }
+
+// decoder thread: the kernels over a prepared batch; the plain bytes start their way back into `sl`
+void CompressedInputStream::decodeBatch(Prep& pr, PSlot& sl)
+{
+    sl.len = 0; sl.ticket = 0;
+    sl.endBit = pr.endBit; sl.consumedBits = pr.consumedBits; sl.last = pr.last;
+    if (pr.nb == 0) return;
+    knz_ctx* c = deviceContext();
+    knz_params p;
+    memset(&p, 0, sizeof(p));
+    p.transform_type = _transformType; p.entropy_type = _entropyType; p.block_size = _blockSize; p.checksum_bits = _checksum; p.jobs = _jobs;
+    const size_t outCap = size_t(pr.nb) * size_t(_blockSize) + 64;
+    // the slot is free, so the copy out of its device buffer (two batches ago) has been waited for
+    if (sl.dOutCap < outCap) {
+        if (sl.dOut) knz_hip_free(c, sl.dOut);
+        sl.dOut = nullptr; sl.dOutCap = 0;
+        devCheck(c, knz_hip_malloc(c, outCap, &sl.dOut), "malloc");
+        sl.dOutCap = outCap;
+    }
+    devCheck(c, knz_hip_copy_wait(c, pr.ticket), "h2d");
+    pr.ticket = 0;
+    uint64_t outBytes = 0, endBit = 0;
+    int64_t done = 0;
+    devCheck(c, knz_hip_decode_blocks(c, &p, static_cast<const uint8_t*>(pr.dIn), uint64(pr.inBytes) * 8, pr.startBit, pr.nb,
+                                      static_cast<uint8_t*>(sl.dOut), outCap, &outBytes, &endBit, &done), "decode blocks");
+    if (sl.cap < size_t(outBytes)) { g_pinned.put(sl.buf, sl.cap); sl.buf = nullptr; sl.cap = 0; sl.buf = g_pinned.get(std::max(size_t(outBytes), outCap), &sl.cap); }
+    sl.len = size_t(outBytes);
+    if (outBytes) devCheck(c, knz_hip_memcpy_d2h_async(c, sl.buf, sl.dOut, size_t(outBytes), &sl.ticket), "d2h");
+}
+
 
 void CompressedInputStream::readerLoop()
 {
     for (;;) {
         {
             std::unique_lock<std::mutex> l(_rmu);
-            _rcv.wait(l, [&] { return _rstop || _ps[_prod].state == 0; });
+            _rcv.wait(l, [&] { return _rstop || _prep[_pprod].state == 0; });
             if (_rstop) return;
         }
-        PSlot& sl = _ps[_prod];
-        sl.err = nullptr; sl.last = false; sl.len = 0;
+        Prep& pr = _prep[_pprod];
+        pr.err = nullptr; pr.last = false;
         try {
-            decodeBatch(sl);
+            prepareBatch(pr);
         } catch (...) {
-            sl.err = std::current_exception();
-            sl.last = true;
+            pr.err = std::current_exception();
+            pr.last = true; pr.nb = 0;
+        }
+        const bool last = pr.last;
+        {
+            std::lock_guard<std::mutex> l(_rmu);
+            pr.state = 1;
+            _pprod ^= 1;
+        }
+        _rcv.notify_all();
+        if (last) return;
+    }
+}
+
+void CompressedInputStream::decoderLoop()
+{
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> l(_rmu);
+            _rcv.wait(l, [&] { return _rstop || (_prep[_pcons].state == 1 && _ps[_prod].state == 0); });
+            if (_rstop) return;
+        }
+        Prep& pr = _prep[_pcons];
+        PSlot& sl = _ps[_prod];
+        sl.err = nullptr; sl.last = false; sl.len = 0; sl.ticket = 0;
+        if (pr.err) { sl.err = pr.err; pr.err = nullptr; sl.last = true; }
+        else {
+            try {
+                decodeBatch(pr, sl);
+            } catch (...) {
+                sl.err = std::current_exception();
+                sl.last = true; sl.len = 0;
+            }
         }
         const bool last = sl.last;
         {
             std::lock_guard<std::mutex> l(_rmu);
+            pr.state = 0;
+            _pcons ^= 1;
             sl.state = 2;
             _prod ^= 1;
         }
@@ -1112,15 +1229,21 @@ void CompressedInputStream::ensureStarted()
     _rstop = false;
     _started = true;
     _reader = std::thread(&CompressedInputStream::readerLoop, this);
+    _decoder = std::thread(&CompressedInputStream::decoderLoop, this);
 }
 
 void CompressedInputStream::stopReader()
 {
-    if (_reader.joinable()) {
+    if (_reader.joinable() || _decoder.joinable()) {
         { std::lock_guard<std::mutex> l(_rmu); _rstop = true; }
         _rcv.notify_all();
-        _reader.join();
+        if (_reader.joinable()) _reader.join();
+        if (_decoder.joinable()) _decoder.join();
     }
+    // copies still on their way belong to batches nobody will look at: let them land before the buffers are reused or freed
+    knz_ctx* c = nullptr;
+    try { c = deviceContext(); } catch (...) {}
+    if (c) for (int i = 0; i < 2; i++) { knz_hip_copy_wait(c, _prep[i].ticket); _prep[i].ticket = 0; knz_hip_copy_wait(c, _ps[i].ticket); _ps[i].ticket = 0; }
     _started = false;
 }
 
@@ -1153,6 +1276,15 @@ bool CompressedInputStream::advance()
         }
         _tellBit = sl->endBit;
         _readBits = sl->consumedBits;
+        if (sl->len != 0 && sl->ticket != 0) {               // the device-to-host copy the decoder thread queued
+            const int rc = knz_hip_copy_wait(deviceContext(), sl->ticket);
+            sl->ticket = 0;
+            if (rc != 0) {
+                { std::lock_guard<std::mutex> l(_rmu); sl->state = 0; }
+                _rcv.notify_all();
+                throw IOException("device to host copy failed", Error::ERR_READ_FILE);
+            }
+        }
         if (sl->len == 0) {
             { std::lock_guard<std::mutex> l(_rmu); sl->state = 0; }
             _rcv.notify_all();
@@ -1214,8 +1346,11 @@ bool CompressedInputStream::seek(int64 bitPos)
     if (_is.fail()) return false;
     // forget everything fetched or decoded; the stream parameters (header) stay
     _comp.clear();
-    for (int i = 0; i < 2; i++) { _ps[i].state = 0; _ps[i].len = 0; _ps[i].err = nullptr; _ps[i].last = false; }
-    _prod = _cons = 0; _cur = nullptr; _lastTaken = false;
+    for (int i = 0; i < 2; i++) {
+        _ps[i].state = 0; _ps[i].len = 0; _ps[i].err = nullptr; _ps[i].last = false;
+        _prep[i].state = 0; _prep[i].nb = 0; _prep[i].err = nullptr; _prep[i].last = false;
+    }
+    _prod = _cons = 0; _pprod = _pcons = 0; _cur = nullptr; _lastTaken = false;
     _plainPos = 0;
     _gcount = 0;
     _srcEof = false; _ended = false;

@@ -38,7 +38,7 @@ def lib():
         L.getCompressorVersion.restype = C.c_uint
         L.getDecompressorVersion.restype = C.c_uint
         L.initCompressor.argtypes = [C.POINTER(cData), C.c_void_p, C.POINTER(C.c_void_p)]
-        L.compress.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.compress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.disposeCompressor.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.initDecompressor.argtypes = [C.POINTER(dData), C.c_void_p, C.POINTER(C.c_void_p)]
         L.decompress.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
@@ -49,6 +49,24 @@ def lib():
         _libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
         _libc.fclose.argtypes = [C.c_void_p]
     return _lib
+
+
+class _PyBuffer(C.Structure):
+    """Py_buffer (CPython's object.h): lets compress() hand the caller's own memory to the library, whatever
+    bytes-like object it lives in (bytes, bytearray, memoryview, numpy array; read-only included), without a copy."""
+    _fields_ = [("buf", C.c_void_p), ("obj", C.py_object), ("len", C.c_ssize_t), ("itemsize", C.c_ssize_t), ("readonly", C.c_int),
+                ("ndim", C.c_int), ("format", C.c_char_p), ("shape", C.POINTER(C.c_ssize_t)), ("strides", C.POINTER(C.c_ssize_t)),
+                ("suboffsets", C.POINTER(C.c_ssize_t)), ("internal", C.c_void_p)]
+
+
+C.pythonapi.PyObject_GetBuffer.argtypes = [C.py_object, C.POINTER(_PyBuffer), C.c_int]
+C.pythonapi.PyObject_GetBuffer.restype = C.c_int
+C.pythonapi.PyBuffer_Release.argtypes = [C.POINTER(_PyBuffer)]
+C.pythonapi.PyBuffer_Release.restype = None
+C.pythonapi.PyBytes_FromStringAndSize.argtypes = [C.c_char_p, C.c_ssize_t]
+C.pythonapi.PyBytes_FromStringAndSize.restype = C.py_object
+C.pythonapi.PyBytes_AsString.argtypes = [C.py_object]
+C.pythonapi.PyBytes_AsString.restype = C.c_void_p
 
 
 class KanziError(RuntimeError):
@@ -92,7 +110,13 @@ class Compressor:
 
     def compress(self, data):
         out = C.c_size_t(0)
-        rc = lib().compress(self._ctx, bytes(data), len(data), C.byref(out))
+        view = _PyBuffer()
+        if C.pythonapi.PyObject_GetBuffer(data, C.byref(view), 0) != 0:     # PyBUF_SIMPLE: contiguous bytes
+            raise TypeError("compress() needs a contiguous bytes-like object")
+        try:
+            rc = lib().compress(self._ctx, view.buf, view.len, C.byref(out))
+        finally:
+            C.pythonapi.PyBuffer_Release(C.byref(view))
         if rc != 0:
             raise KanziError(rc, "compress")
         self.written += out.value
@@ -147,14 +171,14 @@ class Decompressor:
         return self.decompress(max_output)
 
     def decompress(self, n):
-        if getattr(self, "_buf", None) is None or len(self._buf) < max(1, n):
-            self._buf = C.create_string_buffer(max(1, n))      # kept across calls: no zero fill per block
-        buf = self._buf
+        # the library writes straight into the bytes object handed back (no zero fill, no second copy); only a
+        # short last block is cut to size
+        res = C.pythonapi.PyBytes_FromStringAndSize(None, max(1, n))
         ins, outs = C.c_size_t(0), C.c_size_t(n)
-        rc = lib().decompress(self._ctx, buf, C.byref(ins), C.byref(outs))
+        rc = lib().decompress(self._ctx, C.pythonapi.PyBytes_AsString(res), C.byref(ins), C.byref(outs))
         if rc != 0:
             raise KanziError(rc, "decompress")
-        return C.string_at(buf, outs.value)
+        return res if outs.value == len(res) else res[:outs.value]
 
     def close(self):
         if self._ctx:
