@@ -487,7 +487,8 @@ __global__ __launch_bounds__(64) void k_huff_scan(BitSrc src, DecBlock* __restri
     for (int i = lane; i < maxChunks; i += 64) cs[i].kind = 3;
     if (db.error) return;
     __shared__ u32 win[256 + 8];
-    __shared__ u8 codeSize[256];
+    __shared__ u32 codeSizeW[64];                      // 256 code lengths, written four at a time
+    u8* codeSize = reinterpret_cast<u8*>(codeSizeW);
     const u64 limit = db.payloadBit + ((db.bits + 7) & ~7ull);
     u64 pos = db.entropyBit;
     const u64 entropyBit = pos;
@@ -527,6 +528,25 @@ __global__ __launch_bounds__(64) void k_huff_scan(BitSrc src, DecBlock* __restri
         __syncthreads();
         winValid = true;
     };
+    // Signed Exp-Golomb code of a length delta (ExpGolombDecoder.hpp:52-75) by its first 8 bits, for codes that start with a 0
+    // (a leading 1 is the one-bit code of delta 0): bits 6-9 = code length (0: no valid code starts like this), bits 0-4 =
+    // delta + 16. A valid delta has |d| <= 11, i.e. a code of at most 8 bits (a prefix of more than 3 zeros can only decode to an
+    // out-of-range length). 128 entries of 16 bits: lane l holds entries 2l and 2l + 1.
+    u32 egTab = 0;
+    for (u32 j = 0; j < 2; j++) {
+        const u32 v = 2u * (u32)lane + j;                                    // 0xxxxxxx
+        const u32 lg = 1u + (u32)__clz((int)(v << 25));                      // zeros behind the leading 0, plus one
+        u32 e = 0;
+        if ((v << 25) != 0 && lg <= 3) {
+            const u32 total = 2 * lg + 2;
+            int res = (int)((v >> (8 - total)) & ((1u << (lg + 1)) - 1u));
+            const int sgn = res & 1;
+            res = (res >> 1) + (1 << lg) - 1;
+            const int delta = (int)(int8_t)(u8)((res - sgn) ^ -sgn);
+            e = (total << 6) | (u32)(delta + 16);
+        }
+        egTab |= e << (16 * j);
+    }
     const u32 nChunks = (preLen + ENT_CHUNK - 1) / ENT_CHUNK;
     u64 prevPos = pos;
     int err = 0;
@@ -574,38 +594,43 @@ __global__ __launch_bounds__(64) void k_huff_scan(BitSrc src, DecBlock* __restri
         // A valid delta has |d| <= 11, i.e. a code of at most 8 bits (prefix of <= 3 zeros); a longer prefix can only
         // decode to an out-of-range length, so it is rejected right away.  Codes are parsed from a 64-bit register
         // window that is reloaded from LDS only when fewer than 8 bits are left.
-        int curSize = 2;
+        u32 curSize = 2;
         u32 q = (u32)__builtin_amdgcn_readfirstlane((int)p);                 // keep the whole chain on the scalar unit
-        u64 buf = 0;
-        u32 avail = 0;
-        for (u32 k = 0; k < asz; k++) {
-            if (avail < 8) {
-                if (q > HSCAN_WIN_BITS - 96) { err = 1; break; }             // longer than any valid header
-                const u32 i = q >> 5;
-                const u32 wh = (u32)__builtin_amdgcn_readfirstlane((int)win[i]);
-                const u32 wl = (u32)__builtin_amdgcn_readfirstlane((int)win[i + 1]);
-                buf = (((u64)wh << 32) | (u64)wl) << (q & 31);
-                avail = 64 - (q & 31);
-            }
-            int delta = 0;
-            u32 total = 1;
-            if ((buf >> 63) == 0) {
-                const u32 rest = (u32)(buf >> 31);                           // the 32 bits after the leading 0
-                const u32 lg = 1u + (u32)__clz((int)rest);
-                if (rest == 0 || lg > 3) { err = 1; break; }
-                total = 2 * lg + 2;
-                int res = (int)((buf >> (64 - total)) & ((1u << (lg + 1)) - 1u));
-                const int sgn = res & 1;
-                res = (res >> 1) + (1 << lg) - 1;
-                delta = (int)(int8_t)(u8)((res - sgn) ^ -sgn);
-            }
-            curSize = (int)(int8_t)(curSize + delta);
-            if (curSize <= 0 || curSize > HUF_MAX_LEN) { err = 1; break; }
-            codeSize[k] = (u8)curSize;                                       // every lane stores the same value
+        u32 bad = 0;
+        // one code: the next 8 bits decide everything -- one read from the table the wave holds in a register
+        auto one = [&](u64& buf) -> u32 {
+            const u32 top = (u32)(buf >> 56);
+            const u32 w = (u32)__builtin_amdgcn_readlane((int)egTab, (int)((top >> 1) & 63u));
+            const u32 e = (top & 0x80u) ? ((1u << 6) | 16u) : ((w >> (16 * (top & 1))) & 0xFFFFu);
+            const u32 total = e >> 6;                                        // 0 for an invalid prefix: flagged below
+            curSize = (curSize + (e & 31u) - 16u) & 0xFFu;                   // int8 arithmetic of the reference
+            bad |= (total == 0 || curSize - 1u > (u32)HUF_MAX_LEN - 1u) ? 1u : 0u;
             buf <<= total;
-            avail -= total;
             q += total;
+            return curSize;
+        };
+        auto window = [&]() -> u64 {
+            const u32 i = (q >> 5) < 254u ? (q >> 5) : 254u;                 // past any valid header: flagged by the caller
+            const u32 wh = (u32)__builtin_amdgcn_readfirstlane((int)win[i]);
+            const u32 wl = (u32)__builtin_amdgcn_readfirstlane((int)win[i + 1]);
+            return (((u64)wh << 32) | (u64)wl) << (q & 31);
+        };
+        u32 k = 0;
+        for (; k + 4 <= asz; k += 4) {                                       // 4 codes (<= 32 bits) per window read
+            if (q > HSCAN_WIN_BITS - 96) { bad = 1; break; }                 // longer than any valid header
+            u64 buf = window();
+            u32 pk = one(buf);
+            pk |= one(buf) << 8;
+            pk |= one(buf) << 16;
+            pk |= one(buf) << 24;
+            codeSizeW[k >> 2] = pk;                      // every lane stores the same value
         }
+        for (; k < asz && !bad; k++) {
+            if (q > HSCAN_WIN_BITS - 96) { bad = 1; break; }
+            u64 buf = window();
+            codeSize[k] = (u8)one(buf);
+        }
+        if (bad) err = 1;
         if (err) break;
         __syncthreads();
         {
