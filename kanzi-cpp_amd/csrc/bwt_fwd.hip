@@ -755,22 +755,38 @@ __global__ __launch_bounds__(256) void k_bwt_f_large_place(FwdView v, const uint
 //   hi = (a < c) ? R : 2^(kbits+1) - 1 - R,   lo = ISA[p + R] (rank of the suffix behind the run, 0 at the block end)
 // replaces the log2(R / nsym) doubling rounds such a group would otherwise take; members that still tie share R + nsym symbols.
 
-// run-end flags in position order: bit set where the next byte differs or the block ends
-__global__ __launch_bounds__(256) void k_bwt_f_run_ends(BwtView bv, FwdView v, unsigned long long* __restrict__ ebits64)
+// run-end flags in position order: bit set where the next byte differs or the block ends (and for everything past the end);
+// a thread makes the flag byte of 8 positions, a workgroup the 2048 positions of one window
+__global__ __launch_bounds__(256) void k_bwt_f_run_ends(BwtView bv, FwdView v, u8* __restrict__ ebits8)
 {
-    const u32 gp = blockIdx.x * 256 + threadIdx.x;
-    bool f = true;
-    // one search per wave (uniform), then a short walk for the lanes behind a block border
-    const u32 gp0 = gp & ~63u;
-    int b = find_block(v.base, v.nBlocks, gp0 < v.total ? gp0 : v.total - 1);
-    if (gp < v.total) {
-        while (gp >= v.base[b + 1]) b++;
-        const u32 off = gp - v.base[b], n = v.base[b + 1] - v.base[b];
+    __shared__ int sBlk;
+    const u32 pos0 = blockIdx.x * SM_WIN;
+    if (threadIdx.x == 0) sBlk = find_block(v.base, v.nBlocks, pos0 < v.total ? pos0 : v.total - 1);
+    __syncthreads();
+    const u32 g0 = pos0 + 8u * threadIdx.x;
+    u32 flags = 0xFF;
+    if (g0 < v.total) {
+        int b = sBlk;
+        while (g0 >= v.base[b + 1]) b++;
+        u32 bb = v.base[b], be = v.base[b + 1];
         const u8* t = bv.src[b];
-        f = (off + 1 >= n) || (t[off] != t[off + 1]);
+        u32 cur = t[g0 - bb];
+        flags = 0;
+#pragma unroll
+        for (u32 k = 0; k < 8; k++) {
+            const u32 gp = g0 + k;
+            if (gp >= v.total) { flags |= 1u << k; continue; }
+            if (gp + 1 >= be) {                               // last byte of a block: the run ends here
+                flags |= 1u << k;
+                if (gp + 1 < v.total) { b++; while (v.base[b + 1] <= gp + 1) b++; bb = be; be = v.base[b + 1]; t = bv.src[b]; cur = t[0]; }   // (blocks the BWT skips are empty here)
+                continue;
+            }
+            const u32 nxt = t[gp + 1 - bb];
+            flags |= (cur != nxt ? 1u : 0u) << k;
+            cur = nxt;
+        }
     }
-    const unsigned long long m = __ballot(f);
-    if ((threadIdx.x & 63) == 0) ebits64[gp >> 6] = m;
+    ebits8[g0 >> 3] = (u8)flags;
 }
 
 // R[gp] = distance to the end of the run that holds gp (1 = the run ends here); one workgroup per window of 2048 positions
@@ -1019,7 +1035,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     }
     if (nRun) {
         // run lengths of every position (text order), then one sort of the run groups' members on (run length, what follows)
-        { KScope ks_("k_bwt_f_run_ends"); hipLaunchKernelGGL(k_bwt_f_run_ends, dim3((total + 255) / 256), dim3(256), 0, s, bv, v, reinterpret_cast<unsigned long long*>(w.ebits)); }
+        { KScope ks_("k_bwt_f_run_ends"); hipLaunchKernelGGL(k_bwt_f_run_ends, dim3((total + SM_WIN - 1) / SM_WIN), dim3(256), 0, s, bv, v, reinterpret_cast<u8*>(w.ebits)); }
         { KScope ks_("k_bwt_f_r0_winsum"); hipLaunchKernelGGL(k_bwt_f_r0_winsum, GRID1(nWin), w.ebits, total, nWin, w.t0, w.t2); }
         pb = w.primBytes;
         { KScope ks_("bwt_f_scan_min"); if (rocprim::inclusive_scan(w.prim, pb, w.t2, w.t3, (size_t)nWin, rocprim::minimum<u32>(), s) != hipSuccess) return -1; }

@@ -28,6 +28,8 @@ for s in "$@"; do
     pmc3) for c in FETCH_SIZE WRITE_SIZE; do (cd /tmp && timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc3_$c -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu --no-e2e > $GRAFT_REPO_ROOT/$OUT/pmc3_$c.log 2>&1); echo "pmc3 $c rc=$?" >> $OUT/summary.txt; done
           ff=$(find $OUT/pmc3_FETCH_SIZE -name '*counter_collection.csv' | head -1); fw=$(find $OUT/pmc3_WRITE_SIZE -name '*counter_collection.csv' | head -1)
           [ -n "$ff" ] && [ -n "$fw" ] && python tools/pmc_stage_summary.py $ff $fw 3 $OUT/pmc3_traffic.json $OUT/pmc3_traffic.txt && cat $OUT/pmc3_traffic.txt | head -40 ;;
+    trace3) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/trace3 -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu --no-e2e > $GRAFT_REPO_ROOT/$OUT/trace3.log 2>&1); echo "trace3 rc=$?" >> $OUT/summary.txt
+           f=$(find $OUT/trace3 -name '*kernel_trace.csv' | head -1); [ -n "$f" ] && python tools/rocprof_trace_list.py $f 1 > $OUT/trace3_bwt_forward.txt && tail -3 $OUT/trace3_bwt_forward.txt ;;
     cmd:*) echo "running custom: ${s#cmd:}"; timeout 600 bash -c "${s#cmd:}" < /dev/null > $OUT/custom.log 2>&1; echo "custom rc=$?" >> $OUT/summary.txt; tail -40 $OUT/custom.log ;;
     *) echo "unknown step: $s" ;;
   esac
