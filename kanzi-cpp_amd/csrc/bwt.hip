@@ -140,21 +140,39 @@ __global__ __launch_bounds__(256) void k_bwt_i_hist(BwtView v, const BwtHdr* __r
     tileHist[((size_t)b * perTiles + blockIdx.x) * 256 + tid] = cnt[tid];
 }
 
-// per block: tileHist[t][sym] := number of sym in the tiles before t; C[b][sym] = number of smaller symbols in the block;
-// term[b] = node of BWT index 0 (first occurrence of its symbol)
-__global__ __launch_bounds__(256) void k_bwt_i_scan(BwtView v, const BwtHdr* __restrict__ hd, const u32* __restrict__ base, int perTiles,
-                                                    u32* __restrict__ tileHist, u32* __restrict__ Cb, u32* __restrict__ term)
+// tileHist[t][sym] := number of sym in the tiles before t, in two levels (no thread walks more than ~sqrt(tiles) tiles): inside
+// segments of segT tiles first (segSum = the segment's totals), then over the segments; C[b][sym] = number of smaller symbols in the
+// block; term[b] = node of BWT index 0 (first occurrence of its symbol). A tile's count is tileHist + segSum of its segment.
+__host__ __device__ inline u32 bwt_i_seg_tiles(u32 perTiles) { u32 g = 1; while (g * g < perTiles) g <<= 1; return g; }
+
+__global__ __launch_bounds__(256) void k_bwt_i_scan(const BwtHdr* __restrict__ hd, int perTiles, u32 segT, u32 nSeg, u32* __restrict__ tileHist,
+                                                    u32* __restrict__ segSum)
+{
+    const int b = blockIdx.y;
+    const u32 seg = blockIdx.x;
+    const BwtHdr h = hd[b];
+    const int tid = (int)threadIdx.x;
+    u32 run = 0;
+    if (h.okFlag && h.n >= 2) {
+        const u32 nT = (h.n + IT - 1) / IT;
+        const u32 t0 = seg * segT;
+        const u32 t1 = (t0 + segT < nT) ? t0 + segT : nT;
+        u32* p = tileHist + (size_t)b * perTiles * 256 + tid;
+        for (u32 t = t0; t < t1; t++) { const u32 x = p[(size_t)t * 256]; p[(size_t)t * 256] = run; run += x; }
+    }
+    segSum[((size_t)b * nSeg + seg) * 256 + tid] = run;
+}
+
+__global__ __launch_bounds__(256) void k_bwt_i_scan2(BwtView v, const BwtHdr* __restrict__ hd, const u32* __restrict__ base, u32 nSeg,
+                                                     u32* __restrict__ segSum, u32* __restrict__ Cb, u32* __restrict__ term)
 {
     const int b = blockIdx.x;
     const BwtHdr h = hd[b];
     const int tid = (int)threadIdx.x;
     __shared__ u32 tot[256];
     u32 run = 0;
-    if (h.okFlag && h.n >= 2) {
-        const u32 nT = (h.n + IT - 1) / IT;
-        u32* p = tileHist + (size_t)b * perTiles * 256 + tid;
-        for (u32 t = 0; t < nT; t++) { const u32 x = p[(size_t)t * 256]; p[(size_t)t * 256] = run; run += x; }
-    }
+    u32* p = segSum + (size_t)b * nSeg * 256 + tid;
+    for (u32 g = 0; g < nSeg; g++) { const u32 x = p[(size_t)g * 256]; p[(size_t)g * 256] = run; run += x; }
     tot[tid] = run;
     __syncthreads();
     if (tid == 0) { u32 acc = 0; for (int c = 0; c < 256; c++) { const u32 x = tot[c]; tot[c] = acc; acc += x; } }
@@ -166,8 +184,8 @@ __global__ __launch_bounds__(256) void k_bwt_i_scan(BwtView v, const BwtHdr* __r
 __device__ __forceinline__ bool is_splitter(u32 node, u32 head, u32 term) { return hash_split(node) || node == head || node == term; }
 
 __global__ __launch_bounds__(256) void k_bwt_i_links(BwtView v, const BwtHdr* __restrict__ hd, const u32* __restrict__ base, int perTiles,
-                                                     const u32* __restrict__ tileHist, const u32* __restrict__ Cb, const u32* __restrict__ term,
-                                                     u64* __restrict__ rec)
+                                                     const u32* __restrict__ tileHist, u32 segT, u32 nSeg, const u32* __restrict__ segSum,
+                                                     const u32* __restrict__ Cb, const u32* __restrict__ term, u64* __restrict__ rec)
 {
     const int b = blockIdx.y;
     const BwtHdr h = hd[b];
@@ -179,7 +197,8 @@ __global__ __launch_bounds__(256) void k_bwt_i_links(BwtView v, const BwtHdr* __
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     for (int w = 0; w < 4; w++) cntw[w][tid] = 0;
-    start[tid] = base[b] + Cb[b * 256 + tid] + tileHist[((size_t)b * perTiles + blockIdx.x) * 256 + tid];
+    start[tid] = base[b] + Cb[b * 256 + tid] + segSum[((size_t)b * nSeg + blockIdx.x / segT) * 256 + tid]
+                 + tileHist[((size_t)b * perTiles + blockIdx.x) * 256 + tid];
     __syncthreads();
     const u8* s = v.src[b] + h.hdr;
     u32 sym[16], pre[16];
@@ -218,19 +237,49 @@ __global__ __launch_bounds__(256) void k_bwt_i_links(BwtView v, const BwtHdr* __
     }
 }
 
-// splitter flags from the node number alone
+// splitter flags from the node number alone, as a bit map: a thread makes the word of 32 nodes and its population count
 __global__ __launch_bounds__(256) void k_bwt_i_flags(const BwtHdr* __restrict__ hd, const u32* __restrict__ base, const u32* __restrict__ term, int nBlocks,
-                                                     u32 total, u32* __restrict__ flags)
+                                                     u32 total, u32* __restrict__ bits, u32* __restrict__ wcount)
 {
-    const u32 j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= total) return;
-    const int b = find_block(base, nBlocks, j);
-    flags[j] = is_splitter(j, base[b] + hd[b].pIdx - 1, term[b]) ? 1u : 0u;
+    const u32 w = blockIdx.x * 256 + threadIdx.x;
+    const u32 j0 = 32u * w;
+    if (j0 >= total) return;
+    int b = find_block(base, nBlocks, j0);
+    u32 be = base[b + 1], head = base[b] + hd[b].pIdx - 1, tm = term[b];
+    u32 word = 0;
+    for (u32 k = 0; k < 32; k++) {
+        const u32 j = j0 + k;
+        if (j >= total) break;
+        if (j >= be) { do { b++; } while (j >= base[b + 1]); be = base[b + 1]; head = base[b] + hd[b].pIdx - 1; tm = term[b]; }
+        word |= (is_splitter(j, head, tm) ? 1u : 0u) << k;
+    }
+    bits[w] = word;
+    wcount[w] = (u32)__popc(word);
+}
+
+// the set bits of every word, in order: splitNode[rank] = node
+__global__ __launch_bounds__(256) void k_bwt_i_compact(const u32* __restrict__ bits, const u32* __restrict__ wprefix, u32 nWords, u32* __restrict__ splitNode)
+{
+    const u32 w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= nWords) return;
+    u32 word = bits[w];
+    u32 at = wprefix[w];
+    while (word) {
+        const u32 k = (u32)__ffs((int)word) - 1;
+        splitNode[at++] = 32u * w + k;
+        word &= word - 1;
+    }
+}
+
+// rank of a splitter node among the splitters
+__device__ __forceinline__ u32 split_rank(const u32* __restrict__ bits, const u32* __restrict__ wprefix, u32 node)
+{
+    return wprefix[node >> 5] + (u32)__popc(bits[node >> 5] & ((1u << (node & 31)) - 1u));
 }
 
 // walk 1: sub-list length and successor splitter (compact indices)
-__global__ __launch_bounds__(256) void k_bwt_i_walk1(const u64* __restrict__ rec, const u32* __restrict__ splitNode, const u32* __restrict__ scanIdx,
-                                                     u32 count, u32 limit, u32* __restrict__ succ, u32* __restrict__ dist)
+__global__ __launch_bounds__(256) void k_bwt_i_walk1(const u64* __restrict__ rec, const u32* __restrict__ splitNode, const u32* __restrict__ bits,
+                                                     const u32* __restrict__ wprefix, u32 count, u32 limit, u32* __restrict__ succ, u32* __restrict__ dist)
 {
     const u32 c = blockIdx.x * 256 + threadIdx.x;
     if (c >= count) return;
@@ -241,7 +290,7 @@ __global__ __launch_bounds__(256) void k_bwt_i_walk1(const u64* __restrict__ rec
     while (true) {
         len++;
         const u32 nx = (u32)r & 0x7FFFFFFFu;
-        if ((r >> 31) & 1) { succ[c] = scanIdx[nx]; break; }
+        if ((r >> 31) & 1) { succ[c] = split_rank(bits, wprefix, nx); break; }
         if (len > limit) { succ[c] = c; break; }              // malformed input (cycle without splitter)
         node = nx;
         r = rec[node];
@@ -307,7 +356,8 @@ size_t bwt_inverse_scratch_bytes(int nBlocks, u32 VS, size_t total)
     rocprim::exclusive_scan(nullptr, primScan, (u32*)nullptr, (u32*)nullptr, 0u, total, rocprim::plus<u32>(), (hipStream_t)0);
     const size_t prim = primSort > primScan ? primSort : primScan;
     const size_t perTiles = ((size_t)VS + IT - 1) / IT;
-    return align256(1024 * perTiles * (size_t)nBlocks) + align256(1024 * (size_t)nBlocks) + align256(8 * total) + 2 * align256(4 * total) + 6 * align256(4 * (total / 8 + 4096 + 3 * (size_t)nBlocks)) +
+    const u32 segT = bwt_i_seg_tiles((u32)perTiles);
+    return align256(1024 * perTiles * (size_t)nBlocks) + align256(1024 * ((perTiles + segT - 1) / segT) * (size_t)nBlocks) + align256(1024 * (size_t)nBlocks) + align256(8 * total) + align256(8 * (total / 32 + 2)) + align256(4 * (total / 32 + 2)) + 6 * align256(4 * (total / 8 + 4096 + 3 * (size_t)nBlocks)) +
            align256(sizeof(BwtHdr) * (size_t)nBlocks) + align256(4ull * (nBlocks + 2)) + align256(prim) + 16384;
 }
 
@@ -321,10 +371,12 @@ int launch_bwt_inverse(hipStream_t s, const XfStage& st, void* scratch, size_t s
     auto take = [&](size_t sz) { u8* r = q; q += align256(sz); return r; };
     const int perTiles = (int)((v.VS + IT - 1) / IT);
     u32* tileHist = (u32*)take(4ull * 256 * (size_t)perTiles * st.nBlocks);
+    const u32 segT = bwt_i_seg_tiles((u32)perTiles), nSeg = ((u32)perTiles + segT - 1) / segT;
+    u32* segSum = (u32*)take(4ull * 256 * (size_t)nSeg * st.nBlocks);
     u32* Cb = (u32*)take(4ull * 256 * st.nBlocks);
     u32* term = (u32*)take(4ull * (st.nBlocks + 1));
     u64* rec = (u64*)take(8 * maxTotal);
-    u32* flags = (u32*)take(4 * maxTotal); u32* scanIdx = (u32*)take(4 * maxTotal);
+    u32* flags = (u32*)take(8 * (maxTotal / 32 + 2)); u32* scanIdx = (u32*)take(4 * (maxTotal / 32 + 2));   // splitter bit map + word counts, word prefix
     u32* splitNode = (u32*)take(4 * maxSplit);
     u32* nA = (u32*)take(4 * maxSplit); u32* nB = (u32*)take(4 * maxSplit);
     u32* dA = (u32*)take(4 * maxSplit); u32* dB = (u32*)take(4 * maxSplit);
@@ -341,20 +393,23 @@ int launch_bwt_inverse(hipStream_t s, const XfStage& st, void* scratch, size_t s
     if (total == 0) return 0;
     const dim3 gridT((unsigned)perTiles, st.nBlocks);
     { KScope ks_("k_bwt_i_hist"); hipLaunchKernelGGL(k_bwt_i_hist, gridT, dim3(256), 0, s, v, hd, perTiles, tileHist); }
-    { KScope ks_("k_bwt_i_scan"); hipLaunchKernelGGL(k_bwt_i_scan, dim3(st.nBlocks), dim3(256), 0, s, v, hd, base, perTiles, tileHist, Cb, term); }
-    { KScope ks_("k_bwt_i_links"); hipLaunchKernelGGL(k_bwt_i_links, gridT, dim3(256), 0, s, v, hd, base, perTiles, tileHist, Cb, term, rec); }
-    { KScope ks_("k_bwt_i_flags"); hipLaunchKernelGGL(k_bwt_i_flags, GRID1(total), hd, base, term, st.nBlocks, total, flags); }
+    { KScope ks_("k_bwt_i_scan"); hipLaunchKernelGGL(k_bwt_i_scan, dim3(nSeg, st.nBlocks), dim3(256), 0, s, hd, perTiles, segT, nSeg, tileHist, segSum);
+      hipLaunchKernelGGL(k_bwt_i_scan2, dim3(st.nBlocks), dim3(256), 0, s, v, hd, base, nSeg, segSum, Cb, term); }
+    { KScope ks_("k_bwt_i_links"); hipLaunchKernelGGL(k_bwt_i_links, gridT, dim3(256), 0, s, v, hd, base, perTiles, tileHist, segT, nSeg, segSum, Cb, term, rec); }
+    const u32 nWords = (total + 31) / 32;
+    u32* bits = flags; u32* wcount = flags + nWords; u32* wprefix = scanIdx;           // (the two node-sized arrays of the first version)
+    { KScope ks_("k_bwt_i_flags"); hipLaunchKernelGGL(k_bwt_i_flags, GRID1(nWords), hd, base, term, st.nBlocks, total, bits, wcount); }
     size_t pb;
     pb = primBytes;
-    { KScope ks_("bwt_i_scan_sum"); if (rocprim::exclusive_scan(prim, pb, flags, scanIdx, 0u, (size_t)total, rocprim::plus<u32>(), s) != hipSuccess) return -1; }
-    { KScope ks_("k_bwt_i_compact"); hipLaunchKernelGGL(k_compact, GRID1(total), flags, scanIdx, (const u32*)nullptr, total, splitNode); }
-    hipMemcpyAsync(h_pinned, scanIdx + (total - 1), 4, hipMemcpyDeviceToHost, s);
-    hipMemcpyAsync(h_pinned + 1, flags + (total - 1), 4, hipMemcpyDeviceToHost, s);
+    { KScope ks_("bwt_i_scan_sum"); if (rocprim::exclusive_scan(prim, pb, wcount, wprefix, 0u, (size_t)nWords, rocprim::plus<u32>(), s) != hipSuccess) return -1; }
+    { KScope ks_("k_bwt_i_compact"); hipLaunchKernelGGL(k_bwt_i_compact, GRID1(nWords), bits, wprefix, nWords, splitNode); }
+    hipMemcpyAsync(h_pinned, wprefix + (nWords - 1), 4, hipMemcpyDeviceToHost, s);
+    hipMemcpyAsync(h_pinned + 1, wcount + (nWords - 1), 4, hipMemcpyDeviceToHost, s);
     if (hipStreamSynchronize(s) != hipSuccess) return -1;
     const u32 count = h_pinned[0] + h_pinned[1];
     if (count == 0 || count > maxSplit) return -3;
     const u32 limit = v.VS + 1;
-    { KScope ks_("k_bwt_i_walk1"); hipLaunchKernelGGL(k_bwt_i_walk1, GRID1(count), rec, splitNode, scanIdx, count, limit, nA, dA); }
+    { KScope ks_("k_bwt_i_walk1"); hipLaunchKernelGGL(k_bwt_i_walk1, GRID1(count), rec, splitNode, bits, wprefix, count, limit, nA, dA); }
     for (u32 span = 1; span < count; span <<= 1) {
         { KScope ks_("k_bwt_i_jump"); hipLaunchKernelGGL(k_bwt_i_jump, GRID1(count), nA, dA, count, nB, dB); }
         std::swap(nA, nB); std::swap(dA, dB);

@@ -62,21 +62,42 @@ __global__ __launch_bounds__(64) void k_mtf_f_last(XfView v, int perTiles, u32* 
     for (int i = lane; i < 256; i += 64) o[i] = last[i];
 }
 
-// exclusive prefix max over the tiles of a block, one thread per symbol (loads are independent of the carry)
-__global__ __launch_bounds__(256) void k_mtf_f_scan(u32* __restrict__ tileLast, int perTiles, const u32* __restrict__ lens)
+// Exclusive prefix max over the tiles of a block, per symbol, in two levels so that no thread walks more than ~sqrt(tiles) of
+// them: tiles are grouped in segments of segT; level 1 scans inside a segment (from 0) and leaves the segment's maximum in segMax,
+// level 2 scans the segment maxima; the consumer (k_mtf_f_rank) takes the maximum of both.
+__host__ __device__ inline u32 mtf_seg_tiles(u32 perTiles) { u32 g = 1; while (g * g < perTiles) g <<= 1; return g; }
+
+__global__ __launch_bounds__(256) void k_mtf_f_scan(u32* __restrict__ tileLast, int perTiles, u32 segT, u32 nSeg, const u32* __restrict__ lens,
+                                                    u32* __restrict__ segMax)
 {
-    const int b = blockIdx.x;
+    const int b = blockIdx.y;
+    const u32 seg = blockIdx.x;
     const u32 cnt = (lens[b] + MT - 1) / MT;
+    const u32 t0 = seg * segT;
+    const u32 t1 = (t0 + segT < cnt) ? t0 + segT : cnt;
     u32* p = tileLast + (size_t)b * perTiles * 256 + threadIdx.x;
     u32 cur = 0;
-    for (u32 t = 0; t < cnt; t++) {
+    for (u32 t = t0; t < t1; t++) {
         const u32 x = p[(size_t)t * 256];
         p[(size_t)t * 256] = cur;
         cur = x > cur ? x : cur;
     }
+    segMax[((size_t)b * nSeg + seg) * 256 + threadIdx.x] = cur;
 }
 
-__global__ __launch_bounds__(64) void k_mtf_f_rank(XfView v, int perTiles, const u32* __restrict__ tileState)
+__global__ __launch_bounds__(256) void k_mtf_f_scan2(u32* __restrict__ segMax, u32 nSeg)
+{
+    u32* p = segMax + (size_t)blockIdx.x * nSeg * 256 + threadIdx.x;
+    u32 cur = 0;
+    for (u32 g = 0; g < nSeg; g++) {
+        const u32 x = p[(size_t)g * 256];
+        p[(size_t)g * 256] = cur;
+        cur = x > cur ? x : cur;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_mtf_f_rank(XfView v, int perTiles, const u32* __restrict__ tileState, u32 segT, u32 nSeg,
+                                                   const u32* __restrict__ segMax)
 {
     const int b = blockIdx.y;
     const u32 n = (v.len[b] <= v.cap[b]) ? v.len[b] : 0;
@@ -89,7 +110,8 @@ __global__ __launch_bounds__(64) void k_mtf_f_rank(XfView v, int perTiles, const
     const int lane = lane_id();
     // start list: symbols by last occurrence desc, never-seen symbols ascending
     const u32* st = tileState + ((size_t)b * perTiles + blockIdx.x) * 256;
-    for (int i = lane; i < 256; i += 64) keys[i] = st[i];
+    const u32* sg = segMax + ((size_t)b * nSeg + blockIdx.x / segT) * 256;       // last occurrences in the segments before mine
+    for (int i = lane; i < 256; i += 64) { const u32 x = st[i], y = sg[i]; keys[i] = x > y ? x : y; }
     __syncthreads();
     u8* listb = reinterpret_cast<u8*>(listw);
     for (int c = lane; c < 256; c += 64) {
@@ -252,30 +274,55 @@ __global__ __launch_bounds__(64) void k_mtf_i_symbolic(XfView v, int perTiles, u
     reinterpret_cast<u32*>(tilePerm + ((size_t)b * perTiles + blockIdx.x) * 256)[lane] = w;
 }
 
-// inverse, pass 2: per block, state before tile t: S_0 = identity, S_{t+1}[j] = S_t[perm_t[j]] ; in place
-__global__ __launch_bounds__(256) void k_mtf_i_compose(u8* __restrict__ tilePerm, int perTiles, const u32* __restrict__ lens)
+// inverse, pass 2: state before tile t: S_0 = identity, S_{t+1}[j] = S_t[perm_t[j]]. Composition is associative, so it runs in two
+// levels like the forward scan: inside a segment from the identity (L_t, stored in place, and the segment's total in segPerm), then
+// over the segment totals (A_g = state before segment g, in place); the state a tile needs is S_t[j] = A_g[L_t[j]] (pass 3).
+__global__ __launch_bounds__(256) void k_mtf_i_compose(u8* __restrict__ tilePerm, int perTiles, u32 segT, u32 nSeg, const u32* __restrict__ lens,
+                                                       u8* __restrict__ segPerm)
 {
-    const int b = blockIdx.x;
+    const int b = blockIdx.y;
+    const u32 seg = blockIdx.x;
     const u32 cnt = (lens[b] + MT - 1) / MT;
+    const u32 t0 = seg * segT;
+    const u32 t1 = (t0 + segT < cnt) ? t0 + segT : cnt;
     __shared__ u8 S[2][256];
     S[0][threadIdx.x] = (u8)threadIdx.x;
     __syncthreads();
     u8* p = tilePerm + (size_t)b * perTiles * 256;
     int cur = 0;
-    u8 pj = cnt ? p[threadIdx.x] : (u8)0;
-    for (u32 t = 0; t < cnt; t++) {
-        const u8 pjNext = (t + 1 < cnt) ? p[(size_t)(t + 1) * 256 + threadIdx.x] : (u8)0;   // prefetch: independent of the chain
+    u8 pj = (t0 < t1) ? p[(size_t)t0 * 256 + threadIdx.x] : (u8)0;
+    for (u32 t = t0; t < t1; t++) {
+        const u8 pjNext = (t + 1 < t1) ? p[(size_t)(t + 1) * 256 + threadIdx.x] : (u8)0;   // prefetch: independent of the chain
         const u8 nv = S[cur][pj];
-        p[(size_t)t * 256 + threadIdx.x] = S[cur][threadIdx.x];   // state before tile t
+        p[(size_t)t * 256 + threadIdx.x] = S[cur][threadIdx.x];   // state before tile t, relative to the segment start
         S[cur ^ 1][threadIdx.x] = nv;
         __syncthreads();
         cur ^= 1;
         pj = pjNext;
     }
+    segPerm[((size_t)b * nSeg + seg) * 256 + threadIdx.x] = S[cur][threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_mtf_i_compose2(u8* __restrict__ segPerm, u32 nSeg)
+{
+    __shared__ u8 S[2][256];
+    S[0][threadIdx.x] = (u8)threadIdx.x;
+    __syncthreads();
+    u8* p = segPerm + (size_t)blockIdx.x * nSeg * 256;
+    int cur = 0;
+    for (u32 g = 0; g < nSeg; g++) {
+        const u8 pj = p[(size_t)g * 256 + threadIdx.x];
+        const u8 nv = S[cur][pj];
+        p[(size_t)g * 256 + threadIdx.x] = S[cur][threadIdx.x];   // state before segment g
+        S[cur ^ 1][threadIdx.x] = nv;
+        __syncthreads();
+        cur ^= 1;
+    }
 }
 
 // inverse, pass 3: resolve ids in place: out[i] = state_tile[id]
-__global__ __launch_bounds__(256) void k_mtf_i_resolve(XfView v, int perTiles, const u8* __restrict__ tileState)
+__global__ __launch_bounds__(256) void k_mtf_i_resolve(XfView v, int perTiles, const u8* __restrict__ tileState, u32 segT, u32 nSeg,
+                                                       const u8* __restrict__ segState)
 {
     const int b = blockIdx.y;
     const u32 n = (v.len[b] <= v.cap[b]) ? v.len[b] : 0;
@@ -283,7 +330,7 @@ __global__ __launch_bounds__(256) void k_mtf_i_resolve(XfView v, int perTiles, c
     const u32 base = t * MT;
     if (base >= n) return;
     __shared__ u8 S[256];
-    S[threadIdx.x] = tileState[((size_t)b * perTiles + t) * 256 + threadIdx.x];
+    S[threadIdx.x] = segState[((size_t)b * nSeg + t / segT) * 256 + tileState[((size_t)b * perTiles + t) * 256 + threadIdx.x]];
     __syncthreads();
     u8* d = v.dst[b];
     const u32 end = (base + MT < n) ? base + MT : n;
@@ -313,11 +360,14 @@ void launch_mtft_forward(hipStream_t s, const XfStage& st)
     const XfView v = mk(st);
     const int perTiles = (int)((st.maxLen + MT - 1) / MT);
     u32* tileLast = st.scratchU32;                           // nBlocks * perTiles * 256
+    const u32 segT = mtf_seg_tiles((u32)perTiles), nSeg = ((u32)perTiles + segT - 1) / segT;
+    u32* segMax = tileLast + (size_t)st.nBlocks * perTiles * 256;                  // nBlocks * nSeg * 256
     const dim3 grid(perTiles, st.nBlocks);
     { KScope ks_("k_copy_ok"); hipLaunchKernelGGL(k_copy_ok, dim3((st.nBlocks + 255) / 256), dim3(256), 0, s, st.len, st.cap, st.nBlocks, st.ok, st.newLen); }
     { KScope ks_("k_mtf_f_last"); hipLaunchKernelGGL(k_mtf_f_last, grid, dim3(64), 0, s, v, perTiles, tileLast); }
-    { KScope ks_("k_mtf_f_scan"); hipLaunchKernelGGL(k_mtf_f_scan, dim3(st.nBlocks), dim3(256), 0, s, tileLast, perTiles, st.len); }
-    { KScope ks_("k_mtf_f_rank"); hipLaunchKernelGGL(k_mtf_f_rank, grid, dim3(64), 0, s, v, perTiles, tileLast); }
+    { KScope ks_("k_mtf_f_scan"); hipLaunchKernelGGL(k_mtf_f_scan, dim3(nSeg, st.nBlocks), dim3(256), 0, s, tileLast, perTiles, segT, nSeg, st.len, segMax);
+      hipLaunchKernelGGL(k_mtf_f_scan2, dim3(st.nBlocks), dim3(256), 0, s, segMax, nSeg); }
+    { KScope ks_("k_mtf_f_rank"); hipLaunchKernelGGL(k_mtf_f_rank, grid, dim3(64), 0, s, v, perTiles, tileLast, segT, nSeg, segMax); }
 }
 
 void launch_mtft_inverse(hipStream_t s, const XfStage& st)
@@ -325,12 +375,20 @@ void launch_mtft_inverse(hipStream_t s, const XfStage& st)
     const XfView v = mk(st);
     const int perTiles = (int)((st.maxLen + MT - 1) / MT);
     u8* tilePerm = reinterpret_cast<u8*>(st.scratchU32);     // nBlocks * perTiles * 256 bytes
+    const u32 segT = mtf_seg_tiles((u32)perTiles), nSeg = ((u32)perTiles + segT - 1) / segT;
+    u8* segPerm = tilePerm + (size_t)st.nBlocks * perTiles * 256;                  // nBlocks * nSeg * 256 bytes
     { KScope ks_("k_copy_ok"); hipLaunchKernelGGL(k_copy_ok, dim3((st.nBlocks + 255) / 256), dim3(256), 0, s, st.len, st.cap, st.nBlocks, st.ok, st.newLen); }
     { KScope ks_("k_mtf_i_symbolic"); hipLaunchKernelGGL(k_mtf_i_symbolic, dim3(perTiles, st.nBlocks), dim3(64), 0, s, v, perTiles, tilePerm); }
-    { KScope ks_("k_mtf_i_compose"); hipLaunchKernelGGL(k_mtf_i_compose, dim3(st.nBlocks), dim3(256), 0, s, tilePerm, perTiles, st.len); }
-    { KScope ks_("k_mtf_i_resolve"); hipLaunchKernelGGL(k_mtf_i_resolve, dim3(perTiles, st.nBlocks), dim3(256), 0, s, v, perTiles, tilePerm); }
+    { KScope ks_("k_mtf_i_compose"); hipLaunchKernelGGL(k_mtf_i_compose, dim3(nSeg, st.nBlocks), dim3(256), 0, s, tilePerm, perTiles, segT, nSeg, st.len, segPerm);
+      hipLaunchKernelGGL(k_mtf_i_compose2, dim3(st.nBlocks), dim3(256), 0, s, segPerm, nSeg); }
+    { KScope ks_("k_mtf_i_resolve"); hipLaunchKernelGGL(k_mtf_i_resolve, dim3(perTiles, st.nBlocks), dim3(256), 0, s, v, perTiles, tilePerm, segT, nSeg, segPerm); }
 }
 
-size_t mtft_scratch_u32(int nBlocks, u32 maxLen) { return (size_t)nBlocks * ((maxLen + MT - 1) / MT) * 256 + 64; }
+size_t mtft_scratch_u32(int nBlocks, u32 maxLen)
+{
+    const size_t perTiles = (maxLen + MT - 1) / MT;
+    const u32 segT = mtf_seg_tiles((u32)perTiles);
+    return (size_t)nBlocks * (perTiles + (perTiles + segT - 1) / segT) * 256 + 64;    // tile tables + segment tables
+}
 
 }  // namespace knz
