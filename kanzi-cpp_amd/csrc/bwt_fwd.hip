@@ -91,7 +91,10 @@ __global__ void k_bwt_bases(BwtView v, u32* __restrict__ base, u8* __restrict__ 
 // Padding with the smallest byte and breaking ties by length puts a suffix that ends inside the prefix in front of every
 // longer suffix that continues with zero bytes ("shorter sorts first"); suffixes of at least nsym bytes with equal keys share
 // their first nsym symbols.
-__global__ __launch_bounds__(256) void k_bwt_f_init(BwtView v, const u32* __restrict__ base, const u8* __restrict__ ok, int nsym,
+// With pbits != 0 the position inside the block rides in the low pbits bits of the key and there are no values: the sort then
+// moves 8 bytes per element and pass instead of 12 (it only looks at the bits above pbits; it is stable, so equal keys stay in
+// position order either way).
+__global__ __launch_bounds__(256) void k_bwt_f_init(BwtView v, const u32* __restrict__ base, const u8* __restrict__ ok, int nsym, int pbits,
                                                     u64* __restrict__ keys, u32* __restrict__ vals)
 {
     const int b = blockIdx.y;
@@ -106,17 +109,17 @@ __global__ __launch_bounds__(256) void k_bwt_f_init(BwtView v, const u32* __rest
         }
         const u32 left = n - i;
         k = (k << 3) | (u64)(left < (u32)nsym ? left : (u32)nsym);
-        keys[base[b] + i] = k;
-        vals[base[b] + i] = base[b] + i;
+        if (pbits) keys[base[b] + i] = (k << pbits) | (u64)i;
+        else { keys[base[b] + i] = k; vals[base[b] + i] = base[b] + i; }
     }
 }
 
 // group-start flags of the sorted keys as a bit map (one ballot per wave)
-__global__ __launch_bounds__(256) void k_bwt_f_r0_flags(const u64* __restrict__ keys, u32 total, unsigned long long* __restrict__ gbits64)
+__global__ __launch_bounds__(256) void k_bwt_f_r0_flags(const u64* __restrict__ keys, u32 total, int pbits, unsigned long long* __restrict__ gbits64)
 {
     const u32 a = blockIdx.x * 256 + threadIdx.x;
     bool f = true;
-    if (a < total) f = (a == 0) || (keys[a] != keys[a - 1]);
+    if (a < total) f = (a == 0) || ((keys[a] >> pbits) != (keys[a - 1] >> pbits));
     const unsigned long long m = __ballot(f);
     if ((threadIdx.x & 63) == 0) gbits64[a >> 6] = m;
 }
@@ -207,7 +210,7 @@ __device__ __forceinline__ bool sm_group_of(const SmWindow& W, u32 i, u32& s, u3
 // maximum over the windows before it (winLastIncl); the length of a group (needed where it starts) ends at the next set bit.
 __global__ __launch_bounds__(256) void k_bwt_f_r0_place(FwdView v, const u32* __restrict__ vals, const u32* __restrict__ winLastIncl,
                                                         const u32* __restrict__ winFirstInclRev, u32 nWin, uint2* __restrict__ medNext, uint2* __restrict__ largeNext,
-                                                        const u64* __restrict__ keys, int nsym, uint2* __restrict__ runList)
+                                                        const u64* __restrict__ keys, int nsym, int pbits, uint2* __restrict__ runList)
 {
     __shared__ SmWindow W;
     const int tid = (int)threadIdx.x;
@@ -246,7 +249,9 @@ __global__ __launch_bounds__(256) void k_bwt_f_r0_place(FwdView v, const u32* __
         const u32 m = word & lowmask;
         const int si = m ? (int)(w * 32 + 31 - (u32)__clz((int)m)) : W.prevSet[w];
         const u32 hd = (si >= 0) ? slot0 + (u32)si : before;
-        const u32 gp = vals[a];
+        u32 gp;
+        if (pbits) { const u64 kk = keys[a]; gp = v.base[(u32)(kk >> (pbits + 3 + 8 * nsym))] + (u32)(kk & ((1ull << pbits) - 1ull)); }
+        else gp = vals[a];
         v.SA[a] = gp;
         v.ISA[gp] = hd;
         if (hd == a) {
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(256) void k_bwt_f_r0_place(FwdView v, const u32* __
             // of that byte: above the small size it is finished by the run-length round instead of log2(run length) doublings
             bool runGroup = false;
             if (runList != nullptr && size > SM_G) {
-                const u64 k = keys[a];
+                const u64 k = keys[a] >> pbits;
                 const u64 bytes = (k >> 3) & ((1ull << (8 * nsym)) - 1ull);
                 u64 rep = 0;
                 for (int q = 0; q < nsym; q++) rep = (rep << 8) | (bytes & 0xFF);
@@ -966,6 +971,9 @@ size_t bwt_forward_scratch_bytes(int nBlocks, u32 VS, size_t total)
     size_t primSort = 0, primScan = 0;
     rocprim::radix_sort_pairs(nullptr, primSort, (u64*)nullptr, (u64*)nullptr, (u32*)nullptr, (u32*)nullptr, total, 0u, 64u, (hipStream_t)0);
     rocprim::inclusive_scan(nullptr, primScan, (u32*)nullptr, (u32*)nullptr, total, rocprim::maximum<u32>(), (hipStream_t)0);
+    size_t primKeys = 0;
+    rocprim::radix_sort_keys(nullptr, primKeys, (u64*)nullptr, (u64*)nullptr, total, 0u, 64u, (hipStream_t)0);
+    if (primKeys > primSort) primSort = primKeys;
     const size_t prim = fwd_align(primSort > primScan ? primSort : primScan) + 4096;
     FwdScratch w;
     return fwd_carve(nullptr, nBlocks, total, 0, &w) + prim + 4096;
@@ -997,16 +1005,26 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     if (nsym > 7) nsym = 7;
     if (const char* e = getenv("KNZ_BWT_NSYM")) { const int o = atoi(e); if (o >= 1 && o < nsym) nsym = o; }   // tuning knob: shorter round-0 keys
     if (nsym < 1) return -4;
+    // or, when at least 4 symbols still fit: the position packed into the key, 8-byte elements, one pass per key byte
+    int pbits = 0;
+    {
+        int pb0 = 1;
+        while ((1ull << pb0) < (u64)bv.VS) pb0++;
+        const int np = (64 - 3 - bbits - pb0) / 8;
+        const char* e = getenv("KNZ_BWT_PACKED");
+        if (np >= 4 && !(e && atoi(e) == 0)) { pbits = pb0; nsym = np < nsym ? np : nsym; }
+    }
     const dim3 gridB((unsigned)std::min<size_t>(((size_t)bv.VS + 255) / 256, 4096), st.nBlocks);
-    { KScope ks_("k_bwt_f_init"); hipLaunchKernelGGL(k_bwt_f_init, gridB, dim3(256), 0, s, bv, w.base, st.ok, nsym, w.keysA, w.valsA); }
+    { KScope ks_("k_bwt_f_init"); hipLaunchKernelGGL(k_bwt_f_init, gridB, dim3(256), 0, s, bv, w.base, st.ok, nsym, pbits, w.keysA, w.valsA); }
     size_t pb = w.primBytes;
     { KScope ks_("bwt_f_sort_round0");
-      if (rocprim::radix_sort_pairs(w.prim, pb, w.keysA, w.keysB, w.valsA, w.valsB, (size_t)total, 0u, (unsigned)(bbits + 8 * nsym + 3), s) != hipSuccess) return -1; }
+      if (pbits) { if (rocprim::radix_sort_keys(w.prim, pb, w.keysA, w.keysB, (size_t)total, (unsigned)pbits, (unsigned)(pbits + bbits + 8 * nsym + 3), s) != hipSuccess) return -1; }
+      else if (rocprim::radix_sort_pairs(w.prim, pb, w.keysA, w.keysB, w.valsA, w.valsB, (size_t)total, 0u, (unsigned)(bbits + 8 * nsym + 3), s) != hipSuccess) return -1; }
     // every bit from `total` on is set (end sentinel, and windows may look past the end)
     hipMemsetAsync(w.gbits, 0xFF, 4 * w.gbitsWords, s);
     hipMemsetAsync(w.gnew, 0, 4 * w.gbitsWords, s);
     hipMemsetAsync(w.counters, 0, 64, s);
-    { KScope ks_("k_bwt_f_r0_flags"); hipLaunchKernelGGL(k_bwt_f_r0_flags, dim3((total + 255) / 256), dim3(256), 0, s, w.keysB, total,
+    { KScope ks_("k_bwt_f_r0_flags"); hipLaunchKernelGGL(k_bwt_f_r0_flags, dim3((total + 255) / 256), dim3(256), 0, s, w.keysB, total, pbits,
                                                          reinterpret_cast<unsigned long long*>(w.gbits)); }
     // group starts before / after every window of 2048 slots: two scans over ~total/2048 values
     const u32 nWin = (total + SM_WIN - 1) / SM_WIN;
@@ -1021,7 +1039,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     // the run-length round needs descriptor index + (kbits + 1) + kbits bits in one 64-bit key
     const bool runRound = (2 * kbits + 1) < 64 && getenv("KNZ_BWT_NO_RUN_ROUND") == nullptr;
     { KScope ks_("k_bwt_f_r0_place"); hipLaunchKernelGGL(k_bwt_f_r0_place, dim3(nWin), dim3(256), 0, s, v, w.valsB, w.t1, w.t3, nWin, w.med[cur], w.large[cur],
-                                                         w.keysB, nsym, runRound ? w.runList : (uint2*)nullptr); }
+                                                         w.keysB, nsym, pbits, runRound ? w.runList : (uint2*)nullptr); }
     if (hipMemcpyAsync(h_pinned, w.counters, 32, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
     if (hipStreamSynchronize(s) != hipSuccess) return -1;
     u32 nRun = h_pinned[4], runElems = h_pinned[5];
