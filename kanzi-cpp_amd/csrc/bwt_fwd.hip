@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <cmath>
 #include <rocprim/rocprim.hpp>
 
 namespace knz {
@@ -85,6 +86,28 @@ __global__ void k_bwt_bases(BwtView v, u32* __restrict__ base, u8* __restrict__ 
         if (a) sum += v.len[b];
     }
     base[v.nBlocks] = sum;
+}
+
+// byte histogram over a 1-in-16 sample of the blocks the transform applies to (16 bytes of every 256): its entropy decides
+// the shape of the round-0 key (launch_bwt_forward)
+__global__ __launch_bounds__(256) void k_bwt_f_sample(BwtView v, const u8* __restrict__ ok, u32* __restrict__ hist)
+{
+    __shared__ u32 h[4][256];
+    const int tid = (int)threadIdx.x, wave = tid >> 6;
+    for (int k = 0; k < 4; k++) h[k][tid] = 0;
+    __syncthreads();
+    const int b = blockIdx.y;
+    if (ok[b]) {
+        const u32 n = v.len[b];
+        const u8* s = v.src[b];
+        for (u32 o = (blockIdx.x * 256u + (u32)tid) * 256u; o < n; o += gridDim.x * 256u * 256u) {
+            const u32 e = (o + 16 < n) ? o + 16 : n;
+            for (u32 i = o; i < e; i++) atomicAdd(&h[wave][s[i]], 1u);
+        }
+    }
+    __syncthreads();
+    const u32 c = h[0][tid] + h[1][tid] + h[2][tid] + h[3][tid];
+    if (c) atomicAdd(&hist[tid], c);
 }
 
 // keys: [block id | nsym bytes, zero past the block end | min(suffix length, nsym) in 3 bits], values: global position ids.
@@ -250,7 +273,12 @@ __global__ __launch_bounds__(256) void k_bwt_f_r0_place(FwdView v, const u32* __
         const int si = m ? (int)(w * 32 + 31 - (u32)__clz((int)m)) : W.prevSet[w];
         const u32 hd = (si >= 0) ? slot0 + (u32)si : before;
         u32 gp;
-        if (pbits) { const u64 kk = keys[a]; gp = v.base[(u32)(kk >> (pbits + 3 + 8 * nsym))] + (u32)(kk & ((1ull << pbits) - 1ull)); }
+        if (pbits) {
+            // (a lone block may use all 64 bits: no block field to shift down)
+            const u64 kk = keys[a];
+            const int bshift = pbits + 3 + 8 * nsym;
+            gp = v.base[bshift < 64 ? (u32)(kk >> bshift) : 0u] + (u32)(kk & ((1ull << pbits) - 1ull));
+        }
         else gp = vals[a];
         v.SA[a] = gp;
         v.ISA[gp] = hd;
@@ -936,6 +964,7 @@ struct FwdScratch {
     u32* loff;
     u32* base;
     u32* counters;
+    u32* hist;
     void* prim; size_t primBytes;
 };
 
@@ -960,6 +989,7 @@ static size_t fwd_carve(u8* p, int nBlocks, size_t total, size_t bytes, FwdScrat
     w->loff = (u32*)take(4 * (maxMed + 1));
     w->base = (u32*)take(4ull * (nBlocks + 2));
     w->counters = (u32*)take(256);
+    w->hist = (u32*)take(1024);
     w->prim = q;
     w->primBytes = (p && bytes > (size_t)(q - p)) ? bytes - (size_t)(q - p) : 0;
     return (size_t)(q - p);
@@ -990,10 +1020,20 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     fwd_carve(reinterpret_cast<u8*>(scratch), st.nBlocks, maxTotal, scratchBytes, &w);
     { KScope ks_("k_bwt_f_bases"); hipLaunchKernelGGL(k_bwt_bases, dim3(1), dim3(64), 0, s, bv, w.base, st.ok); }
     hipMemsetAsync(st.newLen, 0, sizeof(u32) * st.nBlocks, s);
+    hipMemsetAsync(w.hist, 0, 1024, s);
+    { KScope ks_("k_bwt_f_sample");
+      hipLaunchKernelGGL(k_bwt_f_sample, dim3((unsigned)std::min<size_t>(((size_t)bv.VS + 65535) / 65536, 64), st.nBlocks), dim3(256), 0, s, bv, st.ok, w.hist); }
     if (hipMemcpyAsync(h_pinned, w.base + st.nBlocks, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+    if (hipMemcpyAsync(h_pinned + 16, w.hist, 1024, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
     if (hipStreamSynchronize(s) != hipSuccess) return -1;
     const u32 total = h_pinned[0];
     if (total == 0) return 0;
+    double h0 = 0.0;                                             // order-0 entropy of the sample, bits per byte
+    {
+        double sum = 0.0;
+        for (int c = 0; c < 256; c++) sum += (double)h_pinned[16 + c];
+        if (sum > 0.0) for (int c = 0; c < 256; c++) { const double f = (double)h_pinned[16 + c] / sum; if (f > 0.0) h0 -= f * log2(f); }
+    }
     FwdView v; v.base = w.base; v.nBlocks = st.nBlocks; v.total = total; v.SA = w.SA; v.ISA = w.ISA; v.K = w.K; v.gbits = w.gbits; v.gnew = w.gnew; v.counters = w.counters;
 
     // ---- round 0: sort by the first nsym symbols
@@ -1005,14 +1045,18 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     if (nsym > 7) nsym = 7;
     if (const char* e = getenv("KNZ_BWT_NSYM")) { const int o = atoi(e); if (o >= 1 && o < nsym) nsym = o; }   // tuning knob: shorter round-0 keys
     if (nsym < 1) return -4;
-    // or, when at least 4 symbols still fit: the position packed into the key, 8-byte elements, one pass per key byte
+    // or, when at least 4 symbols still fit: the position packed into the key, 8-byte elements, one pass per key byte. Fewer
+    // symbols leave more to the refinement rounds, which costs more than the sort saves when few symbols say little: with 8 MiB
+    // blocks (4 symbols packed, 6 not) text at 4.1 bits per byte loses 4 ms per 212 MB, mixed binary data at 6.8 gains 1.5 --
+    // so the packed form is taken when it does not shorten the key, or when the sample's entropy is at least 5.5 bits per byte.
     int pbits = 0;
     {
         int pb0 = 1;
         while ((1ull << pb0) < (u64)bv.VS) pb0++;
         const int np = (64 - 3 - bbits - pb0) / 8;
-        const char* e = getenv("KNZ_BWT_PACKED");
-        if (np >= 4 && !(e && atoi(e) == 0)) { pbits = pb0; nsym = np < nsym ? np : nsym; }
+        const char* e = getenv("KNZ_BWT_PACKED");                 // 0 / 1 force the choice (tests, tuning)
+        const bool want = e ? atoi(e) != 0 : (np >= nsym || h0 >= 5.5);
+        if (np >= 4 && want) { pbits = pb0; nsym = np < nsym ? np : nsym; }
     }
     const dim3 gridB((unsigned)std::min<size_t>(((size_t)bv.VS + 255) / 256, 4096), st.nBlocks);
     { KScope ks_("k_bwt_f_init"); hipLaunchKernelGGL(k_bwt_f_init, gridB, dim3(256), 0, s, bv, w.base, st.ok, nsym, pbits, w.keysA, w.valsA); }

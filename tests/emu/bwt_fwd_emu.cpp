@@ -42,7 +42,7 @@ int main(int argc, char** argv)
     const size_t bytes = bwt_forward_scratch_bytes((int)nBlocks, maxLen, (size_t)nBlocks * maxLen);
     std::vector<u8> scratch(bytes + 256);
     u8* sc = reinterpret_cast<u8*>((reinterpret_cast<uintptr_t>(scratch.data()) + 255) & ~(uintptr_t)255);
-    u32 pinned[64];
+    u32 pinned[512];                 // the host read-back area (counters, the 256-entry sample histogram)
     const int rc = launch_bwt_forward(nullptr, st, sc, bytes, pinned);
     if (rc != 0) { printf("FAIL launch rc=%d\n", rc); return 1; }
     int bad = 0;

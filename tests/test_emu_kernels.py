@@ -56,6 +56,8 @@ def test_bwt_forward_kernels_emulated(tmp_path):
         [b"mississippi", b"abcabcabcabcabcabcab", bytes(5), b"a", b"ab", b"zero tail ab\0\0\0" + bytes(9), b"\0\0ab\0\0ab\0\0", c.text(3000, 1), bytes((np.arange(1000) & 255).astype(np.uint8))],
         [c.text(30000, 2), bytes(3000) + c.text(500, 3), ramp, rng.integers(0, 4, 20000, dtype=np.uint8).tobytes()],
         [bytes(z), c.mixed(300000, 2)[250000:290000]],
+        [bytes(5000)],                       # a lone block whose round-0 key (position packed in) takes all 64 bits
+        [c.text(8000, 7)],
     ]
     for i, blocks in enumerate(cases):
         path = str(tmp_path / ("case%d.bin" % i))
