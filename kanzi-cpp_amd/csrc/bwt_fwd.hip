@@ -1053,7 +1053,9 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     {
         int pb0 = 1;
         while ((1ull << pb0) < (u64)bv.VS) pb0++;
-        const int np = (64 - 3 - bbits - pb0) / 8;
+        // (63, not 64: rocPRIM's merge-sort path for mid-sized inputs builds its key mask as (1 << end_bit) - 1, which is
+        // wrong for end_bit == 64 when begin_bit != 0)
+        const int np = (63 - 3 - bbits - pb0) / 8;
         const char* e = getenv("KNZ_BWT_PACKED");                 // 0 / 1 force the choice (tests, tuning)
         const bool want = e ? atoi(e) != 0 : (np >= nsym || h0 >= 5.5);
         if (np >= 4 && want) { pbits = pb0; nsym = np < nsym ? np : nsym; }
