@@ -74,18 +74,19 @@ __device__ __forceinline__ void classify_child(const FwdView& v, uint2* __restri
 // round 0
 // ------------------------------------------------------------------------------------------------
 // base[b] = sum of active lengths of the blocks before b ; total in base[nBlocks]
-__global__ void k_bwt_bases(BwtView v, u32* __restrict__ base, u8* __restrict__ ok)
+__global__ void k_bwt_bases(BwtView v, u32* __restrict__ base, u8* __restrict__ ok, u32* __restrict__ maxLen)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    u32 sum = 0;
+    u32 sum = 0, mx = 0;
     for (int b = 0; b < v.nBlocks; b++) {
         base[b] = sum;
         u32 ps;
         const bool a = bwt_fwd_applies(v.len[b], v.cap[b], &ps);
         ok[b] = a ? 1 : 0;
-        if (a) sum += v.len[b];
+        if (a) { sum += v.len[b]; mx = v.len[b] > mx ? v.len[b] : mx; }
     }
     base[v.nBlocks] = sum;
+    *maxLen = mx;                       // longest block the transform applies to
 }
 
 // byte histogram over a 1-in-16 sample of the blocks the transform applies to (16 bytes of every 256): its entropy decides
@@ -989,7 +990,7 @@ static size_t fwd_carve(u8* p, int nBlocks, size_t total, size_t bytes, FwdScrat
     w->loff = (u32*)take(4 * (maxMed + 1));
     w->base = (u32*)take(4ull * (nBlocks + 2));
     w->counters = (u32*)take(256);
-    w->hist = (u32*)take(1024);
+    w->hist = (u32*)take(1024 + 64);                  // 256 sample counters + the longest active block
     w->prim = q;
     w->primBytes = (p && bytes > (size_t)(q - p)) ? bytes - (size_t)(q - p) : 0;
     return (size_t)(q - p);
@@ -1018,13 +1019,13 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     const size_t maxTotal = (size_t)st.nBlocks * bv.VS;
     FwdScratch w;
     fwd_carve(reinterpret_cast<u8*>(scratch), st.nBlocks, maxTotal, scratchBytes, &w);
-    { KScope ks_("k_bwt_f_bases"); hipLaunchKernelGGL(k_bwt_bases, dim3(1), dim3(64), 0, s, bv, w.base, st.ok); }
+    { KScope ks_("k_bwt_f_bases"); hipLaunchKernelGGL(k_bwt_bases, dim3(1), dim3(64), 0, s, bv, w.base, st.ok, w.hist + 256); }
     hipMemsetAsync(st.newLen, 0, sizeof(u32) * st.nBlocks, s);
     hipMemsetAsync(w.hist, 0, 1024, s);
     { KScope ks_("k_bwt_f_sample");
       hipLaunchKernelGGL(k_bwt_f_sample, dim3((unsigned)std::min<size_t>(((size_t)bv.VS + 65535) / 65536, 64), st.nBlocks), dim3(256), 0, s, bv, st.ok, w.hist); }
     if (hipMemcpyAsync(h_pinned, w.base + st.nBlocks, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
-    if (hipMemcpyAsync(h_pinned + 16, w.hist, 1024, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+    if (hipMemcpyAsync(h_pinned + 16, w.hist, 1024 + 4, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
     if (hipStreamSynchronize(s) != hipSuccess) return -1;
     const u32 total = h_pinned[0];
     if (total == 0) return 0;
@@ -1052,7 +1053,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     int pbits = 0;
     {
         int pb0 = 1;
-        while ((1ull << pb0) < (u64)bv.VS) pb0++;
+        while ((1ull << pb0) < (u64)h_pinned[16 + 256]) pb0++;    // positions inside the longest block
         // (63, not 64: rocPRIM's merge-sort path for mid-sized inputs builds its key mask as (1 << end_bit) - 1, which is
         // wrong for end_bit == 64 when begin_bit != 0)
         const int np = (63 - 3 - bbits - pb0) / 8;
