@@ -487,6 +487,7 @@ __global__ __launch_bounds__(64) void k_huff_scan(BitSrc src, DecBlock* __restri
     for (int i = lane; i < maxChunks; i += 64) cs[i].kind = 3;
     if (db.error) return;
     __shared__ u32 win[256 + 8];
+    __shared__ u16 egT[128];                           // the Exp-Golomb code table below, for per-lane lookups
     __shared__ u32 codeSizeW[64];                      // 256 code lengths, written four at a time
     u8* codeSize = reinterpret_cast<u8*>(codeSizeW);
     const u64 limit = db.payloadBit + ((db.bits + 7) & ~7ull);
@@ -546,7 +547,9 @@ __global__ __launch_bounds__(64) void k_huff_scan(BitSrc src, DecBlock* __restri
             e = (total << 6) | (u32)(delta + 16);
         }
         egTab |= e << (16 * j);
+        egT[v] = (u16)e;
     }
+    __syncthreads();
     const u32 nChunks = (preLen + ENT_CHUNK - 1) / ENT_CHUNK;
     u64 prevPos = pos;
     int err = 0;
@@ -624,46 +627,31 @@ __global__ __launch_bounds__(64) void k_huff_scan(BitSrc src, DecBlock* __restri
             // up to 256 dependent code reads -- and every lane decodes its own codes from its now known entry offset.
             const u32 rel = q + 32u * (u32)lane;
             const u64 V = ((u64)hwin_bits(win, rel, 32) << 8) | (u64)hwin_bits(win, rel + 32, 8);    // 40 bits, the first one is bit 39
-            // the code that starts at my bit `pos` (0..31), left-aligned; its length from the zeros in front of its first 1:
-            // "1" | "01xs" | "001xxs" | "0001xxxs" (0 = no valid code starts like this); pure register arithmetic, no table
-            auto bits_at = [&](u32 pos) -> u32 { return (u32)((V << (24 + pos)) >> 32); };
-            auto len_of = [&](u32 x) -> u32 { const u32 z = (u32)__clz((int)x); return z == 0 ? 1u : (z <= 3 ? 2u * z + 2u : 0u); };
-            auto delta_of = [&](u32 x, u32 total) -> u32 {                   // two's complement
-                if (total == 1) return 0u;
-                const u32 lg = (total - 2) >> 1;
-                const u32 res = (x >> (32 - total)) & ((1u << (lg + 1)) - 1u);
-                const u32 mag = (res >> 1) + (1u << lg) - 1u;
-                return (res & 1u) ? 0u - mag : mag;
+            auto code_at = [&](u32 pos) -> u32 {                             // table entry of the code that starts at my bit `pos`
+                const u32 top = (u32)(V >> (32 - pos)) & 0xFFu;
+                return (top & 0x80u) ? ((1u << 6) | 16u) : (u32)egT[top];
             };
-            // the 8 walks of a lane advance together (independent chains: their latencies overlap)
-            u32 wpos[8], wn[8], winv[8];
-#pragma unroll
-            for (u32 e = 0; e < 8; e++) { wpos[e] = e; wn[e] = 0; winv[e] = 0; }
-            bool more = true;
-            while (more) {
-                more = false;
-#pragma unroll
-                for (u32 e = 0; e < 8; e++) {
-                    if (wpos[e] < 32 && !winv[e]) {
-                        const u32 total = len_of(bits_at(wpos[e]));
-                        if (total == 0) winv[e] = 8;
-                        else { wpos[e] += total; wn[e]++; more = true; }
-                    }
-                }
-            }
-            u32 exits = 0, cntLo = 0, cntHi = 0;                             // 4 bits / 6 bits per entry offset
+            u32 exits = 0;
+            u64 counts = 0;
 #pragma unroll
             for (u32 e = 0; e < 8; e++) {
-                exits |= (winv[e] | ((wpos[e] - 32) & 7u)) << (4 * e);
-                if (e < 4) cntLo |= wn[e] << (6 * e); else cntHi |= wn[e] << (6 * (e - 4));
+                u32 pos = e, n = 0, inv = 0;
+                while (pos < 32) {
+                    const u32 total = code_at(pos) >> 6;
+                    if (total == 0) { inv = 8; break; }
+                    pos += total;
+                    n++;
+                }
+                exits |= (inv | ((pos - 32) & 7u)) << (4 * e);
+                counts |= (u64)n << (6 * e);
             }
             u32 e = 0, cnt = 0, myEntry = 0, myStart = 0xFFFFFFFFu;
             for (int l = 0; l < 64; l++) {
                 if (lane == l) { myEntry = e; myStart = cnt; }
                 const u32 ex = (u32)__builtin_amdgcn_readlane((int)exits, l);
-                const u32 cw = (e < 4) ? (u32)__builtin_amdgcn_readlane((int)cntLo, l) : (u32)__builtin_amdgcn_readlane((int)cntHi, l);
+                const u64 cn = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(counts >> 32), l) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)counts, l);
                 const u32 x = (ex >> (4 * e)) & 0xFu;
-                const u32 n = (cw >> (6 * (e & 3))) & 63u;
+                const u32 n = (u32)(cn >> (6 * e)) & 63u;
                 if ((x & 8u) && cnt + n < asz) { bad = 1; break; }          // an invalid prefix among the codes that count
                 cnt += n;
                 e = x & 7u;
@@ -675,7 +663,7 @@ __global__ __launch_bounds__(64) void k_huff_scan(BitSrc src, DecBlock* __restri
                 u32 sum = 0, nMine = 0, endPos = 0;
                 if (mine) {
                     u32 pos = myEntry, idx = myStart;
-                    while (pos < 32 && idx < asz) { const u32 x = bits_at(pos), t = len_of(x); sum += delta_of(x, t); pos += t; idx++; }
+                    while (pos < 32 && idx < asz) { const u32 ent = code_at(pos); sum += (ent & 31u) - 16u; pos += ent >> 6; idx++; }
                     nMine = idx - myStart;
                     endPos = pos;
                 }
@@ -689,11 +677,11 @@ __global__ __launch_bounds__(64) void k_huff_scan(BitSrc src, DecBlock* __restri
                 if (mine) {
                     u32 pos = myEntry, idx = myStart, cur = before;
                     while (pos < 32 && idx < asz) {
-                        const u32 x = bits_at(pos), t = len_of(x);
-                        cur += delta_of(x, t);
+                        const u32 ent = code_at(pos);
+                        cur += (ent & 31u) - 16u;
                         off |= (cur - 1u > (u32)HUF_MAX_LEN - 1u) ? 1u : 0u;
                         codeSize[idx] = (u8)cur;
-                        pos += t;
+                        pos += ent >> 6;
                         idx++;
                     }
                 }
