@@ -478,7 +478,7 @@ constexpr u32 HSCAN_NEED_BITS = 6 + 256 + 256 * 8 + 4 * 40 + 64;     // alphabet
 // guessed position, presence masks counted in parallel; the Exp-Golomb deltas are a short uniform chain
 // (one LDS read + count-leading-zeros per code).
 __global__ __launch_bounds__(64) void k_huff_scan(BitSrc src, DecBlock* __restrict__ blocks, int nBlocks, int maxChunks,
-                                                  HufDecChunk* __restrict__ chunks, u32 parMin)
+                                                  HufDecChunk* __restrict__ chunks)
 {
     const int b = blockIdx.x;
     const int lane = lane_id();
@@ -487,7 +487,6 @@ __global__ __launch_bounds__(64) void k_huff_scan(BitSrc src, DecBlock* __restri
     for (int i = lane; i < maxChunks; i += 64) cs[i].kind = 3;
     if (db.error) return;
     __shared__ u32 win[256 + 8];
-    __shared__ u16 egT[128];                           // the Exp-Golomb code table below, for per-lane lookups
     __shared__ u32 codeSizeW[64];                      // 256 code lengths, written four at a time
     u8* codeSize = reinterpret_cast<u8*>(codeSizeW);
     const u64 limit = db.payloadBit + ((db.bits + 7) & ~7ull);
@@ -547,9 +546,7 @@ __global__ __launch_bounds__(64) void k_huff_scan(BitSrc src, DecBlock* __restri
             e = (total << 6) | (u32)(delta + 16);
         }
         egTab |= e << (16 * j);
-        egT[v] = (u16)e;
     }
-    __syncthreads();
     const u32 nChunks = (preLen + ENT_CHUNK - 1) / ENT_CHUNK;
     u64 prevPos = pos;
     int err = 0;
@@ -619,77 +616,6 @@ __global__ __launch_bounds__(64) void k_huff_scan(BitSrc src, DecBlock* __restri
             return (((u64)wh << 32) | (u64)wl) << (q & 31);
         };
         u32 k = 0;
-        if (asz >= parMin) {
-            // ---- large alphabets: the parse itself in parallel. Lane l owns the 32 stream bits from q + 32 l (64 x 32 = 2048 bits
-            // hold 256 codes of at most 8 bits). For every offset e = 0..7 at which a parse can enter its bits the lane finds out
-            // where that parse leaves them and how many codes it starts there (8 short walks per lane, all lanes at once); the
-            // true parse is then the composition of these maps from offset 0 of lane 0 -- 64 uniform steps at most instead of
-            // up to 256 dependent code reads -- and every lane decodes its own codes from its now known entry offset.
-            const u32 rel = q + 32u * (u32)lane;
-            const u64 V = ((u64)hwin_bits(win, rel, 32) << 8) | (u64)hwin_bits(win, rel + 32, 8);    // 40 bits, the first one is bit 39
-            auto code_at = [&](u32 pos) -> u32 {                             // table entry of the code that starts at my bit `pos`
-                const u32 top = (u32)(V >> (32 - pos)) & 0xFFu;
-                return (top & 0x80u) ? ((1u << 6) | 16u) : (u32)egT[top];
-            };
-            u32 exits = 0;
-            u64 counts = 0;
-#pragma unroll
-            for (u32 e = 0; e < 8; e++) {
-                u32 pos = e, n = 0, inv = 0;
-                while (pos < 32) {
-                    const u32 total = code_at(pos) >> 6;
-                    if (total == 0) { inv = 8; break; }
-                    pos += total;
-                    n++;
-                }
-                exits |= (inv | ((pos - 32) & 7u)) << (4 * e);
-                counts |= (u64)n << (6 * e);
-            }
-            u32 e = 0, cnt = 0, myEntry = 0, myStart = 0xFFFFFFFFu;
-            for (int l = 0; l < 64; l++) {
-                if (lane == l) { myEntry = e; myStart = cnt; }
-                const u32 ex = (u32)__builtin_amdgcn_readlane((int)exits, l);
-                const u64 cn = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(counts >> 32), l) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)counts, l);
-                const u32 x = (ex >> (4 * e)) & 0xFu;
-                const u32 n = (u32)(cn >> (6 * e)) & 63u;
-                if ((x & 8u) && cnt + n < asz) { bad = 1; break; }          // an invalid prefix among the codes that count
-                cnt += n;
-                e = x & 7u;
-                if (cnt >= asz) break;
-            }
-            if (!bad) {
-                const bool mine = myStart < asz;
-                // first walk: how much my codes add up to, and where the last one ends
-                u32 sum = 0, nMine = 0, endPos = 0;
-                if (mine) {
-                    u32 pos = myEntry, idx = myStart;
-                    while (pos < 32 && idx < asz) { const u32 ent = code_at(pos); sum += (ent & 31u) - 16u; pos += ent >> 6; idx++; }
-                    nMine = idx - myStart;
-                    endPos = pos;
-                }
-                const u32 before = 2u + wave_incl_scan(sum) - sum;         // length in front of my first code (two's complement sums)
-                const u64 lastM = __ballot(mine && nMine != 0 && myStart + nMine == asz);
-                const int ll = __ffsll((long long)lastM) - 1;
-                const u32 qEnd = q + 32u * (u32)ll + (u32)__builtin_amdgcn_readlane((int)endPos, ll);
-                // second walk: the lengths themselves. Plain integer sums: the reference's int8 arithmetic only differs once a
-                // length has left [1, 12], and that is an error either way.
-                u32 off = 0;
-                if (mine) {
-                    u32 pos = myEntry, idx = myStart, cur = before;
-                    while (pos < 32 && idx < asz) {
-                        const u32 ent = code_at(pos);
-                        cur += (ent & 31u) - 16u;
-                        off |= (cur - 1u > (u32)HUF_MAX_LEN - 1u) ? 1u : 0u;
-                        codeSize[idx] = (u8)cur;
-                        pos += ent >> 6;
-                        idx++;
-                    }
-                }
-                if (__ballot(off != 0) != 0 || lastM == 0) bad = 1;
-                q = qEnd;
-            }
-            k = asz;
-        }
         for (; k + 4 <= asz; k += 4) {                                       // 4 codes (<= 32 bits) per window read
             if (q > HSCAN_WIN_BITS - 96) { bad = 1; break; }                 // longer than any valid header
             u64 buf = window();
@@ -749,13 +675,6 @@ __global__ __launch_bounds__(64) void k_huff_scan(BitSrc src, DecBlock* __restri
         if (err) db.error = KNZ_ERR_PROCESS_BLOCK;
         db.usedBits = pos - entropyBit;
     }
-}
-
-// alphabets from this size on take the parallel header parse of k_huff_scan (KNZ_HUF_SCAN_PAR_MIN: tests, tuning)
-static u32 huff_scan_par_min()
-{
-    static const u32 v = [] { const char* e = getenv("KNZ_HUF_SCAN_PAR_MIN"); return e ? (u32)atoi(e) : 24u; }();
-    return v;
 }
 
 constexpr int HUF_DEC_CHUNKS = 8;   // chunks per wave (4 lanes = 4 fragments each)
@@ -955,7 +874,7 @@ void launch_huffman_decode(hipStream_t s, BitSrc src, DecBlock* blocks, int nBlo
 {
     HufDecChunk* chunks = reinterpret_cast<HufDecChunk*>(chunkMeta);
     const int nSlots = nBlocks * maxChunks;
-    { KScope ks_("k_huff_scan"); hipLaunchKernelGGL(k_huff_scan, dim3(nBlocks), dim3(64), 0, s, src, blocks, nBlocks, maxChunks, chunks, huff_scan_par_min()); }
+    { KScope ks_("k_huff_scan"); hipLaunchKernelGGL(k_huff_scan, dim3(nBlocks), dim3(64), 0, s, src, blocks, nBlocks, maxChunks, chunks); }
     { KScope ks_("k_huff_decode"); hipLaunchKernelGGL(k_huff_decode, dim3((nSlots + HUF_DEC_CHUNKS - 1) / HUF_DEC_CHUNKS), dim3(64), 0, s, src, blocks,
                        maxChunks, nSlots, chunks, outPtr); }
 }
