@@ -427,6 +427,7 @@ struct MedLds {
     u32 pn[CAP / 32];
     u32 wtot[WAVES];
     u32 wtot2[WAVES];
+    u32 oldLab;                 // the label (ISA value) the group's members carry
 };
 
 template <int THREADS, int ROWS>
@@ -544,6 +545,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 128) void k_bwt_f_sort_medium(Fw
             for (int r = 0; r < ROWS; r++) { const u32 i = (u32)tid + (u32)r * THREADS; if (i < n) { L.oK[i] = k[r]; L.oV[i] = p[r]; } }
         }
         __syncthreads();
+        if (tid == 0) L.oldLab = v.ISA[L.oV[0]];            // (the load overlaps the sort; read again in the write-back)
         // majority candidate: the key two of three probes agree on, else the middle one
         const u32 ka = L.oK[n >> 2], kb = L.oK[n >> 1], kc = L.oK[(n >> 2) * 3];
         const u32 m = (ka == kc) ? ka : kb;
@@ -663,6 +665,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 128) void k_bwt_f_sort_medium(Fw
         __syncthreads();
         // pm[w] = last boundary at or before the end of word w, pn[w] = first boundary at or after the start of word w
         u32 surv = 0;
+        const u32 oldLab = L.oldLab;
         for (u32 i = (u32)tid; i < n; i += THREADS) {
             const u32 w = i >> 5, bit = i & 31;
             const u32 lowmask = (bit == 31) ? 0xFFFFFFFFu : ((2u << bit) - 1u);
@@ -671,12 +674,18 @@ __global__ __launch_bounds__(THREADS, THREADS / 128) void k_bwt_f_sort_medium(Fw
             const u32 hd = mm ? (w * 32 + 31 - (u32)__clz((int)mm)) : (u32)L.pm[w - 1];      // word 0 always has bit 0
             const u32 gp = L.oV[i];
             v.SA[gs + i] = gp;
-            if (hd != 0) v.ISA[gp] = gs + hd;
-            if (hd == i) {
-                const u32 m2 = word & ~lowmask;
-                const u32 e = m2 ? (w * 32 + (u32)__ffs((int)m2) - 1) : ((w + 1 < (u32)(CAP / 32)) ? L.pn[w + 1] : n);
-                classify_child(v, medNext, largeNext, gs + i, e - i, surv);
-            }
+            const u32 m2 = word & ~lowmask;
+            const u32 e = m2 ? (w * 32 + (u32)__ffs((int)m2) - 1) : ((w + 1 < (u32)(CAP / 32)) ? L.pn[w + 1] : n);     // end of my subgroup
+            // The label of a group only has to be a slot inside the group's range (ranges are disjoint, so labels stay unique and
+            // ordered). Small children take their first slot, as every kernel that works on small groups expects; a larger child
+            // keeps the parent's label when that slot lies inside its range, else it takes its middle slot -- which the part that
+            // holds the majority in the rounds to come will still contain, so that its thousands of members are not relabelled
+            // (a scattered 4-byte store each) round after round just because a few members left in front of them.
+            const u32 size = e - hd;
+            const u32 rel = oldLab - gs;
+            const u32 lab = (size <= SM_G) ? gs + hd : ((rel >= hd && rel < e) ? oldLab : gs + hd + (size >> 1));
+            if (lab != oldLab) v.ISA[gp] = lab;
+            if (hd == i) classify_child(v, medNext, largeNext, gs + i, size, surv);
         }
         if (__ballot(surv != 0) != 0 && lane == 0) v.counters[0] = 1;
         // new group starts into the round's bit map (bit 0 of the group is set already)
