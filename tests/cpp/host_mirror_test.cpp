@@ -250,6 +250,99 @@ static void testBlockRange()
     }
 }
 
+// The stream classes run threads (worker; reader + decoder) and queue copies: a caller that walks away in the middle, a stream that
+// ends in the middle of a batch and a sink that fails must neither hang nor lose their error.
+namespace {
+class FailingBuf : public std::streambuf {
+public:
+    explicit FailingBuf(size_t okBytes) : _left(okBytes) {}
+protected:
+    std::streamsize xsputn(const char*, std::streamsize n) override
+    {
+        if (size_t(n) > _left) { const std::streamsize k = std::streamsize(_left); _left = 0; return k; }
+        _left -= size_t(n);
+        return n;
+    }
+    int_type overflow(int_type ch) override { if (_left == 0) return traits_type::eof(); _left--; return traits_type::not_eof(ch); }
+private:
+    size_t _left;
+};
+}
+
+static void testPipeline()
+{
+    const int bs = 65536;
+    const size_t n = 40 * size_t(bs) + 1234;
+    std::vector<byte> in = gen(1, n, 99);
+    std::stringstream ss;
+    {
+        CompressedOutputStream cos(ss, 2, "ANS0", "BWT+MTFT+ZRLT", bs);
+        cos.setBatchBlocks(4);                                   // 11 batches: every slot and output buffer is reused several times
+        size_t off = 0;
+        while (off < n) { const size_t c = std::min<size_t>(n - off, 100000); cos.write(reinterpret_cast<const char*>(&in[off]), std::streamsize(c)); off += c; }
+        cos.close();
+        CHECK(cos.getWritten() == uint64(ss.str().size()));
+    }
+    const std::string knz = ss.str();
+    // (1) complete read, small batches
+    {
+        std::stringstream is(knz);
+        CompressedInputStream cis(is, 2);
+        cis.setBatchBlocks(3);
+        std::vector<byte> out(n + 16);
+        cis.read(reinterpret_cast<char*>(out.data()), std::streamsize(out.size()));
+        CHECK(size_t(cis.gcount()) == n && memcmp(out.data(), in.data(), n) == 0);
+    }
+    // (2) the caller reads a little and walks away while the threads are ahead of it
+    for (int rep = 0; rep < 3; rep++) {
+        std::stringstream is(knz);
+        CompressedInputStream cis(is, 2);
+        cis.setBatchBlocks(2);
+        std::vector<byte> out(100000);
+        cis.read(reinterpret_cast<char*>(out.data()), std::streamsize(out.size() >> rep));
+        CHECK(memcmp(out.data(), in.data(), out.size() >> rep) == 0);
+        if (rep == 1) cis.close();
+    }
+    // (3) the stream ends in the middle of a later batch: everything before it is delivered, then the error
+    {
+        std::stringstream is(knz.substr(0, knz.size() * 2 / 3));
+        CompressedInputStream cis(is, 2);
+        cis.setBatchBlocks(3);
+        std::vector<byte> out(n + 16);
+        bool threw = false;
+        size_t got = 0;
+        try {
+            for (;;) { cis.read(reinterpret_cast<char*>(out.data()) + got, 50000); const size_t g = size_t(cis.gcount()); got += g; if (g == 0) break; }
+        } catch (const IOException&) { threw = true; }
+        CHECK(threw);
+        CHECK(got >= size_t(bs) && got < n && memcmp(out.data(), in.data(), got) == 0);
+    }
+    // (4) a sink that stops taking bytes: the writer reports it (from write() or close()), and the object can be destroyed
+    {
+        FailingBuf fb(knz.size() / 2);
+        std::ostream os(&fb);
+        bool threw = false;
+        try {
+            CompressedOutputStream cos(os, 2, "ANS0", "BWT+MTFT+ZRLT", bs);
+            cos.setBatchBlocks(4);
+            size_t off = 0;
+            while (off < n) { const size_t c = std::min<size_t>(n - off, 100000); cos.write(reinterpret_cast<const char*>(&in[off]), std::streamsize(c)); off += c; }
+            cos.close();
+        } catch (const IOException& e) { threw = (e.error() == Error::ERR_WRITE_FILE); }
+        CHECK(threw);
+    }
+    // (5) a writer that is dropped without close()
+    {
+        std::stringstream s2;
+        { CompressedOutputStream cos(s2, 2, "ANS0", "NONE", bs); cos.setBatchBlocks(2); cos.write(reinterpret_cast<const char*>(in.data()), std::streamsize(5 * bs + 7)); }
+        std::stringstream is(s2.str());
+        CompressedInputStream cis(is, 1);
+        std::vector<byte> out(5 * bs + 64);
+        cis.read(reinterpret_cast<char*>(out.data()), std::streamsize(out.size()));
+        CHECK(size_t(cis.gcount()) == size_t(5 * bs + 7) && memcmp(out.data(), in.data(), size_t(5 * bs + 7)) == 0);
+    }
+}
+
 int main(int argc, char** argv)
 {
     const std::string what = argc > 1 ? argv[1] : "all";
@@ -260,6 +353,7 @@ int main(int argc, char** argv)
         if (what == "all" || what == "streams") testStreams();
         if (what == "all" || what == "seek") testSeek();
         if (what == "all" || what == "range") testBlockRange();
+        if (what == "all" || what == "pipeline") testPipeline();
     } catch (const std::exception& e) {
         printf("EXCEPTION %s\n", e.what());
         return 2;
