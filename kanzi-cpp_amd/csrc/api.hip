@@ -38,8 +38,8 @@ struct Ctx {
     std::recursive_mutex mu;     // a context is one stream + one set of workspaces: calls on it are serialised
     // Copy engine beside the kernels: one stream per direction, outside the lock above, so that a host thread can move the next
     // batch in (or the last one out) while another thread sits in knz_hip_encode_blocks / knz_hip_decode_blocks.
-    hipStream_t stream2 = nullptr;       // second stream for the half-batch split of the BWT stages
-    hipEvent_t evFork = nullptr, evJoin = nullptr;
+    hipStream_t stream2[3] = { nullptr, nullptr, nullptr };       // further streams for the split of the BWT stages
+    hipEvent_t evFork = nullptr, evJoin[3] = { nullptr, nullptr, nullptr };
     std::mutex copyMu;
     hipStream_t copyIn = nullptr, copyOut = nullptr;
     std::vector<hipEvent_t> copyIdle;
@@ -170,9 +170,8 @@ void knz_hip_destroy(knz_ctx* ctx)
     if (c->pinned) hipHostFree(c->pinned);
     for (auto& kv : c->copyPending) { hipEventSynchronize(kv.second); hipEventDestroy(kv.second); }
     for (auto& e : c->copyIdle) hipEventDestroy(e);
-    if (c->stream2) hipStreamDestroy(c->stream2);
+    for (int k = 0; k < 3; k++) { if (c->stream2[k]) hipStreamDestroy(c->stream2[k]); if (c->evJoin[k]) hipEventDestroy(c->evJoin[k]); }
     if (c->evFork) hipEventDestroy(c->evFork);
-    if (c->evJoin) hipEventDestroy(c->evJoin);
     if (c->copyIn) hipStreamDestroy(c->copyIn);
     if (c->copyOut) hipStreamDestroy(c->copyOut);
     if (c->ownStream) hipStreamDestroy(c->stream);
@@ -393,45 +392,59 @@ static size_t stage_scratch_u32(int t, int nBlocks, u32 maxLen, bool forward = t
     }
 }
 
-// The BWT stages of a batch in two halves at once. A suffix sort (and the inverse's list ranking) is a long sequence of launches with
-// host read-backs in between and rounds that occupy a fraction of the CUs; the blocks are independent, so the second half of them
-// runs on a second stream, driven by a helper thread with its own scratch and read-back area, while the caller's thread drives the
-// first half. Not while per-kernel timing is on (the timing hooks belong to the caller's thread), and KNZ_BWT_SPLIT=0 turns it off.
-static bool bwt_split_wanted(const Ctx* c, int nBlocks)
+// The BWT stages of a batch in several parts at once. A suffix sort (and the inverse's list ranking) is a long sequence of launches
+// with host read-backs in between and rounds that occupy a fraction of the CUs; the blocks are independent, so the batch is cut
+// into KNZ_BWT_SPLIT (default 2, 1 = off, at most 4) runs of blocks: the caller's thread drives the first on the context's stream,
+// helper threads drive the others on streams of their own, each with its own scratch and read-back area. Not while per-kernel
+// timing is on (the timing hooks belong to the caller's thread).
+static int bwt_parts_wanted(const Ctx* c, int nBlocks)
 {
-    static const int env = [] { const char* e = getenv("KNZ_BWT_SPLIT"); return e ? atoi(e) : 1; }();
-    return env != 0 && nBlocks >= 4 && !c->profiling;
+    static const int env = [] { const char* e = getenv("KNZ_BWT_SPLIT"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+    if (c->profiling) return 1;
+    int parts = env;
+    while (parts > 1 && nBlocks < 2 * parts) parts--;            // at least two blocks per part
+    return parts;
 }
 
-static int bwt_in_halves(Ctx* c, hipStream_t s, const XfStage& st, const std::function<size_t(int)>& scratchBytes,
-                         const std::function<int(hipStream_t, const XfStage&, void*, size_t, u32*)>& launch, const char* what)
+static int bwt_in_parts(Ctx* c, hipStream_t s, const XfStage& st, int parts, const std::function<size_t(int)>& scratchBytes,
+                        const std::function<int(hipStream_t, const XfStage&, void*, size_t, u32*)>& launch, const char* what)
 {
-    const int nA = (st.nBlocks + 1) / 2, nB = st.nBlocks - nA;
-    XfStage a = st, b = st;
-    a.nBlocks = nA;
-    b.nBlocks = nB; b.src += nA; b.dst += nA; b.len += nA; b.cap += nA; b.ok += nA; b.newLen += nA;
-    const size_t bytesA = scratchBytes(nA), bytesB = scratchBytes(nB);
-    void *scA, *scB;
-    if (int r = ws_get(c, "bwtScratch", bytesA, &scA)) return r;
-    if (int r = ws_get(c, "bwtScratch2", bytesB, &scB)) return r;
-    if (c->stream2 == nullptr) {
-        HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-        HIPCHK(c, hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
-        HIPCHK(c, hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming));
+    static const char* const wsName[4] = { "bwtScratch", "bwtScratch2", "bwtScratch3", "bwtScratch4" };
+    XfStage part[4];
+    void* sc[4];
+    size_t bytes[4];
+    int first = 0;
+    for (int k = 0; k < parts; k++) {
+        const int nb = st.nBlocks / parts + (k < st.nBlocks % parts ? 1 : 0);
+        part[k] = st;
+        part[k].nBlocks = nb;
+        part[k].src += first; part[k].dst += first; part[k].len += first; part[k].cap += first; part[k].ok += first; part[k].newLen += first;
+        first += nb;
+        bytes[k] = scratchBytes(nb);
+        if (int r = ws_get(c, wsName[k], bytes[k], &sc[k])) return r;
     }
-    HIPCHK(c, hipEventRecord(c->evFork, s));                     // the second stream starts behind what is queued on the first
-    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evFork, 0));
-    int rcB = 0;
-    u32* pinB = reinterpret_cast<u32*>(c->pinned) + 32768;       // read-back area of the helper (the context's is 1 MiB)
-    std::thread helper([&] {
-        if (hipSetDevice(c->device) != hipSuccess) { rcB = -1; return; }
-        rcB = launch(c->stream2, b, scB, bytesB, pinB);
-    });
-    const int rcA = launch(s, a, scA, bytesA, reinterpret_cast<u32*>(c->pinned));
-    helper.join();
-    if (rcA != 0 || rcB != 0) return fail(c, -1, "%s failed: %s", what, hipGetErrorString(hipGetLastError()));
-    HIPCHK(c, hipEventRecord(c->evJoin, c->stream2));            // and the first one continues behind the second
-    HIPCHK(c, hipStreamWaitEvent(s, c->evJoin, 0));
+    for (int k = 1; k < parts; k++)
+        if (c->stream2[k - 1] == nullptr) HIPCHK(c, hipStreamCreateWithFlags(&c->stream2[k - 1], hipStreamNonBlocking));
+    if (c->evFork == nullptr) {
+        HIPCHK(c, hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
+        for (int k = 0; k < 3; k++) HIPCHK(c, hipEventCreateWithFlags(&c->evJoin[k], hipEventDisableTiming));
+    }
+    HIPCHK(c, hipEventRecord(c->evFork, s));                     // the other streams start behind what is queued on the first
+    for (int k = 1; k < parts; k++) HIPCHK(c, hipStreamWaitEvent(c->stream2[k - 1], c->evFork, 0));
+    int rc[4] = { 0, 0, 0, 0 };
+    std::thread helper[3];
+    for (int k = 1; k < parts; k++)
+        helper[k - 1] = std::thread([&, k] {
+            if (hipSetDevice(c->device) != hipSuccess) { rc[k] = -1; return; }
+            rc[k] = launch(c->stream2[k - 1], part[k], sc[k], bytes[k], reinterpret_cast<u32*>(c->pinned) + 32768 * k);   // own read-back area (the context's is 1 MiB)
+        });
+    rc[0] = launch(s, part[0], sc[0], bytes[0], reinterpret_cast<u32*>(c->pinned));
+    for (int k = 1; k < parts; k++) helper[k - 1].join();
+    for (int k = 0; k < parts; k++) if (rc[k] != 0) return fail(c, -1, "%s failed: %s", what, hipGetErrorString(hipGetLastError()));
+    for (int k = 1; k < parts; k++) {                            // and the first stream continues behind the others
+        HIPCHK(c, hipEventRecord(c->evJoin[k - 1], c->stream2[k - 1]));
+        HIPCHK(c, hipStreamWaitEvent(s, c->evJoin[k - 1], 0));
+    }
     return 0;
 }
 
@@ -452,8 +465,8 @@ static int run_forward_stage(Ctx* c, hipStream_t s, int t, const XfStage& st)
         break;
     }
     case KNZ_T_BWT: {
-        if (bwt_split_wanted(c, st.nBlocks))
-            return bwt_in_halves(c, s, st, [&](int nb) { return bwt_forward_scratch_bytes(nb, st.maxLen, (size_t)nb * st.maxLen); },
+        if (const int parts = bwt_parts_wanted(c, st.nBlocks); parts > 1)
+            return bwt_in_parts(c, s, st, parts, [&](int nb) { return bwt_forward_scratch_bytes(nb, st.maxLen, (size_t)nb * st.maxLen); },
                                  [](hipStream_t q, const XfStage& h, void* sc, size_t bytes, u32* pin) { return launch_bwt_forward(q, h, sc, bytes, pin); }, "BWT forward");
         const size_t bytes = bwt_forward_scratch_bytes(st.nBlocks, st.maxLen, (size_t)st.nBlocks * st.maxLen);
         void* sc;
@@ -477,8 +490,8 @@ static int run_inverse_stage(Ctx* c, hipStream_t s, int t, const XfStage& st)
     case KNZ_T_TIMESTAMP: launch_sbrt_inverse(s, st, 3); break;
     case KNZ_T_LZ: case KNZ_T_LZX: launch_lz_inverse(s, st); break;
     case KNZ_T_BWT: {
-        if (bwt_split_wanted(c, st.nBlocks))
-            return bwt_in_halves(c, s, st, [&](int nb) { return bwt_inverse_scratch_bytes(nb, st.maxLen, (size_t)nb * st.maxLen); },
+        if (const int parts = bwt_parts_wanted(c, st.nBlocks); parts > 1)
+            return bwt_in_parts(c, s, st, parts, [&](int nb) { return bwt_inverse_scratch_bytes(nb, st.maxLen, (size_t)nb * st.maxLen); },
                                  [](hipStream_t q, const XfStage& h, void* sc, size_t bytes, u32* pin) { return launch_bwt_inverse(q, h, sc, bytes, pin); }, "BWT inverse");
         const size_t bytes = bwt_inverse_scratch_bytes(st.nBlocks, st.maxLen, (size_t)st.nBlocks * st.maxLen);
         void* sc;
