@@ -394,12 +394,12 @@ static size_t stage_scratch_u32(int t, int nBlocks, u32 maxLen, bool forward = t
 
 // The BWT stages of a batch in several parts at once. A suffix sort (and the inverse's list ranking) is a long sequence of launches
 // with host read-backs in between and rounds that occupy a fraction of the CUs; the blocks are independent, so the batch is cut
-// into KNZ_BWT_SPLIT (default 2, 1 = off, at most 4) runs of blocks: the caller's thread drives the first on the context's stream,
+// into KNZ_BWT_SPLIT (default 3, 1 = off, at most 4; 26 blocks of 8 MiB: 63.7 / 60.4 / 59.9 / 60.3 ms per step with 1 / 2 / 3 / 4) runs of blocks: the caller's thread drives the first on the context's stream,
 // helper threads drive the others on streams of their own, each with its own scratch and read-back area. Not while per-kernel
 // timing is on (the timing hooks belong to the caller's thread).
 static int bwt_parts_wanted(const Ctx* c, int nBlocks)
 {
-    static const int env = [] { const char* e = getenv("KNZ_BWT_SPLIT"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+    static const int env = [] { const char* e = getenv("KNZ_BWT_SPLIT"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
     if (c->profiling) return 1;
     int parts = env;
     while (parts > 1 && nBlocks < 2 * parts) parts--;            // at least two blocks per part
