@@ -374,7 +374,9 @@ def main():
             bound="hbm", stage=dom_stage, kernel=dk_name.split("@")[0], achieved=round(achieved, 2), peak=8000.0, unit="GB/s",
             frac=round(achieved / 8000.0, 5), traffic=traffic, traffic_source=traffic_source, algorithmic_bytes=alg,
             stage_ms=round(dom["ms"], 4), stage_launches_per_step=round(dom["launches"], 1),
-            note="dominant STAGE: algorithmic bytes of one pass of the stage / summed HIP-event time of all its launches in one step",
+            note="dominant STAGE: algorithmic bytes of one pass of the stage / summed HIP-event time of all its launches in one step; per-kernel "
+                 "timing runs every launch of a step back to back on one stream, while the timed steps (value, enc_MBps, dec_MBps, pipeline) run the "
+                 "BWT stages of a batch in 3 parts on 3 streams (KNZ_BWT_SPLIT), so the stage times add up to more than ms_per_step",
             dominant_kernel=dict(name=dk_name.split("@")[0], avg_ms=round(dk["ms_per_step"] / dk["launches_per_step"], 4),
                                  launches_per_step=round(dk["launches_per_step"], 1), ms_per_step=round(dk["ms_per_step"], 4)),
             pipeline=dict(algorithmic_bytes=pipe_bytes, ms=round(step_ms, 4), achieved=round(pipe_bytes / (step_ms * 1e-3) / 1e9, 2),
