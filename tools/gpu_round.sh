@@ -21,14 +21,14 @@ for s in "$@"; do
     bench7) timeout 600 python bench.py --config 7 --limit 211957760 --steps 3 --warmup 1 --no-e2e > $OUT/bench7.json 2> $OUT/bench7.err; echo "bench7 rc=$?" >> $OUT/summary.txt; cat $OUT/bench7.json ;;
     bench4) timeout 900 python bench.py --config 4 --limit 134217728 --steps 1 --warmup 1 --no-e2e > $OUT/bench4.json 2> $OUT/bench4.err; echo "bench4 rc=$?" >> $OUT/summary.txt; cat $OUT/bench4.json ;;
     bench5) timeout 900 python bench.py --config 5 --steps 2 --warmup 1 --no-e2e > $OUT/bench5.json 2> $OUT/bench5.err; echo "bench5 rc=$?" >> $OUT/summary.txt; cat $OUT/bench5.json ;;
-    prof3) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof3 -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-e2e > $GRAFT_REPO_ROOT/$OUT/prof3.log 2>&1); echo "prof3 rc=$?" >> $OUT/summary.txt
+    prof3) (cd /tmp && export KNZ_BWT_SPLIT=1 && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof3 -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-e2e > $GRAFT_REPO_ROOT/$OUT/prof3.log 2>&1); echo "prof3 rc=$?" >> $OUT/summary.txt
            f=$(find $OUT/prof3 -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && python tools/rocprof_csv_summary.py $f > $OUT/prof3_kernel_stats.txt && cp $f $OUT/prof3_kernel_stats.csv && head -30 $OUT/prof3_kernel_stats.txt ;;
     prof2) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof2 -- python $GRAFT_REPO_ROOT/bench.py --config 2 --steps 5 --warmup 2 --no-cpu --no-e2e > $GRAFT_REPO_ROOT/$OUT/prof2.log 2>&1); echo "prof2 rc=$?" >> $OUT/summary.txt
            f=$(find $OUT/prof2 -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && python tools/rocprof_csv_summary.py $f > $OUT/prof2_kernel_stats.txt && cp $f $OUT/prof2_kernel_stats.csv && head -20 $OUT/prof2_kernel_stats.txt ;;
-    pmc3) for c in FETCH_SIZE WRITE_SIZE; do (cd /tmp && timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc3_$c -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu --no-e2e > $GRAFT_REPO_ROOT/$OUT/pmc3_$c.log 2>&1); echo "pmc3 $c rc=$?" >> $OUT/summary.txt; done
+    pmc3) for c in FETCH_SIZE WRITE_SIZE; do (cd /tmp && export KNZ_BWT_SPLIT=1 && timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc3_$c -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu --no-e2e > $GRAFT_REPO_ROOT/$OUT/pmc3_$c.log 2>&1); echo "pmc3 $c rc=$?" >> $OUT/summary.txt; done
           ff=$(find $OUT/pmc3_FETCH_SIZE -name '*counter_collection.csv' | head -1); fw=$(find $OUT/pmc3_WRITE_SIZE -name '*counter_collection.csv' | head -1)
           [ -n "$ff" ] && [ -n "$fw" ] && python tools/pmc_stage_summary.py $ff $fw 3 $OUT/pmc3_traffic.json $OUT/pmc3_traffic.txt && cat $OUT/pmc3_traffic.txt | head -40 ;;
-    trace3) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/trace3 -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu --no-e2e > $GRAFT_REPO_ROOT/$OUT/trace3.log 2>&1); echo "trace3 rc=$?" >> $OUT/summary.txt
+    trace3) (cd /tmp && export KNZ_BWT_SPLIT=1 && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/trace3 -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu --no-e2e > $GRAFT_REPO_ROOT/$OUT/trace3.log 2>&1); echo "trace3 rc=$?" >> $OUT/summary.txt
            f=$(find $OUT/trace3 -name '*kernel_trace.csv' | head -1); [ -n "$f" ] && python tools/rocprof_trace_list.py $f 1 > $OUT/trace3_bwt_forward.txt && tail -3 $OUT/trace3_bwt_forward.txt ;;
     cmd:*) echo "running custom: ${s#cmd:}"; timeout 600 bash -c "${s#cmd:}" < /dev/null > $OUT/custom.log 2>&1; echo "custom rc=$?" >> $OUT/summary.txt; tail -40 $OUT/custom.log ;;
     *) echo "unknown step: $s" ;;
