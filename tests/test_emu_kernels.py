@@ -116,3 +116,19 @@ def test_bwt_inverse_kernels_emulated(tmp_path):
         for order in ("0", "2"):
             r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900, env=dict(os.environ, HIPEMU_ORDER=order))
             assert r.returncode == 0, (i, order, r.stdout[-2000:] + r.stderr[-2000:])
+
+
+def test_mtft_kernels_emulated(tmp_path):
+    # forward and inverse MTFT (4 KiB tiles, two-level scans over the tile tables) against oracle/transforms.c; sizes around tile and
+    # segment borders: 1 tile, 2..5 tiles (segments of 2-4 tiles), 70 tiles (segments of 16), ragged tails, empty-ish blocks
+    exe = build("mtft_emu", tmp_path)
+    c = knzlib.corpus()
+    rng = np.random.default_rng(5)
+    blocks = [c.text(300000, 1)[:287000], bytes(9000), rng.integers(0, 256, 4096, dtype=np.uint8).tobytes(), rng.integers(0, 256, 4097, dtype=np.uint8).tobytes(),
+              c.mixed(300000, 2)[250000:270481], b"a", b"abracadabra", bytes(range(256)) * 33, rng.integers(0, 3, 12289, dtype=np.uint8).tobytes(),
+              c.text(20000, 9)[:16384]]
+    path = str(tmp_path / "mtft.bin")
+    write_case(path, blocks)
+    for order in ("0", "1", "2"):
+        r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900, env=dict(os.environ, HIPEMU_ORDER=order))
+        assert r.returncode == 0, (order, r.stdout[-2000:] + r.stderr[-2000:])

@@ -120,6 +120,17 @@ static inline int __shfl_xor(int var, int mask, int width = 64)
     return (int)(unsigned)v[lane ^ mask];
 }
 static inline int __builtin_amdgcn_readlane(int var, int src) { return __shfl(var, src & 63, 64); }
+// DPP data movement, the controls the kernels use: 0x138 = wave_shr:1 (lane i takes lane i-1; lane 0 keeps `old`, bound_ctrl off)
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int rowMask, int bankMask, bool boundCtrl)
+{
+    unsigned long long v[64], act;
+    hipemu::wave_exchange((unsigned long long)(unsigned)src, v, &act);
+    const int lane = (int)(threadIdx.x & 63);
+    (void)rowMask; (void)bankMask; (void)boundCtrl;
+    if (ctrl == 0x138) return lane == 0 ? old : (int)(unsigned)v[lane - 1];
+    fprintf(stderr, "hipemu: DPP control 0x%x not emulated\n", ctrl);
+    abort();
+}
 static inline int __builtin_amdgcn_readfirstlane(int var)
 {
     unsigned long long v[64], act;
