@@ -378,7 +378,6 @@ static int seq_alloc(Ctx* c, int nBlocks, u64 S, bool needAB, size_t scratchU32,
         if (int r = ws_get(c, "xfA", (size_t)S * nb + 256, (void**)&w->A)) return r;
         if (int r = ws_get(c, "xfB", (size_t)S * nb + 256, (void**)&w->B)) return r;
     }
-    w->a.origLen = nullptr;
     w->scratch = nullptr;
     if (scratchU32) { if (int r = ws_get(c, "xfScratch", scratchU32 * 4 + 64, (void**)&w->scratch)) return r; }
     return 0;
@@ -506,127 +505,6 @@ static int run_inverse_stage(Ctx* c, hipStream_t s, int t, const XfStage& st)
 }
 
 // ------------------------------------------------------------------------------------------------
-// A batch as several pipelines. The blocks of a batch are independent until the bit assembly, and the stages of the path are bound
-// by different things (suffix sorting: random memory accesses and host read-backs; MTFT: vector instructions; entropy decoding: the
-// latency of a 4,096-step chain), so the batch is cut into KNZ_PIPE_PARTS runs of blocks, each of which goes through its transform
-// chain (and, decoding, its entropy stage) on a stream of its own -- the caller's thread drives the first run on the context's
-// stream, helper threads the others -- and what one run leaves idle another one uses. Not while per-kernel timing is on (the
-// timing hooks belong to the caller's thread); when it is off the BWT stages alone can still be cut (KNZ_BWT_SPLIT above).
-// ------------------------------------------------------------------------------------------------
-struct PartRun {
-    int first = 0, nb = 0;
-    hipStream_t q = nullptr;
-    u32* pin = nullptr;                      // host read-back area of the run
-    u32* xfSc = nullptr;                     // stage scratch (MTFT / ZRLT tile tables)
-    void* bwtSc = nullptr; size_t bwtBytes = 0;
-    void* lzSc = nullptr; size_t lzBytes = 0;
-};
-
-static int pipe_parts_wanted(const Ctx* c, int nBlocks)
-{
-    static const int env = [] { const char* e = getenv("KNZ_PIPE_PARTS"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
-    if (c->profiling) return 1;
-    int parts = env;
-    while (parts > 1 && nBlocks < 2 * parts) parts--;            // at least two blocks per run
-    return parts;
-}
-
-static SeqArrays seq_sub(const SeqArrays& a, int f)
-{
-    SeqArrays r = a;
-    r.where += f; r.swaps += f; r.active += f; r.len += f; r.alen += f; r.skip += f; r.src += f; r.dst += f; r.cap += f; r.ok += f; r.newLen += f;
-    if (r.origLen) r.origLen += f;
-    if (r.dataCap) r.dataCap += f;
-    if (r.bufCap) r.bufCap += f;
-    return r;
-}
-
-// the runs of a batch with everything they will need allocated up front (ws_get is not for helper threads); run 0 keeps the
-// context's stream and the stage scratch seq_alloc made
-static int parts_prepare(Ctx* c, hipStream_t s, const int* tok, int nTok, int nBlocks, u32 S, bool forward, u32* scratch0, int parts, PartRun* pr)
-{
-    static const char* const xfName[4] = { "xfScratch", "xfScratch2", "xfScratch3", "xfScratch4" };
-    static const char* const bwtName[4] = { "bwtScratch", "bwtScratch2", "bwtScratch3", "bwtScratch4" };
-    static const char* const lzName[4] = { "lzScratch", "lzScratch2", "lzScratch3", "lzScratch4" };
-    int first = 0;
-    for (int k = 0; k < parts; k++) {
-        PartRun& r = pr[k];
-        r.first = first;
-        r.nb = nBlocks / parts + (k < nBlocks % parts ? 1 : 0);
-        first += r.nb;
-        r.pin = reinterpret_cast<u32*>(c->pinned) + 32768 * k;
-        if (k == 0) { r.q = s; r.xfSc = scratch0; }
-        else {
-            if (c->stream2[k - 1] == nullptr) HIPCHK(c, hipStreamCreateWithFlags(&c->stream2[k - 1], hipStreamNonBlocking));
-            r.q = c->stream2[k - 1];
-            size_t scratch = 0;
-            for (int i = 0; i < nTok; i++) { const size_t q = stage_scratch_u32(tok[i], r.nb, S, forward); if (q > scratch) scratch = q; }
-            if (scratch) { if (int e = ws_get(c, xfName[k], scratch * 4 + 64, (void**)&r.xfSc)) return e; }
-        }
-        for (int i = 0; i < nTok; i++) {
-            if (tok[i] == KNZ_T_BWT) {
-                r.bwtBytes = forward ? bwt_forward_scratch_bytes(r.nb, S, (size_t)r.nb * S) : bwt_inverse_scratch_bytes(r.nb, S, (size_t)r.nb * S);
-                if (int e = ws_get(c, bwtName[k], r.bwtBytes, &r.bwtSc)) return e;
-            } else if ((tok[i] == KNZ_T_LZ || tok[i] == KNZ_T_LZX) && forward) {
-                const size_t b = lz_forward_scratch_bytes(tok[i], r.nb, S);
-                if (b > r.lzBytes) { r.lzBytes = b; if (int e = ws_get(c, lzName[k], r.lzBytes, &r.lzSc)) return e; }
-            }
-        }
-    }
-    if (c->evFork == nullptr) {
-        HIPCHK(c, hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
-        for (int k = 0; k < 3; k++) HIPCHK(c, hipEventCreateWithFlags(&c->evJoin[k], hipEventDisableTiming));
-    }
-    return 0;
-}
-
-// run `body` for every run at once; everything queued on the context's stream so far is ahead of all of them, and the context's
-// stream continues behind all of them
-static int parts_run(Ctx* c, hipStream_t s, const PartRun* pr, int parts, const std::function<int(const PartRun&)>& body, const char* what)
-{
-    HIPCHK(c, hipEventRecord(c->evFork, s));
-    for (int k = 1; k < parts; k++) HIPCHK(c, hipStreamWaitEvent(pr[k].q, c->evFork, 0));
-    int rc[4] = { 0, 0, 0, 0 };
-    std::thread helper[3];
-    for (int k = 1; k < parts; k++)
-        helper[k - 1] = std::thread([&, k] {
-            if (hipSetDevice(c->device) != hipSuccess) { rc[k] = -1; return; }
-            rc[k] = body(pr[k]);
-        });
-    rc[0] = body(pr[0]);
-    for (int k = 1; k < parts; k++) helper[k - 1].join();
-    for (int k = 0; k < parts; k++) if (rc[k] != 0) return fail(c, rc[k] > 0 ? rc[k] : -1, "%s failed: %s", what, hipGetErrorString(hipGetLastError()));
-    for (int k = 1; k < parts; k++) {
-        HIPCHK(c, hipEventRecord(c->evJoin[k - 1], pr[k].q));
-        HIPCHK(c, hipStreamWaitEvent(s, c->evJoin[k - 1], 0));
-    }
-    return 0;
-}
-
-// one stage of one run: scratch comes with the run, nothing is allocated, nothing is cut further; 0 or -1
-static int run_stage_part(int t, bool forward, const XfStage& st, const PartRun& r)
-{
-    hipStream_t q = r.q;
-    switch (t) {
-    case KNZ_T_ZRLT: if (forward) launch_zrlt_forward(q, st); else launch_zrlt_inverse(q, st); break;
-    case KNZ_T_MTFT: if (forward) launch_mtft_forward(q, st); else launch_mtft_inverse(q, st); break;
-    case KNZ_T_SRT: if (forward) launch_srt_forward(q, st); else launch_srt_inverse(q, st); break;
-    case KNZ_T_RLT: if (forward) launch_rlt_forward(q, st); else launch_rlt_inverse(q, st); break;
-    case KNZ_T_RANK: if (forward) launch_sbrt_forward(q, st, 2); else launch_sbrt_inverse(q, st, 2); break;
-    case KNZ_T_TIMESTAMP: if (forward) launch_sbrt_forward(q, st, 3); else launch_sbrt_inverse(q, st, 3); break;
-    case KNZ_T_LZ: case KNZ_T_LZX:
-        if (forward) { if (launch_lz_forward(q, st, t, r.lzSc, r.lzBytes) != 0) return -1; }
-        else launch_lz_inverse(q, st);
-        break;
-    case KNZ_T_BWT:
-        if ((forward ? launch_bwt_forward(q, st, r.bwtSc, r.bwtBytes, r.pin) : launch_bwt_inverse(q, st, r.bwtSc, r.bwtBytes, r.pin)) != 0) return -1;
-        break;
-    default: break;
-    }
-    return 0;
-}
-
-// ------------------------------------------------------------------------------------------------
 // encode
 // ------------------------------------------------------------------------------------------------
 // capsMode: 0 = reference stream buffers (jobs model), otherwise every destination capacity = capsMode (per-stage API)
@@ -725,30 +603,8 @@ static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t 
     }
 
     // ---- transform stages
-    const int pipeParts = (realStages && !direct) ? pipe_parts_wanted(c, nBlocks) : 1;
     if (direct) launch_seq_fwd_direct(s, w.a, d_origLen, n, bs, nBlocks, nTok, d_in, w.d_viewPtr);
-    if (pipeParts > 1) {
-        PartRun pr[4];
-        if (int r = parts_prepare(c, s, tok, nTok, nBlocks, (u32)S, true, w.scratch, pipeParts, pr)) return r;
-        const int rcp = parts_run(c, s, pr, pipeParts, [&](const PartRun& r) -> int {
-            const SeqArrays a = seq_sub(w.a, r.first);
-            const u8* in_k = d_in + (size_t)r.first * bs;
-            u8* A_k = w.A + (size_t)r.first * S; u8* B_k = w.B + (size_t)r.first * S;
-            for (int i = 0; i < nTok; i++) {
-                launch_seq_fwd_prepare(r.q, a, r.nb, i, in_k, bs, A_k, B_k, S);
-                if (tok[i] == KNZ_T_NONE) { launch_seq_fwd_null(r.q, a, r.nb, i); continue; }
-                XfStage st;
-                st.src = a.src; st.dst = a.dst; st.len = a.alen; st.cap = a.cap; st.ok = a.ok; st.newLen = a.newLen;
-                st.nBlocks = r.nb; st.maxLen = (u32)S; st.scratchU32 = r.xfSc; st.entropyType = p->entropy_type;
-                if (run_stage_part(tok[i], true, st, r) != 0) return -1;
-                launch_seq_fwd_commit(r.q, a, r.nb, i);
-            }
-            launch_seq_fwd_finish(r.q, a, r.nb, in_k, bs, A_k, B_k, S, w.d_viewPtr + r.first);
-            return 0;
-        }, "transform chain");
-        if (rcp) return rcp;
-    }
-    for (int i = 0; i < nTok && !direct && pipeParts <= 1; i++) {
+    for (int i = 0; i < nTok && !direct; i++) {
         launch_seq_fwd_prepare(s, w.a, nBlocks, i, d_in, bs, w.A, w.B, S);
         if (tok[i] == KNZ_T_NONE) {
             launch_seq_fwd_null(s, w.a, nBlocks, i);
@@ -760,7 +616,7 @@ static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t 
         if (int r = run_forward_stage(c, s, tok[i], st)) return r;
         launch_seq_fwd_commit(s, w.a, nBlocks, i);
     }
-    if (!direct && pipeParts <= 1) launch_seq_fwd_finish(s, w.a, nBlocks, d_in, bs, w.A, w.B, S, w.d_viewPtr);
+    if (!direct) launch_seq_fwd_finish(s, w.a, nBlocks, d_in, bs, w.A, w.B, S, w.d_viewPtr);
     BlockView view;
     view.ptr = w.d_viewPtr; view.len = w.a.len;
     u32* d_blockLen = w.a.len;
@@ -905,6 +761,7 @@ static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_
     SeqWs w;
     if (int r = seq_alloc(c, nBlocks, S, realStages, scratch, &w)) return r;
     const int maxChunks = (int)((S + ENT_CHUNK - 1) / ENT_CHUNK);
+    const size_t nSlots = (size_t)nBlocks * maxChunks;
     const u64 outStride = framing ? bs : 0;
 
     // entropy stage decodes into workspace A (or straight into d_out when no transform applies)
@@ -914,62 +771,32 @@ static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_
     u32 realMask = 0;
     for (int i = 0; i < nTok; i++) if (tok[i] != KNZ_T_NONE) realMask |= 1u << (7 - i);
     launch_seq_inv_entropy_dst(s, w.a, d_blocks, nBlocks, d_out, outStride, w.A, S, w.d_entDst, realMask, unit, (u64)outCap);
-    // the entropy stage of a run of blocks (ANS1 keeps per-call tables: it always runs over the whole batch)
-    void* d_entMeta = nullptr;
-    size_t entMetaPerBlock = 0;
-    if (p->entropy_type == KNZ_E_ANS0) { entMetaPerBlock = ans0_dec_chunk_bytes() * (size_t)maxChunks; if (int r = ws_get(c, "ansDecChunks", entMetaPerBlock * nBlocks, &d_entMeta)) return r; }
-    else if (p->entropy_type == KNZ_E_HUFFMAN) { entMetaPerBlock = huffman_dec_chunk_bytes() * (size_t)maxChunks; if (int r = ws_get(c, "hufDecChunks", entMetaPerBlock * nBlocks, &d_entMeta)) return r; }
-    auto entropy_decode = [&](hipStream_t q, int first, int nb) {
-        DecBlock* blk = d_blocks + first;
-        u8* const* dstp = w.d_entDst + first;
-        void* meta = d_entMeta ? static_cast<u8*>(d_entMeta) + entMetaPerBlock * (size_t)first : nullptr;
-        if (p->entropy_type == KNZ_E_ANS0) launch_ans0_decode(q, src, blk, nb, maxChunks, meta, dstp);
-        else if (p->entropy_type == KNZ_E_HUFFMAN) launch_huffman_decode(q, src, blk, nb, maxChunks, meta, dstp);
-        else if (p->entropy_type == KNZ_E_FPAQ) launch_fpaq_decode(q, src, blk, nb, dstp);
-        else launch_none_decode(q, src, blk, nb, dstp);
-    };
-    const bool ans1 = (p->entropy_type == KNZ_E_ANS1);
-    const int pipeParts = realStages ? pipe_parts_wanted(c, nBlocks) : 1;
-    if (ans1) {
+    if (p->entropy_type == KNZ_E_ANS0) {
+        void* d_meta;
+        if (int r = ws_get(c, "ansDecChunks", ans0_dec_chunk_bytes() * nSlots, &d_meta)) return r;
+        launch_ans0_decode(s, src, d_blocks, nBlocks, maxChunks, d_meta, w.d_entDst);
+    } else if (p->entropy_type == KNZ_E_ANS1) {
         const int chunksPerBlock = (int)((S + ANS1_CHUNK - 1) / ANS1_CHUNK);
         const size_t nCh = (size_t)nBlocks * chunksPerBlock;
         Ans1DecWs aw;
         if (int r = ws_get(c, "ans1Meta", ans1_meta_bytes(nCh), &aw.meta)) return r;
         if (int r = ws_get(c, "ans1SlotTab", ans1_slottab_bytes(nCh), (void**)&aw.slotTab)) return r;
         launch_ans1_decode(s, src, d_blocks, nBlocks, chunksPerBlock, aw, w.d_entDst);
-    } else if (pipeParts <= 1) {
-        entropy_decode(s, 0, nBlocks);
+    } else if (p->entropy_type == KNZ_E_HUFFMAN) {
+        void* d_meta;
+        if (int r = ws_get(c, "hufDecChunks", huffman_dec_chunk_bytes() * nSlots, &d_meta)) return r;
+        launch_huffman_decode(s, src, d_blocks, nBlocks, maxChunks, d_meta, w.d_entDst);
+    } else if (p->entropy_type == KNZ_E_FPAQ) {
+        launch_fpaq_decode(s, src, d_blocks, nBlocks, w.d_entDst);
+    } else {
+        launch_none_decode(s, src, d_blocks, nBlocks, w.d_entDst);
     }
     // inverse transforms, last stage first (TransformSequence.hpp:197-224)
     if (realStages) {
         const u32 capFinal = framing ? bs : (u32)p->jobs;           // per-stage API passes its capacity in p->jobs
         const u32 blkLenModel = std::max(bs + 512u, bs + (bs >> 4));
         const u32 capMid = framing ? (u32)std::min<u64>(S, blkLenModel) : (u32)p->jobs;
-        if (pipeParts > 1) {
-            PartRun pr[4];
-            if (int r = parts_prepare(c, s, tok, nTok, nBlocks, (u32)S, false, w.scratch, pipeParts, pr)) return r;
-            const int rcp = parts_run(c, s, pr, pipeParts, [&](const PartRun& r) -> int {
-                if (!ans1) entropy_decode(r.q, r.first, r.nb);
-                const SeqArrays a = seq_sub(w.a, r.first);
-                DecBlock* blk = d_blocks + r.first;
-                u8* out_k = d_out + (size_t)r.first * outStride;
-                u8* A_k = w.A + (size_t)r.first * S; u8* B_k = w.B + (size_t)r.first * S;
-                const u64 before = (u64)r.first * outStride;
-                const u64 cap_k = framing ? ((u64)outCap > before ? (u64)outCap - before : 0) : ~0ull;
-                for (int i = nTok - 1; i >= 0; i--) {
-                    if (tok[i] == KNZ_T_NONE) continue;
-                    launch_seq_inv_prepare(r.q, a, blk, r.nb, i, out_k, outStride, A_k, B_k, S, capMid, capFinal, realMask, cap_k);
-                    XfStage st;
-                    st.src = a.src; st.dst = a.dst; st.len = a.alen; st.cap = a.cap; st.ok = a.ok; st.newLen = a.newLen;
-                    st.nBlocks = r.nb; st.maxLen = (u32)S; st.scratchU32 = r.xfSc; st.entropyType = p->entropy_type;
-                    if (run_stage_part(tok[i], false, st, r) != 0) return -1;
-                    launch_seq_inv_commit(r.q, a, blk, r.nb, i, tok[i]);
-                }
-                return 0;
-            }, "inverse transform chain");
-            if (rcp) return rcp;
-        }
-        for (int i = nTok - 1; i >= 0 && pipeParts <= 1; i--) {
+        for (int i = nTok - 1; i >= 0; i--) {
             if (tok[i] == KNZ_T_NONE) continue;
             launch_seq_inv_prepare(s, w.a, d_blocks, nBlocks, i, d_out, outStride, w.A, w.B, S, capMid, capFinal, realMask, framing ? (u64)outCap : ~0ull);
             XfStage st;
