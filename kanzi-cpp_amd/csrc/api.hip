@@ -423,6 +423,7 @@ static int bwt_in_parts(Ctx* c, hipStream_t s, const XfStage& st, int parts, con
         bytes[k] = scratchBytes(nb);
         if (int r = ws_get(c, wsName[k], bytes[k], &sc[k])) return r;
     }
+    HIPCHK(c, hipSetDevice(c->device));                          // the extra streams belong to the context's device
     for (int k = 1; k < parts; k++)
         if (c->stream2[k - 1] == nullptr) HIPCHK(c, hipStreamCreateWithFlags(&c->stream2[k - 1], hipStreamNonBlocking));
     if (c->evFork == nullptr) {
