@@ -49,7 +49,11 @@ struct AnsDecChunk {
 constexpr u32 SCAN_WIN_BITS = 8192;
 constexpr u32 SCAN_NEED_BITS = 3498 + 40 + 128 + 64;   // longest header + var-int + 4 states + one spare dword pair
 
+#ifdef KNZ_EMU
+struct u32x4 { u32 x, y, z, w; };                     // (the CPU emulation of tests/emu is built with g++)
+#else
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+#endif
 
 __device__ __forceinline__ u32 rl(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
 __device__ __forceinline__ u32 uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }

@@ -460,7 +460,11 @@ struct HufDecChunk {
     u8 sizes[256];
 };
 
+#ifdef KNZ_EMU
+struct hu32x4 { u32 x, y, z, w; };                    // (the CPU emulation of tests/emu is built with g++)
+#else
 typedef u32 hu32x4 __attribute__((ext_vector_type(4)));
+#endif
 
 // n in [1, 32]; rel = bit offset from the start of the LDS window (words in bit order)
 __device__ __forceinline__ u32 hwin_bits(const u32* win, u32 rel, u32 n)

@@ -132,3 +132,31 @@ def test_mtft_kernels_emulated(tmp_path):
     for order in ("0", "1", "2"):
         r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900, env=dict(os.environ, HIPEMU_ORDER=order))
         assert r.returncode == 0, (order, r.stdout[-2000:] + r.stderr[-2000:])
+
+
+def test_huffman_decoder_kernels_emulated(tmp_path):
+    # header scan (alphabet masks, table-driven Exp-Golomb length deltas, fragment sizes) and chunk decode against the oracle's
+    # streams: full and tiny alphabets, single-symbol and raw chunks, several chunks per block, blocks at odd bit offsets
+    exe = build("huff_emu", tmp_path)
+    c = knzlib.corpus()
+    rng = np.random.default_rng(8)
+    blocks = [c.text(50000, 1), rng.integers(0, 256, 40000, dtype=np.uint8).tobytes(), bytes(20000), b"ab" * 9000, c.mixed(300000, 2)[250000:299000],
+              rng.integers(0, 3, 16385, dtype=np.uint8).tobytes(), b"x" * 31, c.text(16384, 3), bytes(range(256)) * 70,
+              (rng.integers(0, 256, 30000, dtype=np.uint8) & 0x55).tobytes()]
+    path = str(tmp_path / "huff.bin")
+    write_case(path, blocks)
+    r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_ans0_decoder_kernels_emulated(tmp_path):
+    # rANS order-0 header scan and chunk decode (four interleaved states, LDS payload ring) against the oracle's streams
+    exe = build("ans0_emu", tmp_path)
+    c = knzlib.corpus()
+    rng = np.random.default_rng(9)
+    blocks = [c.text(50000, 1), rng.integers(0, 256, 40000, dtype=np.uint8).tobytes(), bytes(20000), b"ab" * 9000, c.mixed(300000, 2)[250000:299000],
+              rng.integers(0, 3, 16385, dtype=np.uint8).tobytes(), b"x" * 31, c.text(16384, 3), bytes(range(256)) * 70, b"q" * 33, c.text(70001, 4)]
+    path = str(tmp_path / "ans0.bin")
+    write_case(path, blocks)
+    r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -120,7 +120,8 @@ static inline int __shfl_xor(int var, int mask, int width = 64)
     return (int)(unsigned)v[lane ^ mask];
 }
 static inline int __builtin_amdgcn_readlane(int var, int src) { return __shfl(var, src & 63, 64); }
-// DPP data movement, the controls the kernels use: 0x138 = wave_shr:1 (lane i takes lane i-1; lane 0 keeps `old`, bound_ctrl off)
+// DPP data movement, the controls the kernels use: 0x138 = wave_shr:1 (lane i takes lane i-1; lane 0 keeps `old`, bound_ctrl off),
+// 0x00-0xFF = quad_perm (two selector bits per lane of a quad)
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int rowMask, int bankMask, bool boundCtrl)
 {
     unsigned long long v[64], act;
@@ -128,6 +129,7 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int ro
     const int lane = (int)(threadIdx.x & 63);
     (void)rowMask; (void)bankMask; (void)boundCtrl;
     if (ctrl == 0x138) return lane == 0 ? old : (int)(unsigned)v[lane - 1];
+    if (ctrl >= 0 && ctrl < 0x100) return (int)(unsigned)v[(lane & ~3) + ((ctrl >> (2 * (lane & 3))) & 3)];     // quad_perm
     fprintf(stderr, "hipemu: DPP control 0x%x not emulated\n", ctrl);
     abort();
 }
@@ -140,6 +142,7 @@ static inline int __builtin_amdgcn_readfirstlane(int var)
 static inline unsigned long long __lanemask_lt() { const int lane = (int)(threadIdx.x & 63); return lane ? (~0ull >> (64 - lane)) : 0ull; }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
+static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
 static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 static inline int __ffs(int x) { return __builtin_ffs(x); }
 static inline int __clz(int x) { return x == 0 ? 32 : __builtin_clz((unsigned)x); }
