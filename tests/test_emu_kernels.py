@@ -160,3 +160,21 @@ def test_ans0_decoder_kernels_emulated(tmp_path):
     write_case(path, blocks)
     r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_zrlt_kernels_emulated(tmp_path):
+    # ZRLT forward (incl. blocks it refuses at capacity n) and inverse against oracle/transforms.c: sparse data, text, zeros, noise,
+    # 0xFF / 0xFE escapes, runs across tile borders
+    exe = build("zrlt_emu", tmp_path)
+    c = knzlib.corpus()
+    rng = np.random.default_rng(4)
+    sp = bytearray(30000)
+    for p in rng.integers(0, 30000, 600):
+        sp[p] = int(rng.integers(1, 256))
+    blocks = [bytes(sp), c.text(20000, 1), bytes(5000), rng.integers(0, 256, 9000, dtype=np.uint8).tobytes(), bytes([0xFF, 0xFE, 0, 0, 0xFF]) * 3000,
+              b"\0", b"a", bytes(4096) + b"x" + bytes(4095), c.mixed(300000, 2)[250000:270000], bytes(70000)]
+    path = str(tmp_path / "zrlt.bin")
+    write_case(path, blocks)
+    for order in ("0", "2"):
+        r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900, env=dict(os.environ, HIPEMU_ORDER=order))
+        assert r.returncode == 0, (order, r.stdout[-2000:] + r.stderr[-2000:])

@@ -27,6 +27,7 @@ struct dim3 {
 struct uint2 { unsigned x, y; };
 static inline uint2 make_uint2(unsigned a, unsigned b) { uint2 r; r.x = a; r.y = b; return r; }
 struct uint4 { unsigned x, y, z, w; };
+static inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { uint4 r; r.x = a; r.y = b; r.z = c; r.w = d; return r; }
 
 typedef void* hipStream_t;
 typedef int hipError_t;
