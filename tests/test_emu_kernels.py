@@ -178,3 +178,17 @@ def test_zrlt_kernels_emulated(tmp_path):
     for order in ("0", "2"):
         r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900, env=dict(os.environ, HIPEMU_ORDER=order))
         assert r.returncode == 0, (order, r.stdout[-2000:] + r.stderr[-2000:])
+
+
+def test_ans0_encoder_and_bit_assembly_emulated(tmp_path):
+    # k_ans0_stats / k_ans0_encode and the bit assembly kernels, block by block in the per-stage form, bit for bit against the oracle
+    exe = build("ans0_enc_emu", tmp_path)
+    c = knzlib.corpus()
+    rng = np.random.default_rng(10)
+    t = c.text(40000, 1)
+    blocks = [t[:16384], t[16384:20000], t[:16383], t, rng.integers(0, 256, 33000, dtype=np.uint8).tobytes(), bytes(20000), b"ab" * 9000,
+              c.mixed(300000, 2)[250000:283000], rng.integers(0, 3, 16385, dtype=np.uint8).tobytes(), b"x" * 31, b"q" * 33, bytes(range(256)) * 70]
+    path = str(tmp_path / "ans0e.bin")
+    write_case(path, blocks)
+    r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -144,6 +144,7 @@ static inline unsigned long long __lanemask_lt() { const int lane = (int)(thread
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 static inline int __ffs(int x) { return __builtin_ffs(x); }
 static inline int __clz(int x) { return x == 0 ? 32 : __builtin_clz((unsigned)x); }
