@@ -62,6 +62,14 @@ __device__ __forceinline__ u32 bitlen_u32(u32 v) { return v == 0 ? 0u : (u32)(32
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
+// Where a kernel relies on a wave executing its memory operations in program order across lanes (lane 0 stores, every lane loads
+// right after), the CPU emulation of tests/emu -- whose lanes only meet at wave intrinsics -- needs a rendezvous; on the GPU it is nothing.
+#ifdef KNZ_EMU
+#define KNZ_WAVE_ORDER() ((void)__ballot(1))
+#else
+#define KNZ_WAVE_ORDER() ((void)0)
+#endif
+
 #ifdef KNZ_EMU
 // CPU emulation build (tests/emu, tools/hipemu): the same results through the generic lane exchange
 __device__ __forceinline__ u32 wave_incl_scan(u32 v)

@@ -54,6 +54,7 @@ __device__ __forceinline__ bool lz_maybe_dups(u32* seen, u32 h, bool act)
 {
     const u32 fbit = 1u << (h & 31), fidx = (h >> 5) & 2047;
     const u32 old = act ? atomicOr(&seen[fidx], fbit) : 0u;
+    KNZ_WAVE_ORDER();                                     // every lane's OR before any lane's AND (one instruction each on the GPU)
     if (act) atomicAnd(&seen[fidx], ~fbit);
     return __ballot(act && (old & fbit)) != 0;
 }
@@ -264,6 +265,7 @@ __global__ __launch_bounds__(64) void k_lz_walk(XfStage st, LzWs ws)
             return (o >= 0 && o < LZW) ? (u32)sgpr((int)wHash[o]) : ((u32)sgpr((int)gKeys[p]) & HMASK);
         };
         while (pos < srcEnd) {
+            KNZ_WAVE_ORDER();
             // ---- the next (up to 64) positions of a literal run, all at once
             const int stride = 1 + (skip >> 6);
             const bool fast = stride == 1;
@@ -342,6 +344,7 @@ __global__ __launch_bounds__(64) void k_lz_walk(XfStage st, LzWs ws)
             const u32 c4 = (u32)__builtin_amdgcn_readlane((int)cw, f);
             const u64 x8f = readlane64(x8, f), y8f = readlane64(y8, f);
             if (lane == 0) tab_put(table, h0, pos);
+            KNZ_WAVE_ORDER();
             const int nxt = pos + 1;
             const int lo = (pos - maxDist > 0) ? pos - maxDist : 0;
             const int refA = nxt - (recent ? rep1 : rep0);
@@ -389,6 +392,7 @@ __global__ __launch_bounds__(64) void k_lz_walk(XfStage st, LzWs ws)
                             ck = sgpr(tab_get(table, hk));
                         }
                         if (lane == 0) tab_put(table, hk, pk);
+                        KNZ_WAVE_ORDER();
                         if (ck <= lo + k) continue;
                         const int limk = min(srcEnd - pk, LZ_MAXMATCH);
                         const int lk = (int)(infk & 0x7FFFu);
@@ -416,6 +420,7 @@ __global__ __launch_bounds__(64) void k_lz_walk(XfStage st, LzWs ws)
                     pos++;
                     const u32 hp = hash_at(pos);
                     if (lane == 0) tab_put(table, hp, pos);
+                    KNZ_WAVE_ORDER();
                 } else { best++; ref--; }
             }
             skip = 0;
@@ -460,6 +465,7 @@ __global__ __launch_bounds__(64) void k_lz_walk(XfStage st, LzWs ws)
                 u32 hp = 0;
                 if (in) hp = (o >= 0 && o < LZW) ? wHash[o] : (gKeys[p] & HMASK);
                 tab_put_wave(table, seen, hp, p, in, lane);
+                KNZ_WAVE_ORDER();
             }
             pos = anchor;
         }

@@ -1,0 +1,20 @@
+// CPU-only check of the LZ kernels of kanzi-cpp_amd/csrc/lz.hip (transform id 16: candidate phase with the library sort, the
+// wave-per-block walk, the decoder) against the oracle, forward and inverse; see xf_harness.hpp.
+#define KNZ_EMU 1
+#include "hip/hip_runtime.h"
+#include "../../kanzi-cpp_amd/csrc/lz.hip"
+namespace {
+std::vector<unsigned char> g_lzScratch;
+int lz_fwd(const knz::XfStage& st)
+{
+    const size_t bytes = knz::lz_forward_scratch_bytes(16, st.nBlocks, st.maxLen);
+    g_lzScratch.assign(bytes + 512, 0);
+    void* sc = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(g_lzScratch.data()) + 255) & ~(uintptr_t)255);
+    return knz::launch_lz_forward(nullptr, st, 16, sc, bytes);
+}
+}
+#define XF_TTYPE 16
+#define XF_FWD(st) do { if (lz_fwd(st) != 0) { printf("launch_lz_forward failed\n"); return 1; } } while (0)
+#define XF_INV(st) knz::launch_lz_inverse(nullptr, st)
+#define XF_SCRATCH_U32(nb, ml) ((size_t)0)
+#include "xf_harness.hpp"

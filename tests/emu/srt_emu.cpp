@@ -1,0 +1,9 @@
+// CPU-only check of the kernels of kanzi-cpp_amd/csrc/srt.hip (transform id 13) against the oracle, forward and inverse; see xf_harness.hpp.
+#define KNZ_EMU 1
+#include "hip/hip_runtime.h"
+#include "../../kanzi-cpp_amd/csrc/srt.hip"
+#define XF_TTYPE 13
+#define XF_FWD(st) launch_srt_forward(nullptr,st)
+#define XF_INV(st) launch_srt_inverse(nullptr,st)
+#define XF_SCRATCH_U32(nb, ml) ((size_t)0)
+#include "xf_harness.hpp"

@@ -18,7 +18,7 @@ EMU = os.path.join(ROOT, "tests", "emu")
 def build(name, tmp_path):
     knzlib.ensure_oracle()
     exe = str(tmp_path / name)
-    cmd = ["g++", "-O1", "-std=c++17", "-x", "c++", "-I" + os.path.join(ROOT, "tools", "hipemu"), "-I" + os.path.join(ROOT, "include"),
+    cmd = ["g++", "-O1", "-std=c++17", "-x", "c++", "-I" + os.path.join(ROOT, "tools", "hipemu"), "-I" + os.path.join(ROOT, "include"), "-I" + EMU,
            "-Wno-unused-value", "-Wno-attributes", "-Wno-format-extra-args", os.path.join(EMU, name + ".cpp"),
            os.path.join(ROOT, "tools", "hipemu", "hipemu.cpp"), "-x", "none", "-L" + os.path.join(ROOT, "oracle"), "-lknz_oracle",
            "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-o", exe]
@@ -191,4 +191,23 @@ def test_ans0_encoder_and_bit_assembly_emulated(tmp_path):
     path = str(tmp_path / "ans0e.bin")
     write_case(path, blocks)
     r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("name", ["srt", "rlt", "rank", "timestamp", "lz", "lzx"])
+def test_block_serial_transforms_emulated(tmp_path, name):
+    """SRT, RLT, RANK / TIMESTAMP (SBRT) and LZ / LZX: the wave-per-block kernels against the oracle, forward (same accept / refuse
+    decision and bytes at the same capacity) and inverse. Where a kernel counts on a wave executing its memory operations in
+    program order across lanes, KNZ_WAVE_ORDER() marks the spot for the emulation (csrc/common.hpp)."""
+    exe = build(name + "_emu", tmp_path)
+    c = knzlib.corpus()
+    rng = np.random.default_rng(12)
+    runs = bytearray()
+    while len(runs) < 30000:
+        runs += bytes([int(rng.integers(0, 256))]) * int(rng.geometric(0.05))
+    blocks = [c.text(20000, 1), bytes(5000), rng.integers(0, 256, 9000, dtype=np.uint8).tobytes(), bytes(runs[:30000]), b"\0", b"a", b"abcabcabcabcabcabcabcabc" * 50,
+              c.mixed(300000, 2)[250000:270000], bytes(40000), c.text(30000, 5), rng.integers(0, 4, 12000, dtype=np.uint8).tobytes(), b"xy" * 17]
+    path = str(tmp_path / "xf.bin")
+    write_case(path, blocks)
+    r = subprocess.run([exe, path], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

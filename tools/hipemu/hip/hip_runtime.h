@@ -130,6 +130,9 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int ro
     const int lane = (int)(threadIdx.x & 63);
     (void)rowMask; (void)bankMask; (void)boundCtrl;
     if (ctrl == 0x138) return lane == 0 ? old : (int)(unsigned)v[lane - 1];
+    if (ctrl == 0x130) return lane == 63 ? old : (int)(unsigned)v[lane + 1];       // wave_shl:1
+    if (ctrl == 0x134) return (int)(unsigned)v[(lane + 1) & 63];                   // wave_rol:1
+    if (ctrl == 0x13C) return (int)(unsigned)v[(lane + 63) & 63];                  // wave_ror:1
     if (ctrl >= 0 && ctrl < 0x100) return (int)(unsigned)v[(lane & ~3) + ((ctrl >> (2 * (lane & 3))) & 3)];     // quad_perm
     fprintf(stderr, "hipemu: DPP control 0x%x not emulated\n", ctrl);
     abort();
@@ -152,5 +155,14 @@ static inline int __clzll(long long x) { return x == 0 ? 64 : __builtin_clzll((u
 
 template <class T> static inline T atomicAdd(T* p, T v) { const T o = *p; *p = o + v; return o; }
 template <class T> static inline T atomicOr(T* p, T v) { const T o = *p; *p = o | v; return o; }
+template <class T> static inline T atomicAnd(T* p, T v) { const T o = *p; *p = o & v; return o; }
+static inline unsigned long long __ballot(int pred);
+static inline void __threadfence_block() { (void)__ballot(1); }      // (issued by the kernels in workgroup-uniform control flow)
+static inline void __threadfence() {}
+// a wave-scope fence orders the memory operations of the wave's lanes: in the emulation, where lanes only meet at wave
+// intrinsics, it has to be a rendezvous (the kernels issue it in wave-uniform control flow)
+#define __builtin_amdgcn_fence(order, scope) ((void)__ballot(1))
+template <class T> static inline T min(T a, T b) { return a < b ? a : b; }
+template <class T> static inline T max(T a, T b) { return a > b ? a : b; }
 template <class T> static inline T atomicMax(T* p, T v) { const T o = *p; if (v > o) *p = v; return o; }
 template <class T> static inline T atomicMin(T* p, T v) { const T o = *p; if (v < o) *p = v; return o; }
