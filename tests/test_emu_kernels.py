@@ -211,3 +211,18 @@ def test_block_serial_transforms_emulated(tmp_path, name):
     write_case(path, blocks)
     r = subprocess.run([exe, path], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_huffman_encoder_and_bit_assembly_emulated(tmp_path):
+    # k_huff_encode (code lengths, canonical codes, header, fragments) and the bit assembly, bit for bit against the oracle
+    exe = build("huff_enc_emu", tmp_path)
+    c = knzlib.corpus()
+    rng = np.random.default_rng(13)
+    t = c.text(40000, 2)
+    blocks = [t[:16384], t[16384:20000], t, rng.integers(0, 256, 33000, dtype=np.uint8).tobytes(), bytes(20000), b"ab" * 9000,
+              c.mixed(300000, 2)[250000:283000], rng.integers(0, 3, 16385, dtype=np.uint8).tobytes(), b"x" * 31, b"q" * 33, bytes(range(256)) * 70,
+              (rng.integers(0, 256, 30000, dtype=np.uint8) & 0x0F).tobytes()]
+    path = str(tmp_path / "huffe.bin")
+    write_case(path, blocks)
+    r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
