@@ -32,15 +32,13 @@ struct XfView {
 // w: my 4 entries (position 4*lane in byte 0). rank = 4*lane0 + byteIdx (uniform).
 __device__ __forceinline__ u32 mtf_rotate(u32 w, int lane, int lane0, int byteIdx, u32 front)
 {
-    const u32 prev = (u32)__builtin_amdgcn_update_dpp(0, (int)w, 0x138, 0xF, 0xF, false);   // wave_shr:1 (lane i <- lane i-1)
-    const u32 carry = (lane == 0) ? front : (prev >> 24);
-    const u32 shifted = (w << 8) | carry;
-    if (lane < lane0) return shifted;
-    if (lane == lane0) {
-        const u32 mask = (byteIdx == 3) ? 0xFFFFFFFFu : ((1u << (8 * (byteIdx + 1))) - 1u);
-        return (shifted & mask) | (w & ~mask);
-    }
-    return w;
+    // lane i takes lane i-1's entries, lane 0 the new front symbol (the `old` operand of the DPP move); then one funnel shift
+    const u32 prev = (u32)__builtin_amdgcn_update_dpp((int)(front << 24), (int)w, 0x138, 0xF, 0xF, false);   // wave_shr:1
+    const u32 shifted = __builtin_amdgcn_alignbit(w, prev, 24);                  // (w << 8) | (prev >> 24)
+    const u32 mask = (byteIdx == 3) ? 0xFFFFFFFFu : ((1u << (8 * (byteIdx + 1))) - 1u);      // uniform
+    const u32 merged = (shifted & mask) | (w & ~mask);
+    const u32 upTo = (lane == lane0) ? merged : w;
+    return (lane < lane0) ? shifted : upTo;
 }
 
 // per tile: last occurrence (position+1) of each symbol -> tileLast[b][t][256]

@@ -146,6 +146,7 @@ static inline int __builtin_amdgcn_readfirstlane(int var)
 static inline unsigned long long __lanemask_lt() { const int lane = (int)(threadIdx.x & 63); return lane ? (~0ull >> (64 - lane)) : 0ull; }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
+static inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned sh) { return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (sh & 31)); }
 static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
