@@ -325,8 +325,16 @@ public:
     void close();
     uint64 getWritten() const { return _written.load(); }
     // number of blocks handed to the device per call (default: jobs, like the reference keeps `jobs` blocks in flight)
-    void setBatchBlocks(int n) { if (n > 0) _batchBlocks = n; }
+    // (before the first write(): the page-locked staging slots are sized for the batch when the first byte arrives; one device
+    // call takes at most 2 GiB of input)
+    void setBatchBlocks(int n)
+    {
+        if (n <= 0 || _batchBytes != 0) return;
+        const long long lim = (1ll << 31) / (long long)_blockSize - 1;
+        _batchBlocks = (long long)n > lim ? int(lim < 1 ? 1 : lim) : n;
+    }
 private:
+    size_t _batchBytes;           // batch size in bytes, latched by the first write()
     std::ostream& _os;
     int _jobs, _blockSize, _checksum;
     short _entropyType;

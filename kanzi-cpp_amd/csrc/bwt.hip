@@ -18,18 +18,9 @@
 
 #include <cstring>
 #include <algorithm>
-#include <rocprim/rocprim.hpp>
+#include "prims.hpp"
 
 namespace knz {
-
-// compaction: act[out] = value[a] for kept elements, given the exclusive scan of keep
-__global__ __launch_bounds__(256) void k_compact(const u32* __restrict__ keep, const u32* __restrict__ scan, const u32* __restrict__ value, u32 n,
-                                                 u32* __restrict__ out)
-{
-    const u32 a = blockIdx.x * 256 + threadIdx.x;
-    if (a >= n) return;
-    if (keep[a]) out[scan[a]] = value ? value[a] : a;
-}
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -40,7 +31,9 @@ static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // ------------------------------------------------------------------------------------------------
 struct BwtHdr { u32 n; u32 hdr; u32 pIdx; u32 okFlag; };
 
-__global__ void k_bwt_i_header(BwtView v, BwtHdr* __restrict__ hd, u32* __restrict__ base, u8* __restrict__ ok, u32* __restrict__ newLen)
+struct InvInfo { u32 total; u32 nWords; u32 count; u32 dyn; u32 pad[4]; };      // device-resident sizes: no host read-back in this stage
+
+__global__ void k_bwt_i_header(BwtView v, BwtHdr* __restrict__ hd, u32* __restrict__ base, u8* __restrict__ ok, u32* __restrict__ newLen, InvInfo* __restrict__ info)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     u32 sum = 0;
@@ -86,14 +79,17 @@ __global__ void k_bwt_i_header(BwtView v, BwtHdr* __restrict__ hd, u32* __restri
         hd[b] = h;
     }
     base[v.nBlocks] = sum;
+    info->total = sum; info->nWords = (sum + 31) / 32; info->count = 0; info->dyn = 0;
 }
 
 // ---- list ranking with random splitters (Helman-JaJa style) ------------------------------------
 // Node j = F-position (global slot). rec[j] = next node (31 bits) | "next is a splitter" (bit 31) | symbol << 32.
 // The node holding BWT index 0 is the end of the text (self loop). Splitters: a pseudo-random 1/64 of the
-// nodes + every block's chain head + the terminals. Each splitter walks to the next splitter (sub-list
-// length), the short splitter list is ranked by pointer jumping, then each splitter walks its sub-list
-// again and writes the text. Two O(n) random-access passes instead of log2(n) of them.
+// nodes + every block's chain head + the terminals. Every splitter walks to the next splitter ONCE and keeps the symbols
+// it passes in a row of ROW bytes (a sub-list longer than a row continues in a fresh row taken from a counter: the walk
+// never repeats a hop). The rows are ranked by pointer jumping over (successor row, length), then a copy kernel moves every
+// row to its place in the text. A hop is a random 8-byte read, i.e. one 128-byte line from the fabric (55 G/s on MI355X
+// whatever the size of the working set, tools/membench.hip): one O(n) random-access pass -- round 2 made two.
 //
 // The F-position of BWT index i is C[symbol] + (number of equal symbols before i): a stable counting sort, done per tile
 // of 4096 symbols (histogram, scan over tiles and symbols, rank by ballot matching inside a wave) and written straight
@@ -101,7 +97,14 @@ __global__ void k_bwt_i_header(BwtView v, BwtHdr* __restrict__ hd, u32* __restri
 constexpr int SPLIT_LOG = 6;
 constexpr u32 IT = 4096;             // symbols per tile: 4 waves x 16 rows of 64
 
-__device__ __forceinline__ bool hash_split(u32 j) { return ((j * 2654435761u) >> (32 - SPLIT_LOG)) == 0; }
+// Splitters come in clusters of SPLIT_CLUSTER adjacent nodes (1 node in 64 all the same). Adjacent nodes are suffixes that are
+// neighbours in sorted order: they share a prefix, so the chains that start in one cluster -- walked by adjacent lanes -- move
+// through adjacent records for as many hops as that prefix lasts, and the lanes' reads fall into one or two 128-byte lines
+// instead of eight. On data with long repeats most hops of the walk are of that kind.
+#ifndef KNZ_SPLIT_CLUSTER_LOG
+#define KNZ_SPLIT_CLUSTER_LOG 3
+#endif
+__device__ __forceinline__ bool hash_split(u32 j) { return (((j >> KNZ_SPLIT_CLUSTER_LOG) * 2654435761u) >> (32 - SPLIT_LOG)) == 0; }
 
 // lanes of the wave whose (valid) symbol equals mine
 __device__ __forceinline__ unsigned long long sym_peers(bool valid, u32 sym)
@@ -239,10 +242,11 @@ __global__ __launch_bounds__(256) void k_bwt_i_links(BwtView v, const BwtHdr* __
 
 // splitter flags from the node number alone, as a bit map: a thread makes the word of 32 nodes and its population count
 __global__ __launch_bounds__(256) void k_bwt_i_flags(const BwtHdr* __restrict__ hd, const u32* __restrict__ base, const u32* __restrict__ term, int nBlocks,
-                                                     u32 total, u32* __restrict__ bits, u32* __restrict__ wcount)
+                                                     const InvInfo* __restrict__ info, u32* __restrict__ bits, u32* __restrict__ wcount)
 {
     const u32 w = blockIdx.x * 256 + threadIdx.x;
     const u32 j0 = 32u * w;
+    const u32 total = info->total;
     if (j0 >= total) return;
     int b = find_block(base, nBlocks, j0);
     u32 be = base[b + 1], head = base[b] + hd[b].pIdx - 1, tm = term[b];
@@ -258,15 +262,17 @@ __global__ __launch_bounds__(256) void k_bwt_i_flags(const BwtHdr* __restrict__ 
 }
 
 // the set bits of every word, in order: splitNode[rank] = node
-__global__ __launch_bounds__(256) void k_bwt_i_compact(const u32* __restrict__ bits, const u32* __restrict__ wprefix, u32 nWords, u32* __restrict__ splitNode)
+__global__ __launch_bounds__(256) void k_bwt_i_compact(const u32* __restrict__ bits, const u32* __restrict__ wprefix, const InvInfo* __restrict__ info, u32 maxRows,
+                                                       u32* __restrict__ splitNode)
 {
     const u32 w = blockIdx.x * 256 + threadIdx.x;
-    if (w >= nWords) return;
+    if (w >= info->nWords) return;
     u32 word = bits[w];
     u32 at = wprefix[w];
     while (word) {
         const u32 k = (u32)__ffs((int)word) - 1;
-        splitNode[at++] = 32u * w + k;
+        if (at < maxRows) splitNode[at] = 32u * w + k;
+        at++;
         word &= word - 1;
     }
 }
@@ -277,68 +283,99 @@ __device__ __forceinline__ u32 split_rank(const u32* __restrict__ bits, const u3
     return wprefix[node >> 5] + (u32)__popc(bits[node >> 5] & ((1u << (node & 31)) - 1u));
 }
 
-// walk 1: sub-list length and successor splitter (compact indices)
-__global__ __launch_bounds__(256) void k_bwt_i_walk1(const u64* __restrict__ rec, const u32* __restrict__ splitNode, const u32* __restrict__ bits,
-                                                     const u32* __restrict__ wprefix, u32 count, u32 limit, u32* __restrict__ succ, u32* __restrict__ dist)
+constexpr u32 ROW = 128;            // bytes of one row of symbols (sub-lists have 64 nodes on average, 13 % are longer than a row)
+
+// the walk: sub-list length, successor row and the symbols of the sub-list, one thread per splitter
+__global__ __launch_bounds__(256) void k_bwt_i_walk(const u64* __restrict__ rec, u32* __restrict__ rowNode, const u32* __restrict__ bits,
+                                                    const u32* __restrict__ wprefix, InvInfo* __restrict__ info, u32 maxRows, u32* __restrict__ succ,
+                                                    u32* __restrict__ dist, u8* __restrict__ rowLen, u8* __restrict__ rows)
 {
     const u32 c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= count) return;
-    u32 node = splitNode[c];
+    const u32 count = info->count;
+    if (c >= count || c >= maxRows) return;
+    u32 node = rowNode[c];
     u64 r = rec[node];
-    if (((u32)r & 0x7FFFFFFFu) == node) { succ[c] = c; dist[c] = 0; return; }    // terminal
-    u32 len = 0;
-    while (true) {
-        len++;
-        const u32 nx = (u32)r & 0x7FFFFFFFu;
-        if ((r >> 31) & 1) { succ[c] = split_rank(bits, wprefix, nx); break; }
-        if (len > limit) { succ[c] = c; break; }              // malformed input (cycle without splitter)
+    if (((u32)r & 0x7FFFFFFFu) == node) {                        // terminal: the last byte of the text
+        succ[c] = c; dist[c] = 0; rowLen[c] = 1; rows[(size_t)c * ROW] = (u8)(r >> 32);
+        return;
+    }
+    u32 cur = c;
+    for (;;) {
+        u64* row = reinterpret_cast<u64*>(rows + (size_t)cur * ROW);
+        u32 len = 0, nx = 0;
+        u64 acc = 0;
+        bool done = false;
+        for (;;) {
+            acc |= ((r >> 32) & 0xFFull) << (8 * (len & 7));
+            len++;
+            if ((len & 7) == 0) { row[(len >> 3) - 1] = acc; acc = 0; }
+            nx = (u32)r & 0x7FFFFFFFu;
+            if ((r >> 31) & 1) { done = true; break; }
+            if (len == ROW) break;
+            node = nx;
+            r = rec[node];
+        }
+        if (len & 7) row[len >> 3] = acc;
+        dist[cur] = len;
+        rowLen[cur] = (u8)len;
+        if (done) { succ[cur] = split_rank(bits, wprefix, nx); break; }
+        // the sub-list goes on: a fresh row (only malformed input -- a cycle without a splitter -- can exhaust them)
+        const u32 id = count + atomicAdd(&info->dyn, 1u);
+        if (id >= maxRows) { succ[cur] = cur; break; }
+        succ[cur] = id;
+        rowNode[id] = nx;
+        cur = id;
         node = nx;
         r = rec[node];
     }
-    dist[c] = len;
 }
 
-__global__ __launch_bounds__(256) void k_bwt_i_jump(const u32* __restrict__ nextIn, const u32* __restrict__ distIn, u32 total,
+__global__ __launch_bounds__(256) void k_bwt_i_jump(const u32* __restrict__ nextIn, const u32* __restrict__ distIn, const InvInfo* __restrict__ info, u32 maxRows,
                                                     u32* __restrict__ nextOut, u32* __restrict__ distOut)
 {
     const u32 j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= total) return;
+    u32 rowsTotal = info->count + info->dyn;
+    if (rowsTotal > maxRows) rowsTotal = maxRows;
+    if (j >= rowsTotal) return;
     const u32 nx = nextIn[j];
     distOut[j] = distIn[j] + distIn[nx];
     nextOut[j] = nextIn[nx];
 }
 
-// walk 2: every splitter writes the text bytes of its sub-list (ascending addresses: four bytes are gathered per store)
-__global__ __launch_bounds__(256) void k_bwt_i_walk2(BwtView v, const BwtHdr* __restrict__ hd, const u32* __restrict__ base, const u64* __restrict__ rec,
-                                                     const u32* __restrict__ splitNode, const u32* __restrict__ dEnd, u32 count, u32 limit)
+// every row to its place: 32 lanes per row, a lane makes one aligned dword of the output from two aligned dwords of the row
+__global__ __launch_bounds__(256) void k_bwt_i_place(BwtView v, const BwtHdr* __restrict__ hd, const u32* __restrict__ base, const u32* __restrict__ rowNode,
+                                                     const u32* __restrict__ dEnd, const u8* __restrict__ rowLen, const u8* __restrict__ rows,
+                                                     const InvInfo* __restrict__ info, u32 maxRows)
 {
-    const u32 c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= count) return;
-    u32 node = splitNode[c];
-    const int b = find_block(base, v.nBlocks, node);
+    const u32 c = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const u32 l = threadIdx.x & 31;
+    u32 rowsTotal = info->count + info->dyn;
+    if (rowsTotal > maxRows) rowsTotal = maxRows;
+    if (c >= rowsTotal) return;
+    const int b = find_block(base, v.nBlocks, rowNode[c]);
     const u32 n = hd[b].n;
+    const u32 d = dEnd[c];
+    u32 len = rowLen[c];
+    if (d >= n) return;                                          // (malformed input)
+    const u32 a = n - 1 - d;                                     // text position of the row's first symbol
+    if (len > n - a) len = n - a;
     u8* dst = v.dst[b];
-    const bool al = (reinterpret_cast<uintptr_t>(dst) & 3) == 0;
-    u32 d = dEnd[c];
-    u32 steps = 0;
-    u32 curW = 0xFFFFFFFFu, acc = 0, mask = 0;
-    auto flush = [&]() {
-        if (mask == 0xF && al) { reinterpret_cast<u32*>(dst)[curW] = acc; }
-        else { for (u32 k = 0; k < 4; k++) if ((mask >> k) & 1) dst[4 * curW + k] = (u8)(acc >> (8 * k)); }
-    };
-    while (true) {
-        const u64 r = rec[node];
-        if (d < n) {
-            const u32 pos = n - 1 - d;
-            if ((pos >> 2) != curW) { if (mask) flush(); curW = pos >> 2; acc = 0; mask = 0; }
-            acc |= (u32)((r >> 32) & 0xFF) << (8 * (pos & 3));
-            mask |= 1u << (pos & 3);
+    const uintptr_t A = reinterpret_cast<uintptr_t>(dst) + a;
+    const u32* row32 = reinterpret_cast<const u32*>(rows + (size_t)c * ROW);
+    const uintptr_t W0 = A & ~(uintptr_t)3;
+    const int lead = (int)(A - W0);                              // bytes of the first dword that lie in front of the row
+    // dword k of the output range covers row bytes [4k - lead, 4k - lead + 4)
+    for (u32 k = l; 4 * k < (u32)lead + len; k += 32) {
+        const int o = 4 * (int)k - lead;                         // row offset of the dword's first byte (-3..)
+        if (o >= 0 && (u32)o + 4 <= len) {
+            const u32 q = (u32)o >> 2, sh = ((u32)o & 3) * 8;
+            const u32 lo = row32[q], hi = sh ? row32[q + 1] : 0u;
+            *reinterpret_cast<u32*>(W0 + 4 * (uintptr_t)k) = (u32)(((((u64)hi) << 32) | lo) >> sh);
+        } else {
+            const u8* rb = reinterpret_cast<const u8*>(row32);
+            for (int j = 0; j < 4; j++) { const int ro = o + j; if (ro >= 0 && (u32)ro < len) dst[a + (u32)ro] = rb[ro]; }
         }
-        if (((r >> 31) & 1) || d == 0 || ++steps > limit) break;
-        node = (u32)r & 0x7FFFFFFFu;
-        d--;
     }
-    if (mask) flush();
 }
 
 __global__ void k_bwt_i_tiny(BwtView v, const BwtHdr* __restrict__ hd)
@@ -349,72 +386,81 @@ __global__ void k_bwt_i_tiny(BwtView v, const BwtHdr* __restrict__ hd)
     if (h.okFlag && h.n == 1) v.dst[b][0] = v.src[b][h.hdr];     // BWT.cpp:152-158
 }
 
+// scratch layout, shared by the size query and the launch
+struct InvScratch {
+    u32* tileHist; u32* segSum; u32* Cb; u32* term; u64* rec; u32* bits; u32* wcount; u32* wprefix;
+    u32* rowNode; u32* nA; u32* nB; u32* dA; u32* dB; u8* rowLen; u8* rows;
+    BwtHdr* hd; u32* base; InvInfo* info; void* scanTmp;
+    u32 maxRows; int perTiles; u32 segT, nSeg;
+};
+
+static size_t inv_carve(u8* p, int nBlocks, u32 VS, size_t maxTotal, InvScratch* w)
+{
+    u8* q = p;
+    auto take = [&](size_t sz) { u8* r = q; q += align256(sz); return r; };
+    // splitters: a multiplicative hash of consecutive node numbers picks 1 in 64 with low discrepancy; heads and terminals on top
+    const size_t maxRows = maxTotal / 48 + maxTotal / ROW + 4096 + 3 * (size_t)nBlocks;
+    w->maxRows = (u32)maxRows;
+    w->perTiles = (int)(((size_t)VS + IT - 1) / IT);
+    w->segT = bwt_i_seg_tiles((u32)w->perTiles);
+    w->nSeg = ((u32)w->perTiles + w->segT - 1) / w->segT;
+    const size_t nWordsMax = maxTotal / 32 + 2;
+    w->tileHist = (u32*)take(4ull * 256 * (size_t)w->perTiles * nBlocks);
+    w->segSum = (u32*)take(4ull * 256 * (size_t)w->nSeg * nBlocks);
+    w->Cb = (u32*)take(4ull * 256 * nBlocks);
+    w->term = (u32*)take(4ull * (nBlocks + 1));
+    w->rec = (u64*)take(8 * maxTotal);
+    w->bits = (u32*)take(4 * nWordsMax); w->wcount = (u32*)take(4 * nWordsMax); w->wprefix = (u32*)take(4 * nWordsMax);
+    w->rowNode = (u32*)take(4 * maxRows);
+    w->nA = (u32*)take(4 * maxRows); w->nB = (u32*)take(4 * maxRows);
+    w->dA = (u32*)take(4 * maxRows); w->dB = (u32*)take(4 * maxRows);
+    w->rowLen = (u8*)take(maxRows);
+    w->rows = (u8*)take(maxRows * (size_t)ROW + 64);
+    w->hd = (BwtHdr*)take(sizeof(BwtHdr) * (size_t)nBlocks);
+    w->base = (u32*)take(4ull * (nBlocks + 2));
+    w->info = (InvInfo*)take(sizeof(InvInfo));
+    w->scanTmp = take(prims::scan_tmp_bytes(nWordsMax));
+    return (size_t)(q - p);
+}
+
 size_t bwt_inverse_scratch_bytes(int nBlocks, u32 VS, size_t total)
 {
-    size_t primSort = 0, primScan = 0;
-    rocprim::radix_sort_pairs(nullptr, primSort, (u32*)nullptr, (u32*)nullptr, (u32*)nullptr, (u32*)nullptr, total, 0u, 32u, (hipStream_t)0);
-    rocprim::exclusive_scan(nullptr, primScan, (u32*)nullptr, (u32*)nullptr, 0u, total, rocprim::plus<u32>(), (hipStream_t)0);
-    const size_t prim = primSort > primScan ? primSort : primScan;
-    const size_t perTiles = ((size_t)VS + IT - 1) / IT;
-    const u32 segT = bwt_i_seg_tiles((u32)perTiles);
-    return align256(1024 * perTiles * (size_t)nBlocks) + align256(1024 * ((perTiles + segT - 1) / segT) * (size_t)nBlocks) + align256(1024 * (size_t)nBlocks) + align256(8 * total) + align256(8 * (total / 32 + 2)) + align256(4 * (total / 32 + 2)) + 6 * align256(4 * (total / 8 + 4096 + 3 * (size_t)nBlocks)) +
-           align256(sizeof(BwtHdr) * (size_t)nBlocks) + align256(4ull * (nBlocks + 2)) + align256(prim) + 16384;
+    InvScratch w;
+    return inv_carve(nullptr, nBlocks, VS, total, &w) + 4096;
 }
 
 int launch_bwt_inverse(hipStream_t s, const XfStage& st, void* scratch, size_t scratchBytes, u32* h_pinned)
 {
+    (void)h_pinned;
     BwtView v; v.src = st.src; v.dst = st.dst; v.len = st.len; v.cap = st.cap; v.VS = st.maxLen; v.nBlocks = st.nBlocks;
     const size_t maxTotal = (size_t)st.nBlocks * v.VS;
     if (maxTotal >= (1ull << 31)) return -2;                 // node ids share a word with the splitter flag
-    const size_t maxSplit = maxTotal / 8 + 4096 + 3 * (size_t)st.nBlocks;
-    u8* q = reinterpret_cast<u8*>(scratch);
-    auto take = [&](size_t sz) { u8* r = q; q += align256(sz); return r; };
-    const int perTiles = (int)((v.VS + IT - 1) / IT);
-    u32* tileHist = (u32*)take(4ull * 256 * (size_t)perTiles * st.nBlocks);
-    const u32 segT = bwt_i_seg_tiles((u32)perTiles), nSeg = ((u32)perTiles + segT - 1) / segT;
-    u32* segSum = (u32*)take(4ull * 256 * (size_t)nSeg * st.nBlocks);
-    u32* Cb = (u32*)take(4ull * 256 * st.nBlocks);
-    u32* term = (u32*)take(4ull * (st.nBlocks + 1));
-    u64* rec = (u64*)take(8 * maxTotal);
-    u32* flags = (u32*)take(8 * (maxTotal / 32 + 2)); u32* scanIdx = (u32*)take(4 * (maxTotal / 32 + 2));   // splitter bit map + word counts, word prefix
-    u32* splitNode = (u32*)take(4 * maxSplit);
-    u32* nA = (u32*)take(4 * maxSplit); u32* nB = (u32*)take(4 * maxSplit);
-    u32* dA = (u32*)take(4 * maxSplit); u32* dB = (u32*)take(4 * maxSplit);
-    u32* spare = (u32*)take(4 * maxSplit); (void)spare;
-    BwtHdr* hd = (BwtHdr*)take(sizeof(BwtHdr) * (size_t)st.nBlocks);
-    u32* base = (u32*)take(4ull * (st.nBlocks + 2));
-    void* prim = q;
-    const size_t primBytes = scratchBytes - (size_t)(q - reinterpret_cast<u8*>(scratch));
-    { KScope ks_("k_bwt_i_header"); hipLaunchKernelGGL(k_bwt_i_header, dim3(1), dim3(64), 0, s, v, hd, base, st.ok, st.newLen); }
-    if (hipMemcpyAsync(h_pinned, base + st.nBlocks, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
-    if (hipStreamSynchronize(s) != hipSuccess) return -1;
-    const u32 total = h_pinned[0];
-    { KScope ks_("k_bwt_i_tiny"); hipLaunchKernelGGL(k_bwt_i_tiny, dim3((st.nBlocks + 63) / 64), dim3(64), 0, s, v, hd); }
-    if (total == 0) return 0;
+    InvScratch w;
+    if (inv_carve(reinterpret_cast<u8*>(scratch), st.nBlocks, v.VS, maxTotal, &w) > scratchBytes) return -2;
+    const int perTiles = w.perTiles;
+    const u32 segT = w.segT, nSeg = w.nSeg;
+    // no size is read back: every grid is sized by the upper bound (blocks x longest block), the kernels take the sizes from `info`
+    { KScope ks_("k_bwt_i_header"); hipLaunchKernelGGL(k_bwt_i_header, dim3(1), dim3(64), 0, s, v, w.hd, w.base, st.ok, st.newLen, w.info); }
+    { KScope ks_("k_bwt_i_tiny"); hipLaunchKernelGGL(k_bwt_i_tiny, dim3((st.nBlocks + 63) / 64), dim3(64), 0, s, v, w.hd); }
     const dim3 gridT((unsigned)perTiles, st.nBlocks);
-    { KScope ks_("k_bwt_i_hist"); hipLaunchKernelGGL(k_bwt_i_hist, gridT, dim3(256), 0, s, v, hd, perTiles, tileHist); }
-    { KScope ks_("k_bwt_i_scan"); hipLaunchKernelGGL(k_bwt_i_scan, dim3(nSeg, st.nBlocks), dim3(256), 0, s, hd, perTiles, segT, nSeg, tileHist, segSum);
-      hipLaunchKernelGGL(k_bwt_i_scan2, dim3(st.nBlocks), dim3(256), 0, s, v, hd, base, nSeg, segSum, Cb, term); }
-    { KScope ks_("k_bwt_i_links"); hipLaunchKernelGGL(k_bwt_i_links, gridT, dim3(256), 0, s, v, hd, base, perTiles, tileHist, segT, nSeg, segSum, Cb, term, rec); }
-    const u32 nWords = (total + 31) / 32;
-    u32* bits = flags; u32* wcount = flags + nWords; u32* wprefix = scanIdx;           // (the two node-sized arrays of the first version)
-    { KScope ks_("k_bwt_i_flags"); hipLaunchKernelGGL(k_bwt_i_flags, GRID1(nWords), hd, base, term, st.nBlocks, total, bits, wcount); }
-    size_t pb;
-    pb = primBytes;
-    { KScope ks_("bwt_i_scan_sum"); if (rocprim::exclusive_scan(prim, pb, wcount, wprefix, 0u, (size_t)nWords, rocprim::plus<u32>(), s) != hipSuccess) return -1; }
-    { KScope ks_("k_bwt_i_compact"); hipLaunchKernelGGL(k_bwt_i_compact, GRID1(nWords), bits, wprefix, nWords, splitNode); }
-    hipMemcpyAsync(h_pinned, wprefix + (nWords - 1), 4, hipMemcpyDeviceToHost, s);
-    hipMemcpyAsync(h_pinned + 1, wcount + (nWords - 1), 4, hipMemcpyDeviceToHost, s);
-    if (hipStreamSynchronize(s) != hipSuccess) return -1;
-    const u32 count = h_pinned[0] + h_pinned[1];
-    if (count == 0 || count > maxSplit) return -3;
-    const u32 limit = v.VS + 1;
-    { KScope ks_("k_bwt_i_walk1"); hipLaunchKernelGGL(k_bwt_i_walk1, GRID1(count), rec, splitNode, bits, wprefix, count, limit, nA, dA); }
-    for (u32 span = 1; span < count; span <<= 1) {
-        { KScope ks_("k_bwt_i_jump"); hipLaunchKernelGGL(k_bwt_i_jump, GRID1(count), nA, dA, count, nB, dB); }
+    { KScope ks_("k_bwt_i_hist"); hipLaunchKernelGGL(k_bwt_i_hist, gridT, dim3(256), 0, s, v, w.hd, perTiles, w.tileHist); }
+    { KScope ks_("k_bwt_i_scan"); hipLaunchKernelGGL(k_bwt_i_scan, dim3(nSeg, st.nBlocks), dim3(256), 0, s, w.hd, perTiles, segT, nSeg, w.tileHist, w.segSum);
+      hipLaunchKernelGGL(k_bwt_i_scan2, dim3(st.nBlocks), dim3(256), 0, s, v, w.hd, w.base, nSeg, w.segSum, w.Cb, w.term); }
+    { KScope ks_("k_bwt_i_links"); hipLaunchKernelGGL(k_bwt_i_links, gridT, dim3(256), 0, s, v, w.hd, w.base, perTiles, w.tileHist, segT, nSeg, w.segSum, w.Cb, w.term, w.rec); }
+    const u32 nWordsMax = (u32)(maxTotal / 32 + 1);
+    { KScope ks_("k_bwt_i_flags"); hipLaunchKernelGGL(k_bwt_i_flags, GRID1(nWordsMax), w.hd, w.base, w.term, st.nBlocks, w.info, w.bits, w.wcount); }
+    { KScope ks_("k_bwt_i_scan_words"); prims::launch_scan<prims::SCAN_SUM_EXCL>(s, w.wcount, w.wprefix, nWordsMax, &w.info->nWords, w.scanTmp, &w.info->count); }
+    { KScope ks_("k_bwt_i_compact"); hipLaunchKernelGGL(k_bwt_i_compact, GRID1(nWordsMax), w.bits, w.wprefix, w.info, w.maxRows, w.rowNode); }
+    const u32 maxCount = (u32)(maxTotal / 48 + 4096 + 3 * (size_t)st.nBlocks);
+    { KScope ks_("k_bwt_i_walk"); hipLaunchKernelGGL(k_bwt_i_walk, GRID1(maxCount), w.rec, w.rowNode, w.bits, w.wprefix, w.info, w.maxRows, w.nA, w.dA, w.rowLen, w.rows); }
+    u32* nA = w.nA; u32* nB = w.nB; u32* dA = w.dA; u32* dB = w.dB;
+    // chains never leave a block: a chain has at most rows-per-block rows
+    const u64 chainRows = (u64)v.VS / 48 + (u64)v.VS / ROW + 4096 + 3;
+    for (u64 span = 1; span < chainRows; span <<= 1) {
+        { KScope ks_("k_bwt_i_jump"); hipLaunchKernelGGL(k_bwt_i_jump, GRID1(w.maxRows), nA, dA, w.info, w.maxRows, nB, dB); }
         std::swap(nA, nB); std::swap(dA, dB);
     }
-    { KScope ks_("k_bwt_i_walk2"); hipLaunchKernelGGL(k_bwt_i_walk2, GRID1(count), v, hd, base, rec, splitNode, dA, count, limit); }
+    { KScope ks_("k_bwt_i_place"); hipLaunchKernelGGL(k_bwt_i_place, dim3((w.maxRows + 7) / 8), dim3(256), 0, s, v, w.hd, w.base, w.rowNode, dA, w.rowLen, w.rows, w.info, w.maxRows); }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

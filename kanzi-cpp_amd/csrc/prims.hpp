@@ -1,0 +1,417 @@
+// Device-wide primitives written for this library (gfx950, wave64): prefix scans over 32-bit words and a stable LSD
+// radix sort (8-bit digits) over segmented arrays. They replace the rocPRIM calls of rounds 1-2 in the BWT stages and
+// the LZ match finder. Every size a kernel needs can be read from device memory (`nDev`, `base[]`), so that a sequence of
+// launches does not need the host to read a counter back in between.
+//
+// Sort pass = four launches: tile histograms (one row of 256 counters per tile of 4096 keys, coalesced), a column scan
+// of the rows in two levels (inside groups of RS_GROUP tiles, then over the groups and the digits), and the scatter:
+// the tile's keys are ranked inside the workgroup (ballot matching inside a wave, rows in order; per-wave digit counters
+// scanned in (digit, wave) order), staged through LDS in sorted order and written out as runs of consecutive addresses.
+#pragma once
+#include <algorithm>
+#include "common.hpp"
+
+namespace knz {
+namespace prims {
+
+// ------------------------------------------------------------------------------------------------
+// scans over u32
+// ------------------------------------------------------------------------------------------------
+enum ScanOp { SCAN_SUM_EXCL = 0, SCAN_MAX_INCL = 1, SCAN_MIN_INCL = 2 };
+
+constexpr u32 SC_TILE = 4096;            // 256 threads x 16 words
+
+template <int OP> __device__ __forceinline__ u32 sc_ident() { return OP == SCAN_MIN_INCL ? 0xFFFFFFFFu : 0u; }
+template <int OP> __device__ __forceinline__ u32 sc_op(u32 a, u32 b) { return OP == SCAN_SUM_EXCL ? a + b : (OP == SCAN_MAX_INCL ? (a > b ? a : b) : (a < b ? a : b)); }
+
+template <int OP>
+__device__ __forceinline__ u32 sc_wave_incl(u32 v)
+{
+    if (OP == SCAN_SUM_EXCL) return wave_incl_scan(v);
+    for (int o = 1; o < 64; o <<= 1) { const u32 t = (u32)__shfl_up((int)v, (unsigned)o, 64); if (lane_id() >= o) v = sc_op<OP>(t, v); }
+    return v;
+}
+
+// inclusive scan of one value per thread over a workgroup of 256 threads; *total = reduction over the workgroup
+template <int OP>
+__device__ __forceinline__ u32 sc_block_incl(u32 v, u32* wsum /* [4] in LDS */, u32* total)
+{
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const u32 incl = sc_wave_incl<OP>(v);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    u32 carry = sc_ident<OP>();
+    for (int w = 0; w < wave; w++) carry = sc_op<OP>(carry, wsum[w]);
+    u32 tot = sc_ident<OP>();
+    for (int w = 0; w < 4; w++) tot = sc_op<OP>(tot, wsum[w]);
+    *total = tot;
+    __syncthreads();
+    return sc_op<OP>(carry, incl);
+}
+
+// partial[t] = reduction of tile t
+template <int OP>
+__global__ __launch_bounds__(256) void k_scan_reduce(const u32* __restrict__ in, u32 nMax, const u32* __restrict__ nDev, u32* __restrict__ partial)
+{
+    __shared__ u32 wsum[4];
+    const u32 n = nDev ? (*nDev < nMax ? *nDev : nMax) : nMax;
+    const u32 nT = (n + SC_TILE - 1) / SC_TILE;
+    for (u32 t = blockIdx.x; t < nT; t += gridDim.x) {
+        u32 acc = sc_ident<OP>();
+        const u32 i0 = t * SC_TILE + threadIdx.x * 16u;
+        if (i0 + 16 <= n) {
+            const uint4* p = reinterpret_cast<const uint4*>(in + i0);
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const uint4 x = p[k]; acc = sc_op<OP>(sc_op<OP>(sc_op<OP>(sc_op<OP>(acc, x.x), x.y), x.z), x.w); }
+        } else {
+            for (u32 k = 0; k < 16; k++) if (i0 + k < n) acc = sc_op<OP>(acc, in[i0 + k]);
+        }
+        u32 tot;
+        sc_block_incl<OP>(acc, wsum, &tot);
+        if (threadIdx.x == 0) partial[t] = tot;
+    }
+}
+
+// one workgroup of 256 threads scans a short array in place (exclusive for the sum, which is what the tiles need as their
+// carry; for max / min the carry of tile t is the inclusive result of tile t-1, i.e. also "exclusive")
+template <int OP>
+__global__ __launch_bounds__(256) void k_scan_carries(u32* __restrict__ partial, u32 nMax, const u32* __restrict__ nDev)
+{
+    __shared__ u32 wsum[4];
+    __shared__ u32 inclAll[256];
+    const u32 n = nDev ? (*nDev < nMax ? *nDev : nMax) : nMax;
+    const u32 nT = (n + SC_TILE - 1) / SC_TILE;
+    u32 carry = sc_ident<OP>();
+    for (u32 c0 = 0; c0 < nT; c0 += 256 * 16) {
+        u32 x[16];
+        const u32 i0 = c0 + threadIdx.x * 16u;
+        u32 acc = sc_ident<OP>();
+#pragma unroll
+        for (u32 k = 0; k < 16; k++) { x[k] = (i0 + k < nT) ? partial[i0 + k] : sc_ident<OP>(); acc = sc_op<OP>(acc, x[k]); }
+        u32 tot;
+        const u32 incl = sc_block_incl<OP>(acc, wsum, &tot);
+        inclAll[threadIdx.x] = incl;
+        __syncthreads();
+        u32 run = sc_op<OP>(carry, threadIdx.x ? inclAll[threadIdx.x - 1] : sc_ident<OP>());     // everything before this thread's 16 values
+        __syncthreads();
+#pragma unroll
+        for (u32 k = 0; k < 16; k++) { if (i0 + k < nT) partial[i0 + k] = run; run = sc_op<OP>(run, x[k]); }
+        carry = sc_op<OP>(carry, tot);
+    }
+}
+
+template <int OP>
+__global__ __launch_bounds__(256) void k_scan_apply(const u32* __restrict__ in, u32* __restrict__ out, u32 nMax, const u32* __restrict__ nDev,
+                                                    const u32* __restrict__ carries, u32* __restrict__ totalOut)
+{
+    __shared__ u32 wsum[4];
+    __shared__ u32 inclAll[256];
+    const u32 n = nDev ? (*nDev < nMax ? *nDev : nMax) : nMax;
+    const u32 nT = (n + SC_TILE - 1) / SC_TILE;
+    for (u32 t = blockIdx.x; t < nT; t += gridDim.x) {
+        u32 x[16];
+        const u32 i0 = t * SC_TILE + threadIdx.x * 16u;
+        u32 acc = sc_ident<OP>();
+        if (i0 + 16 <= n) {
+            const uint4* p = reinterpret_cast<const uint4*>(in + i0);
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const uint4 v = p[k]; x[4 * k] = v.x; x[4 * k + 1] = v.y; x[4 * k + 2] = v.z; x[4 * k + 3] = v.w; }
+        } else {
+#pragma unroll
+            for (u32 k = 0; k < 16; k++) x[k] = (i0 + k < n) ? in[i0 + k] : sc_ident<OP>();
+        }
+#pragma unroll
+        for (u32 k = 0; k < 16; k++) acc = sc_op<OP>(acc, x[k]);
+        u32 tot;
+        const u32 incl = sc_block_incl<OP>(acc, wsum, &tot);
+        inclAll[threadIdx.x] = incl;
+        __syncthreads();
+        u32 run = threadIdx.x ? inclAll[threadIdx.x - 1] : sc_ident<OP>();
+        __syncthreads();
+        run = sc_op<OP>(carries[t], run);
+        u32 y[16];
+#pragma unroll
+        for (u32 k = 0; k < 16; k++) {
+            if (OP == SCAN_SUM_EXCL) { y[k] = run; run += x[k]; }
+            else { run = sc_op<OP>(run, x[k]); y[k] = run; }
+        }
+        if (i0 + 16 <= n) {
+            uint4* q = reinterpret_cast<uint4*>(out + i0);
+#pragma unroll
+            for (int k = 0; k < 4; k++) q[k] = make_uint4(y[4 * k], y[4 * k + 1], y[4 * k + 2], y[4 * k + 3]);
+        } else {
+#pragma unroll
+            for (u32 k = 0; k < 16; k++) if (i0 + k < n) out[i0 + k] = y[k];
+        }
+        if (totalOut != nullptr && t + 1 == nT && threadIdx.x == 255) *totalOut = run;       // sum of everything (exclusive scan: n-th value)
+    }
+}
+
+static inline size_t scan_tmp_bytes(size_t nMax) { return (((nMax + SC_TILE - 1) / SC_TILE) * 4 + 255 + 256) & ~(size_t)255; }
+
+// out[i] = scan of in[0..i) (sum) or in[0..i] (max / min); in == out allowed; both 16-byte aligned. n = min(nMax, *nDev) when nDev
+// is given. totalOut (optional, sum only): the sum of all n values.
+template <int OP>
+static inline void launch_scan(hipStream_t s, const u32* in, u32* out, size_t nMax, const u32* nDev, void* tmp, u32* totalOut = nullptr)
+{
+    if (nMax == 0) return;
+    u32* partial = reinterpret_cast<u32*>(tmp);
+    const u32 nT = (u32)((nMax + SC_TILE - 1) / SC_TILE);
+    const u32 grid = nT < 4096 ? nT : 4096;
+    hipLaunchKernelGGL((k_scan_reduce<OP>), dim3(grid), dim3(256), 0, s, in, (u32)nMax, nDev, partial);
+    hipLaunchKernelGGL((k_scan_carries<OP>), dim3(1), dim3(256), 0, s, partial, (u32)nMax, nDev);
+    hipLaunchKernelGGL((k_scan_apply<OP>), dim3(grid), dim3(256), 0, s, in, out, (u32)nMax, nDev, partial, totalOut);
+}
+
+// ------------------------------------------------------------------------------------------------
+// radix sort
+// ------------------------------------------------------------------------------------------------
+constexpr u32 RS_TILE = 4096;            // keys per tile: 4 waves x 16 rows of 64
+constexpr u32 RS_GROUP = 64;             // tiles per group of the column scan
+
+// lanes of the wave whose (valid) 8-bit digit equals mine
+__device__ __forceinline__ unsigned long long digit_peers(bool valid, u32 dg)
+{
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 8; bit++) {
+        const bool one = (dg >> bit) & 1u;
+        const unsigned long long bal = __ballot(valid && one);
+        peers &= one ? bal : ~bal;
+    }
+    return peers;
+}
+
+// Segments: segment g is [base[g], base[g+1]) of the key arrays (dense, base[0] = 0); a tile never straddles segments.
+// tileOff[g] = number of tiles in the segments before g (tileOff[nSeg] = all tiles), grpOff likewise for tile groups.
+struct RsLayout {
+    const u32* base;
+    u32* tileOff;        // [nSeg + 1]
+    u32* grpOff;         // [nSeg + 1]
+    u32* tileHist;       // [tiles][256]: counts, then exclusive inside the tile's group
+    u32* grpSum;         // [groups][256]: group totals, then exclusive over the groups of the segment
+    u32* digitBase;      // [nSeg][256]: output position of the first key with that digit (includes base[g])
+    int nSeg;
+};
+
+__global__ void k_rs_layout(RsLayout L)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    u32 t = 0, g = 0;
+    for (int sgm = 0; sgm < L.nSeg; sgm++) {
+        L.tileOff[sgm] = t; L.grpOff[sgm] = g;
+        const u32 len = L.base[sgm + 1] - L.base[sgm];
+        const u32 nT = (len + RS_TILE - 1) / RS_TILE;
+        t += nT; g += (nT + RS_GROUP - 1) / RS_GROUP;
+    }
+    L.tileOff[L.nSeg] = t; L.grpOff[L.nSeg] = g;
+}
+
+// digit of a key; the caller's functor may read anything (a key array, or the text for the first pass of the suffix sort)
+template <class KEY> struct DigitOfKey {
+    const KEY* keys; int shift; u32 mask;
+    __device__ __forceinline__ KEY load(u32 idx) const { return keys[idx]; }
+    __device__ __forceinline__ u32 digit(KEY k) const { return (u32)(k >> shift) & mask; }
+};
+
+template <class SRC>
+__global__ __launch_bounds__(256) void k_rs_count(SRC src, RsLayout L)
+{
+    __shared__ u32 cnt[4][256];
+    const int sgm = blockIdx.y;
+    const u32 b0 = L.base[sgm], len = L.base[sgm + 1] - b0;
+    const u32 nT = (len + RS_TILE - 1) / RS_TILE;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (u32 t = blockIdx.x; t < nT; t += gridDim.x) {
+        for (int w = 0; w < 4; w++) cnt[w][tid] = 0;
+        __syncthreads();
+#pragma unroll 4
+        for (int r = 0; r < 16; r++) {
+            const u32 i = t * RS_TILE + (u32)wave * 1024u + (u32)r * 64u + (u32)lane;
+            const bool valid = i < len;
+            const u32 dg = valid ? src.digit(src.load(b0 + i)) : 0u;
+            const unsigned long long peers = digit_peers(valid, dg);
+            if (valid && lane == __ffsll((long long)peers) - 1) cnt[wave][dg] += (u32)__popcll(peers);
+            KNZ_WAVE_ORDER();
+        }
+        __syncthreads();
+        L.tileHist[((size_t)L.tileOff[sgm] + t) * 256 + tid] = cnt[0][tid] + cnt[1][tid] + cnt[2][tid] + cnt[3][tid];
+        __syncthreads();
+    }
+}
+
+// exclusive scan of the tile rows inside every group of RS_GROUP tiles, one thread per digit; grpSum = the group's totals
+__global__ __launch_bounds__(256) void k_rs_colscan1(RsLayout L)
+{
+    const int sgm = blockIdx.y;
+    const u32 len = L.base[sgm + 1] - L.base[sgm];
+    const u32 nT = (len + RS_TILE - 1) / RS_TILE, nG = (nT + RS_GROUP - 1) / RS_GROUP;
+    const int tid = (int)threadIdx.x;
+    for (u32 g = blockIdx.x; g < nG; g += gridDim.x) {
+        const u32 t0 = g * RS_GROUP, t1 = (t0 + RS_GROUP < nT) ? t0 + RS_GROUP : nT;
+        u32* p = L.tileHist + (size_t)L.tileOff[sgm] * 256 + tid;
+        u32 run = 0;
+        for (u32 t = t0; t < t1; t++) { const u32 x = p[(size_t)t * 256]; p[(size_t)t * 256] = run; run += x; }
+        L.grpSum[((size_t)L.grpOff[sgm] + g) * 256 + tid] = run;
+    }
+}
+
+// per segment: exclusive scan over the groups (per digit), then over the digits
+__global__ __launch_bounds__(256) void k_rs_colscan2(RsLayout L)
+{
+    __shared__ u32 wsum[4];
+    __shared__ u32 inclAll[256];
+    const int sgm = blockIdx.x;
+    const u32 len = L.base[sgm + 1] - L.base[sgm];
+    const u32 nT = (len + RS_TILE - 1) / RS_TILE, nG = (nT + RS_GROUP - 1) / RS_GROUP;
+    const int tid = (int)threadIdx.x;
+    u32* p = L.grpSum + (size_t)L.grpOff[sgm] * 256 + tid;
+    u32 run = 0;
+    for (u32 g = 0; g < nG; g++) { const u32 x = p[(size_t)g * 256]; p[(size_t)g * 256] = run; run += x; }
+    u32 tot;
+    const u32 incl = sc_block_incl<SCAN_SUM_EXCL>(run, wsum, &tot);
+    inclAll[tid] = incl;
+    __syncthreads();
+    L.digitBase[sgm * 256 + tid] = L.base[sgm] + (tid ? inclAll[tid - 1] : 0u);
+}
+
+// Ranks the tile's keys (held 16 per thread, element (wave, row, lane) = tile index wave*1024 + row*64 + lane) by digit, stably,
+// and leaves in pos[] the index every element takes in the tile's sorted order; dStart[d] (LDS) = first sorted index of digit d.
+__device__ __forceinline__ void rs_rank_tile(const u32 (&dg)[16], const bool (&valid)[16], u32 (&pos)[16], u32 (*cnt)[256], u32* dStart, u32* wsum, u32* inclAll)
+{
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int w = 0; w < 4; w++) cnt[w][tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const unsigned long long peers = digit_peers(valid[r], dg[r]);
+        const int leader = __ffsll((long long)peers) - 1;
+        u32 old = 0;
+        if (valid[r] && lane == leader) { old = cnt[wave][dg[r]]; cnt[wave][dg[r]] = old + (u32)__popcll(peers); }
+        KNZ_WAVE_ORDER();
+        old = (u32)__shfl((int)old, leader < 0 ? 0 : leader, 64);
+        pos[r] = old + (u32)__popcll(peers & ltMask);
+    }
+    __syncthreads();
+    // (digit, wave) order: a thread owns a digit
+    const u32 c0 = cnt[0][tid], c1 = cnt[1][tid], c2 = cnt[2][tid], c3 = cnt[3][tid];
+    u32 tot;
+    const u32 incl = sc_block_incl<SCAN_SUM_EXCL>(c0 + c1 + c2 + c3, wsum, &tot);
+    inclAll[tid] = incl;
+    __syncthreads();
+    const u32 excl = tid ? inclAll[tid - 1] : 0u;
+    dStart[tid] = excl;
+    cnt[0][tid] = excl; cnt[1][tid] = excl + c0; cnt[2][tid] = excl + c0 + c1; cnt[3][tid] = excl + c0 + c1 + c2;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; r++) if (valid[r]) pos[r] += cnt[wave][dg[r]];
+}
+
+template <class KEY, bool HAS_VAL, class SRC>
+__global__ __launch_bounds__(256) void k_rs_scatter(SRC src, const u32* __restrict__ vin, KEY* __restrict__ kout, u32* __restrict__ vout, RsLayout L)
+{
+    __shared__ u32 cnt[4][256];
+    __shared__ u32 dStart[256];
+    __shared__ u32 gBase[256];
+    __shared__ u32 wsum[4];
+    __shared__ u32 inclAll[256];
+    __shared__ KEY sK[RS_TILE];
+    __shared__ u32 sV[HAS_VAL ? RS_TILE : 1];
+    const int sgm = blockIdx.y;
+    const u32 b0 = L.base[sgm], len = L.base[sgm + 1] - b0;
+    const u32 nT = (len + RS_TILE - 1) / RS_TILE;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (u32 t = blockIdx.x; t < nT; t += gridDim.x) {
+        KEY key[16]; u32 val[16]; u32 dg[16], pos[16]; bool valid[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const u32 i = t * RS_TILE + (u32)wave * 1024u + (u32)r * 64u + (u32)lane;
+            valid[r] = i < len;
+            key[r] = valid[r] ? src.load(b0 + i) : (KEY)0;
+            if (HAS_VAL) val[r] = valid[r] ? vin[b0 + i] : 0u;
+            dg[r] = valid[r] ? src.digit(key[r]) : 0u;
+        }
+        rs_rank_tile(dg, valid, pos, cnt, dStart, wsum, inclAll);
+        gBase[tid] = L.digitBase[sgm * 256 + tid] + L.grpSum[((size_t)L.grpOff[sgm] + t / RS_GROUP) * 256 + tid]
+                     + L.tileHist[((size_t)L.tileOff[sgm] + t) * 256 + tid];
+#pragma unroll
+        for (int r = 0; r < 16; r++) if (valid[r]) { sK[pos[r]] = key[r]; if (HAS_VAL) sV[pos[r]] = val[r]; }
+        __syncthreads();
+        const u32 cntTile = (len - t * RS_TILE < RS_TILE) ? len - t * RS_TILE : RS_TILE;
+#pragma unroll 4
+        for (u32 j = (u32)tid; j < cntTile; j += 256) {
+            const KEY k = sK[j];
+            const u32 d = src.digit(k);
+            const u32 at = gBase[d] + (j - dStart[d]);
+            kout[at] = k;
+            if (HAS_VAL) vout[at] = sV[j];
+        }
+        __syncthreads();
+    }
+}
+
+struct RsWs { RsLayout L; size_t maxTiles; };
+
+static inline size_t rs_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// workspace for sorts of up to maxN keys in up to maxSeg segments
+static inline size_t rs_ws_bytes(size_t maxN, int maxSeg)
+{
+    const size_t tiles = maxN / RS_TILE + (size_t)maxSeg + 1, groups = tiles / RS_GROUP + (size_t)maxSeg + 1;
+    return rs_align(tiles * 1024) + rs_align(groups * 1024) + rs_align((size_t)maxSeg * 1024) + 2 * rs_align(4ull * (maxSeg + 1)) + 256;
+}
+
+static inline RsWs rs_carve(void* p, size_t maxN, int maxSeg, const u32* base, int nSeg)
+{
+    const size_t tiles = maxN / RS_TILE + (size_t)maxSeg + 1, groups = tiles / RS_GROUP + (size_t)maxSeg + 1;
+    u8* q = reinterpret_cast<u8*>(p);
+    RsWs w;
+    w.L.base = base; w.L.nSeg = nSeg;
+    w.L.tileHist = reinterpret_cast<u32*>(q); q += rs_align(tiles * 1024);
+    w.L.grpSum = reinterpret_cast<u32*>(q); q += rs_align(groups * 1024);
+    w.L.digitBase = reinterpret_cast<u32*>(q); q += rs_align((size_t)maxSeg * 1024);
+    w.L.tileOff = reinterpret_cast<u32*>(q); q += rs_align(4ull * (maxSeg + 1));
+    w.L.grpOff = reinterpret_cast<u32*>(q); q += rs_align(4ull * (maxSeg + 1));
+    w.maxTiles = tiles;
+    return w;
+}
+
+static inline void rs_launch_layout(hipStream_t s, const RsWs& w) { hipLaunchKernelGGL(k_rs_layout, dim3(1), dim3(64), 0, s, w.L); }
+
+// grid.x for a pass over segments of at most maxSegLen keys
+static inline unsigned rs_grid_x(size_t maxSegLen, int nSeg)
+{
+    size_t t = (maxSegLen + RS_TILE - 1) / RS_TILE;
+    const size_t cap = nSeg > 1 ? 2048 : 8192;
+    if (t > cap) t = cap;
+    return (unsigned)(t ? t : 1);
+}
+
+// one stable pass on the digit SRC extracts; the layout kernel must have run for these segments
+template <class KEY, bool HAS_VAL, class SRC>
+static inline void rs_launch_pass(hipStream_t s, const RsWs& w, SRC src, const u32* vin, KEY* kout, u32* vout, size_t maxSegLen)
+{
+    const dim3 grid(rs_grid_x(maxSegLen, w.L.nSeg), (unsigned)w.L.nSeg);
+    const unsigned gx = (unsigned)std::max<size_t>(1, std::min<size_t>(((maxSegLen + RS_TILE - 1) / RS_TILE + RS_GROUP - 1) / RS_GROUP, 1024));
+    hipLaunchKernelGGL((k_rs_count<SRC>), grid, dim3(256), 0, s, src, w.L);
+    hipLaunchKernelGGL(k_rs_colscan1, dim3(gx, (unsigned)w.L.nSeg), dim3(256), 0, s, w.L);
+    hipLaunchKernelGGL(k_rs_colscan2, dim3((unsigned)w.L.nSeg), dim3(256), 0, s, w.L);
+    hipLaunchKernelGGL((k_rs_scatter<KEY, HAS_VAL, SRC>), grid, dim3(256), 0, s, src, vin, kout, vout, w.L);
+}
+
+// Stable LSD sort on key bits [loBit, hiBit). Returns 0 when the result is in (ka, va), 1 when in (kb, vb).
+template <class KEY, bool HAS_VAL>
+static inline int rs_sort(hipStream_t s, const RsWs& w, KEY* ka, KEY* kb, u32* va, u32* vb, size_t maxSegLen, int loBit, int hiBit)
+{
+    int cur = 0;
+    for (int sh = loBit; sh < hiBit; sh += 8) {
+        DigitOfKey<KEY> src; src.keys = cur ? kb : ka; src.shift = sh; src.mask = (hiBit - sh >= 8) ? 255u : ((1u << (hiBit - sh)) - 1u);
+        rs_launch_pass<KEY, HAS_VAL>(s, w, src, cur ? vb : va, cur ? ka : kb, cur ? va : vb, maxSegLen);
+        cur ^= 1;
+    }
+    return cur;
+}
+
+}  // namespace prims
+}  // namespace knz

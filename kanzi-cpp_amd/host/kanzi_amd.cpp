@@ -735,6 +735,7 @@ CompressedOutputStream::CompressedOutputStream(std::ostream& os, int tasks, cons
         _out[i].buf = nullptr; _out[i].cap = 0; _out[i].bytes = 0; _out[i].state = 0;
     }
     _fill = 0; _proc = 0; _outProd = 0; _outCons = 0; _stop = false;
+    _batchBytes = 0;
     deviceContext();
 }
 
@@ -758,7 +759,7 @@ CompressedOutputStream::~CompressedOutputStream()
 void CompressedOutputStream::rethrow()
 {
     std::exception_ptr e;
-    { std::lock_guard<std::mutex> l(_mu); e = _err; _err = nullptr; }
+    { std::lock_guard<std::mutex> l(_mu); e = _err; }          // a failure is sticky: no batch is submitted after a failed one
     if (e) std::rethrow_exception(e);
 }
 
@@ -767,7 +768,8 @@ std::ostream& CompressedOutputStream::write(const char* data, std::streamsize le
     if (length < 0) throw IOException("Invalid buffer size");
     if (_closed) throw IOException("Stream closed", Error::ERR_WRITE_FILE);
     rethrow();
-    const size_t batchBytes = size_t(_batchBlocks) * size_t(_blockSize);
+    if (_batchBytes == 0) _batchBytes = size_t(_batchBlocks) * size_t(_blockSize);      // latched: the staging slots are sized for it
+    const size_t batchBytes = _batchBytes;
     size_t off = 0;
     while (off < size_t(length)) {
         Slot& sl = _slot[_fill];
@@ -807,6 +809,7 @@ bool CompressedOutputStream::drainOne(std::unique_lock<std::mutex>& l)
 // in flight), write finished batches to the sink, and wait until the other slot is free
 void CompressedOutputStream::enqueue(bool last)
 {
+    rethrow();
     if (!_worker.joinable()) _worker = std::thread(&CompressedOutputStream::workerLoop, this);
     {
         // the device buffer of this slot was last read by the batch that freed the slot: safe to overwrite
@@ -842,23 +845,26 @@ void CompressedOutputStream::workerLoop()
         {
             std::unique_lock<std::mutex> l(_mu);
             _cv.wait(l, [&] { return _stop || _slot[_proc].state == 1; });
-            if (_slot[_proc].state != 1) return;
+            if (_slot[_proc].state != 1 || _err) return;
         }
         bool last = _slot[_proc].last;
+        std::exception_ptr ex;
         try {
             submit(last);
         } catch (...) {
-            std::lock_guard<std::mutex> l(_mu);
-            if (!_err) _err = std::current_exception();
+            ex = std::current_exception();
         }
         {
+            // the failure is recorded and the slot released in ONE critical section: a caller that leaves its wait because of
+            // the error never sees a slot the worker still owns
             std::lock_guard<std::mutex> l(_mu);
+            if (ex && !_err) _err = ex;
             _slot[_proc].n = 0;
             _slot[_proc].state = 0;
             _proc ^= 1;
         }
         _cv.notify_all();
-        if (last) return;
+        if (last || ex) return;
     }
 }
 
@@ -925,7 +931,9 @@ void CompressedOutputStream::close()
     if (_closed) return;
     _closed = true;
     try {
-        enqueue(true);                      // the last batch (possibly empty) carries the end marker
+        bool failed;
+        { std::lock_guard<std::mutex> l(_mu); failed = bool(_err); }
+        if (!failed) enqueue(true);         // the last batch (possibly empty) carries the end marker; nothing follows a failed batch
         {
             std::unique_lock<std::mutex> l(_mu);
             for (;;) {
