@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <algorithm>
 #include <functional>
 #include <map>
@@ -176,6 +177,19 @@ void knz_hip_destroy(knz_ctx* ctx)
     if (c->copyOut) hipStreamDestroy(c->copyOut);
     if (c->ownStream) hipStreamDestroy(c->stream);
     delete c;
+}
+
+static std::atomic<int>& bwt_split_knob()
+{
+    static std::atomic<int> v([] { const char* e = getenv("KNZ_BWT_SPLIT"); const int x = e ? atoi(e) : 3; return x < 1 ? 1 : (x > 4 ? 4 : x); }());
+    return v;
+}
+
+int knz_hip_tune(const char* name, int value)
+{
+    if (name == nullptr) return -1;
+    if (!strcmp(name, "bwt_split")) { bwt_split_knob().store(value < 1 ? 1 : (value > 4 ? 4 : value)); return 0; }
+    return bwt_forward_tune(name, value);
 }
 
 const char* knz_hip_last_error(knz_ctx* ctx) { return ctx ? reinterpret_cast<Ctx*>(ctx)->err : "null context"; }
@@ -399,9 +413,8 @@ static size_t stage_scratch_u32(int t, int nBlocks, u32 maxLen, bool forward = t
 // timing is on (the timing hooks belong to the caller's thread).
 static int bwt_parts_wanted(const Ctx* c, int nBlocks)
 {
-    static const int env = [] { const char* e = getenv("KNZ_BWT_SPLIT"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
     if (c->profiling) return 1;
-    int parts = env;
+    int parts = bwt_split_knob().load();
     while (parts > 1 && nBlocks < 2 * parts) parts--;            // at least two blocks per part
     return parts;
 }

@@ -27,7 +27,7 @@
 #include <cstring>
 #include <algorithm>
 #include <cmath>
-#include <rocprim/rocprim.hpp>
+#include "prims.hpp"
 
 namespace knz {
 
@@ -89,61 +89,71 @@ __global__ void k_bwt_bases(BwtView v, u32* __restrict__ base, u8* __restrict__ 
     *maxLen = mx;                       // longest block the transform applies to
 }
 
-// byte histogram over a 1-in-16 sample of the blocks the transform applies to (16 bytes of every 256): its entropy decides
-// the shape of the round-0 key (launch_bwt_forward)
-__global__ __launch_bounds__(256) void k_bwt_f_sample(BwtView v, const u8* __restrict__ ok, u32* __restrict__ hist)
-{
-    __shared__ u32 h[4][256];
-    const int tid = (int)threadIdx.x, wave = tid >> 6;
-    for (int k = 0; k < 4; k++) h[k][tid] = 0;
-    __syncthreads();
-    const int b = blockIdx.y;
-    if (ok[b]) {
-        const u32 n = v.len[b];
-        const u8* s = v.src[b];
-        for (u32 o = (blockIdx.x * 256u + (u32)tid) * 256u; o < n; o += gridDim.x * 256u * 256u) {
-            const u32 e = (o + 16 < n) ? o + 16 : n;
-            for (u32 i = o; i < e; i++) atomicAdd(&h[wave][s[i]], 1u);
-        }
+// Round-0 key of a suffix: [P bytes of the suffix, zero past the block end | position inside the block in the low pbits bits].
+// There is no block field (every block is a segment of the sort with its own digit bins) and no length field: the P - 1 suffixes
+// that end inside their own key ("short" suffixes) are handed to the first pass IN FRONT of the others, shortest first, and the
+// sort is stable -- so among equal padded keys they come first, shortest first, which is their place ("a proper prefix sorts
+// first"); the flag kernel makes each of them a group of its own.
+struct TextSrc {
+    const u8* const* src;
+    int P, pbits, shift;
+    __device__ __forceinline__ u32 pos_of(u32 n, u32 i) const
+    {
+        const u32 nShort = (u32)(P - 1) < n ? (u32)(P - 1) : n;
+        return i < nShort ? n - 1 - i : i - nShort;
     }
-    __syncthreads();
-    const u32 c = h[0][tid] + h[1][tid] + h[2][tid] + h[3][tid];
-    if (c) atomicAdd(&hist[tid], c);
-}
-
-// keys: [block id | nsym bytes, zero past the block end | min(suffix length, nsym) in 3 bits], values: global position ids.
-// Padding with the smallest byte and breaking ties by length puts a suffix that ends inside the prefix in front of every
-// longer suffix that continues with zero bytes ("shorter sorts first"); suffixes of at least nsym bytes with equal keys share
-// their first nsym symbols.
-// With pbits != 0 the position inside the block rides in the low pbits bits of the key and there are no values: the sort then
-// moves 8 bytes per element and pass instead of 12 (it only looks at the bits above pbits; it is stable, so equal keys stay in
-// position order either way).
-__global__ __launch_bounds__(256) void k_bwt_f_init(BwtView v, const u32* __restrict__ base, const u8* __restrict__ ok, int nsym, int pbits,
-                                                    u64* __restrict__ keys, u32* __restrict__ vals)
-{
-    const int b = blockIdx.y;
-    if (!ok[b]) return;
-    const u32 n = v.len[b];
-    const u8* s = v.src[b];
-    for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        u64 k = (u64)b;
-        for (int q = 0; q < nsym; q++) {
-            const u32 j = i + (u32)q;
-            k = (k << 8) | (j < n ? (u64)s[j] : 0ull);
+    __device__ __forceinline__ u64 load(int sgm, u32, u32 n, u32 i) const
+    {
+        const u8* t = src[sgm];
+        const u32 pos = pos_of(n, i);
+        u64 v = 0;
+        if (pos + 12 <= n) {
+            // eight bytes from three aligned dwords
+            const uintptr_t a = reinterpret_cast<uintptr_t>(t + pos);
+            const u32* w = reinterpret_cast<const u32*>(a & ~(uintptr_t)3);
+            const u32 sh = (u32)(a & 3) * 8;
+            const u64 lo = (u64)w[0] | ((u64)w[1] << 32);
+            v = sh ? ((lo >> sh) | ((u64)w[2] << (64 - sh))) : lo;
+        } else {
+            for (u32 k = 0; k < 8; k++) if (pos + k < n) v |= (u64)t[pos + k] << (8 * k);
         }
-        const u32 left = n - i;
-        k = (k << 3) | (u64)(left < (u32)nsym ? left : (u32)nsym);
-        if (pbits) keys[base[b] + i] = (k << pbits) | (u64)i;
-        else { keys[base[b] + i] = k; vals[base[b] + i] = base[b] + i; }
+        u64 kb = __builtin_bswap64(v) >> (64 - 8 * P);
+        const u32 left = n - pos;
+        if (left < (u32)P) kb &= ~0ull << (8 * ((u32)P - left));
+        return (kb << pbits) | (u64)pos;
     }
-}
+    __device__ __forceinline__ u32 digit(u64 k) const { return (u32)(k >> shift) & 255u; }
+    // (the first pass sorts on the last key byte)
+    __device__ __forceinline__ u32 digit_at(int sgm, u32, u32 n, u32 i) const
+    {
+        const u32 q = pos_of(n, i) + (u32)(P - 1);
+        return q < n ? (u32)src[sgm][q] : 0u;
+    }
+};
 
-// group-start flags of the sorted keys as a bit map (one ballot per wave)
-__global__ __launch_bounds__(256) void k_bwt_f_r0_flags(const u64* __restrict__ keys, u32 total, int pbits, unsigned long long* __restrict__ gbits64)
+// group-start flags of the sorted keys as a bit map (one ballot per wave): a slot starts a group when its key bytes differ from
+// its left neighbour's, when it is the first slot of a block, or when it or its left neighbour is a short suffix
+__global__ __launch_bounds__(256) void k_bwt_f_r0_flags(const u64* __restrict__ keys, const u32* __restrict__ base, int nBlocks, u32 total, int P, int pbits,
+                                                        unsigned long long* __restrict__ gbits64)
 {
-    const u32 a = blockIdx.x * 256 + threadIdx.x;
+    __shared__ int sBlk;
+    const u32 a0 = blockIdx.x * 256;
+    if (threadIdx.x == 0) sBlk = find_block(base, nBlocks, a0 < total ? a0 : (total ? total - 1 : 0));
+    __syncthreads();
+    const u32 a = a0 + threadIdx.x;
     bool f = true;
-    if (a < total) f = (a == 0) || ((keys[a] >> pbits) != (keys[a - 1] >> pbits));
+    if (a < total) {
+        int b = sBlk;
+        while (a >= base[b + 1]) b++;
+        const u32 bb = base[b], n = base[b + 1] - bb;
+        const u64 pm = (1ull << pbits) - 1ull;
+        const u64 k = keys[a];
+        f = (a == bb);
+        if (!f) {
+            const u64 kp = keys[a - 1];
+            f = ((k >> pbits) != (kp >> pbits)) || ((u32)(k & pm) + (u32)P > n) || ((u32)(kp & pm) + (u32)P > n);
+        }
+    }
     const unsigned long long m = __ballot(f);
     if ((threadIdx.x & 63) == 0) gbits64[a >> 6] = m;
 }
@@ -237,9 +247,12 @@ __global__ __launch_bounds__(256) void k_bwt_f_r0_place(FwdView v, const u32* __
                                                         const u64* __restrict__ keys, int nsym, int pbits, uint2* __restrict__ runList)
 {
     __shared__ SmWindow W;
+    __shared__ int sBlk;
     const int tid = (int)threadIdx.x;
     const u32 win = blockIdx.x;
     const u32 slot0 = win * SM_WIN;
+    if (tid == 0) sBlk = find_block(v.base, v.nBlocks, slot0 < v.total ? slot0 : v.total - 1);
+    (void)vals;
     if (tid < 64) {
         const u32 w = v.gbits[(slot0 >> 5) + (u32)tid];
         W.bw[tid] = w;
@@ -273,14 +286,11 @@ __global__ __launch_bounds__(256) void k_bwt_f_r0_place(FwdView v, const u32* __
         const u32 m = word & lowmask;
         const int si = m ? (int)(w * 32 + 31 - (u32)__clz((int)m)) : W.prevSet[w];
         const u32 hd = (si >= 0) ? slot0 + (u32)si : before;
-        u32 gp;
-        if (pbits) {
-            // (a lone block may use all 64 bits: no block field to shift down)
-            const u64 kk = keys[a];
-            const int bshift = pbits + 3 + 8 * nsym;
-            gp = v.base[bshift < 64 ? (u32)(kk >> bshift) : 0u] + (u32)(kk & ((1ull << pbits) - 1ull));
-        }
-        else gp = vals[a];
+        int blk = sBlk;
+        while (a >= v.base[blk + 1]) blk++;
+        const u64 kk = keys[a];
+        const u32 pos = (u32)(kk & ((1ull << pbits) - 1ull));
+        const u32 gp = v.base[blk] + pos;
         v.SA[a] = gp;
         v.ISA[gp] = hd;
         if (hd == a) {
@@ -293,11 +303,10 @@ __global__ __launch_bounds__(256) void k_bwt_f_r0_place(FwdView v, const u32* __
             // of that byte: above the small size it is finished by the run-length round instead of log2(run length) doublings
             bool runGroup = false;
             if (runList != nullptr && size > SM_G) {
-                const u64 k = keys[a] >> pbits;
-                const u64 bytes = (k >> 3) & ((1ull << (8 * nsym)) - 1ull);
+                const u64 bytes = kk >> pbits;
                 u64 rep = 0;
                 for (int q = 0; q < nsym; q++) rep = (rep << 8) | (bytes & 0xFF);
-                runGroup = ((k & 7) == (u64)nsym) && bytes == rep;
+                runGroup = (pos + (u32)nsym <= v.base[blk + 1] - v.base[blk]) && bytes == rep;
             }
             if (runGroup) {
                 const u32 at = atomicAdd(&v.counters[4], 1u);
@@ -388,7 +397,7 @@ __global__ __launch_bounds__(256) void k_bwt_f_sort_small(FwdView v)
 // The 32 workgroups that run on one XCD (workgroup index mod 8 -- an observed placement, used for speed only) walk through one
 // contiguous eighth of the list side by side, so that a line of ISA fetched for one group is found in that XCD's L2 by the
 // 31 groups next to it, instead of being fetched from memory once per group.
-__global__ __launch_bounds__(1024) void k_bwt_f_gather_desc(FwdView v, const uint2* __restrict__ desc, u32 nDesc, u32 h)
+__global__ __launch_bounds__(1024) void k_bwt_f_gather_desc(FwdView v, const uint2* __restrict__ desc, u32 nDesc, u32 h, uint2* __restrict__ descInfo)
 {
     __shared__ int sBlk;
     const u32 xcd = blockIdx.x & 7, lanesPerXcd = gridDim.x >> 3, slot = blockIdx.x >> 3;      // the grid is a multiple of 8 workgroups
@@ -399,6 +408,8 @@ __global__ __launch_bounds__(1024) void k_bwt_f_gather_desc(FwdView v, const uin
         if (threadIdx.x == 0) sBlk = find_block(v.base, v.nBlocks, d.x);
         __syncthreads();
         const u32 bb = v.base[sBlk], be = v.base[sBlk + 1];
+        // (block base, label the members carry): what the sorting kernel needs per group without a chain of dependent loads of its own
+        if (threadIdx.x == 0) descInfo[g] = make_uint2(bb, v.ISA[v.SA[d.x]]);
         // eight members per thread at a time: all position loads, then all key loads, then the stores -- two memory
         // latencies per batch instead of two per member
         for (u32 i0 = 0; i0 < d.y; i0 += 8 * 1024) {
@@ -517,6 +528,86 @@ __device__ __forceinline__ void med_radix_sort(MedLds<THREADS, ROWS>& L, u32 n, 
     (void)WAVES;
 }
 
+// Write-back of a group sorted in LDS (oK = keys in order, oV = positions): subgroup boundaries, SA, labels, the round's bit map
+// and the children's descriptors. Entered and left with the workgroup in step.
+template <int THREADS, int ROWS>
+__device__ __noinline__ void med_write_back(MedLds<THREADS, ROWS>& L, const FwdView& v, u32 gs, u32 n, uint2* __restrict__ medNext, uint2* __restrict__ largeNext)
+{
+    constexpr u32 CAP = (u32)ROWS * THREADS;
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    // ---- subgroup boundaries of the sorted keys as a bit map in LDS + per-word summaries
+    const int nWords = (int)((n + 31) >> 5);
+    if (tid < (int)(CAP / 32)) {
+        u32 bits = 0;
+        if (tid < nWords) {
+            const u32 i0 = (u32)tid * 32u;
+            u32 prev = (i0 == 0) ? 0u : L.oK[i0 - 1];
+            for (u32 k = 0; k < 32; k++) {
+                const u32 i = i0 + k;
+                if (i >= n) break;
+                const u32 cur = L.oK[i];
+                if (i == 0 || cur != prev) bits |= 1u << k;
+                prev = cur;
+            }
+        }
+        L.fb[tid] = bits;
+        L.pm[tid] = bits ? (tid * 32 + 31 - __clz((int)bits)) : -1;
+        L.pn[tid] = bits ? (u32)(tid * 32 + __ffs((int)bits) - 1) : n;
+    }
+    __syncthreads();
+    // inclusive prefix max of pm / suffix min of pn over the words, by the first wave (WPL consecutive words per lane)
+    if (tid < 64) {
+        constexpr int WPL = (int)(CAP / 32) / 64;
+        int run = -1;
+        for (int k = 0; k < WPL; k++) { const int x = L.pm[tid * WPL + k]; run = x > run ? x : run; }
+        int incl = run;
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, (unsigned)o, 64); if (tid >= o) incl = t > incl ? t : incl; }
+        int carry = __shfl_up(incl, 1u, 64);
+        if (tid == 0) carry = -1;
+        for (int k = 0; k < WPL; k++) { const int x = L.pm[tid * WPL + k]; carry = x > carry ? x : carry; L.pm[tid * WPL + k] = carry; }
+        u32 runn = n;
+        for (int k = WPL - 1; k >= 0; k--) { const u32 x = L.pn[tid * WPL + k]; runn = x < runn ? x : runn; }
+        u32 incn = runn;
+        for (int o = 1; o < 64; o <<= 1) { const u32 t = (u32)__shfl_down((int)incn, (unsigned)o, 64); if (tid + o < 64) incn = t < incn ? t : incn; }
+        u32 carn = (u32)__shfl_down((int)incn, 1u, 64);
+        if (tid == 63) carn = n;
+        for (int k = WPL - 1; k >= 0; k--) { const u32 x = L.pn[tid * WPL + k]; carn = x < carn ? x : carn; L.pn[tid * WPL + k] = carn; }
+    }
+    __syncthreads();
+    // pm[w] = last boundary at or before the end of word w, pn[w] = first boundary at or after the start of word w
+    u32 surv = 0;
+    const u32 oldLab = L.oldLab;
+    for (u32 i = (u32)tid; i < n; i += THREADS) {
+        const u32 w = i >> 5, bit = i & 31;
+        const u32 lowmask = (bit == 31) ? 0xFFFFFFFFu : ((2u << bit) - 1u);
+        const u32 word = L.fb[w];
+        const u32 mm = word & lowmask;
+        const u32 hd = mm ? (w * 32 + 31 - (u32)__clz((int)mm)) : (u32)L.pm[w - 1];      // word 0 always has bit 0
+        const u32 gp = L.oV[i];
+        v.SA[gs + i] = gp;
+        const u32 m2 = word & ~lowmask;
+        const u32 e = m2 ? (w * 32 + (u32)__ffs((int)m2) - 1) : ((w + 1 < (u32)(CAP / 32)) ? L.pn[w + 1] : n);     // end of my subgroup
+        // The label of a group only has to be a slot inside the group's range (ranges are disjoint, so labels stay unique and
+        // ordered). Small children take their first slot, as every kernel that works on small groups expects; a larger child
+        // keeps the parent's label when that slot lies inside its range, else it takes its middle slot -- which the part that
+        // holds the majority in the rounds to come will still contain, so that its thousands of members are not relabelled
+        // (a scattered 4-byte store each) round after round just because a few members left in front of them.
+        const u32 size = e - hd;
+        const u32 rel = oldLab - gs;
+        const u32 lab = (size <= SM_G) ? gs + hd : ((rel >= hd && rel < e) ? oldLab : gs + hd + (size >> 1));
+        if (lab != oldLab) v.ISA[gp] = lab;
+        if (hd == i) classify_child(v, medNext, largeNext, gs + i, size, surv);
+    }
+    if (__ballot(surv != 0) != 0 && lane == 0) v.counters[0] = 1;
+    // new group starts into the round's bit map (bit 0 of the group is set already)
+    if (tid < nWords && L.fb[tid]) {
+        const u32 off = gs + (u32)tid * 32u;
+        const u32 sh = off & 31;
+        atomicOr(&v.gnew[off >> 5], L.fb[tid] << sh);
+        if (sh && (L.fb[tid] >> (32 - sh))) atomicOr(&v.gnew[(off >> 5) + 1], L.fb[tid] >> (32 - sh));
+    }
+}
+
 // One workgroup refines one group of 257..ROWS*THREADS members (descriptors of other sizes are left to the other
 // instantiations of the kernel): keys and positions into LDS, sort, subgroup boundaries, SA / ISA / bit map / children.
 // A group in which one key holds the majority (periodic stretches and runs: every member but the ones near the end of the
@@ -524,7 +615,8 @@ __device__ __forceinline__ void med_radix_sort(MedLds<THREADS, ROWS>& L, u32 n, 
 // others are sorted.
 template <int THREADS, int ROWS>
 __global__ __launch_bounds__(THREADS, THREADS / 128) void k_bwt_f_sort_medium(FwdView v, const uint2* __restrict__ desc, u32 nDesc, int npass, u32 minLen,
-                                                               uint2* __restrict__ medNext, uint2* __restrict__ largeNext)
+                                                               uint2* __restrict__ medNext, uint2* __restrict__ largeNext, const uint2* __restrict__ descInfo,
+                                                               uint4* __restrict__ superList)
 {
     constexpr int WAVES = THREADS / 64;
     constexpr u32 CAP = (u32)ROWS * THREADS;
@@ -536,6 +628,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 128) void k_bwt_f_sort_medium(Fw
         const uint2 d = desc[g];
         const u32 gs = d.x, n = d.y;
         if (n <= minLen || n > CAP) continue;               // uniform for the workgroup
+        const uint2 info = descInfo[g];                     // (block base, the members' label)
         {
             // all loads of the group in flight before the first one is used
             u32 k[ROWS], p[ROWS];
@@ -545,13 +638,19 @@ __global__ __launch_bounds__(THREADS, THREADS / 128) void k_bwt_f_sort_medium(Fw
             for (int r = 0; r < ROWS; r++) { const u32 i = (u32)tid + (u32)r * THREADS; if (i < n) { L.oK[i] = k[r]; L.oV[i] = p[r]; } }
         }
         __syncthreads();
-        if (tid == 0) L.oldLab = v.ISA[L.oV[0]];            // (the load overlaps the sort; read again in the write-back)
+        if (tid == 0) L.oldLab = info.y;
         // majority candidate: the key two of three probes agree on, else the middle one
         const u32 ka = L.oK[n >> 2], kb = L.oK[n >> 1], kc = L.oK[(n >> 2) * 3];
         const u32 m = (ka == kc) ? ka : kb;
         u32 c = 0;
         for (u32 i = (u32)tid; i < n; i += THREADS) c += (L.oK[i] == m) ? 1u : 0u;
         c = med_block_sum(L, c);
+        if (c < n && 2 * c >= n && superList != nullptr && m == info.y - info.x + 1u) {
+            // the majority looks at the group itself (a periodic stretch whose period divides h): k_bwt_f_super finishes it in one round
+            if (tid == 0) { const u32 at = atomicAdd(&v.counters[7], 1u); superList[at] = make_uint4(gs, n, info.x, info.y); }
+            __syncthreads();
+            continue;
+        }
         if (c < n) {
             if (2 * c >= n) {
                 // ---- stable split: [others (nOth)][members with key m (c)]
@@ -624,77 +723,139 @@ __global__ __launch_bounds__(THREADS, THREADS / 128) void k_bwt_f_sort_medium(Fw
                 med_radix_sort<THREADS, ROWS>(L, n, npass);
             }
         }
-        // ---- subgroup boundaries of the sorted keys as a bit map in LDS + per-word summaries
-        const int nWords = (int)((n + 31) >> 5);
-        if (tid < (int)(CAP / 32)) {
-            u32 bits = 0;
-            if (tid < nWords) {
-                const u32 i0 = (u32)tid * 32u;
-                u32 prev = (i0 == 0) ? 0u : L.oK[i0 - 1];
-                for (u32 k = 0; k < 32; k++) {
-                    const u32 i = i0 + k;
-                    if (i >= n) break;
-                    const u32 cur = L.oK[i];
-                    if (i == 0 || cur != prev) bits |= 1u << k;
-                    prev = cur;
-                }
+        med_write_back<THREADS, ROWS>(L, v, gs, n, medNext, largeNext);
+        __syncthreads();
+    }
+}
+
+// A group whose majority key is the group's OWN label: for most members p the suffix p + h is a member too, i.e. the members form
+// chains p, p + h, p + 2h, ... inside the group (a periodic stretch whose period divides h) that end in a member e whose key is another
+// label. With c(p) = steps from p to the end e(p) of its chain, two members compare like this: all of them start with the group's
+// h symbols B, so suffix p = B^(c+1) followed by what the key of e(p) stands for. The one with the shorter chain meets its foreign
+// key while the other still shows B (label = the group's own): it is the smaller one when that key is below the own label,
+// the larger one when above; equal chain lengths leave the two foreign keys to decide. One sort on
+//     hi = key(e) < own ? c : 2 CAP - c,   lo = rank of key(e) among the chain ends
+// therefore does what log2(longest chain) doubling rounds would do; ties share (c + 1) h symbols and the depth of the end's label
+// (at least 2h altogether) and go on as ordinary groups. The members are in position order (every sort of the pipeline is stable),
+// so p + h is found by binary search in the group itself and c, e come from pointer jumping in LDS.
+__global__ __launch_bounds__(512) void k_bwt_f_super(FwdView v, const uint4* __restrict__ superList, u32 h, int npass, uint2* __restrict__ medNext, uint2* __restrict__ largeNext)
+{
+    constexpr int THREADS = 512, ROWS = 16;
+    constexpr u32 CAP = (u32)ROWS * THREADS;
+    __shared__ MedLds<THREADS, ROWS> L;
+    __shared__ u16 nxt[CAP];
+    __shared__ u16 cn[CAP];
+    __shared__ u16 trEnd[CAP];
+    __shared__ u32 sEnds;
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const unsigned long long ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const u32 nList = v.counters[7];
+    for (u32 g = blockIdx.x; g < nList; g += gridDim.x) {
+        const uint4 d = superList[g];
+        const u32 gs = d.x, n = d.y;                       // 256 < n <= CAP
+        {
+            u32 k[ROWS], p[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) { const u32 i = (u32)tid + (u32)r * THREADS; k[r] = 0; p[r] = 0; if (i < n) { k[r] = v.K[gs + i]; p[r] = v.SA[gs + i]; } }
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) { const u32 i = (u32)tid + (u32)r * THREADS; if (i < n) { L.oK[i] = k[r]; L.oV[i] = p[r]; } }
+        }
+        if (tid == 0) { sEnds = 0; L.oldLab = d.w; }
+        __syncthreads();
+        const u32 m = d.w - d.z + 1u;
+        // ---- chain links: the member h further on
+#pragma unroll 4
+        for (int r = 0; r < ROWS; r++) {
+            const u32 i = (u32)tid + (u32)r * THREADS;
+            if (i >= n) continue;
+            u32 to = i, one = 0;
+            if (L.oK[i] == m) {
+                const u32 target = L.oV[i] + h;
+                u32 lo = i + 1, hi = n;                     // first index with position >= target
+                while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (L.oV[mid] < target) lo = mid + 1; else hi = mid; }
+                if (lo < n && L.oV[lo] == target) { to = lo; one = 1; }
             }
-            L.fb[tid] = bits;
-            L.pm[tid] = bits ? (tid * 32 + 31 - __clz((int)bits)) : -1;
-            L.pn[tid] = bits ? (u32)(tid * 32 + __ffs((int)bits) - 1) : n;
+            nxt[i] = (u16)to; cn[i] = (u16)one;
         }
         __syncthreads();
-        // inclusive prefix max of pm / suffix min of pn over the words, by the first wave (WPL consecutive words per lane)
-        if (tid < 64) {
-            constexpr int WPL = (int)(CAP / 32) / 64;
-            int run = -1;
-            for (int k = 0; k < WPL; k++) { const int x = L.pm[tid * WPL + k]; run = x > run ? x : run; }
-            int incl = run;
-            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, (unsigned)o, 64); if (tid >= o) incl = t > incl ? t : incl; }
-            int carry = __shfl_up(incl, 1u, 64);
-            if (tid == 0) carry = -1;
-            for (int k = 0; k < WPL; k++) { const int x = L.pm[tid * WPL + k]; carry = x > carry ? x : carry; L.pm[tid * WPL + k] = carry; }
-            u32 runn = n;
-            for (int k = WPL - 1; k >= 0; k--) { const u32 x = L.pn[tid * WPL + k]; runn = x < runn ? x : runn; }
-            u32 incn = runn;
-            for (int o = 1; o < 64; o <<= 1) { const u32 t = (u32)__shfl_down((int)incn, (unsigned)o, 64); if (tid + o < 64) incn = t < incn ? t : incn; }
-            u32 carn = (u32)__shfl_down((int)incn, 1u, 64);
-            if (tid == 63) carn = n;
-            for (int k = WPL - 1; k >= 0; k--) { const u32 x = L.pn[tid * WPL + k]; carn = x < carn ? x : carn; L.pn[tid * WPL + k] = carn; }
+        // ---- pointer jumping: chain end and chain length of every member
+        for (u32 span = 1; span < n; span <<= 1) {
+            u32 a[ROWS], b[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                const u32 i = (u32)tid + (u32)r * THREADS;
+                a[r] = 0; b[r] = 0;
+                if (i < n) { const u32 j = nxt[i]; a[r] = nxt[j]; b[r] = (u32)cn[i] + (u32)cn[j]; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) { const u32 i = (u32)tid + (u32)r * THREADS; if (i < n) { nxt[i] = (u16)a[r]; cn[i] = (u16)b[r]; } }
+            __syncthreads();
+        }
+        u32 e[ROWS], cc[ROWS], tail[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            const u32 i = (u32)tid + (u32)r * THREADS;
+            e[r] = 0; cc[r] = 0; tail[r] = 0;
+            if (i < n) { e[r] = nxt[i]; cc[r] = cn[i]; tail[r] = L.oK[e[r]]; }
         }
         __syncthreads();
-        // pm[w] = last boundary at or before the end of word w, pn[w] = first boundary at or after the start of word w
-        u32 surv = 0;
-        const u32 oldLab = L.oldLab;
-        for (u32 i = (u32)tid; i < n; i += THREADS) {
-            const u32 w = i >> 5, bit = i & 31;
-            const u32 lowmask = (bit == 31) ? 0xFFFFFFFFu : ((2u << bit) - 1u);
-            const u32 word = L.fb[w];
-            const u32 mm = word & lowmask;
-            const u32 hd = mm ? (w * 32 + 31 - (u32)__clz((int)mm)) : (u32)L.pm[w - 1];      // word 0 always has bit 0
-            const u32 gp = L.oV[i];
-            v.SA[gs + i] = gp;
-            const u32 m2 = word & ~lowmask;
-            const u32 e = m2 ? (w * 32 + (u32)__ffs((int)m2) - 1) : ((w + 1 < (u32)(CAP / 32)) ? L.pn[w + 1] : n);     // end of my subgroup
-            // The label of a group only has to be a slot inside the group's range (ranges are disjoint, so labels stay unique and
-            // ordered). Small children take their first slot, as every kernel that works on small groups expects; a larger child
-            // keeps the parent's label when that slot lies inside its range, else it takes its middle slot -- which the part that
-            // holds the majority in the rounds to come will still contain, so that its thousands of members are not relabelled
-            // (a scattered 4-byte store each) round after round just because a few members left in front of them.
-            const u32 size = e - hd;
-            const u32 rel = oldLab - gs;
-            const u32 lab = (size <= SM_G) ? gs + hd : ((rel >= hd && rel < e) ? oldLab : gs + hd + (size >> 1));
-            if (lab != oldLab) v.ISA[gp] = lab;
-            if (hd == i) classify_child(v, medNext, largeNext, gs + i, size, surv);
+        // ---- the chain ends, compacted (any order) and sorted by key
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            const u32 i = (u32)tid + (u32)r * THREADS;
+            const bool isEnd = (i < n) && cc[r] == 0;
+            const unsigned long long bal = __ballot(isEnd);
+            u32 base0 = 0;
+            if (lane == 0 && bal) base0 = atomicAdd(&sEnds, (u32)__popcll(bal));
+            base0 = (u32)__shfl((int)base0, 0, 64);
+            if (isEnd) { const u32 at = base0 + (u32)__popcll(bal & ltMask); L.oK[at] = tail[r]; L.oV[at] = i; }
         }
-        if (__ballot(surv != 0) != 0 && lane == 0) v.counters[0] = 1;
-        // new group starts into the round's bit map (bit 0 of the group is set already)
-        if (tid < nWords && L.fb[tid]) {
-            const u32 off = gs + (u32)tid * 32u;
-            const u32 sh = off & 31;
-            atomicOr(&v.gnew[off >> 5], L.fb[tid] << sh);
-            if (sh && (L.fb[tid] >> (32 - sh))) atomicOr(&v.gnew[(off >> 5) + 1], L.fb[tid] >> (32 - sh));
+        __syncthreads();
+        const u32 nEnds = sEnds;
+        if (nEnds <= (u32)THREADS) {
+            u32 kk = 0, vv = 0, at = 0;
+            if ((u32)tid < nEnds) {
+                kk = L.oK[tid]; vv = L.oV[tid];
+                for (u32 j = 0; j < nEnds; j++) { const u32 kj = L.oK[j]; at += (kj < kk || (kj == kk && j < (u32)tid)) ? 1u : 0u; }
+            }
+            __syncthreads();
+            if ((u32)tid < nEnds) { L.oK[at] = kk; L.oV[at] = vv; }
+            __syncthreads();
+        } else {
+            med_radix_sort<THREADS, ROWS>(L, nEnds, npass);
         }
+        // rank of an end's key = first index with that key
+        for (u32 j = (u32)tid; j < nEnds; j += THREADS) {
+            const u32 key = L.oK[j];
+            u32 lo = 0, hi = j;
+            while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (L.oK[mid] < key) lo = mid + 1; else hi = mid; }
+            trEnd[L.oV[j]] = (u16)lo;
+        }
+        __syncthreads();
+        // ---- one sort of all members on (hi, rank of the end's key)
+        u32 fk[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            const u32 i = (u32)tid + (u32)r * THREADS;
+            fk[r] = 0;
+            if (i < n) { const u32 hiKey = (tail[r] < m) ? cc[r] : (2u * CAP - cc[r]); fk[r] = (hiKey << 13) | (u32)trEnd[e[r]]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) { const u32 i = (u32)tid + (u32)r * THREADS; if (i < n) { L.oK[i] = fk[r]; L.oV[i] = i; } }
+        __syncthreads();
+        med_radix_sort<THREADS, ROWS>(L, n, 4);
+        {
+            u32 p[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) { const u32 i = (u32)tid + (u32)r * THREADS; p[r] = 0; if (i < n) p[r] = v.SA[gs + L.oV[i]]; }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) { const u32 i = (u32)tid + (u32)r * THREADS; if (i < n) L.oV[i] = p[r]; }
+        }
+        __syncthreads();
+        med_write_back<THREADS, ROWS>(L, v, gs, n, medNext, largeNext);
         __syncthreads();
     }
 }
@@ -964,23 +1125,61 @@ __global__ __launch_bounds__(256) void k_bwt_f_emit(BwtView v, const u32* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// the descriptors of a round sorted by start slot, one workgroup (the usual case: a few thousand groups)
+__global__ __launch_bounds__(512) void k_bwt_f_sort_desc_lds(const uint2* __restrict__ in, uint2* __restrict__ out, u32 n, int npass)
+{
+    __shared__ MedLds<512, 16> L;
+    for (u32 i = threadIdx.x; i < n; i += 512) { const uint2 d = in[i]; L.oK[i] = d.x; L.oV[i] = d.y; }
+    __syncthreads();
+    med_radix_sort<512, 16>(L, n, npass);
+    for (u32 i = threadIdx.x; i < n; i += 512) out[i] = make_uint2(L.oK[i], L.oV[i]);
+}
+
+__global__ void k_set2(u32* p, u32 a, u32 b) { if (threadIdx.x == 0 && blockIdx.x == 0) { p[0] = a; p[1] = b; } }
+
+// knobs (tests, tuning): read from the environment once per process, or set through knz_hip_tune()
+struct FwdTuning { int nsym; int noRunRound; int runFallback; int noSuper; };
+static FwdTuning& fwd_tuning()
+{
+    static FwdTuning t = [] {
+        FwdTuning x; x.nsym = 0; x.noRunRound = 0; x.runFallback = 0; x.noSuper = 0;
+        if (const char* e = getenv("KNZ_BWT_NSYM")) x.nsym = atoi(e);
+        if (getenv("KNZ_BWT_NO_RUN_ROUND")) x.noRunRound = 1;
+        if (getenv("KNZ_BWT_RUN_FALLBACK")) x.runFallback = 1;
+        if (getenv("KNZ_BWT_NO_SUPER")) x.noSuper = 1;
+        return x;
+    }();
+    return t;
+}
+int bwt_forward_tune(const char* key, int value)
+{
+    FwdTuning& t = fwd_tuning();
+    if (!strcmp(key, "bwt_nsym")) t.nsym = value;
+    else if (!strcmp(key, "bwt_no_run_round")) t.noRunRound = value;
+    else if (!strcmp(key, "bwt_run_fallback")) t.runFallback = value;
+    else if (!strcmp(key, "bwt_no_super")) t.noSuper = value;
+    else return -1;
+    return 0;
+}
+
 struct FwdScratch {
     u64* keysA; u64* keysB;
     u32* valsA; u32* valsB;
     u32* SA; u32* ISA; u32* K;
     u32* t0; u32* t1; u32* t2; u32* t3;
     u32* gbits; u32* gnew; size_t gbitsWords;
-    uint2* med[2]; uint2* medSorted; uint2* large[2]; uint2* runList; u32* ebits;
+    uint2* med[2]; uint2* medSorted; uint2* descInfo; uint2* large[2]; uint2* runList; uint4* superList; u32* ebits;
     u32* loff;
     u32* base;
     u32* counters;
-    u32* hist;
-    void* prim; size_t primBytes;
+    u32* seg2;
+    void* scanTmp;
+    void* rsMem;
 };
 
 static size_t fwd_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
-static size_t fwd_carve(u8* p, int nBlocks, size_t total, size_t bytes, FwdScratch* w)
+static size_t fwd_carve(u8* p, int nBlocks, size_t total, FwdScratch* w)
 {
     u8* q = p;
     auto take = [&](size_t sz) { u8* r = q; q += fwd_align(sz); return r; };
@@ -995,28 +1194,23 @@ static size_t fwd_carve(u8* p, int nBlocks, size_t total, size_t bytes, FwdScrat
     w->med[0] = (uint2*)take(8 * maxMed); w->med[1] = (uint2*)take(8 * maxMed); w->medSorted = (uint2*)take(8 * maxMed);
     w->large[0] = (uint2*)take(8 * maxLarge); w->large[1] = (uint2*)take(8 * maxLarge);
     w->runList = (uint2*)take(8 * maxMed);
+    w->superList = (uint4*)take(16 * maxMed);
+    w->descInfo = (uint2*)take(8 * maxMed);
     w->ebits = (u32*)take(4 * w->gbitsWords);
     w->loff = (u32*)take(4 * (maxMed + 1));
     w->base = (u32*)take(4ull * (nBlocks + 2));
     w->counters = (u32*)take(256);
-    w->hist = (u32*)take(1024 + 64);                  // 256 sample counters + the longest active block
-    w->prim = q;
-    w->primBytes = (p && bytes > (size_t)(q - p)) ? bytes - (size_t)(q - p) : 0;
+    w->seg2 = (u32*)take(64);
+    w->scanTmp = take(prims::scan_tmp_bytes(total + 16));
+    w->rsMem = take(prims::rs_ws_bytes(total, nBlocks + 1));
     return (size_t)(q - p);
 }
 
 size_t bwt_forward_scratch_bytes(int nBlocks, u32 VS, size_t total)
 {
     (void)VS;
-    size_t primSort = 0, primScan = 0;
-    rocprim::radix_sort_pairs(nullptr, primSort, (u64*)nullptr, (u64*)nullptr, (u32*)nullptr, (u32*)nullptr, total, 0u, 64u, (hipStream_t)0);
-    rocprim::inclusive_scan(nullptr, primScan, (u32*)nullptr, (u32*)nullptr, total, rocprim::maximum<u32>(), (hipStream_t)0);
-    size_t primKeys = 0;
-    rocprim::radix_sort_keys(nullptr, primKeys, (u64*)nullptr, (u64*)nullptr, total, 0u, 64u, (hipStream_t)0);
-    if (primKeys > primSort) primSort = primKeys;
-    const size_t prim = fwd_align(primSort > primScan ? primSort : primScan) + 4096;
     FwdScratch w;
-    return fwd_carve(nullptr, nBlocks, total, 0, &w) + prim + 4096;
+    return fwd_carve(nullptr, nBlocks, total, &w) + 4096;
 }
 
 #define GRID1(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256), 0, s
@@ -1027,92 +1221,77 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     BwtView bv; bv.src = st.src; bv.dst = st.dst; bv.len = st.len; bv.cap = st.cap; bv.VS = st.maxLen; bv.nBlocks = st.nBlocks;
     const size_t maxTotal = (size_t)st.nBlocks * bv.VS;
     FwdScratch w;
-    fwd_carve(reinterpret_cast<u8*>(scratch), st.nBlocks, maxTotal, scratchBytes, &w);
-    { KScope ks_("k_bwt_f_bases"); hipLaunchKernelGGL(k_bwt_bases, dim3(1), dim3(64), 0, s, bv, w.base, st.ok, w.hist + 256); }
+    if (fwd_carve(reinterpret_cast<u8*>(scratch), st.nBlocks, maxTotal, &w) > scratchBytes) return -2;
+    const FwdTuning tune = fwd_tuning();
+    { KScope ks_("k_bwt_f_bases"); hipLaunchKernelGGL(k_bwt_bases, dim3(1), dim3(64), 0, s, bv, w.base, st.ok, w.counters + 32); }
     hipMemsetAsync(st.newLen, 0, sizeof(u32) * st.nBlocks, s);
-    hipMemsetAsync(w.hist, 0, 1024, s);
-    { KScope ks_("k_bwt_f_sample");
-      hipLaunchKernelGGL(k_bwt_f_sample, dim3((unsigned)std::min<size_t>(((size_t)bv.VS + 65535) / 65536, 64), st.nBlocks), dim3(256), 0, s, bv, st.ok, w.hist); }
     if (hipMemcpyAsync(h_pinned, w.base + st.nBlocks, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
-    if (hipMemcpyAsync(h_pinned + 16, w.hist, 1024 + 4, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+    if (hipMemcpyAsync(h_pinned + 1, w.counters + 32, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
     if (hipStreamSynchronize(s) != hipSuccess) return -1;
     const u32 total = h_pinned[0];
     if (total == 0) return 0;
-    double h0 = 0.0;                                             // order-0 entropy of the sample, bits per byte
-    {
-        double sum = 0.0;
-        for (int c = 0; c < 256; c++) sum += (double)h_pinned[16 + c];
-        if (sum > 0.0) for (int c = 0; c < 256; c++) { const double f = (double)h_pinned[16 + c] / sum; if (f > 0.0) h0 -= f * log2(f); }
-    }
     FwdView v; v.base = w.base; v.nBlocks = st.nBlocks; v.total = total; v.SA = w.SA; v.ISA = w.ISA; v.K = w.K; v.gbits = w.gbits; v.gnew = w.gnew; v.counters = w.counters;
 
-    // ---- round 0: sort by the first nsym symbols
-    int bbits = 0;
-    while ((1 << bbits) < st.nBlocks) bbits++;
-    // 56 key bits = 7 passes of the LSD sort where the block count allows it
-    int nsym = (53 - bbits) / 8;
-    if (nsym < 4) nsym = (61 - bbits) / 8;
-    if (nsym > 7) nsym = 7;
-    if (const char* e = getenv("KNZ_BWT_NSYM")) { const int o = atoi(e); if (o >= 1 && o < nsym) nsym = o; }   // tuning knob: shorter round-0 keys
+    // ---- round 0: the suffixes of every block sorted by their first nsym symbols. Keys = [nsym bytes | position in the block];
+    // one stable LSD pass per symbol, the first one reads the text, the blocks are the segments of the sort.
+    int pbits = 1;
+    while ((1ull << pbits) < (u64)h_pinned[1]) pbits++;           // positions inside the longest block the transform applies to
+    int nsym = (64 - pbits) / 8;
+    if (nsym > 4) nsym = 4;       // h = 4, 8, 16, ...: powers of two meet the periods real data has (record and row sizes)
+    if (tune.nsym >= 1 && tune.nsym < nsym) nsym = tune.nsym;      // tuning knob: shorter round-0 keys
     if (nsym < 1) return -4;
-    // or, when at least 4 symbols still fit: the position packed into the key, 8-byte elements, one pass per key byte. Fewer
-    // symbols leave more to the refinement rounds, which costs more than the sort saves when few symbols say little: with 8 MiB
-    // blocks (4 symbols packed, 6 not) text at 4.1 bits per byte loses 4 ms per 212 MB, mixed binary data at 6.8 gains 1.5 --
-    // so the packed form is taken when it does not shorten the key, or when the sample's entropy is at least 5.5 bits per byte.
-    int pbits = 0;
-    {
-        int pb0 = 1;
-        while ((1ull << pb0) < (u64)h_pinned[16 + 256]) pb0++;    // positions inside the longest block
-        // (63, not 64: rocPRIM's merge-sort path for mid-sized inputs builds its key mask as (1 << end_bit) - 1, which is
-        // wrong for end_bit == 64 when begin_bit != 0)
-        const int np = (63 - 3 - bbits - pb0) / 8;
-        const char* e = getenv("KNZ_BWT_PACKED");                 // 0 / 1 force the choice (tests, tuning)
-        const bool want = e ? atoi(e) != 0 : (np >= nsym || h0 >= 5.5);
-        if (np >= 4 && want) { pbits = pb0; nsym = np < nsym ? np : nsym; }
+    prims::RsWs rs = prims::rs_carve(w.rsMem, maxTotal, st.nBlocks + 1, w.base, st.nBlocks);
+    { KScope ks_("k_bwt_f_r0_layout"); prims::rs_launch_layout(s, rs); }
+    u64* kin = w.keysA; u64* kout = w.keysB;
+    for (int pass = 0; pass < nsym; pass++) {
+        KScope ks_("k_bwt_f_r0_sort");
+        if (pass == 0) {
+            TextSrc src; src.src = bv.src; src.P = nsym; src.pbits = pbits; src.shift = pbits;
+            prims::rs_launch_pass<u64, false>(s, rs, src, (const u32*)nullptr, kout, (u32*)nullptr, (size_t)bv.VS);
+        } else {
+            prims::DigitOfKey<u64> src; src.keys = kin; src.shift = pbits + 8 * pass; src.mask = 255u;
+            prims::rs_launch_pass<u64, false>(s, rs, src, (const u32*)nullptr, kout, (u32*)nullptr, (size_t)bv.VS);
+        }
+        std::swap(kin, kout);
     }
-    const dim3 gridB((unsigned)std::min<size_t>(((size_t)bv.VS + 255) / 256, 4096), st.nBlocks);
-    { KScope ks_("k_bwt_f_init"); hipLaunchKernelGGL(k_bwt_f_init, gridB, dim3(256), 0, s, bv, w.base, st.ok, nsym, pbits, w.keysA, w.valsA); }
-    size_t pb = w.primBytes;
-    { KScope ks_("bwt_f_sort_round0");
-      if (pbits) { if (rocprim::radix_sort_keys(w.prim, pb, w.keysA, w.keysB, (size_t)total, (unsigned)pbits, (unsigned)(pbits + bbits + 8 * nsym + 3), s) != hipSuccess) return -1; }
-      else if (rocprim::radix_sort_pairs(w.prim, pb, w.keysA, w.keysB, w.valsA, w.valsB, (size_t)total, 0u, (unsigned)(bbits + 8 * nsym + 3), s) != hipSuccess) return -1; }
+    const u64* sortedKeys = kin;                                  // (the last pass wrote into what is now `kin`)
+    u64* keysFree = kout;                                         // scratch for the rounds that follow
+    u64* keysFree2 = const_cast<u64*>(sortedKeys);                // free again once r0_place has read it
     // every bit from `total` on is set (end sentinel, and windows may look past the end)
     hipMemsetAsync(w.gbits, 0xFF, 4 * w.gbitsWords, s);
     hipMemsetAsync(w.gnew, 0, 4 * w.gbitsWords, s);
     hipMemsetAsync(w.counters, 0, 64, s);
-    { KScope ks_("k_bwt_f_r0_flags"); hipLaunchKernelGGL(k_bwt_f_r0_flags, dim3((total + 255) / 256), dim3(256), 0, s, w.keysB, total, pbits,
+    { KScope ks_("k_bwt_f_r0_flags"); hipLaunchKernelGGL(k_bwt_f_r0_flags, dim3((total + 255) / 256), dim3(256), 0, s, sortedKeys, w.base, st.nBlocks, total, nsym, pbits,
                                                          reinterpret_cast<unsigned long long*>(w.gbits)); }
     // group starts before / after every window of 2048 slots: two scans over ~total/2048 values
     const u32 nWin = (total + SM_WIN - 1) / SM_WIN;
     { KScope ks_("k_bwt_f_r0_winsum"); hipLaunchKernelGGL(k_bwt_f_r0_winsum, GRID1(nWin), w.gbits, total, nWin, w.t0, w.t2); }
-    pb = w.primBytes;
-    { KScope ks_("bwt_f_scan_max"); if (rocprim::inclusive_scan(w.prim, pb, w.t0, w.t1, (size_t)nWin, rocprim::maximum<u32>(), s) != hipSuccess) return -1; }
-    pb = w.primBytes;
-    { KScope ks_("bwt_f_scan_min"); if (rocprim::inclusive_scan(w.prim, pb, w.t2, w.t3, (size_t)nWin, rocprim::minimum<u32>(), s) != hipSuccess) return -1; }
+    { KScope ks_("k_bwt_f_scan_max"); prims::launch_scan<prims::SCAN_MAX_INCL>(s, w.t0, w.t1, nWin, nullptr, w.scanTmp); }
+    { KScope ks_("k_bwt_f_scan_min"); prims::launch_scan<prims::SCAN_MIN_INCL>(s, w.t2, w.t3, nWin, nullptr, w.scanTmp); }
     int cur = 0;
     int kbits = 1;
     while ((1ull << kbits) < (u64)bv.VS + 2) kbits++;
     // the run-length round needs descriptor index + (kbits + 1) + kbits bits in one 64-bit key
-    const bool runRound = (2 * kbits + 1) < 64 && getenv("KNZ_BWT_NO_RUN_ROUND") == nullptr;
-    { KScope ks_("k_bwt_f_r0_place"); hipLaunchKernelGGL(k_bwt_f_r0_place, dim3(nWin), dim3(256), 0, s, v, w.valsB, w.t1, w.t3, nWin, w.med[cur], w.large[cur],
-                                                         w.keysB, nsym, pbits, runRound ? w.runList : (uint2*)nullptr); }
+    const bool runRound = (2 * kbits + 1) < 64 && !tune.noRunRound;
+    { KScope ks_("k_bwt_f_r0_place"); hipLaunchKernelGGL(k_bwt_f_r0_place, dim3(nWin), dim3(256), 0, s, v, (const u32*)nullptr, w.t1, w.t3, nWin, w.med[cur], w.large[cur],
+                                                         sortedKeys, nsym, pbits, runRound ? w.runList : (uint2*)nullptr); }
     if (hipMemcpyAsync(h_pinned, w.counters, 32, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
     if (hipStreamSynchronize(s) != hipSuccess) return -1;
     u32 nRun = h_pinned[4], runElems = h_pinned[5];
     const int maxKeyBits = 2 * kbits + 1;
-    if (nRun && ((u64)nRun > (1ull << (64 - maxKeyBits)) || getenv("KNZ_BWT_RUN_FALLBACK") != nullptr)) {     // (the variable: tests force this path)
+    if (nRun && ((u64)nRun > (1ull << (64 - maxKeyBits)) || tune.runFallback)) {     // (the knob: tests force this path)
         // more run groups than the key has index bits left for (thousands of blocks in one batch): they go the ordinary way
         { KScope ks_("k_bwt_f_run_fallback"); hipLaunchKernelGGL(k_bwt_f_run_fallback, GRID1(nRun), v, w.runList, nRun, w.med[cur], w.large[cur]); }
         if (hipMemcpyAsync(h_pinned, w.counters, 32, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
         if (hipStreamSynchronize(s) != hipSuccess) return -1;
         nRun = 0;
     }
+    prims::RsWs rs1 = prims::rs_carve(w.rsMem, maxTotal, st.nBlocks + 1, w.seg2, 1);     // single-segment sorts of the rounds: [0, seg2[1])
     if (nRun) {
         // run lengths of every position (text order), then one sort of the run groups' members on (run length, what follows)
         { KScope ks_("k_bwt_f_run_ends"); hipLaunchKernelGGL(k_bwt_f_run_ends, dim3((total + SM_WIN - 1) / SM_WIN), dim3(256), 0, s, bv, v, reinterpret_cast<u8*>(w.ebits)); }
         { KScope ks_("k_bwt_f_r0_winsum"); hipLaunchKernelGGL(k_bwt_f_r0_winsum, GRID1(nWin), w.ebits, total, nWin, w.t0, w.t2); }
-        pb = w.primBytes;
-        { KScope ks_("bwt_f_scan_min"); if (rocprim::inclusive_scan(w.prim, pb, w.t2, w.t3, (size_t)nWin, rocprim::minimum<u32>(), s) != hipSuccess) return -1; }
+        { KScope ks_("k_bwt_f_scan_min"); prims::launch_scan<prims::SCAN_MIN_INCL>(s, w.t2, w.t3, nWin, nullptr, w.scanTmp); }
         { KScope ks_("k_bwt_f_run_len"); hipLaunchKernelGGL(k_bwt_f_run_len, dim3(nWin), dim3(256), 0, s, v, w.ebits, w.t3, nWin, w.K); }
         if (hipMemcpyAsync(h_pinned + 8, w.counters + 6, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
         if (hipStreamSynchronize(s) != hipSuccess) return -1;
@@ -1123,16 +1302,17 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
         int rbits = 0;
         while ((1u << rbits) < nRun) rbits++;
         { KScope ks_("k_bwt_f_large_prefix"); hipLaunchKernelGGL(k_bwt_f_large_prefix, dim3(1), dim3(1024), 0, s, w.runList, nRun, w.loff); }
-        { KScope ks_("k_bwt_f_run_keys"); hipLaunchKernelGGL(k_bwt_f_run_keys, GRID1(runElems), bv, v, w.runList, nRun, w.loff, runElems, w.K, kbits, hbits, w.keysA, w.valsA); }
-        pb = w.primBytes;
-        { KScope ks_("bwt_f_sort_runs");
-          if (rocprim::radix_sort_pairs(w.prim, pb, w.keysA, w.keysB, w.valsA, w.valsB, (size_t)runElems, 0u, (unsigned)(keyBits + rbits), s) != hipSuccess) return -1; }
-        { KScope ks_("k_bwt_f_large_flags"); hipLaunchKernelGGL(k_bwt_f_large_flags<u64>, GRID1(runElems), w.keysB, runElems, w.t0, w.t2); }
-        pb = w.primBytes;
-        { KScope ks_("bwt_f_scan_max"); if (rocprim::inclusive_scan(w.prim, pb, w.t0, w.t1, (size_t)runElems, rocprim::maximum<u32>(), s) != hipSuccess) return -1; }
-        pb = w.primBytes;
-        { KScope ks_("bwt_f_scan_min"); if (rocprim::inclusive_scan(w.prim, pb, w.t2, w.t3, (size_t)runElems, rocprim::minimum<u32>(), s) != hipSuccess) return -1; }
-        { KScope ks_("k_bwt_f_large_place"); hipLaunchKernelGGL(k_bwt_f_large_place<u64>, GRID1(runElems), v, w.runList, w.loff, runElems, keyBits, w.keysB, w.valsB, w.t1, w.t3,
+        { KScope ks_("k_bwt_f_run_keys"); hipLaunchKernelGGL(k_bwt_f_run_keys, GRID1(runElems), bv, v, w.runList, nRun, w.loff, runElems, w.K, kbits, hbits, keysFree, w.valsA); }
+        u64* rk; u32* rv;
+        { KScope ks_("k_bwt_f_sort_runs");
+          hipLaunchKernelGGL(k_set2, dim3(1), dim3(64), 0, s, w.seg2, 0u, runElems);
+          prims::rs_launch_layout(s, rs1);
+          const int r = prims::rs_sort<u64, true>(s, rs1, keysFree, keysFree2, w.valsA, w.valsB, (size_t)runElems, 0, keyBits + rbits);
+          rk = r ? keysFree2 : keysFree; rv = r ? w.valsB : w.valsA; }
+        { KScope ks_("k_bwt_f_large_flags"); hipLaunchKernelGGL(k_bwt_f_large_flags<u64>, GRID1(runElems), rk, runElems, w.t0, w.t2); }
+        { KScope ks_("k_bwt_f_scan_max"); prims::launch_scan<prims::SCAN_MAX_INCL>(s, w.t0, w.t1, runElems, nullptr, w.scanTmp); }
+        { KScope ks_("k_bwt_f_scan_min"); prims::launch_scan<prims::SCAN_MIN_INCL>(s, w.t2, w.t3, runElems, nullptr, w.scanTmp); }
+        { KScope ks_("k_bwt_f_large_place"); hipLaunchKernelGGL(k_bwt_f_large_place<u64>, GRID1(runElems), v, w.runList, w.loff, runElems, keyBits, rk, rv, w.t1, w.t3,
                                                                 w.med[cur], w.large[cur]); }
         { KScope ks_("k_bwt_f_merge_bits"); hipLaunchKernelGGL(k_bwt_f_merge_bits, GRID1(total / 32 + 2), w.gbits, w.gnew, total / 32 + 2); }
         if (hipMemcpyAsync(h_pinned, w.counters, 32, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
@@ -1140,10 +1320,12 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     }
     u32 surv = h_pinned[0], nMed = h_pinned[1], nLarge = h_pinned[2], largeElems = h_pinned[3];
 #ifdef KNZ_FWD_DEBUG
-    fprintf(stderr, "after round 0: run groups %u (%u members), small left %u, medium %u, large %u (%u members)\n", nRun, runElems, surv, nMed, nLarge, largeElems);
+    fprintf(stderr, "after round 0 (nsym %d): run groups %u (%u members), small left %u, medium %u, large %u (%u members)\n", nsym, nRun, runElems, surv, nMed, nLarge, largeElems);
 #endif
 
     const int npass = (kbits + 7) / 8;
+    int sbits = 1;
+    while ((1ull << sbits) < (u64)total + 1) sbits++;
     const u32 nTiles = (total + SM_TS - 1) / SM_TS;
     u32 h = (u32)nsym;
     while (surv || nMed || nLarge) {
@@ -1153,62 +1335,72 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
         // -- all keys first
         if (surv) { KScope ks_("k_bwt_f_gather_small"); hipLaunchKernelGGL(k_bwt_f_gather_small, dim3(nTiles), dim3(256), 0, s, v, h); }
         if (nMed) {
-            // sorted by start slot (bits 0..31 of the (start, length) pair read as one 64-bit key)
-            pb = w.primBytes;
-            { KScope ks_("bwt_f_sort_desc");
-              if (rocprim::radix_sort_keys(w.prim, pb, reinterpret_cast<u64*>(w.med[cur]), reinterpret_cast<u64*>(w.medSorted), (size_t)nMed, 0u, 32u, s) != hipSuccess) return -1; }
+            // sorted by start slot
+            { KScope ks_("k_bwt_f_sort_desc");
+              if (nMed <= 8192) hipLaunchKernelGGL(k_bwt_f_sort_desc_lds, dim3(1), dim3(512), 0, s, w.med[cur], w.medSorted, nMed, (sbits + 7) / 8);
+              else {
+                  hipLaunchKernelGGL(k_set2, dim3(1), dim3(64), 0, s, w.seg2, 0u, nMed);
+                  prims::rs_launch_layout(s, rs1);
+                  u64* a = reinterpret_cast<u64*>(w.med[cur]); u64* b = reinterpret_cast<u64*>(w.medSorted);
+                  const int r = prims::rs_sort<u64, false>(s, rs1, a, b, (u32*)nullptr, (u32*)nullptr, (size_t)nMed, 0, ((sbits + 7) / 8) * 8 > 32 ? 32 : ((sbits + 7) / 8) * 8);
+                  if (r == 0) hipMemcpyAsync(w.medSorted, w.med[cur], 8ull * nMed, hipMemcpyDeviceToDevice, s);
+              } }
             KScope ks_("k_bwt_f_gather_desc");
-            hipLaunchKernelGGL(k_bwt_f_gather_desc, dim3(256), dim3(1024), 0, s, v, w.medSorted, nMed, h);
+            hipLaunchKernelGGL(k_bwt_f_gather_desc, dim3(256), dim3(1024), 0, s, v, w.medSorted, nMed, h, w.descInfo);
         }
         int lbits = 0;
         bool small32 = false;
+        u64* lkA = keysFree; u64* lkB = keysFree2;
         if (nLarge) {
             while ((1u << lbits) < nLarge) lbits++;
             small32 = (kbits + lbits) <= 32;
             { KScope ks_("k_bwt_f_large_prefix"); hipLaunchKernelGGL(k_bwt_f_large_prefix, dim3(1), dim3(1024), 0, s, w.large[cur], nLarge, w.loff); }
             KScope ks_("k_bwt_f_large_keys");
-            if (small32) hipLaunchKernelGGL(k_bwt_f_large_keys<u32>, GRID1(largeElems), v, w.large[cur], nLarge, w.loff, largeElems, h, kbits, reinterpret_cast<u32*>(w.keysA), w.valsA);
-            else hipLaunchKernelGGL(k_bwt_f_large_keys<u64>, GRID1(largeElems), v, w.large[cur], nLarge, w.loff, largeElems, h, kbits, w.keysA, w.valsA);
+            if (small32) hipLaunchKernelGGL(k_bwt_f_large_keys<u32>, GRID1(largeElems), v, w.large[cur], nLarge, w.loff, largeElems, h, kbits, reinterpret_cast<u32*>(lkA), w.valsA);
+            else hipLaunchKernelGGL(k_bwt_f_large_keys<u64>, GRID1(largeElems), v, w.large[cur], nLarge, w.loff, largeElems, h, kbits, lkA, w.valsA);
         }
         // -- then the refinements
         if (surv) { KScope ks_("k_bwt_f_sort_small"); hipLaunchKernelGGL(k_bwt_f_sort_small, dim3(nTiles), dim3(256), 0, s, v); }
         if (nMed) {
             // two workgroup shapes over the same list, each takes the groups of its size class: 256 threads x 8 elements (21 KB of LDS,
             // groups up to 2048) and 512 threads x 16 elements (76 KB: two groups per CU in flight)
-            KScope ks_("k_bwt_f_sort_medium");
-            const dim3 gridM(std::min<u32>(nMed, 8192));
-            hipLaunchKernelGGL((k_bwt_f_sort_medium<256, 8>), gridM, dim3(256), 0, s, v, w.medSorted, nMed, npass, SM_G, w.med[nxt], w.large[nxt]);
-            hipLaunchKernelGGL((k_bwt_f_sort_medium<512, 16>), gridM, dim3(512), 0, s, v, w.medSorted, nMed, npass, 2048u, w.med[nxt], w.large[nxt]);
+            uint4* sup = tune.noSuper ? (uint4*)nullptr : w.superList;
+            { KScope ks_("k_bwt_f_sort_medium");
+              const dim3 gridM(std::min<u32>(nMed, 8192));
+              hipLaunchKernelGGL((k_bwt_f_sort_medium<256, 8>), gridM, dim3(256), 0, s, v, w.medSorted, nMed, npass, SM_G, w.med[nxt], w.large[nxt], w.descInfo, sup);
+              hipLaunchKernelGGL((k_bwt_f_sort_medium<512, 16>), gridM, dim3(512), 0, s, v, w.medSorted, nMed, npass, 2048u, w.med[nxt], w.large[nxt], w.descInfo, sup); }
+            // groups whose majority looks at the group itself (sort_medium has listed them; the kernel reads the count itself)
+            if (sup) { KScope ks_("k_bwt_f_super"); hipLaunchKernelGGL(k_bwt_f_super, dim3(std::min<u32>(nMed, 512)), dim3(512), 0, s, v, sup, h, npass, w.med[nxt], w.large[nxt]); }
         }
         if (nLarge) {
-            u32* k32a = reinterpret_cast<u32*>(w.keysA); u32* k32b = reinterpret_cast<u32*>(w.keysB);
-            pb = w.primBytes;
-            { KScope ks_("bwt_f_sort_large");
-              const hipError_t e = small32 ? rocprim::radix_sort_pairs(w.prim, pb, k32a, k32b, w.valsA, w.valsB, (size_t)largeElems, 0u, (unsigned)(kbits + lbits), s)
-                                           : rocprim::radix_sort_pairs(w.prim, pb, w.keysA, w.keysB, w.valsA, w.valsB, (size_t)largeElems, 0u, (unsigned)(kbits + lbits), s);
-              if (e != hipSuccess) return -1; }
+            u32* k32a = reinterpret_cast<u32*>(lkA); u32* k32b = reinterpret_cast<u32*>(lkB);
+            int r;
+            { KScope ks_("k_bwt_f_sort_large");
+              hipLaunchKernelGGL(k_set2, dim3(1), dim3(64), 0, s, w.seg2, 0u, largeElems);
+              prims::rs_launch_layout(s, rs1);
+              r = small32 ? prims::rs_sort<u32, true>(s, rs1, k32a, k32b, w.valsA, w.valsB, (size_t)largeElems, 0, kbits + lbits)
+                          : prims::rs_sort<u64, true>(s, rs1, lkA, lkB, w.valsA, w.valsB, (size_t)largeElems, 0, kbits + lbits); }
+            const u32* sk32 = r ? k32b : k32a; const u64* sk64 = r ? lkB : lkA; const u32* sv = r ? w.valsB : w.valsA;
             { KScope ks_("k_bwt_f_large_flags");
-              if (small32) hipLaunchKernelGGL(k_bwt_f_large_flags<u32>, GRID1(largeElems), k32b, largeElems, w.t0, w.t2);
-              else hipLaunchKernelGGL(k_bwt_f_large_flags<u64>, GRID1(largeElems), w.keysB, largeElems, w.t0, w.t2); }
-            pb = w.primBytes;
-            { KScope ks_("bwt_f_scan_max"); if (rocprim::inclusive_scan(w.prim, pb, w.t0, w.t1, (size_t)largeElems, rocprim::maximum<u32>(), s) != hipSuccess) return -1; }
-            pb = w.primBytes;
-            { KScope ks_("bwt_f_scan_min"); if (rocprim::inclusive_scan(w.prim, pb, w.t2, w.t3, (size_t)largeElems, rocprim::minimum<u32>(), s) != hipSuccess) return -1; }
+              if (small32) hipLaunchKernelGGL(k_bwt_f_large_flags<u32>, GRID1(largeElems), sk32, largeElems, w.t0, w.t2);
+              else hipLaunchKernelGGL(k_bwt_f_large_flags<u64>, GRID1(largeElems), sk64, largeElems, w.t0, w.t2); }
+            { KScope ks_("k_bwt_f_scan_max"); prims::launch_scan<prims::SCAN_MAX_INCL>(s, w.t0, w.t1, largeElems, nullptr, w.scanTmp); }
+            { KScope ks_("k_bwt_f_scan_min"); prims::launch_scan<prims::SCAN_MIN_INCL>(s, w.t2, w.t3, largeElems, nullptr, w.scanTmp); }
             { KScope ks_("k_bwt_f_large_place");
-              if (small32) hipLaunchKernelGGL(k_bwt_f_large_place<u32>, GRID1(largeElems), v, w.large[cur], w.loff, largeElems, kbits, k32b, w.valsB, w.t1, w.t3, w.med[nxt], w.large[nxt]);
-              else hipLaunchKernelGGL(k_bwt_f_large_place<u64>, GRID1(largeElems), v, w.large[cur], w.loff, largeElems, kbits, w.keysB, w.valsB, w.t1, w.t3, w.med[nxt], w.large[nxt]); }
+              if (small32) hipLaunchKernelGGL(k_bwt_f_large_place<u32>, GRID1(largeElems), v, w.large[cur], w.loff, largeElems, kbits, sk32, sv, w.t1, w.t3, w.med[nxt], w.large[nxt]);
+              else hipLaunchKernelGGL(k_bwt_f_large_place<u64>, GRID1(largeElems), v, w.large[cur], w.loff, largeElems, kbits, sk64, sv, w.t1, w.t3, w.med[nxt], w.large[nxt]); }
         }
         { KScope ks_("k_bwt_f_merge_bits"); hipLaunchKernelGGL(k_bwt_f_merge_bits, GRID1(total / 32 + 2), w.gbits, w.gnew, total / 32 + 2); }
-        if (hipMemcpyAsync(h_pinned, w.counters, 16, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+        if (hipMemcpyAsync(h_pinned, w.counters, 32, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
         if (hipStreamSynchronize(s) != hipSuccess) return -1;
         surv = h_pinned[0]; nMed = h_pinned[1]; nLarge = h_pinned[2]; largeElems = h_pinned[3];
 #ifdef KNZ_FWD_DEBUG
-        fprintf(stderr, "round h=%u: small left %u, medium %u, large %u (%u members)\n", h, surv, nMed, nLarge, largeElems);
-        for (u32 q = 0; q < nMed && q < 8; q++) fprintf(stderr, "   med[%u] = (%u, %u)\n", q, w.med[nxt][q].x, w.med[nxt][q].y);
+        fprintf(stderr, "round h=%u: small left %u, medium %u, large %u (%u members); %u groups took the chain round\n", h, surv, nMed, nLarge, largeElems, h_pinned[7]);
 #endif
         cur = nxt;
         h <<= 1;
     }
+    const dim3 gridB((unsigned)std::min<size_t>(((size_t)bv.VS + 255) / 256, 4096), st.nBlocks);
     { KScope ks_("k_bwt_f_emit"); hipLaunchKernelGGL(k_bwt_f_emit, gridB, dim3(256), 0, s, bv, w.base, st.ok, w.SA, w.ISA, st.newLen); }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -194,7 +194,7 @@ struct RsLayout {
     int nSeg;
 };
 
-__global__ void k_rs_layout(RsLayout L)
+static __global__ void k_rs_layout(RsLayout L)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     u32 t = 0, g = 0;
@@ -207,13 +207,19 @@ __global__ void k_rs_layout(RsLayout L)
     L.tileOff[L.nSeg] = t; L.grpOff[L.nSeg] = g;
 }
 
-// digit of a key; the caller's functor may read anything (a key array, or the text for the first pass of the suffix sort)
+// Source of a pass: element i of segment sgm (which starts at b0 and has len elements) as a key, the digit of a key, and the
+// digit of element i alone (what the counting kernel needs). The functor may read anything: a key array, or the text for the
+// first pass of the suffix sort.
 template <class KEY> struct DigitOfKey {
     const KEY* keys; int shift; u32 mask;
-    __device__ __forceinline__ KEY load(u32 idx) const { return keys[idx]; }
+    __device__ __forceinline__ KEY load(int, u32 b0, u32, u32 i) const { return keys[b0 + i]; }
     __device__ __forceinline__ u32 digit(KEY k) const { return (u32)(k >> shift) & mask; }
+    __device__ __forceinline__ u32 digit_at(int, u32 b0, u32, u32 i) const { return (u32)(keys[b0 + i] >> shift) & mask; }
 };
 
+// Tile histograms. A row of 64 keys that shows one digit (runs, zero stretches, the high bytes of small keys) costs one counter
+// update; other rows go through LDS atomics on the wave's private counters (equal digits inside a row serialise, which bounds the cost
+// at the multiplicity of the row's most frequent digit).
 template <class SRC>
 __global__ __launch_bounds__(256) void k_rs_count(SRC src, RsLayout L)
 {
@@ -225,13 +231,17 @@ __global__ __launch_bounds__(256) void k_rs_count(SRC src, RsLayout L)
     for (u32 t = blockIdx.x; t < nT; t += gridDim.x) {
         for (int w = 0; w < 4; w++) cnt[w][tid] = 0;
         __syncthreads();
-#pragma unroll 4
+        u32 dg[16];
+        const u32 i0 = t * RS_TILE + (u32)wave * 1024u + (u32)lane;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { const u32 i = i0 + (u32)r * 64u; dg[r] = (i < len) ? src.digit_at(sgm, b0, len, i) : 0xFFFFFFFFu; }
+#pragma unroll
         for (int r = 0; r < 16; r++) {
-            const u32 i = t * RS_TILE + (u32)wave * 1024u + (u32)r * 64u + (u32)lane;
-            const bool valid = i < len;
-            const u32 dg = valid ? src.digit(src.load(b0 + i)) : 0u;
-            const unsigned long long peers = digit_peers(valid, dg);
-            if (valid && lane == __ffsll((long long)peers) - 1) cnt[wave][dg] += (u32)__popcll(peers);
+            const bool valid = dg[r] != 0xFFFFFFFFu;
+            const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)dg[r]);        // (lane 0 is valid when any lane of the row is)
+            const unsigned long long va = __ballot(valid);
+            if (__ballot(valid && dg[r] != d0) == 0) { if (lane == 0 && va) cnt[wave][d0] += (u32)__popcll(va); }
+            else if (valid) atomicAdd(&cnt[wave][dg[r]], 1u);
             KNZ_WAVE_ORDER();
         }
         __syncthreads();
@@ -241,7 +251,7 @@ __global__ __launch_bounds__(256) void k_rs_count(SRC src, RsLayout L)
 }
 
 // exclusive scan of the tile rows inside every group of RS_GROUP tiles, one thread per digit; grpSum = the group's totals
-__global__ __launch_bounds__(256) void k_rs_colscan1(RsLayout L)
+static __global__ __launch_bounds__(256) void k_rs_colscan1(RsLayout L)
 {
     const int sgm = blockIdx.y;
     const u32 len = L.base[sgm + 1] - L.base[sgm];
@@ -257,7 +267,7 @@ __global__ __launch_bounds__(256) void k_rs_colscan1(RsLayout L)
 }
 
 // per segment: exclusive scan over the groups (per digit), then over the digits
-__global__ __launch_bounds__(256) void k_rs_colscan2(RsLayout L)
+static __global__ __launch_bounds__(256) void k_rs_colscan2(RsLayout L)
 {
     __shared__ u32 wsum[4];
     __shared__ u32 inclAll[256];
@@ -328,7 +338,7 @@ __global__ __launch_bounds__(256) void k_rs_scatter(SRC src, const u32* __restri
         for (int r = 0; r < 16; r++) {
             const u32 i = t * RS_TILE + (u32)wave * 1024u + (u32)r * 64u + (u32)lane;
             valid[r] = i < len;
-            key[r] = valid[r] ? src.load(b0 + i) : (KEY)0;
+            key[r] = valid[r] ? src.load(sgm, b0, len, i) : (KEY)0;
             if (HAS_VAL) val[r] = valid[r] ? vin[b0 + i] : 0u;
             dg[r] = valid[r] ? src.digit(key[r]) : 0u;
         }

@@ -73,6 +73,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
 int launch_bwt_inverse(hipStream_t s, const XfStage& st, void* scratch, size_t scratchBytes, u32* h_pinned);
 size_t bwt_forward_scratch_bytes(int nBlocks, u32 VS, size_t total);
 size_t bwt_inverse_scratch_bytes(int nBlocks, u32 VS, size_t total);
+int bwt_forward_tune(const char* key, int value);          // developer knobs of the suffix sort (knz_hip_tune)
 
 // fpaq.hip (probs: fpaq_probs_bytes(nBlocks, S) bytes of scratch, S = upper bound of the block lengths)
 void launch_fpaq_encode(hipStream_t s, BlockView view, const u32* origLen, u32 copyThreshold, int nBlocks, int maxChunks, ChunkDesc* desc, u8* tmp, u64 tmpStride,

@@ -203,23 +203,26 @@ def test_bwt_known_strings(hip):
     assert hip.transform_inverse("BWT", bad, 64)[0] == 0
 
 
-def test_bwt_round0_key_shapes(hip, oracle, monkeypatch):
-    """launch_bwt_forward picks the shape of its round-0 sort key from a byte-entropy sample (position packed into a 4..7-symbol key,
-    keys-only sort; or (key, position) pairs). Both shapes, forced through KNZ_BWT_PACKED, and the automatic choice must give the
-    reference's BWT on lone blocks around the sizes where the packed key changes its symbol count."""
+def test_bwt_round0_key_shapes(hip, oracle):
+    """launch_bwt_forward sorts the first round on as many symbols as fit a 64-bit key beside the position (5 for blocks up to
+    16 MiB, 4 above); short suffixes take their place through the order in which the first pass is fed. Every key length the knob
+    can force (knz_hip_tune "bwt_nsym") must give the reference's BWT on lone blocks, also around the ends of blocks that finish in
+    zero bytes (where the padded keys of short suffixes collide with real ones)."""
+    from kanzi_amd import hipapi
     rng = np.random.default_rng(11)
     cases = [bytes(5000), vectors.make(("text", 8000, 3)), vectors.make(("mixed", 70000, 4)), rng.integers(0, 256, 4097, dtype=np.uint8).tobytes(),
-             vectors.make(("runs", 300, 40)), vectors.make(("text", 300000, 5)), bytes(2500) + b"\x01" + bytes(2499)]
-    for d in cases:
-        ok1, o1 = oracle.forward("BWT", d, len(d) + 64, "ANS0")
-        assert ok1
-        for packed in ("0", "1", None):
-            if packed is None:
-                monkeypatch.delenv("KNZ_BWT_PACKED", raising=False)
-            else:
-                monkeypatch.setenv("KNZ_BWT_PACKED", packed)
-            ok2, o2 = hip.transform_forward("BWT", d, len(d) + 64, "ANS0")
-            assert ok2 and o1 == o2, (len(d), packed)
+             vectors.make(("runs", 300, 40)), vectors.make(("text", 300000, 5)), bytes(2500) + b"\x01" + bytes(2499),
+             b"ab\0\0\0\0ab\0\0\0\0\0\0", b"\0\0\0", b"xyzxyz\0xyzxy", bytes(3000) + b"ab" + bytes(4), bytes(7) + b"\x01" + bytes(3)]
+    try:
+        for d in cases:
+            ok1, o1 = oracle.forward("BWT", d, len(d) + 64, "ANS0")
+            assert ok1
+            for nsym in (0, 1, 2, 3, 4):
+                assert hipapi.lib().knz_hip_tune(b"bwt_nsym", nsym) == 0
+                ok2, o2 = hip.transform_forward("BWT", d, len(d) + 64, "ANS0")
+                assert ok2 and o1 == o2, (len(d), nsym)
+    finally:
+        hipapi.lib().knz_hip_tune(b"bwt_nsym", 0)
 
 
 def test_jobs_capacity_model(hip, oracle):

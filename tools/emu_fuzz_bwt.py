@@ -46,8 +46,6 @@ while time.time() - t0 < budget:
     T.write_case(path, blocks)
     env = dict(os.environ, HIPEMU_ORDER=str(int(rng.integers(0, 3))))
     r = rng.random()
-    if r < 0.2: env["KNZ_BWT_PACKED"] = "0"
-    elif r < 0.4: env["KNZ_BWT_PACKED"] = "1"
     if rng.random() < 0.1: env["KNZ_BWT_NO_RUN_ROUND"] = "1"
     if rng.random() < 0.1: env["KNZ_BWT_RUN_FALLBACK"] = "1"
     if rng.random() < 0.15: env["KNZ_BWT_NSYM"] = str(int(rng.integers(1, 6)))
