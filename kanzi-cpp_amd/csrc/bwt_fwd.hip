@@ -1135,7 +1135,6 @@ __global__ __launch_bounds__(512) void k_bwt_f_sort_desc_lds(const uint2* __rest
     for (u32 i = threadIdx.x; i < n; i += 512) out[i] = make_uint2(L.oK[i], L.oV[i]);
 }
 
-__global__ void k_set2(u32* p, u32 a, u32 b) { if (threadIdx.x == 0 && blockIdx.x == 0) { p[0] = a; p[1] = b; } }
 
 // knobs (tests, tuning): read from the environment once per process, or set through knz_hip_tune()
 struct FwdTuning { int nsym; int noRunRound; int runFallback; int noSuper; };
@@ -1305,7 +1304,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
         { KScope ks_("k_bwt_f_run_keys"); hipLaunchKernelGGL(k_bwt_f_run_keys, GRID1(runElems), bv, v, w.runList, nRun, w.loff, runElems, w.K, kbits, hbits, keysFree, w.valsA); }
         u64* rk; u32* rv;
         { KScope ks_("k_bwt_f_sort_runs");
-          hipLaunchKernelGGL(k_set2, dim3(1), dim3(64), 0, s, w.seg2, 0u, runElems);
+          hipLaunchKernelGGL(prims::k_rs_one_segment, dim3(1), dim3(64), 0, s, w.seg2, runElems);
           prims::rs_launch_layout(s, rs1);
           const int r = prims::rs_sort<u64, true>(s, rs1, keysFree, keysFree2, w.valsA, w.valsB, (size_t)runElems, 0, keyBits + rbits);
           rk = r ? keysFree2 : keysFree; rv = r ? w.valsB : w.valsA; }
@@ -1339,7 +1338,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
             { KScope ks_("k_bwt_f_sort_desc");
               if (nMed <= 8192) hipLaunchKernelGGL(k_bwt_f_sort_desc_lds, dim3(1), dim3(512), 0, s, w.med[cur], w.medSorted, nMed, (sbits + 7) / 8);
               else {
-                  hipLaunchKernelGGL(k_set2, dim3(1), dim3(64), 0, s, w.seg2, 0u, nMed);
+                  hipLaunchKernelGGL(prims::k_rs_one_segment, dim3(1), dim3(64), 0, s, w.seg2, nMed);
                   prims::rs_launch_layout(s, rs1);
                   u64* a = reinterpret_cast<u64*>(w.med[cur]); u64* b = reinterpret_cast<u64*>(w.medSorted);
                   const int r = prims::rs_sort<u64, false>(s, rs1, a, b, (u32*)nullptr, (u32*)nullptr, (size_t)nMed, 0, ((sbits + 7) / 8) * 8 > 32 ? 32 : ((sbits + 7) / 8) * 8);
@@ -1376,7 +1375,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
             u32* k32a = reinterpret_cast<u32*>(lkA); u32* k32b = reinterpret_cast<u32*>(lkB);
             int r;
             { KScope ks_("k_bwt_f_sort_large");
-              hipLaunchKernelGGL(k_set2, dim3(1), dim3(64), 0, s, w.seg2, 0u, largeElems);
+              hipLaunchKernelGGL(prims::k_rs_one_segment, dim3(1), dim3(64), 0, s, w.seg2, largeElems);
               prims::rs_launch_layout(s, rs1);
               r = small32 ? prims::rs_sort<u32, true>(s, rs1, k32a, k32b, w.valsA, w.valsB, (size_t)largeElems, 0, kbits + lbits)
                           : prims::rs_sort<u64, true>(s, rs1, lkA, lkB, w.valsA, w.valsB, (size_t)largeElems, 0, kbits + lbits); }

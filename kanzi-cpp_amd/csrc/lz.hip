@@ -19,7 +19,7 @@
 #include "stages.hpp"
 #include <cstring>
 #include <algorithm>
-#include <rocprim/rocprim.hpp>
+#include "prims.hpp"
 
 namespace knz {
 
@@ -137,7 +137,7 @@ constexpr int LZW = 1024;             // positions per LDS window of the walk
 
 struct LzWs {
     int* tables; u8* side; size_t secStride;
-    u32* keysA; u32* keysB; u32* valsA; u32* valsB; u32* prev; u16* info;
+    u32* keysA; u32* keysB; u32* valsA; u32* valsB; u32* prev; u16* info;      // (keysA = the hash of every position: the walk reads it too)
     u32 S;                            // positions per block in the flat arrays
 };
 
@@ -610,9 +610,7 @@ size_t lz_forward_scratch_bytes(int ttype, int nBlocks, u32 maxLen)
     const int G = lz_group_blocks(ttype, nBlocks);
     const size_t total = (size_t)G * maxLen;
     const size_t sec = ((size_t)maxLen + 64 + 15) & ~(size_t)15;
-    size_t prim = 0;
-    rocprim::radix_sort_pairs(nullptr, prim, (u32*)nullptr, (u32*)nullptr, (u32*)nullptr, (u32*)nullptr, total, 0u, 32u, (hipStream_t)0);
-    return lz_align(((size_t)G << hl) * 4) + lz_align((size_t)G * 3 * sec) + 5 * lz_align(total * 4) + lz_align(total * 2) + lz_align(prim) + 256;
+    return lz_align(((size_t)G << hl) * 4) + lz_align((size_t)G * 3 * sec) + 7 * lz_align(total * 4) + lz_align(total * 2) + lz_align(prims::rs_ws_bytes(total, 1)) + 512;
 }
 
 // Returns 0 or a negative value on a HIP / rocPRIM error.
@@ -634,8 +632,11 @@ int launch_lz_forward(hipStream_t s, const XfStage& stAll, int ttype, void* scra
     ws.valsB = reinterpret_cast<u32*>(p); p += lz_align(totalMax * 4);
     ws.prev = reinterpret_cast<u32*>(p); p += lz_align(totalMax * 4);
     ws.info = reinterpret_cast<u16*>(p); p += lz_align(totalMax * 2);
-    void* prim = p;
-    const size_t primBytes = scratchBytes - (size_t)(p - reinterpret_cast<u8*>(scratch));
+    u32* keysC = reinterpret_cast<u32*>(p); p += lz_align(totalMax * 4);
+    u32* valsC = reinterpret_cast<u32*>(p); p += lz_align(totalMax * 4);
+    u32* seg2 = reinterpret_cast<u32*>(p); p += 256;
+    if ((size_t)(p - reinterpret_cast<u8*>(scratch)) + prims::rs_ws_bytes(totalMax, 1) > scratchBytes) return -2;
+    const prims::RsWs rs = prims::rs_carve(p, totalMax, 1, seg2, 1);
     ws.S = S;
     for (int g0 = 0; g0 < stAll.nBlocks; g0 += G) {
         XfStage st = stAll;
@@ -646,16 +647,22 @@ int launch_lz_forward(hipStream_t s, const XfStage& stAll, int ttype, void* scra
         while ((1 << bbits) < st.nBlocks + 1) bbits++;
         const dim3 grid((unsigned)((total + 255) / 256));
         if (hipMemsetAsync(ws.tables, 0, ((size_t)st.nBlocks << hl) * sizeof(int), s) != hipSuccess) return -1;
-        size_t pb = primBytes;
+        // (hash, position) pairs of the group's blocks in hash order, equal hashes in position order: one stable sort
+        auto sortPairs = [&](int bits) -> int {
+            KScope ks_("k_lz_sort");
+            hipLaunchKernelGGL(prims::k_rs_one_segment, dim3(1), dim3(64), 0, s, seg2, (u32)total);
+            prims::rs_launch_layout(s, rs);
+            return prims::rs_sort_keep<u32, true>(s, rs, ws.keysA, ws.valsA, ws.keysB, keysC, ws.valsB, valsC, total, 0, bits);
+        };
         if (ttype == KNZ_T_LZX) {
             { KScope ks_("k_lz_keys"); hipLaunchKernelGGL((k_lz_keys<19>), grid, dim3(256), 0, s, st, S, st.nBlocks, ws.keysA, ws.valsA); }
-            { KScope ks_("rocprim_sort_lz"); if (rocprim::radix_sort_pairs(prim, pb, ws.keysA, ws.keysB, ws.valsA, ws.valsB, total, 0u, (unsigned)(19 + bbits), s) != hipSuccess) return -1; }
-            { KScope ks_("k_lz_prev"); hipLaunchKernelGGL((k_lz_prev<19>), grid, dim3(256), 0, s, st, S, st.nBlocks, total, ws.keysB, ws.valsB, ws.prev, ws.info); }
+            const int r = sortPairs(19 + bbits);
+            { KScope ks_("k_lz_prev"); hipLaunchKernelGGL((k_lz_prev<19>), grid, dim3(256), 0, s, st, S, st.nBlocks, total, r ? keysC : ws.keysB, r ? valsC : ws.valsB, ws.prev, ws.info); }
             { KScope ks_("k_lz_walk"); hipLaunchKernelGGL((k_lz_walk<19, true>), dim3(st.nBlocks), dim3(64), 0, s, st, ws); }
         } else {
             { KScope ks_("k_lz_keys"); hipLaunchKernelGGL((k_lz_keys<16>), grid, dim3(256), 0, s, st, S, st.nBlocks, ws.keysA, ws.valsA); }
-            { KScope ks_("rocprim_sort_lz"); if (rocprim::radix_sort_pairs(prim, pb, ws.keysA, ws.keysB, ws.valsA, ws.valsB, total, 0u, (unsigned)(16 + bbits), s) != hipSuccess) return -1; }
-            { KScope ks_("k_lz_prev"); hipLaunchKernelGGL((k_lz_prev<16>), grid, dim3(256), 0, s, st, S, st.nBlocks, total, ws.keysB, ws.valsB, ws.prev, ws.info); }
+            const int r = sortPairs(16 + bbits);
+            { KScope ks_("k_lz_prev"); hipLaunchKernelGGL((k_lz_prev<16>), grid, dim3(256), 0, s, st, S, st.nBlocks, total, r ? keysC : ws.keysB, r ? valsC : ws.valsB, ws.prev, ws.info); }
             { KScope ks_("k_lz_walk"); hipLaunchKernelGGL((k_lz_walk<16, false>), dim3(st.nBlocks), dim3(64), 0, s, st, ws); }
         }
     }

@@ -361,6 +361,8 @@ __global__ __launch_bounds__(256) void k_rs_scatter(SRC src, const u32* __restri
     }
 }
 
+static __global__ void k_rs_one_segment(u32* seg2, u32 n) { if (threadIdx.x == 0 && blockIdx.x == 0) { seg2[0] = 0; seg2[1] = n; } }
+
 struct RsWs { RsLayout L; size_t maxTiles; };
 
 static inline size_t rs_align(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -421,6 +423,21 @@ static inline int rs_sort(hipStream_t s, const RsWs& w, KEY* ka, KEY* kb, u32* v
         cur ^= 1;
     }
     return cur;
+}
+
+// The same with the input left untouched: the first pass reads (kin, vin), the others move between (kb, vb) and (kc, vc).
+// Returns 0 when the result is in (kb, vb), 1 when in (kc, vc).
+template <class KEY, bool HAS_VAL>
+static inline int rs_sort_keep(hipStream_t s, const RsWs& w, const KEY* kin, const u32* vin, KEY* kb, KEY* kc, u32* vb, u32* vc, size_t maxSegLen, int loBit, int hiBit)
+{
+    int cur = -1;                                            // -1: input, 0: b, 1: c
+    for (int sh = loBit; sh < hiBit; sh += 8) {
+        DigitOfKey<KEY> src; src.keys = cur < 0 ? kin : (cur ? kc : kb); src.shift = sh; src.mask = (hiBit - sh >= 8) ? 255u : ((1u << (hiBit - sh)) - 1u);
+        const int nxt = cur < 0 ? 0 : (cur ^ 1);
+        rs_launch_pass<KEY, HAS_VAL>(s, w, src, cur < 0 ? vin : (cur ? vc : vb), nxt ? kc : kb, nxt ? vc : vb, maxSegLen);
+        cur = nxt;
+    }
+    return cur < 0 ? 0 : cur;
 }
 
 }  // namespace prims
