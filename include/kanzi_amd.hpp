@@ -190,6 +190,12 @@ public:
 
 // One device context per process and device id (lazy). Throws IOException when no GPU is usable.
 knz_ctx* deviceContext(int device = -1);
+// The lanes the stream classes spread their batches over: (device, context) pairs from KNZ_DEVICES ("0,1,2,3": one lane per
+// entry, a device may be named more than once) or, when that is not set, KNZ_LANES (default 2) lanes on the default device.
+// setLaneDevices() overrides the environment for streams created afterwards (empty vector: back to the environment).
+void setLaneDevices(const std::vector<int>& devices);
+std::vector<int> laneDevices();
+knz_ctx* laneContext(int device, int index);
 void setDefaultDevice(int device);
 
 // ---- transforms on the device ------------------------------------------------------------------
@@ -345,28 +351,36 @@ private:
     int64 _blockId;               // blocks submitted so far
     byte _pendingByte;            // partial last byte of the stream written so far
     uint _pendingBits;
-    std::atomic<uint64_t> _written;   // bytes that reached the sink (advanced by the worker thread)
-    // Two page-locked input slots, each with its own device input buffer: write() fills one and queues its host-to-device copy
-    // (copy stream) while a worker thread has the other one in the kernels. The worker brings the compressed bytes back into one
-    // of two page-locked output buffers; the caller's thread writes them to the sink (in order, from write()/close()) while the
-    // device is already busy with the next batch.
-    struct Slot { byte* buf; size_t cap; size_t n; bool last; int state; void* dIn; size_t dInCap; uint64 ticket; };   // state: 0 free, 1 queued
-    Slot _slot[2];
-    int _fill, _proc;
-    struct Out { byte* buf; size_t cap; size_t bytes; int state; };   // state: 0 free, 1 waiting for the sink
-    Out _out[2];
-    int _outProd, _outCons;
-    void* _dOut; size_t _dOutCap;
-    std::thread _worker;
+    std::atomic<uint64_t> _written;   // bytes that reached the sink
+    // Lanes: one per entry of KNZ_DEVICES (default: two lanes on the default device). A lane owns a device context of its own
+    // (stream, workspaces), a worker thread, a page-locked input slot with its device copy and a page-locked output buffer.
+    // write() fills the lanes round robin, one batch each; every batch is compressed as an independent bit run (only the
+    // first carries the stream header, block ids continue), so the lanes -- and the devices behind them -- work side by side.
+    // Where a run starts in the stream is known once the runs in front of it have their lengths (published in batch order);
+    // a run that does not start on a byte boundary is moved by 1..7 bits on its device before it comes back. The caller's
+    // thread appends the runs in order (from write() / close()), OR-ing the byte two runs share: the reference's ordered
+    // bit-granular append (io/CompressedOutputStream.cpp:835-868) with whole batches as the unit.
+    struct Lane {
+        int device; knz_ctx* ctx; std::thread worker;
+        byte* in; size_t inCap; size_t n; bool last; void* dIn; size_t dInCap; uint64 ticket;
+        void* dOut; size_t dOutCap; void* dShift; size_t dShiftCap;
+        byte* out; size_t outCap; size_t outBytes; uint shiftR; uint64 bits;
+        int64 seq; int64 firstBlock;
+        int state;                // 0 free (the caller may fill it), 1 queued / in the kernels, 2 compressed bytes wait for the sink
+    };
+    std::vector<Lane> _lanes;
+    int _fillLane;
+    int64 _nextSeq, _sinkSeq, _pubSeq;    // batches handed out / appended to the sink / whose end position is known
+    uint64 _cumBits;                      // end position (bits) of the batches published so far
     std::mutex _mu;
     std::condition_variable _cv;
     bool _stop;
     std::exception_ptr _err;
     bool drainOne(std::unique_lock<std::mutex>& l);
     void enqueue(bool last);
-    void workerLoop();
+    void workerLoop(int lane);
     void rethrow();
-    void submit(bool last);
+    void submit(Lane& ln);
 };
 
 class CompressedInputStream : public std::istream {
@@ -414,15 +428,19 @@ private:
     // copies the batch to the device (page-locked staging, copy stream); the decoder thread runs the kernels and queues the
     // device-to-host copy of the result into a page-locked slot; read() waits for that copy and drains the slot. So the file reads
     // and both PCIe directions of neighbouring batches run beside the kernels.
-    struct Prep { void* dIn; size_t dInCap; byte* stage; size_t stageCap; size_t inBytes; uint64 startBit; int nb; bool last;
+    // One (Prep, PSlot, decoder thread) per lane -- an entry of KNZ_DEVICES, by default two lanes on the default device; the reader
+    // hands the batches to the lanes round robin and read() takes them back in the same order, so consecutive batches are decoded
+    // side by side on different contexts / devices.
+    struct Prep { knz_ctx* ctx; void* dIn; size_t dInCap; byte* stage; size_t stageCap; size_t inBytes; uint64 startBit; int nb; bool last;
                   int64 endBit; uint64 consumedBits; std::exception_ptr err; uint64 ticket; int state; };                    // state: 0 free, 1 prepared
-    Prep _prep[2];
-    int _pprod, _pcons;
-    struct PSlot { byte* buf; size_t cap; size_t len; int64 endBit; uint64 consumedBits; bool last; std::exception_ptr err;
+    std::vector<Prep> _prep;
+    int _pprod;
+    struct PSlot { knz_ctx* ctx; byte* buf; size_t cap; size_t len; int64 endBit; uint64 consumedBits; bool last; std::exception_ptr err;
                    void* dOut; size_t dOutCap; uint64 ticket; int state; };                                                    // state: 0 free, 2 ready
-    PSlot _ps[2];
-    int _prod, _cons;
-    std::thread _reader, _decoder;
+    std::vector<PSlot> _ps;
+    int _cons;
+    std::thread _reader;
+    std::vector<std::thread> _decoders;
     std::mutex _rmu;
     std::condition_variable _rcv;
     bool _rstop, _started;
@@ -441,7 +459,7 @@ private:
     bool fetch(size_t minBytes);
     void prepareBatch(Prep& pr);
     void decodeBatch(Prep& pr, PSlot& sl);
-    void decoderLoop();
+    void decoderLoop(int lane);
 };
 
 }  // namespace kanzi_amd

@@ -141,6 +141,11 @@ KNZ_API int knz_hip_copy_wait(knz_ctx* ctx, uint64_t ticket);
 KNZ_API int knz_hip_host_alloc(size_t bytes, void** ptr);
 KNZ_API int knz_hip_host_free(void* ptr);
 
+/* d_out = r zero bits (1..7) followed by the nbits bits of d_in (MSB-first byte streams, (r + nbits + 7) / 8 bytes written): what a
+ * host that appends bit runs of independent batches in order needs (io/CompressedOutputStream.cpp:835-868 appends at bit granularity).
+ * Queued on the context's stream. */
+KNZ_API int knz_hip_shift_bits(knz_ctx* ctx, const uint8_t* d_in, uint64_t nbits, uint32_t r, uint8_t* d_out);
+
 /* Timing of the kernels of the last encode/decode call, measured with HIP events on the context's
  * stream: name/ms pairs. Returns the number of entries written (<= cap). */
 typedef struct { char name[48]; float ms; uint64_t launches; } knz_kernel_time;

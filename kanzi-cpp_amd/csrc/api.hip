@@ -341,6 +341,17 @@ int knz_hip_sync(knz_ctx* ctx)
     return 0;
 }
 
+int knz_hip_shift_bits(knz_ctx* ctx, const uint8_t* d_in, uint64_t nbits, uint32_t r, uint8_t* d_out)
+{
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (c == nullptr || d_in == nullptr || d_out == nullptr || r == 0 || r > 7) return KNZ_ERR_INVALID_PARAM;
+    CTX_LOCK(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    launch_shift_bits(c->stream, d_in, nbits, r, d_out);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // shared plumbing
 // ------------------------------------------------------------------------------------------------

@@ -10,6 +10,7 @@
 //                      into the zero-initialised output.
 #include "common.hpp"
 #include "stages.hpp"
+#include <algorithm>
 
 namespace knz {
 
@@ -311,6 +312,25 @@ __global__ void k_check_prelen(DecBlock* blocks, int nBlocks, u32 maxPre, u64 ou
 void launch_check_prelen(hipStream_t s, DecBlock* blocks, int nBlocks, u32 maxPre, u64 outCap, u64 outStride)
 {
     { KScope ks_("k_check_prelen"); hipLaunchKernelGGL(k_check_prelen, dim3((nBlocks + 255) / 256), dim3(256), 0, s, blocks, nBlocks, maxPre, outCap, outStride); }
+}
+
+// out = r zero bits (0 < r < 8) followed by the nbits bits of in, both MSB-first byte streams; out gets (r + nbits + 7) / 8 bytes
+// (bits of the last byte beyond the stream are zero, as they are in `in`)
+__global__ __launch_bounds__(256) void k_shift_bits(const u8* __restrict__ in, u64 nbits, u32 r, u8* __restrict__ out)
+{
+    const u64 inBytes = (nbits + 7) >> 3, outBytes = (nbits + r + 7) >> 3;
+    for (u64 q = (u64)blockIdx.x * 256 + threadIdx.x; q < outBytes; q += (u64)gridDim.x * 256) {
+        const u32 a = (q > 0 && q - 1 < inBytes) ? in[q - 1] : 0u;
+        const u32 b = (q < inBytes) ? in[q] : 0u;
+        out[q] = (u8)((a << (8 - r)) | (b >> r));
+    }
+}
+
+void launch_shift_bits(hipStream_t s, const u8* in, u64 nbits, u32 r, u8* out)
+{
+    const u64 outBytes = (nbits + r + 7) >> 3;
+    const unsigned grid = (unsigned)std::min<u64>((outBytes + 255) / 256, 65536);
+    { KScope ks_("k_shift_bits"); hipLaunchKernelGGL(k_shift_bits, dim3(grid ? grid : 1), dim3(256), 0, s, in, nbits, r, out); }
 }
 
 void launch_put_prologue(hipStream_t s, u32* out, const u8* d_prologue, u32 bits)

@@ -21,6 +21,7 @@ void launch_assemble(hipStream_t s, const ChunkDesc* desc, const BlockInfo* info
                      const u8* skipFlags, const u64* checksums, const u8* hdrBase, int nBlocks, int maxChunks, u32 chunkSize,
                      u32 slotMul, u32 hdrStride, FrameParams fp, u32* out);
 void launch_put_prologue(hipStream_t s, u32* out, const u8* d_prologue, u32 bits);
+void launch_shift_bits(hipStream_t s, const u8* in, u64 nbits, u32 r, u8* out);
 void launch_walk_blocks(hipStream_t s, BitSrc src, u64 startBit, int64_t maxBlocks, int framing, u32 rawLen, int checksumBits,
                         u32 blockSize, DecBlock* blocks, void* res);
 void launch_check_prelen(hipStream_t s, DecBlock* blocks, int nBlocks, u32 maxPre, u64 outCap, u64 outStride);

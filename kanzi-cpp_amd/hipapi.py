@@ -19,7 +19,7 @@ SYMBOLS = [
     "knz_hip_encode_blocks", "knz_hip_decode_blocks", "knz_hip_entropy_encode", "knz_hip_entropy_decode",
     "knz_hip_transform_forward", "knz_hip_transform_inverse", "knz_hip_malloc", "knz_hip_free",
     "knz_hip_memcpy_h2d", "knz_hip_memcpy_d2h", "knz_hip_sync", "knz_hip_memcpy_h2d_async", "knz_hip_memcpy_d2h_async", "knz_hip_copy_wait", "knz_hip_host_alloc", "knz_hip_host_free", "knz_hip_set_profiling", "knz_hip_get_kernel_times",
-    "knz_hip_tune",
+    "knz_hip_tune", "knz_hip_shift_bits",
 ]
 
 
@@ -88,6 +88,7 @@ def lib():
         L.knz_hip_set_profiling.argtypes = [vp, C.c_int]
         L.knz_hip_get_kernel_times.argtypes = [vp, C.POINTER(KernelTime), C.c_int]
         L.knz_hip_tune.argtypes = [C.c_char_p, C.c_int]
+        L.knz_hip_shift_bits.argtypes = [vp, u8p, C.c_uint64, C.c_uint32, u8p]
         _lib = L
     return _lib
 

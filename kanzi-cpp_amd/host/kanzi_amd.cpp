@@ -43,6 +43,76 @@ knz_ctx* deviceContext(int device)
     return c;
 }
 
+// ---- lanes: (device, context) pairs the stream classes spread their batches over
+static std::vector<int> g_laneOverride;
+static bool g_laneOverrideSet = false;
+static std::map<std::pair<int, int>, knz_ctx*> g_laneCtx;
+
+void setLaneDevices(const std::vector<int>& devices)
+{
+    std::lock_guard<std::mutex> l(g_devMutex);
+    g_laneOverride = devices;
+    g_laneOverrideSet = !devices.empty();
+}
+
+std::vector<int> laneDevices()
+{
+    {
+        std::lock_guard<std::mutex> l(g_devMutex);
+        if (g_laneOverrideSet) return g_laneOverride;
+    }
+    std::vector<int> v;
+    if (const char* e = getenv("KNZ_DEVICES")) {
+        const char* p = e;
+        while (*p) {
+            while (*p == ',' || *p == ' ') p++;
+            if (*p < '0' || *p > '9') break;
+            v.push_back(int(strtol(p, const_cast<char**>(&p), 10)));
+            if (v.size() >= 64) break;
+        }
+    }
+    if (v.empty()) {
+        int dev;
+        {
+            std::lock_guard<std::mutex> l(g_devMutex);
+            if (g_defaultDevice < 0) {
+                const char* e = getenv("KNZ_DEVICE");
+                if (!e) e = getenv("LOCAL_RANK");
+                g_defaultDevice = e ? atoi(e) : 0;
+            }
+            dev = g_defaultDevice;
+        }
+        int lanes = 2;
+        if (const char* e = getenv("KNZ_LANES")) lanes = std::max(1, std::min(8, atoi(e)));
+        v.assign(size_t(lanes), dev);
+    }
+    return v;
+}
+
+// context number `index` of a device (0 = the one the transform / entropy mirror classes use); kept for the life of the process
+knz_ctx* laneContext(int device, int index)
+{
+    if (index == 0) return deviceContext(device);
+    std::lock_guard<std::mutex> l(g_devMutex);
+    auto key = std::make_pair(device, index);
+    auto it = g_laneCtx.find(key);
+    if (it != g_laneCtx.end()) return it->second;
+    knz_ctx* c = nullptr;
+    if (knz_hip_create(device, nullptr, &c) != 0 || c == nullptr)
+        throw IOException("No usable GPU: the kanzi_amd block pipeline has no CPU fallback", Error::ERR_CREATE_CODEC);
+    g_laneCtx[key] = c;
+    return c;
+}
+
+// lane k of a stream -> its context (the k-th lane that names a device gets that device's context number k')
+static std::vector<knz_ctx*> openLanes(const std::vector<int>& devs)
+{
+    std::vector<knz_ctx*> out;
+    std::map<int, int> used;
+    for (int d : devs) { const int idx = used[d]++; out.push_back(laneContext(d, idx)); }
+    return out;
+}
+
 static void devCheck(knz_ctx* c, int rc, const char* what)
 {
     if (rc == 0) return;
@@ -728,32 +798,34 @@ CompressedOutputStream::CompressedOutputStream(std::ostream& os, int tasks, cons
     { const int64_t lim = (int64_t(1) << 31) / int64_t(blockSize) - 1; if (_batchBlocks > lim) _batchBlocks = int(lim < 1 ? 1 : lim); }
     _blockId = 0;
     _pendingByte = 0; _pendingBits = 0; _written = 0;
-    _dOut = nullptr; _dOutCap = 0;
-    for (int i = 0; i < 2; i++) {
-        _slot[i].buf = nullptr; _slot[i].cap = 0; _slot[i].n = 0; _slot[i].last = false; _slot[i].state = 0;
-        _slot[i].dIn = nullptr; _slot[i].dInCap = 0; _slot[i].ticket = 0;
-        _out[i].buf = nullptr; _out[i].cap = 0; _out[i].bytes = 0; _out[i].state = 0;
-    }
-    _fill = 0; _proc = 0; _outProd = 0; _outCons = 0; _stop = false;
+    _fillLane = 0; _nextSeq = 0; _sinkSeq = 0; _pubSeq = 0; _cumBits = 0; _stop = false;
     _batchBytes = 0;
-    deviceContext();
+    const std::vector<int> devs = laneDevices();
+    const std::vector<knz_ctx*> ctxs = openLanes(devs);
+    _lanes.resize(devs.size());
+    for (size_t i = 0; i < _lanes.size(); i++) {
+        Lane& ln = _lanes[i];
+        ln.device = devs[i]; ln.ctx = ctxs[i];
+        ln.in = nullptr; ln.inCap = 0; ln.n = 0; ln.last = false; ln.dIn = nullptr; ln.dInCap = 0; ln.ticket = 0;
+        ln.dOut = nullptr; ln.dOutCap = 0; ln.dShift = nullptr; ln.dShiftCap = 0;
+        ln.out = nullptr; ln.outCap = 0; ln.outBytes = 0; ln.shiftR = 0; ln.bits = 0; ln.seq = -1; ln.firstBlock = 0; ln.state = 0;
+    }
 }
 
 CompressedOutputStream::~CompressedOutputStream()
 {
     try { close(); } catch (...) {}
-    if (_worker.joinable()) {
-        { std::lock_guard<std::mutex> l(_mu); _stop = true; }
-        _cv.notify_all();
-        _worker.join();
+    { std::lock_guard<std::mutex> l(_mu); _stop = true; }
+    _cv.notify_all();
+    for (Lane& ln : _lanes) if (ln.worker.joinable()) ln.worker.join();
+    for (Lane& ln : _lanes) {
+        knz_hip_copy_wait(ln.ctx, ln.ticket);
+        if (ln.dIn) knz_hip_free(ln.ctx, ln.dIn);
+        if (ln.dOut) knz_hip_free(ln.ctx, ln.dOut);
+        if (ln.dShift) knz_hip_free(ln.ctx, ln.dShift);
+        g_pinned.put(ln.in, ln.inCap);
+        g_pinned.put(ln.out, ln.outCap);
     }
-    knz_ctx* c = nullptr;
-    try { c = deviceContext(); } catch (...) {}
-    if (c) {
-        for (int i = 0; i < 2; i++) { knz_hip_copy_wait(c, _slot[i].ticket); if (_slot[i].dIn) knz_hip_free(c, _slot[i].dIn); }
-        if (_dOut) knz_hip_free(c, _dOut);
-    }
-    for (int i = 0; i < 2; i++) { g_pinned.put(_slot[i].buf, _slot[i].cap); g_pinned.put(_out[i].buf, _out[i].cap); }
 }
 
 void CompressedOutputStream::rethrow()
@@ -772,156 +844,174 @@ std::ostream& CompressedOutputStream::write(const char* data, std::streamsize le
     const size_t batchBytes = _batchBytes;
     size_t off = 0;
     while (off < size_t(length)) {
-        Slot& sl = _slot[_fill];
-        if (sl.buf == nullptr) sl.buf = g_pinned.get(batchBytes + 64, &sl.cap);
-        const size_t take = std::min(size_t(length) - off, batchBytes - sl.n);
-        memcpy(sl.buf + sl.n, data + off, take);
-        sl.n += take;
+        Lane& ln = _lanes[size_t(_fillLane)];                  // free: enqueue() waited for it
+        if (ln.in == nullptr) ln.in = g_pinned.get(batchBytes + 64, &ln.inCap);
+        const size_t take = std::min(size_t(length) - off, batchBytes - ln.n);
+        memcpy(ln.in + ln.n, data + off, take);
+        ln.n += take;
         off += take;
-        if (sl.n == batchBytes) enqueue(false);
+        if (ln.n == batchBytes) enqueue(false);
     }
     return *this;
 }
 
 std::ostream& CompressedOutputStream::put(char c) { return write(&c, 1); }
 
-// caller's thread: the oldest finished batch goes to the sink (the lock is dropped around the write); false if none is waiting
+// caller's thread: the next batch in stream order goes to the sink if its bytes are back (the lock is dropped around the
+// write); false if it is not ready
 bool CompressedOutputStream::drainOne(std::unique_lock<std::mutex>& l)
 {
-    Out& o = _out[_outCons];
-    if (o.state != 1) return false;
+    Lane& ln = _lanes[size_t(_sinkSeq % int64(_lanes.size()))];
+    if (ln.state != 2 || ln.seq != _sinkSeq) return false;
     l.unlock();
     bool bad = false;
-    if (o.bytes) {
-        _os.write(reinterpret_cast<const char*>(o.buf), std::streamsize(o.bytes));
-        bad = _os.fail();
-        if (!bad) _written += o.bytes;
+    {
+        // the run starts with shiftR zero bits: the place of the previous run's last bits
+        if (ln.shiftR != 0 && ln.outBytes != 0) ln.out[0] |= _pendingByte;
+        const uint64 totalBits = uint64(ln.shiftR) + ln.bits;
+        const size_t full = size_t(totalBits >> 3);
+        const uint rem = uint(totalBits & 7);
+        const size_t toWrite = (ln.last && rem) ? full + 1 : full;          // close(): the last byte is zero padded
+        if (toWrite) {
+            _os.write(reinterpret_cast<const char*>(ln.out), std::streamsize(toWrite));
+            bad = _os.fail();
+            if (!bad) _written += toWrite;
+        }
+        _pendingBits = ln.last ? 0 : rem;
+        _pendingByte = (rem && !ln.last) ? ln.out[full] : 0;
     }
     l.lock();
-    o.state = 0;
-    _outCons ^= 1;
+    ln.state = 0;
+    ln.n = 0;
+    _sinkSeq++;
     if (bad && !_err) _err = std::make_exception_ptr(IOException("Write to bitstream failed", Error::ERR_WRITE_FILE));
     _cv.notify_all();
     return true;
 }
 
-// hand the slot being filled to the worker (its host-to-device copy starts right away, beside the kernels of the batch
-// in flight), write finished batches to the sink, and wait until the other slot is free
+// hand the lane being filled to its worker (the host-to-device copy starts right away), append finished batches to the sink,
+// and wait until the next lane is free
 void CompressedOutputStream::enqueue(bool last)
 {
     rethrow();
-    if (!_worker.joinable()) _worker = std::thread(&CompressedOutputStream::workerLoop, this);
+    Lane& ln = _lanes[size_t(_fillLane)];
+    if (!ln.worker.joinable()) ln.worker = std::thread(&CompressedOutputStream::workerLoop, this, _fillLane);
     {
-        // the device buffer of this slot was last read by the batch that freed the slot: safe to overwrite
-        knz_ctx* c = deviceContext();
-        Slot& sl = _slot[_fill];
-        if (sl.dInCap < sl.n + 64) {
-            if (sl.dIn) knz_hip_free(c, sl.dIn);
-            sl.dIn = nullptr; sl.dInCap = 0;
-            const size_t want = sl.n + 64;                  // a full batch, except for a stream shorter than one
-            devCheck(c, knz_hip_malloc(c, want, &sl.dIn), "malloc");
-            sl.dInCap = want;
+        // the device buffer of this lane was last read by the batch that freed the lane: safe to overwrite
+        knz_ctx* c = ln.ctx;
+        if (ln.dInCap < ln.n + 64) {
+            if (ln.dIn) knz_hip_free(c, ln.dIn);
+            ln.dIn = nullptr; ln.dInCap = 0;
+            const size_t want = ln.n + 64;                  // a full batch, except for a stream shorter than one
+            devCheck(c, knz_hip_malloc(c, want, &ln.dIn), "malloc");
+            ln.dInCap = want;
         }
-        sl.ticket = 0;
-        if (sl.n) devCheck(c, knz_hip_memcpy_h2d_async(c, sl.dIn, sl.buf, sl.n, &sl.ticket), "h2d");
+        ln.ticket = 0;
+        if (ln.n) devCheck(c, knz_hip_memcpy_h2d_async(c, ln.dIn, ln.in, ln.n, &ln.ticket), "h2d");
     }
     {
         std::unique_lock<std::mutex> l(_mu);
-        _slot[_fill].last = last;
-        _slot[_fill].state = 1;
-        _fill ^= 1;
+        ln.last = last;
+        ln.seq = _nextSeq++;
+        ln.firstBlock = _blockId;
+        _blockId += int64((ln.n + size_t(_blockSize) - 1) / size_t(_blockSize));
+        ln.state = 1;
+        _fillLane = (_fillLane + 1) % int(_lanes.size());
         _cv.notify_all();
         for (;;) {
-            _cv.wait(l, [&] { return _slot[_fill].state == 0 || _err || _out[_outCons].state == 1; });
+            _cv.wait(l, [&] { const Lane& nx = _lanes[size_t(_fillLane)];
+                              const Lane& sk = _lanes[size_t(_sinkSeq % int64(_lanes.size()))];
+                              return nx.state == 0 || _err || (sk.state == 2 && sk.seq == _sinkSeq); });
             if (!drainOne(l)) break;
         }
     }
     rethrow();
 }
 
-void CompressedOutputStream::workerLoop()
+void CompressedOutputStream::workerLoop(int lane)
 {
+    Lane& ln = _lanes[size_t(lane)];
     for (;;) {
         {
             std::unique_lock<std::mutex> l(_mu);
-            _cv.wait(l, [&] { return _stop || _slot[_proc].state == 1; });
-            if (_slot[_proc].state != 1 || _err) return;
+            _cv.wait(l, [&] { return _stop || _err || ln.state == 1; });
+            if (ln.state != 1 || _err) return;
         }
-        bool last = _slot[_proc].last;
+        const bool last = ln.last;
         std::exception_ptr ex;
         try {
-            submit(last);
+            submit(ln);
         } catch (...) {
             ex = std::current_exception();
         }
         {
-            // the failure is recorded and the slot released in ONE critical section: a caller that leaves its wait because of
-            // the error never sees a slot the worker still owns
+            // a failure is recorded and the lane released in ONE critical section: a caller that leaves its wait because of
+            // the error never sees a lane its worker still owns
             std::lock_guard<std::mutex> l(_mu);
-            if (ex && !_err) _err = ex;
-            _slot[_proc].n = 0;
-            _slot[_proc].state = 0;
-            _proc ^= 1;
+            if (ex) { if (!_err) _err = ex; ln.n = 0; ln.state = 0; }
         }
         _cv.notify_all();
         if (last || ex) return;
     }
 }
 
-// worker thread: one batch through the device and into the sink
-void CompressedOutputStream::submit(bool last)
+// worker thread of a lane: one batch through the device; the compressed run ends up in the lane's page-locked output buffer
+void CompressedOutputStream::submit(Lane& ln)
 {
-    knz_ctx* c = deviceContext();
-    Slot& sl = _slot[_proc];
-    const size_t n = sl.n;
+    knz_ctx* c = ln.ctx;
+    const size_t n = ln.n;
     knz_params p;
     memset(&p, 0, sizeof(p));
     p.transform_type = _transformType; p.entropy_type = _entropyType; p.block_size = _blockSize; p.checksum_bits = _checksum; p.jobs = _jobs;
-    // prologue: the stream header before the first block, afterwards the pending bits of the last byte
+    // prologue: the stream header in front of the first batch
     BitPacker pro;
-    if (!_headerDone) {
-        if (!_headless) {
-            const uint32_t ckSize = _checksum == 32 ? 1 : (_checksum == 64 ? 2 : 0);
-            pro.put(0x4B414E5Au, 32); pro.put(6, 4); pro.put(ckSize, 2); pro.put(uint64(_entropyType), 5); pro.put(_transformType, 48);
-            pro.put(uint64(_blockSize >> 4), 28);
-            int szMask = 0;
-            if (_inputSize != 0 && _inputSize < (uint64(1) << 48)) { int lg = 63; while (!((_inputSize >> lg) & 1)) lg--; szMask = (lg >> 4) + 1; }
-            pro.put(uint64(szMask), 2);
-            if (szMask) pro.put(_inputSize, uint(16 * szMask));
-            pro.put(0, 15);
-            pro.put(headerChecksum(ckSize, uint32_t(_entropyType), _transformType, uint32_t(_blockSize), szMask, _inputSize), 24);
-        }
-        _headerDone = true;
-    } else if (_pendingBits) {
-        pro.put(uint64(_pendingByte >> (8 - _pendingBits)), _pendingBits);
+    if (ln.seq == 0 && !_headless) {
+        const uint32_t ckSize = _checksum == 32 ? 1 : (_checksum == 64 ? 2 : 0);
+        pro.put(0x4B414E5Au, 32); pro.put(6, 4); pro.put(ckSize, 2); pro.put(uint64(_entropyType), 5); pro.put(_transformType, 48);
+        pro.put(uint64(_blockSize >> 4), 28);
+        int szMask = 0;
+        if (_inputSize != 0 && _inputSize < (uint64(1) << 48)) { int lg = 63; while (!((_inputSize >> lg) & 1)) lg--; szMask = (lg >> 4) + 1; }
+        pro.put(uint64(szMask), 2);
+        if (szMask) pro.put(_inputSize, uint(16 * szMask));
+        pro.put(0, 15);
+        pro.put(headerChecksum(ckSize, uint32_t(_entropyType), _transformType, uint32_t(_blockSize), szMask, _inputSize), 24);
     }
     const size_t cap = knz_hip_encode_bound(&p, n) + pro.bytes.size() + 256;
-    if (_dOutCap < cap) { if (_dOut) knz_hip_free(c, _dOut); devCheck(c, knz_hip_malloc(c, cap + (cap >> 2), &_dOut), "malloc"); _dOutCap = cap + (cap >> 2); }
-    devCheck(c, knz_hip_copy_wait(c, sl.ticket), "h2d");           // queued by enqueue(), normally long complete
-    sl.ticket = 0;
+    if (ln.dOutCap < cap) { if (ln.dOut) knz_hip_free(c, ln.dOut); ln.dOut = nullptr; ln.dOutCap = 0; devCheck(c, knz_hip_malloc(c, cap + (cap >> 2), &ln.dOut), "malloc"); ln.dOutCap = cap + (cap >> 2); }
+    devCheck(c, knz_hip_copy_wait(c, ln.ticket), "h2d");           // queued by enqueue(), normally long complete
+    ln.ticket = 0;
     uint64_t bits = 0;
-    devCheck(c, knz_hip_encode_blocks(c, &p, static_cast<const uint8_t*>(sl.dIn), n, pro.bytes.empty() ? nullptr : pro.bytes.data(), uint32_t(pro.nbits),
-                                      _blockId, last ? 1 : 0, static_cast<uint8_t*>(_dOut), _dOutCap, &bits), "encode blocks");
-    const size_t bytes = size_t((bits + 7) >> 3);
-    // the output buffer the sink is not reading from
-    Out& o = _out[_outProd];
+    devCheck(c, knz_hip_encode_blocks(c, &p, static_cast<const uint8_t*>(ln.dIn), n, pro.bytes.empty() ? nullptr : pro.bytes.data(), uint32_t(pro.nbits),
+                                      ln.firstBlock, ln.last ? 1 : 0, static_cast<uint8_t*>(ln.dOut), ln.dOutCap, &bits), "encode blocks");
+    // where the run starts: behind the runs of the batches before it, whose lengths are published in batch order
+    uint64 start;
     {
         std::unique_lock<std::mutex> l(_mu);
-        _cv.wait(l, [&] { return o.state == 0 || _stop || _err; });
-        if (o.state != 0) return;
+        _cv.wait(l, [&] { return _pubSeq == ln.seq || _stop || _err; });
+        if (_pubSeq != ln.seq) return;
+        start = _cumBits;
+        _cumBits += bits;
+        _pubSeq++;
     }
-    if (o.cap < bytes + 8) { g_pinned.put(o.buf, o.cap); o.buf = nullptr; o.cap = 0; o.buf = g_pinned.get(std::max(bytes + 8, cap / 2), &o.cap); }
-    if (bytes) devCheck(c, knz_hip_memcpy_d2h(c, o.buf, _dOut, bytes), "d2h");
-    const size_t full = size_t(bits >> 3);
-    const uint rem = uint(bits & 7);
-    _pendingBits = last ? 0 : rem;
-    _pendingByte = (rem && !last) ? o.buf[full] : 0;
-    _blockId += int64((n + size_t(_blockSize) - 1) / size_t(_blockSize));
+    _cv.notify_all();
+    const uint r = uint(start & 7);
+    const size_t bytes = size_t((uint64(r) + bits + 7) >> 3);
+    const void* src = ln.dOut;
+    if (r != 0 && bits != 0) {
+        if (ln.dShiftCap < bytes + 8) { if (ln.dShift) knz_hip_free(c, ln.dShift); ln.dShift = nullptr; ln.dShiftCap = 0; devCheck(c, knz_hip_malloc(c, ln.dOutCap + 8, &ln.dShift), "malloc"); ln.dShiftCap = ln.dOutCap + 8; }
+        devCheck(c, knz_hip_shift_bits(c, static_cast<const uint8_t*>(ln.dOut), bits, r, static_cast<uint8_t*>(ln.dShift)), "shift");
+        src = ln.dShift;
+    }
+    if (ln.outCap < bytes + 8) { g_pinned.put(ln.out, ln.outCap); ln.out = nullptr; ln.outCap = 0; ln.out = g_pinned.get(std::max(bytes + 8, cap / 2), &ln.outCap); }
+    if (bits == 0) { if (ln.outCap) ln.out[0] = 0; }
+    else devCheck(c, knz_hip_memcpy_d2h(c, ln.out, src, bytes), "d2h");
     {
         std::lock_guard<std::mutex> l(_mu);
-        o.bytes = (last && rem) ? full + 1 : full;          // close(): the last byte is zero padded
-        o.state = 1;
-        _outProd ^= 1;
+        ln.shiftR = (bits != 0) ? r : 0;
+        ln.bits = bits;
+        ln.outBytes = bytes;
+        if (bits == 0 && r != 0) { ln.shiftR = r; ln.outBytes = 1; }       // (an empty run in the middle of a byte: only the shared byte)
+        ln.state = 2;
     }
     _cv.notify_all();
 }
@@ -937,13 +1027,14 @@ void CompressedOutputStream::close()
         {
             std::unique_lock<std::mutex> l(_mu);
             for (;;) {
-                _cv.wait(l, [&] { return (_slot[0].state == 0 && _slot[1].state == 0 && _out[0].state == 0 && _out[1].state == 0) || _err || _out[_outCons].state == 1; });
+                _cv.wait(l, [&] { const Lane& sk = _lanes[size_t(_sinkSeq % int64(_lanes.size()))];
+                                  return _sinkSeq == _nextSeq || _err || (sk.state == 2 && sk.seq == _sinkSeq); });
                 if (!drainOne(l)) break;
             }
-            if (_err) _stop = true;           // releases a worker that waits for an output buffer
+            _stop = true;                     // releases the workers (all of them idle, or stuck behind a failed batch)
         }
         _cv.notify_all();
-        if (_worker.joinable()) _worker.join();
+        for (Lane& ln : _lanes) if (ln.worker.joinable()) ln.worker.join();
         rethrow();
         _os.flush();
     } catch (const IOException&) {
@@ -978,17 +1069,20 @@ CompressedInputStream::CompressedInputStream(std::istream& is, int tasks, const 
     _batchFromEnv = false;
     if (e && atoi(e) > 0) { _batchBlocks = atoi(e); _batchFromEnv = true; }
     _compBit = 0; _consumedBits = 0; _plainPos = 0; _gcount = 0; _srcEof = false;
-    for (int i = 0; i < 2; i++) {
-        _ps[i].buf = nullptr; _ps[i].cap = 0; _ps[i].len = 0; _ps[i].endBit = 0; _ps[i].consumedBits = 0; _ps[i].last = false; _ps[i].state = 0;
-        _ps[i].dOut = nullptr; _ps[i].dOutCap = 0; _ps[i].ticket = 0;
-        _prep[i].dIn = nullptr; _prep[i].dInCap = 0; _prep[i].stage = nullptr; _prep[i].stageCap = 0; _prep[i].inBytes = 0; _prep[i].startBit = 0;
-        _prep[i].nb = 0; _prep[i].last = false; _prep[i].endBit = 0; _prep[i].consumedBits = 0; _prep[i].ticket = 0; _prep[i].state = 0;
+    {
+        const std::vector<knz_ctx*> ctxs = openLanes(laneDevices());
+        _ps.resize(ctxs.size()); _prep.resize(ctxs.size());
+        for (size_t i = 0; i < ctxs.size(); i++) {
+            _ps[i].ctx = ctxs[i]; _ps[i].buf = nullptr; _ps[i].cap = 0; _ps[i].len = 0; _ps[i].endBit = 0; _ps[i].consumedBits = 0; _ps[i].last = false; _ps[i].state = 0;
+            _ps[i].dOut = nullptr; _ps[i].dOutCap = 0; _ps[i].ticket = 0;
+            _prep[i].ctx = ctxs[i]; _prep[i].dIn = nullptr; _prep[i].dInCap = 0; _prep[i].stage = nullptr; _prep[i].stageCap = 0; _prep[i].inBytes = 0; _prep[i].startBit = 0;
+            _prep[i].nb = 0; _prep[i].last = false; _prep[i].endBit = 0; _prep[i].consumedBits = 0; _prep[i].ticket = 0; _prep[i].state = 0;
+        }
     }
-    _pprod = _pcons = 0;
-    _prod = _cons = 0; _rstop = false; _started = false; _cur = nullptr; _lastTaken = false; _tellBit = 0; _readBits = 0;
+    _pprod = 0;
+    _cons = 0; _rstop = false; _started = false; _cur = nullptr; _lastTaken = false; _tellBit = 0; _readBits = 0;
     _from = 1; _to = 0x7FFFFFFF; _nextBlockId = 1;
     { _is.clear(); const std::streamoff at = std::streamoff(_is.tellg()); _originBit = (at < 0) ? 0 : 8 * int64(at); _is.clear(); }
-    deviceContext();
 }
 
 CompressedInputStream::CompressedInputStream(std::istream& is, Context& ctx, bool headerless)
@@ -1002,10 +1096,11 @@ CompressedInputStream::CompressedInputStream(std::istream& is, Context& ctx, boo
 CompressedInputStream::~CompressedInputStream()
 {
     stopReader();
-    knz_ctx* c = nullptr;
-    try { c = deviceContext(); } catch (...) {}
-    if (c) for (int i = 0; i < 2; i++) { if (_prep[i].dIn) knz_hip_free(c, _prep[i].dIn); if (_ps[i].dOut) knz_hip_free(c, _ps[i].dOut); }
-    for (int i = 0; i < 2; i++) { g_pinned.put(_ps[i].buf, _ps[i].cap); g_pinned.put(_prep[i].stage, _prep[i].stageCap); }
+    for (size_t i = 0; i < _ps.size(); i++) {
+        if (_prep[i].dIn) knz_hip_free(_prep[i].ctx, _prep[i].dIn);
+        if (_ps[i].dOut) knz_hip_free(_ps[i].ctx, _ps[i].dOut);
+        g_pinned.put(_ps[i].buf, _ps[i].cap); g_pinned.put(_prep[i].stage, _prep[i].stageCap);
+    }
 }
 
 bool CompressedInputStream::fetch(size_t minBytes)
@@ -1111,7 +1206,7 @@ void CompressedInputStream::prepareBatch(Prep& pr)
         _nextBlockId++;
     }
     if (nb > 0) {
-        knz_ctx* c = deviceContext();
+        knz_ctx* c = pr.ctx;
         const size_t firstByte = size_t(_compBit >> 3) & ~size_t(15);
         const size_t lastByte = size_t((pos + 7) >> 3);
         const size_t inBytes = lastByte - firstByte;
@@ -1143,7 +1238,7 @@ void CompressedInputStream::decodeBatch(Prep& pr, PSlot& sl)
     sl.len = 0; sl.ticket = 0;
     sl.endBit = pr.endBit; sl.consumedBits = pr.consumedBits; sl.last = pr.last;
     if (pr.nb == 0) return;
-    knz_ctx* c = deviceContext();
+    knz_ctx* c = sl.ctx;
     knz_params p;
     memset(&p, 0, sizeof(p));
     p.transform_type = _transformType; p.entropy_type = _entropyType; p.block_size = _blockSize; p.checksum_bits = _checksum; p.jobs = _jobs;
@@ -1187,23 +1282,23 @@ void CompressedInputStream::readerLoop()
         {
             std::lock_guard<std::mutex> l(_rmu);
             pr.state = 1;
-            _pprod ^= 1;
+            _pprod = (_pprod + 1) % int(_prep.size());
         }
         _rcv.notify_all();
         if (last) return;
     }
 }
 
-void CompressedInputStream::decoderLoop()
+void CompressedInputStream::decoderLoop(int lane)
 {
     for (;;) {
         {
             std::unique_lock<std::mutex> l(_rmu);
-            _rcv.wait(l, [&] { return _rstop || (_prep[_pcons].state == 1 && _ps[_prod].state == 0); });
+            _rcv.wait(l, [&] { return _rstop || (_prep[size_t(lane)].state == 1 && _ps[size_t(lane)].state == 0); });
             if (_rstop) return;
         }
-        Prep& pr = _prep[_pcons];
-        PSlot& sl = _ps[_prod];
+        Prep& pr = _prep[size_t(lane)];
+        PSlot& sl = _ps[size_t(lane)];
         sl.err = nullptr; sl.last = false; sl.len = 0; sl.ticket = 0;
         if (pr.err) { sl.err = pr.err; pr.err = nullptr; sl.last = true; }
         else {
@@ -1218,9 +1313,7 @@ void CompressedInputStream::decoderLoop()
         {
             std::lock_guard<std::mutex> l(_rmu);
             pr.state = 0;
-            _pcons ^= 1;
             sl.state = 2;
-            _prod ^= 1;
         }
         _rcv.notify_all();
         if (last) return;
@@ -1237,21 +1330,26 @@ void CompressedInputStream::ensureStarted()
     _rstop = false;
     _started = true;
     _reader = std::thread(&CompressedInputStream::readerLoop, this);
-    _decoder = std::thread(&CompressedInputStream::decoderLoop, this);
+    _decoders.clear();
+    for (size_t i = 0; i < _ps.size(); i++) _decoders.emplace_back(&CompressedInputStream::decoderLoop, this, int(i));
 }
 
 void CompressedInputStream::stopReader()
 {
-    if (_reader.joinable() || _decoder.joinable()) {
+    bool any = _reader.joinable();
+    for (std::thread& t : _decoders) any = any || t.joinable();
+    if (any) {
         { std::lock_guard<std::mutex> l(_rmu); _rstop = true; }
         _rcv.notify_all();
         if (_reader.joinable()) _reader.join();
-        if (_decoder.joinable()) _decoder.join();
+        for (std::thread& t : _decoders) if (t.joinable()) t.join();
+        _decoders.clear();
     }
     // copies still on their way belong to batches nobody will look at: let them land before the buffers are reused or freed
-    knz_ctx* c = nullptr;
-    try { c = deviceContext(); } catch (...) {}
-    if (c) for (int i = 0; i < 2; i++) { knz_hip_copy_wait(c, _prep[i].ticket); _prep[i].ticket = 0; knz_hip_copy_wait(c, _ps[i].ticket); _ps[i].ticket = 0; }
+    for (size_t i = 0; i < _ps.size(); i++) {
+        knz_hip_copy_wait(_prep[i].ctx, _prep[i].ticket); _prep[i].ticket = 0;
+        knz_hip_copy_wait(_ps[i].ctx, _ps[i].ticket); _ps[i].ticket = 0;
+    }
     _started = false;
 }
 
@@ -1270,9 +1368,9 @@ bool CompressedInputStream::advance()
         PSlot* sl;
         {
             std::unique_lock<std::mutex> l(_rmu);
-            _rcv.wait(l, [&] { return _ps[_cons].state == 2; });
-            sl = &_ps[_cons];
-            _cons ^= 1;
+            _rcv.wait(l, [&] { return _ps[size_t(_cons)].state == 2; });
+            sl = &_ps[size_t(_cons)];
+            _cons = (_cons + 1) % int(_ps.size());
         }
         if (sl->last) _lastTaken = true;
         if (sl->err) {
@@ -1285,7 +1383,7 @@ bool CompressedInputStream::advance()
         _tellBit = sl->endBit;
         _readBits = sl->consumedBits;
         if (sl->len != 0 && sl->ticket != 0) {               // the device-to-host copy the decoder thread queued
-            const int rc = knz_hip_copy_wait(deviceContext(), sl->ticket);
+            const int rc = knz_hip_copy_wait(sl->ctx, sl->ticket);
             sl->ticket = 0;
             if (rc != 0) {
                 { std::lock_guard<std::mutex> l(_rmu); sl->state = 0; }
@@ -1354,11 +1452,11 @@ bool CompressedInputStream::seek(int64 bitPos)
     if (_is.fail()) return false;
     // forget everything fetched or decoded; the stream parameters (header) stay
     _comp.clear();
-    for (int i = 0; i < 2; i++) {
+    for (size_t i = 0; i < _ps.size(); i++) {
         _ps[i].state = 0; _ps[i].len = 0; _ps[i].err = nullptr; _ps[i].last = false;
         _prep[i].state = 0; _prep[i].nb = 0; _prep[i].err = nullptr; _prep[i].last = false;
     }
-    _prod = _cons = 0; _pprod = _pcons = 0; _cur = nullptr; _lastTaken = false;
+    _cons = 0; _pprod = 0; _cur = nullptr; _lastTaken = false;
     _plainPos = 0;
     _gcount = 0;
     _srcEof = false; _ended = false;

@@ -13,6 +13,8 @@ Decode (`decompress_sharded`): every rank walks the block length prefixes on the
 """
 import importlib
 
+import numpy as np
+
 
 def block_ranges(n_bytes, block_size, world):
     """Contiguous, balanced ranges of block indices: [(first_block, n_blocks)] per rank."""
@@ -27,16 +29,27 @@ def block_ranges(n_bytes, block_size, world):
 
 
 def concat_bit_runs(runs):
-    """runs: [(bytes, nbits)] in stream order -> (bytes, nbits) MSB-first."""
-    acc, total = 0, 0
+    """runs: [(bytes, nbits)] in stream order -> (bytes, nbits) MSB-first. A run that does not start on a byte boundary is moved
+    by 1..7 bits with two numpy shifts over its bytes (what knz_hip_shift_bits does on the device for the stream classes)."""
+    total = sum(nbits for _, nbits in runs)
+    out = np.zeros((total + 7) // 8 + 1, dtype=np.uint8)
+    pos = 0
     for data, nbits in runs:
         if nbits == 0:
             continue
-        v = int.from_bytes(data[:(nbits + 7) // 8], "big") >> ((-nbits) % 8)
-        acc = (acc << nbits) | v
-        total += nbits
-    nbytes = (total + 7) // 8
-    return (acc << ((-total) % 8)).to_bytes(nbytes, "big") if nbytes else b"", total
+        nb = (nbits + 7) // 8
+        src = np.frombuffer(data, dtype=np.uint8, count=nb)
+        if nbits & 7:                                   # bits behind the run's end do not belong to it
+            src = src.copy()
+            src[-1] &= (0xFF << (8 - (nbits & 7))) & 0xFF
+        r, at = pos & 7, pos >> 3
+        if r == 0:
+            out[at:at + nb] |= src
+        else:
+            out[at:at + nb] |= src >> r
+            out[at + 1:at + 1 + nb] |= (src << (8 - r)).astype(np.uint8)
+        pos += nbits
+    return out[:(total + 7) // 8].tobytes(), total
 
 
 class _DeviceBuffers:

@@ -119,3 +119,14 @@ int knz_hip_host_alloc(size_t bytes, void** p) { *p = malloc(bytes ? bytes : 1);
 int knz_hip_host_free(void* p) { free(p); return 0; }
 int knz_hip_set_profiling(knz_ctx* c, int on) { (void)c; (void)on; return 0; }
 int knz_hip_get_kernel_times(knz_ctx* c, knz_kernel_time* out, int cap) { (void)c; (void)out; (void)cap; return 0; }
+int knz_hip_tune(const char* name, int value) { (void)name; (void)value; return 0; }
+int knz_hip_shift_bits(knz_ctx* c, const uint8_t* in, uint64_t nbits, uint32_t r, uint8_t* out)
+{
+    (void)c;
+    const uint64_t inBytes = (nbits + 7) >> 3, outBytes = (nbits + r + 7) >> 3;
+    for (uint64_t q = 0; q < outBytes; q++) {
+        const unsigned a = (q > 0 && q - 1 < inBytes) ? in[q - 1] : 0u, b = (q < inBytes) ? in[q] : 0u;
+        out[q] = (uint8_t)((a << (8 - r)) | (b >> r));
+    }
+    return 0;
+}

@@ -66,6 +66,48 @@ def test_c_api_roundtrip_and_bit_exact(tmp_path, oracle):
         assert bytes(out) == data
 
 
+def test_lanes_and_devices_give_the_single_device_stream(tmp_path, oracle, monkeypatch):
+    """The stream classes spread consecutive batches over lanes -- one (device, context, worker thread) per entry of KNZ_DEVICES,
+    two lanes on the default device when it is not set -- and append the independent bit runs in order (a run that does not start
+    on a byte boundary is moved on its device). Whatever the lanes and the batch size, the file must be the reference's and must
+    decode through the same lanes. KNZ_TEST_DEVICES (tests/test_host_stub.py: the stand-in device library accepts any device
+    number) adds a list with two different devices."""
+    kz = _kanzi()
+    data = vectors.make(("mixed", 23 * 16384 + 777, 21))
+    lists = ["0", "0,0", "0,0,0"] + ([os.environ["KNZ_TEST_DEVICES"]] if os.environ.get("KNZ_TEST_DEVICES") else [])
+    for transform, entropy, bs, jobs, ck in [("BWT+MTFT+ZRLT", "ANS0", 16384, 3, 0), ("NONE", "HUFFMAN", 16384, 1, 32), ("RLT", "FPAQ", 32768, 2, 64)]:
+        rc, ref = oracle.compress(data, transform, entropy, bs, orig_size=0, jobs=jobs, checksum=ck)
+        assert rc == 0
+        for devs in lists:
+            for batch in ("1", "2", "5"):
+                monkeypatch.setenv("KNZ_DEVICES", devs)
+                monkeypatch.setenv("KNZ_BATCH_BLOCKS", batch)
+                path = str(tmp_path / "lanes.knz")
+                c = kz.Compressor(path, transform, entropy, bs, jobs, checksum=ck)
+                for off in range(0, len(data), bs):
+                    c.compress(data[off:off + bs])
+                c.close()
+                assert open(path, "rb").read() == ref, (transform, entropy, devs, batch)
+                d = kz.Decompressor(path, buffer_size=bs, jobs=jobs)
+                out = bytearray()
+                while True:
+                    chunk = d.decompress(bs)
+                    out += chunk
+                    if len(chunk) < bs:
+                        break
+                d.close()
+                assert bytes(out) == data, (transform, entropy, devs, batch)
+    # an empty stream and a stream of one short block go through the same machinery
+    monkeypatch.setenv("KNZ_DEVICES", "0,0")
+    for n in (0, 5, 1000):
+        path = str(tmp_path / "tiny.knz")
+        c = kz.Compressor(path, "BWT", "ANS0", 4096, 1)
+        if n:
+            c.compress(data[:n])
+        c.close()
+        assert open(path, "rb").read() == oracle.compress(data[:n], "BWT", "ANS0", 4096, orig_size=0)[1]
+
+
 def test_reference_python_api_cases(tmp_path, oracle):
     """The cases of the reference's own ctypes test (src/test/test_api.py), written against the same class interface
     (bytes codec names, context managers, decompress_block, the reference's keyword names), plus what that test does

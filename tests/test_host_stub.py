@@ -35,7 +35,7 @@ def build_stub(tmp_path):
 
 def test_host_layer_against_stub_device(tmp_path):
     lib, exe, _ = build_stub(tmp_path)
-    env = dict(os.environ, KNZ_TEST_KANZI_LIB=lib, KNZ_TEST_HOST_MIRROR_EXE=exe)
+    env = dict(os.environ, KNZ_TEST_KANZI_LIB=lib, KNZ_TEST_HOST_MIRROR_EXE=exe, KNZ_TEST_DEVICES="0,1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_host_api.py"), "-m", "gpu", "-x", "-q",
                         "-p", "no:cacheprovider", "-k", "not threads_share_the_device"], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
