@@ -191,7 +191,7 @@ public:
 // One device context per process and device id (lazy). Throws IOException when no GPU is usable.
 knz_ctx* deviceContext(int device = -1);
 // The lanes the stream classes spread their batches over: (device, context) pairs from KNZ_DEVICES ("0,1,2,3": one lane per
-// entry, a device may be named more than once) or, when that is not set, KNZ_LANES (default 2) lanes on the default device.
+// entry, a device may be named more than once) or, when that is not set, KNZ_LANES (default 4) lanes on the default device.
 // setLaneDevices() overrides the environment for streams created afterwards (empty vector: back to the environment).
 void setLaneDevices(const std::vector<int>& devices);
 std::vector<int> laneDevices();
@@ -352,7 +352,7 @@ private:
     byte _pendingByte;            // partial last byte of the stream written so far
     uint _pendingBits;
     std::atomic<uint64_t> _written;   // bytes that reached the sink
-    // Lanes: one per entry of KNZ_DEVICES (default: two lanes on the default device). A lane owns a device context of its own
+    // Lanes: one per entry of KNZ_DEVICES (default: four lanes on the default device). A lane owns a device context of its own
     // (stream, workspaces), a worker thread, a page-locked input slot with its device copy and a page-locked output buffer.
     // write() fills the lanes round robin, one batch each; every batch is compressed as an independent bit run (only the
     // first carries the stream header, block ids continue), so the lanes -- and the devices behind them -- work side by side.
@@ -428,7 +428,7 @@ private:
     // copies the batch to the device (page-locked staging, copy stream); the decoder thread runs the kernels and queues the
     // device-to-host copy of the result into a page-locked slot; read() waits for that copy and drains the slot. So the file reads
     // and both PCIe directions of neighbouring batches run beside the kernels.
-    // One (Prep, PSlot, decoder thread) per lane -- an entry of KNZ_DEVICES, by default two lanes on the default device; the reader
+    // One (Prep, PSlot, decoder thread) per lane -- an entry of KNZ_DEVICES, by default four lanes on the default device; the reader
     // hands the batches to the lanes round robin and read() takes them back in the same order, so consecutive batches are decoded
     // side by side on different contexts / devices.
     struct Prep { knz_ctx* ctx; void* dIn; size_t dInCap; byte* stage; size_t stageCap; size_t inBytes; uint64 startBit; int nb; bool last;

@@ -994,12 +994,16 @@ __global__ __launch_bounds__(256) void k_bwt_f_run_ends(BwtView bv, FwdView v, u
 }
 
 // R[gp] = distance to the end of the run that holds gp (1 = the run ends here); one workgroup per window of 2048 positions
-__global__ __launch_bounds__(256) void k_bwt_f_run_len(FwdView v, const u32* __restrict__ ebits, const u32* __restrict__ winFirstInclRev, u32 nWin, u32* __restrict__ R)
+__global__ __launch_bounds__(256) void k_bwt_f_run_len(BwtView bv, FwdView v, const u32* __restrict__ ebits, const u32* __restrict__ winFirstInclRev, u32 nWin,
+                                                       u32* __restrict__ R, const u32* __restrict__ classTab, u32 nsym, unsigned long long* __restrict__ startBits64,
+                                                       u32* __restrict__ startCount)
 {
     __shared__ u32 bw[64];
     __shared__ u32 nextSet[64];
+    __shared__ int sBlk;
     const int tid = (int)threadIdx.x;
     const u32 win = blockIdx.x, pos0 = win * SM_WIN;
+    if (tid == 64) sBlk = find_block(v.base, v.nBlocks, pos0 < v.total ? pos0 : v.total - 1);
     if (tid < 64) {
         const u32 w = ebits[(pos0 >> 5) + (u32)tid];
         bw[tid] = w;
@@ -1014,18 +1018,36 @@ __global__ __launch_bounds__(256) void k_bwt_f_run_len(FwdView v, const u32* __r
     }
     __syncthreads();
     const u32 after = (win + 1 < nWin) ? winFirstInclRev[nWin - 2 - win] : v.total - 1;
+    const u32 prevWord = pos0 ? ebits[(pos0 >> 5) - 1] : 0xFFFFFFFFu;      // (the run-end bit of the position in front of the window)
     u32 rmax = 0;
 #pragma unroll
     for (int k = 0; k < (int)(SM_WIN / 256); k++) {
         const u32 i = (u32)tid + 256u * (u32)k;
         const u32 gp = pos0 + i;
-        if (gp >= v.total) continue;
-        const u32 w = i >> 5, bit = i & 31;
-        const u32 m = bw[w] & (0xFFFFFFFFu << bit);              // this position or later
-        const u32 ei = m ? (w * 32 + (u32)__ffs((int)m) - 1) : nextSet[w];
-        const u32 e = (ei != NO_BIT) ? pos0 + ei : after;
-        R[gp] = e - gp + 1;
-        rmax = (e - gp + 1) > rmax ? (e - gp + 1) : rmax;
+        bool start = false;
+        if (gp < v.total) {
+            const u32 w = i >> 5, bit = i & 31;
+            const u32 m = bw[w] & (0xFFFFFFFFu << bit);              // this position or later
+            const u32 ei = m ? (w * 32 + (u32)__ffs((int)m) - 1) : nextSet[w];
+            const u32 e = (ei != NO_BIT) ? pos0 + ei : after;
+            const u32 r = e - gp + 1;
+            R[gp] = r;
+            rmax = r > rmax ? r : rmax;
+            // a run starts here when a run ends right in front (block ends are run ends); it takes part in the run-length round when it
+            // is at least nsym long and its byte has a run group
+            const bool endBefore = (i == 0) ? ((prevWord >> 31) & 1u) != 0 : ((bw[(i - 1) >> 5] >> ((i - 1) & 31)) & 1u) != 0;
+            if (endBefore && r >= nsym && classTab != nullptr) {
+                int b = sBlk;
+                while (gp >= v.base[b + 1]) b++;
+                start = classTab[(u32)b * 256u + (u32)bv.src[b][gp - v.base[b]]] != 0xFFFFFFFFu;
+            }
+        }
+        const unsigned long long m64 = __ballot(start);
+        if ((tid & 63) == 0 && startBits64 != nullptr) {
+            startBits64[(pos0 + 256u * (u32)k + (u32)(tid & ~63)) >> 6] = m64;
+            startCount[((pos0 + 256u * (u32)k + (u32)(tid & ~63)) >> 5)] = (u32)__popc((u32)m64);
+            startCount[((pos0 + 256u * (u32)k + (u32)(tid & ~63)) >> 5) + 1] = (u32)__popc((u32)(m64 >> 32));
+        }
     }
     rmax = wave_max(rmax);
     // longest run: sizes the key of the run-length sort (read first: one atomic per wave on one address would serialise the launch)
@@ -1040,27 +1062,121 @@ __global__ __launch_bounds__(256) void k_bwt_f_run_fallback(FwdView v, const uin
     if (g < nRun) classify_child(v, medNext, largeNext, runList[g].x, runList[g].y, surv);
 }
 
-__global__ __launch_bounds__(256) void k_bwt_f_run_keys(BwtView bv, FwdView v, const uint2* __restrict__ desc, u32 nDesc, const u32* __restrict__ loff,
-                                                        u32 L, const u32* __restrict__ R, int kbits, int hbits, u64* __restrict__ keys, u32* __restrict__ vals)
+// ---- the run-length round without a sort of (key, position) pairs over 48 bits ----------------------------------------------
+// A member's key (run length R, what follows the run) is a property of its RUN except for R itself: a run of length L of a
+// run-group byte has the members R = nsym .. L, and all of them share the direction bit and the rank T of the suffix behind the
+// run. So the runs (a few per cent of the members in number) are sorted on (class, direction, T) first; the members are then
+// generated run by run in that order and sorted, stably, on (class, hi(R)) alone -- three passes over 8-byte elements for 24 key
+// bits, where the pair sort took six passes over 12-byte elements: the order of equal (class, hi) is the order of the runs, i.e.
+// T. What k_bwt_f_large_flags / _place want -- the full key and the position per slot -- is rebuilt from the run table.
+
+// class of a run-group byte: classTab[block * 256 + byte] = index of the group's descriptor
+__global__ __launch_bounds__(256) void k_bwt_f_run_classes(BwtView bv, FwdView v, const uint2* __restrict__ runList, u32 nRun, u32* __restrict__ classTab)
+{
+    const u32 d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= nRun) return;
+    const u32 gp = v.SA[runList[d].x];
+    const int b = find_block(v.base, v.nBlocks, gp);
+    classTab[(u32)b * 256u + (u32)bv.src[b][gp - v.base[b]]] = d;
+}
+
+__global__ __launch_bounds__(256) void k_bwt_f_run_compact(const u32* __restrict__ bits, const u32* __restrict__ wprefix, u32 nWords, u32* __restrict__ runPos)
+{
+    const u32 w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= nWords) return;
+    u32 word = bits[w];
+    u32 at = wprefix[w];
+    while (word) {
+        const u32 k = (u32)__ffs((int)word) - 1;
+        runPos[at++] = 32u * w + k;
+        word &= word - 1;
+    }
+}
+
+// run k: end, length, and the sort key [class | above? | T | k]
+__global__ __launch_bounds__(256) void k_bwt_f_run_table(BwtView bv, FwdView v, const u32* __restrict__ runPos, u32 nRuns, const u32* __restrict__ R,
+                                                         const u32* __restrict__ classTab, int kbits, int idxBits, u64* __restrict__ runKeys,
+                                                         u32* __restrict__ runE, u32* __restrict__ runL)
+{
+    const u32 k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= nRuns) return;
+    const u32 p = runPos[k];
+    const int b = find_block(v.base, v.nBlocks, p);
+    const u32 bb = v.base[b], be = v.base[b + 1];
+    const u8* t = bv.src[b];
+    const u32 c = t[p - bb], L = R[p], e = p + L;
+    const bool below = (e >= be) || (t[e - bb] < c);                 // the block end sorts in front of every byte
+    const u64 T = (e < be) ? (u64)(v.ISA[e] - bb + 1u) : 0ull;
+    const u64 cls = classTab[(u32)b * 256u + c];
+    runKeys[k] = ((((cls << 1) | (below ? 0ull : 1ull)) << kbits | T) << idxBits) | (u64)k;
+    runE[k] = e;
+    runL[k] = L;
+}
+
+// the runs in sorted order: end, (class, direction, T), number of members
+__global__ __launch_bounds__(256) void k_bwt_f_run_sorted(const u64* __restrict__ runKeys, u32 nRuns, int idxBits, const u32* __restrict__ runE,
+                                                          const u32* __restrict__ runL, u32 nsym, u32* __restrict__ sE, u64* __restrict__ sKey, u32* __restrict__ cnt)
+{
+    const u32 k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= nRuns) return;
+    const u64 key = runKeys[k];
+    const u32 idx = (u32)(key & ((1ull << idxBits) - 1ull));
+    sE[k] = runE[idx];
+    sKey[k] = key >> idxBits;
+    cnt[k] = runL[idx] - nsym + 1u;
+}
+
+// member j (members of run 0 first, then of run 1, ...): [class | hi(R) | run index]; a workgroup makes 2048 consecutive members
+__global__ __launch_bounds__(256) void k_bwt_f_run_members(const u32* __restrict__ moff, u32 nRuns, u32 M, const u64* __restrict__ sKey, int kbits, int hbits,
+                                                           u32 nsym, u64* __restrict__ mkeys)
+{
+    __shared__ u32 sOff[2048 + 1];
+    __shared__ u32 sFirst;
+    const u32 j0 = blockIdx.x * 2048u;
+    if (j0 >= M) return;
+    if (threadIdx.x == 0) {
+        u32 lo = 0, hi = nRuns;                                      // last run with moff <= j0
+        while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (moff[mid] <= j0) lo = mid; else hi = mid; }
+        sFirst = lo;
+    }
+    __syncthreads();
+    const u32 k0 = sFirst;
+    // every run has at least one member: the members of this tile belong to at most 2048 runs
+    for (u32 i = threadIdx.x; i <= 2048u; i += 256) sOff[i] = (k0 + i < nRuns) ? moff[k0 + i] : 0xFFFFFFFFu;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const u32 j = j0 + (u32)q * 256u + threadIdx.x;
+        if (j >= M) continue;
+        u32 lo = 0, hi = 2048;
+        while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (sOff[mid] <= j) lo = mid; else hi = mid; }
+        if (sOff[hi] <= j) lo = hi;
+        const u32 k = k0 + lo;
+        const u64 key = sKey[k];
+        const u64 cls = key >> (kbits + 1);
+        const bool above = (key >> kbits) & 1ull;
+        const u64 Rr = (u64)nsym + (u64)(j - sOff[lo]);
+        const u64 hiK = above ? ((1ull << hbits) - 1ull - Rr) : Rr;
+        mkeys[j] = (((cls << hbits) | hiK) << 32) | (u64)k;
+    }
+}
+
+// sorted members -> the (key, position) pairs k_bwt_f_large_flags / k_bwt_f_large_place work on: key = [class | hi | T]
+__global__ __launch_bounds__(256) void k_bwt_f_run_expand(const u64* __restrict__ mkeys, u32 M, const u64* __restrict__ sKey, const u32* __restrict__ sE,
+                                                          int kbits, int hbits, u64* __restrict__ keys, u32* __restrict__ vals)
 {
     const u32 j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= L) return;
-    u32 lo = 0, hi = nDesc;
-    while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (loff[mid] <= j) lo = mid; else hi = mid; }
-    const uint2 d = desc[lo];
-    const u32 slot = d.x + (j - loff[lo]);
-    const int b = find_block(v.base, v.nBlocks, d.x);
-    const u32 bb = v.base[b], be = v.base[b + 1];
-    const u32 gp = v.SA[slot];
-    const u32 r = R[gp];
-    const u32 q = gp + r;
-    const u8* t = bv.src[b];
-    const u32 c = t[gp - bb];
-    const bool below = (q >= be) || (t[q - bb] < c);                 // the block end sorts in front of every byte
-    const u64 khi = below ? (u64)r : ((1ull << hbits) - 1ull - (u64)r);      // hbits = bits of the longest run + 1
-    const u64 klo = (q < be) ? (u64)(v.ISA[q] - bb + 1u) : 0ull;
-    keys[j] = ((u64)lo << (hbits + kbits)) | (khi << kbits) | klo;
-    vals[j] = gp;
+    if (j >= M) return;
+    const u64 mk = mkeys[j];
+    const u32 k = (u32)mk;
+    const u64 ch = mk >> 32;                                         // class | hi
+    const u64 hiK = ch & ((1ull << hbits) - 1ull);
+    const u64 rk = sKey[k];
+    const bool above = (rk >> kbits) & 1ull;
+    const u64 T = rk & ((1ull << kbits) - 1ull);
+    const u32 Rr = (u32)(above ? ((1ull << hbits) - 1ull - hiK) : hiK);
+    keys[j] = (ch << kbits) | T;
+    vals[j] = sE[k] - Rr;
 }
 
 // end of a round: the group starts found in it become visible
@@ -1174,6 +1290,11 @@ struct FwdScratch {
     u32* seg2;
     void* scanTmp;
     void* rsMem;
+    // run round: class table, run-start bit map (+ counts, prefix), run tables
+    u32* classTab; u32* rbits; u32* rcount; u32* rprefix;
+    u32* runPos; u32* runE; u32* runL; u32* sE; u32* rcnt; u32* moff;
+    u64* runKeysA; u64* runKeysB; u64* sKey;
+    size_t maxRuns;
 };
 
 static size_t fwd_align(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1202,6 +1323,13 @@ static size_t fwd_carve(u8* p, int nBlocks, size_t total, FwdScratch* w)
     w->seg2 = (u32*)take(64);
     w->scanTmp = take(prims::scan_tmp_bytes(total + 16));
     w->rsMem = take(prims::rs_ws_bytes(total, nBlocks + 1));
+    w->maxRuns = total / 4 + 64;                                   // (runs of at least 4 symbols; with a shorter round-0 key there can be more: fallback)
+    w->classTab = (u32*)take(1024ull * (size_t)nBlocks);
+    const size_t rw = total / 32 + SM_WIN / 32 + 8;
+    w->rbits = (u32*)take(4 * rw); w->rcount = (u32*)take(4 * rw); w->rprefix = (u32*)take(4 * rw);
+    w->runPos = (u32*)take(4 * w->maxRuns); w->runE = (u32*)take(4 * w->maxRuns); w->runL = (u32*)take(4 * w->maxRuns);
+    w->sE = (u32*)take(4 * w->maxRuns); w->rcnt = (u32*)take(4 * w->maxRuns); w->moff = (u32*)take(4 * w->maxRuns + 64);
+    w->runKeysA = (u64*)take(8 * w->maxRuns); w->runKeysB = (u64*)take(8 * w->maxRuns); w->sKey = (u64*)take(8 * w->maxRuns);
     return (size_t)(q - p);
 }
 
@@ -1291,23 +1419,55 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
         { KScope ks_("k_bwt_f_run_ends"); hipLaunchKernelGGL(k_bwt_f_run_ends, dim3((total + SM_WIN - 1) / SM_WIN), dim3(256), 0, s, bv, v, reinterpret_cast<u8*>(w.ebits)); }
         { KScope ks_("k_bwt_f_r0_winsum"); hipLaunchKernelGGL(k_bwt_f_r0_winsum, GRID1(nWin), w.ebits, total, nWin, w.t0, w.t2); }
         { KScope ks_("k_bwt_f_scan_min"); prims::launch_scan<prims::SCAN_MIN_INCL>(s, w.t2, w.t3, nWin, nullptr, w.scanTmp); }
-        { KScope ks_("k_bwt_f_run_len"); hipLaunchKernelGGL(k_bwt_f_run_len, dim3(nWin), dim3(256), 0, s, v, w.ebits, w.t3, nWin, w.K); }
-        if (hipMemcpyAsync(h_pinned + 8, w.counters + 6, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+        // run lengths of every position, and the starts of the runs of run-group bytes as a bit map
+        hipMemsetAsync(w.classTab, 0xFF, 1024ull * (size_t)st.nBlocks, s);
+        { KScope ks_("k_bwt_f_run_classes"); hipLaunchKernelGGL(k_bwt_f_run_classes, GRID1(nRun), bv, v, w.runList, nRun, w.classTab); }
+        { KScope ks_("k_bwt_f_run_len"); hipLaunchKernelGGL(k_bwt_f_run_len, dim3(nWin), dim3(256), 0, s, bv, v, w.ebits, w.t3, nWin, w.K, w.classTab, (u32)nsym,
+                                                            reinterpret_cast<unsigned long long*>(w.rbits), w.rcount); }
+        // the runs themselves, compacted in position order (the windows of k_bwt_f_run_len cover whole words up to nWin * 2048)
+        const u32 nRW = nWin * (SM_WIN / 32);
+        { KScope ks_("k_bwt_f_scan_sum"); prims::launch_scan<prims::SCAN_SUM_EXCL>(s, w.rcount, w.rprefix, nRW, nullptr, w.scanTmp, w.counters + 8); }
+        { KScope ks_("k_bwt_f_run_compact"); hipLaunchKernelGGL(k_bwt_f_run_compact, GRID1(nRW), w.rbits, w.rprefix, nRW, w.runPos); }
+        if (hipMemcpyAsync(h_pinned + 8, w.counters + 6, 12, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;     // longest run, -, number of runs
         if (hipStreamSynchronize(s) != hipSuccess) return -1;
+        const u32 nRuns = h_pinned[10];
         int hbits = 1;
         while ((1ull << hbits) < (u64)h_pinned[8] + 1) hbits++;
         hbits++;                                                  // both halves of the order: R and 2^hbits - 1 - R
         const int keyBits = hbits + kbits;
         int rbits = 0;
         while ((1u << rbits) < nRun) rbits++;
+        int idxBits = 1;
+        while ((1ull << idxBits) < (u64)nRuns) idxBits++;
+        if (nRuns == 0 || nRuns > w.maxRuns || rbits + hbits > 32 || idxBits + kbits + 1 + rbits > 64) {
+            // more runs than the tables hold (a round-0 key shorter than 4 symbols) or fields that do not fit their words: the run groups
+            // go the ordinary way
+            { KScope ks_("k_bwt_f_run_fallback"); hipLaunchKernelGGL(k_bwt_f_run_fallback, GRID1(nRun), v, w.runList, nRun, w.med[cur], w.large[cur]); }
+            if (hipMemcpyAsync(h_pinned, w.counters, 32, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+            if (hipStreamSynchronize(s) != hipSuccess) return -1;
+            nRun = 0;
+        }
+      if (nRun) {
         { KScope ks_("k_bwt_f_large_prefix"); hipLaunchKernelGGL(k_bwt_f_large_prefix, dim3(1), dim3(1024), 0, s, w.runList, nRun, w.loff); }
-        { KScope ks_("k_bwt_f_run_keys"); hipLaunchKernelGGL(k_bwt_f_run_keys, GRID1(runElems), bv, v, w.runList, nRun, w.loff, runElems, w.K, kbits, hbits, keysFree, w.valsA); }
-        u64* rk; u32* rv;
+        { KScope ks_("k_bwt_f_run_table"); hipLaunchKernelGGL(k_bwt_f_run_table, GRID1(nRuns), bv, v, w.runPos, nRuns, w.K, w.classTab, kbits, idxBits, w.runKeysA, w.runE, w.runL); }
+        const u64* rkSorted;
         { KScope ks_("k_bwt_f_sort_runs");
+          hipLaunchKernelGGL(prims::k_rs_one_segment, dim3(1), dim3(64), 0, s, w.seg2, nRuns);
+          prims::rs_launch_layout(s, rs1);
+          const int r = prims::rs_sort<u64, false>(s, rs1, w.runKeysA, w.runKeysB, (u32*)nullptr, (u32*)nullptr, (size_t)nRuns, idxBits, idxBits + kbits + 1 + rbits);
+          rkSorted = r ? w.runKeysB : w.runKeysA; }
+        { KScope ks_("k_bwt_f_run_sorted"); hipLaunchKernelGGL(k_bwt_f_run_sorted, GRID1(nRuns), rkSorted, nRuns, idxBits, w.runE, w.runL, (u32)nsym, w.sE, w.sKey, w.rcnt); }
+        { KScope ks_("k_bwt_f_scan_sum"); prims::launch_scan<prims::SCAN_SUM_EXCL>(s, w.rcnt, w.moff, nRuns, nullptr, w.scanTmp); }
+        { KScope ks_("k_bwt_f_run_members"); hipLaunchKernelGGL(k_bwt_f_run_members, dim3((runElems + 2047) / 2048), dim3(256), 0, s, w.moff, nRuns, runElems, w.sKey, kbits, hbits,
+                                                                (u32)nsym, keysFree); }
+        u64* rk; u32* rv = w.valsA;
+        { KScope ks_("k_bwt_f_sort_members");
           hipLaunchKernelGGL(prims::k_rs_one_segment, dim3(1), dim3(64), 0, s, w.seg2, runElems);
           prims::rs_launch_layout(s, rs1);
-          const int r = prims::rs_sort<u64, true>(s, rs1, keysFree, keysFree2, w.valsA, w.valsB, (size_t)runElems, 0, keyBits + rbits);
-          rk = r ? keysFree2 : keysFree; rv = r ? w.valsB : w.valsA; }
+          const int r = prims::rs_sort<u64, false>(s, rs1, keysFree, keysFree2, (u32*)nullptr, (u32*)nullptr, (size_t)runElems, 32, 32 + hbits + rbits);
+          const u64* sortedM = r ? keysFree2 : keysFree;
+          rk = r ? keysFree : keysFree2;
+          hipLaunchKernelGGL(k_bwt_f_run_expand, GRID1(runElems), sortedM, runElems, w.sKey, w.sE, kbits, hbits, rk, rv); }
         { KScope ks_("k_bwt_f_large_flags"); hipLaunchKernelGGL(k_bwt_f_large_flags<u64>, GRID1(runElems), rk, runElems, w.t0, w.t2); }
         { KScope ks_("k_bwt_f_scan_max"); prims::launch_scan<prims::SCAN_MAX_INCL>(s, w.t0, w.t1, runElems, nullptr, w.scanTmp); }
         { KScope ks_("k_bwt_f_scan_min"); prims::launch_scan<prims::SCAN_MIN_INCL>(s, w.t2, w.t3, runElems, nullptr, w.scanTmp); }
@@ -1316,6 +1476,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
         { KScope ks_("k_bwt_f_merge_bits"); hipLaunchKernelGGL(k_bwt_f_merge_bits, GRID1(total / 32 + 2), w.gbits, w.gnew, total / 32 + 2); }
         if (hipMemcpyAsync(h_pinned, w.counters, 32, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
         if (hipStreamSynchronize(s) != hipSuccess) return -1;
+      }
     }
     u32 surv = h_pinned[0], nMed = h_pinned[1], nLarge = h_pinned[2], largeElems = h_pinned[3];
 #ifdef KNZ_FWD_DEBUG

@@ -82,7 +82,7 @@ std::vector<int> laneDevices()
             }
             dev = g_defaultDevice;
         }
-        int lanes = 2;
+        int lanes = 4;
         if (const char* e = getenv("KNZ_LANES")) lanes = std::max(1, std::min(8, atoi(e)));
         v.assign(size_t(lanes), dev);
     }
@@ -789,9 +789,9 @@ CompressedOutputStream::CompressedOutputStream(std::ostream& os, int tasks, cons
     _inputSize = fileSize;
     _headless = headerless; _closed = false; _headerDone = false;
     // Blocks per device call.  `jobs` only selects the reference's buffer-slot capacities in the bitstream; the
-    // GPU wants many blocks per launch and the host wants several batches in flight (the caller fills one staging
-    // slot while the device works on the other), so by default a batch is 64 MiB (at least `jobs` blocks, at most 64).
-    { const int64_t want = (int64_t(64) << 20) / int64_t(blockSize); _batchBlocks = std::max(tasks, int(std::min<int64_t>(64, std::max<int64_t>(1, want)))); }
+    // GPU wants many blocks per launch and the host wants several batches in flight (one per lane: the caller fills a staging
+    // slot while the lanes work), so by default a batch is 32 MiB (at least one block, at most 64).
+    { const int64_t want = (int64_t(32) << 20) / int64_t(blockSize); _batchBlocks = int(std::min<int64_t>(64, std::max<int64_t>(1, want))); }
     const char* e = getenv("KNZ_BATCH_BLOCKS");
     if (e && atoi(e) > 0) _batchBlocks = atoi(e);
     // one device call takes at most 2 GiB of input (32-bit positions on the device side)
@@ -1177,7 +1177,7 @@ void CompressedInputStream::prepareBatch(Prep& pr)
     const int64_t lim = (int64_t(1) << 31) / bsz - 1;
     const int wantBatch = _batchBlocks.load();
     int batch = (wantBatch > lim) ? int(lim < 1 ? 1 : lim) : wantBatch;
-    if (!_batchFromEnv.load()) batch = std::max(_jobs, int(std::min<int64_t>(batch, std::max<int64_t>(1, (int64_t(64) << 20) / bsz))));
+    if (!_batchFromEnv.load()) batch = int(std::min<int64_t>(batch, std::max<int64_t>(1, (int64_t(32) << 20) / bsz)));
     while (nb < batch) {
         if (!fetch(size_t(((pos + 40) >> 3) + 1 - (_compBit >> 3)))) {
             if (uint64(_comp.size()) * 8 < pos + 8) { if (nb == 0) throw IOException("Unexpected end of stream", Error::ERR_READ_FILE); break; }
