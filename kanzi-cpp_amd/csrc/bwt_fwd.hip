@@ -738,15 +738,17 @@ __global__ __launch_bounds__(THREADS, THREADS / 128) void k_bwt_f_sort_medium(Fw
 // therefore does what log2(longest chain) doubling rounds would do; ties share (c + 1) h symbols and the depth of the end's label
 // (at least 2h altogether) and go on as ordinary groups. The members are in position order (every sort of the pipeline is stable),
 // so p + h is found by binary search in the group itself and c, e come from pointer jumping in LDS.
-__global__ __launch_bounds__(512) void k_bwt_f_super(FwdView v, const uint4* __restrict__ superList, u32 h, int npass, uint2* __restrict__ medNext, uint2* __restrict__ largeNext)
+__global__ __launch_bounds__(1024) void k_bwt_f_super(FwdView v, const uint4* __restrict__ superList, u32 h, int npass, uint2* __restrict__ medNext, uint2* __restrict__ largeNext)
 {
-    constexpr int THREADS = 512, ROWS = 16;
+    constexpr int THREADS = 1024, ROWS = 8;                // (126 KB of LDS: one workgroup per CU, so as many waves in it as a workgroup can have)
     constexpr u32 CAP = (u32)ROWS * THREADS;
     __shared__ MedLds<THREADS, ROWS> L;
     __shared__ u16 nxt[CAP];
     __shared__ u16 cn[CAP];
     __shared__ u16 trEnd[CAP];
     __shared__ u32 sEnds;
+    __shared__ u32 sMoved[2];
+    __shared__ u32 sCmax;
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const unsigned long long ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const u32 nList = v.counters[7];
@@ -760,7 +762,7 @@ __global__ __launch_bounds__(512) void k_bwt_f_super(FwdView v, const uint4* __r
 #pragma unroll
             for (int r = 0; r < ROWS; r++) { const u32 i = (u32)tid + (u32)r * THREADS; if (i < n) { L.oK[i] = k[r]; L.oV[i] = p[r]; } }
         }
-        if (tid == 0) { sEnds = 0; L.oldLab = d.w; }
+        if (tid == 0) { sEnds = 0; sCmax = 0; L.oldLab = d.w; }
         __syncthreads();
         const u32 m = d.w - d.z + 1u;
         // ---- chain links: the member h further on
@@ -778,19 +780,23 @@ __global__ __launch_bounds__(512) void k_bwt_f_super(FwdView v, const uint4* __r
             nxt[i] = (u16)to; cn[i] = (u16)one;
         }
         __syncthreads();
-        // ---- pointer jumping: chain end and chain length of every member
-        for (u32 span = 1; span < n; span <<= 1) {
+        // ---- pointer jumping: chain end and chain length of every member (until no link moves any more)
+        for (u32 span = 1, it = 0; span < n; span <<= 1, it ^= 1) {
             u32 a[ROWS], b[ROWS];
+            bool moved = false;
 #pragma unroll
             for (int r = 0; r < ROWS; r++) {
                 const u32 i = (u32)tid + (u32)r * THREADS;
                 a[r] = 0; b[r] = 0;
-                if (i < n) { const u32 j = nxt[i]; a[r] = nxt[j]; b[r] = (u32)cn[i] + (u32)cn[j]; }
+                if (i < n) { const u32 j = nxt[i]; a[r] = nxt[j]; b[r] = (u32)cn[i] + (u32)cn[j]; moved = moved || (a[r] != j); }
             }
+            if (tid == 0) sMoved[it] = 0;                          // (two flags in turn: the other one may still be read by a slow thread)
             __syncthreads();
+            if (moved) sMoved[it] = 1;
 #pragma unroll
             for (int r = 0; r < ROWS; r++) { const u32 i = (u32)tid + (u32)r * THREADS; if (i < n) { nxt[i] = (u16)a[r]; cn[i] = (u16)b[r]; } }
             __syncthreads();
+            if (!sMoved[it]) break;
         }
         u32 e[ROWS], cc[ROWS], tail[ROWS];
 #pragma unroll
@@ -833,19 +839,29 @@ __global__ __launch_bounds__(512) void k_bwt_f_super(FwdView v, const uint4* __r
             trEnd[L.oV[j]] = (u16)lo;
         }
         __syncthreads();
-        // ---- one sort of all members on (hi, rank of the end's key)
+        // ---- one sort of all members on (hi, rank of the end's key); the key is as wide as the longest chain and the number of ends ask for
+        {
+            u32 cm = 0;
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) cm = cc[r] > cm ? cc[r] : cm;
+            cm = wave_max(cm);
+            if (lane == 0 && cm) atomicMax(&sCmax, cm);
+        }
+        __syncthreads();
+        const u32 cmax = sCmax;
+        const u32 trBits = bitlen_u32(nEnds ? nEnds - 1 : 0), hiBits = bitlen_u32(2u * cmax + 1u);
         u32 fk[ROWS];
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {
             const u32 i = (u32)tid + (u32)r * THREADS;
             fk[r] = 0;
-            if (i < n) { const u32 hiKey = (tail[r] < m) ? cc[r] : (2u * CAP - cc[r]); fk[r] = (hiKey << 13) | (u32)trEnd[e[r]]; }
+            if (i < n) { const u32 hiKey = (tail[r] < m) ? cc[r] : (2u * cmax + 1u - cc[r]); fk[r] = (hiKey << trBits) | (u32)trEnd[e[r]]; }
         }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < ROWS; r++) { const u32 i = (u32)tid + (u32)r * THREADS; if (i < n) { L.oK[i] = fk[r]; L.oV[i] = i; } }
         __syncthreads();
-        med_radix_sort<THREADS, ROWS>(L, n, 4);
+        med_radix_sort<THREADS, ROWS>(L, n, (int)((hiBits + trBits + 7) / 8));
         {
             u32 p[ROWS];
 #pragma unroll
@@ -1530,7 +1546,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
               hipLaunchKernelGGL((k_bwt_f_sort_medium<256, 8>), gridM, dim3(256), 0, s, v, w.medSorted, nMed, npass, SM_G, w.med[nxt], w.large[nxt], w.descInfo, sup);
               hipLaunchKernelGGL((k_bwt_f_sort_medium<512, 16>), gridM, dim3(512), 0, s, v, w.medSorted, nMed, npass, 2048u, w.med[nxt], w.large[nxt], w.descInfo, sup); }
             // groups whose majority looks at the group itself (sort_medium has listed them; the kernel reads the count itself)
-            if (sup) { KScope ks_("k_bwt_f_super"); hipLaunchKernelGGL(k_bwt_f_super, dim3(std::min<u32>(nMed, 512)), dim3(512), 0, s, v, sup, h, npass, w.med[nxt], w.large[nxt]); }
+            if (sup) { KScope ks_("k_bwt_f_super"); hipLaunchKernelGGL(k_bwt_f_super, dim3(std::min<u32>(nMed, 512)), dim3(1024), 0, s, v, sup, h, npass, w.med[nxt], w.large[nxt]); }
         }
         if (nLarge) {
             u32* k32a = reinterpret_cast<u32*>(lkA); u32* k32b = reinterpret_cast<u32*>(lkB);
