@@ -51,15 +51,15 @@ STAGE_PREFIXES = [
     ("k_mtf_f", "mtft_forward"), ("k_mtf_i", "mtft_inverse"),
     ("k_zrlt_f", "zrlt_forward"), ("k_zrlt_i", "zrlt_inverse"), ("k_zero_dst", "zrlt_inverse"),
     ("k_srt_f", "srt_forward"), ("k_srt_zero", "srt_forward"), ("k_srt_i", "srt_inverse"),
-    ("k_lz_inverse", "lz_inverse"), ("k_lz", "lz_forward"), ("rocprim_lz", "lz_forward"),
+    ("k_lz_inverse", "lz_inverse"), ("k_lz", "lz_forward"),
     ("k_ans0_stats", "ans0_encode"), ("k_ans0_encode", "ans0_encode"),
     ("k_ans0_scan", "ans0_decode"), ("k_ans0_decode", "ans0_decode"),
     ("k_ans1_hist", "ans1_encode"), ("k_ans1_ctx", "ans1_encode"), ("k_ans1_encode", "ans1_encode"),
     ("k_ans1_scan", "ans1_decode"), ("k_ans1_tables", "ans1_decode"), ("k_ans1_decode", "ans1_decode"),
     ("k_huff_encode", "huffman_encode"), ("k_huff_scan", "huffman_decode"), ("k_huff_decode", "huffman_decode"),
-    ("k_fpaq_e", "fpaq_encode"), ("k_fpaq_d", "fpaq_decode"),
+    ("k_fpaq_probs", "fpaq_encode"), ("k_fpaq_code", "fpaq_encode"), ("k_fpaq_e", "fpaq_encode"), ("k_fpaq_d", "fpaq_decode"),
     ("k_block_sum", "bit_assembly"), ("k_block_scan", "bit_assembly"), ("k_assemble", "bit_assembly"),
-    ("memset_out", "bit_assembly"), ("k_put_prologue", "bit_assembly"),
+    ("memset_out", "bit_assembly"), ("k_put_prologue", "bit_assembly"), ("k_shift_bits", "bit_assembly"),
     ("k_walk_blocks", "framing_walk"), ("k_check_prelen", "framing_walk"),
 ]
 
@@ -110,11 +110,16 @@ def cpu_baseline(data, n_sample, cfg, cores):
                                          C.POINTER(C.c_size_t), u8p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         jobs = max(1, min(cores, 64, nblocks))
         clen, te, td = C.c_size_t(0), C.c_double(0), C.c_double(0)
-        rc = L.ref_time_roundtrip(src.ctypes.data_as(u8p), n_sample, cfg["transform"].encode(), cfg["entropy"].encode(), bs, jobs,
-                                  comp.ctypes.data_as(u8p), comp.size, C.byref(clen), back.ctypes.data_as(u8p), C.byref(te), C.byref(td))
-        if rc != 0:
-            raise RuntimeError("reference round trip failed: %d" % rc)
-        kind, t_enc, t_dec = "reference", te.value, td.value
+        best = None
+        for _ in range(3 if n_sample <= (512 << 20) else 1):          # best of 3, BASELINE.md's own method
+            rc = L.ref_time_roundtrip(src.ctypes.data_as(u8p), n_sample, cfg["transform"].encode(), cfg["entropy"].encode(), bs, jobs,
+                                      comp.ctypes.data_as(u8p), comp.size, C.byref(clen), back.ctypes.data_as(u8p), C.byref(te), C.byref(td))
+            if rc != 0:
+                raise RuntimeError("reference round trip failed: %d" % rc)
+            if best is None or te.value + td.value < best[0] + best[1]:
+                best = (te.value, td.value)
+        info = ", best of 3 runs" if n_sample <= (512 << 20) else ""
+        kind, t_enc, t_dec = "reference", best[0], best[1]
         enc = comp[:clen.value].tobytes()
     else:
         # Clean checkout without the reference build: the C restatement (oracle/), one independent stream per block on
@@ -378,7 +383,8 @@ def main():
                  "timing runs every launch of a step back to back on one stream, while the timed steps (value, enc_MBps, dec_MBps, pipeline) run the "
                  "BWT stages of a batch in 3 parts on 3 streams (KNZ_BWT_SPLIT), so the stage times add up to more than ms_per_step",
             dominant_kernel=dict(name=dk_name.split("@")[0], avg_ms=round(dk["ms_per_step"] / dk["launches_per_step"], 4),
-                                 launches_per_step=round(dk["launches_per_step"], 1), ms_per_step=round(dk["ms_per_step"], 4)),
+                                 launches_per_step=round(dk["launches_per_step"], 1), ms_per_step=round(dk["ms_per_step"], 4),
+                                 library=None),       # every launch of the pipeline is a kernel of this repository (no rocPRIM / hipCUB since round 3)
             pipeline=dict(algorithmic_bytes=pipe_bytes, ms=round(step_ms, 4), achieved=round(pipe_bytes / (step_ms * 1e-3) / 1e9, 2),
                           frac=round(pipe_bytes / (step_ms * 1e-3) / 1e9 / 8000.0, 5),
                           note="2*(N + C): uncompressed read + compressed write per direction, over encode + decode"),

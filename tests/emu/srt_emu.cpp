@@ -5,5 +5,5 @@
 #define XF_TTYPE 13
 #define XF_FWD(st) launch_srt_forward(nullptr,st)
 #define XF_INV(st) launch_srt_inverse(nullptr,st)
-#define XF_SCRATCH_U32(nb, ml) ((size_t)0)
+#define XF_SCRATCH_U32(nb, ml) knz::srt_scratch_u32(nb, ml)
 #include "xf_harness.hpp"

@@ -30,6 +30,15 @@ for s in "$@"; do
           [ -n "$ff" ] && [ -n "$fw" ] && python tools/pmc_stage_summary.py $ff $fw 3 $OUT/pmc3_traffic.json $OUT/pmc3_traffic.txt && cat $OUT/pmc3_traffic.txt | head -40 ;;
     trace3) (cd /tmp && export KNZ_BWT_SPLIT=1 && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/trace3 -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu --no-e2e > $GRAFT_REPO_ROOT/$OUT/trace3.log 2>&1); echo "trace3 rc=$?" >> $OUT/summary.txt
            f=$(find $OUT/trace3 -name '*kernel_trace.csv' | head -1); [ -n "$f" ] && python tools/rocprof_trace_list.py $f 1 > $OUT/trace3_bwt_forward.txt && tail -3 $OUT/trace3_bwt_forward.txt ;;
+    prof4) (cd /tmp && export KNZ_BWT_SPLIT=1 && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof4 -- python $GRAFT_REPO_ROOT/bench.py --config 4 --limit 134217728 --steps 1 --warmup 1 --no-cpu --no-e2e > $GRAFT_REPO_ROOT/$OUT/prof4.log 2>&1); echo "prof4 rc=$?" >> $OUT/summary.txt
+           f=$(find $OUT/prof4 -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && python tools/rocprof_csv_summary.py $f > $OUT/prof4_kernel_stats.txt && cp $f $OUT/prof4_kernel_stats.csv && head -14 $OUT/prof4_kernel_stats.txt ;;
+    prof5) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof5 -- python $GRAFT_REPO_ROOT/bench.py --config 5 --steps 1 --warmup 1 --no-cpu --no-e2e > $GRAFT_REPO_ROOT/$OUT/prof5.log 2>&1); echo "prof5 rc=$?" >> $OUT/summary.txt
+           f=$(find $OUT/prof5 -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && python tools/rocprof_csv_summary.py $f > $OUT/prof5_kernel_stats.txt && cp $f $OUT/prof5_kernel_stats.csv && head -14 $OUT/prof5_kernel_stats.txt ;;
+    calib) tools/bin/membench > $OUT/membench.txt 2>&1
+           for c in FETCH_SIZE WRITE_SIZE; do (cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/calib_$c -- $GRAFT_REPO_ROOT/tools/bin/membench pmc > /dev/null 2>&1); echo "calib $c rc=$?" >> $OUT/summary.txt; done
+           ff=$(find $OUT/calib_FETCH_SIZE -name '*counter_collection.csv' | head -1); fw=$(find $OUT/calib_WRITE_SIZE -name '*counter_collection.csv' | head -1)
+           [ -n "$ff" ] && [ -n "$fw" ] && python tools/pmc_calibration.py $ff $fw $OUT/membench.txt > $OUT/pmc_calibration.txt && head -24 $OUT/pmc_calibration.txt ;;
+    limits) for L in 33554432 58720256 109051904 211957760; do timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu --no-e2e --limit $L 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps({'blocks': d['config']['blocks'], 'bytes': d['config']['corpus_bytes'], 'ms_per_step': d['ms_per_step'], 'MBps': d['value'], 'enc_MBps': d['enc_MBps'], 'dec_MBps': d['dec_MBps']}))" >> $OUT/limits.jsonl; done; echo "limits rc=$?" >> $OUT/summary.txt; cat $OUT/limits.jsonl ;;
     cmd:*) echo "running custom: ${s#cmd:}"; timeout 600 bash -c "${s#cmd:}" < /dev/null > $OUT/custom.log 2>&1; echo "custom rc=$?" >> $OUT/summary.txt; tail -40 $OUT/custom.log ;;
     *) echo "unknown step: $s" ;;
   esac
