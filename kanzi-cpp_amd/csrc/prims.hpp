@@ -32,9 +32,9 @@ __device__ __forceinline__ u32 sc_wave_incl(u32 v)
     return v;
 }
 
-// inclusive scan of one value per thread over a workgroup of 256 threads; *total = reduction over the workgroup
-template <int OP>
-__device__ __forceinline__ u32 sc_block_incl(u32 v, u32* wsum /* [4] in LDS */, u32* total)
+// inclusive scan of one value per thread over a workgroup of NW waves; *total = reduction over the workgroup
+template <int OP, int NW = 4>
+__device__ __forceinline__ u32 sc_block_incl(u32 v, u32* wsum /* [NW] in LDS */, u32* total)
 {
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
     const u32 incl = sc_wave_incl<OP>(v);
@@ -43,7 +43,7 @@ __device__ __forceinline__ u32 sc_block_incl(u32 v, u32* wsum /* [4] in LDS */, 
     u32 carry = sc_ident<OP>();
     for (int w = 0; w < wave; w++) carry = sc_op<OP>(carry, wsum[w]);
     u32 tot = sc_ident<OP>();
-    for (int w = 0; w < 4; w++) tot = sc_op<OP>(tot, wsum[w]);
+    for (int w = 0; w < NW; w++) tot = sc_op<OP>(tot, wsum[w]);
     *total = tot;
     __syncthreads();
     return sc_op<OP>(carry, incl);
@@ -166,7 +166,12 @@ static inline void launch_scan(hipStream_t s, const u32* in, u32* out, size_t nM
 // ------------------------------------------------------------------------------------------------
 // radix sort
 // ------------------------------------------------------------------------------------------------
-constexpr u32 RS_TILE = 4096;            // keys per tile: 4 waves x 16 rows of 64
+#ifndef KNZ_RS_WAVES
+#define KNZ_RS_WAVES 4
+#endif
+constexpr int RS_WAVES = KNZ_RS_WAVES;    // waves per workgroup: each owns 16 rows of 64 consecutive keys
+constexpr int RS_THREADS = 64 * RS_WAVES;
+constexpr u32 RS_TILE = 1024u * RS_WAVES; // keys per tile
 constexpr u32 RS_GROUP = 64;             // tiles per group of the column scan
 
 // lanes of the wave whose (valid) 8-bit digit equals mine
@@ -221,15 +226,15 @@ template <class KEY> struct DigitOfKey {
 // update; other rows go through LDS atomics on the wave's private counters (equal digits inside a row serialise, which bounds the cost
 // at the multiplicity of the row's most frequent digit).
 template <class SRC>
-__global__ __launch_bounds__(256) void k_rs_count(SRC src, RsLayout L)
+__global__ __launch_bounds__(RS_THREADS) void k_rs_count(SRC src, RsLayout L)
 {
-    __shared__ u32 cnt[4][256];
+    __shared__ u32 cnt[RS_WAVES][256];
     const int sgm = blockIdx.y;
     const u32 b0 = L.base[sgm], len = L.base[sgm + 1] - b0;
     const u32 nT = (len + RS_TILE - 1) / RS_TILE;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (u32 t = blockIdx.x; t < nT; t += gridDim.x) {
-        for (int w = 0; w < 4; w++) cnt[w][tid] = 0;
+        for (int q = tid; q < RS_WAVES * 256; q += RS_THREADS) (&cnt[0][0])[q] = 0;
         __syncthreads();
         u32 dg[16];
         const u32 i0 = t * RS_TILE + (u32)wave * 1024u + (u32)lane;
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(256) void k_rs_count(SRC src, RsLayout L)
             KNZ_WAVE_ORDER();
         }
         __syncthreads();
-        L.tileHist[((size_t)L.tileOff[sgm] + t) * 256 + tid] = cnt[0][tid] + cnt[1][tid] + cnt[2][tid] + cnt[3][tid];
+        if (tid < 256) { u32 sum = 0; for (int w = 0; w < RS_WAVES; w++) sum += cnt[w][tid]; L.tileHist[((size_t)L.tileOff[sgm] + t) * 256 + tid] = sum; }
         __syncthreads();
     }
 }
@@ -291,7 +296,7 @@ __device__ __forceinline__ void rs_rank_tile(const u32 (&dg)[16], const bool (&v
 {
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    for (int w = 0; w < 4; w++) cnt[w][tid] = 0;
+    for (int q = tid; q < RS_WAVES * 256; q += RS_THREADS) (&cnt[0][0])[q] = 0;
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; r++) {
@@ -304,27 +309,31 @@ __device__ __forceinline__ void rs_rank_tile(const u32 (&dg)[16], const bool (&v
         pos[r] = old + (u32)__popcll(peers & ltMask);
     }
     __syncthreads();
-    // (digit, wave) order: a thread owns a digit
-    const u32 c0 = cnt[0][tid], c1 = cnt[1][tid], c2 = cnt[2][tid], c3 = cnt[3][tid];
+    // (digit, wave) order: the first 256 threads own a digit each
+    u32 c[RS_WAVES];
+    u32 sum = 0;
+    if (tid < 256) { for (int w = 0; w < RS_WAVES; w++) { c[w] = cnt[w][tid]; sum += c[w]; } }
     u32 tot;
-    const u32 incl = sc_block_incl<SCAN_SUM_EXCL>(c0 + c1 + c2 + c3, wsum, &tot);
-    inclAll[tid] = incl;
+    const u32 incl = sc_block_incl<SCAN_SUM_EXCL, RS_WAVES>(sum, wsum, &tot);
+    if (tid < 256) inclAll[tid] = incl;
     __syncthreads();
-    const u32 excl = tid ? inclAll[tid - 1] : 0u;
-    dStart[tid] = excl;
-    cnt[0][tid] = excl; cnt[1][tid] = excl + c0; cnt[2][tid] = excl + c0 + c1; cnt[3][tid] = excl + c0 + c1 + c2;
+    if (tid < 256) {
+        u32 run = tid ? inclAll[tid - 1] : 0u;
+        dStart[tid] = run;
+        for (int w = 0; w < RS_WAVES; w++) { cnt[w][tid] = run; run += c[w]; }
+    }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; r++) if (valid[r]) pos[r] += cnt[wave][dg[r]];
 }
 
 template <class KEY, bool HAS_VAL, class SRC>
-__global__ __launch_bounds__(256) void k_rs_scatter(SRC src, const u32* __restrict__ vin, KEY* __restrict__ kout, u32* __restrict__ vout, RsLayout L)
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(SRC src, const u32* __restrict__ vin, KEY* __restrict__ kout, u32* __restrict__ vout, RsLayout L)
 {
-    __shared__ u32 cnt[4][256];
+    __shared__ u32 cnt[RS_WAVES][256];
     __shared__ u32 dStart[256];
     __shared__ u32 gBase[256];
-    __shared__ u32 wsum[4];
+    __shared__ u32 wsum[RS_WAVES];
     __shared__ u32 inclAll[256];
     __shared__ KEY sK[RS_TILE];
     __shared__ u32 sV[HAS_VAL ? RS_TILE : 1];
@@ -343,14 +352,14 @@ __global__ __launch_bounds__(256) void k_rs_scatter(SRC src, const u32* __restri
             dg[r] = valid[r] ? src.digit(key[r]) : 0u;
         }
         rs_rank_tile(dg, valid, pos, cnt, dStart, wsum, inclAll);
-        gBase[tid] = L.digitBase[sgm * 256 + tid] + L.grpSum[((size_t)L.grpOff[sgm] + t / RS_GROUP) * 256 + tid]
-                     + L.tileHist[((size_t)L.tileOff[sgm] + t) * 256 + tid];
+        if (tid < 256) gBase[tid] = L.digitBase[sgm * 256 + tid] + L.grpSum[((size_t)L.grpOff[sgm] + t / RS_GROUP) * 256 + tid]
+                                    + L.tileHist[((size_t)L.tileOff[sgm] + t) * 256 + tid];
 #pragma unroll
         for (int r = 0; r < 16; r++) if (valid[r]) { sK[pos[r]] = key[r]; if (HAS_VAL) sV[pos[r]] = val[r]; }
         __syncthreads();
         const u32 cntTile = (len - t * RS_TILE < RS_TILE) ? len - t * RS_TILE : RS_TILE;
 #pragma unroll 4
-        for (u32 j = (u32)tid; j < cntTile; j += 256) {
+        for (u32 j = (u32)tid; j < cntTile; j += RS_THREADS) {
             const KEY k = sK[j];
             const u32 d = src.digit(k);
             const u32 at = gBase[d] + (j - dStart[d]);
@@ -406,10 +415,10 @@ static inline void rs_launch_pass(hipStream_t s, const RsWs& w, SRC src, const u
 {
     const dim3 grid(rs_grid_x(maxSegLen, w.L.nSeg), (unsigned)w.L.nSeg);
     const unsigned gx = (unsigned)std::max<size_t>(1, std::min<size_t>(((maxSegLen + RS_TILE - 1) / RS_TILE + RS_GROUP - 1) / RS_GROUP, 1024));
-    hipLaunchKernelGGL((k_rs_count<SRC>), grid, dim3(256), 0, s, src, w.L);
+    hipLaunchKernelGGL((k_rs_count<SRC>), grid, dim3(RS_THREADS), 0, s, src, w.L);
     hipLaunchKernelGGL(k_rs_colscan1, dim3(gx, (unsigned)w.L.nSeg), dim3(256), 0, s, w.L);
     hipLaunchKernelGGL(k_rs_colscan2, dim3((unsigned)w.L.nSeg), dim3(256), 0, s, w.L);
-    hipLaunchKernelGGL((k_rs_scatter<KEY, HAS_VAL, SRC>), grid, dim3(256), 0, s, src, vin, kout, vout, w.L);
+    hipLaunchKernelGGL((k_rs_scatter<KEY, HAS_VAL, SRC>), grid, dim3(RS_THREADS), 0, s, src, vin, kout, vout, w.L);
 }
 
 // Stable LSD sort on key bits [loBit, hiBit). Returns 0 when the result is in (ka, va), 1 when in (kb, vb).
