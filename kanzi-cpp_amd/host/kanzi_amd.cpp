@@ -790,8 +790,8 @@ CompressedOutputStream::CompressedOutputStream(std::ostream& os, int tasks, cons
     _headless = headerless; _closed = false; _headerDone = false;
     // Blocks per device call.  `jobs` only selects the reference's buffer-slot capacities in the bitstream; the
     // GPU wants many blocks per launch and the host wants several batches in flight (one per lane: the caller fills a staging
-    // slot while the lanes work), so by default a batch is 32 MiB (at least one block, at most 64).
-    { const int64_t want = (int64_t(32) << 20) / int64_t(blockSize); _batchBlocks = int(std::min<int64_t>(64, std::max<int64_t>(1, want))); }
+    // slot while the lanes work), so by default a batch is 16 MiB (at least one block, at most 64; measured best with four lanes: short tail, decode batches overlap).
+    { const int64_t want = (int64_t(16) << 20) / int64_t(blockSize); _batchBlocks = int(std::min<int64_t>(64, std::max<int64_t>(1, want))); }
     const char* e = getenv("KNZ_BATCH_BLOCKS");
     if (e && atoi(e) > 0) _batchBlocks = atoi(e);
     // one device call takes at most 2 GiB of input (32-bit positions on the device side)
@@ -1177,7 +1177,7 @@ void CompressedInputStream::prepareBatch(Prep& pr)
     const int64_t lim = (int64_t(1) << 31) / bsz - 1;
     const int wantBatch = _batchBlocks.load();
     int batch = (wantBatch > lim) ? int(lim < 1 ? 1 : lim) : wantBatch;
-    if (!_batchFromEnv.load()) batch = int(std::min<int64_t>(batch, std::max<int64_t>(1, (int64_t(32) << 20) / bsz)));
+    if (!_batchFromEnv.load()) batch = int(std::min<int64_t>(batch, std::max<int64_t>(1, (int64_t(16) << 20) / bsz)));
     while (nb < batch) {
         if (!fetch(size_t(((pos + 40) >> 3) + 1 - (_compBit >> 3)))) {
             if (uint64(_comp.size()) * 8 < pos + 8) { if (nb == 0) throw IOException("Unexpected end of stream", Error::ERR_READ_FILE); break; }
