@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <atomic>
+#include <condition_variable>
 #include <algorithm>
 #include <functional>
 #include <map>
@@ -26,8 +27,43 @@ struct WsBuf { void* p = nullptr; size_t cap = 0; };
 
 struct ProfEntry { std::string name; hipEvent_t a, b; };
 
+// A helper thread of a context that lives as long as the context (the parts of a BWT stage each need a host thread of their own:
+// the suffix sort reads counters back between its rounds). Creating threads per call cost ~0.1 ms each on a 4-block batch.
+struct Helper {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has = false, done = true, quit = false;
+    void loop()
+    {
+        for (;;) {
+            std::function<void()> j;
+            { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return has || quit; }); if (!has) return; j = std::move(job); has = false; }
+            j();
+            { std::lock_guard<std::mutex> l(m); done = true; }
+            cv.notify_all();
+        }
+    }
+    void run(std::function<void()> f)
+    {
+        if (!th.joinable()) th = std::thread(&Helper::loop, this);
+        { std::lock_guard<std::mutex> l(m); job = std::move(f); has = true; done = false; }
+        cv.notify_all();
+    }
+    void wait() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return done; }); }
+    void stop()
+    {
+        if (!th.joinable()) return;
+        { std::lock_guard<std::mutex> l(m); quit = true; }
+        cv.notify_all();
+        th.join();
+    }
+};
+
 struct Ctx {
     int device = 0;
+    Helper helpers[3];
     hipStream_t stream = nullptr;
     bool ownStream = false;
     char err[512] = { 0 };
@@ -164,6 +200,7 @@ void knz_hip_destroy(knz_ctx* ctx)
 {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c) return;
+    for (Helper& h : c->helpers) h.stop();
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     for (auto& kv : c->ws) if (kv.second.p) hipFree(kv.second.p);
@@ -432,7 +469,7 @@ static int bwt_parts_wanted(const Ctx* c, int nBlocks)
 }
 
 static int bwt_in_parts(Ctx* c, hipStream_t s, const XfStage& st, int parts, const std::function<size_t(int)>& scratchBytes,
-                        const std::function<int(hipStream_t, const XfStage&, void*, size_t, u32*)>& launch, const char* what)
+                        const std::function<int(hipStream_t, const XfStage&, void*, size_t, u32*)>& launch, const char* what, bool needThreads)
 {
     static const char* const wsName[4] = { "bwtScratch", "bwtScratch2", "bwtScratch3", "bwtScratch4" };
     XfStage part[4];
@@ -458,14 +495,23 @@ static int bwt_in_parts(Ctx* c, hipStream_t s, const XfStage& st, int parts, con
     HIPCHK(c, hipEventRecord(c->evFork, s));                     // the other streams start behind what is queued on the first
     for (int k = 1; k < parts; k++) HIPCHK(c, hipStreamWaitEvent(c->stream2[k - 1], c->evFork, 0));
     int rc[4] = { 0, 0, 0, 0 };
-    std::thread helper[3];
-    for (int k = 1; k < parts; k++)
-        helper[k - 1] = std::thread([&, k] {
-            if (hipSetDevice(c->device) != hipSuccess) { rc[k] = -1; return; }
-            rc[k] = launch(c->stream2[k - 1], part[k], sc[k], bytes[k], reinterpret_cast<u32*>(c->pinned) + 32768 * k);   // own read-back area (the context's is 1 MiB)
-        });
-    rc[0] = launch(s, part[0], sc[0], bytes[0], reinterpret_cast<u32*>(c->pinned));
-    for (int k = 1; k < parts; k++) helper[k - 1].join();
+    if (!needThreads) {
+        // a stage that never waits for the device (the inverse): the caller's thread queues every part on its stream
+        for (int k = 0; k < parts; k++) rc[k] = launch(k ? c->stream2[k - 1] : s, part[k], sc[k], bytes[k], reinterpret_cast<u32*>(c->pinned) + 32768 * k);
+    } else {
+        try {
+            for (int k = 1; k < parts; k++)
+                c->helpers[k - 1].run([&, k] {
+                    if (hipSetDevice(c->device) != hipSuccess) { rc[k] = -1; return; }
+                    rc[k] = launch(c->stream2[k - 1], part[k], sc[k], bytes[k], reinterpret_cast<u32*>(c->pinned) + 32768 * k);   // own read-back area (the context's is 1 MiB)
+                });
+        } catch (...) {
+            for (int k = 1; k < parts; k++) c->helpers[k - 1].wait();
+            return fail(c, -1, "%s: cannot start a helper thread", what);
+        }
+        rc[0] = launch(s, part[0], sc[0], bytes[0], reinterpret_cast<u32*>(c->pinned));
+        for (int k = 1; k < parts; k++) c->helpers[k - 1].wait();
+    }
     for (int k = 0; k < parts; k++) if (rc[k] != 0) return fail(c, -1, "%s failed: %s", what, hipGetErrorString(hipGetLastError()));
     for (int k = 1; k < parts; k++) {                            // and the first stream continues behind the others
         HIPCHK(c, hipEventRecord(c->evJoin[k - 1], c->stream2[k - 1]));
@@ -493,7 +539,7 @@ static int run_forward_stage(Ctx* c, hipStream_t s, int t, const XfStage& st)
     case KNZ_T_BWT: {
         if (const int parts = bwt_parts_wanted(c, st.nBlocks); parts > 1)
             return bwt_in_parts(c, s, st, parts, [&](int nb) { return bwt_forward_scratch_bytes(nb, st.maxLen, (size_t)nb * st.maxLen); },
-                                 [](hipStream_t q, const XfStage& h, void* sc, size_t bytes, u32* pin) { return launch_bwt_forward(q, h, sc, bytes, pin); }, "BWT forward");
+                                 [](hipStream_t q, const XfStage& h, void* sc, size_t bytes, u32* pin) { return launch_bwt_forward(q, h, sc, bytes, pin); }, "BWT forward", true);
         const size_t bytes = bwt_forward_scratch_bytes(st.nBlocks, st.maxLen, (size_t)st.nBlocks * st.maxLen);
         void* sc;
         if (int r = ws_get(c, "bwtScratch", bytes, &sc)) return r;
@@ -518,7 +564,7 @@ static int run_inverse_stage(Ctx* c, hipStream_t s, int t, const XfStage& st)
     case KNZ_T_BWT: {
         if (const int parts = bwt_parts_wanted(c, st.nBlocks); parts > 1)
             return bwt_in_parts(c, s, st, parts, [&](int nb) { return bwt_inverse_scratch_bytes(nb, st.maxLen, (size_t)nb * st.maxLen); },
-                                 [](hipStream_t q, const XfStage& h, void* sc, size_t bytes, u32* pin) { return launch_bwt_inverse(q, h, sc, bytes, pin); }, "BWT inverse");
+                                 [](hipStream_t q, const XfStage& h, void* sc, size_t bytes, u32* pin) { return launch_bwt_inverse(q, h, sc, bytes, pin); }, "BWT inverse", false);
         const size_t bytes = bwt_inverse_scratch_bytes(st.nBlocks, st.maxLen, (size_t)st.nBlocks * st.maxLen);
         void* sc;
         if (int r = ws_get(c, "bwtScratch", bytes, &sc)) return r;
