@@ -48,6 +48,9 @@ struct FwdView {
     u32* gnew;           // group starts found in the current round; merged into gbits when the round is over (a window must
                          // not see the subgroups a neighbouring window has just made: their keys belong to the old order)
     u32* counters;       // [0] != 0: small groups are left, [1] medium descriptors, [2] large descriptors, [3] members of large groups
+    uint2* medStage;     // medium groups found in the current round, one slot per 256 slots of SA (a medium group has more than 256
+                         // members, so two of them never start in the same 256): written without atomics, compacted -- in slot order --
+                         // into the next round's descriptor list by k_bwt_f_med_compact
 };
 
 __device__ __forceinline__ u32 gather_key(const u32* __restrict__ ISA, u32 gp, u32 h, u32 blkBase, u32 blkEnd)
@@ -63,11 +66,45 @@ __device__ __forceinline__ void classify_child(const FwdView& v, uint2* __restri
         largeNext[at] = make_uint2(start, size);
         atomicAdd(&v.counters[3], size);
     } else if (size > SM_G) {
-        const u32 at = atomicAdd(&v.counters[1], 1u);
-        medNext[at] = make_uint2(start, size);
+        v.medStage[start >> 8] = make_uint2(start, size);
     } else if (size > 1) {
         surv = 1;
     }
+}
+
+// The same through the workgroup: the large / run groups a workgroup finds are counted in LDS first, ONE thread then reserves their
+// places in the lists (one global atomic per list and workgroup instead of one per group), and the descriptors are written at
+// base + local index. Medium groups -- hundreds of thousands after round 0 of a text, where atomics on ONE counter were two thirds
+// of k_bwt_f_r0_place -- use no counter at all: they go to v.medStage (see FwdView).
+struct ClassAgg { u32 cnt[3]; u32 elems[3]; u32 base[3]; };        // 0 medium, 1 large, 2 run groups
+
+__device__ __forceinline__ void agg_init(ClassAgg& A) { if (threadIdx.x < 3) { A.cnt[threadIdx.x] = 0; A.elems[threadIdx.x] = 0; A.base[threadIdx.x] = 0; } }
+
+// kind of the group (-1: small or resolved) and its index among the workgroup's groups of that kind
+__device__ __forceinline__ int agg_note(ClassAgg& A, u32 size, bool run, u32& surv, u32& local)
+{
+    int kind;
+    if (run) kind = 2;
+    else if (size > MED_CAP) kind = 1;
+    else if (size > SM_G) kind = 0;
+    else { if (size > 1) surv = 1; return -1; }
+    if (kind != 0) { local = atomicAdd(&A.cnt[kind], 1u); atomicAdd(&A.elems[kind], size); }
+    return kind;
+}
+
+// one thread, between two barriers
+__device__ __forceinline__ void agg_reserve(ClassAgg& A, const FwdView& v)
+{
+    if (A.cnt[1]) { A.base[1] = atomicAdd(&v.counters[2], A.cnt[1]); atomicAdd(&v.counters[3], A.elems[1]); }
+    if (A.cnt[2]) { A.base[2] = atomicAdd(&v.counters[4], A.cnt[2]); atomicAdd(&v.counters[5], A.elems[2]); }
+}
+
+__device__ __forceinline__ void agg_write(const ClassAgg& A, const FwdView& v, int kind, u32 local, u32 start, u32 size, uint2* __restrict__ largeNext,
+                                          uint2* __restrict__ runList)
+{
+    if (kind == 0) { v.medStage[start >> 8] = make_uint2(start, size); return; }        // (medium groups: no counter at all)
+    uint2* dst = kind == 1 ? largeNext : runList;
+    dst[A.base[kind] + local] = make_uint2(start, size);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -248,10 +285,14 @@ __global__ __launch_bounds__(256) void k_bwt_f_r0_place(FwdView v, const u32* __
 {
     __shared__ SmWindow W;
     __shared__ int sBlk;
+    __shared__ ClassAgg A;
     const int tid = (int)threadIdx.x;
     const u32 win = blockIdx.x;
     const u32 slot0 = win * SM_WIN;
     if (tid == 0) sBlk = find_block(v.base, v.nBlocks, slot0 < v.total ? slot0 : v.total - 1);
+    agg_init(A);
+    int hKind[SM_WIN / 256];
+    u32 hLocal[SM_WIN / 256], hSize[SM_WIN / 256];
     (void)vals;
     if (tid < 64) {
         const u32 w = v.gbits[(slot0 >> 5) + (u32)tid];
@@ -279,6 +320,7 @@ __global__ __launch_bounds__(256) void k_bwt_f_r0_place(FwdView v, const u32* __
     for (int k = 0; k < (int)(SM_WIN / 256); k++) {
         const u32 i = (u32)tid + 256u * (u32)k;
         const u32 a = slot0 + i;
+        hKind[k] = -1; hLocal[k] = 0; hSize[k] = 0;
         if (a >= v.total) continue;
         const u32 w = i >> 5, bit = i & 31;
         const u32 lowmask = (bit == 31) ? 0xFFFFFFFFu : ((2u << bit) - 1u);
@@ -308,16 +350,17 @@ __global__ __launch_bounds__(256) void k_bwt_f_r0_place(FwdView v, const u32* __
                 for (int q = 0; q < nsym; q++) rep = (rep << 8) | (bytes & 0xFF);
                 runGroup = (pos + (u32)nsym <= v.base[blk + 1] - v.base[blk]) && bytes == rep;
             }
-            if (runGroup) {
-                const u32 at = atomicAdd(&v.counters[4], 1u);
-                runList[at] = make_uint2(a, size);
-                atomicAdd(&v.counters[5], size);
-            } else {
-                classify_child(v, medNext, largeNext, a, size, surv);
-            }
+            hSize[k] = size;
+            hKind[k] = agg_note(A, size, runGroup, surv, hLocal[k]);
         }
     }
     if (__ballot(surv != 0) != 0 && (tid & 63) == 0) v.counters[0] = 1;
+    __syncthreads();
+    if (tid == 0) agg_reserve(A, v);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < (int)(SM_WIN / 256); k++)
+        if (hKind[k] >= 0) agg_write(A, v, hKind[k], hLocal[k], slot0 + (u32)tid + 256u * (u32)k, hSize[k], largeNext, runList);
 }
 
 __global__ __launch_bounds__(256) void k_bwt_f_gather_small(FwdView v, u32 h)
@@ -577,7 +620,15 @@ __device__ __noinline__ void med_write_back(MedLds<THREADS, ROWS>& L, const FwdV
     // pm[w] = last boundary at or before the end of word w, pn[w] = first boundary at or after the start of word w
     u32 surv = 0;
     const u32 oldLab = L.oldLab;
-    for (u32 i = (u32)tid; i < n; i += THREADS) {
+    __shared__ ClassAgg A;
+    agg_init(A);
+    __syncthreads();
+    int hKind[ROWS];
+    u32 hLocal[ROWS], hSize[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) hKind[r] = -1;
+    int row = 0;
+    for (u32 i = (u32)tid; i < n; i += THREADS, row++) {
         const u32 w = i >> 5, bit = i & 31;
         const u32 lowmask = (bit == 31) ? 0xFFFFFFFFu : ((2u << bit) - 1u);
         const u32 word = L.fb[w];
@@ -596,9 +647,18 @@ __device__ __noinline__ void med_write_back(MedLds<THREADS, ROWS>& L, const FwdV
         const u32 rel = oldLab - gs;
         const u32 lab = (size <= SM_G) ? gs + hd : ((rel >= hd && rel < e) ? oldLab : gs + hd + (size >> 1));
         if (lab != oldLab) v.ISA[gp] = lab;
-        if (hd == i) classify_child(v, medNext, largeNext, gs + i, size, surv);
+        if (hd == i) {
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) if (r == row) { hSize[r] = size; hKind[r] = agg_note(A, size, false, surv, hLocal[r]); }
+        }
     }
     if (__ballot(surv != 0) != 0 && lane == 0) v.counters[0] = 1;
+    __syncthreads();
+    if (tid == 0) agg_reserve(A, v);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ROWS; r++)
+        if (hKind[r] >= 0) agg_write(A, v, hKind[r], hLocal[r], gs + (u32)tid + (u32)r * THREADS, hSize[r], largeNext, (uint2*)nullptr);
     // new group starts into the round's bit map (bit 0 of the group is set already)
     if (tid < nWords && L.fb[tid]) {
         const u32 off = gs + (u32)tid * 32u;
@@ -932,6 +992,11 @@ __global__ __launch_bounds__(256) void k_bwt_f_large_place(FwdView v, const uint
     u32 surv = 0;
     u32 mySlot = 0;
     bool setBit = false;
+    __shared__ ClassAgg A;
+    agg_init(A);
+    __syncthreads();
+    int hKind = -1;
+    u32 hLocal = 0, hSize = 0;
     if (j < L) {
         const u32 di = (u32)(keys[j] >> kbits);
         const u32 gs = desc[di].x, off = loff[di];
@@ -943,10 +1008,15 @@ __global__ __launch_bounds__(256) void k_bwt_f_large_place(FwdView v, const uint
         if (nh == j) {
             const u32 nxt = (j + 1 < L) ? nextRev[L - 2 - j] : L;
             setBit = (j != off);
-            classify_child(v, medNext, largeNext, mySlot, nxt - j, surv);
+            hSize = nxt - j;
+            hKind = agg_note(A, hSize, false, surv, hLocal);
         }
     }
     if (__ballot(surv != 0) != 0 && (threadIdx.x & 63) == 0) v.counters[0] = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) agg_reserve(A, v);
+    __syncthreads();
+    if (hKind >= 0) agg_write(A, v, hKind, hLocal, mySlot, hSize, largeNext, (uint2*)nullptr);
     // new group starts: the lanes of a wave mostly hold consecutive slots (one group), so their bits are put together with a
     // ballot and leave as at most three word-wide ORs per wave; lanes that are out of line (a group border inside the wave) OR
     // their own bit
@@ -1257,16 +1327,20 @@ __global__ __launch_bounds__(256) void k_bwt_f_emit(BwtView v, const u32* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// the descriptors of a round sorted by start slot, one workgroup (the usual case: a few thousand groups)
-__global__ __launch_bounds__(512) void k_bwt_f_sort_desc_lds(const uint2* __restrict__ in, uint2* __restrict__ out, u32 n, int npass)
+// medium groups of the round that ends: the staging slots in order -> flags, (scan), descriptor list; the slots are cleared for the next round
+__global__ __launch_bounds__(256) void k_bwt_f_med_flags(const uint2* __restrict__ stage, u32 nSlots, u32* __restrict__ flags)
 {
-    __shared__ MedLds<512, 16> L;
-    for (u32 i = threadIdx.x; i < n; i += 512) { const uint2 d = in[i]; L.oK[i] = d.x; L.oV[i] = d.y; }
-    __syncthreads();
-    med_radix_sort<512, 16>(L, n, npass);
-    for (u32 i = threadIdx.x; i < n; i += 512) out[i] = make_uint2(L.oK[i], L.oV[i]);
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nSlots) flags[i] = stage[i].y ? 1u : 0u;
 }
 
+__global__ __launch_bounds__(256) void k_bwt_f_med_compact(uint2* __restrict__ stage, u32 nSlots, const u32* __restrict__ prefix, uint2* __restrict__ medNext)
+{
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nSlots) return;
+    const uint2 d = stage[i];
+    if (d.y) { medNext[prefix[i]] = d; stage[i] = make_uint2(0u, 0u); }
+}
 
 // knobs (tests, tuning): read from the environment once per process, or set through knz_hip_tune()
 struct FwdTuning { int nsym; int noRunRound; int runFallback; int noSuper; };
@@ -1299,7 +1373,7 @@ struct FwdScratch {
     u32* SA; u32* ISA; u32* K;
     u32* t0; u32* t1; u32* t2; u32* t3;
     u32* gbits; u32* gnew; size_t gbitsWords;
-    uint2* med[2]; uint2* medSorted; uint2* descInfo; uint2* large[2]; uint2* runList; uint4* superList; u32* ebits;
+    uint2* med[2]; uint2* medStage; u32* medFlags; u32* medPrefix; size_t medSlots; uint2* descInfo; uint2* large[2]; uint2* runList; uint4* superList; u32* ebits;
     u32* loff;
     u32* base;
     u32* counters;
@@ -1327,7 +1401,9 @@ static size_t fwd_carve(u8* p, int nBlocks, size_t total, FwdScratch* w)
     w->t0 = (u32*)take(4 * total); w->t1 = (u32*)take(4 * total); w->t2 = (u32*)take(4 * total); w->t3 = (u32*)take(4 * total);
     w->gbits = (u32*)take(4 * w->gbitsWords);
     w->gnew = (u32*)take(4 * w->gbitsWords);
-    w->med[0] = (uint2*)take(8 * maxMed); w->med[1] = (uint2*)take(8 * maxMed); w->medSorted = (uint2*)take(8 * maxMed);
+    w->med[0] = (uint2*)take(8 * maxMed); w->med[1] = (uint2*)take(8 * maxMed);
+    w->medSlots = total / 256 + 2;
+    w->medStage = (uint2*)take(8 * w->medSlots); w->medFlags = (u32*)take(4 * w->medSlots + 64); w->medPrefix = (u32*)take(4 * w->medSlots + 64);
     w->large[0] = (uint2*)take(8 * maxLarge); w->large[1] = (uint2*)take(8 * maxLarge);
     w->runList = (uint2*)take(8 * maxMed);
     w->superList = (uint4*)take(16 * maxMed);
@@ -1373,7 +1449,16 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     if (hipStreamSynchronize(s) != hipSuccess) return -1;
     const u32 total = h_pinned[0];
     if (total == 0) return 0;
-    FwdView v; v.base = w.base; v.nBlocks = st.nBlocks; v.total = total; v.SA = w.SA; v.ISA = w.ISA; v.K = w.K; v.gbits = w.gbits; v.gnew = w.gnew; v.counters = w.counters;
+    FwdView v; v.base = w.base; v.nBlocks = st.nBlocks; v.total = total; v.SA = w.SA; v.ISA = w.ISA; v.K = w.K; v.gbits = w.gbits; v.gnew = w.gnew; v.counters = w.counters; v.medStage = w.medStage;
+    const u32 medSlots = (u32)((size_t)total / 256 + 1);
+    hipMemsetAsync(w.medStage, 0, 8ull * w.medSlots, s);
+    // the medium groups staged by the kernels of a round -> descriptor list `dst` (in slot order) and counters[1]
+    auto compactMedium = [&](uint2* dst) {
+        KScope ks_("k_bwt_f_med_compact");
+        hipLaunchKernelGGL(k_bwt_f_med_flags, GRID1(medSlots), w.medStage, medSlots, w.medFlags);
+        prims::launch_scan<prims::SCAN_SUM_EXCL>(s, w.medFlags, w.medPrefix, medSlots, nullptr, w.scanTmp, w.counters + 1);
+        hipLaunchKernelGGL(k_bwt_f_med_compact, GRID1(medSlots), w.medStage, medSlots, w.medPrefix, dst);
+    };
 
     // ---- round 0: the suffixes of every block sorted by their first nsym symbols. Keys = [nsym bytes | position in the block];
     // one stable LSD pass per symbol, the first one reads the text, the blocks are the segments of the sort.
@@ -1421,6 +1506,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     if (hipMemcpyAsync(h_pinned, w.counters, 32, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
     if (hipStreamSynchronize(s) != hipSuccess) return -1;
     u32 nRun = h_pinned[4], runElems = h_pinned[5];
+    bool medCompacted = false;
     const int maxKeyBits = 2 * kbits + 1;
     if (nRun && ((u64)nRun > (1ull << (64 - maxKeyBits)) || tune.runFallback)) {     // (the knob: tests force this path)
         // more run groups than the key has index bits left for (thousands of blocks in one batch): they go the ordinary way
@@ -1490,9 +1576,16 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
         { KScope ks_("k_bwt_f_large_place"); hipLaunchKernelGGL(k_bwt_f_large_place<u64>, GRID1(runElems), v, w.runList, w.loff, runElems, keyBits, rk, rv, w.t1, w.t3,
                                                                 w.med[cur], w.large[cur]); }
         { KScope ks_("k_bwt_f_merge_bits"); hipLaunchKernelGGL(k_bwt_f_merge_bits, GRID1(total / 32 + 2), w.gbits, w.gnew, total / 32 + 2); }
+        compactMedium(w.med[cur]);
+        medCompacted = true;
         if (hipMemcpyAsync(h_pinned, w.counters, 32, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
         if (hipStreamSynchronize(s) != hipSuccess) return -1;
       }
+    }
+    if (!medCompacted) {
+        compactMedium(w.med[cur]);
+        if (hipMemcpyAsync(h_pinned, w.counters, 32, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+        if (hipStreamSynchronize(s) != hipSuccess) return -1;
     }
     u32 surv = h_pinned[0], nMed = h_pinned[1], nLarge = h_pinned[2], largeElems = h_pinned[3];
 #ifdef KNZ_FWD_DEBUG
@@ -1500,8 +1593,6 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
 #endif
 
     const int npass = (kbits + 7) / 8;
-    int sbits = 1;
-    while ((1ull << sbits) < (u64)total + 1) sbits++;
     const u32 nTiles = (total + SM_TS - 1) / SM_TS;
     u32 h = (u32)nsym;
     while (surv || nMed || nLarge) {
@@ -1511,18 +1602,9 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
         // -- all keys first
         if (surv) { KScope ks_("k_bwt_f_gather_small"); hipLaunchKernelGGL(k_bwt_f_gather_small, dim3(nTiles), dim3(256), 0, s, v, h); }
         if (nMed) {
-            // sorted by start slot
-            { KScope ks_("k_bwt_f_sort_desc");
-              if (nMed <= 8192) hipLaunchKernelGGL(k_bwt_f_sort_desc_lds, dim3(1), dim3(512), 0, s, w.med[cur], w.medSorted, nMed, (sbits + 7) / 8);
-              else {
-                  hipLaunchKernelGGL(prims::k_rs_one_segment, dim3(1), dim3(64), 0, s, w.seg2, nMed);
-                  prims::rs_launch_layout(s, rs1);
-                  u64* a = reinterpret_cast<u64*>(w.med[cur]); u64* b = reinterpret_cast<u64*>(w.medSorted);
-                  const int r = prims::rs_sort<u64, false>(s, rs1, a, b, (u32*)nullptr, (u32*)nullptr, (size_t)nMed, 0, ((sbits + 7) / 8) * 8 > 32 ? 32 : ((sbits + 7) / 8) * 8);
-                  if (r == 0) hipMemcpyAsync(w.medSorted, w.med[cur], 8ull * nMed, hipMemcpyDeviceToDevice, s);
-              } }
+            // (the list is in slot order: k_bwt_f_med_compact)
             KScope ks_("k_bwt_f_gather_desc");
-            hipLaunchKernelGGL(k_bwt_f_gather_desc, dim3(256), dim3(1024), 0, s, v, w.medSorted, nMed, h, w.descInfo);
+            hipLaunchKernelGGL(k_bwt_f_gather_desc, dim3(256), dim3(1024), 0, s, v, w.med[cur], nMed, h, w.descInfo);
         }
         int lbits = 0;
         bool small32 = false;
@@ -1543,8 +1625,8 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
             uint4* sup = tune.noSuper ? (uint4*)nullptr : w.superList;
             { KScope ks_("k_bwt_f_sort_medium");
               const dim3 gridM(std::min<u32>(nMed, 8192));
-              hipLaunchKernelGGL((k_bwt_f_sort_medium<256, 8>), gridM, dim3(256), 0, s, v, w.medSorted, nMed, npass, SM_G, w.med[nxt], w.large[nxt], w.descInfo, sup);
-              hipLaunchKernelGGL((k_bwt_f_sort_medium<512, 16>), gridM, dim3(512), 0, s, v, w.medSorted, nMed, npass, 2048u, w.med[nxt], w.large[nxt], w.descInfo, sup); }
+              hipLaunchKernelGGL((k_bwt_f_sort_medium<256, 8>), gridM, dim3(256), 0, s, v, w.med[cur], nMed, npass, SM_G, w.med[nxt], w.large[nxt], w.descInfo, sup);
+              hipLaunchKernelGGL((k_bwt_f_sort_medium<512, 16>), gridM, dim3(512), 0, s, v, w.med[cur], nMed, npass, 2048u, w.med[nxt], w.large[nxt], w.descInfo, sup); }
             // groups whose majority looks at the group itself (sort_medium has listed them; the kernel reads the count itself)
             if (sup) { KScope ks_("k_bwt_f_super"); hipLaunchKernelGGL(k_bwt_f_super, dim3(std::min<u32>(nMed, 512)), dim3(1024), 0, s, v, sup, h, npass, w.med[nxt], w.large[nxt]); }
         }
@@ -1567,6 +1649,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
               else hipLaunchKernelGGL(k_bwt_f_large_place<u64>, GRID1(largeElems), v, w.large[cur], w.loff, largeElems, kbits, sk64, sv, w.t1, w.t3, w.med[nxt], w.large[nxt]); }
         }
         { KScope ks_("k_bwt_f_merge_bits"); hipLaunchKernelGGL(k_bwt_f_merge_bits, GRID1(total / 32 + 2), w.gbits, w.gnew, total / 32 + 2); }
+        compactMedium(w.med[nxt]);
         if (hipMemcpyAsync(h_pinned, w.counters, 32, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
         if (hipStreamSynchronize(s) != hipSuccess) return -1;
         surv = h_pinned[0]; nMed = h_pinned[1]; nLarge = h_pinned[2]; largeElems = h_pinned[3];
