@@ -179,17 +179,17 @@ __global__ __launch_bounds__(256) void k_bwt_f_r0_flags(const u64* __restrict__ 
     __syncthreads();
     const u32 a = a0 + threadIdx.x;
     bool f = true;
+    // the left neighbour's key comes from the lane next door (lane 0 of a wave loads it)
+    const u64 k = (a < total) ? keys[a] : 0ull;
+    u32 klo = (u32)__shfl_up((int)(u32)k, 1u, 64), khi = (u32)__shfl_up((int)(u32)(k >> 32), 1u, 64);
+    u64 kp = ((u64)khi << 32) | klo;
+    if ((threadIdx.x & 63) == 0 && a > 0 && a < total) kp = keys[a - 1];
     if (a < total) {
         int b = sBlk;
         while (a >= base[b + 1]) b++;
         const u32 bb = base[b], n = base[b + 1] - bb;
         const u64 pm = (1ull << pbits) - 1ull;
-        const u64 k = keys[a];
-        f = (a == bb);
-        if (!f) {
-            const u64 kp = keys[a - 1];
-            f = ((k >> pbits) != (kp >> pbits)) || ((u32)(k & pm) + (u32)P > n) || ((u32)(kp & pm) + (u32)P > n);
-        }
+        f = (a == bb) || ((k >> pbits) != (kp >> pbits)) || ((u32)(k & pm) + (u32)P > n) || ((u32)(kp & pm) + (u32)P > n);
     }
     const unsigned long long m = __ballot(f);
     if ((threadIdx.x & 63) == 0) gbits64[a >> 6] = m;
