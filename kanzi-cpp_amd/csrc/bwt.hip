@@ -131,13 +131,17 @@ __global__ __launch_bounds__(256) void k_bwt_i_hist(BwtView v, const BwtHdr* __r
     cnt[tid] = 0;
     __syncthreads();
     const u8* s = v.src[b] + h.hdr;
-#pragma unroll 4
+    // a row of 64 symbols that shows one symbol (a run of the BWT) costs one update, other rows go through LDS atomics
+    u32 sy[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) { const u32 i = t0 + (u32)wave * 1024u + (u32)r * 64u + (u32)lane; sy[r] = (i < h.n) ? (u32)s[i] : 0xFFFFFFFFu; }
+#pragma unroll
     for (int r = 0; r < 16; r++) {
-        const u32 i = t0 + (u32)wave * 1024u + (u32)r * 64u + (u32)lane;
-        const bool valid = i < h.n;
-        const u32 sym = valid ? s[i] : 0u;
-        const unsigned long long peers = sym_peers(valid, sym);
-        if (valid && lane == __ffsll((long long)peers) - 1) atomicAdd(&cnt[sym], (u32)__popcll(peers));
+        const bool valid = sy[r] != 0xFFFFFFFFu;
+        const u32 s0 = (u32)__builtin_amdgcn_readfirstlane((int)sy[r]);
+        const unsigned long long va = __ballot(valid);
+        if (__ballot(valid && sy[r] != s0) == 0) { if (lane == 0 && va) atomicAdd(&cnt[s0], (u32)__popcll(va)); }
+        else if (valid) atomicAdd(&cnt[sy[r]], 1u);
     }
     __syncthreads();
     tileHist[((size_t)b * perTiles + blockIdx.x) * 256 + tid] = cnt[tid];
@@ -286,15 +290,19 @@ __device__ __forceinline__ u32 split_rank(const u32* __restrict__ bits, const u3
 constexpr u32 ROW = 128;            // bytes of one row of symbols (sub-lists have 64 nodes on average, 13 % are longer than a row)
 
 // the walk: sub-list length, successor row and the symbols of the sub-list, one thread per splitter
-__global__ __launch_bounds__(256) void k_bwt_i_walk(const u64* __restrict__ rec, u32* __restrict__ rowNode, const u32* __restrict__ bits,
+__global__ __launch_bounds__(256) void k_bwt_i_walk(const u64* __restrict__ rec, const u32* __restrict__ rowNode, const u32* __restrict__ bits,
                                                     const u32* __restrict__ wprefix, InvInfo* __restrict__ info, u32 maxRows, u32* __restrict__ succ,
-                                                    u32* __restrict__ dist, u8* __restrict__ rowLen, u8* __restrict__ rows)
+                                                    u32* __restrict__ dist, u8* __restrict__ rowLen, u8* __restrict__ rows, const u32* __restrict__ base,
+                                                    int nBlocks, u32* __restrict__ rowBlk)
 {
     const u32 c = blockIdx.x * 256 + threadIdx.x;
     const u32 count = info->count;
     if (c >= count || c >= maxRows) return;
     u32 node = rowNode[c];
     u64 r = rec[node];
+    // a chain never leaves its block: the block of every row this thread fills, looked up once (the copy kernel needs it per row)
+    const u32 blk = (u32)find_block(base, nBlocks, node);
+    rowBlk[c] = blk;
     if (((u32)r & 0x7FFFFFFFu) == node) {                        // terminal: the last byte of the text
         succ[c] = c; dist[c] = 0; rowLen[c] = 1; rows[(size_t)c * ROW] = (u8)(r >> 32);
         return;
@@ -323,7 +331,7 @@ __global__ __launch_bounds__(256) void k_bwt_i_walk(const u64* __restrict__ rec,
         const u32 id = count + atomicAdd(&info->dyn, 1u);
         if (id >= maxRows) { succ[cur] = cur; break; }
         succ[cur] = id;
-        rowNode[id] = nx;
+        rowBlk[id] = blk;
         cur = id;
         node = nx;
         r = rec[node];
@@ -343,7 +351,7 @@ __global__ __launch_bounds__(256) void k_bwt_i_jump(const u32* __restrict__ next
 }
 
 // every row to its place: 32 lanes per row, a lane makes one aligned dword of the output from two aligned dwords of the row
-__global__ __launch_bounds__(256) void k_bwt_i_place(BwtView v, const BwtHdr* __restrict__ hd, const u32* __restrict__ base, const u32* __restrict__ rowNode,
+__global__ __launch_bounds__(256) void k_bwt_i_place(BwtView v, const BwtHdr* __restrict__ hd, const u32* __restrict__ rowBlk,
                                                      const u32* __restrict__ dEnd, const u8* __restrict__ rowLen, const u8* __restrict__ rows,
                                                      const InvInfo* __restrict__ info, u32 maxRows)
 {
@@ -352,7 +360,7 @@ __global__ __launch_bounds__(256) void k_bwt_i_place(BwtView v, const BwtHdr* __
     u32 rowsTotal = info->count + info->dyn;
     if (rowsTotal > maxRows) rowsTotal = maxRows;
     if (c >= rowsTotal) return;
-    const int b = find_block(base, v.nBlocks, rowNode[c]);
+    const int b = (int)rowBlk[c];
     const u32 n = hd[b].n;
     const u32 d = dEnd[c];
     u32 len = rowLen[c];
@@ -389,7 +397,7 @@ __global__ void k_bwt_i_tiny(BwtView v, const BwtHdr* __restrict__ hd)
 // scratch layout, shared by the size query and the launch
 struct InvScratch {
     u32* tileHist; u32* segSum; u32* Cb; u32* term; u64* rec; u32* bits; u32* wcount; u32* wprefix;
-    u32* rowNode; u32* nA; u32* nB; u32* dA; u32* dB; u8* rowLen; u8* rows;
+    u32* rowNode; u32* rowBlk; u32* nA; u32* nB; u32* dA; u32* dB; u8* rowLen; u8* rows;
     BwtHdr* hd; u32* base; InvInfo* info; void* scanTmp;
     u32 maxRows; int perTiles; u32 segT, nSeg;
 };
@@ -412,6 +420,7 @@ static size_t inv_carve(u8* p, int nBlocks, u32 VS, size_t maxTotal, InvScratch*
     w->rec = (u64*)take(8 * maxTotal);
     w->bits = (u32*)take(4 * nWordsMax); w->wcount = (u32*)take(4 * nWordsMax); w->wprefix = (u32*)take(4 * nWordsMax);
     w->rowNode = (u32*)take(4 * maxRows);
+    w->rowBlk = (u32*)take(4 * maxRows);
     w->nA = (u32*)take(4 * maxRows); w->nB = (u32*)take(4 * maxRows);
     w->dA = (u32*)take(4 * maxRows); w->dB = (u32*)take(4 * maxRows);
     w->rowLen = (u8*)take(maxRows);
@@ -452,7 +461,7 @@ int launch_bwt_inverse(hipStream_t s, const XfStage& st, void* scratch, size_t s
     { KScope ks_("k_bwt_i_scan_words"); prims::launch_scan<prims::SCAN_SUM_EXCL>(s, w.wcount, w.wprefix, nWordsMax, &w.info->nWords, w.scanTmp, &w.info->count); }
     { KScope ks_("k_bwt_i_compact"); hipLaunchKernelGGL(k_bwt_i_compact, GRID1(nWordsMax), w.bits, w.wprefix, w.info, w.maxRows, w.rowNode); }
     const u32 maxCount = (u32)(maxTotal / 48 + 4096 + 3 * (size_t)st.nBlocks);
-    { KScope ks_("k_bwt_i_walk"); hipLaunchKernelGGL(k_bwt_i_walk, GRID1(maxCount), w.rec, w.rowNode, w.bits, w.wprefix, w.info, w.maxRows, w.nA, w.dA, w.rowLen, w.rows); }
+    { KScope ks_("k_bwt_i_walk"); hipLaunchKernelGGL(k_bwt_i_walk, GRID1(maxCount), w.rec, w.rowNode, w.bits, w.wprefix, w.info, w.maxRows, w.nA, w.dA, w.rowLen, w.rows, w.base, st.nBlocks, w.rowBlk); }
     u32* nA = w.nA; u32* nB = w.nB; u32* dA = w.dA; u32* dB = w.dB;
     // chains never leave a block: a chain has at most rows-per-block rows
     const u64 chainRows = (u64)v.VS / 48 + (u64)v.VS / ROW + 4096 + 3;
@@ -460,7 +469,7 @@ int launch_bwt_inverse(hipStream_t s, const XfStage& st, void* scratch, size_t s
         { KScope ks_("k_bwt_i_jump"); hipLaunchKernelGGL(k_bwt_i_jump, GRID1(w.maxRows), nA, dA, w.info, w.maxRows, nB, dB); }
         std::swap(nA, nB); std::swap(dA, dB);
     }
-    { KScope ks_("k_bwt_i_place"); hipLaunchKernelGGL(k_bwt_i_place, dim3((w.maxRows + 7) / 8), dim3(256), 0, s, v, w.hd, w.base, w.rowNode, dA, w.rowLen, w.rows, w.info, w.maxRows); }
+    { KScope ks_("k_bwt_i_place"); hipLaunchKernelGGL(k_bwt_i_place, dim3((w.maxRows + 7) / 8), dim3(256), 0, s, v, w.hd, w.rowBlk, dA, w.rowLen, w.rows, w.info, w.maxRows); }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
