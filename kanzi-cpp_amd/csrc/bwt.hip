@@ -246,13 +246,14 @@ __global__ __launch_bounds__(256) void k_bwt_i_links(BwtView v, const BwtHdr* __
 
 // splitter flags from the node number alone, as a bit map: a thread makes the word of 32 nodes and its population count
 __global__ __launch_bounds__(256) void k_bwt_i_flags(const BwtHdr* __restrict__ hd, const u32* __restrict__ base, const u32* __restrict__ term, int nBlocks,
-                                                     const InvInfo* __restrict__ info, u32* __restrict__ bits, u32* __restrict__ wcount)
+                                                     const InvInfo* __restrict__ info, u32* __restrict__ bits, u32* __restrict__ wcount, u32* __restrict__ wblk)
 {
     const u32 w = blockIdx.x * 256 + threadIdx.x;
     const u32 j0 = 32u * w;
     const u32 total = info->total;
     if (j0 >= total) return;
     int b = find_block(base, nBlocks, j0);
+    wblk[w] = (u32)b;                                            // block of the word's first node (the walk starts its search there)
     u32 be = base[b + 1], head = base[b] + hd[b].pIdx - 1, tm = term[b];
     u32 word = 0;
     for (u32 k = 0; k < 32; k++) {
@@ -293,7 +294,7 @@ constexpr u32 ROW = 128;            // bytes of one row of symbols (sub-lists ha
 __global__ __launch_bounds__(256) void k_bwt_i_walk(const u64* __restrict__ rec, const u32* __restrict__ rowNode, const u32* __restrict__ bits,
                                                     const u32* __restrict__ wprefix, InvInfo* __restrict__ info, u32 maxRows, u32* __restrict__ succ,
                                                     u32* __restrict__ dist, u8* __restrict__ rowLen, u8* __restrict__ rows, const u32* __restrict__ base,
-                                                    int nBlocks, u32* __restrict__ rowBlk)
+                                                    int nBlocks, u32* __restrict__ rowBlk, const u32* __restrict__ wblk)
 {
     const u32 c = blockIdx.x * 256 + threadIdx.x;
     const u32 count = info->count;
@@ -301,7 +302,9 @@ __global__ __launch_bounds__(256) void k_bwt_i_walk(const u64* __restrict__ rec,
     u32 node = rowNode[c];
     u64 r = rec[node];
     // a chain never leaves its block: the block of every row this thread fills, looked up once (the copy kernel needs it per row)
-    const u32 blk = (u32)find_block(base, nBlocks, node);
+    u32 blk = wblk[node >> 5];
+    while (node >= base[blk + 1]) blk++;
+    (void)nBlocks;
     rowBlk[c] = blk;
     if (((u32)r & 0x7FFFFFFFu) == node) {                        // terminal: the last byte of the text
         succ[c] = c; dist[c] = 0; rowLen[c] = 1; rows[(size_t)c * ROW] = (u8)(r >> 32);
@@ -396,7 +399,7 @@ __global__ void k_bwt_i_tiny(BwtView v, const BwtHdr* __restrict__ hd)
 
 // scratch layout, shared by the size query and the launch
 struct InvScratch {
-    u32* tileHist; u32* segSum; u32* Cb; u32* term; u64* rec; u32* bits; u32* wcount; u32* wprefix;
+    u32* tileHist; u32* segSum; u32* Cb; u32* term; u64* rec; u32* bits; u32* wcount; u32* wprefix; u32* wblk;
     u32* rowNode; u32* rowBlk; u32* nA; u32* nB; u32* dA; u32* dB; u8* rowLen; u8* rows;
     BwtHdr* hd; u32* base; InvInfo* info; void* scanTmp;
     u32 maxRows; int perTiles; u32 segT, nSeg;
@@ -418,7 +421,7 @@ static size_t inv_carve(u8* p, int nBlocks, u32 VS, size_t maxTotal, InvScratch*
     w->Cb = (u32*)take(4ull * 256 * nBlocks);
     w->term = (u32*)take(4ull * (nBlocks + 1));
     w->rec = (u64*)take(8 * maxTotal);
-    w->bits = (u32*)take(4 * nWordsMax); w->wcount = (u32*)take(4 * nWordsMax); w->wprefix = (u32*)take(4 * nWordsMax);
+    w->bits = (u32*)take(4 * nWordsMax); w->wcount = (u32*)take(4 * nWordsMax); w->wprefix = (u32*)take(4 * nWordsMax); w->wblk = (u32*)take(4 * nWordsMax);
     w->rowNode = (u32*)take(4 * maxRows);
     w->rowBlk = (u32*)take(4 * maxRows);
     w->nA = (u32*)take(4 * maxRows); w->nB = (u32*)take(4 * maxRows);
@@ -457,11 +460,11 @@ int launch_bwt_inverse(hipStream_t s, const XfStage& st, void* scratch, size_t s
       hipLaunchKernelGGL(k_bwt_i_scan2, dim3(st.nBlocks), dim3(256), 0, s, v, w.hd, w.base, nSeg, w.segSum, w.Cb, w.term); }
     { KScope ks_("k_bwt_i_links"); hipLaunchKernelGGL(k_bwt_i_links, gridT, dim3(256), 0, s, v, w.hd, w.base, perTiles, w.tileHist, segT, nSeg, w.segSum, w.Cb, w.term, w.rec); }
     const u32 nWordsMax = (u32)(maxTotal / 32 + 1);
-    { KScope ks_("k_bwt_i_flags"); hipLaunchKernelGGL(k_bwt_i_flags, GRID1(nWordsMax), w.hd, w.base, w.term, st.nBlocks, w.info, w.bits, w.wcount); }
+    { KScope ks_("k_bwt_i_flags"); hipLaunchKernelGGL(k_bwt_i_flags, GRID1(nWordsMax), w.hd, w.base, w.term, st.nBlocks, w.info, w.bits, w.wcount, w.wblk); }
     { KScope ks_("k_bwt_i_scan_words"); prims::launch_scan<prims::SCAN_SUM_EXCL>(s, w.wcount, w.wprefix, nWordsMax, &w.info->nWords, w.scanTmp, &w.info->count); }
     { KScope ks_("k_bwt_i_compact"); hipLaunchKernelGGL(k_bwt_i_compact, GRID1(nWordsMax), w.bits, w.wprefix, w.info, w.maxRows, w.rowNode); }
     const u32 maxCount = (u32)(maxTotal / 48 + 4096 + 3 * (size_t)st.nBlocks);
-    { KScope ks_("k_bwt_i_walk"); hipLaunchKernelGGL(k_bwt_i_walk, GRID1(maxCount), w.rec, w.rowNode, w.bits, w.wprefix, w.info, w.maxRows, w.nA, w.dA, w.rowLen, w.rows, w.base, st.nBlocks, w.rowBlk); }
+    { KScope ks_("k_bwt_i_walk"); hipLaunchKernelGGL(k_bwt_i_walk, GRID1(maxCount), w.rec, w.rowNode, w.bits, w.wprefix, w.info, w.maxRows, w.nA, w.dA, w.rowLen, w.rows, w.base, st.nBlocks, w.rowBlk, w.wblk); }
     u32* nA = w.nA; u32* nB = w.nB; u32* dA = w.dA; u32* dB = w.dB;
     // chains never leave a block: a chain has at most rows-per-block rows
     const u64 chainRows = (u64)v.VS / 48 + (u64)v.VS / ROW + 4096 + 3;
