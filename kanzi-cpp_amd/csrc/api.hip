@@ -73,6 +73,7 @@ struct Ctx {
     void* pinned = nullptr;      // small pinned host scratch
     size_t pinnedCap = 0;
     std::recursive_mutex mu;     // a context is one stream + one set of workspaces: calls on it are serialised
+    std::mutex errMu;            // the last-error string is also written by the copy entry points, which do not take `mu`
     // Copy engine beside the kernels: one stream per direction, outside the lock above, so that a host thread can move the next
     // batch in (or the last one out) while another thread sits in knz_hip_encode_blocks / knz_hip_decode_blocks.
     hipStream_t stream2[3] = { nullptr, nullptr, nullptr };       // further streams for the split of the BWT stages
@@ -87,6 +88,7 @@ struct Ctx {
 
 static int fail(Ctx* c, int code, const char* fmt, ...)
 {
+    std::lock_guard<std::mutex> el(c->errMu);
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(c->err, sizeof(c->err), fmt, ap);
@@ -325,8 +327,12 @@ static int copy_async(Ctx* c, void* dst, const void* src, size_t bytes, bool in,
     hipEvent_t ev;
     if (!c->copyIdle.empty()) { ev = c->copyIdle.back(); c->copyIdle.pop_back(); }
     else HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    if (bytes) HIPCHK(c, hipMemcpyAsync(dst, src, bytes, in ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipEventRecord(ev, st));
+    hipError_t e = bytes ? hipMemcpyAsync(dst, src, bytes, in ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, st) : hipSuccess;
+    if (e == hipSuccess) e = hipEventRecord(ev, st);
+    if (e != hipSuccess) {                                       // the event goes back to the idle list, the caller gets no ticket
+        c->copyIdle.push_back(ev);
+        return fail(c, -1, "asynchronous copy failed: %s", hipGetErrorString(e));
+    }
     *ticket = c->copyNext++;
     c->copyPending[*ticket] = ev;
     return 0;

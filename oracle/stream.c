@@ -508,7 +508,9 @@ int knzo_decode_run(const uint8_t* in, uint64_t inBits, uint64_t startBit, uint6
     int64_t done = 0;
     *endBit = startBit;
     while (maxBlocks < 0 || done < maxBlocks) {
-        if (r.pos + 8 > inBits) break;
+        /* a run (maxBlocks >= 0) may end with the data; a whole stream must end with the end marker, like the reference, which
+         * throws at the end of the input (io/CompressedInputStream.cpp:823-856) */
+        if (r.pos + 8 > inBits) { if (maxBlocks < 0) err = ERR_READ_FILE; break; }
         const unsigned lr = 3 + (unsigned)knzo_br_bits(&r, 5);
         const uint64_t bits = knzo_br_bits(&r, lr);
         if (r.error) { err = ERR_READ_FILE; break; }
