@@ -432,6 +432,81 @@ __global__ __launch_bounds__(256) void k_bwt_f_sort_small(FwdView v)
     if (threadIdx.x < 64 && sNew[threadIdx.x]) atomicOr(&v.gnew[(slot0 >> 5) + threadIdx.x], sNew[threadIdx.x]);
 }
 
+// The small groups of round 0 once more, on the EIGHT TEXT BYTES behind the sorted symbols (zero past the block end): the keys come
+// from the text, which nobody changes, so gathering and sorting are one kernel (no key array, no ordering constraint between
+// windows), and a member pays one random read and one label write for eight symbols of depth where a doubling round at h = 4 buys
+// four. Most small groups of round 0 are resolved here and never enter a doubling round; ties (also: a suffix that ends inside the
+// eight bytes against one that continues with zeros) stay groups and go on as usual.
+__global__ __launch_bounds__(256) void k_bwt_f_sort_small_text(BwtView bv, FwdView v, u32 off)
+{
+    __shared__ SmWindow W;
+    __shared__ int sAny;
+    __shared__ int sBlk;
+    __shared__ u32 sSA[SM_WIN];
+    __shared__ u64 sK[SM_WIN];
+    __shared__ u32 sNew[64];
+    const u32 slot0 = blockIdx.x * SM_TS;
+    if (!sm_load_window(v, slot0, W, &sAny)) return;
+    if (threadIdx.x < 64) sNew[threadIdx.x] = 0;
+    if (threadIdx.x == 64) sBlk = find_block(v.base, v.nBlocks, slot0 < v.total ? slot0 : v.total - 1);
+    __syncthreads();
+    const int b0 = sBlk;
+    u32 gs[SM_WIN / 256], ge[SM_WIN / 256];
+    bool act[SM_WIN / 256];
+#pragma unroll
+    for (int k = 0; k < (int)(SM_WIN / 256); k++) {
+        const u32 i = threadIdx.x + 256u * k;
+        act[k] = sm_group_of(W, i, gs[k], ge[k]);
+        if (!act[k]) continue;
+        const u32 slot = slot0 + i;
+        int b = b0;
+        while (slot >= v.base[b + 1]) b++;
+        const u32 bb = v.base[b], n = v.base[b + 1] - bb;
+        const u32 gp = v.SA[slot];
+        const u32 q = gp - bb + off;
+        const u8* t = bv.src[b];
+        u64 x = 0;
+        if (q + 12 <= n) {
+            const uintptr_t a = reinterpret_cast<uintptr_t>(t + q);
+            const u32* w = reinterpret_cast<const u32*>(a & ~(uintptr_t)3);
+            const u32 sh = (u32)(a & 3) * 8;
+            const u64 lo = (u64)w[0] | ((u64)w[1] << 32);
+            x = sh ? ((lo >> sh) | ((u64)w[2] << (64 - sh))) : lo;
+        } else {
+            for (u32 j = 0; j < 8; j++) if (q + j < n) x |= (u64)t[q + j] << (8 * j);
+        }
+        sSA[i] = gp;
+        sK[i] = __builtin_bswap64(x);
+    }
+    __syncthreads();
+    u32 surv = 0;
+#pragma unroll
+    for (int k = 0; k < (int)(SM_WIN / 256); k++) {
+        if (!act[k]) continue;
+        const u32 i = threadIdx.x + 256u * k;
+        const u64 ki = sK[i];
+        u32 less = 0, eq = 0, eqBefore = 0;
+        for (u32 j = gs[k]; j < ge[k]; j++) {
+            const u64 kj = sK[j];
+            less += (kj < ki) ? 1u : 0u;
+            const u32 same = (kj == ki) ? 1u : 0u;
+            eq += same;
+            eqBefore += (j < i) ? same : 0u;
+        }
+        const u32 gp = sSA[i];
+        const u32 headIdx = gs[k] + less;
+        v.SA[slot0 + headIdx + eqBefore] = gp;
+        if (less != 0) {
+            v.ISA[gp] = slot0 + headIdx;
+            if (eqBefore == 0) atomicOr(&sNew[headIdx >> 5], 1u << (headIdx & 31));
+        }
+        if (eq > 1) surv = 1;
+    }
+    if (__ballot(surv != 0) != 0 && (threadIdx.x & 63) == 0) v.counters[0] = 1;
+    __syncthreads();
+    if (threadIdx.x < 64 && sNew[threadIdx.x]) atomicOr(&v.gnew[(slot0 >> 5) + threadIdx.x], sNew[threadIdx.x]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // medium groups: one workgroup per descriptor
 // ------------------------------------------------------------------------------------------------
@@ -1343,15 +1418,16 @@ __global__ __launch_bounds__(256) void k_bwt_f_med_compact(uint2* __restrict__ s
 }
 
 // knobs (tests, tuning): read from the environment once per process, or set through knz_hip_tune()
-struct FwdTuning { int nsym; int noRunRound; int runFallback; int noSuper; };
+struct FwdTuning { int nsym; int noRunRound; int runFallback; int noSuper; int noTextRound; };
 static FwdTuning& fwd_tuning()
 {
     static FwdTuning t = [] {
-        FwdTuning x; x.nsym = 0; x.noRunRound = 0; x.runFallback = 0; x.noSuper = 0;
+        FwdTuning x; x.nsym = 0; x.noRunRound = 0; x.runFallback = 0; x.noSuper = 0; x.noTextRound = 0;
         if (const char* e = getenv("KNZ_BWT_NSYM")) x.nsym = atoi(e);
         if (getenv("KNZ_BWT_NO_RUN_ROUND")) x.noRunRound = 1;
         if (getenv("KNZ_BWT_RUN_FALLBACK")) x.runFallback = 1;
         if (getenv("KNZ_BWT_NO_SUPER")) x.noSuper = 1;
+        if (getenv("KNZ_BWT_NO_TEXT_ROUND")) x.noTextRound = 1;
         return x;
     }();
     return t;
@@ -1363,6 +1439,7 @@ int bwt_forward_tune(const char* key, int value)
     else if (!strcmp(key, "bwt_no_run_round")) t.noRunRound = value;
     else if (!strcmp(key, "bwt_run_fallback")) t.runFallback = value;
     else if (!strcmp(key, "bwt_no_super")) t.noSuper = value;
+    else if (!strcmp(key, "bwt_no_text_round")) t.noTextRound = value;
     else return -1;
     return 0;
 }
@@ -1506,6 +1583,11 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     const bool runRound = (2 * kbits + 1) < 64 && !tune.noRunRound;
     { KScope ks_("k_bwt_f_r0_place"); hipLaunchKernelGGL(k_bwt_f_r0_place, dim3(nWin), dim3(256), 0, s, v, (const u32*)nullptr, w.t1, w.t3, nWin, w.med[cur], w.large[cur],
                                                          sortedKeys, nsym, pbits, runRound ? w.runList : (uint2*)nullptr); }
+    if (!tune.noTextRound) {
+        const u32 nTiles0 = (total + SM_TS - 1) / SM_TS;
+        { KScope ks_("k_bwt_f_sort_small_text"); hipLaunchKernelGGL(k_bwt_f_sort_small_text, dim3(nTiles0), dim3(256), 0, s, bv, v, (u32)nsym); }
+        { KScope ks_("k_bwt_f_merge_bits"); hipLaunchKernelGGL(k_bwt_f_merge_bits, GRID1(total / 32 + 2), w.gbits, w.gnew, total / 32 + 2); }
+    }
     if (hipMemcpyAsync(h_pinned, w.counters, 32, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
     if (hipStreamSynchronize(s) != hipSuccess) return -1;
     u32 nRun = h_pinned[4], runElems = h_pinned[5];
