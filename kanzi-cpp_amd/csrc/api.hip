@@ -227,6 +227,7 @@ static std::atomic<int>& bwt_split_knob()
 int knz_hip_tune(const char* name, int value)
 {
     if (name == nullptr) return -1;
+    if (!strcmp(name, "mtf_tile")) return mtft_tune(value);
     if (!strcmp(name, "bwt_split")) { bwt_split_knob().store(value < 1 ? 1 : (value > 4 ? 4 : value)); return 0; }
     return bwt_forward_tune(name, value);
 }

@@ -16,10 +16,20 @@
 // O(rank)); many waves per SIMD hide the short dependent chain.
 #include "common.hpp"
 #include "stages.hpp"
+#include <cstdlib>
 
 namespace knz {
 
-constexpr u32 MT = 4096;            // bytes per tile (one wave)
+// bytes per tile (one wave): 4096, or 1024 when the batch has fewer 4 KiB tiles than the device has wave slots -- the tile kernels
+// are one dependent chain per tile, so a small batch finishes in the time of ONE chain and shorter chains are what shortens it
+// (2 blocks of 8 MiB: k_mtf_f_rank 0.82 -> see DESIGN.md)
+static int g_mtfTileKnob = []() { const char* e = getenv("KNZ_MTF_TILE"); return e ? atoi(e) : 0; }();      // 0 = by batch size; 1024 / 4096 force
+int mtft_tune(int tileBytes) { g_mtfTileKnob = (tileBytes == 1024 || tileBytes == 4096) ? tileBytes : 0; return 0; }
+static inline u32 mtf_tile_bytes(int nBlocks, u32 maxLen)
+{
+    if (g_mtfTileKnob) return (u32)g_mtfTileKnob;
+    return ((u64)nBlocks * ((maxLen + 4095) / 4096) < 12288ull) ? 1024u : 4096u;
+}
 
 struct XfView {
     const u8* const* src;
@@ -42,6 +52,7 @@ __device__ __forceinline__ u32 mtf_rotate(u32 w, int lane, int lane0, int byteId
 }
 
 // per tile: last occurrence (position+1) of each symbol -> tileLast[b][t][256]
+template <u32 MT>
 __global__ __launch_bounds__(64) void k_mtf_f_last(XfView v, int perTiles, u32* __restrict__ tileLast)
 {
     const int b = blockIdx.y;
@@ -65,6 +76,7 @@ __global__ __launch_bounds__(64) void k_mtf_f_last(XfView v, int perTiles, u32* 
 // level 2 scans the segment maxima; the consumer (k_mtf_f_rank) takes the maximum of both.
 __host__ __device__ inline u32 mtf_seg_tiles(u32 perTiles) { u32 g = 1; while (g * g < perTiles) g <<= 1; return g; }
 
+template <u32 MT>
 __global__ __launch_bounds__(256) void k_mtf_f_scan(u32* __restrict__ tileLast, int perTiles, u32 segT, u32 nSeg, const u32* __restrict__ lens,
                                                     u32* __restrict__ segMax)
 {
@@ -94,6 +106,7 @@ __global__ __launch_bounds__(256) void k_mtf_f_scan2(u32* __restrict__ segMax, u
     }
 }
 
+template <u32 MT>
 __global__ __launch_bounds__(64) void k_mtf_f_rank(XfView v, int perTiles, const u32* __restrict__ tileState, u32 segT, u32 nSeg,
                                                    const u32* __restrict__ segMax)
 {
@@ -153,11 +166,11 @@ __global__ __launch_bounds__(64) void k_mtf_f_rank(XfView v, int perTiles, const
     if (al && cnt == MT) {
         // full tile: the 4 KiB are loaded up front (16 dwords per lane, coalesced) and handed to the chain with
         // readlane, results are collected the same way and stored coalesced -- no memory latency inside the chain
-        u32 inr[16], outr[16];
+        u32 inr[MT / 256], outr[MT / 256];
 #pragma unroll
-        for (int t = 0; t < 16; t++) inr[t] = reinterpret_cast<const u32*>(src)[64 * t + lane];
+        for (int t = 0; t < (int)(MT / 256); t++) inr[t] = reinterpret_cast<const u32*>(src)[64 * t + lane];
 #pragma unroll
-        for (int t = 0; t < 16; t++) {
+        for (int t = 0; t < (int)(MT / 256); t++) {
             u32 acc = 0;
             for (int l = 0; l < 64; l++) {
                 const u32 o = rank4((u32)__builtin_amdgcn_readlane((int)inr[t], l));
@@ -166,7 +179,7 @@ __global__ __launch_bounds__(64) void k_mtf_f_rank(XfView v, int perTiles, const
             outr[t] = acc;
         }
 #pragma unroll
-        for (int t = 0; t < 16; t++) reinterpret_cast<u32*>(dst)[64 * t + lane] = outr[t];
+        for (int t = 0; t < (int)(MT / 256); t++) reinterpret_cast<u32*>(dst)[64 * t + lane] = outr[t];
         k = MT;
     }
     for (; k + 4 <= cnt; k += 4) {
@@ -196,6 +209,7 @@ __global__ __launch_bounds__(64) void k_mtf_f_rank(XfView v, int perTiles, const
 }
 
 // inverse, pass 1: symbolic decode from the identity list; ids -> dst, final list (ids) -> tilePerm
+template <u32 MT>
 __global__ __launch_bounds__(64) void k_mtf_i_symbolic(XfView v, int perTiles, u8* __restrict__ tilePerm)
 {
     const int b = blockIdx.y;
@@ -231,11 +245,11 @@ __global__ __launch_bounds__(64) void k_mtf_i_symbolic(XfView v, int perTiles, u
     };
     u32 k = 0;
     if (al && cnt == MT) {
-        u32 inr[16], outr[16];
+        u32 inr[MT / 256], outr[MT / 256];
 #pragma unroll
-        for (int t = 0; t < 16; t++) inr[t] = reinterpret_cast<const u32*>(src)[64 * t + lane];
+        for (int t = 0; t < (int)(MT / 256); t++) inr[t] = reinterpret_cast<const u32*>(src)[64 * t + lane];
 #pragma unroll
-        for (int t = 0; t < 16; t++) {
+        for (int t = 0; t < (int)(MT / 256); t++) {
             u32 acc = 0;
             for (int l = 0; l < 64; l++) {
                 const u32 o = ids4((u32)__builtin_amdgcn_readlane((int)inr[t], l));
@@ -244,7 +258,7 @@ __global__ __launch_bounds__(64) void k_mtf_i_symbolic(XfView v, int perTiles, u
             outr[t] = acc;
         }
 #pragma unroll
-        for (int t = 0; t < 16; t++) reinterpret_cast<u32*>(dst)[64 * t + lane] = outr[t];
+        for (int t = 0; t < (int)(MT / 256); t++) reinterpret_cast<u32*>(dst)[64 * t + lane] = outr[t];
         k = MT;
     }
     for (; k + 4 <= cnt; k += 4) {
@@ -275,6 +289,7 @@ __global__ __launch_bounds__(64) void k_mtf_i_symbolic(XfView v, int perTiles, u
 // inverse, pass 2: state before tile t: S_0 = identity, S_{t+1}[j] = S_t[perm_t[j]]. Composition is associative, so it runs in two
 // levels like the forward scan: inside a segment from the identity (L_t, stored in place, and the segment's total in segPerm), then
 // over the segment totals (A_g = state before segment g, in place); the state a tile needs is S_t[j] = A_g[L_t[j]] (pass 3).
+template <u32 MT>
 __global__ __launch_bounds__(256) void k_mtf_i_compose(u8* __restrict__ tilePerm, int perTiles, u32 segT, u32 nSeg, const u32* __restrict__ lens,
                                                        u8* __restrict__ segPerm)
 {
@@ -319,6 +334,7 @@ __global__ __launch_bounds__(256) void k_mtf_i_compose2(u8* __restrict__ segPerm
 }
 
 // inverse, pass 3: resolve ids in place: out[i] = state_tile[id]
+template <u32 MT>
 __global__ __launch_bounds__(256) void k_mtf_i_resolve(XfView v, int perTiles, const u8* __restrict__ tileState, u32 segT, u32 nSeg,
                                                        const u8* __restrict__ segState)
 {
@@ -353,7 +369,8 @@ __global__ void k_copy_ok(const u32* __restrict__ lens, const u32* __restrict__ 
 
 static XfView mk(const XfStage& st) { XfView v; v.src = st.src; v.dst = st.dst; v.len = st.len; v.cap = st.cap; return v; }
 
-void launch_mtft_forward(hipStream_t s, const XfStage& st)
+template <u32 MT>
+static void mtft_forward_t(hipStream_t s, const XfStage& st)
 {
     const XfView v = mk(st);
     const int perTiles = (int)((st.maxLen + MT - 1) / MT);
@@ -362,13 +379,20 @@ void launch_mtft_forward(hipStream_t s, const XfStage& st)
     u32* segMax = tileLast + (size_t)st.nBlocks * perTiles * 256;                  // nBlocks * nSeg * 256
     const dim3 grid(perTiles, st.nBlocks);
     { KScope ks_("k_copy_ok"); hipLaunchKernelGGL(k_copy_ok, dim3((st.nBlocks + 255) / 256), dim3(256), 0, s, st.len, st.cap, st.nBlocks, st.ok, st.newLen); }
-    { KScope ks_("k_mtf_f_last"); hipLaunchKernelGGL(k_mtf_f_last, grid, dim3(64), 0, s, v, perTiles, tileLast); }
-    { KScope ks_("k_mtf_f_scan"); hipLaunchKernelGGL(k_mtf_f_scan, dim3(nSeg, st.nBlocks), dim3(256), 0, s, tileLast, perTiles, segT, nSeg, st.len, segMax);
+    { KScope ks_("k_mtf_f_last"); hipLaunchKernelGGL((k_mtf_f_last<MT>), grid, dim3(64), 0, s, v, perTiles, tileLast); }
+    { KScope ks_("k_mtf_f_scan"); hipLaunchKernelGGL((k_mtf_f_scan<MT>), dim3(nSeg, st.nBlocks), dim3(256), 0, s, tileLast, perTiles, segT, nSeg, st.len, segMax);
       hipLaunchKernelGGL(k_mtf_f_scan2, dim3(st.nBlocks), dim3(256), 0, s, segMax, nSeg); }
-    { KScope ks_("k_mtf_f_rank"); hipLaunchKernelGGL(k_mtf_f_rank, grid, dim3(64), 0, s, v, perTiles, tileLast, segT, nSeg, segMax); }
+    { KScope ks_("k_mtf_f_rank"); hipLaunchKernelGGL((k_mtf_f_rank<MT>), grid, dim3(64), 0, s, v, perTiles, tileLast, segT, nSeg, segMax); }
 }
 
-void launch_mtft_inverse(hipStream_t s, const XfStage& st)
+void launch_mtft_forward(hipStream_t s, const XfStage& st)
+{
+    if (mtf_tile_bytes(st.nBlocks, st.maxLen) == 1024u) mtft_forward_t<1024>(s, st);
+    else mtft_forward_t<4096>(s, st);
+}
+
+template <u32 MT>
+static void mtft_inverse_t(hipStream_t s, const XfStage& st)
 {
     const XfView v = mk(st);
     const int perTiles = (int)((st.maxLen + MT - 1) / MT);
@@ -376,15 +400,22 @@ void launch_mtft_inverse(hipStream_t s, const XfStage& st)
     const u32 segT = mtf_seg_tiles((u32)perTiles), nSeg = ((u32)perTiles + segT - 1) / segT;
     u8* segPerm = tilePerm + (size_t)st.nBlocks * perTiles * 256;                  // nBlocks * nSeg * 256 bytes
     { KScope ks_("k_copy_ok"); hipLaunchKernelGGL(k_copy_ok, dim3((st.nBlocks + 255) / 256), dim3(256), 0, s, st.len, st.cap, st.nBlocks, st.ok, st.newLen); }
-    { KScope ks_("k_mtf_i_symbolic"); hipLaunchKernelGGL(k_mtf_i_symbolic, dim3(perTiles, st.nBlocks), dim3(64), 0, s, v, perTiles, tilePerm); }
-    { KScope ks_("k_mtf_i_compose"); hipLaunchKernelGGL(k_mtf_i_compose, dim3(nSeg, st.nBlocks), dim3(256), 0, s, tilePerm, perTiles, segT, nSeg, st.len, segPerm);
+    { KScope ks_("k_mtf_i_symbolic"); hipLaunchKernelGGL((k_mtf_i_symbolic<MT>), dim3(perTiles, st.nBlocks), dim3(64), 0, s, v, perTiles, tilePerm); }
+    { KScope ks_("k_mtf_i_compose"); hipLaunchKernelGGL((k_mtf_i_compose<MT>), dim3(nSeg, st.nBlocks), dim3(256), 0, s, tilePerm, perTiles, segT, nSeg, st.len, segPerm);
       hipLaunchKernelGGL(k_mtf_i_compose2, dim3(st.nBlocks), dim3(256), 0, s, segPerm, nSeg); }
-    { KScope ks_("k_mtf_i_resolve"); hipLaunchKernelGGL(k_mtf_i_resolve, dim3(perTiles, st.nBlocks), dim3(256), 0, s, v, perTiles, tilePerm, segT, nSeg, segPerm); }
+    { KScope ks_("k_mtf_i_resolve"); hipLaunchKernelGGL((k_mtf_i_resolve<MT>), dim3(perTiles, st.nBlocks), dim3(256), 0, s, v, perTiles, tilePerm, segT, nSeg, segPerm); }
+}
+
+void launch_mtft_inverse(hipStream_t s, const XfStage& st)
+{
+    if (mtf_tile_bytes(st.nBlocks, st.maxLen) == 1024u) mtft_inverse_t<1024>(s, st);
+    else mtft_inverse_t<4096>(s, st);
 }
 
 size_t mtft_scratch_u32(int nBlocks, u32 maxLen)
 {
-    const size_t perTiles = (maxLen + MT - 1) / MT;
+    const u32 MT = mtf_tile_bytes(nBlocks, maxLen);
+    const size_t perTiles = ((size_t)maxLen + MT - 1) / MT;
     const u32 segT = mtf_seg_tiles((u32)perTiles);
     return (size_t)nBlocks * (perTiles + (perTiles + segT - 1) / segT) * 256 + 64;    // tile tables + segment tables
 }

@@ -225,6 +225,24 @@ def test_bwt_round0_key_shapes(hip, oracle):
         hipapi.lib().knz_hip_tune(b"bwt_nsym", 0)
 
 
+def test_mtft_tile_sizes(hip, oracle):
+    """MTFT cuts a block into tiles of 4 KiB, or 1 KiB when the batch is small (shorter dependent chains); both sizes, forced through
+    knz_hip_tune("mtf_tile"), must give the reference's bytes in both directions."""
+    from kanzi_amd import hipapi
+    d = vectors.make(("mixed", 300001, 6))
+    ok1, o1 = oracle.forward("MTFT", d, len(d) + 64, "ANS0")
+    assert ok1
+    try:
+        for tile in (1024, 4096, 0):
+            assert hipapi.lib().knz_hip_tune(b"mtf_tile", tile) == 0
+            ok2, o2 = hip.transform_forward("MTFT", d, len(d) + 64, "ANS0")
+            assert ok2 and o1 == o2, tile
+            ok3, back = hip.transform_inverse("MTFT", o1, len(d))
+            assert ok3 and back == d, tile
+    finally:
+        hipapi.lib().knz_hip_tune(b"mtf_tile", 0)
+
+
 def test_jobs_capacity_model(hip, oracle):
     # the reference's output depends on -j through buffer-slot capacities (SURVEY App. C #1)
     d = vectors.make(("mixed", 700001, 11))
