@@ -7,18 +7,22 @@
 //   SA[r] != 0, 8 primary indexes rank(suffix k*ceil(n/8)) + 1 (BWT.hpp:40-61).
 //
 // GPU formulation: prefix doubling with group refinement (Larsson-Sadakane order refinement, made data parallel).
-//   State in HBM: SA[slot] (global position ids), ISA[position] = first slot of the position's group, and one bit per
-//   slot, gbits, set where a group starts. A position is resolved when its group has one member. Unresolved groups
-//   are refined every round on the key ISA[p + h] (0 past the block end: "shorter sorts first"), h doubling:
-//     * small groups (2..256 members) need no list at all: a kernel sweeps the bit map in windows of 2048 slots, finds
-//       the groups that start in its window and ranks every member by counting inside LDS (less / equal / equal-before),
-//     * medium groups (257..8192) are kept as (start, length) descriptors; one workgroup sorts a group in LDS with a
-//       stable LSD radix sort (8-bit digits, ranking by ballot matching inside a wave, per-wave digit counters),
-//     * large groups go through one global radix sort of (descriptor index, key) pairs (rocPRIM) -- runs of one
-//       symbol are what produces them.
+//   State in HBM: SA[slot] (global position ids), ISA[position] = a label of the position's group (a slot inside the group's range), and
+//   one bit per slot, gbits, set where a group starts. A position is resolved when its group has one member.
+//   Round 0 sorts every block's suffixes on their first 4 symbols with the segmented LSD radix sort of prims.hpp; its first pass reads
+//   the text. Then:
+//     * the small groups once on the next eight text bytes (k_bwt_f_sort_small_text),
+//     * run groups (4 equal symbols) in one round by run length: the runs are sorted, the members follow their runs (k_bwt_f_run_*),
+//   and the doubling rounds, h = 4, 8, 16, ..., refine what is left on the key ISA[p + h] (0 past the block end: "shorter sorts first"):
+//     * small groups (2..256 members) need no list at all: a kernel sweeps the bit map in windows of 2048 slots, finds the groups that
+//       start in its window and ranks every member by counting inside LDS (less / equal / equal-before),
+//     * medium groups (257..8192) are (start, length) descriptors (found through staging slots, no atomics); one workgroup sorts a
+//       group in LDS: majority-key split or a stable LSD radix sort (8-bit digits, ranking by ballot matching inside a wave),
+//     * a group whose majority key is its OWN label (a periodic stretch whose period divides h) is finished in one round by pointer
+//       jumping along its chains (k_bwt_f_super),
+//     * large groups go through one global radix sort of (descriptor index, key) pairs.
 //   Keys are gathered by separate kernels before any kernel of the round moves a position or changes ISA (a refined
 //   head read beside an unrefined one would order two suffixes that are still equal).
-//   Round 0 sorts the first 6 bytes (block id on top, suffix length below) as one 64-bit key with rocPRIM's LSD sort.
 #include "common.hpp"
 #include "stages.hpp"
 #include "bwt_common.hpp"

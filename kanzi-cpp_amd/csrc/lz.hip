@@ -613,7 +613,7 @@ size_t lz_forward_scratch_bytes(int ttype, int nBlocks, u32 maxLen)
     return lz_align(((size_t)G << hl) * 4) + lz_align((size_t)G * 3 * sec) + 7 * lz_align(total * 4) + lz_align(total * 2) + lz_align(prims::rs_ws_bytes(total, 1)) + 512;
 }
 
-// Returns 0 or a negative value on a HIP / rocPRIM error.
+// Returns 0 or a negative value on a HIP error.
 int launch_lz_forward(hipStream_t s, const XfStage& stAll, int ttype, void* scratch, size_t scratchBytes)
 {
     const int hl = (ttype == KNZ_T_LZX) ? 19 : 16;

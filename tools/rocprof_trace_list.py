@@ -6,7 +6,7 @@ occ = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 for r in rows:
     n = r["Kernel_Name"].replace("void ", "").replace("knz::", "")
-    r["Kernel_Name"] = ("rocprim:" + ("onesweep" if "onesweep_iteration" in n else "histogram" if "histogram" in n else "scan" if "scan" in n else "other")) if "rocprim" in n else n.split("(")[0]
+    r["Kernel_Name"] = n.split("(")[0]
 starts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_bwt_bases")]
 ends = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_bwt_f_emit")]
 a, b = starts[occ], ends[occ]
