@@ -457,7 +457,7 @@ static size_t stage_scratch_u32(int t, int nBlocks, u32 maxLen, bool forward = t
     switch (t) {
     case KNZ_T_ZRLT: return zrlt_scratch_u32(nBlocks, maxLen);
     case KNZ_T_MTFT: return mtft_scratch_u32(nBlocks, maxLen);
-    case KNZ_T_SRT: return forward ? srt_scratch_u32(nBlocks, maxLen) : 0;
+    case KNZ_T_SRT: return forward ? srt_scratch_u32(nBlocks, maxLen) : srt_inverse_scratch_u32(nBlocks, maxLen);
     default: return 0;
     }
 }

@@ -84,7 +84,8 @@ size_t fpaq_probs_bytes(int nBlocks, u64 S);
 void launch_fpaq_decode(hipStream_t s, BitSrc src, DecBlock* blocks, int nBlocks, u8* const* outPtr);
 void launch_srt_forward(hipStream_t s, const XfStage& st);          // scratch: srt_scratch_u32(nBlocks, maxLen) words
 size_t srt_scratch_u32(int nBlocks, u32 maxLen);
-void launch_srt_inverse(hipStream_t s, const XfStage& st);
+void launch_srt_inverse(hipStream_t s, const XfStage& st);          // scratch: srt_inverse_scratch_u32(nBlocks, maxLen) words
+size_t srt_inverse_scratch_u32(int nBlocks, u32 maxLen);
 void launch_rlt_forward(hipStream_t s, const XfStage& st);
 void launch_rlt_inverse(hipStream_t s, const XfStage& st);
 

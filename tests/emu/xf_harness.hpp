@@ -1,12 +1,15 @@
 // Shared driver of the transform emulation tests (tests/emu/*_emu.cpp): reads a case file (u32 nBlocks, then per block u32 len +
 // bytes), runs the oracle's forward transform, the kernels' forward (same capacity: same accept / refuse decision, same bytes) and
 // the kernels' inverse of what the oracle produced. The including file defines, before including this header and after including
-// its .hip file:  XF_TTYPE (kanzi transform id), XF_FWD(st), XF_INV(st)  and  XF_SCRATCH_U32(nBlocks, maxLen).
+// its .hip file:  XF_TTYPE (kanzi transform id), XF_FWD(st), XF_INV(st)  and  XF_SCRATCH_U32(nBlocks, maxLen); optionally
+// XF_MALFORM(bytes, len, variant, block) with XF_MALFORM_VARIANTS: damaged copies of the oracle's output go through both inverses,
+// which have to agree on accept / refuse and on every byte of what they accept.
 // Test infrastructure only.
 #include <stdio.h>
 #include <vector>
 
 extern "C" int knzo_transform_forward(int ttype, const uint8_t* src, int n, uint8_t* dst, int dstCap, int etype, int* outLen);
+extern "C" int knzo_transform_inverse(int ttype, const uint8_t* src, int n, uint8_t* dst, int dstCap, int* outLen);
 
 namespace knz { thread_local ProfHook* g_prof = nullptr; }
 
@@ -73,6 +76,33 @@ int main(int argc, char** argv)
             bad++;
         }
     }
+#ifdef XF_MALFORM
+    for (int variant = 0; variant < XF_MALFORM_VARIANTS; variant++) {
+        std::vector<std::vector<u8>> mal(nBlocks), wantBack(nBlocks);
+        std::vector<int> wOk(nBlocks, 0), wLen(nBlocks, 0);
+        for (u32 b = 0; b < nBlocks; b++) {
+            mal[b] = want[b];
+            if (wantOk[b]) XF_MALFORM(mal[b].data(), wantLen[b], variant, (int)b);
+            wantBack[b].assign((size_t)origN[b] + 64, 0xEE);
+            if (wantOk[b]) { int ol = 0; wOk[b] = knzo_transform_inverse(XF_TTYPE, mal[b].data(), wantLen[b], wantBack[b].data(), (int)origN[b], &ol); wLen[b] = wOk[b] ? ol : 0; }
+            std::fill(back[b].begin(), back[b].end(), (u8)0xEE);
+            src[b] = mal[b].data(); dst[b] = back[b].data(); ok[b] = 0; newLen[b] = 0;
+            len[b] = wantOk[b] ? (u32)wantLen[b] : 0;
+            cap[b] = origN[b];
+        }
+        XF_INV(st);
+        for (u32 b = 0; b < nBlocks; b++) {
+            if (!wantOk[b]) continue;
+            const bool same = (ok[b] != 0) == (wOk[b] != 0) && (!wOk[b] || ((int)newLen[b] == wLen[b] && memcmp(back[b].data(), wantBack[b].data(), (size_t)wLen[b]) == 0));
+            if (!same) {
+                size_t at = 0;
+                while (wOk[b] && at < (size_t)wLen[b] && back[b][at] == wantBack[b][at]) at++;
+                printf("FAIL malformed inverse, variant %d block %u (n=%u): ok %d/%d len %u/%d first difference at %zu\n", variant, b, origN[b], ok[b], wOk[b], newLen[b], wLen[b], at);
+                bad++;
+            }
+        }
+    }
+#endif
     printf(bad ? "FAILED %d blocks\n" : "OK %u blocks\n", bad ? bad : nBlocks, nBlocks);
     return bad ? 1 : 0;
 }

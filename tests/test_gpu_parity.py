@@ -145,6 +145,49 @@ def test_transform_stage_golden(hip, golden):
     assert n > 100
 
 
+def test_srt_inverse_of_damaged_blocks(hip, oracle):
+    """SRT.cpp:111-204 checks nothing about the body, so a damaged one decodes to definite bytes: first bucket bytes that make the
+    initial list no permutation, ranks beyond the live part of the list (stale entries come back), ranks for zeros and zeros for ranks.
+    The fast chain (one list entry per lane, queue offsets riding with the symbols) has to notice and hand the block to the general
+    one; accept / refuse and every byte as the oracle."""
+    rng = np.random.default_rng(77)
+    blocks = [vectors.make(("text", 60000, 3)), rng.integers(0, 4, 20000, dtype=np.uint8).tobytes(), b"xy" * 500,
+              vectors.make(("mixed", 300000, 2))[250000:290000], rng.integers(0, 256, 9000, dtype=np.uint8).tobytes()]
+    n = 0
+    for d in blocks:
+        ok, good = oracle.forward("SRT", d, len(d) + 2048, "FPAQ")
+        assert ok
+        at = 0
+        for _ in range(256):                                      # the header: 256 var-ints
+            while good[at] & 0x80:
+                at += 1
+            at += 1
+        for variant in range(12):
+            m = bytearray(good)
+            body = len(m) - at
+            if variant == 0:
+                m[at] = (m[at] + 1) & 0xFF
+            elif variant == 1:
+                m[at] = 200
+            elif variant < 5:
+                for i in rng.integers(1, body, 4):
+                    if m[at + int(i)]:
+                        m[at + int(i)] = int(rng.integers(variant * 60, 256))
+            elif variant < 9:
+                for i in rng.integers(1, body, 1 << (variant - 4)):
+                    m[at + int(i)] = int(rng.integers(0, 7))
+            else:
+                for i in rng.integers(1, body, 30):
+                    m[at + int(i)] = int(rng.integers(0, 256))
+            k1, b1 = oracle.inverse("SRT", bytes(m), len(d))
+            k2, b2 = hip.transform_inverse("SRT", bytes(m), len(d))
+            assert bool(k1) == bool(k2), (len(d), variant)
+            if k1:
+                assert b1 == b2, (len(d), variant)
+            n += 1
+    assert n == 60
+
+
 def test_transform_capacity_semantics(hip, oracle):
     # destination capacity changes results (ZRLT/RLT): src/test/TestTransforms.cpp:371-498,500-757
     rng = np.random.default_rng(5)

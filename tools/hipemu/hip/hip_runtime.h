@@ -65,6 +65,8 @@ void launch(const std::function<void()>& body, dim3 grid, dim3 block);
 void block_barrier();
 // rendezvous of the (live) lanes of the calling fiber's wave: every lane deposits v, gets the array of all 64
 void wave_exchange(unsigned long long v, unsigned long long out[64], unsigned long long* activeMask);
+// the same rendezvous for a wave that polls memory written by another wave of its block: the other waves run before it returns
+void wave_spin();
 
 }  // namespace hipemu
 
@@ -148,6 +150,18 @@ static inline unsigned long long __lanemask_lt() { const int lane = (int)(thread
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 static inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned sh) { return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (sh & 31)); }
+// v_perm_b32: result byte i = byte sel[i] of the 8 bytes {b (0-3), a (4-7)} (the constant selectors 0x0C.. are not used by the kernels)
+static inline unsigned __builtin_amdgcn_perm(unsigned a, unsigned b, unsigned sel)
+{
+    const unsigned long long v = ((unsigned long long)a << 32) | b;
+    unsigned r = 0;
+    for (int i = 0; i < 4; i++) {
+        const unsigned s = (sel >> (8 * i)) & 0xFF;
+        if (s > 7) { fprintf(stderr, "hipemu: v_perm selector 0x%x not emulated\n", s); abort(); }
+        r |= (unsigned)((v >> (8 * s)) & 0xFF) << (8 * i);
+    }
+    return r;
+}
 static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline int __ffsll(long long x) { return __builtin_ffsll(x); }

@@ -34,7 +34,7 @@ static Block g_blk;
 static std::vector<char*> g_stacks;
 
 // per-wave rendezvous state
-struct WaveX { unsigned long long val[64]; unsigned long long arrived; int gen; unsigned long long snapshot[64]; unsigned long long snapMask; };
+struct WaveX { unsigned long long val[64]; unsigned long long arrived; int gen; unsigned long long snapshot[64]; unsigned long long snapMask; bool spin; };
 static std::vector<WaveX> g_wave;
 static int g_barCount, g_barGen;
 
@@ -85,6 +85,15 @@ void wave_exchange(unsigned long long v, unsigned long long out[64], unsigned lo
     *activeMask = w.snapMask;
 }
 
+// a wave that polls memory another wave of the block writes: a rendezvous after which the scheduler moves on to the other waves
+void wave_spin()
+{
+    const int t = (int)(g_blk.cur - &g_blk.fibers[0]);
+    g_wave[t >> 6].spin = true;
+    unsigned long long v[64], act;
+    wave_exchange(0, v, &act);
+}
+
 static void run_block()
 {
     const int n = (int)g_blk.fibers.size();
@@ -126,7 +135,8 @@ static void run_block()
                         w.arrived = 0;
                         w.gen++;
                         for (int l = 0; l < 64; l++) if ((live >> l) & 1) g_blk.fibers[wv * 64 + l].state = 0;
-                        again = true; progress = true;
+                        again = !w.spin; progress = true;
+                        w.spin = false;
                     }
                 }
             }
