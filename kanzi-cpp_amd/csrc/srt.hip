@@ -505,8 +505,9 @@ __device__ __forceinline__ void srt_list_drop(u32 (&a)[4], u32 rank, bool insert
 // (the front's entry then still has the offset's carry in it) or the staging registers are full. Wait states: the SGPRs the VALU
 // writes (v_readlane, v_readfirstlane) are read by SALU instructions or at least two instructions later; the register the DPP move
 // reads was last written five instructions earlier.
-__device__ __forceinline__ u32 srt_hot_runs(u32& a0, u32& outLen, u32& outSym, u32& ec, u32& z, u32& term, u32& remaining, u32& head, u32 lim1, u32 vbase)
+__device__ __forceinline__ u32 srt_hot_runs(u32& a0, u32& outLen, u32& outSym, u32& ec, u32& z, u32& term, u32& remaining, u32& head, u32 lim1, const u64* q)
 {
+    const u32 vbase = (u32)reinterpret_cast<uintptr_t>(q);      // (the low half of a generic LDS address is the LDS offset)
     u32 why, e1, en, t, u, sym, tmp, vaddr;
     u64 mask;
     asm volatile(
@@ -554,6 +555,28 @@ __device__ __forceinline__ u32 srt_hot_runs(u32& a0, u32& outLen, u32& outSym, u
         : "m0", "scc", "v100", "v101", "memory");
     return why;
 }
+#else
+// the same loop for the CPU emulation of tests/emu (it has no assembler): statement for statement what the instructions above do
+__device__ __forceinline__ u32 srt_hot_runs(u32& a0, u32& outLen, u32& outSym, u32& ec, u32& z, u32& term, u32& remaining, u32& head, u32 lim1, const u64* q)
+{
+    for (;;) {
+        const u32 full = z + 1;
+        if (full >= remaining) return 1;
+        if (term - 1u >= lim1) return 1;
+        const u32 e1 = (u32)__builtin_amdgcn_readlane((int)a0, 1);
+        remaining -= full;
+        const u64 rcn = *reinterpret_cast<const u64*>(reinterpret_cast<const char*>(q) + e1);
+        const u32 en = e1 + 8u;
+        a0 = srt_writelane(en, 1u, a0);
+        srt_writelane2(outLen, outSym, full, ec >> 8, head & 63u);
+        head++;
+        const u32 s0 = (u32)__builtin_amdgcn_update_dpp(0, (int)a0, 0x130, 0xF, 0xF, true);
+        a0 = srt_lane_merge(a0, s0, term, true, ec);
+        ec = en;
+        z = (u32)__builtin_amdgcn_readfirstlane((int)(u32)rcn); term = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(rcn >> 32));
+        if ((en & 0x7Fu) == 0 || (head & 63u) == 0) return 2;
+    }
+}
 #endif
 
 __global__ __launch_bounds__(192) void k_srt_inverse(XfStage st, SrtInv w)
@@ -600,12 +623,8 @@ __global__ __launch_bounds__(192) void k_srt_inverse(XfStage st, SrtInv w)
     u32 how = 1;
     bool open = true;                                           // (false: the block is complete, or given up)
     u32 lim1 = (nbSymbols < 64u ? nbSymbols : 64u) - 1u;        // the ranks the short way handles: 1 .. lim1
-#ifndef KNZ_EMU
-    const u32 vbase = (u32)reinterpret_cast<uintptr_t>(L.q);    // (the low half of a generic LDS address is the LDS offset)
-#endif
     if (nbSymbols >= 2) for (;;) {
-#ifndef KNZ_EMU
-        if (srt_hot_runs(a[0], io.outLen, io.outSym, ec, z, term, remaining, io.head, lim1, vbase) == 2u) {
+        if (srt_hot_runs(a[0], io.outLen, io.outSym, ec, z, term, remaining, io.head, lim1, L.q) == 2u) {
             if ((ec & (8u * SRT_QH - 1u)) == 0) {
                 if ((ec & 0xFFu) == 0) ec -= 0x100u;
                 srt_chain_half(L, io, ec >> 8, lane);
@@ -613,7 +632,6 @@ __global__ __launch_bounds__(192) void k_srt_inverse(XfStage st, SrtInv w)
             if ((io.head & 63u) == 0) srt_chain_flush(L, io, 64u, lane);
             continue;
         }
-#endif
         // (the long way, any run.) Whatever this run's record says (the front goes back to a rank >= 1, or leaves the list), the symbol
         // of the NEXT run is the one behind the front now: its record is read first and picked up at the bottom, behind the work on this run.
         u32 en;
