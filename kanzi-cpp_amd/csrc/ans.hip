@@ -248,17 +248,13 @@ __global__ __launch_bounds__(64) void k_ans0_encode(BlockView view, int maxChunk
             step(16 * k + (u32)u, e);
             e = en;
         }
-#ifdef KNZ_EMU
-        (void)__ballot(1);      // the emulation's lanes only meet at wave intrinsics: the ring stores of every lane before the reads below
-#endif
+        KNZ_WAVE_ORDER();       // (the ring stores of every lane before the reads below)
         if (act && q + 128 <= Hi) { flush_line(); Hi -= 128; }
 #pragma unroll
         for (int c = 0; c < 4; c++) cur[c] = nxt[c];
     }
     // remaining staged bytes [q, Hi): 16-bit units, interleaved over the chunk's 4 lanes
-#ifdef KNZ_EMU
-    (void)__ballot(1);
-#endif
+    KNZ_WAVE_ORDER();
     if (act) {
         for (u32 a = q + 2 * (u32)j; a < Hi; a += 8)
             *reinterpret_cast<u16*>(pay + a) = *reinterpret_cast<const u16*>(stg + (a & 255));

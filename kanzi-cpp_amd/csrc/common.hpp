@@ -70,28 +70,6 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 #define KNZ_WAVE_ORDER() ((void)0)
 #endif
 
-#ifdef KNZ_EMU
-// CPU emulation build (tests/emu, tools/hipemu): the same results through the generic lane exchange
-__device__ __forceinline__ u32 wave_incl_scan(u32 v)
-{
-    for (int o = 1; o < 64; o <<= 1) { const u32 t = (u32)__shfl_up((int)v, (unsigned)o, 64); if (lane_id() >= o) v += t; }
-    return v;
-}
-__device__ __forceinline__ u32 wave_sum(u32 v) { return (u32)__shfl((int)wave_incl_scan(v), 63, 64); }
-__device__ __forceinline__ u32 wave_max(u32 v)
-{
-    for (int o = 1; o < 64; o <<= 1) { const u32 t = (u32)__shfl_xor((int)v, o, 64); v = t > v ? t : v; }
-    return v;
-}
-__device__ __forceinline__ u64 wave_incl_scan64(u64 v)
-{
-    for (int o = 1; o < 64; o <<= 1) {
-        const u32 lo = (u32)__shfl_up((int)(u32)v, (unsigned)o, 64), hi = (u32)__shfl_up((int)(u32)(v >> 32), (unsigned)o, 64);
-        if (lane_id() >= o) v += ((u64)hi << 32) | lo;
-    }
-    return v;
-}
-#else
 // Wave64 scans and reductions on the DPP data path (row shifts inside 16-lane rows, then row_bcast15 / row_bcast31
 // to carry across rows): about a dozen VALU instructions, where the ds_bpermute-based __shfl versions pay an LDS
 // round trip per step.
@@ -142,8 +120,6 @@ __device__ __forceinline__ u64 wave_incl_scan64(u64 v)
 #undef KNZ_SCAN64_STEP
     return v;
 }
-
-#endif  // KNZ_EMU
 
 // OR `n` bits (value right-aligned, n <= 32) at bit position `pos` of an MSB-first bit buffer held
 // as 32-bit words in "stream order" (word w holds stream bits [32w, 32w+32), MSB first). LDS or global.

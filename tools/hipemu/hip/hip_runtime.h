@@ -124,18 +124,25 @@ static inline int __shfl_xor(int var, int mask, int width = 64)
     return (int)(unsigned)v[lane ^ mask];
 }
 static inline int __builtin_amdgcn_readlane(int var, int src) { return __shfl(var, src & 63, 64); }
-// DPP data movement, the controls the kernels use: 0x138 = wave_shr:1 (lane i takes lane i-1; lane 0 keeps `old`, bound_ctrl off),
-// 0x00-0xFF = quad_perm (two selector bits per lane of a quad)
+// DPP data movement, the controls the kernels use: 0x130 / 0x138 = wave_shl:1 / wave_shr:1, 0x134 / 0x13C = wave_rol:1 / wave_ror:1,
+// 0x111-0x11F = row_shr:n (inside rows of 16 lanes), 0x142 / 0x143 = row_bcast:15 / row_bcast:31 (lane 15 of a row to the next row,
+// lane 31 to rows 2 and 3), 0x00-0xFF = quad_perm. A lane without a source lane keeps `old` (0 with bound_ctrl); a lane whose row or
+// bank (group of 4 lanes inside its row) is masked out keeps `old`.
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int rowMask, int bankMask, bool boundCtrl)
 {
     unsigned long long v[64], act;
     hipemu::wave_exchange((unsigned long long)(unsigned)src, v, &act);
     const int lane = (int)(threadIdx.x & 63);
-    (void)rowMask; (void)bankMask; (void)boundCtrl;
-    if (ctrl == 0x138) return lane == 0 ? old : (int)(unsigned)v[lane - 1];
-    if (ctrl == 0x130) return lane == 63 ? old : (int)(unsigned)v[lane + 1];       // wave_shl:1
-    if (ctrl == 0x134) return (int)(unsigned)v[(lane + 1) & 63];                   // wave_rol:1
-    if (ctrl == 0x13C) return (int)(unsigned)v[(lane + 63) & 63];                  // wave_ror:1
+    const int row = lane >> 4, inRow = lane & 15;
+    if (!((rowMask >> row) & 1) || !((bankMask >> (inRow >> 2)) & 1)) return old;
+    const int none = boundCtrl ? 0 : old;
+    if (ctrl == 0x138) return lane == 0 ? none : (int)(unsigned)v[lane - 1];
+    if (ctrl == 0x130) return lane == 63 ? none : (int)(unsigned)v[lane + 1];
+    if (ctrl == 0x134) return (int)(unsigned)v[(lane + 1) & 63];
+    if (ctrl == 0x13C) return (int)(unsigned)v[(lane + 63) & 63];
+    if (ctrl > 0x110 && ctrl < 0x120) { const int n = ctrl & 15; return inRow >= n ? (int)(unsigned)v[lane - n] : none; }
+    if (ctrl == 0x142) return row >= 1 ? (int)(unsigned)v[16 * row - 1] : none;
+    if (ctrl == 0x143) return row >= 2 ? (int)(unsigned)v[31] : none;
     if (ctrl >= 0 && ctrl < 0x100) return (int)(unsigned)v[(lane & ~3) + ((ctrl >> (2 * (lane & 3))) & 3)];     // quad_perm
     fprintf(stderr, "hipemu: DPP control 0x%x not emulated\n", ctrl);
     abort();
