@@ -414,6 +414,7 @@ private:
     uint64 _transformType;
     uint64 _outputSize;
     bool _headless, _closed, _headerDone, _ended;
+    int _bsVersion;                               // bitstream version of the stream being read (6 = current; 3..5: see readHeader)
     int _from, _to;               // block range (1-based ids), default everything
     int64 _nextBlockId;           // id of the next block the host walk will meet
     std::atomic<int> _batchBlocks;

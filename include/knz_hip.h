@@ -57,6 +57,13 @@ typedef struct {
     int32_t checksum_bits;
     int32_t jobs;            /* reference job count being reproduced (0/1 = single). It only selects the
                                 buffer slot, hence the capacities, a block sees. */
+    int32_t bs_version;      /* decode only: bitstream version of the stream the blocks come from, as
+                                CompressedInputStream puts it in the Context (io/CompressedInputStream.cpp:528-537).
+                                0 or 6 = current. 3..5 select the old layouts the reference still reads: Huffman chunks
+                                (entropy/HuffmanDecoder.cpp:349-459) and the BWT block header
+                                (transform/BWTBlockCodec.cpp:140-164); LZ / LZX blocks of such streams are refused
+                                (transform/LZCodec.cpp:460-463 has a reader for them, this library does not).
+                                The encoder writes version 6 only, like the reference. */
 } knz_params;
 
 /* Upper bound, in bytes, of the bit-packed output of knz_hip_encode_blocks for n input bytes. */

@@ -803,6 +803,13 @@ static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_
         if (!transform_supported(tok[i])) return fail(c, KNZ_ERR_INVALID_CODEC, "transform id %d not implemented on device", tok[i]);
     if (!entropy_supported(p->entropy_type)) return fail(c, KNZ_ERR_INVALID_CODEC, "entropy id %d not implemented on device", p->entropy_type);
     if (p->checksum_bits != 0 && p->checksum_bits != 32 && p->checksum_bits != 64) return fail(c, KNZ_ERR_INVALID_PARAM, "checksum must be 0, 32 or 64");
+    // bitstream version of the blocks (0 = current). Below 6 the Huffman chunks and the BWT block header have their old layouts; the
+    // old LZ layouts (LZCodec.cpp:460-463) have no reader here
+    const int bsVersion = (p->bs_version == 0) ? 6 : p->bs_version;
+    if (bsVersion < 0 || bsVersion > 6) return fail(c, KNZ_ERR_STREAM_VERSION, "cannot read bitstream version %d", bsVersion);
+    if (bsVersion < 6)
+        for (int i = 0; i < nTok; i++)
+            if (tok[i] == KNZ_T_LZ || tok[i] == KNZ_T_LZX) return fail(c, KNZ_ERR_STREAM_VERSION, "LZ blocks of bitstream version %d are not supported", bsVersion);
     hipStream_t s = c->stream;
 
     BitSrc src;
@@ -864,7 +871,7 @@ static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_
     } else if (p->entropy_type == KNZ_E_HUFFMAN) {
         void* d_meta;
         if (int r = ws_get(c, "hufDecChunks", huffman_dec_chunk_bytes() * nSlots, &d_meta)) return r;
-        launch_huffman_decode(s, src, d_blocks, nBlocks, maxChunks, d_meta, w.d_entDst);
+        launch_huffman_decode(s, src, d_blocks, nBlocks, maxChunks, d_meta, w.d_entDst, bsVersion);
     } else if (p->entropy_type == KNZ_E_FPAQ) {
         launch_fpaq_decode(s, src, d_blocks, nBlocks, w.d_entDst);
     } else {
@@ -880,7 +887,7 @@ static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_
             launch_seq_inv_prepare(s, w.a, d_blocks, nBlocks, i, d_out, outStride, w.A, w.B, S, capMid, capFinal, realMask, framing ? (u64)outCap : ~0ull);
             XfStage st;
             st.src = w.a.src; st.dst = w.a.dst; st.len = w.a.alen; st.cap = w.a.cap; st.ok = w.a.ok; st.newLen = w.a.newLen;
-            st.nBlocks = nBlocks; st.maxLen = (u32)S; st.scratchU32 = w.scratch; st.entropyType = p->entropy_type;
+            st.nBlocks = nBlocks; st.maxLen = (u32)S; st.scratchU32 = w.scratch; st.entropyType = p->entropy_type; st.bsVersion = bsVersion;
             if (int r = run_inverse_stage(c, s, tok[i], st)) return r;
             launch_seq_inv_commit(s, w.a, d_blocks, nBlocks, i, tok[i]);
         }

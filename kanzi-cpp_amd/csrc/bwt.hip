@@ -33,6 +33,7 @@ struct BwtHdr { u32 n; u32 hdr; u32 pIdx; u32 okFlag; };
 
 struct InvInfo { u32 total; u32 nWords; u32 count; u32 dyn; u32 pad[4]; };      // device-resident sizes: no host read-back in this stage
 
+template <bool OLD>
 __global__ void k_bwt_i_header(BwtView v, BwtHdr* __restrict__ hd, u32* __restrict__ base, u8* __restrict__ ok, u32* __restrict__ newLen, InvInfo* __restrict__ info)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -44,7 +45,35 @@ __global__ void k_bwt_i_header(BwtView v, BwtHdr* __restrict__ hd, u32* __restri
         newLen[b] = 0;
         ok[b] = 0;
         if (blockSize == 0) { hd[b] = h; ok[b] = 1; continue; }     // nothing to do / inactive
-        if (blockSize >= 2) {
+        if (OLD) {
+            // the header of bitstream versions below 6 (BWTBlockCodec.cpp:140-164): the chunk count follows from the length WITH the
+            // header, every chunk has a mode byte (top two bits: bytes of its primary index - 1, low six bits: the index's top bits)
+            // and the rest of the index, stored as it is (since version 6: index - 1, behind one mode byte for all chunks)
+            const u8* s = v.src[b];
+            const u32 chunks = (u32)bwt_chunks(blockSize);
+            u32 prim[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+            u32 left = blockSize, idx = 0;
+            bool good = chunks <= 8;
+            for (u32 k = 0; k < chunks && good; k++) {
+                if (idx >= blockSize) { good = false; break; }
+                const u32 mode = s[idx++];
+                const u32 sz = 1 + ((mode >> 6) & 3);
+                if (left < sz || idx + (sz - 1) > blockSize) { good = false; break; }
+                left -= sz;
+                u32 shift = (sz - 1) << 3;
+                u32 pi = (mode & 0x3F) << shift;
+                for (u32 q = 1; q < sz; q++) { shift -= 8; pi |= (u32)s[idx++] << shift; }
+                prim[k] = pi;
+            }
+            const u32 n = left;
+            if (good && n > 1) {
+                // BWT.cpp:176-177 (chunk 0), :230-245 / :310-318 (every chunk the data itself is cut into)
+                if (prim[0] == 0 || prim[0] > n) good = false;
+                if (bwt_chunks(n) == 8) for (u32 k = 1; k < 8; k++) if (prim[k] == 0 || prim[k] > n) good = false;
+            }
+            if (good && n > v.cap[b]) good = false;
+            if (good) { h.n = n; h.hdr = idx; h.pIdx = prim[0]; h.okFlag = 1; ok[b] = 1; newLen[b] = n; if (n >= 2) sum += n; }
+        } else if (blockSize >= 2) {
             const u8* s = v.src[b];
             const u32 mode = s[0];
             const u32 logNbChunks = (mode >> 2) & 7;
@@ -452,7 +481,11 @@ int launch_bwt_inverse(hipStream_t s, const XfStage& st, void* scratch, size_t s
     const int perTiles = w.perTiles;
     const u32 segT = w.segT, nSeg = w.nSeg;
     // no size is read back: every grid is sized by the upper bound (blocks x longest block), the kernels take the sizes from `info`
-    { KScope ks_("k_bwt_i_header"); hipLaunchKernelGGL(k_bwt_i_header, dim3(1), dim3(64), 0, s, v, w.hd, w.base, st.ok, st.newLen, w.info); }
+    {
+        KScope ks_("k_bwt_i_header");
+        if (st.bsVersion < 6) hipLaunchKernelGGL(k_bwt_i_header<true>, dim3(1), dim3(64), 0, s, v, w.hd, w.base, st.ok, st.newLen, w.info);
+        else hipLaunchKernelGGL(k_bwt_i_header<false>, dim3(1), dim3(64), 0, s, v, w.hd, w.base, st.ok, st.newLen, w.info);
+    }
     { KScope ks_("k_bwt_i_tiny"); hipLaunchKernelGGL(k_bwt_i_tiny, dim3((st.nBlocks + 63) / 64), dim3(64), 0, s, v, w.hd); }
     const dim3 gridT((unsigned)perTiles, st.nBlocks);
     { KScope ks_("k_bwt_i_hist"); hipLaunchKernelGGL(k_bwt_i_hist, gridT, dim3(256), 0, s, v, w.hd, perTiles, w.tileHist); }

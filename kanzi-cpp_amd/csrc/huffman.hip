@@ -481,6 +481,9 @@ constexpr u32 HSCAN_NEED_BITS = 6 + 256 + 256 * 8 + 4 * 40 + 64;     // alphabet
 // :204-246).  Same scheme as the rANS scan: a 1 KiB window of the stream in LDS, the next window prefetched at a
 // guessed position, presence masks counted in parallel; the Exp-Golomb deltas are a short uniform chain
 // (one LDS read + count-leading-zeros per code).
+// V5: the chunk layout of bitstream versions below 6 (HuffmanDecoder.cpp:349-459): no raw small chunks; behind the lengths a 2-bit
+// stream count (0 = one) and ONE var-int bit count, then one code stream for the whole chunk -- kept as "fragment 0" here.
+template <bool V5>
 __global__ __launch_bounds__(64) void k_huff_scan(BitSrc src, DecBlock* __restrict__ blocks, int nBlocks, int maxChunks,
                                                   HufDecChunk* __restrict__ chunks)
 {
@@ -557,7 +560,7 @@ __global__ __launch_bounds__(64) void k_huff_scan(BitSrc src, DecBlock* __restri
     for (u32 ci = 0; ci < nChunks && !err; ci++) {
         HufDecChunk& c = cs[ci];
         const u32 n = (preLen - ci * ENT_CHUNK < ENT_CHUNK) ? (preLen - ci * ENT_CHUNK) : ENT_CHUNK;
-        if (n < 32) {
+        if (!V5 && n < 32) {
             if (lane == 0) { c.kind = 2; c.tailBit = pos; }
             pos += 8ull * n;
             if (pos > limit) err = 1;
@@ -650,6 +653,31 @@ __global__ __launch_bounds__(64) void k_huff_scan(BitSrc src, DecBlock* __restri
             pos = winBit0 + q;
             continue;
         }
+        if (V5) {
+            // ---- HuffmanDecoder.cpp:374-383: stream count, bit count
+            if (hwin_bits(win, q, 2) != 0) { err = 1; break; }
+            q += 2;
+            u32 value = hwin_bits(win, q, 8); q += 8;
+            u32 res = value & 0x7F;
+            for (int shift = 7; value >= 128; shift += 7) {
+                value = hwin_bits(win, q, 8); q += 8;
+                if (shift == 28) { if (value >= 128 || (value & 0x70) != 0) err = 1; res |= (value & 0x0F) << shift; break; }
+                res |= (value & 0x7F) << shift;
+            }
+            if ((int)res < 0 || res > n * (u32)HUF_MAX_LEN) err = 1;
+            if (err) break;
+            const u64 fp5 = winBit0 + q;
+            if (lane == 0 && res != 0) {                         // (:386: a chunk that declares no bits is left as it is)
+                c.asz = (u16)asz;
+                c.fragBit[0] = fp5; c.fragBits[0] = res;
+                for (int j = 1; j < 4; j++) { c.fragBit[j] = fp5 + res; c.fragBits[j] = 0; }
+                c.tailBit = fp5 + res;
+                c.kind = 0;
+            }
+            pos = fp5 + res;
+            if (pos > limit) err = 1;
+            continue;
+        }
         // ---- decodeChunk prologue (HuffmanDecoder.cpp:204-246): 4 fragment sizes in bits
         const u32 maxFragBits = 8192u << 3;
         u32 szb[4];
@@ -688,6 +716,8 @@ constexpr int HUF_DEC_CHUNKS = 8;   // chunks per wave (4 lanes = 4 fragments ea
 // 32..64 bits of its stream in a register pair; the next 32 bits are loaded every 2 steps without a branch and
 // only committed when there is room (the load is simply repeated otherwise), so no global access sits on the
 // table-lookup chain.
+// V5 (chunks of bitstream versions below 6): the chunk is one code stream, so one lane of the four decodes all of it.
+template <bool V5>
 __global__ __launch_bounds__(64) void k_huff_decode(BitSrc src, DecBlock* __restrict__ blocks, int maxChunks, int nSlots,
                                                     const HufDecChunk* __restrict__ chunks, u8* const* __restrict__ outPtr)
 {
@@ -784,11 +814,11 @@ __global__ __launch_bounds__(64) void k_huff_decode(BitSrc src, DecBlock* __rest
             const HufDecChunk& c = chunks[slot];
             b = slot / maxChunks;
             ci = slot - b * maxChunks;
-            if (c.kind == 0 && !blocks[b].error && !chunkErr[g]) {
+            if (c.kind == 0 && !blocks[b].error && !chunkErr[g] && (!V5 || j == 0)) {
                 act = true;
                 const u32 preLen = blocks[b].preLen;
                 n = (preLen - (u32)ci * ENT_CHUNK < ENT_CHUNK) ? (preLen - (u32)ci * ENT_CHUNK) : ENT_CHUNK;
-                szFrag = n / 4;
+                szFrag = V5 ? n : n / 4;
                 dst = outPtr[b] + (size_t)ci * ENT_CHUNK + (size_t)j * szFrag;
                 fbeg = c.fragBit[j];
                 fragBits = c.fragBits[j];
@@ -846,7 +876,7 @@ __global__ __launch_bounds__(64) void k_huff_decode(BitSrc src, DecBlock* __rest
                 used += on ? len : 0u;
             }
         }
-        if (used > (8192u << 3)) bad = true;
+        if (used > (V5 ? (u32)(ENT_CHUNK * HUF_MAX_LEN) : (8192u << 3))) bad = true;
         if (i + 4 <= steps) {
             if (al4) *reinterpret_cast<u32*>(dst + i) = acc;
             else { dst[i] = (u8)acc; dst[i + 1] = (u8)(acc >> 8); dst[i + 2] = (u8)(acc >> 16); dst[i + 3] = (u8)(acc >> 24); }
@@ -856,7 +886,7 @@ __global__ __launch_bounds__(64) void k_huff_decode(BitSrc src, DecBlock* __rest
     }
     if (act) {
         if (used != fragBits) bad = true;
-        if (j == 0) {
+        if (!V5 && j == 0) {
             const HufDecChunk& c = chunks[slotBase + g];
             for (u32 i = 4 * szFrag; i < n; i++)
                 outPtr[b][(size_t)ci * ENT_CHUNK + i] = (u8)peek_bits(src, c.tailBit + 8ull * (i - 4 * szFrag), 8);
@@ -874,13 +904,18 @@ void launch_huffman_encode(hipStream_t s, BlockView view, int nBlocks, int maxCh
     { KScope ks_("k_huff_encode"); hipLaunchKernelGGL(k_huff_encode, dim3(nSlots), dim3(64), 0, s, view, maxChunks, desc, tmp); }
 }
 
-void launch_huffman_decode(hipStream_t s, BitSrc src, DecBlock* blocks, int nBlocks, int maxChunks, void* chunkMeta, u8* const* outPtr)
+void launch_huffman_decode(hipStream_t s, BitSrc src, DecBlock* blocks, int nBlocks, int maxChunks, void* chunkMeta, u8* const* outPtr, int bsVersion)
 {
     HufDecChunk* chunks = reinterpret_cast<HufDecChunk*>(chunkMeta);
     const int nSlots = nBlocks * maxChunks;
-    { KScope ks_("k_huff_scan"); hipLaunchKernelGGL(k_huff_scan, dim3(nBlocks), dim3(64), 0, s, src, blocks, nBlocks, maxChunks, chunks); }
-    { KScope ks_("k_huff_decode"); hipLaunchKernelGGL(k_huff_decode, dim3((nSlots + HUF_DEC_CHUNKS - 1) / HUF_DEC_CHUNKS), dim3(64), 0, s, src, blocks,
-                       maxChunks, nSlots, chunks, outPtr); }
+    const dim3 gridD((nSlots + HUF_DEC_CHUNKS - 1) / HUF_DEC_CHUNKS);
+    if (bsVersion < 6) {
+        { KScope ks_("k_huff_scan"); hipLaunchKernelGGL(k_huff_scan<true>, dim3(nBlocks), dim3(64), 0, s, src, blocks, nBlocks, maxChunks, chunks); }
+        { KScope ks_("k_huff_decode"); hipLaunchKernelGGL(k_huff_decode<true>, gridD, dim3(64), 0, s, src, blocks, maxChunks, nSlots, chunks, outPtr); }
+        return;
+    }
+    { KScope ks_("k_huff_scan"); hipLaunchKernelGGL(k_huff_scan<false>, dim3(nBlocks), dim3(64), 0, s, src, blocks, nBlocks, maxChunks, chunks); }
+    { KScope ks_("k_huff_decode"); hipLaunchKernelGGL(k_huff_decode<false>, gridD, dim3(64), 0, s, src, blocks, maxChunks, nSlots, chunks, outPtr); }
 }
 
 size_t huffman_dec_chunk_bytes() { return sizeof(HufDecChunk); }

@@ -59,6 +59,7 @@ struct XfStage {
     u32 maxLen;              // upper bound of len[] (grid sizing)
     u32* scratchU32;         // stage scratch (8-byte aligned)
     int entropyType;         // stream entropy id (RLT escape choice)
+    int bsVersion = 6;       // bitstream version the blocks come from (inverse only: BWT block header of versions below 6)
 };
 
 // zrlt_mtft.hip
@@ -132,7 +133,7 @@ void launch_seq_inv_commit(hipStream_t s, const SeqArrays& a, DecBlock* blocks, 
 
 // huffman.hip
 void launch_huffman_encode(hipStream_t s, BlockView view, int nBlocks, int maxChunks, ChunkDesc* desc, u8* tmp);
-void launch_huffman_decode(hipStream_t s, BitSrc src, DecBlock* blocks, int nBlocks, int maxChunks, void* chunkMeta, u8* const* outPtr);
+void launch_huffman_decode(hipStream_t s, BitSrc src, DecBlock* blocks, int nBlocks, int maxChunks, void* chunkMeta, u8* const* outPtr, int bsVersion = 6);
 size_t huffman_dec_chunk_bytes();
 
 }  // namespace knz

@@ -25,7 +25,7 @@ SYMBOLS = [
 
 class Params(C.Structure):
     _fields_ = [("transform_type", C.c_uint64), ("entropy_type", C.c_int32), ("block_size", C.c_int32),
-                ("checksum_bits", C.c_int32), ("jobs", C.c_int32)]
+                ("checksum_bits", C.c_int32), ("jobs", C.c_int32), ("bs_version", C.c_int32)]
 
 
 class KernelTime(C.Structure):
@@ -141,13 +141,14 @@ class Context:
         self._chk(self.L.knz_hip_sync(self.h))
 
     # ---- batch API on device pointers
-    def params(self, transform, entropy, block_size, checksum=0, jobs=1):
+    def params(self, transform, entropy, block_size, checksum=0, jobs=1, bs_version=0):
         p = Params()
         p.transform_type = transform_type(transform) if isinstance(transform, str) else transform
         p.entropy_type = ENTROPY_IDS[entropy.upper()] if isinstance(entropy, str) else entropy
         p.block_size = block_size
         p.checksum_bits = checksum
         p.jobs = jobs
+        p.bs_version = bs_version
         return p
 
     def encode_bound(self, p, n):

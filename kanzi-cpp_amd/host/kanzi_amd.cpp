@@ -1057,9 +1057,11 @@ CompressedInputStream::CompressedInputStream(std::istream& is, int tasks, const 
     if ((tasks <= 0) || (tasks > 64)) throw std::invalid_argument("The number of jobs must be in [1..64]");
     _jobs = tasks; _blockSize = blockSize; _checksum = checksum; _outputSize = originalSize;
     _headless = headerless; _closed = false; _headerDone = false; _ended = false;
-    _entropyType = 0; _transformType = 0;
+    _entropyType = 0; _transformType = 0; _bsVersion = 6;
     if (headerless) {
-        if (bsVersion != 6) throw std::invalid_argument("Only bitstream version 6 is supported");
+        // (io/CompressedInputStream.cpp:97-98 takes the caller's word for the version of a headerless stream)
+        if (bsVersion < 0 || bsVersion > 6) throw std::invalid_argument("Invalid or missing bitstream version, cannot read this version of the stream");
+        _bsVersion = bsVersion;
         if ((blockSize < 1024) || (blockSize > 1024 * 1024 * 1024) || ((blockSize & -16) != blockSize)) throw std::invalid_argument("Invalid block size");
         _entropyType = EntropyEncoderFactory::getType(entropy.c_str());
         _transformType = TransformFactory<byte>::getType(transform.c_str());
@@ -1124,8 +1126,9 @@ void CompressedInputStream::readHeader()
     if (_headerDone) return;
     _headerDone = true;
     if (_headless) return;
-    if (!fetch(20)) throw IOException("Invalid stream type", Error::ERR_INVALID_FILE);
+    if (!fetch(17)) throw IOException("Invalid stream type", Error::ERR_INVALID_FILE);       // (17 bytes: the shortest old header; 20: the shortest current one)
     fetch(24);
+    const size_t headerBytesSeen = _comp.size();
     _comp.resize(_comp.size() + 8, 0);           // reading margin for getBitsAt
     uint64 pos = _compBit;
     auto get = [&](uint n) { const uint64 v = getBitsAt(_comp, pos, n); pos += n; return v; };
@@ -1133,9 +1136,16 @@ void CompressedInputStream::readHeader()
     if (uint32_t(get(32)) != 0x4B414E5Au) throw IOException("Invalid stream type", Error::ERR_INVALID_FILE);
     const int bsVersion = int(get(4));
     if (bsVersion > 6) throw IOException("Invalid bitstream, cannot read this version of the stream", Error::ERR_STREAM_VERSION);
-    if (bsVersion < 6) throw IOException("Bitstream versions below 6 are not supported by the device path", Error::ERR_STREAM_VERSION);
-    const uint64 ckSize = get(2);
-    if (ckSize == 3) throw IOException("Invalid bitstream, incorrect block checksum size", Error::ERR_INVALID_FILE);
+    if (bsVersion >= 6 && headerBytesSeen < 20) throw IOException("Invalid stream type", Error::ERR_INVALID_FILE);
+    _bsVersion = bsVersion;
+    // io/CompressedInputStream.cpp:541-558: two bits of checksum size since version 6, one checksum flag before
+    uint64 ckSize;
+    if (bsVersion >= 6) {
+        ckSize = get(2);
+        if (ckSize == 3) throw IOException("Invalid bitstream, incorrect block checksum size", Error::ERR_INVALID_FILE);
+    } else {
+        ckSize = get(1);
+    }
     _checksum = int(32 * ckSize);
     _entropyType = short(get(5));
     try { EntropyEncoderFactory::getName(_entropyType); } catch (const std::invalid_argument&) { throw IOException("Invalid bitstream, unknown entropy type", Error::ERR_INVALID_CODEC); }
@@ -1145,10 +1155,25 @@ void CompressedInputStream::readHeader()
     if ((_blockSize < 1024) || (_blockSize > 1024 * 1024 * 1024)) throw IOException("Invalid bitstream, incorrect block size", Error::ERR_BLOCK_SIZE);
     const int szMask = int(get(2));
     if (szMask != 0) { if (!enough24 && szMask > 1) throw IOException("Invalid stream type", Error::ERR_INVALID_FILE); _outputSize = get(uint(16 * szMask)); }
-    get(15);
-    const uint32_t ck1 = uint32_t(get(24));
-    if (ck1 != headerChecksum(uint32_t(ckSize), uint32_t(_entropyType), _transformType, uint32_t(_blockSize), szMask, _outputSize))
-        throw IOException("Invalid bitstream, header checksum mismatch", Error::ERR_CRC_CHECK);
+    // :606-645: padding and 24 checksum bits since version 6; before, no padding, 16 bits, seeded with the bare version and
+    // without the checksum size
+    uint32_t ck1, ck2;
+    if (bsVersion >= 6) {
+        get(15);
+        ck1 = uint32_t(get(24));
+        ck2 = headerChecksum(uint32_t(ckSize), uint32_t(_entropyType), _transformType, uint32_t(_blockSize), szMask, _outputSize);
+    } else {
+        ck1 = uint32_t(get(16));
+        const uint32_t HASH = 0x1E35A7BDu;
+        uint32_t c = HASH * uint32_t(bsVersion);
+        c ^= HASH * uint32_t(~uint32_t(_entropyType));
+        c ^= HASH * uint32_t((~_transformType) >> 32);
+        c ^= HASH * uint32_t(~_transformType);
+        c ^= HASH * uint32_t(~uint32_t(_blockSize));
+        if (szMask != 0) { c ^= HASH * uint32_t((~_outputSize) >> 32); c ^= HASH * uint32_t(~_outputSize); }
+        ck2 = ((c >> 23) ^ (c >> 3)) & 0xFFFFu;
+    }
+    if (ck1 != ck2) throw IOException("Invalid bitstream, header checksum mismatch", Error::ERR_CRC_CHECK);
     _comp.resize(_comp.size() - 8);
     _consumedBits += pos - _compBit;
     _compBit = pos;
@@ -1242,6 +1267,7 @@ void CompressedInputStream::decodeBatch(Prep& pr, PSlot& sl)
     knz_params p;
     memset(&p, 0, sizeof(p));
     p.transform_type = _transformType; p.entropy_type = _entropyType; p.block_size = _blockSize; p.checksum_bits = _checksum; p.jobs = _jobs;
+    p.bs_version = _bsVersion;
     const size_t outCap = size_t(pr.nb) * size_t(_blockSize) + 64;
     // the slot is free, so the copy out of its device buffer (two batches ago) has been waited for
     if (sl.dOutCap < outCap) {

@@ -152,3 +152,7 @@ int knzo_decode_alphabet(knzo_br* r, uint32_t* alphabet)
             if ((masks[i] >> j) & 1) alphabet[count++] = (uint32_t)(8 * i + j);
     return count;
 }
+
+static __thread int g_bs_version = 6;
+void knzo_set_bs_version(int v) { g_bs_version = (v >= 0 && v <= 6) ? v : 6; }
+int knzo_get_bs_version(void) { return g_bs_version; }

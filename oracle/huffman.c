@@ -6,7 +6,10 @@
  *   common   entropy/HuffmanCommon.cpp:29-63 (generateCanonicalCodes)
  *   lengths  entropy/ExpGolombEncoder.hpp:51-62 / ExpGolombDecoder.hpp:52-75 (signed Exp-Golomb)
  *   decoder  entropy/HuffmanDecoder.cpp:65-108 (readLengths), :111-140 (buildDecodingTable),
- *            :156-201 (decodeV6), :204-347 (decodeChunk)
+ *            :156-201 (decodeV6), :204-347 (decodeChunk), :349-459 (decodeV5: bitstream versions below 6, one code stream per
+ *            chunk behind a 2-bit stream count and a var-int bit count; no raw small chunks)
+ * The reference only WRITES version 6. knzo_huffman_encode_bw under knzo_set_bs_version(< 6) is this file's own writer of the old
+ * layout (what decodeV5 reads), there to hand-build old streams for the tests; the reference decoding them is what pins it.
  */
 #include "knz_oracle.h"
 #include <stdlib.h>
@@ -242,9 +245,41 @@ static int update_frequencies(knzo_bw* w, uint32_t* freqs, uint16_t* codes)
 }
 
 /* HuffmanEncoder.cpp:304-421 */
+static int huffman_encode_v5(knzo_bw* w, const uint8_t* block, uint32_t count)
+{
+    uint32_t startChunk = 0;
+    uint16_t codes[256];
+    const size_t cap = (size_t)HUF_CHUNK * 2 + 64;
+    uint8_t* tmp = (uint8_t*)malloc(cap);
+    while (startChunk < count) {
+        const uint32_t sizeChunk = (HUF_CHUNK < count - startChunk) ? HUF_CHUNK : count - startChunk;
+        const uint8_t* blk = &block[startChunk];
+        uint32_t freqs[256];
+        memset(freqs, 0, sizeof(freqs));
+        for (uint32_t i = 0; i < sizeChunk; i++) freqs[blk[i]]++;
+        const int asz = update_frequencies(w, freqs, codes);
+        if (asz < 0) { free(tmp); return -1; }
+        if (asz > 1) {
+            knzo_bw cw;
+            knzo_bw_init(&cw, tmp, cap);
+            for (uint32_t i = 0; i < sizeChunk; i++) {
+                const uint16_t c = codes[blk[i]];
+                knzo_bw_bits(&cw, c & 0x0FFF, c >> 12);
+            }
+            knzo_bw_bits(w, 0, 2);                          /* number of streams - 1 */
+            knzo_write_varint(w, (uint32_t)cw.bits);
+            knzo_bw_bytes(w, cw.buf, cw.bits);
+        }
+        startChunk += sizeChunk;
+    }
+    free(tmp);
+    return w->overflow ? -1 : (int)count;
+}
+
 int knzo_huffman_encode_bw(knzo_bw* w, const uint8_t* block, uint32_t count)
 {
     if (count == 0) return 0;
+    if (knzo_get_bs_version() < 6) return huffman_encode_v5(w, block, count);
     uint32_t startChunk = 0;
     uint16_t codes[256];
     uint8_t* frag = (uint8_t*)malloc(4 * (HUF_CHUNK / 4) * 2 + 64);
@@ -285,10 +320,84 @@ int knzo_huffman_encode_bw(knzo_bw* w, const uint8_t* block, uint32_t count)
     return w->overflow ? -1 : (int)count;
 }
 
+/* HuffmanDecoder.cpp:349-459 */
+static int huffman_decode_v5(knzo_br* r, uint8_t* block, uint32_t count)
+{
+    uint16_t codes[256], sizes[256];
+    uint32_t alphabet[256];
+    uint16_t* table = (uint16_t*)malloc(sizeof(uint16_t) * (1 << HUF_TABLE_BITS));
+    uint8_t* buf = NULL;
+    for (int i = 0; i < 256; i++) { codes[i] = (uint16_t)i; sizes[i] = 8; }
+    memset(alphabet, 0, sizeof(alphabet));
+    uint32_t startChunk = 0;
+    int ret = (int)count;
+    while (startChunk < count) {
+        const uint32_t sizeChunk = (HUF_CHUNK < count - startChunk) ? HUF_CHUNK : count - startChunk;
+        uint8_t* blk = &block[startChunk];
+        /* readLengths :65-108 */
+        const int asz = knzo_decode_alphabet(r, alphabet);
+        if (r->error) { ret = -2; break; }
+        if (asz <= 0) { ret = (int)startChunk; break; }
+        int8_t curSize = 2;
+        int bad = 0;
+        for (int i = 0; i < asz; i++) {
+            const uint32_t s = alphabet[i];
+            codes[s] = 0;
+            curSize = (int8_t)(curSize + (int8_t)eg_decode_signed(r));
+            if (r->error || curSize <= 0 || curSize > HUF_MAX_SYMBOL_SIZE) { bad = 1; break; }
+            sizes[s] = (uint16_t)curSize;
+        }
+        if (bad || gen_canonical(sizes, codes, alphabet, asz) < 0) { ret = -2; break; }
+        if (asz == 1) { memset(blk, (int)alphabet[0], sizeChunk); startChunk += sizeChunk; continue; }
+        /* buildDecodingTable :111-140 */
+        for (int i = 0; i < (1 << HUF_TABLE_BITS); i++) table[i] = 0x0707;
+        uint16_t length = 0;
+        for (int i = 0; i < asz; i++) {
+            const uint32_t s = alphabet[i];
+            if (sizes[s] > length) length = sizes[s];
+            const int wdt = 1 << (HUF_TABLE_BITS - length);
+            int idx = (int)codes[s] * wdt;
+            const int end = idx + wdt;
+            if (end > (1 << HUF_TABLE_BITS)) { bad = 1; break; }
+            const uint16_t val = (uint16_t)((s << 8) | sizes[s]);
+            while (idx < end) table[idx++] = val;
+        }
+        if (bad) { ret = -1; break; }
+        if (knzo_br_bits(r, 2) != 0 || r->error) { ret = r->error ? -2 : -1; break; }      /* one stream only, :375-377 */
+        const int szBits = (int)knzo_read_varint(r);
+        if (r->error) { ret = -2; break; }
+        if (szBits < 0 || szBits > (int)sizeChunk * HUF_MAX_SYMBOL_SIZE) { ret = -1; break; }
+        if (szBits != 0) {
+            const size_t sz = ((size_t)szBits + 7) >> 3;
+            buf = (uint8_t*)realloc(buf, sz + 8);
+            memset(buf, 0, sz + 8);
+            knzo_br_bytes(r, buf, (uint64_t)szBits);
+            if (r->error) { ret = -2; break; }
+            /* every symbol is one table look-up on the next 12 bits (zeros behind the end), :396-450; the chunk is good when
+             * exactly szBits bits were used, :452-453 */
+            uint64_t used = 0;
+            for (uint32_t i = 0; i < sizeChunk; i++) {
+                if (used > (uint64_t)szBits) { bad = 1; break; }
+                const size_t b = (size_t)(used >> 3);
+                uint32_t win = ((uint32_t)buf[b] << 16) | ((uint32_t)buf[b + 1] << 8) | buf[b + 2];
+                win = (win >> (12 - (used & 7))) & 0xFFF;
+                const uint16_t val = table[win];
+                blk[i] = (uint8_t)(val >> 8);
+                used += (val & 0xFF);
+            }
+            if (bad || used != (uint64_t)szBits) { ret = -1; break; }
+        }
+        startChunk += sizeChunk;
+    }
+    free(table); free(buf);
+    return ret;
+}
+
 /* HuffmanDecoder.cpp:156-347 (v6 path) */
 int knzo_huffman_decode_br(knzo_br* r, uint8_t* block, uint32_t count)
 {
     if (count == 0) return 0;
+    if (knzo_get_bs_version() < 6) return huffman_decode_v5(r, block, count);
     uint16_t codes[256], sizes[256];
     uint32_t alphabet[256];
     uint16_t* table = (uint16_t*)malloc(sizeof(uint16_t) * (1 << HUF_TABLE_BITS));

@@ -18,6 +18,13 @@
 extern "C" {
 #endif
 
+/* ---- Bitstream version the calling thread's codec calls work in (6 = current; 3..5 = the old layouts the reference still DECODES:
+ * Huffman chunks, HuffmanDecoder.cpp:349-459; BWT block header, BWTBlockCodec.cpp:140-164; stream header,
+ * CompressedInputStream.cpp:541-558,623-625). The writers follow it too, which is how the tests get old streams: the reference
+ * has no writer for them. knzo_decompress switches by the header it reads. */
+void knzo_set_bs_version(int v);
+int knzo_get_bs_version(void);
+
 /* ---- MSB-first bit I/O (bitstream/DefaultOutputBitStream.hpp:83-131, DefaultInputBitStream.hpp:88-150) */
 typedef struct {
     uint8_t* buf;

@@ -361,6 +361,23 @@ int knzo_decode_block(const uint8_t* in, uint64_t nbits, uint64_t ttype, int ety
     return 0;
 }
 
+/* CompressedInputStream.cpp:622-645: versions below 6 seed with the version alone, leave the checksum size out and keep 16 bits */
+static uint32_t header_checksum_v(int ver, uint32_t ckSize, uint32_t etype, uint64_t ttype, uint32_t blockSize, int szMask, uint64_t size)
+{
+    const uint32_t HASH = 0x1E35A7BDu;
+    uint32_t c = HASH * ((ver >= 6 ? 0x01030507u : 1u) * (uint32_t)ver);
+    if (ver >= 6) c ^= HASH * (uint32_t)~ckSize;
+    c ^= HASH * (uint32_t)~etype;
+    c ^= HASH * (uint32_t)((~ttype) >> 32);
+    c ^= HASH * (uint32_t)~ttype;
+    c ^= HASH * (uint32_t)~blockSize;
+    if (szMask != 0) {
+        c ^= HASH * (uint32_t)((~size) >> 32);
+        c ^= HASH * (uint32_t)~size;
+    }
+    return ((c >> 23) ^ (c >> 3)) & (ver >= 6 ? 0xFFFFFFu : 0xFFFFu);
+}
+
 static uint32_t header_checksum(uint32_t ckSize, uint32_t etype, uint64_t ttype, uint32_t blockSize, int szMask, uint64_t size)
 {
     const uint32_t HASH = 0x1E35A7BDu;
@@ -470,7 +487,22 @@ int knzo_compress_run(const uint8_t* in, size_t n, const char* transform, const 
     if (checksum != 0 && checksum != 32 && checksum != 64) return ERR_INVALID_PARAM;
     knzo_bw w;
     knzo_bw_init(&w, out, cap);
-    if (!headerless) {
+    const int ver = knzo_get_bs_version();
+    if (!headerless && ver < 6) {
+        /* the header as versions below 6 had it (what CompressedInputStream.cpp:541-558,606-645 reads): one checksum bit, no padding,
+         * 16 checksum bits. Test writer: the reference writes version 6 only. */
+        if (checksum == 64) return ERR_INVALID_PARAM;
+        knzo_bw_bits(&w, KNZ_MAGIC, 32);
+        knzo_bw_bits(&w, (uint64_t)ver, 4);
+        knzo_bw_bits(&w, checksum == 32 ? 1 : 0, 1);
+        knzo_bw_bits(&w, (uint64_t)etype, 5);
+        knzo_bw_bits(&w, ttype, 48);
+        knzo_bw_bits(&w, (uint64_t)(blockSize >> 4), 28);
+        const int szMask = (origSize == 0 || origSize >= (1ull << 48)) ? 0 : (ilog2_64(origSize) >> 4) + 1;
+        knzo_bw_bits(&w, (uint64_t)szMask, 2);
+        if (szMask) knzo_bw_bits(&w, origSize, 16u * (unsigned)szMask);
+        knzo_bw_bits(&w, header_checksum_v(ver, 0, (uint32_t)etype, ttype, (uint32_t)blockSize, szMask, origSize), 16);
+    } else if (!headerless) {
         const uint32_t ckSize = checksum == 32 ? 1 : (checksum == 64 ? 2 : 0);
         knzo_bw_bits(&w, KNZ_MAGIC, 32);
         knzo_bw_bits(&w, KNZ_VERSION, 4);
@@ -543,9 +575,14 @@ int knzo_decompress(const uint8_t* in, size_t inLen, uint8_t* out, size_t cap, s
     knzo_br_init(&r, in, 8ull * inLen);
     if ((uint32_t)knzo_br_bits(&r, 32) != KNZ_MAGIC) return ERR_INVALID_FILE;
     const int ver = (int)knzo_br_bits(&r, 4);
-    if (ver != KNZ_VERSION) return ERR_STREAM_VERSION;   /* older versions: out of scope */
-    const uint32_t ckSize = (uint32_t)knzo_br_bits(&r, 2);
-    if (ckSize == 3) return ERR_INVALID_FILE;
+    if (ver > KNZ_VERSION) return ERR_STREAM_VERSION;
+    uint32_t ckSize;
+    if (ver >= 6) {
+        ckSize = (uint32_t)knzo_br_bits(&r, 2);
+        if (ckSize == 3) return ERR_INVALID_FILE;
+    } else {
+        ckSize = (uint32_t)knzo_br_bits(&r, 1);         /* CompressedInputStream.cpp:555-558 */
+    }
     const int etype = (int)knzo_br_bits(&r, 5);
     const uint64_t ttype = knzo_br_bits(&r, 48);
     const int blockSize = (int)(knzo_br_bits(&r, 28) << 4);
@@ -553,13 +590,17 @@ int knzo_decompress(const uint8_t* in, size_t inLen, uint8_t* out, size_t cap, s
     const int szMask = (int)knzo_br_bits(&r, 2);
     uint64_t size = 0;
     if (szMask) size = knzo_br_bits(&r, 16u * (unsigned)szMask);
-    knzo_br_bits(&r, 15);
-    const uint32_t ck1 = (uint32_t)knzo_br_bits(&r, 24);
+    if (ver >= 6) knzo_br_bits(&r, 15);
+    const uint32_t ck1 = (uint32_t)knzo_br_bits(&r, ver >= 6 ? 24 : 16);
     if (r.error) return ERR_INVALID_FILE;
-    if (ck1 != header_checksum(ckSize, (uint32_t)etype, ttype, (uint32_t)blockSize, szMask, size)) return ERR_CRC_CHECK;
+    if (ck1 != header_checksum_v(ver, ckSize, (uint32_t)etype, ttype, (uint32_t)blockSize, szMask, size)) return ERR_CRC_CHECK;
     const int checksumBits = ckSize == 1 ? 32 : (ckSize == 2 ? 64 : 0);
     uint64_t endBit = 0;
     int64_t done = 0;
-    return knzo_decode_run(in, 8ull * inLen, r.pos, ttype, etype, checksumBits, blockSize, -1, out, cap, outLen, &endBit, &done);
+    const int before = knzo_get_bs_version();
+    knzo_set_bs_version(ver);                              /* the codecs' old layouts, where they have one */
+    const int rc = knzo_decode_run(in, 8ull * inLen, r.pos, ttype, etype, checksumBits, blockSize, -1, out, cap, outLen, &endBit, &done);
+    knzo_set_bs_version(before);
+    return rc;
 }
 

@@ -514,8 +514,69 @@ static int rlt_inverse(const uint8_t* src, int count, uint8_t* dst, int dstCap, 
 
 /* ------------------------------------------------------------------ BWT block codec
  * transform/BWTBlockCodec.cpp:32-87 (forward), :89-168 (inverse, bsVersion 6 branch) */
+/* The header bitstream versions below 6 carried, as BWTBlockCodec.cpp:140-164 reads it: per chunk a mode byte (top two bits: bytes of
+ * the primary index - 1, low six bits: its top bits) and the rest of the index; the chunk count follows from the length WITH the
+ * header; the index is stored as it is (no - 1). The reference does not write this any more: this writer exists for the tests. */
+static int bwtblock_forward_v5(const uint8_t* src, int blockSize, uint8_t* dst, int dstCap, int* outLen)
+{
+    *outLen = 0;
+    if (blockSize == 0) return 1;
+    if (dstCap < blockSize + 33) return 0;
+    int primary[8];
+    uint8_t* tmp = (uint8_t*)malloc((size_t)blockSize + 16);
+    if (!knzo_bwt_forward_raw(src, blockSize, tmp, primary)) { free(tmp); return 0; }
+    /* the reader takes the chunk count from the length that includes the header: settle it by trying both */
+    for (int chunks = 1; chunks <= 8; chunks += 7) {
+        if (knzo_bwt_chunks(blockSize) > chunks) continue;        /* (the data alone already needs 8) */
+        int idx = 0;
+        for (int i = 0; i < chunks; i++) {
+            const int p = (i < knzo_bwt_chunks(blockSize)) ? primary[i] : 0;
+            int sz = 1;
+            while (sz < 4 && (p >> (6 + 8 * (sz - 1))) != 0) sz++;
+            int shift = (sz - 1) << 3;
+            dst[idx++] = (uint8_t)(((sz - 1) << 6) | ((p >> shift) & 0x3F));
+            while (shift >= 8) { shift -= 8; dst[idx++] = (uint8_t)(p >> shift); }
+        }
+        if (knzo_bwt_chunks(blockSize + idx) != chunks) continue;
+        memcpy(dst + idx, tmp, (size_t)blockSize);
+        free(tmp);
+        *outLen = idx + blockSize;
+        return 1;
+    }
+    free(tmp);
+    return 0;
+}
+
+static int bwtblock_inverse_v5(const uint8_t* src, int blockSize, uint8_t* dst, int dstCap, int* outLen)
+{
+    *outLen = 0;
+    if (blockSize < 1) return blockSize == 0;
+    const int total = blockSize;
+    const int chunks = knzo_bwt_chunks(blockSize);
+    int primary[8];
+    memset(primary, 0, sizeof(primary));
+    int idx = 0;
+    for (int i = 0; i < chunks; i++) {
+        if (idx >= total) return 0;
+        const int blockMode = src[idx++];
+        const int sz = 1 + ((blockMode >> 6) & 0x03);
+        if (blockSize < sz || idx + (sz - 1) > total) return 0;
+        blockSize -= sz;
+        int shift = (sz - 1) << 3;
+        int p = (blockMode & 0x3F) << shift;
+        for (int n = 1; n < sz; n++) { shift -= 8; p |= (int)src[idx++] << shift; }
+        if (p < 0) return 0;
+        primary[i] = p;
+    }
+    if (blockSize > dstCap) return 0;
+    if (!knzo_bwt_inverse_raw(src + idx, blockSize, dst, primary)) return 0;
+    *outLen = blockSize;
+    return 1;
+}
+
 static int bwtblock_forward(const uint8_t* src, int blockSize, uint8_t* dst, int dstCap, int* outLen)
 {
+    if (knzo_get_bs_version() < 6) return bwtblock_forward_v5(src, blockSize, dst, dstCap, outLen);
     *outLen = 0;
     if (blockSize == 0) return 1;
     if (dstCap < blockSize + 33) return 0;          /* BWTBlockCodec.hpp:47-50 */
@@ -540,6 +601,7 @@ static int bwtblock_forward(const uint8_t* src, int blockSize, uint8_t* dst, int
 
 static int bwtblock_inverse(const uint8_t* src, int blockSize, uint8_t* dst, int dstCap, int* outLen)
 {
+    if (knzo_get_bs_version() < 6) return bwtblock_inverse_v5(src, blockSize, dst, dstCap, outLen);
     *outLen = 0;
     if (blockSize <= 1) return blockSize == 0;
     const uint8_t mode = src[0];

@@ -1,6 +1,7 @@
 // CPU-only check of the inverse BWT kernels' logic: kanzi-cpp_amd/csrc/bwt.hip compiled as plain C++ against tools/hipemu,
 // fed with the oracle's forward BWT block codec output, must reproduce the input. Test infrastructure only.
-//   usage: bwt_inv_emu <case file>    (binary: u32 nBlocks, then per block u32 len + bytes)
+//   usage: bwt_inv_emu <case file> [bitstream version]   (binary: u32 nBlocks, then per block u32 len + bytes; a version below 6 selects
+//   the block header of BWTBlockCodec.cpp:140-164 on both sides)
 #include "hip/hip_runtime.h"
 #include "../../kanzi-cpp_amd/csrc/bwt.hip"
 
@@ -8,6 +9,7 @@
 #include <vector>
 
 extern "C" int knzo_transform_forward(int ttype, const uint8_t* src, int n, uint8_t* dst, int dstCap, int etype, int* outLen);
+extern "C" void knzo_set_bs_version(int v);
 
 namespace knz { thread_local ProfHook* g_prof = nullptr; }
 
@@ -15,6 +17,8 @@ int main(int argc, char** argv)
 {
     using namespace knz;
     if (argc < 2) return 2;
+    const int bsVersion = argc > 2 ? atoi(argv[2]) : 6;
+    knzo_set_bs_version(bsVersion);
     FILE* f = fopen(argv[1], "rb");
     if (!f) return 2;
     u32 nBlocks = 0;
@@ -40,7 +44,7 @@ int main(int argc, char** argv)
     for (u32 b = 0; b < nBlocks; b++) { enc[b].reserve(enc[b].size() + 64); src[b] = enc[b].data(); dst[b] = out[b].data(); len[b] = (u32)enc[b].size(); cap[b] = (u32)plain[b].size() + 16; }
     XfStage st;
     st.src = src.data(); st.dst = dst.data(); st.len = len.data(); st.cap = cap.data(); st.ok = ok.data(); st.newLen = newLen.data();
-    st.nBlocks = (int)nBlocks; st.maxLen = maxLen; st.scratchU32 = nullptr; st.entropyType = -1;
+    st.nBlocks = (int)nBlocks; st.maxLen = maxLen; st.scratchU32 = nullptr; st.entropyType = -1; st.bsVersion = bsVersion;
     const size_t bytes = bwt_inverse_scratch_bytes((int)nBlocks, maxLen, (size_t)nBlocks * maxLen);
     std::vector<u8> scratch(bytes + 256);
     u8* sc = reinterpret_cast<u8*>((reinterpret_cast<uintptr_t>(scratch.data()) + 255) & ~(uintptr_t)255);

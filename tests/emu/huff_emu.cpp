@@ -2,7 +2,8 @@
 // parse of the Exp-Golomb code-length deltas; k_huff_decode: canonical tables and the four fragments of a chunk):
 // kanzi-cpp_amd/csrc/huffman.hip compiled as plain C++ against tools/hipemu, fed with the oracle's Huffman streams, must
 // reproduce the input and consume exactly the stream's bits. Test infrastructure only.
-//   usage: huff_emu <case file>    (binary: u32 nBlocks, then per block u32 len + bytes)
+//   usage: huff_emu <case file> [bitstream version]   (binary: u32 nBlocks, then per block u32 len + bytes; a version below 6 makes the
+//   oracle write, and the kernels read, the chunk layout of HuffmanDecoder.cpp:349-459)
 #define KNZ_EMU 1
 #include "hip/hip_runtime.h"
 #include "../../kanzi-cpp_amd/csrc/huffman.hip"
@@ -11,6 +12,7 @@
 #include <vector>
 
 extern "C" int64_t knzo_entropy_encode(int etype, const uint8_t* in, uint32_t n, uint8_t* out, size_t cap);
+extern "C" void knzo_set_bs_version(int v);
 
 namespace knz { thread_local ProfHook* g_prof = nullptr; }
 
@@ -18,6 +20,8 @@ int main(int argc, char** argv)
 {
     using namespace knz;
     if (argc < 2) return 2;
+    const int bsVersion = argc > 2 ? atoi(argv[2]) : 6;
+    knzo_set_bs_version(bsVersion);
     FILE* f = fopen(argv[1], "rb");
     if (!f) return 2;
     u32 nBlocks = 0;
@@ -54,7 +58,7 @@ int main(int argc, char** argv)
     std::vector<u8> meta(huffman_dec_chunk_bytes() * (size_t)nBlocks * maxChunks + 64);
     std::vector<u8*> outPtr(nBlocks);
     for (u32 b = 0; b < nBlocks; b++) outPtr[b] = out[b].data();
-    launch_huffman_decode(nullptr, src, blocks.data(), (int)nBlocks, maxChunks, meta.data(), outPtr.data());
+    launch_huffman_decode(nullptr, src, blocks.data(), (int)nBlocks, maxChunks, meta.data(), outPtr.data(), bsVersion);
     int bad = 0;
     for (u32 b = 0; b < nBlocks; b++) {
         const u32 n = (u32)plain[b].size();

@@ -105,6 +105,12 @@ class Oracle:
         r = self.L.knzo_entropy_decode(ETYPE[name], _buf(enc), len(enc), out, n)
         return r, C.string_at(out, n)
 
+    def set_bs_version(self, v):
+        """Bitstream version the oracle's codecs of this thread work in (6 = current): below 6 its writers produce, and its readers
+        take, the old Huffman chunk / BWT header / stream header layouts (the reference only reads those)."""
+        self.L.knzo_set_bs_version.argtypes = [C.c_int]
+        self.L.knzo_set_bs_version(v)
+
     def forward(self, name, data, dst_cap=None, entropy=None):
         cap = dst_cap if dst_cap is not None else len(data) + 2048
         out = (C.c_uint8 * (max(cap, len(data)) + 2048))()

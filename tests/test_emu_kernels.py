@@ -125,6 +125,9 @@ def test_bwt_inverse_kernels_emulated(tmp_path):
         for order in ("0", "2"):
             r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900, env=dict(os.environ, HIPEMU_ORDER=order))
             assert r.returncode == 0, (i, order, r.stdout[-2000:] + r.stderr[-2000:])
+        # the block header of bitstream versions below 6 (BWTBlockCodec.cpp:140-164), written by the oracle, read by k_bwt_i_header<true>
+        r = subprocess.run([exe, path, "5"], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (i, "v5", r.stdout[-2000:] + r.stderr[-2000:])
 
 
 def test_mtft_kernels_emulated(tmp_path):
@@ -155,6 +158,10 @@ def test_huffman_decoder_kernels_emulated(tmp_path):
     path = str(tmp_path / "huff.bin")
     write_case(path, blocks)
     r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    # the chunk layout of bitstream versions below 6 (HuffmanDecoder.cpp:349-459: one code stream per chunk), k_huff_scan<true> /
+    # k_huff_decode<true>
+    r = subprocess.run([exe, path, "5"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 

@@ -319,6 +319,43 @@ def test_stream_golden(hip, golden):
     assert n >= 15
 
 
+def test_blocks_of_bitstream_versions_below_6(hip, oracle):
+    """SURVEY.md 8(f)4 on the device: knz_params.bs_version 3..5 selects the old Huffman chunk layout (HuffmanDecoder.cpp:349-459: one
+    code stream per chunk; k_huff_scan<true> / k_huff_decode<true>) and the old BWT block header (BWTBlockCodec.cpp:140-164: a mode byte
+    per chunk; k_bwt_i_header<true>). The blocks come from the oracle's writers for those layouts, which tests/test_old_bitstreams.py
+    pins with the reference's decoder. LZ blocks of such streams are refused (their old layout has no reader here)."""
+    hipapi = importlib.import_module("kanzi_amd.hipapi")
+    rng = np.random.default_rng(21)
+    datas = [vectors.make(("text", 70000, 1)), vectors.make(("mixed", 300000, 2))[180000:290000], rng.integers(0, 256, 20000, dtype=np.uint8).tobytes(),
+             b"a" * 40000, b"xyz" * 10, rng.integers(0, 3, 16385, dtype=np.uint8).tobytes()]
+    n = 0
+    for ver in (3, 5):
+        for t, e in (("NONE", "HUFFMAN"), ("BWT", "HUFFMAN"), ("BWT+MTFT+ZRLT", "ANS0"), ("BWT", "NONE"), ("BWT+SRT+ZRLT", "HUFFMAN")):
+            for d in datas:
+                for bs, ck in ((4096, 0), (65536, 32), (1 << 20, 0)):
+                    oracle.set_bs_version(ver)
+                    try:
+                        rc, enc = oracle.compress(d, t, e, bs, checksum=ck, headerless=1)
+                    finally:
+                        oracle.set_bs_version(6)
+                    assert rc == 0
+                    p = hip.params(t, e, bs, ck, bs_version=ver)
+                    d_in, d_out = hip.malloc(len(enc) + 64), hip.malloc(len(d) + bs + 64)
+                    hip.h2d(d_in, enc)
+                    ob, eb, nb = hip.decode_blocks(p, d_in, 8 * len(enc), 0, d_out, len(d) + bs)
+                    out = hip.d2h(d_out, ob)
+                    hip.free(d_in); hip.free(d_out)
+                    assert out == d, (ver, t, e, len(d), bs, ck)
+                    n += 1
+    assert n == 2 * 5 * len(datas) * 3
+    p = hip.params("LZ", "HUFFMAN", 65536, 0, bs_version=5)
+    d_in, d_out = hip.malloc(4096), hip.malloc(70000)
+    with pytest.raises(hipapi.KnzError) as ei:
+        hip.decode_blocks(p, d_in, 8 * 1024, 0, d_out, 65536)
+    assert ei.value.code == 16
+    hip.free(d_in); hip.free(d_out)
+
+
 def test_stream_vs_oracle_ragged(hip, oracle):
     for spec, bs in [(("mixed", 3 * 262144 + 777, 4), 262144), (("text", 100000, 3), 1024), (("rand", 40000, 1), 16384),
                      (("ramp", 15), 1024), (("ramp", 16), 1024), (("ramp", 33), 1024), (("const", 50000, 7), 4096)]:
