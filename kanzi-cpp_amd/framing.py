@@ -33,6 +33,22 @@ def _cksum(ck_size, etype, ttype, block_size, sz_mask, size):
     return ((c >> 23) ^ (c >> 3)) & 0xFFFFFF
 
 
+def _cksum_old(ver, etype, ttype, block_size, sz_mask, size):
+    """io/CompressedInputStream.cpp:622-645 for versions below 6: seeded with the bare version, no checksum size, 16 bits"""
+    H = 0x1E35A7BD
+    c = (H * ver) & _M32
+    c ^= (H * (~etype & _M32)) & _M32
+    nt = ~ttype & 0xFFFFFFFFFFFFFFFF
+    c ^= (H * ((nt >> 32) & _M32)) & _M32
+    c ^= (H * (nt & _M32)) & _M32
+    c ^= (H * (~block_size & _M32)) & _M32
+    if sz_mask:
+        ns = ~size & 0xFFFFFFFFFFFFFFFF
+        c ^= (H * ((ns >> 32) & _M32)) & _M32
+        c ^= (H * (ns & _M32)) & _M32
+    return ((c >> 23) ^ (c >> 3)) & 0xFFFF
+
+
 def make_header(etype, ttype, block_size, checksum_bits=0, orig_size=0):
     """Returns (bytes, nbits)."""
     ck = {0: 0, 32: 1, 64: 2}[checksum_bits]
@@ -68,11 +84,14 @@ def parse_header(data):
     if get(32) != MAGIC:
         raise HeaderError(15, "Invalid stream type")
     ver = get(4)
-    if ver != VERSION:
+    if ver > VERSION:
         raise HeaderError(16, "Cannot read this version of the stream: %d" % ver)
-    ck = get(2)
-    if ck == 3:
-        raise HeaderError(15, "Invalid bitstream, incorrect block checksum size")
+    if ver >= 6:
+        ck = get(2)
+        if ck == 3:
+            raise HeaderError(15, "Invalid bitstream, incorrect block checksum size")
+    else:
+        ck = get(1)                      # io/CompressedInputStream.cpp:555-558: one checksum flag before version 6
     etype = get(5)
     ttype = get(48)
     block_size = get(28) << 4
@@ -80,8 +99,11 @@ def parse_header(data):
         raise HeaderError(2, "Invalid bitstream, incorrect block size: %d" % block_size)
     sz_mask = get(2)
     size = get(16 * sz_mask) if sz_mask else 0
-    get(15)
-    c1 = get(24)
-    if c1 != _cksum(ck, etype, ttype, block_size, sz_mask, size):
+    if ver >= 6:
+        get(15)
+        c1, c2 = get(24), _cksum(ck, etype, ttype, block_size, sz_mask, size)
+    else:
+        c1, c2 = get(16), _cksum_old(ver, etype, ttype, block_size, sz_mask, size)
+    if c1 != c2:
         raise HeaderError(19, "Invalid bitstream, header checksum mismatch")
-    return dict(etype=etype, ttype=ttype, block_size=block_size, checksum_bits=32 * ck, orig_size=size, bits=pos)
+    return dict(etype=etype, ttype=ttype, block_size=block_size, checksum_bits=32 * ck, orig_size=size, bits=pos, bs_version=ver)

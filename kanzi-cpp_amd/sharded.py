@@ -102,7 +102,7 @@ class DeviceRunDecoder:
 
     def __call__(self, chunk, start_bit, end_bit, n_blocks, hdr):
         ctx = self.ctx
-        p = ctx.params(hdr["ttype"], hdr["etype"], hdr["block_size"], hdr["checksum_bits"], self.jobs)
+        p = ctx.params(hdr["ttype"], hdr["etype"], hdr["block_size"], hdr["checksum_bits"], self.jobs, hdr.get("bs_version", 0))
         out_cap = n_blocks * hdr["block_size"] + 64
         d_in, d_out = self.bufs.get("in", len(chunk) + 64), self.bufs.get("out", out_cap)
         ctx.h2d(d_in, chunk)

@@ -57,3 +57,23 @@ def test_old_headers_differ_where_the_reference_says():
     assert oracle.decompress(bytes(bad), 4096)[0] == 19                # ERR_CRC_CHECK
     v7 = bytearray(old); v7[4] = (7 << 4) | (v7[4] & 15)
     assert oracle.decompress(bytes(v7), 4096)[0] == 16                 # ERR_STREAM_VERSION
+
+
+def test_python_header_parser_reads_old_headers():
+    import importlib
+    knzlib.load_pkg()
+    fr = importlib.import_module("kanzi_amd.framing")
+    oracle = knzlib.Oracle()
+    d = vectors.make(("text", 9000, 4))
+    for ver, ck, osz in ((3, 0, 0), (4, 32, None), (5, 0, None), (5, 32, 1 << 40)):
+        enc = old_stream(oracle, ver, d, "BWT+MTFT+ZRLT", "HUFFMAN", 4096, ck, osz)
+        h = fr.parse_header(enc)
+        assert h["bs_version"] == ver and h["checksum_bits"] == ck and h["block_size"] == 4096 and h["etype"] == 1
+        assert h["orig_size"] == (len(d) if osz is None else osz)
+        assert h["bits"] == 32 + 4 + 1 + 5 + 48 + 28 + 2 + 16 * (0 if h["orig_size"] == 0 else (h["orig_size"].bit_length() - 1) // 16 + 1) + 16
+        bad = bytearray(enc); bad[10] ^= 0x40
+        with pytest.raises(fr.HeaderError) as ei:
+            fr.parse_header(bytes(bad))
+        assert ei.value.code in (16, 19, 2)
+    new = oracle.compress(d, "NONE", "ANS0", 4096, orig_size=len(d))[1]
+    assert fr.parse_header(new)["bs_version"] == 6
