@@ -60,9 +60,8 @@ typedef struct {
     int32_t bs_version;      /* decode only: bitstream version of the stream the blocks come from, as
                                 CompressedInputStream puts it in the Context (io/CompressedInputStream.cpp:528-537).
                                 0 or 6 = current. 3..5 select the old layouts the reference still reads: Huffman chunks
-                                (entropy/HuffmanDecoder.cpp:349-459) and the BWT block header
-                                (transform/BWTBlockCodec.cpp:140-164); LZ / LZX blocks of such streams are refused
-                                (transform/LZCodec.cpp:460-463 has a reader for them, this library does not).
+                                (entropy/HuffmanDecoder.cpp:349-459), the BWT block header
+                                (transform/BWTBlockCodec.cpp:140-164) and LZ / LZX blocks (transform/LZCodec.cpp:614-760).
                                 The encoder writes version 6 only, like the reference. */
 } knz_params;
 

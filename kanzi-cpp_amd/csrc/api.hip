@@ -803,13 +803,10 @@ static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_
         if (!transform_supported(tok[i])) return fail(c, KNZ_ERR_INVALID_CODEC, "transform id %d not implemented on device", tok[i]);
     if (!entropy_supported(p->entropy_type)) return fail(c, KNZ_ERR_INVALID_CODEC, "entropy id %d not implemented on device", p->entropy_type);
     if (p->checksum_bits != 0 && p->checksum_bits != 32 && p->checksum_bits != 64) return fail(c, KNZ_ERR_INVALID_PARAM, "checksum must be 0, 32 or 64");
-    // bitstream version of the blocks (0 = current). Below 6 the Huffman chunks and the BWT block header have their old layouts; the
-    // old LZ layouts (LZCodec.cpp:460-463) have no reader here
+    // bitstream version of the blocks (0 = current). Below 6 the Huffman chunks, the BWT block header and the LZ blocks have their
+    // old layouts (HuffmanDecoder.cpp:349-459, BWTBlockCodec.cpp:140-164, LZCodec.cpp:614-760)
     const int bsVersion = (p->bs_version == 0) ? 6 : p->bs_version;
     if (bsVersion < 0 || bsVersion > 6) return fail(c, KNZ_ERR_STREAM_VERSION, "cannot read bitstream version %d", bsVersion);
-    if (bsVersion < 6)
-        for (int i = 0; i < nTok; i++)
-            if (tok[i] == KNZ_T_LZ || tok[i] == KNZ_T_LZX) return fail(c, KNZ_ERR_STREAM_VERSION, "LZ blocks of bitstream version %d are not supported", bsVersion);
     hipStream_t s = c->stream;
 
     BitSrc src;

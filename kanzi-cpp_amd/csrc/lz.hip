@@ -529,6 +529,10 @@ __device__ __forceinline__ u32 lz_get_len(LzByteWin& w, const u8* s, int& pos, i
     return 255 + ((b1 << 16) | (b2 << 8) | b3);
 }
 
+// V5: the block layout of bitstream versions below 6 (LZCodec.cpp:614-760): same four sections, other token -- bits 3-0 match
+// length - minMatch (14: + extension; 15: repeat distance, bit 4 picks the older one, the length is all extension), bit 4 otherwise:
+// one distance byte more than the flag byte's bit 0 gives; minimum match { 4, 9, 6, 6 }[flag bits 2-1]; repeat distances start at 0.
+template <bool V5>
 __global__ __launch_bounds__(64) void k_lz_inverse(XfStage st)
 {
     const int b = blockIdx.x;
@@ -547,8 +551,8 @@ __global__ __launch_bounds__(64) void k_lz_inverse(XfStage st)
         int t = litEnd, m = litEnd + nTok, l = m + nDist;
         const int flags = sgpr((int)src[12]);
         const int maxDist = (flags & 1) ? LZ_MAXD2 : LZ_MAXD1;
-        const int mm = ((flags >> 1) & 7) + 2;
-        int s = 13, rep0 = n, rep1 = n;
+        const int mm = V5 ? ((((flags >> 1) & 3) == 0) ? 4 : ((((flags >> 1) & 3) == 1) ? 9 : 6)) : ((flags >> 1) & 7) + 2;
+        int s = 13, rep0 = V5 ? 0 : n, rep1 = V5 ? 0 : n;
         int settled = 0;                         // output bytes below this index are known to have left the wave
         LzByteWin wt, wm, wl, ws;
         wt.refill(src, t, n, lane); wm.refill(src, m, n, lane); wl.refill(src, l, n, lane); ws.refill(src, s, n, lane);
@@ -557,7 +561,20 @@ __global__ __launch_bounds__(64) void k_lz_inverse(XfStage st)
             const int token = (int)wt.at(src, t, n, lane);
             t++;
             int mlen, dist;
-            if ((token & 0x18) == 0) {
+            if (V5) {
+                mlen = token & 15;
+                if (mlen == 15) {
+                    mlen = mm + (int)lz_get_len(wl, src, l, n, lane);
+                    dist = (token & 0x10) ? rep1 : rep0;
+                } else {
+                    mlen = (mlen == 14) ? 14 + mm + (int)lz_get_len(wl, src, l, n, lane) : mlen + mm;
+                    const int nb = 1 + (flags & 1) + ((token >> 4) & 1);     // most significant first
+                    dist = (int)wm.at(src, m, n, lane);
+                    if (nb >= 2) dist = (dist << 8) | (int)wm.at(src, m + 1, n, lane);
+                    if (nb == 3) dist = (dist << 8) | (int)wm.at(src, m + 2, n, lane);
+                    m += nb;
+                }
+            } else if ((token & 0x18) == 0) {
                 mlen = token & 3;
                 mlen = (mlen == 3) ? 3 + mm + (int)lz_get_len(wl, src, l, n, lane) : mlen + mm;
                 dist = (token & 4) ? rep1 : rep0;
@@ -669,6 +686,11 @@ int launch_lz_forward(hipStream_t s, const XfStage& stAll, int ttype, void* scra
     return 0;
 }
 
-void launch_lz_inverse(hipStream_t s, const XfStage& st) { KScope ks_("k_lz_inverse"); hipLaunchKernelGGL(k_lz_inverse, dim3(st.nBlocks), dim3(64), 0, s, st); }
+void launch_lz_inverse(hipStream_t s, const XfStage& st)
+{
+    KScope ks_("k_lz_inverse");
+    if (st.bsVersion < 6) hipLaunchKernelGGL(k_lz_inverse<true>, dim3(st.nBlocks), dim3(64), 0, s, st);
+    else hipLaunchKernelGGL(k_lz_inverse<false>, dim3(st.nBlocks), dim3(64), 0, s, st);
+}
 
 }  // namespace knz

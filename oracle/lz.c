@@ -48,7 +48,7 @@ static int lz_put_len(uint8_t* p, int len)
 
 static int imin(int a, int b) { return a < b ? a : b; }
 
-int knzo_lz_forward(const uint8_t* src, int n, uint8_t* dst, int dstCap, int extra, int* outLen)
+static int lz_forward_v6(const uint8_t* src, int n, uint8_t* dst, int dstCap, int extra, int* outLen)
 {
     *outLen = 0;
     if (n == 0) return 1;
@@ -178,7 +178,7 @@ static uint32_t lz_get_len(const uint8_t* s, int* pos, int limit)
     return 255 + ((b[1] << 16) | (b[2] << 8) | b[3]);
 }
 
-int knzo_lz_inverse(const uint8_t* src, int n, uint8_t* dst, int dstCap, int* outLen)
+static int lz_inverse_v6(const uint8_t* src, int n, uint8_t* dst, int dstCap, int* outLen)
 {
     *outLen = 0;
     if (n == 0) return 1;
@@ -223,4 +223,137 @@ int knzo_lz_inverse(const uint8_t* src, int n, uint8_t* dst, int dstCap, int* ou
     }
     *outLen = d;
     return ok && s == litEnd;
+}
+
+/* ------------------------------------------------------------------ the block layout of bitstream versions below 6
+ * LZCodec.cpp:614-760 (inverseV5) reads it; the reference has no writer for it any more. Same four sections behind the same 13-byte
+ * header, other token: bits 7-5 literal run (7: + extension), bits 3-0 match length - minMatch (14: + extension; 15: a repeat
+ * distance, length always in the extension, bit 4 picks the older one), bit 4 otherwise: one more distance byte than the flag byte's
+ * bit 0 gives (1 or 2); flag bits 2-1 index the minimum match { 4, 9, 6, 6 }. */
+static int lz_inverse_v5(const uint8_t* src, int n, uint8_t* dst, int dstCap, int* outLen)
+{
+    *outLen = 0;
+    if (n == 0) return 1;
+    if (n < 13) return 0;
+    const int32_t tk0 = (int32_t)ld32(src), nTok = (int32_t)ld32(src + 4), nDist = (int32_t)ld32(src + 8);
+    if (tk0 < 0 || nTok < 0 || nDist < 0) return 0;
+    if (tk0 < 13 || tk0 > n || nTok > n - tk0 || nDist > n - tk0 - nTok) return 0;
+    int t = tk0, m = tk0 + nTok, l = m + nDist;
+    const int srcEnd = tk0 - 13, litEnd = tk0;
+    const int mFlag = src[12] & 1;
+    const int maxDist = mFlag ? LZ_MAXD2 : LZ_MAXD1;
+    static const int MINM[4] = { 4, 9, 6, 6 };
+    const int mm = MINM[(src[12] >> 1) & 3];
+    int s = 13, d = 0, rep0 = 0, rep1 = 0, ok = 1;
+    for (;;) {
+        const int token = (t < n) ? src[t] : 0;
+        t++;
+        if (token >= 32) {
+            const uint32_t lit = (token >= 0xE0) ? 7u + lz_get_len(src, &s, n) : (uint32_t)(token >> 5);
+            if (lit > (uint32_t)(dstCap - d) || lit > (uint32_t)(litEnd - s)) { ok = 0; break; }
+            memcpy(dst + d, src + s, lit);
+            s += (int)lit; d += (int)lit;
+            if (s >= srcEnd) break;
+        }
+        int mlen = token & 0x0F, dist;
+        if (mlen == 15) {
+            mlen = mm + (int)lz_get_len(src, &l, n);
+            dist = (token & 0x10) ? rep1 : rep0;
+        } else {
+            mlen = (mlen == 14) ? 14 + mm + (int)lz_get_len(src, &l, n) : mlen + mm;
+            dist = (m < n) ? src[m] : 0; m++;
+            if (mFlag) { dist = (dist << 8) | ((m < n) ? src[m] : 0); m++; }
+            if (token & 0x10) { dist = (dist << 8) | ((m < n) ? src[m] : 0); m++; }
+        }
+        rep1 = rep0; rep0 = dist;
+        const int end = d + mlen;
+        int ref = d - dist;
+        if (ref < 0 || dist > maxDist || end > dstCap) { ok = 0; break; }
+        while (d < end) dst[d++] = dst[ref++];
+    }
+    *outLen = d;
+    return ok && s == srcEnd + 13;
+}
+
+/* test writer: the current layout of a block, sequence by sequence, in the old tokens */
+static int lz_current_to_v5(const uint8_t* src, int n, uint8_t* dst, int dstCap, int* outLen)
+{
+    *outLen = 0;
+    if (n < 13) return 0;
+    const int litEnd = (int)ld32(src), nTok = (int)ld32(src + 4), nDist = (int)ld32(src + 8);
+    int t = litEnd, m = litEnd + nTok, l = m + nDist;
+    const int mFlag = src[12] & 1;
+    const int mm = ((src[12] >> 1) & 7) + 2;
+    int mmIdx = -1;
+    if (mm == 4) mmIdx = 0; else if (mm == 9) mmIdx = 1; else if (mm == 6) mmIdx = 2;
+    if (mmIdx < 0) return 0;
+    uint8_t* tk = (uint8_t*)malloc((size_t)n + 16);
+    uint8_t* mb = (uint8_t*)malloc((size_t)3 * n + 16);
+    uint8_t* ml = (uint8_t*)malloc((size_t)4 * n + 16);
+    int nt = 0, nm = 0, nl = 0, s = 13, ok = 1;
+    for (;;) {
+        const int token = src[t++];
+        int mlen, dist = 0, rep = -1;
+        if ((token & 0x18) == 0) {
+            mlen = token & 3;
+            mlen = (mlen == 3) ? 3 + mm + (int)lz_get_len(src, &l, n) : mlen + mm;
+            rep = (token & 4) ? 1 : 0;
+        } else {
+            mlen = token & 7;
+            mlen = (mlen == 7) ? 7 + mm + (int)lz_get_len(src, &l, n) : mlen + mm;
+            const int nb = (token >> 3) & 3;
+            for (int k = 0; k < nb; k++) dist = (dist << 8) | src[m++];
+        }
+        int out = token & 0xE0;
+        if (token >= 32) {
+            const uint32_t lit = (token >= 0xE0) ? 7u + lz_get_len(src, &s, n) : (uint32_t)(token >> 5);
+            s += (int)lit;
+            if (s >= litEnd - 13) { tk[nt++] = (uint8_t)out; break; }     /* the last token: literals only */
+        }
+        if (rep >= 0) {
+            out |= 15 | (rep ? 0x10 : 0);
+            nl += lz_put_len(ml + nl, mlen - mm);
+        } else {
+            const int wide = mFlag ? (dist >= 65536) : (dist >= 256);
+            if (wide) { out |= 0x10; }
+            if (mFlag && wide) mb[nm++] = (uint8_t)(dist >> 16);
+            if (mFlag || wide) mb[nm++] = (uint8_t)(dist >> 8);
+            mb[nm++] = (uint8_t)dist;
+            const int c = mlen - mm;
+            if (c >= 14) { out |= 14; nl += lz_put_len(ml + nl, c - 14); } else out |= c;
+        }
+        tk[nt++] = (uint8_t)out;
+    }
+    const int total = litEnd + nt + nm + nl;
+    if (total > dstCap) ok = 0;
+    if (ok) {
+        memcpy(dst, src, (size_t)litEnd);                   /* header + literal section: the same bytes */
+        const uint32_t hd[3] = { (uint32_t)litEnd, (uint32_t)nt, (uint32_t)nm };
+        for (int k = 0; k < 3; k++) for (int j = 0; j < 4; j++) dst[4 * k + j] = (uint8_t)(hd[k] >> (8 * j));
+        dst[12] = (uint8_t)(mFlag | (mmIdx << 1));
+        memcpy(dst + litEnd, tk, (size_t)nt);
+        memcpy(dst + litEnd + nt, mb, (size_t)nm);
+        memcpy(dst + litEnd + nt + nm, ml, (size_t)nl);
+        *outLen = total;
+    }
+    free(tk); free(mb); free(ml);
+    return ok;
+}
+
+int knzo_lz_forward(const uint8_t* src, int n, uint8_t* dst, int dstCap, int extra, int* outLen)
+{
+    if (knzo_get_bs_version() >= 6) return lz_forward_v6(src, n, dst, dstCap, extra, outLen);
+    *outLen = 0;
+    if (n == 0) return 1;
+    uint8_t* cur = (uint8_t*)malloc((size_t)knzo_lz_max_encoded(n) + 64);
+    int cl = 0, ok = lz_forward_v6(src, n, cur, knzo_lz_max_encoded(n), extra, &cl);
+    if (ok) ok = lz_current_to_v5(cur, cl, dst, dstCap, outLen) && *outLen <= n - n / 100;
+    if (!ok) *outLen = 0;
+    free(cur);
+    return ok;
+}
+
+int knzo_lz_inverse(const uint8_t* src, int n, uint8_t* dst, int dstCap, int* outLen)
+{
+    return knzo_get_bs_version() < 6 ? lz_inverse_v5(src, n, dst, dstCap, outLen) : lz_inverse_v6(src, n, dst, dstCap, outLen);
 }

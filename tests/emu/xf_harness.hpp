@@ -4,12 +4,15 @@
 // its .hip file:  XF_TTYPE (kanzi transform id), XF_FWD(st), XF_INV(st)  and  XF_SCRATCH_U32(nBlocks, maxLen); optionally
 // XF_MALFORM(bytes, len, variant, block) with XF_MALFORM_VARIANTS: damaged copies of the oracle's output go through both inverses,
 // which have to agree on accept / refuse and on every byte of what they accept.
+// A second argument below 6 is a bitstream version: the oracle then writes the transform's OLD block layout (the reference only reads
+// those), the kernels' forward is not compared (it writes the current one), their inverse gets the version.
 // Test infrastructure only.
 #include <stdio.h>
 #include <vector>
 
 extern "C" int knzo_transform_forward(int ttype, const uint8_t* src, int n, uint8_t* dst, int dstCap, int etype, int* outLen);
 extern "C" int knzo_transform_inverse(int ttype, const uint8_t* src, int n, uint8_t* dst, int dstCap, int* outLen);
+extern "C" void knzo_set_bs_version(int v);
 
 namespace knz { thread_local ProfHook* g_prof = nullptr; }
 
@@ -17,6 +20,8 @@ int main(int argc, char** argv)
 {
     using namespace knz;
     if (argc < 2) return 2;
+    const int bsVersion = argc > 2 ? atoi(argv[2]) : 6;
+    knzo_set_bs_version(bsVersion);
     FILE* f = fopen(argv[1], "rb");
     if (!f) return 2;
     u32 nBlocks = 0;
@@ -47,11 +52,11 @@ int main(int argc, char** argv)
     std::vector<u32> scratch(XF_SCRATCH_U32((int)nBlocks, maxLen) + 64);
     XfStage st;
     st.src = src.data(); st.dst = dst.data(); st.len = len.data(); st.cap = cap.data(); st.ok = ok.data(); st.newLen = newLen.data();
-    st.nBlocks = (int)nBlocks; st.maxLen = maxLen; st.scratchU32 = scratch.data(); st.entropyType = 5;
+    st.nBlocks = (int)nBlocks; st.maxLen = maxLen; st.scratchU32 = scratch.data(); st.entropyType = 5; st.bsVersion = bsVersion;
     int bad = 0;
     for (u32 b = 0; b < nBlocks; b++) { src[b] = plain[b].data(); dst[b] = fwd[b].data(); len[b] = origN[b]; cap[b] = fcap[b]; }
-    XF_FWD(st);
-    for (u32 b = 0; b < nBlocks; b++) {
+    if (bsVersion >= 6) XF_FWD(st);
+    for (u32 b = 0; b < nBlocks && bsVersion >= 6; b++) {
         const bool same = (ok[b] != 0) == (wantOk[b] != 0) && (!wantOk[b] || ((int)newLen[b] == wantLen[b] && memcmp(fwd[b].data(), want[b].data(), (size_t)wantLen[b]) == 0));
         if (!same) {
             size_t at = 0;

@@ -53,11 +53,6 @@ int knz_hip_decode_blocks(knz_ctx* c, const knz_params* p, const uint8_t* d_in, 
     int64_t done = 0;
     const int ver = p->bs_version == 0 ? 6 : p->bs_version;
     if (ver < 0 || ver > 6) return fail(c, KNZ_ERR_STREAM_VERSION, "unknown bitstream version");
-    if (ver < 6) {
-        /* like the device library: the old LZ layouts have no reader here */
-        uint64_t t = p->transform_type;
-        for (int i = 0; i < 8; i++, t >>= 6) if ((t & 63) == 3 || (t & 63) == 16) return fail(c, KNZ_ERR_STREAM_VERSION, "LZ blocks of bitstream versions below 6 are not supported");
-    }
     knzo_set_bs_version(ver);
     const int rc = knzo_decode_run(d_in, in_bits, start_bit, p->transform_type, p->entropy_type, p->checksum_bits, p->block_size,
                                    max_blocks > 0 ? max_blocks : -1, d_out, out_cap, &ol, &eb, &done);

@@ -68,11 +68,12 @@ def test_c_api_roundtrip_and_bit_exact(tmp_path, oracle):
 
 def test_streams_of_bitstream_versions_below_6(tmp_path, oracle):
     """the header of versions 3-5 (io/CompressedInputStream.cpp:541-558,606-645: one checksum bit, no padding, 16
-    checksum bits) read by the host stream class, the blocks' old Huffman chunk and BWT header layouts read on the device. The
+    checksum bits) read by the host stream class, the blocks' old Huffman chunk, BWT header and LZ layouts read on the device. The
     streams come from the oracle's writers for the old layouts, which tests/test_old_bitstreams.py pins with the reference's decoder."""
     kz = _kanzi()
     for ver, transform, entropy, bs, ck, n in [(5, "BWT", "HUFFMAN", 65536, 0, 300000), (4, "NONE", "HUFFMAN", 4096, 32, 20000),
-                                               (3, "BWT+MTFT+ZRLT", "ANS0", 1 << 20, 0, 1500000), (5, "BWT+SRT+ZRLT", "FPAQ", 16384, 32, 50000)]:
+                                               (3, "BWT+MTFT+ZRLT", "ANS0", 1 << 20, 0, 1500000), (5, "BWT+SRT+ZRLT", "FPAQ", 16384, 32, 50000),
+                                               (5, "LZ", "HUFFMAN", 65536, 0, 200000), (4, "LZX", "ANS1", 1 << 18, 32, 700000)]:
         data = vectors.make(("mixed", n, 7))
         oracle.set_bs_version(ver)
         try:
@@ -91,18 +92,6 @@ def test_streams_of_bitstream_versions_below_6(tmp_path, oracle):
                 break
         d.close()
         assert bytes(out) == data, (ver, transform, entropy)
-    # an old stream with LZ blocks: the reference has a reader for their old layout (LZCodec.cpp:460-463), this library refuses
-    oracle.set_bs_version(5)
-    try:
-        rc, enc = oracle.compress(vectors.make(("text", 50000, 1)), "LZ", "HUFFMAN", 65536, orig_size=50000)
-    finally:
-        oracle.set_bs_version(6)
-    path = str(tmp_path / "oldlz.knz")
-    open(path, "wb").write(enc)
-    with pytest.raises(kz.KanziError) as ei:
-        d = kz.Decompressor(path, buffer_size=65536, jobs=1)
-        d.decompress(65536)
-    assert ei.value.code == 16                                  # ERR_STREAM_VERSION
 
 
 def test_lanes_and_devices_give_the_single_device_stream(tmp_path, oracle, monkeypatch):

@@ -323,14 +323,15 @@ def test_blocks_of_bitstream_versions_below_6(hip, oracle):
     """SURVEY.md 8(f)4 on the device: knz_params.bs_version 3..5 selects the old Huffman chunk layout (HuffmanDecoder.cpp:349-459: one
     code stream per chunk; k_huff_scan<true> / k_huff_decode<true>) and the old BWT block header (BWTBlockCodec.cpp:140-164: a mode byte
     per chunk; k_bwt_i_header<true>). The blocks come from the oracle's writers for those layouts, which tests/test_old_bitstreams.py
-    pins with the reference's decoder. LZ blocks of such streams are refused (their old layout has no reader here)."""
+    pins with the reference's decoder. LZ / LZX blocks in their old token layout (LZCodec.cpp:614-760): k_lz_inverse<true>."""
     hipapi = importlib.import_module("kanzi_amd.hipapi")
     rng = np.random.default_rng(21)
     datas = [vectors.make(("text", 70000, 1)), vectors.make(("mixed", 300000, 2))[180000:290000], rng.integers(0, 256, 20000, dtype=np.uint8).tobytes(),
              b"a" * 40000, b"xyz" * 10, rng.integers(0, 3, 16385, dtype=np.uint8).tobytes()]
     n = 0
     for ver in (3, 5):
-        for t, e in (("NONE", "HUFFMAN"), ("BWT", "HUFFMAN"), ("BWT+MTFT+ZRLT", "ANS0"), ("BWT", "NONE"), ("BWT+SRT+ZRLT", "HUFFMAN")):
+        for t, e in (("NONE", "HUFFMAN"), ("BWT", "HUFFMAN"), ("BWT+MTFT+ZRLT", "ANS0"), ("BWT", "NONE"), ("BWT+SRT+ZRLT", "HUFFMAN"), ("LZ", "HUFFMAN"),
+                     ("LZX", "NONE")):
             for d in datas:
                 for bs, ck in ((4096, 0), (65536, 32), (1 << 20, 0)):
                     oracle.set_bs_version(ver)
@@ -347,8 +348,8 @@ def test_blocks_of_bitstream_versions_below_6(hip, oracle):
                     hip.free(d_in); hip.free(d_out)
                     assert out == d, (ver, t, e, len(d), bs, ck)
                     n += 1
-    assert n == 2 * 5 * len(datas) * 3
-    p = hip.params("LZ", "HUFFMAN", 65536, 0, bs_version=5)
+    assert n == 2 * 7 * len(datas) * 3
+    p = hip.params("NONE", "NONE", 65536, 0, bs_version=7)
     d_in, d_out = hip.malloc(4096), hip.malloc(70000)
     with pytest.raises(hipapi.KnzError) as ei:
         hip.decode_blocks(p, d_in, 8 * 1024, 0, d_out, 65536)

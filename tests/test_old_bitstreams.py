@@ -1,6 +1,6 @@
 """Bitstream versions below 6: the reference still DECODES them -- stream header
 (io/CompressedInputStream.cpp:541-558,606-645), Huffman chunks (entropy/HuffmanDecoder.cpp:349-459), BWT block header
-(transform/BWTBlockCodec.cpp:140-164) -- but writes version 6 only, so there is nothing to take fixtures from. The oracle therefore
+(transform/BWTBlockCodec.cpp:140-164), LZ / LZX blocks (transform/LZCodec.cpp:614-760) -- but writes version 6 only, so there is nothing to take fixtures from. The oracle therefore
 carries writers for the old layouts (oracle/huffman.c, transforms.c, stream.c under knzo_set_bs_version), and what pins them is the
 unmodified reference decoding what they write. Everything else (the device kernels for the old layouts in tests/test_emu_kernels.py
 and tests/test_gpu_parity.py, the host header parser in tests/test_gpu_host_api.py) is checked against streams made this way."""
@@ -11,7 +11,7 @@ import knzlib
 import vectors
 
 CHAINS = [("NONE", "HUFFMAN"), ("BWT", "HUFFMAN"), ("BWT+MTFT+ZRLT", "ANS0"), ("BWT", "NONE"), ("BWT+SRT+ZRLT", "FPAQ"), ("RLT", "HUFFMAN"),
-          ("BWT+RANK+ZRLT", "ANS1")]
+          ("BWT+RANK+ZRLT", "ANS1"), ("LZ", "HUFFMAN"), ("LZX", "ANS0")]
 
 
 def old_stream(oracle, ver, data, transform, entropy, bs, checksum=0, orig_size=None):
