@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box visit: parity suite, bench lines, rocprofv3 kernel stats (developer tool; run through gpurun).
-# usage: tools/gpu_round.sh <tag> [steps...]   steps: tests bench3 bench2 prof3 pmc3
+# usage: tools/gpu_round.sh <tag> [steps...]   steps: tests bench1..5,7 prof3..5 pmc3 trace3 calib limits issue srtprobe cmd:<shell>
 set -u
 TAG=${1:-run}; shift || true
 [ $# -eq 0 ] && set -- tests bench3
@@ -39,6 +39,8 @@ for s in "$@"; do
            ff=$(find $OUT/calib_FETCH_SIZE -name '*counter_collection.csv' | head -1); fw=$(find $OUT/calib_WRITE_SIZE -name '*counter_collection.csv' | head -1)
            [ -n "$ff" ] && [ -n "$fw" ] && python tools/pmc_calibration.py $ff $fw $OUT/membench.txt > $OUT/pmc_calibration.txt && head -24 $OUT/pmc_calibration.txt ;;
     limits) for L in 33554432 58720256 109051904 211957760; do timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu --no-e2e --limit $L 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps({'blocks': d['config']['blocks'], 'bytes': d['config']['corpus_bytes'], 'ms_per_step': d['ms_per_step'], 'MBps': d['value'], 'enc_MBps': d['enc_MBps'], 'dec_MBps': d['dec_MBps']}))" >> $OUT/limits.jsonl; done; echo "limits rc=$?" >> $OUT/summary.txt; cat $OUT/limits.jsonl ;;
+    issue) timeout 120 tools/bin/issuebench > $OUT/issue_rates.txt 2>&1; echo "issue rc=$?" >> $OUT/summary.txt; cat $OUT/issue_rates.txt ;;
+    srtprobe) timeout 200 python tools/srt_probe.py 32 > $OUT/srt_probe.txt 2>&1; echo "srtprobe rc=$?" >> $OUT/summary.txt; tail -4 $OUT/srt_probe.txt ;;
     cmd:*) echo "running custom: ${s#cmd:}"; timeout 600 bash -c "${s#cmd:}" < /dev/null > $OUT/custom.log 2>&1; echo "custom rc=$?" >> $OUT/summary.txt; tail -40 $OUT/custom.log ;;
     *) echo "unknown step: $s" ;;
   esac

@@ -20,6 +20,7 @@ cpif $SRC/pmc3_traffic.txt ${P}_config3_pmc_traffic.txt
 cpif $SRC/pmc_calibration.txt ${P}_pmc_calibration.txt
 cpif $SRC/trace3_bwt_forward.txt ${P}_config3_bwt_forward_trace.txt
 cpif $SRC/limits.jsonl ${P}_config3_limits.jsonl
+cpif $SRC/issue_rates.txt ${P}_issue_rates.txt
 if [ -s $SRC/pmc3_traffic.json ]; then
   python - "$SRC/pmc3_traffic.json" <<'PY'
 import json, sys
