@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64) void k_ans1_encode(BlockView view, int chunksPe
                     const u32 sh = (e.y >> 13) & 0xF;
                     const u32 bias = e.y >> 17;
                     const bool flag = st >= (fr << 20);          // xMax = ((TOP >> 11) << 16) * freq
-                    const u32 m = (u32)__ballot(flag) & 0xF;
+                    const u32 m = (u32)KNZ_BALLOT_OF(flag, 0xFull) & 0xF;    // (lanes 0-3 are in here)
                     if (flag) {
                         const u32 before = __popc(m & lowMask);
                         const u32 a = q - 2 * (before + 1);

@@ -781,7 +781,7 @@ __global__ __launch_bounds__(64) void k_ans1_decode(BitSrc src, DecBlock* __rest
                 const u32 sym = e & 0xFF;
                 st = ((e >> 8) & 0xFFF) * (st >> lr) + slotv - (e >> 20);
                 const bool flag = st < ANS_TOP;
-                const u32 m = (u32)__ballot(flag) & 0xF;
+                const u32 m = (u32)KNZ_BALLOT_OF(flag, 0xFull) & 0xF;        // (lanes 0-3 are in here)
                 if (flag) {
                     const u32 kk = __popc(m & higherMask);
                     st = (st << 16) | (u32)ring16[(q + kk) & (A1_RN - 1)];

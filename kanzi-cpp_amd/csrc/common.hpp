@@ -69,6 +69,13 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 #else
 #define KNZ_WAVE_ORDER() ((void)0)
 #endif
+// A ballot inside divergent control flow: on the GPU the exec mask restricts it to the lanes that are there; the emulation has no
+// exec mask, so the kernel says which lanes those are (all of them call it, nobody else does).
+#ifdef KNZ_EMU
+#define KNZ_BALLOT_OF(pred, lanes) hipemu_ballot_of((pred), (lanes))
+#else
+#define KNZ_BALLOT_OF(pred, lanes) __ballot(pred)
+#endif
 
 // Wave64 scans and reductions on the DPP data path (row shifts inside 16-lane rows, then row_bcast15 / row_bcast31
 // to carry across rows): about a dozen VALU instructions, where the ds_bpermute-based __shfl versions pay an LDS

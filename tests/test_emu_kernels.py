@@ -178,6 +178,33 @@ def test_ans0_decoder_kernels_emulated(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_ans1_decoder_kernels_emulated(tmp_path):
+    # rANS order-1: header scan over the 256 contexts of a chunk, per-context slot tables, chunk decode (the context of a symbol is the
+    # previous byte of its own quarter) against the oracle's streams: text, noise, few symbols, a single symbol, tiny blocks
+    exe = build("ans1_emu", tmp_path)
+    c = knzlib.corpus()
+    rng = np.random.default_rng(19)
+    blocks = [c.text(30000, 1), rng.integers(0, 256, 20000, dtype=np.uint8).tobytes(), bytes(9000), b"ab" * 5000, c.mixed(300000, 2)[250000:270000],
+              rng.integers(0, 3, 7001, dtype=np.uint8).tobytes(), b"x" * 31, b"q" * 33, c.text(4099, 3)]
+    path = str(tmp_path / "ans1.bin")
+    write_case(path, blocks)
+    r = subprocess.run([exe, path], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_ans1_encoder_and_bit_assembly_emulated(tmp_path):
+    # k_ans1_hist / k_ans1_ctx / k_ans1_encode and the bit assembly with 257 slots per chunk, bit for bit against the oracle
+    exe = build("ans1_enc_emu", tmp_path)
+    c = knzlib.corpus()
+    rng = np.random.default_rng(23)
+    blocks = [c.text(30000, 1), rng.integers(0, 256, 12000, dtype=np.uint8).tobytes(), bytes(9000), b"ab" * 5000, c.mixed(300000, 2)[250000:265000],
+              rng.integers(0, 3, 7001, dtype=np.uint8).tobytes(), b"x" * 31, b"q" * 33, c.text(4099, 3)]
+    path = str(tmp_path / "ans1e.bin")
+    write_case(path, blocks)
+    r = subprocess.run([exe, path], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_zrlt_kernels_emulated(tmp_path):
     # ZRLT forward (incl. blocks it refuses at capacity n) and inverse against oracle/transforms.c: sparse data, text, zeros, noise,
     # 0xFF / 0xFE escapes, runs across tile borders

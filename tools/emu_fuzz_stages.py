@@ -1,4 +1,4 @@
-"""Randomised CPU fuzz of the emulated stage kernels (tests/emu/*_emu.cpp): MTFT, ZRLT, ANS0 and Huffman in both directions, SRT,
+"""Randomised CPU fuzz of the emulated stage kernels (tests/emu/*_emu.cpp): MTFT, ZRLT, ANS0, ANS1 and Huffman in both directions, SRT,
 RLT -- random blocks made of text, noise, runs, periodic and sparse pieces, checked against the oracle by the harnesses themselves
 (developer tool).   usage: emu_fuzz_stages.py SEED SECONDS"""
 import os, subprocess, sys, tempfile, time, pathlib
@@ -10,7 +10,7 @@ seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
 rng = np.random.default_rng(seed)
 tmp = pathlib.Path(tempfile.mkdtemp())
-names = ["mtft_emu", "zrlt_emu", "ans0_emu", "ans0_enc_emu", "huff_emu", "huff_enc_emu", "srt_emu", "rlt_emu"]
+names = ["mtft_emu", "zrlt_emu", "ans0_emu", "ans0_enc_emu", "ans1_emu", "ans1_enc_emu", "huff_emu", "huff_enc_emu", "srt_emu", "rlt_emu"]
 exes = {n: T.build(n, tmp) for n in names}
 c = knzlib.corpus()
 

@@ -67,6 +67,8 @@ void block_barrier();
 void wave_exchange(unsigned long long v, unsigned long long out[64], unsigned long long* activeMask);
 // the same rendezvous for a wave that polls memory written by another wave of its block: the other waves run before it returns
 void wave_spin();
+// a rendezvous of the named lanes only (wave intrinsics inside divergent control flow)
+void wave_exchange_subset(unsigned long long v, unsigned long long out[64], unsigned long long lanes);
 
 }  // namespace hipemu
 
@@ -89,6 +91,15 @@ static inline unsigned long long __ballot(int pred)
     hipemu::wave_exchange(pred ? 1ull : 0ull, v, &act);
     unsigned long long m = 0;
     for (int i = 0; i < 64; i++) if (((act >> i) & 1) && v[i]) m |= 1ull << i;
+    return m;
+}
+// ballot among the lanes of `lanes` (every one of them calls it, nobody else does)
+static inline unsigned long long hipemu_ballot_of(int pred, unsigned long long lanes)
+{
+    unsigned long long v[64];
+    hipemu::wave_exchange_subset(pred ? 1ull : 0ull, v, lanes);
+    unsigned long long m = 0;
+    for (int i = 0; i < 64; i++) if (((lanes >> i) & 1) && v[i]) m |= 1ull << i;
     return m;
 }
 static inline int __shfl(int var, int src, int width = 64)

@@ -34,7 +34,12 @@ static Block g_blk;
 static std::vector<char*> g_stacks;
 
 // per-wave rendezvous state
-struct WaveX { unsigned long long val[64]; unsigned long long arrived; int gen; unsigned long long snapshot[64]; unsigned long long snapMask; bool spin; };
+struct WaveX {
+    unsigned long long val[64]; unsigned long long arrived; int gen; unsigned long long snapshot[64]; unsigned long long snapMask; bool spin;
+    // a second meeting point for a SUBSET of the lanes (a wave intrinsic inside divergent control flow: on the device the exec mask
+    // restricts it to the lanes that are there; here the kernel names them, KNZ_BALLOT_OF)
+    unsigned long long subVal[64]; unsigned long long subArrived, subMask; int subGen; unsigned long long subSnapshot[64];
+};
 static std::vector<WaveX> g_wave;
 static int g_barCount, g_barGen;
 
@@ -85,6 +90,23 @@ void wave_exchange(unsigned long long v, unsigned long long out[64], unsigned lo
     *activeMask = w.snapMask;
 }
 
+void wave_exchange_subset(unsigned long long v, unsigned long long out[64], unsigned long long lanes)
+{
+    Fiber* f = g_blk.cur;
+    const int t = (int)(f - &g_blk.fibers[0]);
+    const int wave = t >> 6, lane = t & 63;
+    WaveX& w = g_wave[wave];
+    if (w.subArrived != 0 && w.subMask != lanes) { fprintf(stderr, "hipemu: two subset rendezvous of one wave at a time\n"); abort(); }
+    const int gen = w.subGen;
+    w.subMask = lanes;
+    w.subVal[lane] = v;
+    w.subArrived |= 1ull << lane;
+    f->state = 4;
+    while (w.subGen == gen) yield_to_scheduler();
+    f->state = 0;
+    memcpy(out, w.subSnapshot, sizeof(w.subSnapshot));
+}
+
 // a wave that polls memory another wave of the block writes: a rendezvous after which the scheduler moves on to the other waves
 void wave_spin()
 {
@@ -126,6 +148,14 @@ static void run_block()
                 // wave rendezvous complete? (every live lane of the wave has arrived)
                 WaveX& w = g_wave[wv];
                 const unsigned long long live = live_mask(wv);
+                if (w.subArrived != 0 && w.subArrived == (w.subMask & live)) {
+                    memcpy(w.subSnapshot, w.subVal, sizeof(w.subVal));
+                    const unsigned long long who = w.subArrived;
+                    w.subArrived = 0;
+                    w.subGen++;
+                    for (int l = 0; l < 64; l++) if ((who >> l) & 1) g_blk.fibers[wv * 64 + l].state = 0;
+                    again = true; progress = true;
+                }
                 if (w.arrived != 0 && (w.arrived & live) == live) {
                     bool allWaiting = true;
                     for (int l = 0; l < 64; l++) if ((live >> l) & 1) if (g_blk.fibers[wv * 64 + l].state != 2) allWaiting = false;
