@@ -1154,7 +1154,12 @@ void CompressedInputStream::readHeader()
     _blockSize = int(get(28) << 4);
     if ((_blockSize < 1024) || (_blockSize > 1024 * 1024 * 1024)) throw IOException("Invalid bitstream, incorrect block size", Error::ERR_BLOCK_SIZE);
     const int szMask = int(get(2));
-    if (szMask != 0) { if (!enough24 && szMask > 1) throw IOException("Invalid stream type", Error::ERR_INVALID_FILE); _outputSize = get(uint(16 * szMask)); }
+    // (the whole header has to be there: 160 + 16 szMask bits since version 6, 136 + 16 szMask before)
+    if (szMask != 0) {
+        const size_t need = bsVersion >= 6 ? size_t(20 + 2 * szMask) : size_t((136 + 16 * szMask + 7) / 8);
+        if ((!enough24 && szMask > 1 && bsVersion >= 6) || headerBytesSeen < need) throw IOException("Invalid stream type", Error::ERR_INVALID_FILE);
+        _outputSize = get(uint(16 * szMask));
+    }
     // :606-645: padding and 24 checksum bits since version 6; before, no padding, 16 bits, seeded with the bare version and
     // without the checksum size
     uint32_t ck1, ck2;
