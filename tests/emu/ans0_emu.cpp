@@ -9,6 +9,7 @@
 
 #include <stdio.h>
 #include <vector>
+#include "emu_corrupt.hpp"
 
 extern "C" int64_t knzo_entropy_encode(int etype, const uint8_t* in, uint32_t n, uint8_t* out, size_t cap);
 
@@ -45,6 +46,7 @@ int main(int argc, char** argv)
         maxLen = std::max(maxLen, n);
     }
     fclose(f);
+    emu_corrupt(stream.data(), stream.size(), 1);
     stream.resize((stream.size() + 64 + 3) & ~(size_t)3, 0);
     std::vector<u32> words(stream.size() / 4);
     memcpy(words.data(), stream.data(), stream.size());
@@ -56,6 +58,7 @@ int main(int argc, char** argv)
     for (u32 b = 0; b < nBlocks; b++) outPtr[b] = out[b].data();
     launch_ans0_decode(nullptr, src, blocks.data(), (int)nBlocks, maxChunks, meta.data(), outPtr.data());
     int bad = 0;
+    if (emu_corrupt_on()) { int errs = 0; for (u32 b = 0; b < nBlocks; b++) errs += blocks[b].error != 0; printf("damaged input: %d of %u blocks refused\n", errs, nBlocks); return 0; }
     for (u32 b = 0; b < nBlocks; b++) {
         const u32 n = (u32)plain[b].size();
         if (blocks[b].error || blocks[b].usedBits != blocks[b].bits || memcmp(out[b].data(), plain[b].data(), n) != 0) {

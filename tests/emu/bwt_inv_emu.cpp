@@ -7,6 +7,7 @@
 
 #include <stdio.h>
 #include <vector>
+#include "emu_corrupt.hpp"
 
 extern "C" int knzo_transform_forward(int ttype, const uint8_t* src, int n, uint8_t* dst, int dstCap, int etype, int* outLen);
 extern "C" void knzo_set_bs_version(int v);
@@ -34,6 +35,7 @@ int main(int argc, char** argv)
         int el = 0;
         if (!knzo_transform_forward(1, plain[b].data(), (int)n, enc[b].data(), (int)n + 33, -1, &el)) { printf("oracle forward refused block %u\n", b); return 2; }
         enc[b].resize(el);
+        emu_corrupt(enc[b].data(), enc[b].size() < 64 ? enc[b].size() : 64, b);      // (the header is where damage changes the course; the body is any bytes)
         out[b].assign(n + 64, 0xEE);
         maxLen = std::max(maxLen, (u32)el);
     }
@@ -51,6 +53,7 @@ int main(int argc, char** argv)
     u32 pinned[64];
     const int rc = launch_bwt_inverse(nullptr, st, sc, bytes, pinned);
     if (rc != 0) { printf("FAIL launch rc=%d\n", rc); return 1; }
+    if (emu_corrupt_on()) { int no = 0; for (u32 b = 0; b < nBlocks; b++) no += !ok[b]; printf("damaged input: %d of %u blocks refused\n", no, nBlocks); return 0; }
     int bad = 0;
     for (u32 b = 0; b < nBlocks; b++) {
         const u32 n = (u32)plain[b].size();

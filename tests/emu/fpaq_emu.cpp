@@ -6,6 +6,7 @@
 
 #include <stdio.h>
 #include <vector>
+#include "emu_corrupt.hpp"
 
 extern "C" int64_t knzo_entropy_encode(int etype, const uint8_t* in, uint32_t n, uint8_t* out, size_t cap);
 
@@ -66,6 +67,7 @@ int main(int argc, char** argv)
         }
         // decode the oracle's stream
         std::vector<u8> stream(ref.begin(), ref.begin() + (bits + 7) / 8);
+        emu_corrupt(stream.data(), stream.size(), b);
         stream.resize(stream.size() + 64, 0);
         BitSrc src; src.words = reinterpret_cast<const u32*>(stream.data()); src.nBytes = (u64)((bits + 7) / 8); src.nWords = src.nBytes >> 2; src.limitBits = (u64)bits;
         DecBlock db; memset(&db, 0, sizeof(db));
@@ -74,6 +76,7 @@ int main(int argc, char** argv)
         u8* op = out.data();
         u8* const* outPtr = &op;
         launch_fpaq_decode(nullptr, src, &db, 1, outPtr);
+        if (emu_corrupt_on()) continue;
         if (db.error || memcmp(out.data(), in[b].data(), n) != 0 || db.usedBits != (u64)bits) {
             u32 at = 0;
             while (at < n && out[at] == in[b][at]) at++;

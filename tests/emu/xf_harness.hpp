@@ -9,6 +9,7 @@
 // Test infrastructure only.
 #include <stdio.h>
 #include <vector>
+#include "emu_corrupt.hpp"
 
 extern "C" int knzo_transform_forward(int ttype, const uint8_t* src, int n, uint8_t* dst, int dstCap, int etype, int* outLen);
 extern "C" int knzo_transform_inverse(int ttype, const uint8_t* src, int n, uint8_t* dst, int dstCap, int* outLen);
@@ -66,11 +67,13 @@ int main(int argc, char** argv)
         }
     }
     for (u32 b = 0; b < nBlocks; b++) {
+        if (wantOk[b]) emu_corrupt(want[b].data(), (size_t)wantLen[b], b);
         src[b] = want[b].data(); dst[b] = back[b].data(); ok[b] = 0; newLen[b] = 0;
         len[b] = wantOk[b] ? (u32)wantLen[b] : 0;                // 0 = the block takes no part
         cap[b] = origN[b];
     }
     XF_INV(st);
+    if (emu_corrupt_on()) { int no = 0; for (u32 b = 0; b < nBlocks; b++) no += wantOk[b] && !ok[b]; printf("damaged input: %d of %u blocks refused\n", no, nBlocks); return 0; }
     for (u32 b = 0; b < nBlocks; b++) {
         if (!wantOk[b]) continue;
         const u32 n = origN[b];

@@ -15,13 +15,13 @@ ROOT = knzlib.ROOT
 EMU = os.path.join(ROOT, "tests", "emu")
 
 
-def build(name, tmp_path):
+def build(name, tmp_path, extra=()):
     knzlib.ensure_oracle()
     exe = str(tmp_path / name)
     cmd = ["g++", "-O1", "-std=c++17", "-x", "c++", "-I" + os.path.join(ROOT, "tools", "hipemu"), "-I" + os.path.join(ROOT, "include"), "-I" + EMU,
            "-Wno-unused-value", "-Wno-attributes", "-Wno-format-extra-args", os.path.join(EMU, name + ".cpp"),
            os.path.join(ROOT, "tools", "hipemu", "hipemu.cpp"), "-x", "none", "-L" + os.path.join(ROOT, "oracle"), "-lknz_oracle",
-           "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-o", exe]
+           "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-o", exe] + list(extra)
     subprocess.check_call(cmd)
     return exe
 
@@ -273,3 +273,32 @@ def test_huffman_encoder_and_bit_assembly_emulated(tmp_path):
     write_case(path, blocks)
     r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_decoders_survive_damaged_input_emulated(tmp_path):
+    """src/test/TestMalformedStream.cpp in spirit, below the C ABI and on the CPU: the decoder and inverse kernels on damaged input
+    (bit flips, overwritten bytes and ranges, zeroed tails; tests/emu/emu_corrupt.hpp) must neither touch memory outside their
+    buffers (the drivers are built with AddressSanitizer here: LDS arrays are globals, device buffers heap blocks), nor deadlock
+    (the emulator's scheduler aborts), nor run away (timeouts). What they decode is not compared."""
+    c = knzlib.corpus()
+    rng = np.random.default_rng(31)
+    blocks = [c.text(20000, 1), rng.integers(0, 256, 9000, dtype=np.uint8).tobytes(), b"ab" * 4000, c.mixed(300000, 2)[250000:268000],
+              rng.integers(0, 3, 6000, dtype=np.uint8).tobytes(), b"x" * 31, c.text(4099, 3), bytes(3000)]
+    path = str(tmp_path / "dmg.bin")
+    write_case(path, blocks)
+    runs = [("huff_emu", ["6", "5"]), ("ans0_emu", ["6"]), ("ans1_emu", ["6"]), ("fpaq_emu", ["6"]), ("bwt_inv_emu", ["6", "5"]),
+            ("lz_emu", ["6", "5"]), ("lzx_emu", ["6"]), ("srt_emu", ["6"]), ("zrlt_emu", ["6"]), ("mtft_emu", ["6"]), ("rlt_emu", ["6"]),
+            ("rank_emu", ["6"])]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=6) as pool:                # (compiles and runs are subprocesses: threads are enough)
+        exes = dict(zip([n for n, _ in runs], pool.map(lambda n: build(n, tmp_path, extra=["-fsanitize=address", "-g", "-fno-omit-frame-pointer"]),
+                                                       [n for n, _ in runs])))
+
+        def one(job):
+            name, ver, seed = job
+            env = dict(os.environ, EMU_CORRUPT=str(seed), ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0")
+            r = subprocess.run([exes[name], path] + ([ver] if ver != "6" else []), capture_output=True, text=True, timeout=900, env=env)
+            return job, r
+        jobs = [(name, ver, seed) for name, versions in runs for ver in versions for seed in range(1, 7)]
+        for job, r in pool.map(one, jobs):
+            assert r.returncode == 0 and "AddressSanitizer" not in r.stderr, (job, r.stdout[-500:] + r.stderr[-3000:])
