@@ -254,6 +254,10 @@ def test_block_serial_transforms_emulated(tmp_path, name):
     write_case(path, blocks)
     r = subprocess.run([exe, path], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    if name == "srt":
+        # the inverse's three waves talk through LDS rings: the same with the emulator visiting the waves of a workgroup last to first
+        r = subprocess.run([exe, path], capture_output=True, text=True, timeout=1500, env=dict(os.environ, HIPEMU_WAVE_ORDER="1"))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     if name in ("lz", "lzx"):
         # the token layout of bitstream versions below 6 (LZCodec.cpp:614-760), written by the oracle, read by k_lz_inverse<true>
         r = subprocess.run([exe, path, "5"], capture_output=True, text=True, timeout=1500)

@@ -135,7 +135,11 @@ static void run_block()
     }
     while (g_blk.nLive > 0) {
         bool progress = false;
-        for (int wv = 0; wv < nWaves; wv++) {
+        // HIPEMU_WAVE_ORDER=1: the waves of a workgroup are visited last to first (kernels whose waves talk through LDS must not
+        // depend on who runs first)
+        static const bool revWaves = getenv("HIPEMU_WAVE_ORDER") && atoi(getenv("HIPEMU_WAVE_ORDER")) == 1;
+        for (int wi = 0; wi < nWaves; wi++) {
+            const int wv = revWaves ? nWaves - 1 - wi : wi;
             bool again = true;
             while (again) {
                 again = false;
