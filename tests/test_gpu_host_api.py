@@ -92,6 +92,25 @@ def test_streams_of_bitstream_versions_below_6(tmp_path, oracle):
                 break
         d.close()
         assert bytes(out) == data, (ver, transform, entropy)
+    # headerless: the caller names the version (dData.bsVersion, src/api/Decompressor.hpp:76 -> io/CompressedInputStream.cpp:97-98)
+    data = vectors.make(("text", 90000, 6))
+    oracle.set_bs_version(5)
+    try:
+        rc, enc = oracle.compress(data, "BWT", "HUFFMAN", 32768, headerless=1)
+    finally:
+        oracle.set_bs_version(6)
+    assert rc == 0
+    path = str(tmp_path / "old_headerless.knz")
+    open(path, "wb").write(enc)
+    d = kz.Decompressor(path, buffer_size=32768, headerless=True, transform="BWT", entropy="HUFFMAN", block_size=32768, bsVersion=5)
+    out = bytearray()
+    while True:
+        chunk = d.decompress(32768)
+        out += chunk
+        if len(chunk) < 32768:
+            break
+    d.close()
+    assert bytes(out) == data
 
 
 def test_lanes_and_devices_give_the_single_device_stream(tmp_path, oracle, monkeypatch):
