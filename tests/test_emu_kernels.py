@@ -71,7 +71,7 @@ def test_bwt_forward_kernels_emulated(tmp_path):
     for i, blocks in enumerate(cases):
         path = str(tmp_path / ("case%d.bin" % i))
         write_case(path, blocks)
-        for order in ("0", "1", "2"):       # workgroup dispatch order is not defined: forward, reverse, shuffled
+        for order in (("0", "1", "2") if i in (2, 5, 6) else ("0", "2")):       # workgroup dispatch order is not defined: forward, reverse, shuffled
             r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900, env=dict(os.environ, HIPEMU_ORDER=order))
             assert r.returncode == 0, (i, order, r.stdout[-2000:] + r.stderr[-2000:])
         # the same without the run-length round (run groups refined by doubling like any other group), and with the run groups
@@ -141,7 +141,7 @@ def test_mtft_kernels_emulated(tmp_path):
               c.text(20000, 9)[:16384]]
     path = str(tmp_path / "mtft.bin")
     write_case(path, blocks)
-    for order in ("0", "1", "2"):
+    for order in ("0", "2"):
         r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900, env=dict(os.environ, HIPEMU_ORDER=order))
         assert r.returncode == 0, (order, r.stdout[-2000:] + r.stderr[-2000:])
 
@@ -256,7 +256,9 @@ def test_block_serial_transforms_emulated(tmp_path, name):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     if name == "srt":
         # the inverse's three waves talk through LDS rings: the same with the emulator visiting the waves of a workgroup last to first
-        r = subprocess.run([exe, path], capture_output=True, text=True, timeout=1500, env=dict(os.environ, HIPEMU_WAVE_ORDER="1"))
+        path2 = str(tmp_path / "xf2.bin")
+        write_case(path2, [blocks[0], blocks[3][:9000], blocks[10], blocks[11]])
+        r = subprocess.run([exe, path2], capture_output=True, text=True, timeout=1500, env=dict(os.environ, HIPEMU_WAVE_ORDER="1"))
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     if name in ("lz", "lzx"):
         # the token layout of bitstream versions below 6 (LZCodec.cpp:614-760), written by the oracle, read by k_lz_inverse<true>
@@ -291,8 +293,7 @@ def test_decoders_survive_damaged_input_emulated(tmp_path):
     path = str(tmp_path / "dmg.bin")
     write_case(path, blocks)
     runs = [("huff_emu", ["6", "5"]), ("ans0_emu", ["6"]), ("ans1_emu", ["6"]), ("fpaq_emu", ["6"]), ("bwt_inv_emu", ["6", "5"]),
-            ("lz_emu", ["6", "5"]), ("lzx_emu", ["6"]), ("srt_emu", ["6"]), ("zrlt_emu", ["6"]), ("mtft_emu", ["6"]), ("rlt_emu", ["6"]),
-            ("rank_emu", ["6"])]
+            ("lz_emu", ["6", "5"]), ("srt_emu", ["6"]), ("zrlt_emu", ["6"]), ("rlt_emu", ["6"])]       # (tools/emu_damage_fuzz.py: all of them, longer)
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=6) as pool:                # (compiles and runs are subprocesses: threads are enough)
         exes = dict(zip([n for n, _ in runs], pool.map(lambda n: build(n, tmp_path, extra=["-fsanitize=address", "-g", "-fno-omit-frame-pointer"]),
@@ -303,6 +304,6 @@ def test_decoders_survive_damaged_input_emulated(tmp_path):
             env = dict(os.environ, EMU_CORRUPT=str(seed), ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0")
             r = subprocess.run([exes[name], path] + ([ver] if ver != "6" else []), capture_output=True, text=True, timeout=900, env=env)
             return job, r
-        jobs = [(name, ver, seed) for name, versions in runs for ver in versions for seed in range(1, 7)]
+        jobs = [(name, ver, seed) for name, versions in runs for ver in versions for seed in range(1, 5)]
         for job, r in pool.map(one, jobs):
             assert r.returncode == 0 and "AddressSanitizer" not in r.stderr, (job, r.stdout[-500:] + r.stderr[-3000:])
