@@ -248,7 +248,8 @@ __device__ __forceinline__ u32 srt_rec_index(const SrtInv& w, int b, u32 pos)
 // The chain kernels: three waves per block.
 //   wave 0  the chain. Per run: the front symbol's next record (one LDS read at an address that comes out of registers), the list
 //           update, and the run (symbol, length) dropped into a pair of VGPRs that go to the run ring every 64 runs. The record of
-//           the NEXT run's symbol (list[1], whatever this run's record says) is read a run ahead, so no LDS latency sits on the chain.
+//           the NEXT run's symbol (list[1], whatever this run's record says) is read a run ahead: the rest of the step sits between
+//           the read and its use (44 cycles of LDS latency against ≈ 250 for a step, tools/issuebench.hip).
 //   wave 1  the writer: takes 64 runs at a time from the ring, scans their lengths, stores the bytes.
 //   wave 2  the refiller: a symbol's queue is two halves of 16 records; when the chain finishes a half it posts the symbol, the refiller
 //           loads the next 16 records (four requests side by side) while the chain works through the other half.
