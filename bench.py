@@ -42,6 +42,8 @@ CONFIGS = {
     6: dict(transform="NONE", entropy="ANS1", block=16 << 20, corpus="silesia"),
     # config 3's chain on text (use with --limit 211957760): how the suffix sorter does without the stand-in's periodic segments
     7: dict(transform="BWT+MTFT+ZRLT", entropy="ANS0", block=8 << 20, corpus="enwik9"),
+    # config 3's chain on text with 30 % copied spans (1-64 KiB): long common prefixes, i.e. many doubling rounds of the suffix sorter
+    8: dict(transform="BWT+MTFT+ZRLT", entropy="ANS0", block=8 << 20, corpus="repeats"),
 }
 
 # Kernel name (the KScope label of the launch) -> pipeline stage. First matching prefix wins.
@@ -256,6 +258,8 @@ def main():
     cfg = CONFIGS[args.config]
     data, desc = corpus.load(cfg["corpus"], args.limit or None)
     n_total = len(data)
+    import hashlib
+    input_md5 = hashlib.md5(data).hexdigest()
     bs = cfg["block"]
     nblocks_total = (n_total + bs - 1) // bs
     # this rank's share of the corpus
@@ -410,6 +414,8 @@ def main():
                     e2e = end_to_end(data, cfg)
                 except Exception as ex:      # the host library is a separate .so; its absence must not hide the device line
                     e2e = dict(error=str(ex))
+        if "k_bwt_f_round" in kern:
+            roofline["bwt_doubling_rounds"] = round(kern["k_bwt_f_round"]["launches_per_step"], 1)
         ms_per_step = elapsed / args.steps * 1e3
         job_bytes = n_total if (world == 1 or args.scaling == "strong") else world * n_total
         value = job_bytes / (elapsed / args.steps) / 1e6
@@ -421,7 +427,7 @@ def main():
             "scaling": "weak" if (world > 1 and args.scaling == "weak") else ("strong" if world > 1 else "weak"),
             "vs_baseline": None, "dtype": "u8", "data": "real" if real else "synthetic",
             "config": {"workload": "-t %s -e %s -b %dm, %s" % (cfg["transform"], cfg["entropy"], bs >> 20, desc),
-                       "corpus_bytes": n_total, "blocks": nblocks_total, "compressed_bytes": comp_total,
+                       "corpus_bytes": n_total, "input_md5": input_md5, "blocks": nblocks_total, "compressed_bytes": comp_total,
                        "bytes_rank0": n, "blocks_rank0": cnt,
                        "parallelism": ("1 GPU" if world == 1 else
                                        "blocks of one corpus sharded over %d ranks in contiguous ranges, no collective" % world if args.scaling == "strong"
@@ -432,6 +438,12 @@ def main():
             "cpu_baseline": cpu,
             "end_to_end": e2e,
         }
+        if world > 1 and args.scaling == "strong":
+            # what block granularity allows: the largest share is ceil(blocks / N) blocks, so N ranks can be at most blocks / ceil(blocks / N)
+            # times faster than one; the driver computes the efficiency from the per-N values, this is the bound to hold it against
+            most = max(c for _, c in sharded.block_ranges(n_total, bs, world))
+            result["config"]["block_count_ceiling"] = round(nblocks_total / most, 3) if most else None
+            result["config"]["blocks_largest_share"] = most
         print(json.dumps(result))
     if world > 1:
         dist.barrier()

@@ -5,6 +5,15 @@ output could be recorded):
   text(N, seed)  -- Zipf-skewed 4096-word vocabulary over 26 letters, splitmix64 draws
   mixed(N, seed) -- 256 KiB segments cycling ramp / text / random / sparse zeros / runs
 MD5(text(4194304,1)) = 533763267af795f681817771bd17d0cc, MD5(mixed(4194304,2)) = 4f3716bf4e8db9d931141d3c144dfc8c.
+
+Round 4 adds inputs that are hard for a suffix sorter (long common prefixes; the shapes members of silesia.tar such as nci, xml
+and mozilla have), used by the parity tests at full block size and by `bench.py --config 8`:
+  repeats(N, seed)       -- text in which ~30 % of the bytes are copies of an earlier span (1-64 KiB, at most 4 MiB back, a few
+                            single-byte edits per copy)
+  tile(N, seed, period)  -- text(period, seed) repeated: with period = half a block every block is X || X
+  periodic(N, seed, p)   -- a random unit of p bytes repeated (p = 3, 5, 7: periods no power of two divides)
+  fibword(N)             -- the Fibonacci word over {a, b} (every prefix doubling round keeps groups alive)
+  dna(N, seed)           -- random ACGT with ~25 % copied spans
 """
 import os
 
@@ -121,13 +130,74 @@ def mixed(n, seed):
     return out[:n].tobytes()
 
 
+def _copy_spans(arr, seed, frac, min_len, max_len, back, alphabet):
+    """Overwrites about frac * len(arr) bytes with copies of earlier spans (src within `back` bytes in front of the copy), then
+    edits up to three bytes of each copy. Sequential: later copies see earlier ones."""
+    n = len(arr)
+    if n < 4 * min_len:
+        return arr
+    max_len = min(max_len, n // 4)
+    want = int(frac * n)
+    done = 0
+    k = 1
+    al = np.frombuffer(alphabet, dtype=np.uint8)
+    while done < want:
+        r = _sm(seed ^ 0xC0FFEE, 1024 * 6, k).reshape(1024, 6)
+        k += 1024 * 6
+        for r0, r1, r2, r3, r4, r5 in r.tolist():
+            L = min_len + r0 % (max_len - min_len + 1)
+            dst = L + r1 % (n - 2 * L + 1)
+            gap = r2 % min(dst - L + 1, back)
+            src = dst - L - gap
+            arr[dst:dst + L] = arr[src:src + L]
+            for e, rr in enumerate((r3, r4, r5)):
+                if e < r3 % 4:
+                    arr[dst + (rr >> 8) % L] = al[(rr >> 40) % len(al)]
+            done += L
+            if done >= want:
+                break
+    return arr
+
+
+def repeats(n, seed):
+    a = np.frombuffer(text(n, seed + 7), dtype=np.uint8).copy()
+    return _copy_spans(a, seed, 0.30, 1024, 65536, 4 << 20, _LET.encode()).tobytes()
+
+
+def tile(n, seed, period):
+    unit = np.frombuffer(text(period, seed), dtype=np.uint8)
+    return np.tile(unit, (n + period - 1) // period)[:n].tobytes()
+
+
+def periodic(n, seed, p):
+    unit = (_sm(seed ^ 0x9E71, p) % np.uint64(251)).astype(np.uint8)
+    return np.tile(unit, (n + p - 1) // p)[:n].tobytes()
+
+
+def fibword(n):
+    a, b = b"a", b"b"              # s1 = a, s0 = b, s(k) = s(k-1) + s(k-2)
+    while len(a) < n:
+        a, b = a + b, a
+    return a[:n]
+
+
+def dna(n, seed):
+    a = np.frombuffer(b"ACGT", dtype=np.uint8)[(_sm(seed ^ 0xD7A, n) >> np.uint64(33)) % np.uint64(4)].copy()
+    return _copy_spans(a, seed + 1, 0.25, 256, 32768, 4 << 20, b"ACGT").tobytes()
+
+
 _REAL = {"silesia": "silesia.tar", "enwik9": "enwik9", "enwik8": "enwik8"}
 
 
 def find_real(name):
-    """Look for a real corpus file on this box ($KNZ_CORPUS_DIR, ~, /data, /datasets)."""
+    """Look for a real corpus file on this box ($KNZ_CORPUS_DIR, the working directory, ~, /root, /data, /datasets, /mnt, /workspace,
+    each also with a corpus/ or corpora/ subdirectory)."""
     fn = _REAL[name]
-    dirs = [os.environ.get("KNZ_CORPUS_DIR"), os.path.expanduser("~"), "/data", "/datasets"]
+    roots = [os.environ.get("KNZ_CORPUS_DIR"), os.getcwd(), os.path.expanduser("~"), "/root", "/data", "/datasets", "/mnt", "/workspace", "/tmp"]
+    dirs = []
+    for r in roots:
+        if r:
+            dirs += [r, os.path.join(r, "corpus"), os.path.join(r, "corpora"), os.path.join(r, "silesia")]
     for d in dirs:
         if d and os.path.isfile(os.path.join(d, fn)):
             return os.path.join(d, fn)
@@ -142,6 +212,9 @@ def load(name, limit=None):
             with open(p, "rb") as f:
                 return f.read(4194304), "enwik8[:4MiB] (real)"
         return text(4194304, 1), "text(4194304,1) stand-in for enwik8 head"
+    if name == "repeats":              # (no real counterpart: the long-common-prefix stand-in, bench.py --config 8)
+        n = 211957760 if limit is None else min(limit, 211957760)
+        return repeats(n, 3), "repeats(%d,3) stand-in for long-common-prefix data (text with 30%% copied spans of 1-64 KiB)" % n
     p = find_real(name)
     if p:
         with open(p, "rb") as f:

@@ -1690,7 +1690,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     while (2 * h <= (u32)nsym) h <<= 1;
     while (surv || nMed || nLarge) {
         if (h > bv.VS) return -5;                                    // cannot happen: suffixes of one block differ in length
-        hipMemsetAsync(w.counters, 0, 64, s);
+        { KScope ks_("k_bwt_f_round"); hipMemsetAsync(w.counters, 0, 64, s); }      // (the scope counts the doubling rounds for the profile)
         const int nxt = cur ^ 1;
         // -- all keys first
         if (surv) { KScope ks_("k_bwt_f_gather_small"); hipLaunchKernelGGL(k_bwt_f_gather_small, dim3(nTiles), dim3(256), 0, s, v, h); }

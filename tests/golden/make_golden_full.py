@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Generates tests/golden/golden_full.json: md5 + length of the UNMODIFIED reference's .knz (oracle/_ref) for the
-BASELINE.json configurations at their own block sizes (vectors.FULL_CASES), 64 MiB inputs, -j 1.
+BASELINE.json configurations at their own block sizes (vectors.FULL_CASES), 64 MiB inputs, -j 1, and for the long-common-prefix
+inputs of vectors.HARD_CASES at 8 MiB / 32 MiB blocks.
 
     make -C oracle ref && python tests/golden/make_golden_full.py
 
@@ -20,7 +21,7 @@ import vectors  # noqa: E402
 def main():
     R = knzlib.Ref()
     out = []
-    for cfg, spec, t, e, bs in vectors.FULL_CASES:
+    for cfg, spec, t, e, bs in vectors.FULL_CASES + vectors.HARD_CASES:
         d = vectors.make(spec)
         rc, o = R.compress(d, t, e, bs, jobs=1, orig_size=len(d))
         assert rc == 0, (cfg, rc)

@@ -423,6 +423,13 @@ def test_full_size_reference_stream_config5_lzx_ans1_16m(hip):
     _full_case(hip, 5)
 
 
+@pytest.mark.parametrize("name", [c[0] for c in vectors.HARD_CASES])
+def test_long_common_prefix_inputs_at_full_block_size(hip, name):
+    """Inputs a prefix-doubling sorter finds hard (copies with edits, X || X, periods 3 / 5 / 7 / 768, the Fibonacci word, DNA with
+    repeats, one constant block) at 8 MiB / 32 MiB blocks: the device stream must be the reference's .knz (digests from oracle/_ref)."""
+    _full_case(hip, name)
+
+
 def test_full_size_determinism(hip):
     # two encodes of the same batch give the same bytes (no dependence on what earlier calls left in the workspaces)
     d = vectors.make(("mixed", 32 << 20, 2))

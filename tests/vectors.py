@@ -49,6 +49,16 @@ def make(spec):
         rng = np.random.default_rng(spec[3])
         w = np.array([spec[2] ** (-i / 10.0) for i in range(spec[4])])
         return bytes(rng.choice(spec[4], size=spec[1], p=w / w.sum()).astype(np.uint8))
+    if kind == "repeats":
+        return c.repeats(spec[1], spec[2])
+    if kind == "tile":                # text(period, seed) repeated
+        return c.tile(spec[1], spec[2], spec[3])
+    if kind == "periodic":            # random unit of spec[3] bytes repeated
+        return c.periodic(spec[1], spec[2], spec[3])
+    if kind == "fibword":
+        return c.fibword(spec[1])
+    if kind == "dna":
+        return c.dna(spec[1], spec[2])
     if kind == "bytes":
         return bytes.fromhex(spec[1])
     if kind == "str":
@@ -111,4 +121,19 @@ FULL_CASES = [
     (3, ("mixed", 64 << 20, 2), "BWT+MTFT+ZRLT", "ANS0", 8 << 20),
     (4, ("text", 64 << 20, 1), "BWT+SRT+ZRLT", "FPAQ", 32 << 20),
     (5, ("mixed", 64 << 20, 2), "LZX", "ANS1", 16 << 20),
+]
+
+# Inputs with long common prefixes at the headline chain's own block size (8 MiB): what a prefix-doubling suffix sorter finds hard and
+# what divsufsort (the reference) does not care about. Same fixture file, config "hard:<name>".
+HARD_CASES = [
+    ("hard:repeats", ("repeats", 16 << 20, 3), "BWT+MTFT+ZRLT", "ANS0", 8 << 20),
+    ("hard:xx", ("tile", 16 << 20, 1, 4 << 20), "BWT+MTFT+ZRLT", "ANS0", 8 << 20),
+    ("hard:period3", ("periodic", 8 << 20, 5, 3), "BWT+MTFT+ZRLT", "ANS0", 8 << 20),
+    ("hard:period5", ("periodic", (8 << 20) - 3, 6, 5), "BWT+MTFT+ZRLT", "ANS0", 8 << 20),
+    ("hard:period7", ("periodic", 8 << 20, 7, 7), "BWT+MTFT+ZRLT", "ANS0", 8 << 20),
+    ("hard:period768", ("periodic", 8 << 20, 8, 768), "BWT+MTFT+ZRLT", "ANS0", 8 << 20),
+    ("hard:fibword", ("fibword", 8 << 20), "BWT+MTFT+ZRLT", "ANS0", 8 << 20),
+    ("hard:dna", ("dna", 16 << 20, 4), "BWT+MTFT+ZRLT", "ANS0", 8 << 20),
+    ("hard:const", ("const", 8 << 20, 65), "BWT+MTFT+ZRLT", "ANS0", 8 << 20),
+    ("hard:repeats_srt", ("repeats", 32 << 20, 5), "BWT+SRT+ZRLT", "ANS0", 32 << 20),
 ]

@@ -19,6 +19,9 @@ for s in "$@"; do
     bench1) timeout 600 python bench.py --config 1 --steps 10 --warmup 3 --no-e2e > $OUT/bench1.json 2> $OUT/bench1.err; echo "bench1 rc=$?" >> $OUT/summary.txt; cat $OUT/bench1.json ;;
     bench3x2) timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 2 --warmup 1 --dist-backend gloo --share-device > $OUT/bench3x2.json 2> $OUT/bench3x2.err; echo "bench3x2 rc=$?" >> $OUT/summary.txt; tail -2 $OUT/bench3x2.json ;;
     bench7) timeout 600 python bench.py --config 7 --limit 211957760 --steps 3 --warmup 1 --no-e2e > $OUT/bench7.json 2> $OUT/bench7.err; echo "bench7 rc=$?" >> $OUT/summary.txt; cat $OUT/bench7.json ;;
+    bench8) timeout 600 python bench.py --config 8 --steps 3 --warmup 1 --no-e2e ${BENCH8_ARGS:-} > $OUT/bench8.json 2> $OUT/bench8.err; echo "bench8 rc=$?" >> $OUT/summary.txt; cat $OUT/bench8.json ;;
+    bench8q) timeout 600 python bench.py --config 8 --steps 3 --warmup 1 --no-e2e --no-cpu > $OUT/bench8q.json 2> $OUT/bench8q.err; echo "bench8q rc=$?" >> $OUT/summary.txt; cat $OUT/bench8q.json ;;
+    hard) timeout 420 python tools/gpu_hard.py > $OUT/hard.txt 2>&1; echo "hard rc=$?" >> $OUT/summary.txt; cat $OUT/hard.txt ;;
     bench4) timeout 900 python bench.py --config 4 --limit 134217728 --steps 1 --warmup 1 --no-e2e > $OUT/bench4.json 2> $OUT/bench4.err; echo "bench4 rc=$?" >> $OUT/summary.txt; cat $OUT/bench4.json ;;
     bench5) timeout 900 python bench.py --config 5 --steps 2 --warmup 1 --no-e2e > $OUT/bench5.json 2> $OUT/bench5.err; echo "bench5 rc=$?" >> $OUT/summary.txt; cat $OUT/bench5.json ;;
     prof3) (cd /tmp && export KNZ_BWT_SPLIT=1 && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof3 -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-e2e > $GRAFT_REPO_ROOT/$OUT/prof3.log 2>&1); echo "prof3 rc=$?" >> $OUT/summary.txt
