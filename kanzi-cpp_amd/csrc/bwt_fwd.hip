@@ -52,6 +52,10 @@ struct FwdView {
     u32* gnew;           // group starts found in the current round; merged into gbits when the round is over (a window must
                          // not see the subgroups a neighbouring window has just made: their keys belong to the old order)
     u32* counters;       // [0] != 0: small groups are left, [1] medium descriptors, [2] large descriptors, [3] members of large groups
+    const u32* ovr;      // [total] by slot: run length R of the members of a group the run round left unresolved (valid where rtbits is set)
+    const u32* rtbits;   // bit per slot: the slot belongs to such a group. Its members are c^R followed by different things, so the key that
+                         // tells them apart is the label R positions on -- the doubling rounds look there (at max(R, h)) instead of h positions
+                         // on, where for h < R they would find the same run again and learn nothing (null: no run round)
     uint2* medStage;     // medium groups found in the current round, one slot per 256 slots of SA (a medium group has more than 256
                          // members, so two of them never start in the same 256): written without atomics, compacted -- in slot order --
                          // into the next round's descriptor list by k_bwt_f_med_compact
@@ -367,12 +371,14 @@ __global__ __launch_bounds__(256) void k_bwt_f_r0_place(FwdView v, const u32* __
         if (hKind[k] >= 0) agg_write(A, v, hKind[k], hLocal[k], slot0 + (u32)tid + 256u * (u32)k, hSize[k], largeNext, runList);
 }
 
-__global__ __launch_bounds__(256) void k_bwt_f_gather_small(FwdView v, u32 h)
+__global__ __launch_bounds__(256) void k_bwt_f_gather_small(FwdView v, u32 h, int stats)
 {
     __shared__ SmWindow W;
     __shared__ int sAny;
     __shared__ int sBlk;
+    __shared__ u32 sRt[64];
     const u32 slot0 = blockIdx.x * SM_TS;
+    if (threadIdx.x >= 64 && threadIdx.x < 128) sRt[threadIdx.x - 64] = v.rtbits ? v.rtbits[(slot0 >> 5) + threadIdx.x - 64] : 0u;
     if (!sm_load_window(v, slot0, W, &sAny)) return;
     if (threadIdx.x == 0) sBlk = find_block(v.base, v.nBlocks, slot0 < v.total ? slot0 : v.total - 1);
     __syncthreads();
@@ -385,7 +391,10 @@ __global__ __launch_bounds__(256) void k_bwt_f_gather_small(FwdView v, u32 h)
         const u32 slot = slot0 + i;
         int b = b0;
         while (slot >= v.base[b + 1]) b++;
-        v.K[slot] = gather_key(v.ISA, v.SA[slot], h, v.base[b], v.base[b + 1]);
+        u32 off = h;
+        if ((sRt[i >> 5] >> (i & 31)) & 1u) { const u32 r = v.ovr[slot]; off = r > h ? r : h; }
+        v.K[slot] = gather_key(v.ISA, v.SA[slot], off, v.base[b], v.base[b + 1]);
+        if (stats) { atomicAdd(&v.counters[10], 1u); if (i == s) atomicAdd(&v.counters[11], 1u); }      // (developer statistics, knob bwt_stats)
     }
 }
 
@@ -519,7 +528,7 @@ __global__ __launch_bounds__(256) void k_bwt_f_sort_small_text(BwtView bv, FwdVi
 // The 32 workgroups that run on one XCD (workgroup index mod 8 -- an observed placement, used for speed only) walk through one
 // contiguous eighth of the list side by side, so that a line of ISA fetched for one group is found in that XCD's L2 by the
 // 31 groups next to it, instead of being fetched from memory once per group.
-__global__ __launch_bounds__(1024) void k_bwt_f_gather_desc(FwdView v, const uint2* __restrict__ desc, u32 nDesc, u32 h, uint2* __restrict__ descInfo)
+__global__ __launch_bounds__(1024) void k_bwt_f_gather_desc(FwdView v, const uint2* __restrict__ desc, u32 nDesc, u32 h, uint2* __restrict__ descInfo, int stats)
 {
     __shared__ int sBlk;
     const u32 xcd = blockIdx.x & 7, lanesPerXcd = gridDim.x >> 3, slot = blockIdx.x >> 3;      // the grid is a multiple of 8 workgroups
@@ -530,8 +539,10 @@ __global__ __launch_bounds__(1024) void k_bwt_f_gather_desc(FwdView v, const uin
         if (threadIdx.x == 0) sBlk = find_block(v.base, v.nBlocks, d.x);
         __syncthreads();
         const u32 bb = v.base[sBlk], be = v.base[sBlk + 1];
+        u32 off = h;                                        // (uniform for the group)
+        if (v.rtbits && ((v.rtbits[d.x >> 5] >> (d.x & 31)) & 1u)) { const u32 r = v.ovr[d.x]; off = r > h ? r : h; }
         // (block base, label the members carry): what the sorting kernel needs per group without a chain of dependent loads of its own
-        if (threadIdx.x == 0) descInfo[g] = make_uint2(bb, v.ISA[v.SA[d.x]]);
+        if (threadIdx.x == 0) { descInfo[g] = make_uint2(bb, v.ISA[v.SA[d.x]]); if (stats) atomicAdd(&v.counters[12], d.y); }
         // eight members per thread at a time: all position loads, then all key loads, then the stores -- two memory
         // latencies per batch instead of two per member
         for (u32 i0 = 0; i0 < d.y; i0 += 8 * 1024) {
@@ -539,7 +550,7 @@ __global__ __launch_bounds__(1024) void k_bwt_f_gather_desc(FwdView v, const uin
 #pragma unroll
             for (int k = 0; k < 8; k++) { const u32 i = i0 + (u32)k * 1024u + threadIdx.x; gp[k] = (i < d.y) ? v.SA[d.x + i] : bb; }
 #pragma unroll
-            for (int k = 0; k < 8; k++) { const u32 i = i0 + (u32)k * 1024u + threadIdx.x; key[k] = (i < d.y) ? gather_key(v.ISA, gp[k], h, bb, be) : 0u; }
+            for (int k = 0; k < 8; k++) { const u32 i = i0 + (u32)k * 1024u + threadIdx.x; key[k] = (i < d.y) ? gather_key(v.ISA, gp[k], off, bb, be) : 0u; }
 #pragma unroll
             for (int k = 0; k < 8; k++) { const u32 i = i0 + (u32)k * 1024u + threadIdx.x; if (i < d.y) v.K[d.x + i] = key[k]; }
         }
@@ -784,7 +795,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 128) void k_bwt_f_sort_medium(Fw
         u32 c = 0;
         for (u32 i = (u32)tid; i < n; i += THREADS) c += (L.oK[i] == m) ? 1u : 0u;
         c = med_block_sum(L, c);
-        if (c < n && 2 * c >= n && superList != nullptr && m == info.y - info.x + 1u) {
+        if (c < n && 2 * c >= n && superList != nullptr && m == info.y - info.x + 1u && !(v.rtbits && ((v.rtbits[gs >> 5] >> (gs & 31)) & 1u))) {
             // the majority looks at the group itself (a periodic stretch whose period divides h): k_bwt_f_super finishes it in one round
             if (tid == 0) { const u32 at = atomicAdd(&v.counters[7], 1u); superList[at] = make_uint4(gs, n, info.x, info.y); }
             __syncthreads();
@@ -1047,7 +1058,9 @@ __global__ __launch_bounds__(256) void k_bwt_f_large_keys(FwdView v, const uint2
     const u32 slot = d.x + (j - loff[lo]);
     const int b = find_block(v.base, v.nBlocks, d.x);
     const u32 gp = v.SA[slot];
-    const u32 key = gather_key(v.ISA, gp, h, v.base[b], v.base[b + 1]);
+    u32 off = h;
+    if (v.rtbits && ((v.rtbits[d.x >> 5] >> (d.x & 31)) & 1u)) { const u32 r = v.ovr[d.x]; off = r > h ? r : h; }
+    const u32 key = gather_key(v.ISA, gp, off, v.base[b], v.base[b + 1]);
     keys[j] = (KEY)(((u64)lo << kbits) | (u64)key);
     vals[j] = gp;
 }
@@ -1065,7 +1078,8 @@ __global__ __launch_bounds__(256) void k_bwt_f_large_flags(const KEY* __restrict
 template <class KEY>
 __global__ __launch_bounds__(256) void k_bwt_f_large_place(FwdView v, const uint2* __restrict__ desc, const u32* __restrict__ loff, u32 L, int kbits,
                                                            const KEY* __restrict__ keys, const u32* __restrict__ vals, const u32* __restrict__ head,
-                                                           const u32* __restrict__ nextRev, uint2* __restrict__ medNext, uint2* __restrict__ largeNext)
+                                                           const u32* __restrict__ nextRev, uint2* __restrict__ medNext, uint2* __restrict__ largeNext,
+                                                           const u32* __restrict__ memberR, u32* __restrict__ ovr, u32* __restrict__ rtbits)
 {
     const u32 j = blockIdx.x * 256 + threadIdx.x;
     u32 surv = 0;
@@ -1084,6 +1098,7 @@ __global__ __launch_bounds__(256) void k_bwt_f_large_place(FwdView v, const uint
         v.SA[gs + (j - off)] = gp;
         if (nh != off) v.ISA[gp] = gs + (nh - off);
         mySlot = gs + (j - off);
+        if (memberR != nullptr) ovr[mySlot] = memberR[j];          // the run round: what the doubling rounds need to look behind the run
         if (nh == j) {
             const u32 nxt = (j + 1 < L) ? nextRev[L - 2 - j] : L;
             setBit = (j != off);
@@ -1102,6 +1117,19 @@ __global__ __launch_bounds__(256) void k_bwt_f_large_place(FwdView v, const uint
     const int lane = (int)(threadIdx.x & 63);
     const u32 s0 = (u32)__shfl((int)mySlot, 0, 64);
     const bool inLine = (j < L) && (mySlot == s0 + (u32)lane);
+    if (rtbits != nullptr) {
+        const unsigned long long rm = __ballot(inLine);
+        if (j < L && !inLine) atomicOr(&rtbits[mySlot >> 5], 1u << (mySlot & 31));
+        if (rm != 0 && lane == 0) {
+            const u32 w0 = s0 >> 5, sh = s0 & 31;
+            const u32 p0 = (u32)(rm << sh);
+            const u32 p1 = sh ? (u32)(rm >> (32 - sh)) : (u32)(rm >> 32);
+            const u32 p2 = sh ? (u32)(rm >> (64 - sh)) : 0u;
+            if (p0) atomicOr(&rtbits[w0], p0);
+            if (p1) atomicOr(&rtbits[w0 + 1], p1);
+            if (p2) atomicOr(&rtbits[w0 + 2], p2);
+        }
+    }
     const unsigned long long mask = __ballot(setBit && inLine);
     if (setBit && !inLine) atomicOr(&v.gnew[mySlot >> 5], 1u << (mySlot & 31));
     if (mask != 0 && lane == 0) {
@@ -1328,7 +1356,7 @@ __global__ __launch_bounds__(256) void k_bwt_f_run_members(const u32* __restrict
 
 // sorted members -> the (key, position) pairs k_bwt_f_large_flags / k_bwt_f_large_place work on: key = [class | hi | T]
 __global__ __launch_bounds__(256) void k_bwt_f_run_expand(const u64* __restrict__ mkeys, u32 M, const u64* __restrict__ sKey, const u32* __restrict__ sE,
-                                                          int kbits, int hbits, u64* __restrict__ keys, u32* __restrict__ vals)
+                                                          int kbits, int hbits, u64* __restrict__ keys, u32* __restrict__ vals, u32* __restrict__ Rout)
 {
     const u32 j = blockIdx.x * 256 + threadIdx.x;
     if (j >= M) return;
@@ -1342,6 +1370,7 @@ __global__ __launch_bounds__(256) void k_bwt_f_run_expand(const u64* __restrict_
     const u32 Rr = (u32)(above ? ((1ull << hbits) - 1ull - hiK) : hiK);
     keys[j] = (ch << kbits) | T;
     vals[j] = sE[k] - Rr;
+    if (Rout != nullptr) Rout[j] = Rr;
 }
 
 // end of a round: the group starts found in it become visible
@@ -1422,11 +1451,13 @@ __global__ __launch_bounds__(256) void k_bwt_f_med_compact(uint2* __restrict__ s
 }
 
 // knobs (tests, tuning): read from the environment once per process, or set through knz_hip_tune()
-struct FwdTuning { int nsym; int noRunRound; int runFallback; int noSuper; int noTextRound; };
+struct FwdTuning { int nsym; int noRunRound; int runFallback; int noSuper; int noTextRound; int stats; int noRunOffsets; };
 static FwdTuning& fwd_tuning()
 {
     static FwdTuning t = [] {
-        FwdTuning x; x.nsym = 0; x.noRunRound = 0; x.runFallback = 0; x.noSuper = 0; x.noTextRound = 0;
+        FwdTuning x; x.nsym = 0; x.noRunRound = 0; x.runFallback = 0; x.noSuper = 0; x.noTextRound = 0; x.stats = 0; x.noRunOffsets = 0;
+        if (getenv("KNZ_BWT_NO_RUN_OFFSETS")) x.noRunOffsets = 1;
+        if (getenv("KNZ_BWT_STATS")) x.stats = 1;
         if (const char* e = getenv("KNZ_BWT_NSYM")) x.nsym = atoi(e);
         if (getenv("KNZ_BWT_NO_RUN_ROUND")) x.noRunRound = 1;
         if (getenv("KNZ_BWT_RUN_FALLBACK")) x.runFallback = 1;
@@ -1444,6 +1475,8 @@ int bwt_forward_tune(const char* key, int value)
     else if (!strcmp(key, "bwt_run_fallback")) t.runFallback = value;
     else if (!strcmp(key, "bwt_no_super")) t.noSuper = value;
     else if (!strcmp(key, "bwt_no_text_round")) t.noTextRound = value;
+    else if (!strcmp(key, "bwt_stats")) t.stats = value;
+    else if (!strcmp(key, "bwt_no_run_offsets")) t.noRunOffsets = value;
     else return -1;
     return 0;
 }
@@ -1453,7 +1486,7 @@ struct FwdScratch {
     u32* valsA; u32* valsB;
     u32* SA; u32* ISA; u32* K;
     u32* t0; u32* t1; u32* t2; u32* t3;
-    u32* gbits; u32* gnew; size_t gbitsWords;
+    u32* gbits; u32* gnew; u32* rtbits; u32* ovr; size_t gbitsWords;
     uint2* med[2]; uint2* medStage; u32* medFlags; u32* medPrefix; size_t medSlots; uint2* descInfo; uint2* large[2]; uint2* runList; uint4* superList; u32* ebits;
     u32* loff;
     u32* base;
@@ -1482,6 +1515,8 @@ static size_t fwd_carve(u8* p, int nBlocks, size_t total, FwdScratch* w)
     w->t0 = (u32*)take(4 * total); w->t1 = (u32*)take(4 * total); w->t2 = (u32*)take(4 * total); w->t3 = (u32*)take(4 * total);
     w->gbits = (u32*)take(4 * w->gbitsWords);
     w->gnew = (u32*)take(4 * w->gbitsWords);
+    w->rtbits = (u32*)take(4 * w->gbitsWords);
+    w->ovr = (u32*)take(4 * total);
     w->med[0] = (uint2*)take(8 * maxMed); w->med[1] = (uint2*)take(8 * maxMed);
     w->medSlots = total / 256 + 2;
     w->medStage = (uint2*)take(8 * w->medSlots); w->medFlags = (u32*)take(4 * w->medSlots + 64); w->medPrefix = (u32*)take(4 * w->medSlots + 64);
@@ -1530,7 +1565,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     if (hipStreamSynchronize(s) != hipSuccess) return -1;
     const u32 total = h_pinned[0];
     if (total == 0) return 0;
-    FwdView v; v.base = w.base; v.nBlocks = st.nBlocks; v.total = total; v.SA = w.SA; v.ISA = w.ISA; v.K = w.K; v.gbits = w.gbits; v.gnew = w.gnew; v.counters = w.counters; v.medStage = w.medStage;
+    FwdView v; v.base = w.base; v.nBlocks = st.nBlocks; v.total = total; v.SA = w.SA; v.ISA = w.ISA; v.K = w.K; v.gbits = w.gbits; v.gnew = w.gnew; v.counters = w.counters; v.medStage = w.medStage; v.ovr = nullptr; v.rtbits = nullptr;
     const u32 medSlots = (u32)((size_t)total / 256 + 1);
     hipMemsetAsync(w.medStage, 0, 8ull * w.medSlots, s);
     // the medium groups staged by the kernels of a round -> descriptor list `dst` (in slot order) and counters[1]
@@ -1585,6 +1620,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     while ((1ull << kbits) < (u64)bv.VS + 2) kbits++;
     // the run-length round needs descriptor index + (kbits + 1) + kbits bits in one 64-bit key
     const bool runRound = (2 * kbits + 1) < 64 && !tune.noRunRound;
+    const bool runOffsets = !tune.noRunOffsets;
     { KScope ks_("k_bwt_f_r0_place"); hipLaunchKernelGGL(k_bwt_f_r0_place, dim3(nWin), dim3(256), 0, s, v, (const u32*)nullptr, w.t1, w.t3, nWin, w.med[cur], w.large[cur],
                                                          sortedKeys, nsym, pbits, runRound ? w.runList : (uint2*)nullptr); }
     if (!tune.noTextRound) {
@@ -1592,7 +1628,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
         { KScope ks_("k_bwt_f_sort_small_text"); hipLaunchKernelGGL(k_bwt_f_sort_small_text, dim3(nTiles0), dim3(256), 0, s, bv, v, (u32)nsym); }
         { KScope ks_("k_bwt_f_merge_bits"); hipLaunchKernelGGL(k_bwt_f_merge_bits, GRID1(total / 32 + 2), w.gbits, w.gnew, total / 32 + 2); }
     }
-    if (hipMemcpyAsync(h_pinned, w.counters, 32, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+    if (hipMemcpyAsync(h_pinned, w.counters, 64, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
     if (hipStreamSynchronize(s) != hipSuccess) return -1;
     u32 nRun = h_pinned[4], runElems = h_pinned[5];
     bool medCompacted = false;
@@ -1600,7 +1636,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     if (nRun && ((u64)nRun > (1ull << (64 - maxKeyBits)) || tune.runFallback)) {     // (the knob: tests force this path)
         // more run groups than the key has index bits left for (thousands of blocks in one batch): they go the ordinary way
         { KScope ks_("k_bwt_f_run_fallback"); hipLaunchKernelGGL(k_bwt_f_run_fallback, GRID1(nRun), v, w.runList, nRun, w.med[cur], w.large[cur]); }
-        if (hipMemcpyAsync(h_pinned, w.counters, 32, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+        if (hipMemcpyAsync(h_pinned, w.counters, 64, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
         if (hipStreamSynchronize(s) != hipSuccess) return -1;
         nRun = 0;
     }
@@ -1634,7 +1670,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
             // more runs than the tables hold (a round-0 key shorter than 4 symbols) or fields that do not fit their words: the run groups
             // go the ordinary way
             { KScope ks_("k_bwt_f_run_fallback"); hipLaunchKernelGGL(k_bwt_f_run_fallback, GRID1(nRun), v, w.runList, nRun, w.med[cur], w.large[cur]); }
-            if (hipMemcpyAsync(h_pinned, w.counters, 32, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+            if (hipMemcpyAsync(h_pinned, w.counters, 64, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
             if (hipStreamSynchronize(s) != hipSuccess) return -1;
             nRun = 0;
         }
@@ -1658,28 +1694,30 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
           const int r = prims::rs_sort<u64, false>(s, rs1, keysFree, keysFree2, (u32*)nullptr, (u32*)nullptr, (size_t)runElems, 32, 32 + hbits + rbits);
           const u64* sortedM = r ? keysFree2 : keysFree;
           rk = r ? keysFree : keysFree2;
-          hipLaunchKernelGGL(k_bwt_f_run_expand, GRID1(runElems), sortedM, runElems, w.sKey, w.sE, kbits, hbits, rk, rv); }
+          hipLaunchKernelGGL(k_bwt_f_run_expand, GRID1(runElems), sortedM, runElems, w.sKey, w.sE, kbits, hbits, rk, rv, runOffsets ? w.valsB : (u32*)nullptr); }
         { KScope ks_("k_bwt_f_large_flags"); hipLaunchKernelGGL(k_bwt_f_large_flags<u64>, GRID1(runElems), rk, runElems, w.t0, w.t2); }
         { KScope ks_("k_bwt_f_scan_max"); prims::launch_scan<prims::SCAN_MAX_INCL>(s, w.t0, w.t1, runElems, nullptr, w.scanTmp); }
         { KScope ks_("k_bwt_f_scan_min"); prims::launch_scan<prims::SCAN_MIN_INCL>(s, w.t2, w.t3, runElems, nullptr, w.scanTmp); }
-        { KScope ks_("k_bwt_f_large_place"); hipLaunchKernelGGL(k_bwt_f_large_place<u64>, GRID1(runElems), v, w.runList, w.loff, runElems, keyBits, rk, rv, w.t1, w.t3,
-                                                                w.med[cur], w.large[cur]); }
+        { KScope ks_("k_bwt_f_large_place");
+          if (runOffsets) hipMemsetAsync(w.rtbits, 0, 4 * w.gbitsWords, s);
+          hipLaunchKernelGGL(k_bwt_f_large_place<u64>, GRID1(runElems), v, w.runList, w.loff, runElems, keyBits, rk, rv, w.t1, w.t3, w.med[cur], w.large[cur],
+                             runOffsets ? (const u32*)w.valsB : (const u32*)nullptr, runOffsets ? w.ovr : (u32*)nullptr, runOffsets ? w.rtbits : (u32*)nullptr);
+          if (runOffsets) { v.ovr = w.ovr; v.rtbits = w.rtbits; } }
         { KScope ks_("k_bwt_f_merge_bits"); hipLaunchKernelGGL(k_bwt_f_merge_bits, GRID1(total / 32 + 2), w.gbits, w.gnew, total / 32 + 2); }
         compactMedium(w.med[cur]);
         medCompacted = true;
-        if (hipMemcpyAsync(h_pinned, w.counters, 32, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+        if (hipMemcpyAsync(h_pinned, w.counters, 64, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
         if (hipStreamSynchronize(s) != hipSuccess) return -1;
       }
     }
     if (!medCompacted) {
         compactMedium(w.med[cur]);
-        if (hipMemcpyAsync(h_pinned, w.counters, 32, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+        if (hipMemcpyAsync(h_pinned, w.counters, 64, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
         if (hipStreamSynchronize(s) != hipSuccess) return -1;
     }
     u32 surv = h_pinned[0], nMed = h_pinned[1], nLarge = h_pinned[2], largeElems = h_pinned[3];
-#ifdef KNZ_FWD_DEBUG
-    fprintf(stderr, "after round 0 (nsym %d): run groups %u (%u members), small left %u, medium %u, large %u (%u members)\n", nsym, nRun, runElems, surv, nMed, nLarge, largeElems);
-#endif
+    if (tune.stats) fprintf(stderr, "after round 0 (nsym %d, total %u): run groups %u (%u members); small left %u, medium %u, large %u (%u members)\n",
+                            nsym, total, nRun, runElems, surv, nMed, nLarge, largeElems);
 
     const int npass = (kbits + 7) / 8;
     const u32 nTiles = (total + SM_TS - 1) / SM_TS;
@@ -1693,11 +1731,11 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
         { KScope ks_("k_bwt_f_round"); hipMemsetAsync(w.counters, 0, 64, s); }      // (the scope counts the doubling rounds for the profile)
         const int nxt = cur ^ 1;
         // -- all keys first
-        if (surv) { KScope ks_("k_bwt_f_gather_small"); hipLaunchKernelGGL(k_bwt_f_gather_small, dim3(nTiles), dim3(256), 0, s, v, h); }
+        if (surv) { KScope ks_("k_bwt_f_gather_small"); hipLaunchKernelGGL(k_bwt_f_gather_small, dim3(nTiles), dim3(256), 0, s, v, h, tune.stats); }
         if (nMed) {
             // (the list is in slot order: k_bwt_f_med_compact)
             KScope ks_("k_bwt_f_gather_desc");
-            hipLaunchKernelGGL(k_bwt_f_gather_desc, dim3(256), dim3(1024), 0, s, v, w.med[cur], nMed, h, w.descInfo);
+            hipLaunchKernelGGL(k_bwt_f_gather_desc, dim3(256), dim3(1024), 0, s, v, w.med[cur], nMed, h, w.descInfo, tune.stats);
         }
         int lbits = 0;
         bool small32 = false;
@@ -1738,17 +1776,16 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
             { KScope ks_("k_bwt_f_scan_max"); prims::launch_scan<prims::SCAN_MAX_INCL>(s, w.t0, w.t1, largeElems, nullptr, w.scanTmp); }
             { KScope ks_("k_bwt_f_scan_min"); prims::launch_scan<prims::SCAN_MIN_INCL>(s, w.t2, w.t3, largeElems, nullptr, w.scanTmp); }
             { KScope ks_("k_bwt_f_large_place");
-              if (small32) hipLaunchKernelGGL(k_bwt_f_large_place<u32>, GRID1(largeElems), v, w.large[cur], w.loff, largeElems, kbits, sk32, sv, w.t1, w.t3, w.med[nxt], w.large[nxt]);
-              else hipLaunchKernelGGL(k_bwt_f_large_place<u64>, GRID1(largeElems), v, w.large[cur], w.loff, largeElems, kbits, sk64, sv, w.t1, w.t3, w.med[nxt], w.large[nxt]); }
+              if (small32) hipLaunchKernelGGL(k_bwt_f_large_place<u32>, GRID1(largeElems), v, w.large[cur], w.loff, largeElems, kbits, sk32, sv, w.t1, w.t3, w.med[nxt], w.large[nxt], (const u32*)nullptr, (u32*)nullptr, (u32*)nullptr);
+              else hipLaunchKernelGGL(k_bwt_f_large_place<u64>, GRID1(largeElems), v, w.large[cur], w.loff, largeElems, kbits, sk64, sv, w.t1, w.t3, w.med[nxt], w.large[nxt], (const u32*)nullptr, (u32*)nullptr, (u32*)nullptr); }
         }
         { KScope ks_("k_bwt_f_merge_bits"); hipLaunchKernelGGL(k_bwt_f_merge_bits, GRID1(total / 32 + 2), w.gbits, w.gnew, total / 32 + 2); }
         compactMedium(w.med[nxt]);
-        if (hipMemcpyAsync(h_pinned, w.counters, 32, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+        if (hipMemcpyAsync(h_pinned, w.counters, 64, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
         if (hipStreamSynchronize(s) != hipSuccess) return -1;
         surv = h_pinned[0]; nMed = h_pinned[1]; nLarge = h_pinned[2]; largeElems = h_pinned[3];
-#ifdef KNZ_FWD_DEBUG
-        fprintf(stderr, "round h=%u: small left %u, medium %u, large %u (%u members); %u groups took the chain round\n", h, surv, nMed, nLarge, largeElems, h_pinned[7]);
-#endif
+        if (tune.stats) fprintf(stderr, "round h=%u: small members worked on %u in %u groups, medium members %u; after it: small left %u, medium groups %u, large %u (%u members); %u groups took the chain round\n",
+                                h, h_pinned[10], h_pinned[11], h_pinned[12], surv, nMed, nLarge, largeElems, h_pinned[7]);
         cur = nxt;
         h <<= 1;
     }
