@@ -225,6 +225,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=256 << 20, help="bytes of the workload the CPU reference is timed on (the whole silesia corpus fits)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--reps", type=int, default=0, help="repetitions of the separate encode / decode / per-kernel timing passes (default: 2..5 by --steps)")
     ap.add_argument("--dist-backend", default="nccl", help="gloo + --share-device: the N-rank code path on a 1-GPU box (developer check)")
     ap.add_argument("--share-device", action="store_true", help="every rank uses cuda:0")
     args = ap.parse_args()
@@ -342,7 +343,7 @@ def main():
             torch.cuda.synchronize()
             return (time.perf_counter() - a) / reps
 
-        reps = max(2, min(args.steps, 5))
+        reps = args.reps if args.reps > 0 else max(2, min(args.steps, 5))
         t_enc = timed(encode, reps)
         t_dec = timed(decode, reps)
         kern, stages = {}, {}

@@ -59,7 +59,8 @@ typedef struct {
                                 buffer slot, hence the capacities, a block sees. */
     int32_t bs_version;      /* decode only: bitstream version of the stream the blocks come from, as
                                 CompressedInputStream puts it in the Context (io/CompressedInputStream.cpp:528-537).
-                                0 or 6 = current. 3..5 select the old layouts the reference still reads: Huffman chunks
+                                0 (unset, the ABI default) or 6 = current. 1..5 select the old layouts the reference still reads (it treats every
+                                version below 6 alike; a caller that parsed or was given version 0 passes 1): Huffman chunks
                                 (entropy/HuffmanDecoder.cpp:349-459), the BWT block header
                                 (transform/BWTBlockCodec.cpp:140-164) and LZ / LZX blocks (transform/LZCodec.cpp:614-760).
                                 The encoder writes version 6 only, like the reference. */

@@ -232,7 +232,18 @@ int knz_hip_tune(const char* name, int value)
     return bwt_forward_tune(name, value);
 }
 
-const char* knz_hip_last_error(knz_ctx* ctx) { return ctx ? reinterpret_cast<Ctx*>(ctx)->err : "null context"; }
+// (a copy taken under the lock the writers hold, into a buffer of the calling thread: lane contexts are shared between the stream
+// classes' worker threads and the copy entry points run outside `mu`, so the context's own buffer may be rewritten while it is read)
+const char* knz_hip_last_error(knz_ctx* ctx)
+{
+    if (!ctx) return "null context";
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    thread_local char copy[sizeof(c->err)];
+    std::lock_guard<std::mutex> el(c->errMu);
+    memcpy(copy, c->err, sizeof(copy));
+    copy[sizeof(copy) - 1] = 0;
+    return copy;
+}
 
 size_t knz_hip_encode_bound(const knz_params* p, size_t n)
 {

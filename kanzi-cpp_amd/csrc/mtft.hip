@@ -17,17 +17,18 @@
 #include "common.hpp"
 #include "stages.hpp"
 #include <cstdlib>
+#include <atomic>
 
 namespace knz {
 
 // bytes per tile (one wave): 4096, or 1024 when the batch has fewer 4 KiB tiles than the device has wave slots -- the tile kernels
 // are one dependent chain per tile, so a small batch finishes in the time of ONE chain and shorter chains are what shortens it
 // (2 blocks of 8 MiB: k_mtf_f_rank 0.82 -> see DESIGN.md)
-static int g_mtfTileKnob = []() { const char* e = getenv("KNZ_MTF_TILE"); return e ? atoi(e) : 0; }();      // 0 = by batch size; 1024 / 4096 force
-int mtft_tune(int tileBytes) { g_mtfTileKnob = (tileBytes == 1024 || tileBytes == 4096) ? tileBytes : 0; return 0; }
+static std::atomic<int> g_mtfTileKnob([]() { const char* e = getenv("KNZ_MTF_TILE"); return e ? atoi(e) : 0; }());      // 0 = by batch size; 1024 / 4096 force
+int mtft_tune(int tileBytes) { g_mtfTileKnob.store((tileBytes == 1024 || tileBytes == 4096) ? tileBytes : 0); return 0; }
 static inline u32 mtf_tile_bytes(int nBlocks, u32 maxLen)
 {
-    if (g_mtfTileKnob) return (u32)g_mtfTileKnob;
+    if (const int k = g_mtfTileKnob.load()) return (u32)k;
     return ((u64)nBlocks * ((maxLen + 4095) / 4096) < 12288ull) ? 1024u : 4096u;
 }
 
@@ -414,7 +415,10 @@ void launch_mtft_inverse(hipStream_t s, const XfStage& st)
 
 size_t mtft_scratch_u32(int nBlocks, u32 maxLen)
 {
-    const u32 MT = mtf_tile_bytes(nBlocks, maxLen);
+    // sized for the smaller tile (the larger table) whatever the launch will pick: the knob may change between this call and the
+    // launch (another thread's knz_hip_tune), and the tables must hold either choice
+    const u32 MT = 1024u;
+    (void)mtf_tile_bytes;
     const size_t perTiles = ((size_t)maxLen + MT - 1) / MT;
     const u32 segT = mtf_seg_tiles((u32)perTiles);
     return (size_t)nBlocks * (perTiles + (perTiles + segT - 1) / segT) * 256 + 64;    // tile tables + segment tables

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <sstream>
 #include <sys/stat.h>
@@ -800,7 +801,16 @@ CompressedOutputStream::CompressedOutputStream(std::ostream& os, int tasks, cons
     _pendingByte = 0; _pendingBits = 0; _written = 0;
     _fillLane = 0; _nextSeq = 0; _sinkSeq = 0; _pubSeq = 0; _cumBits = 0; _stop = false;
     _batchBytes = 0;
-    const std::vector<int> devs = laneDevices();
+    // lanes per device bounded by the block size: a lane holds a batch's input, output and the suffix sort's scratch (about 64
+    // bytes per input byte), so that with 1 GiB blocks one lane per GPU is what fits comfortably, with blocks up to 256 MiB four
+    std::vector<int> devs = laneDevices();
+    {
+        const size_t perDev = std::max<size_t>(1, (size_t(1) << 30) / size_t(std::max(blockSize, 1)));
+        std::map<int, size_t> seen;
+        std::vector<int> kept;
+        for (int d : devs) if (seen[d]++ < perDev) kept.push_back(d);
+        devs.swap(kept);
+    }
     const std::vector<knz_ctx*> ctxs = openLanes(devs);
     _lanes.resize(devs.size());
     for (size_t i = 0; i < _lanes.size(); i++) {
@@ -998,7 +1008,15 @@ void CompressedOutputStream::submit(Lane& ln)
     const size_t bytes = size_t((uint64(r) + bits + 7) >> 3);
     const void* src = ln.dOut;
     if (r != 0 && bits != 0) {
-        if (ln.dShiftCap < bytes + 8) { if (ln.dShift) knz_hip_free(c, ln.dShift); ln.dShift = nullptr; ln.dShiftCap = 0; devCheck(c, knz_hip_malloc(c, ln.dOutCap + 8, &ln.dShift), "malloc"); ln.dShiftCap = ln.dOutCap + 8; }
+        if (ln.dShiftCap < bytes + 8) {
+            // sized by what a batch actually produced (plus a quarter, so that batches of similar size do not reallocate), never
+            // beyond the encode bound: with large blocks the bound is several GiB per lane, the compressed run a fraction of it
+            const size_t want = std::min(ln.dOutCap + 8, std::max(bytes + 8 + (bytes >> 2), size_t(1) << 20));
+            if (ln.dShift) knz_hip_free(c, ln.dShift);
+            ln.dShift = nullptr; ln.dShiftCap = 0;
+            devCheck(c, knz_hip_malloc(c, want, &ln.dShift), "malloc");
+            ln.dShiftCap = want;
+        }
         devCheck(c, knz_hip_shift_bits(c, static_cast<const uint8_t*>(ln.dOut), bits, r, static_cast<uint8_t*>(ln.dShift)), "shift");
         src = ln.dShift;
     }
@@ -1272,7 +1290,7 @@ void CompressedInputStream::decodeBatch(Prep& pr, PSlot& sl)
     knz_params p;
     memset(&p, 0, sizeof(p));
     p.transform_type = _transformType; p.entropy_type = _entropyType; p.block_size = _blockSize; p.checksum_bits = _checksum; p.jobs = _jobs;
-    p.bs_version = _bsVersion;
+    p.bs_version = _bsVersion == 0 ? 1 : _bsVersion;      // (0 is the C ABI's "unset = current"; the reference reads a version-0 stream as an old one)
     const size_t outCap = size_t(pr.nb) * size_t(_blockSize) + 64;
     // the slot is free, so the copy out of its device buffer (two batches ago) has been waited for
     if (sl.dOutCap < outCap) {

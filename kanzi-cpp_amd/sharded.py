@@ -102,7 +102,7 @@ class DeviceRunDecoder:
 
     def __call__(self, chunk, start_bit, end_bit, n_blocks, hdr):
         ctx = self.ctx
-        p = ctx.params(hdr["ttype"], hdr["etype"], hdr["block_size"], hdr["checksum_bits"], self.jobs, hdr.get("bs_version", 0))
+        p = ctx.params(hdr["ttype"], hdr["etype"], hdr["block_size"], hdr["checksum_bits"], self.jobs, hdr.get("bs_version", 6) or 1)      # a parsed version 0 is an old layout (the C ABI keeps 0 for "unset = current")
         out_cap = n_blocks * hdr["block_size"] + 64
         d_in, d_out = self.bufs.get("in", len(chunk) + 64), self.bufs.get("out", out_cap)
         ctx.h2d(d_in, chunk)

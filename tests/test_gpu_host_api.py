@@ -158,9 +158,9 @@ def test_lanes_and_devices_give_the_single_device_stream(tmp_path, oracle, monke
 def test_reference_python_api_cases(tmp_path, oracle):
     """The cases of the reference's own ctypes test (src/test/test_api.py), written against the same class interface
     (bytes codec names, context managers, decompress_block, the reference's keyword names), plus what that test does
-    not check: the file on disk is byte-identical to the reference's. One deviation: its headerless case passes
-    bsVersion=1 (harmless there: a 25-byte block is stored raw); decoding older bitstream versions is not built, so
-    the case runs with bsVersion=6."""
+    not check: the file on disk is byte-identical to the reference's. Its headerless case declares bsVersion=1 for a stream
+    written as version 6 (harmless there: LZ skips a 25-byte block and ANS0 chunks did not change with the version); it runs as
+    written, and once more with bsVersion=0, which the reference also reads as an old layout (every version below 6)."""
     kz = _kanzi()
     fill = lambda size: bytes((i * 17 + 3) & 0xFF for i in range(size))
     lzx = dict(transform=b"LZX", entropy=b"HUFFMAN", block_size=1024, jobs=1, checksum=0, headerless=0)
@@ -207,9 +207,10 @@ def test_reference_python_api_cases(tmp_path, oracle):
     path = str(tmp_path / "g.knz")
     with kz.Compressor(path, transform=b"LZ", entropy=b"ANS0", block_size=1 << 15, jobs=1, checksum=0, headerless=1) as c:
         c.compress(msg)
-    with kz.Decompressor(path, buffer_size=1 << 15, jobs=1, headerless=1, transform=b"LZ", entropy=b"ANS0", blockSize=1 << 15,
-                         originalSize=len(msg), checksum=0, bsVersion=6) as d:
-        assert d.decompress_block(256) == msg
+    for ver in (1, 0, 6):
+        with kz.Decompressor(path, buffer_size=1 << 15, jobs=1, headerless=1, transform=b"LZ", entropy=b"ANS0", blockSize=1 << 15,
+                             originalSize=len(msg), checksum=0, bsVersion=ver) as d:
+            assert d.decompress_block(256) == msg, ver
 
 
 def test_c_api_parameter_validation(tmp_path):

@@ -12,7 +12,7 @@ of round 3 (tools/membench.hip under rocprofv3, profiles/r03_pmc_calibration.txt
 therefore NOT doubled. WRITE_SIZE needs no correction: exact for coalesced stores, 32 B per random 4-byte store.
 A dispatch belongs to the stage of the bracket it falls in (k_bwt_bases .. k_bwt_f_emit = bwt_forward, k_bwt_i_header ..
 k_bwt_i_place = bwt_inverse: the scan / sort primitives in between carry generic names), otherwise to the stage its own name
-says. Per step = total / number of encodes seen (k_bwt_bases or k_ans0_stats dispatches)."""
+says. Per step = total / number of encodes seen (dispatches of the first kernel of an encode: k_bwt_bases, k_ans0_stats, k_huff_encode, k_lz_keys or k_ans1_hist)."""
 import collections
 import csv
 import json
@@ -63,7 +63,7 @@ def main():
     fpath, wpath, cfg, out = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
     ft, fk, calls = per_stage(fpath, "FETCH_SIZE")
     wt, wk, _ = per_stage(wpath, "WRITE_SIZE")
-    n_enc = calls.get("k_bwt_bases") or calls.get("k_ans0_stats") or 1
+    n_enc = calls.get("k_bwt_bases") or calls.get("k_ans0_stats") or calls.get("k_huff_encode") or calls.get("k_lz_keys") or calls.get("k_ans1_hist") or 1
     stages = {}
     for st in sorted(set(ft) | set(wt)):
         stages[st] = int((ft.get(st, 0.0) * 1024 + wt.get(st, 0.0) * 1024) / n_enc)
