@@ -205,16 +205,17 @@ __global__ __launch_bounds__(256) void k_bwt_f_r0_flags(const u64* __restrict__ 
 
 // per window of 2048 slots: the last group start in it (0 when it has none: slot 0 always starts a group, so 0 is neutral
 // for the running maximum) and, mirrored for a running minimum from the right, the first one (`total` when none)
-__global__ __launch_bounds__(256) void k_bwt_f_r0_winsum(const u32* __restrict__ gbits, u32 total, u32 nWin, u32* __restrict__ winLast, u32* __restrict__ winFirstRev)
+__global__ __launch_bounds__(256) void k_bwt_f_r0_winsum(const u32* __restrict__ gbits, u32 total, u32 nWin, u32* __restrict__ winLast, u32* __restrict__ winFirstRev,
+                                                         u32 wordsPerWin)
 {
     const u32 w = blockIdx.x * 256 + threadIdx.x;
     if (w >= nWin) return;
     u32 last = 0, first = total;
     bool seen = false;
-    for (u32 k = 0; k < SM_WIN / 32; k++) {
-        const u32 x = gbits[w * (SM_WIN / 32) + k];
+    for (u32 k = 0; k < wordsPerWin; k++) {
+        const u32 x = gbits[w * wordsPerWin + k];
         if (x) {
-            const u32 b0 = (w * (SM_WIN / 32) + k) * 32;
+            const u32 b0 = (w * wordsPerWin + k) * 32;
             if (!seen) { first = b0 + (u32)__ffs((int)x) - 1; seen = true; }
             last = b0 + 31 - (u32)__clz((int)x);
         }
@@ -369,6 +370,170 @@ __global__ __launch_bounds__(256) void k_bwt_f_r0_place(FwdView v, const u32* __
 #pragma unroll
     for (int k = 0; k < (int)(SM_WIN / 256); k++)
         if (hKind[k] >= 0) agg_write(A, v, hKind[k], hLocal[k], slot0 + (u32)tid + 256u * (u32)k, hSize[k], largeNext, runList);
+}
+
+// Round 0 and the text round in one sweep (the default; knob bwt_no_text_round = 2 runs k_bwt_f_r0_place and k_bwt_f_sort_small_text one
+// after the other instead): windows of SM_TS owned slots that look SM_G slots further, as the small-group kernels do. A slot is placed
+// by the window that owns it -- except the members of a SMALL group (2..SM_G members), which are all placed by the window that owns
+// the group's first slot: that window has their keys in LDS anyway, sorts them on the eight text bytes behind the round-0 symbols
+// before anything is written, and writes position and label ONCE, with the label the text order gives (the separate text round read
+// SA back, and wrote SA and the labels of every member that moved a second time).
+__global__ __launch_bounds__(256) void k_bwt_f_r0_place_text(BwtView bv, FwdView v, const u32* __restrict__ winLastIncl, const u32* __restrict__ winFirstInclRev, u32 nWin,
+                                                             uint2* __restrict__ largeNext, const u64* __restrict__ keys, int nsym, int pbits, uint2* __restrict__ runList)
+{
+    __shared__ SmWindow W;
+    __shared__ int sBlk;
+    __shared__ ClassAgg A;
+    __shared__ u32 sSA[SM_WIN];
+    __shared__ u64 sK[SM_WIN];
+    __shared__ u32 sNew[64];
+    __shared__ u32 sAfterLocal;           // first group start in the owned part of the NEXT window behind what this one looks at
+    constexpr int E = (int)(SM_WIN / 256);
+    constexpr u32 TSW = SM_TS / 32;       // words a window owns
+    const int tid = (int)threadIdx.x;
+    const u32 win = blockIdx.x;
+    const u32 slot0 = win * SM_TS;
+    if (tid == 0) sBlk = find_block(v.base, v.nBlocks, slot0 < v.total ? slot0 : v.total - 1);
+    agg_init(A);
+    if (tid < 64) {
+        sNew[tid] = 0;
+        const u32 w = v.gbits[(slot0 >> 5) + (u32)tid];
+        W.bw[tid] = w;
+        int pm = w ? (tid * 32 + 31 - __clz((int)w)) : -1;
+        u32 sm = w ? (u32)(tid * 32 + __ffs((int)w) - 1) : NO_BIT;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(pm, (unsigned)o, 64);
+            if (tid >= o) pm = t > pm ? t : pm;
+            const u32 u = (u32)__shfl_down((int)sm, (unsigned)o, 64);
+            if (tid + o < 64) sm = u < sm ? u : sm;
+        }
+        int pex = __shfl_up(pm, 1u, 64);
+        if (tid == 0) pex = -1;
+        u32 sex = (u32)__shfl_down((int)sm, 1u, 64);
+        if (tid == 63) sex = NO_BIT;
+        W.prevSet[tid] = pex;
+        W.nextSet[tid] = sex;
+    } else if (tid < 128) {
+        // the rest of the next window's owned words (2 TSW - 64 of them): where a group that leaves this window's view ends, if it ends there
+        const int k = tid - 64;
+        const u32 w = (k < (int)(2 * TSW - 64)) ? v.gbits[(slot0 >> 5) + 64u + (u32)k] : 0u;
+        const unsigned long long any = __ballot(w != 0);
+        const int first = any ? __ffsll((long long)any) - 1 : 0;          // (this wave alone writes the word: lane 0 says "none")
+        if (k == first) sAfterLocal = any ? SM_WIN + (u32)k * 32u + (u32)__ffs((int)w) - 1u : NO_BIT;
+    }
+    __syncthreads();
+    const u32 before = win ? winLastIncl[win - 1] : 0u;
+    u32 after = (sAfterLocal != NO_BIT) ? slot0 + sAfterLocal : ((win + 2 < nWin) ? winFirstInclRev[nWin - 3 - win] : v.total);
+    if (after > v.total) after = v.total;
+    const u64 pmask = (1ull << pbits) - 1ull;
+    // ---- every slot in view: position, group, and -- for the members of small groups this window owns -- the text key
+    u32 gp[E], gs[E], ge[E];
+    u64 kk[E];
+    bool inView[E], mine[E];              // mine: member of a small group whose first slot this window owns
+    int blkOf[E];
+#pragma unroll
+    for (int k = 0; k < E; k++) {
+        const u32 i = (u32)tid + 256u * (u32)k;
+        const u32 a = slot0 + i;
+        inView[k] = a < v.total;
+        mine[k] = false; gp[k] = 0; kk[k] = 0; gs[k] = 0; ge[k] = 0; blkOf[k] = 0;
+        if (!inView[k]) continue;
+        int blk = sBlk;
+        while (a >= v.base[blk + 1]) blk++;
+        blkOf[k] = blk;
+        kk[k] = keys[a];
+        gp[k] = v.base[blk] + (u32)(kk[k] & pmask);
+        mine[k] = sm_group_of(W, i, gs[k], ge[k]);
+        if (mine[k]) {
+            const u32 bb = v.base[blk], n = v.base[blk + 1] - bb;
+            const u32 q = gp[k] - bb + (u32)nsym;
+            const u8* t = bv.src[blk];
+            u64 x = 0;
+            if (q + 12 <= n) {
+                const uintptr_t ad = reinterpret_cast<uintptr_t>(t + q);
+                const u32* w = reinterpret_cast<const u32*>(ad & ~(uintptr_t)3);
+                const u32 sh = (u32)(ad & 3) * 8;
+                const u64 lo = (u64)w[0] | ((u64)w[1] << 32);
+                x = sh ? ((lo >> sh) | ((u64)w[2] << (64 - sh))) : lo;
+            } else {
+                for (u32 j = 0; j < 8; j++) if (q + j < n) x |= (u64)t[q + j] << (8 * j);
+            }
+            sSA[i] = gp[k];
+            sK[i] = __builtin_bswap64(x);
+        }
+    }
+    __syncthreads();
+    u32 surv = 0;
+    int hKind[E];
+    u32 hLocal[E], hSize[E];
+#pragma unroll
+    for (int k = 0; k < E; k++) {
+        const u32 i = (u32)tid + 256u * (u32)k;
+        const u32 a = slot0 + i;
+        hKind[k] = -1; hLocal[k] = 0; hSize[k] = 0;
+        if (!inView[k]) continue;
+        if (mine[k]) {
+            // a member of a small group of this window: its place and label come from the text order inside the group
+            const u64 ki = sK[i];
+            u32 less = 0, eq = 0, eqBefore = 0;
+            for (u32 j = gs[k]; j < ge[k]; j++) {
+                const u64 kj = sK[j];
+                less += (kj < ki) ? 1u : 0u;
+                const u32 same = (kj == ki) ? 1u : 0u;
+                eq += same;
+                eqBefore += (j < i) ? same : 0u;
+            }
+            const u32 headIdx = gs[k] + less;
+            v.SA[slot0 + headIdx + eqBefore] = gp[k];
+            v.ISA[gp[k]] = slot0 + headIdx;
+            if (less != 0 && eqBefore == 0) atomicOr(&sNew[headIdx >> 5], 1u << (headIdx & 31));
+            if (eq > 1) surv = 1;
+            continue;
+        }
+        if (i >= SM_TS) continue;                                  // in view only: the next window owns it
+        // the group of the slot: starts at the last set bit at or before it
+        const u32 w = i >> 5, bit = i & 31;
+        const u32 lowmask = (bit == 31) ? 0xFFFFFFFFu : ((2u << bit) - 1u);
+        const u32 word = W.bw[w];
+        const u32 m = word & lowmask;
+        const int si = m ? (int)(w * 32 + 31 - (u32)__clz((int)m)) : W.prevSet[w];
+        const u32 hd = (si >= 0) ? slot0 + (u32)si : before;
+        if (si < 0) {
+            // the group began in front of this window. If it is a small one, the window in front places its members (this one included)
+            const u32 m2 = word & ~lowmask;
+            const u32 ei = m2 ? (w * 32 + (u32)__ffs((int)m2) - 1) : W.nextSet[w];
+            const u32 endSlot = (ei != NO_BIT) ? slot0 + ei : after;
+            if (endSlot - hd <= SM_G) continue;
+        }
+        v.SA[a] = gp[k];
+        v.ISA[gp[k]] = hd;
+        if (hd == a) {
+            const u32 m2 = word & ~lowmask;
+            const u32 ei = m2 ? (w * 32 + (u32)__ffs((int)m2) - 1) : W.nextSet[w];
+            u32 nxt = (ei != NO_BIT) ? slot0 + ei : after;
+            if (nxt > v.total) nxt = v.total;
+            const u32 size = nxt - a;
+            if (size <= SM_G) continue;                            // (a singleton; small groups went the other way)
+            bool runGroup = false;
+            if (runList != nullptr) {
+                const u64 bytes = kk[k] >> pbits;
+                u64 rep = 0;
+                for (int q = 0; q < nsym; q++) rep = (rep << 8) | (bytes & 0xFF);
+                const int blk = blkOf[k];
+                runGroup = ((u32)(kk[k] & pmask) + (u32)nsym <= v.base[blk + 1] - v.base[blk]) && bytes == rep;
+            }
+            hSize[k] = size;
+            hKind[k] = agg_note(A, size, runGroup, surv, hLocal[k]);
+        }
+    }
+    if (__ballot(surv != 0) != 0 && (tid & 63) == 0) v.counters[0] = 1;
+    __syncthreads();
+    if (tid == 0) agg_reserve(A, v);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < E; k++)
+        if (hKind[k] >= 0) agg_write(A, v, hKind[k], hLocal[k], slot0 + (u32)tid + 256u * (u32)k, hSize[k], largeNext, runList);
+    if (tid < 64 && sNew[tid]) atomicOr(&v.gnew[(slot0 >> 5) + (u32)tid], sNew[tid]);
 }
 
 __global__ __launch_bounds__(256) void k_bwt_f_gather_small(FwdView v, u32 h, int stats)
@@ -1462,7 +1627,7 @@ static FwdTuning& fwd_tuning()
         if (getenv("KNZ_BWT_NO_RUN_ROUND")) x.noRunRound = 1;
         if (getenv("KNZ_BWT_RUN_FALLBACK")) x.runFallback = 1;
         if (getenv("KNZ_BWT_NO_SUPER")) x.noSuper = 1;
-        if (getenv("KNZ_BWT_NO_TEXT_ROUND")) x.noTextRound = 1;
+        if (const char* e = getenv("KNZ_BWT_NO_TEXT_ROUND")) x.noTextRound = atoi(e);
         return x;
     }();
     return t;
@@ -1508,7 +1673,7 @@ static size_t fwd_carve(u8* p, int nBlocks, size_t total, FwdScratch* w)
     u8* q = p;
     auto take = [&](size_t sz) { u8* r = q; q += fwd_align(sz); return r; };
     const size_t maxMed = total / (SM_G + 1) + 2, maxLarge = total / (MED_CAP + 1) + 2;
-    w->gbitsWords = ((total + 64) / 64 + SM_WIN / 64 + 4) * 2;
+    w->gbitsWords = ((total + 64) / 64 + SM_WIN / 64 + 4) * 2 + 128;       // (the placement kernel looks 2 SM_TS slots behind a window's start)
     w->keysA = (u64*)take(8 * total); w->keysB = (u64*)take(8 * total);
     w->valsA = (u32*)take(4 * total); w->valsB = (u32*)take(4 * total);
     w->SA = (u32*)take(4 * total); w->ISA = (u32*)take(4 * total); w->K = (u32*)take(4 * total);
@@ -1612,18 +1777,28 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
                                                          reinterpret_cast<unsigned long long*>(w.gbits)); }
     // group starts before / after every window of 2048 slots: two scans over ~total/2048 values
     const u32 nWin = (total + SM_WIN - 1) / SM_WIN;
-    { KScope ks_("k_bwt_f_r0_winsum"); hipLaunchKernelGGL(k_bwt_f_r0_winsum, GRID1(nWin), w.gbits, total, nWin, w.t0, w.t2); }
-    { KScope ks_("k_bwt_f_scan_max"); prims::launch_scan<prims::SCAN_MAX_INCL>(s, w.t0, w.t1, nWin, nullptr, w.scanTmp); }
-    { KScope ks_("k_bwt_f_scan_min"); prims::launch_scan<prims::SCAN_MIN_INCL>(s, w.t2, w.t3, nWin, nullptr, w.scanTmp); }
+    // (windows of SM_TS slots for the fused placement + text round, of SM_WIN slots for the separate kernels)
+    const bool fusedText = tune.noTextRound == 0;
+    const u32 nWinP = fusedText ? (total + SM_TS - 1) / SM_TS : nWin;
+    { KScope ks_("k_bwt_f_r0_winsum"); hipLaunchKernelGGL(k_bwt_f_r0_winsum, GRID1(nWinP), w.gbits, total, nWinP, w.t0, w.t2, fusedText ? SM_TS / 32 : SM_WIN / 32); }
+    { KScope ks_("k_bwt_f_scan_max"); prims::launch_scan<prims::SCAN_MAX_INCL>(s, w.t0, w.t1, nWinP, nullptr, w.scanTmp); }
+    { KScope ks_("k_bwt_f_scan_min"); prims::launch_scan<prims::SCAN_MIN_INCL>(s, w.t2, w.t3, nWinP, nullptr, w.scanTmp); }
     int cur = 0;
     int kbits = 1;
     while ((1ull << kbits) < (u64)bv.VS + 2) kbits++;
     // the run-length round needs descriptor index + (kbits + 1) + kbits bits in one 64-bit key
     const bool runRound = (2 * kbits + 1) < 64 && !tune.noRunRound;
     const bool runOffsets = !tune.noRunOffsets;
-    { KScope ks_("k_bwt_f_r0_place"); hipLaunchKernelGGL(k_bwt_f_r0_place, dim3(nWin), dim3(256), 0, s, v, (const u32*)nullptr, w.t1, w.t3, nWin, w.med[cur], w.large[cur],
-                                                         sortedKeys, nsym, pbits, runRound ? w.runList : (uint2*)nullptr); }
-    if (!tune.noTextRound) {
+    if (fusedText) {
+        KScope ks_("k_bwt_f_r0_place");
+        hipLaunchKernelGGL(k_bwt_f_r0_place_text, dim3(nWinP), dim3(256), 0, s, bv, v, w.t1, w.t3, nWinP, w.large[cur], sortedKeys, nsym, pbits, runRound ? w.runList : (uint2*)nullptr);
+        hipLaunchKernelGGL(k_bwt_f_merge_bits, GRID1(total / 32 + 2), w.gbits, w.gnew, total / 32 + 2);
+    } else {
+        KScope ks_("k_bwt_f_r0_place");
+        hipLaunchKernelGGL(k_bwt_f_r0_place, dim3(nWin), dim3(256), 0, s, v, (const u32*)nullptr, w.t1, w.t3, nWin, w.med[cur], w.large[cur],
+                           sortedKeys, nsym, pbits, runRound ? w.runList : (uint2*)nullptr);
+    }
+    if (tune.noTextRound == 2) {
         const u32 nTiles0 = (total + SM_TS - 1) / SM_TS;
         { KScope ks_("k_bwt_f_sort_small_text"); hipLaunchKernelGGL(k_bwt_f_sort_small_text, dim3(nTiles0), dim3(256), 0, s, bv, v, (u32)nsym); }
         { KScope ks_("k_bwt_f_merge_bits"); hipLaunchKernelGGL(k_bwt_f_merge_bits, GRID1(total / 32 + 2), w.gbits, w.gnew, total / 32 + 2); }
@@ -1644,7 +1819,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     if (nRun) {
         // run lengths of every position (text order), then one sort of the run groups' members on (run length, what follows)
         { KScope ks_("k_bwt_f_run_ends"); hipLaunchKernelGGL(k_bwt_f_run_ends, dim3((total + SM_WIN - 1) / SM_WIN), dim3(256), 0, s, bv, v, reinterpret_cast<u8*>(w.ebits)); }
-        { KScope ks_("k_bwt_f_r0_winsum"); hipLaunchKernelGGL(k_bwt_f_r0_winsum, GRID1(nWin), w.ebits, total, nWin, w.t0, w.t2); }
+        { KScope ks_("k_bwt_f_r0_winsum"); hipLaunchKernelGGL(k_bwt_f_r0_winsum, GRID1(nWin), w.ebits, total, nWin, w.t0, w.t2, SM_WIN / 32); }
         { KScope ks_("k_bwt_f_scan_min"); prims::launch_scan<prims::SCAN_MIN_INCL>(s, w.t2, w.t3, nWin, nullptr, w.scanTmp); }
         // run lengths of every position, and the starts of the runs of run-group bytes as a bit map
         hipMemsetAsync(w.classTab, 0xFF, 1024ull * (size_t)st.nBlocks, s);

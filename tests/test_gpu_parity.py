@@ -423,7 +423,11 @@ def test_full_size_reference_stream_config5_lzx_ans1_16m(hip):
     _full_case(hip, 5)
 
 
-@pytest.mark.parametrize("name", [c[0] for c in vectors.HARD_CASES])
+def test_full_size_reference_stream_config4_four_blocks_of_32m(hip):
+    _full_case(hip, "config4:4blocks")
+
+
+@pytest.mark.parametrize("name", [c[0] for c in vectors.HARD_CASES if c[0].startswith("hard:")])
 def test_long_common_prefix_inputs_at_full_block_size(hip, name):
     """Inputs a prefix-doubling sorter finds hard (copies with edits, X || X, periods 3 / 5 / 7 / 768, the Fibonacci word, DNA with
     repeats, one constant block) at 8 MiB / 32 MiB blocks: the device stream must be the reference's .knz (digests from oracle/_ref)."""

@@ -136,4 +136,6 @@ HARD_CASES = [
     ("hard:dna", ("dna", 16 << 20, 4), "BWT+MTFT+ZRLT", "ANS0", 8 << 20),
     ("hard:const", ("const", 8 << 20, 65), "BWT+MTFT+ZRLT", "ANS0", 8 << 20),
     ("hard:repeats_srt", ("repeats", 32 << 20, 5), "BWT+SRT+ZRLT", "ANS0", 32 << 20),
+    # config 4's chain on four blocks of its own size: block ids 2 and 3 of a 32 MiB stream (slot model i % jobs, first_block_id)
+    ("config4:4blocks", ("text", 128 << 20, 1), "BWT+SRT+ZRLT", "FPAQ", 32 << 20),
 ]
