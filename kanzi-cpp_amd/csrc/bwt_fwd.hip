@@ -960,7 +960,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 128) void k_bwt_f_sort_medium(Fw
         u32 c = 0;
         for (u32 i = (u32)tid; i < n; i += THREADS) c += (L.oK[i] == m) ? 1u : 0u;
         c = med_block_sum(L, c);
-        if (c < n && 2 * c >= n && superList != nullptr && m == info.y - info.x + 1u && !(v.rtbits && ((v.rtbits[gs >> 5] >> (gs & 31)) & 1u))) {
+        if (c < n && 2 * c >= n && superList != nullptr && m == info.y - info.x + 1u) {
             // the majority looks at the group itself (a periodic stretch whose period divides h): k_bwt_f_super finishes it in one round
             if (tid == 0) { const u32 at = atomicAdd(&v.counters[7], 1u); superList[at] = make_uint4(gs, n, info.x, info.y); }
             __syncthreads();
@@ -1080,14 +1080,17 @@ __global__ __launch_bounds__(1024) void k_bwt_f_super(FwdView v, const uint4* __
         if (tid == 0) { sEnds = 0; sCmax = 0; L.oldLab = d.w; }
         __syncthreads();
         const u32 m = d.w - d.z + 1u;
-        // ---- chain links: the member h further on
+        // the offset the group's keys were gathered at (k_bwt_f_gather_desc): h, or what the group is known to share beyond it
+        u32 link = h;
+        if (v.rtbits && ((v.rtbits[gs >> 5] >> (gs & 31)) & 1u)) { const u32 r = v.ovr[gs]; link = r > h ? r : h; }
+        // ---- chain links: the member `link` further on
 #pragma unroll 4
         for (int r = 0; r < ROWS; r++) {
             const u32 i = (u32)tid + (u32)r * THREADS;
             if (i >= n) continue;
             u32 to = i, one = 0;
             if (L.oK[i] == m) {
-                const u32 target = L.oV[i] + h;
+                const u32 target = L.oV[i] + link;
                 u32 lo = i + 1, hi = n;                     // first index with position >= target
                 while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (L.oV[mid] < target) lo = mid + 1; else hi = mid; }
                 if (lo < n && L.oV[lo] == target) { to = lo; one = 1; }
@@ -1188,6 +1191,128 @@ __global__ __launch_bounds__(1024) void k_bwt_f_super(FwdView v, const uint4* __
         __syncthreads();
         med_write_back<THREADS, ROWS>(L, v, gs, n, medNext, largeNext);
         __syncthreads();
+    }
+}
+
+constexpr u32 PROBE_PMAX = 2048;
+// Periodic stretches of ANY period, found by looking at the text (once, in front of the first doubling round). The members of a medium group are
+// in position order; when most neighbours are the same distance P apart the group is mostly made of chains p, p + P, p + 2P, ...
+// through stretches of period P, and doubling would refine it log2(stretch / h) times, peeling off only the members near the ends of
+// the stretches each time, before the chain round can see the group look at itself (which it only does once P divides h). Here every
+// member is compared with ONE member's text over the P symbols behind the ones the group shares: members that differ leave, ordered by
+// where they differ and how (an ordinary refinement: a member that falls below the pattern earlier is smaller, one that rises above it
+// earlier is larger, same place and byte stay together); the members that equal the pattern stay one group that is now KNOWN to share P
+// symbols, which is recorded like a run length (FwdView::ovr / rtbits): its keys are gathered P positions on, where most members find
+// the group itself, and the chain round finishes it in the first doubling round whatever P is (a block of text(2000) + 550 copies of a
+// random 700-byte unit: 16 doubling rounds without this, 1 with it).
+// candidates: medium groups with three equal distances around their middle member, a distance that is no power of two
+// (a period that is a power of two is left to the doubling rounds: the chain round takes the group as soon as h reaches it, and the rounds up
+// to there are cheap -- the majority of the members looks at one and the same group and is split off unsorted; measured on the stand-in's
+// period-256 stretches the text comparison costs 3.4 ms and saves 1.7. Any other period never meets h.)
+__global__ __launch_bounds__(256) void k_bwt_f_probe_scan(FwdView v, const uint2* __restrict__ desc, u32 depth, const u32* __restrict__ rtbits, u32* __restrict__ cand)
+{
+    const u32 nDesc = v.counters[1];
+    for (u32 g = blockIdx.x * 256 + threadIdx.x; g < nDesc; g += gridDim.x * 256) {
+        const uint2 d = desc[g];
+        const u32 gs = d.x, n = d.y;
+        if (n <= SM_G || n > MED_CAP) continue;
+        if (rtbits != nullptr && ((rtbits[gs >> 5] >> (gs & 31)) & 1u)) continue;         // (groups of the run round know their offset already)
+        const u32 a0 = v.SA[gs + (n >> 1) - 2], a1 = v.SA[gs + (n >> 1) - 1], a2 = v.SA[gs + (n >> 1)], a3 = v.SA[gs + (n >> 1) + 1];
+        const u32 pd = a2 - a1;
+        if ((a1 - a0 == pd) && (a3 - a2 == pd) && (pd > depth) && (pd <= 2048u) && ((pd & (pd - 1)) != 0)) cand[atomicAdd(&v.counters[14], 1u)] = g;
+    }
+}
+
+__global__ __launch_bounds__(512, 4) void k_bwt_f_probe(BwtView bv, FwdView v, uint2* __restrict__ desc, const u32* __restrict__ cand, u32 nCand, u32 depth, uint2* __restrict__ medNext,
+                                                        uint2* __restrict__ largeNext, u32* __restrict__ ovr, u32* __restrict__ rtbits)
+{
+    constexpr int THREADS = 512, ROWS = 16;
+    constexpr u32 CAP = (u32)ROWS * THREADS;
+    __shared__ MedLds<THREADS, ROWS> L;
+    __shared__ u32 patw[PROBE_PMAX / 4];
+    u8* pat = reinterpret_cast<u8*>(patw);
+    __shared__ u32 sInfo[4];                 // block base, block end, label of the group, -
+    const int tid = (int)threadIdx.x;
+    for (u32 cg = blockIdx.x; cg < nCand; cg += gridDim.x) {
+        const u32 g = cand[cg];
+        const uint2 d = desc[g];
+        const u32 gs = d.x, n = d.y;
+        bool take = n > SM_G && n <= CAP;
+        __syncthreads();                                     // (LDS of the group before)
+        if (take) {
+            for (u32 i = (u32)tid; i < n; i += THREADS) L.oV[i] = v.SA[gs + i];
+            if (tid == 0) {
+                const int b = find_block(v.base, v.nBlocks, gs);
+                sInfo[0] = v.base[b]; sInfo[1] = v.base[b + 1]; sInfo[3] = (u32)b;
+            }
+        }
+        __syncthreads();
+        u32 P = 0, pr = 0;
+        if (take) {
+            pr = L.oV[n >> 1];
+            P = pr - L.oV[(n >> 1) - 1];
+            take = P > depth && P <= PROBE_PMAX && pr + P <= sInfo[1];
+        }
+        if (take) {
+            u32 c = 0;
+            for (u32 i = (u32)tid; i + 1 < n; i += THREADS) c += (L.oV[i + 1] - L.oV[i] == P) ? 1u : 0u;
+            c = med_block_sum(L, c);
+            take = 2 * c >= n;
+        }
+        if (!take) continue;                                  // (uniform) the group goes on as it is
+        const u32 bb = sInfo[0], be = sInfo[1];
+        const u8* t = bv.src[sInfo[3]];
+        for (u32 j = (u32)tid; j < P; j += THREADS) pat[j] = t[pr - bb + j];
+        if (tid == 0) sInfo[2] = v.ISA[pr];
+        __syncthreads();
+        // ---- every member against the pattern: where and how it differs
+        constexpr u32 MID = 1u << 21;
+        u32 nEq = 0, nBelow = 0;
+        for (u32 i = (u32)tid; i < n; i += THREADS) {
+            const u32 q0 = L.oV[i] - bb;
+            u32 l = depth;
+            // sixteen bytes at a time while they agree: the member's from five aligned dwords (all loads issued together), the pattern's
+            // as dwords from LDS (`depth` and the steps are multiples of four)
+            if ((depth & 3u) == 0) {
+                const u32* pw = patw;
+                while (l + 16 <= P && q0 + l + 20 <= be - bb) {
+                    const uintptr_t ad = reinterpret_cast<uintptr_t>(t + q0 + l);
+                    const u32* w = reinterpret_cast<const u32*>(ad & ~(uintptr_t)3);
+                    const u32 sh = (u32)(ad & 3) * 8;
+                    const u32 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
+                    const u32 x0 = sh ? ((w0 >> sh) | (w1 << (32 - sh))) : w0, x1 = sh ? ((w1 >> sh) | (w2 << (32 - sh))) : w1;
+                    const u32 x2 = sh ? ((w2 >> sh) | (w3 << (32 - sh))) : w2, x3 = sh ? ((w3 >> sh) | (w4 << (32 - sh))) : w3;
+                    const u32 d0 = x0 ^ pw[l >> 2], d1 = x1 ^ pw[(l >> 2) + 1], d2 = x2 ^ pw[(l >> 2) + 2], d3 = x3 ^ pw[(l >> 2) + 3];
+                    if ((d0 | d1 | d2 | d3) != 0) break;
+                    l += 16;
+                }
+            }
+            u32 code = MID;
+            while (l < P) {
+                if (q0 + l >= be - bb) { code = l * 512u; break; }                        // the suffix ends here: a proper prefix sorts first
+                const u32 x = t[q0 + l], y = pat[l];
+                if (x != y) { code = (x < y) ? (l * 512u + x + 1u) : (MID + 1u + (P - l) * 512u + x + 1u); break; }
+                l++;
+            }
+            L.oK[i] = code;
+            nEq += (code == MID) ? 1u : 0u;
+            nBelow += (code < MID) ? 1u : 0u;
+        }
+        nEq = med_block_sum(L, nEq);
+        nBelow = med_block_sum(L, nBelow);
+        if (2 * nEq < n) continue;                            // the pattern was not the stretches' (or there are none): nothing was written
+        // the parts of the group are staged for the next round's list (med_write_back); this round's descriptor is void
+        if (tid == 0) { L.oldLab = sInfo[2]; desc[g].y = 0; }
+        med_radix_sort<THREADS, ROWS>(L, n, 3);
+        med_write_back<THREADS, ROWS>(L, v, gs, n, medNext, largeNext);
+        // what every member is now known to share with the members it stays together with: the ones that equal the pattern P symbols
+        // (slots [gs + nBelow, + nEq)), a member that left at symbol l with the ones that left there with the same byte l + 1
+        for (u32 i = (u32)tid; i < n; i += THREADS) {
+            const u32 code = L.oK[i];
+            const u32 lshare = (code == MID) ? P : ((code < MID) ? (code >> 9) : (P - ((code - MID - 1u) >> 9))) + 1u;
+            ovr[gs + i] = lshare;
+            atomicOr(&rtbits[(gs + i) >> 5], 1u << ((gs + i) & 31));
+        }
     }
 }
 
@@ -1616,11 +1741,12 @@ __global__ __launch_bounds__(256) void k_bwt_f_med_compact(uint2* __restrict__ s
 }
 
 // knobs (tests, tuning): read from the environment once per process, or set through knz_hip_tune()
-struct FwdTuning { int nsym; int noRunRound; int runFallback; int noSuper; int noTextRound; int stats; int noRunOffsets; };
+struct FwdTuning { int nsym; int noRunRound; int runFallback; int noSuper; int noTextRound; int stats; int noRunOffsets; int noProbe; };
 static FwdTuning& fwd_tuning()
 {
     static FwdTuning t = [] {
-        FwdTuning x; x.nsym = 0; x.noRunRound = 0; x.runFallback = 0; x.noSuper = 0; x.noTextRound = 0; x.stats = 0; x.noRunOffsets = 0;
+        FwdTuning x; x.nsym = 0; x.noRunRound = 0; x.runFallback = 0; x.noSuper = 0; x.noTextRound = 0; x.stats = 0; x.noRunOffsets = 0; x.noProbe = 0;
+        if (getenv("KNZ_BWT_NO_PROBE")) x.noProbe = 1;
         if (getenv("KNZ_BWT_NO_RUN_OFFSETS")) x.noRunOffsets = 1;
         if (getenv("KNZ_BWT_STATS")) x.stats = 1;
         if (const char* e = getenv("KNZ_BWT_NSYM")) x.nsym = atoi(e);
@@ -1642,6 +1768,7 @@ int bwt_forward_tune(const char* key, int value)
     else if (!strcmp(key, "bwt_no_text_round")) t.noTextRound = value;
     else if (!strcmp(key, "bwt_stats")) t.stats = value;
     else if (!strcmp(key, "bwt_no_run_offsets")) t.noRunOffsets = value;
+    else if (!strcmp(key, "bwt_no_probe")) t.noProbe = value;
     else return -1;
     return 0;
 }
@@ -1672,7 +1799,8 @@ static size_t fwd_carve(u8* p, int nBlocks, size_t total, FwdScratch* w)
 {
     u8* q = p;
     auto take = [&](size_t sz) { u8* r = q; q += fwd_align(sz); return r; };
-    const size_t maxMed = total / (SM_G + 1) + 2, maxLarge = total / (MED_CAP + 1) + 2;
+    // (twice the medium groups there can be: the list of the first round may hold groups k_bwt_f_probe took apart, void, beside their parts)
+    const size_t maxMed = 2 * (total / (SM_G + 1) + 2), maxLarge = total / (MED_CAP + 1) + 2;
     w->gbitsWords = ((total + 64) / 64 + SM_WIN / 64 + 4) * 2 + 128;       // (the placement kernel looks 2 SM_TS slots behind a window's start)
     w->keysA = (u64*)take(8 * total); w->keysB = (u64*)take(8 * total);
     w->valsA = (u32*)take(4 * total); w->valsB = (u32*)take(4 * total);
@@ -1815,6 +1943,13 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
         if (hipStreamSynchronize(s) != hipSuccess) return -1;
         nRun = 0;
     }
+    // candidates for k_bwt_f_probe among the medium groups of the list just compacted (their number comes back with the counters)
+    u32* probeCand = w.medFlags;                                  // (free between two compactions)
+    auto probeScan = [&]() {
+        if (tune.noProbe) return;
+        KScope ks_("k_bwt_f_probe");
+        hipLaunchKernelGGL(k_bwt_f_probe_scan, dim3(256), dim3(256), 0, s, v, w.med[cur], (u32)nsym, v.rtbits, probeCand);
+    };
     prims::RsWs rs1 = prims::rs_carve(w.rsMem, maxTotal, st.nBlocks + 1, w.seg2, 1);     // single-segment sorts of the rounds: [0, seg2[1])
     if (nRun) {
         // run lengths of every position (text order), then one sort of the run groups' members on (run length, what follows)
@@ -1880,6 +2015,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
           if (runOffsets) { v.ovr = w.ovr; v.rtbits = w.rtbits; } }
         { KScope ks_("k_bwt_f_merge_bits"); hipLaunchKernelGGL(k_bwt_f_merge_bits, GRID1(total / 32 + 2), w.gbits, w.gnew, total / 32 + 2); }
         compactMedium(w.med[cur]);
+        probeScan();
         medCompacted = true;
         if (hipMemcpyAsync(h_pinned, w.counters, 64, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
         if (hipStreamSynchronize(s) != hipSuccess) return -1;
@@ -1887,10 +2023,25 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     }
     if (!medCompacted) {
         compactMedium(w.med[cur]);
+        probeScan();
         if (hipMemcpyAsync(h_pinned, w.counters, 64, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
         if (hipStreamSynchronize(s) != hipSuccess) return -1;
     }
     u32 surv = h_pinned[0], nMed = h_pinned[1], nLarge = h_pinned[2], largeElems = h_pinned[3];
+    if (const u32 nCand = tune.noProbe ? 0u : h_pinned[14]) {
+        // Periodic stretches of a period the doubling offsets never meet, by looking at the text (k_bwt_f_probe), before the first round: the
+        // groups it takes apart are void in the list (length 0), their parts that are medium groups are appended to it
+        if (!v.rtbits) { hipMemsetAsync(w.rtbits, 0, 4 * w.gbitsWords, s); v.ovr = w.ovr; v.rtbits = w.rtbits; }
+        hipMemsetAsync(w.counters, 0, 8, s);
+        { KScope ks_("k_bwt_f_probe");
+          hipLaunchKernelGGL(k_bwt_f_probe, dim3(std::min<u32>(nCand, 4096)), dim3(512), 0, s, bv, v, w.med[cur], probeCand, nCand, (u32)nsym, w.med[cur ^ 1], w.large[cur], w.ovr, w.rtbits);
+          hipLaunchKernelGGL(k_bwt_f_merge_bits, GRID1(total / 32 + 2), w.gbits, w.gnew, total / 32 + 2); }
+        compactMedium(w.med[cur] + nMed);
+        if (hipMemcpyAsync(h_pinned, w.counters, 8, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+        if (hipStreamSynchronize(s) != hipSuccess) return -1;
+        surv |= h_pinned[0];
+        nMed += h_pinned[1];
+    }
     if (tune.stats) fprintf(stderr, "after round 0 (nsym %d, total %u): run groups %u (%u members); small left %u, medium %u, large %u (%u members)\n",
                             nsym, total, nRun, runElems, surv, nMed, nLarge, largeElems);
 

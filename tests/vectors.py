@@ -132,6 +132,7 @@ HARD_CASES = [
     ("hard:period5", ("periodic", (8 << 20) - 3, 6, 5), "BWT+MTFT+ZRLT", "ANS0", 8 << 20),
     ("hard:period7", ("periodic", 8 << 20, 7, 7), "BWT+MTFT+ZRLT", "ANS0", 8 << 20),
     ("hard:period768", ("periodic", 8 << 20, 8, 768), "BWT+MTFT+ZRLT", "ANS0", 8 << 20),
+    ("hard:period1500", ("periodic", 8 << 20, 9, 1500), "BWT+MTFT+ZRLT", "ANS0", 8 << 20),      # medium groups of a period no power of two: k_bwt_f_probe
     ("hard:fibword", ("fibword", 8 << 20), "BWT+MTFT+ZRLT", "ANS0", 8 << 20),
     ("hard:dna", ("dna", 16 << 20, 4), "BWT+MTFT+ZRLT", "ANS0", 8 << 20),
     ("hard:const", ("const", 8 << 20, 65), "BWT+MTFT+ZRLT", "ANS0", 8 << 20),
