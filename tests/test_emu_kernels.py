@@ -74,11 +74,47 @@ def test_bwt_forward_kernels_emulated(tmp_path):
         for order in (("0", "1", "2") if i in (2, 5, 6) else ("0", "2")):       # workgroup dispatch order is not defined: forward, reverse, shuffled
             r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900, env=dict(os.environ, HIPEMU_ORDER=order))
             assert r.returncode == 0, (i, order, r.stdout[-2000:] + r.stderr[-2000:])
-        # the same without the run-length round (run groups refined by doubling like any other group), and with the run groups
-        # handed back to the ordinary lists (the path taken when a batch has more run groups than the sort key has index bits)
-        for var in ("KNZ_BWT_NO_RUN_ROUND", "KNZ_BWT_RUN_FALLBACK"):
-            r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900, env=dict(os.environ, **{var: "1"}))
+        # the same without the run-length round (run groups refined by doubling like any other group), with the run groups
+        # handed back to the ordinary lists (the path taken when a batch has more run groups than the sort key has index bits),
+        # without the "look behind the run" offsets of the groups the run round leaves tied, without the periodic-stretch probe, and
+        # with round-0 placement and text round as two kernels
+        for var in ("KNZ_BWT_NO_RUN_ROUND", "KNZ_BWT_RUN_FALLBACK", "KNZ_BWT_NO_RUN_OFFSETS", "KNZ_BWT_NO_PROBE", "KNZ_BWT_NO_TEXT_ROUND"):
+            r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900, env=dict(os.environ, **{var: "2" if var == "KNZ_BWT_NO_TEXT_ROUND" else "1"}))
             assert r.returncode == 0, (i, var, r.stdout[-2000:] + r.stderr[-2000:])
+
+
+def test_bwt_forward_long_common_prefixes_emulated(tmp_path):
+    """The shapes of tests/vectors.HARD_CASES at emulator size: copies with edits, X || X, periods 3 / 5 / 7 (large groups all the way),
+    period 700 and 1500 in medium groups (k_bwt_f_probe: one doubling round instead of ~16), ramps of period 256 and 64 (chain round),
+    the Fibonacci word, DNA with repeats, sparse values in zero runs and runs of random lengths (groups the run round leaves tied look
+    behind their run)."""
+    exe = build("bwt_fwd_emu", tmp_path)
+    c = knzlib.corpus()
+    rng = np.random.default_rng(5)
+    unit = rng.integers(0, 256, 700, dtype=np.uint8).tobytes()
+    z = bytearray(120000)
+    for p in rng.integers(0, len(z), len(z) // 64):
+        z[p] = int(rng.integers(1, 4))
+    runs = bytearray()
+    while len(runs) < 100000:
+        runs += bytes([int(rng.integers(0, 3))]) * int(rng.geometric(0.03))
+    ramp = lambda n, k, o=0: bytes(((np.arange(n) + o) % k).astype(np.uint8))
+    cases = [
+        [c.repeats(150000, 3), c.tile(100000, 1, 50000)],
+        [c.periodic(60000, 5, 3), c.periodic(59997, 6, 5), c.periodic(60000, 7, 7)],
+        [unit * 300 + c.text(2000, 6) + unit * 250, c.periodic(600000, 9, 1500)],
+        [ramp(140000, 256) + c.text(3000, 1) + ramp(90000, 256, 7), ramp(60000, 64) + c.text(500, 2) + ramp(40000, 64, 3)],
+        [c.fibword(60000), c.dna(100000, 4)],
+        [bytes(z), bytes(runs[:100000])],
+    ]
+    for i, blocks in enumerate(cases):
+        path = str(tmp_path / ("hard%d.bin" % i))
+        write_case(path, blocks)
+        for order in ("0", "2"):
+            r = subprocess.run([exe, path], capture_output=True, text=True, timeout=1800, env=dict(os.environ, HIPEMU_ORDER=order, KNZ_BWT_STATS="1"))
+            assert r.returncode == 0, (i, order, r.stdout[-2000:] + r.stderr[-2000:])
+            if i == 2:
+                assert r.stderr.count("round h=") <= 2, r.stderr[-1500:]          # the probe took the periodic groups
 
 
 def test_fpaq_kernels_emulated(tmp_path):

@@ -10,6 +10,9 @@ cpif $SRC/bench1.json ${P}_bench_config1.json
 cpif $SRC/bench4.json ${P}_bench_config4.json
 cpif $SRC/bench5.json ${P}_bench_config5.json
 cpif $SRC/bench7.json ${P}_bench_config7_text.json
+cpif $SRC/bench8.json ${P}_bench_config8_repeats.json
+cpif $SRC/bench3x2.json ${P}_bench_config3_2ranks_one_gpu_smoke.json
+cpif $SRC/hard.txt ${P}_hard_inputs.txt
 cpif $SRC/prof3_kernel_stats.txt ${P}_config3_kernel_stats.txt
 cpif $SRC/prof3_kernel_stats.csv ${P}_config3_kernel_stats.csv
 cpif $SRC/prof4_kernel_stats.txt ${P}_config4_kernel_stats.txt
