@@ -85,7 +85,7 @@ def test_bwt_forward_kernels_emulated(tmp_path):
 
 def test_bwt_forward_long_common_prefixes_emulated(tmp_path):
     """The shapes of tests/vectors.HARD_CASES at emulator size: copies with edits, X || X, periods 3 / 5 / 7 (large groups all the way),
-    period 700 and 1500 in medium groups (k_bwt_f_probe: one doubling round instead of ~16), ramps of period 256 and 64 (chain round),
+    period 700 and 520 in medium groups (k_bwt_f_probe: one doubling round instead of ~16), ramps of period 256 and 64 (chain round),
     the Fibonacci word, DNA with repeats, sparse values in zero runs and runs of random lengths (groups the run round leaves tied look
     behind their run)."""
     exe = build("bwt_fwd_emu", tmp_path)
@@ -100,17 +100,17 @@ def test_bwt_forward_long_common_prefixes_emulated(tmp_path):
         runs += bytes([int(rng.integers(0, 3))]) * int(rng.geometric(0.03))
     ramp = lambda n, k, o=0: bytes(((np.arange(n) + o) % k).astype(np.uint8))
     cases = [
-        [c.repeats(150000, 3), c.tile(100000, 1, 50000)],
-        [c.periodic(60000, 5, 3), c.periodic(59997, 6, 5), c.periodic(60000, 7, 7)],
-        [unit * 300 + c.text(2000, 6) + unit * 250, c.periodic(600000, 9, 1500)],
-        [ramp(140000, 256) + c.text(3000, 1) + ramp(90000, 256, 7), ramp(60000, 64) + c.text(500, 2) + ramp(40000, 64, 3)],
+        [c.repeats(100000, 3), c.tile(60000, 1, 30000)],
+        [c.periodic(30000, 5, 3), c.periodic(29997, 6, 5), c.periodic(30000, 7, 7)],
+        [unit * 150 + c.text(2000, 6) + unit * 130, c.periodic(140000, 9, 520)],
+        [ramp(80000, 256) + c.text(3000, 1) + ramp(70000, 256, 7), ramp(30000, 64) + c.text(500, 2) + ramp(20000, 64, 3)],
         [c.fibword(60000), c.dna(100000, 4)],
         [bytes(z), bytes(runs[:100000])],
     ]
     for i, blocks in enumerate(cases):
         path = str(tmp_path / ("hard%d.bin" % i))
         write_case(path, blocks)
-        for order in ("0", "2"):
+        for order in (("0", "2") if i == 2 else ("2",)):
             r = subprocess.run([exe, path], capture_output=True, text=True, timeout=1800, env=dict(os.environ, HIPEMU_ORDER=order, KNZ_BWT_STATS="1"))
             assert r.returncode == 0, (i, order, r.stdout[-2000:] + r.stderr[-2000:])
             if i == 2:
