@@ -228,6 +228,31 @@ public:
     LZCodec() : DeviceTransform(KNZ_T_LZ, nullptr) {}
     explicit LZCodec(Context& ctx);
 };
+// ---- transforms on the host (kanzi-cpp_amd/host/text_codec.cpp): the stages of the level presets 5 and 6 that sit in front of the
+// device chain. transform/TextCodec.hpp:140-215 (the encoding -- word indexes behind an escape byte or with the top bit set -- follows the
+// context's "textcodec" entry, which TransformFactory derives from the entropy codec, TransformFactory.hpp:225-242), transform/UTFCodec.hpp:41-66.
+// Both read and write the context's "dataType" like the reference's.
+class TextCodec : public Transform<byte> {
+public:
+    TextCodec() : _ctx(nullptr), _variant(1), _blockSize(0), _bsVersion(6) {}
+    explicit TextCodec(Context& ctx);
+    bool forward(SliceArray<byte>& src, SliceArray<byte>& dst, int length);
+    bool inverse(SliceArray<byte>& src, SliceArray<byte>& dst, int length);
+    int getMaxEncodedLength(int n) const { return n; }
+private:
+    Context* _ctx;
+    int _variant, _blockSize, _bsVersion;
+};
+class UTFCodec : public Transform<byte> {
+public:
+    UTFCodec() : _ctx(nullptr) {}
+    explicit UTFCodec(Context& ctx) : _ctx(&ctx) {}
+    bool forward(SliceArray<byte>& src, SliceArray<byte>& dst, int length);
+    bool inverse(SliceArray<byte>& src, SliceArray<byte>& dst, int length);
+    int getMaxEncodedLength(int n) const { return n + 8192; }
+private:
+    Context* _ctx;
+};
 class NullTransform : public Transform<byte> {
 public:
     NullTransform() {}
@@ -335,7 +360,7 @@ public:
     // call takes at most 2 GiB of input)
     void setBatchBlocks(int n)
     {
-        if (n <= 0 || _batchBytes != 0) return;
+        if (n <= 0 || _batchBytes != 0 || _hosted) return;
         const long long lim = (1ll << 31) / (long long)_blockSize - 1;
         _batchBlocks = (long long)n > lim ? int(lim < 1 ? 1 : lim) : n;
     }
@@ -344,6 +369,8 @@ private:
     std::ostream& _os;
     int _jobs, _blockSize, _checksum;
     short _entropyType;
+    int _hosted;                  // leading stages of the chain that run on the host (TEXT, UTF): blocks then go to the device one by one
+    int _hostIds[8];
     uint64 _transformType;
     uint64 _inputSize;
     bool _headless, _closed, _headerDone;
@@ -361,6 +388,7 @@ private:
     // thread appends the runs in order (from write() / close()), OR-ing the byte two runs share: the reference's ordered
     // bit-granular append (io/CompressedOutputStream.cpp:835-868) with whole batches as the unit.
     struct Lane {
+        std::vector<uint8_t> hostA, hostB;      // output of the host stages of a block (chains that start with TEXT / UTF)
         int device; knz_ctx* ctx; std::thread worker;
         byte* in; size_t inCap; size_t n; bool last; void* dIn; size_t dInCap; uint64 ticket;
         void* dOut; size_t dOutCap; void* dShift; size_t dShiftCap;
@@ -411,6 +439,8 @@ private:
     std::istream& _is;
     int _jobs, _blockSize, _checksum;
     short _entropyType;
+    int _hosted;                  // see CompressedOutputStream
+    int _hostIds[8];
     uint64 _transformType;
     uint64 _outputSize;
     bool _headless, _closed, _headerDone, _ended;

@@ -29,7 +29,8 @@ extern "C" {
 /* kanzi ids: entropy (entropy/EntropyEncoderFactory.hpp:37-52) and transforms (transform/TransformFactory.hpp:49-73) */
 enum { KNZ_E_NONE = 0, KNZ_E_HUFFMAN = 1, KNZ_E_FPAQ = 2, KNZ_E_ANS0 = 5, KNZ_E_ANS1 = 8 };
 enum { KNZ_T_NONE = 0, KNZ_T_BWT = 1, KNZ_T_LZ = 3, KNZ_T_RLT = 5, KNZ_T_ZRLT = 6, KNZ_T_MTFT = 7, KNZ_T_RANK = 8, KNZ_T_SRT = 13, KNZ_T_LZX = 16,
-       KNZ_T_TIMESTAMP = 64 /* SBRT's third mode: no kanzi id, never part of a chain; per-stage entry points only */ };
+       KNZ_T_TIMESTAMP = 64 /* SBRT's third mode: no kanzi id, never part of a chain; per-stage entry points only */,
+       KNZ_T_TEXT = 10, KNZ_T_UTF = 17 /* stages that run on the HOST in front of the device chain: knz_hip_encode_block_hosted / _decode_ */ };
 
 /* kanzi error codes surfaced for data errors (src/Error.hpp:26-48) */
 enum { KNZ_ERR_BLOCK_SIZE = 2, KNZ_ERR_INVALID_CODEC = 3, KNZ_ERR_READ_FILE = 11, KNZ_ERR_WRITE_FILE = 12,
@@ -100,6 +101,29 @@ KNZ_API int knz_hip_encode_blocks(knz_ctx* ctx, const knz_params* p, const uint8
 KNZ_API int knz_hip_decode_blocks(knz_ctx* ctx, const knz_params* p, const uint8_t* d_in, uint64_t in_bits,
                                   uint64_t start_bit, int64_t max_blocks, uint8_t* d_out, size_t out_cap,
                                   uint64_t* out_bytes, uint64_t* end_bit, int64_t* blocks_done);
+
+/*
+ * Chains whose first stages run on the host (the reference's level presets 5 and 6: TEXT + UTF in front of BWT + RANK / SRT + ZRLT,
+ * app/BlockCompressor.cpp:583-591). The host applies those stages to ONE block (they change its length by a different amount per block)
+ * and hands over what TransformSequence::forward would have left for the next stage (transform/TransformSequence.hpp:88-162):
+ *   stages        how many leading stages of p->transform_type the host owns (each KNZ_T_TEXT or KNZ_T_UTF)
+ *   applied_mask  bit i set = stage i succeeded (its skip flag is clear, and it counts as a buffer swap for the capacities the
+ *                 device stages see); clear = the stage refused the block and the block went on unchanged
+ *   orig_len      length of the block before any stage (decides copy blocks and the buffer sizes of the reference)
+ *   checksum      XXHash32 / 64 of the ORIGINAL block when p->checksum_bits != 0 (the device only ever sees the transformed bytes)
+ * d_in holds the n bytes the host stages left. Everything else as knz_hip_encode_blocks with exactly one block; the block header
+ * carries the skip flags of all stages (a separate byte when the chain has more than four, io/CompressedOutputStream.cpp:791-799).
+ */
+typedef struct { int32_t stages; uint32_t applied_mask; uint32_t orig_len; uint32_t reserved; uint64_t checksum; } knz_host_stages;
+KNZ_API int knz_hip_encode_block_hosted(knz_ctx* ctx, const knz_params* p, const knz_host_stages* hs, const uint8_t* d_in, size_t n,
+                                        const uint8_t* prologue, uint32_t prologue_bits, int64_t first_block_id, int finish,
+                                        uint8_t* d_out, size_t out_cap, uint64_t* out_bits);
+/* The way back: ONE block is entropy-decoded and taken through the inverse of the device stages; the host stages are left to the
+ * caller, who gets the block's skip flags (bit 7 = stage 0; 0xFF for a copy block) and its stored checksum (not verified here: it is
+ * the checksum of the original block). *done = 0 when the end marker was found instead of a block. */
+KNZ_API int knz_hip_decode_block_hosted(knz_ctx* ctx, const knz_params* p, int32_t host_stages, const uint8_t* d_in, uint64_t in_bits,
+                                        uint64_t start_bit, uint8_t* d_out, size_t out_cap, uint64_t* out_bytes, uint64_t* end_bit,
+                                        uint32_t* skip_flags, uint64_t* checksum, int32_t* done);
 
 /* ---- per-stage entry points (host buffers in/out; used by the host mirror classes and tests) ---- */
 

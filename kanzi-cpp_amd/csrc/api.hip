@@ -155,6 +155,7 @@ static int count_transforms(uint64_t t, int* tok)
     return nb;
 }
 
+static bool host_stage_id(int t) { return t == KNZ_T_TEXT || t == KNZ_T_UTF; }
 static bool transform_supported(int t) { return t == KNZ_T_NONE || t == KNZ_T_ZRLT || t == KNZ_T_MTFT || t == KNZ_T_BWT || t == KNZ_T_SRT || t == KNZ_T_RLT || t == KNZ_T_LZ || t == KNZ_T_LZX || t == KNZ_T_RANK || t == KNZ_T_TIMESTAMP; }
 static bool entropy_supported(int e) { return e == KNZ_E_NONE || e == KNZ_E_ANS0 || e == KNZ_E_ANS1 || e == KNZ_E_HUFFMAN || e == KNZ_E_FPAQ; }
 
@@ -165,6 +166,7 @@ static int max_encoded_len(int t, int n)
     case KNZ_T_SRT: return n + 1024;
     case KNZ_T_RLT: return (n <= 512) ? n + 32 : n;
     case KNZ_T_LZ: case KNZ_T_LZX: return ((n <= 1024) ? n + 16 : n + n / 64) + 2;     // LZCodec.hpp:91-95
+    case KNZ_T_UTF: return n + 8192;                                                   // UTFCodec.hpp:54 (a host stage: only its share of the chain's buffer size matters here)
     default: return n;
     }
 }
@@ -600,7 +602,7 @@ static int run_inverse_stage(Ctx* c, hipStream_t s, int t, const XfStage& st)
 // capsMode: 0 = reference stream buffers (jobs model), otherwise every destination capacity = capsMode (per-stage API)
 static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t n, const uint8_t* prologue,
                        uint32_t prologueBits, int framing, int finish, int64_t firstBlock, uint8_t* d_out, size_t outCap,
-                       uint64_t* outBits)
+                       uint64_t* outBits, const knz_host_stages* hs = nullptr)
 {
     ProfInstall pi_(c);
     HIPCHK(c, hipSetDevice(c->device));
@@ -610,14 +612,22 @@ static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t 
     if (framing && (bs < 1024 || bs > (1u << 30) || (bs & 15))) return fail(c, KNZ_ERR_INVALID_PARAM, "invalid block size %u", bs);
     int tok[8];
     const int nTok = count_transforms(p->transform_type, tok);
-    for (int i = 0; i < nTok; i++)
-        if (!transform_supported(tok[i])) return fail(c, KNZ_ERR_INVALID_CODEC, "transform id %d not implemented on device", tok[i]);
+    const int nHosted = hs ? hs->stages : 0;
+    if (nHosted < 0 || nHosted > nTok) return fail(c, KNZ_ERR_INVALID_PARAM, "host stage count %d does not fit the chain", nHosted);
+    for (int i = 0; i < nTok; i++) {
+        if (i < nHosted) { if (!host_stage_id(tok[i])) return fail(c, KNZ_ERR_INVALID_CODEC, "transform id %d is no host stage", tok[i]); }
+        else if (!transform_supported(tok[i])) return fail(c, KNZ_ERR_INVALID_CODEC, "transform id %d not implemented on device", tok[i]);
+    }
     if (!entropy_supported(p->entropy_type)) return fail(c, KNZ_ERR_INVALID_CODEC, "entropy id %d not implemented on device", p->entropy_type);
-    if (nTok > 4) return fail(c, KNZ_ERR_INVALID_CODEC, "more than 4 transforms not supported");
     if (p->checksum_bits != 0 && p->checksum_bits != 32 && p->checksum_bits != 64) return fail(c, KNZ_ERR_INVALID_PARAM, "checksum must be 0, 32 or 64");
     hipStream_t s = c->stream;
 
     const int nBlocks = (n == 0) ? 0 : (int)((n + bs - 1) / bs);
+    if (hs) {
+        // one block, in the length the host stages left it (never longer than the block it came from)
+        if (nBlocks != 1 || hs->orig_len > bs || n > hs->orig_len + 8192u) return fail(c, KNZ_ERR_INVALID_PARAM, "a hosted call takes exactly one block");
+        if ((hs->orig_len <= 15) != (n <= 15) || (hs->orig_len <= 15 && hs->applied_mask)) return fail(c, KNZ_ERR_INVALID_PARAM, "copy blocks go through no stage");
+    }
     // device-side positions of a batch are 32-bit (suffix array slots, bit offsets inside staging areas): a batch
     // is limited to 2 GiB of input; the host layers split larger inputs into several calls
     if (n > (size_t)0x7FFFFFFF - 8ull * (size_t)(nBlocks + 1) * 1056) return fail(c, KNZ_ERR_INVALID_PARAM, "batch of %zu bytes exceeds the 2 GiB per-call limit", n);
@@ -649,7 +659,7 @@ static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t 
     const u64 S = ((u64)required + 255) & ~255ull;
     bool realStages = false;
     size_t scratch = 0;
-    for (int i = 0; i < nTok; i++) if (tok[i] != KNZ_T_NONE) { realStages = true; const size_t q = stage_scratch_u32(tok[i], nBlocks, (u32)S); if (q > scratch) scratch = q; }
+    for (int i = 0; i < nTok; i++) if (tok[i] != KNZ_T_NONE) { realStages = true; const size_t q = (i < nHosted) ? 0 : stage_scratch_u32(tok[i], nBlocks, (u32)S); if (q > scratch) scratch = q; }
     SeqWs w;
     if (int r = seq_alloc(c, nBlocks, S, realStages, scratch, &w)) return r;
     w.a.origLen = d_origLen;
@@ -659,8 +669,15 @@ static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t 
     u64* d_sums = nullptr;
     if (p->checksum_bits) {
         if (int r = ws_get(c, "sums", sizeof(u64) * nBlocks, (void**)&d_sums)) return r;
-        launch_block_ptrs(s, d_in, bs, nBlocks, w.d_viewPtr);
-        launch_xxhash(s, w.d_viewPtr, d_origLen, nBlocks, p->checksum_bits, d_sums);
+        if (hs) {
+            // (the checksum is the ORIGINAL block's: the host computed it before its stages ran)
+            u64* hsum = reinterpret_cast<u64*>(c->pinned) + 512;
+            *hsum = hs->checksum;
+            HIPCHK(c, hipMemcpyAsync(d_sums, hsum, sizeof(u64), hipMemcpyHostToDevice, s));
+        } else {
+            launch_block_ptrs(s, d_in, bs, nBlocks, w.d_viewPtr);
+            launch_xxhash(s, w.d_viewPtr, d_origLen, nBlocks, p->checksum_bits, d_sums);
+        }
     }
 
     // destination capacities the reference would present (io/CompressedOutputStream.cpp:141,461-462,733-739):
@@ -675,7 +692,7 @@ static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t 
         for (int64_t b = 0; b < nBlocks; b++) {
             const int64_t gid = firstBlock + b;
             const int slot = (int)(gid % jobs);
-            const u32 len = (u32)(((size_t)(b + 1) * bs <= n) ? bs : n - (size_t)b * bs);
+            const u32 len = hs ? hs->orig_len : (u32)(((size_t)(b + 1) * bs <= n) ? bs : n - (size_t)b * bs);      // (the reference sizes its buffers by the block as read)
             const u32 req = (u32)seq_required(tok, nTok, (int)len);
             // a slot's buffer is at least what a full block needed earlier on that slot
             u32 bufc = slotBuf[slot];
@@ -696,6 +713,10 @@ static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t 
     if (direct) launch_seq_fwd_direct(s, w.a, d_origLen, n, bs, nBlocks, nTok, d_in, w.d_viewPtr);
     for (int i = 0; i < nTok && !direct; i++) {
         launch_seq_fwd_prepare(s, w.a, nBlocks, i, d_in, bs, w.A, w.B, S);
+        if (i < nHosted) {
+            launch_seq_fwd_hosted(s, w.a, nBlocks, i, (hs->applied_mask >> i) & 1u);
+            continue;
+        }
         if (tok[i] == KNZ_T_NONE) {
             launch_seq_fwd_null(s, w.a, nBlocks, i);
             continue;
@@ -755,7 +776,7 @@ static int encode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, size_t 
     FrameParams fp;
     fp.framing = framing; fp.nTransforms = nTok; fp.checksumBits = p->checksum_bits; fp.finish = finish; fp.prologueBits = prologueBits;
     launch_block_sum(s, d_desc, d_info, d_blockLen, nBlocks, maxChunks, entChunk, slotMul);
-    launch_block_scan(s, d_info, d_blockLen, nBlocks, fp, d_total);
+    launch_block_scan(s, d_info, d_blockLen, d_origLen, nBlocks, fp, d_total);
     // The output must be zero before the OR-assembly; its size is only known on the device, so the
     // total is read back first (8 bytes) and only the used part is cleared.
     u64* h_total = reinterpret_cast<u64*>(c->pinned);
@@ -793,6 +814,15 @@ int knz_hip_encode_blocks(knz_ctx* ctx, const knz_params* p, const uint8_t* d_in
     return encode_impl(c, p, d_in, n, prologue, prologue_bits, 1, finish, first_block_id, d_out, out_cap, out_bits);
 }
 
+int knz_hip_encode_block_hosted(knz_ctx* ctx, const knz_params* p, const knz_host_stages* hs, const uint8_t* d_in, size_t n, const uint8_t* prologue,
+                                uint32_t prologue_bits, int64_t first_block_id, int finish, uint8_t* d_out, size_t out_cap, uint64_t* out_bits)
+{
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    CTX_LOCK(c);
+    if (!hs) return fail(c, KNZ_ERR_INVALID_PARAM, "no host stage record");
+    return encode_impl(c, p, d_in, n, prologue, prologue_bits, 1, finish, first_block_id, d_out, out_cap, out_bits, hs);
+}
+
 // ------------------------------------------------------------------------------------------------
 // decode
 // ------------------------------------------------------------------------------------------------
@@ -800,7 +830,7 @@ struct WalkResultHost { u64 endBit; int64_t nBlocks; int32_t ended; int32_t erro
 
 static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_t inBits, uint64_t startBit, int64_t maxBlocks,
                        int framing, u32 rawLen, uint8_t* d_out, size_t outCap, uint64_t* outBytes, uint64_t* endBit,
-                       int64_t* blocksDone, int32_t* rawDecoded, uint64_t* usedBits)
+                       int64_t* blocksDone, int32_t* rawDecoded, uint64_t* usedBits, int nHosted = 0, uint32_t* skipOut = nullptr, uint64_t* sumOut = nullptr)
 {
     ProfInstall pi_(c);
     HIPCHK(c, hipSetDevice(c->device));
@@ -810,8 +840,16 @@ static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_
     if (framing && (bs < 1024 || bs > (1u << 30) || (bs & 15))) return fail(c, KNZ_ERR_INVALID_PARAM, "invalid block size %u", bs);
     int tok[8];
     const int nTok = count_transforms(p->transform_type, tok);
-    for (int i = 0; i < nTok; i++)
-        if (!transform_supported(tok[i])) return fail(c, KNZ_ERR_INVALID_CODEC, "transform id %d not implemented on device", tok[i]);
+    if (nHosted < 0 || nHosted > nTok) return fail(c, KNZ_ERR_INVALID_PARAM, "host stage count %d does not fit the chain", nHosted);
+    int tokAll[8];                                           // (the whole chain sizes the buffers, as in the encoder: a UTF stage adds 8 KiB of room)
+    for (int i = 0; i < nTok; i++) tokAll[i] = tok[i];
+    for (int i = 0; i < nTok; i++) {
+        if (i < nHosted) {
+            // the caller undoes these after the call: for the device they are stages that leave the data alone
+            if (!host_stage_id(tok[i])) return fail(c, KNZ_ERR_INVALID_CODEC, "transform id %d is no host stage", tok[i]);
+            tok[i] = KNZ_T_NONE;
+        } else if (!transform_supported(tok[i])) return fail(c, KNZ_ERR_INVALID_CODEC, "transform id %d not implemented on device", tok[i]);
+    }
     if (!entropy_supported(p->entropy_type)) return fail(c, KNZ_ERR_INVALID_CODEC, "entropy id %d not implemented on device", p->entropy_type);
     if (p->checksum_bits != 0 && p->checksum_bits != 32 && p->checksum_bits != 64) return fail(c, KNZ_ERR_INVALID_PARAM, "checksum must be 0, 32 or 64");
     // bitstream version of the blocks (0 = current). Below 6 the Huffman chunks, the BWT block header and the LZ blocks have their
@@ -846,7 +884,7 @@ static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_
 
     // workspace stride: large enough for every valid preTransformLength of this chain
     const u32 unit = framing ? bs : rawLen;
-    const int required = seq_required(tok, nTok, (int)unit);
+    const int required = seq_required(tokAll, nTok, (int)unit);
     const u64 S = ((u64)required + 255) & ~255ull;
     const u32 maxPre = (u32)S;
     bool realStages = false;
@@ -900,7 +938,7 @@ static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_
             launch_seq_inv_commit(s, w.a, d_blocks, nBlocks, i, tok[i]);
         }
     }
-    if (p->checksum_bits && framing) {
+    if (p->checksum_bits && framing && nHosted == 0) {
         u64* d_sums;
         if (int r = ws_get(c, "sums", sizeof(u64) * nBlocks, (void**)&d_sums)) return r;
         launch_verify_checksums(s, d_blocks, nBlocks, p->checksum_bits, d_out, outStride, w.d_viewPtr, w.a.alen, d_sums);
@@ -922,6 +960,8 @@ static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_
         total += hb[b].preLen;
     }
     if (outBytes) *outBytes = total;
+    if (skipOut) *skipOut = hb[0].copyBlock ? 0xFFu : hb[0].skipFlags;
+    if (sumOut) *sumOut = hb[0].checksum;
     if (rawDecoded) *rawDecoded = (int32_t)hb[0].preLen;
     if (usedBits) *usedBits = hb[0].usedBits;
     return 0;
@@ -935,6 +975,19 @@ int knz_hip_decode_blocks(knz_ctx* ctx, const knz_params* p, const uint8_t* d_in
     CTX_LOCK(c);
     return decode_impl(c, p, d_in, in_bits, start_bit, max_blocks, 1, 0, d_out, out_cap, out_bytes, end_bit, blocks_done,
                        nullptr, nullptr);
+}
+
+int knz_hip_decode_block_hosted(knz_ctx* ctx, const knz_params* p, int32_t host_stages, const uint8_t* d_in, uint64_t in_bits, uint64_t start_bit,
+                                uint8_t* d_out, size_t out_cap, uint64_t* out_bytes, uint64_t* end_bit, uint32_t* skip_flags, uint64_t* checksum, int32_t* done)
+{
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    CTX_LOCK(c);
+    int64_t nb = 0;
+    if (skip_flags) *skip_flags = 0xFF;
+    if (checksum) *checksum = 0;
+    const int r = decode_impl(c, p, d_in, in_bits, start_bit, 1, 1, 0, d_out, out_cap, out_bytes, end_bit, &nb, nullptr, nullptr, host_stages, skip_flags, checksum);
+    if (done) *done = (int32_t)nb;
+    return r;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k_block_sum(ChunkDesc* __restrict__ desc,
     if (threadIdx.x == 0) info[b].payloadBits = carry;
 }
 
-__global__ void k_block_scan(BlockInfo* __restrict__ info, const u32* __restrict__ blockLen, int nBlocks,
+__global__ void k_block_scan(BlockInfo* __restrict__ info, const u32* __restrict__ blockLen, const u32* __restrict__ origLen, int nBlocks,
                              FrameParams fp, u64* __restrict__ totalBits)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -118,7 +118,9 @@ __global__ void k_block_scan(BlockInfo* __restrict__ info, const u32* __restrict
         if (fp.framing) {
             const u32 postLen = blockLen[b];
             const u32 ds = block_data_size(postLen);
-            bi.hdrBits = 8u + 8u * ds + (u32)fp.checksumBits;
+            // (more than four transforms: the skip flags get a byte of their own, except in copy blocks; io/CompressedOutputStream.cpp:791-799)
+            const u32 skipByte = (fp.nTransforms > 4 && origLen[b] > 15) ? 8u : 0u;
+            bi.hdrBits = 8u + skipByte + 8u * ds + (u32)fp.checksumBits;
             bi.written = (u64)bi.hdrBits + bi.payloadBits;
             bi.lw = (bi.written < 8) ? 3u : (u32)ilog2_u32((u32)(bi.written >> 3)) + 4u;
             bi.bitOff = cur;
@@ -160,9 +162,10 @@ __global__ __launch_bounds__(64) void k_assemble(const ChunkDesc* __restrict__ d
             const u32 ds = block_data_size(len);
             u32 mode = ((ds - 1) & 3) << 5;
             const u32 skip = skipFlags[b];
-            if (origLen[b] <= 15) mode |= 0x80;                // copy block (SMALL_BLOCK_SIZE, :691-695)
-            mode |= (skip >> 4);                               // <= 4 transforms only (checked on the host)
-            or_bits_mem(out, p, mode, 8); p += 8;
+            const bool copy = origLen[b] <= 15;                // copy block (SMALL_BLOCK_SIZE, :691-695)
+            if (copy) mode |= 0x80;
+            if (copy || fp.nTransforms <= 4) { mode |= (skip >> 4); or_bits_mem(out, p, mode, 8); p += 8; }
+            else { mode |= 0x10; or_bits_mem(out, p, mode, 8); or_bits_mem(out, p + 8, skip, 8); p += 16; }
             or_bits_mem(out, p, len, 8 * ds); p += 8 * ds;
             if (fp.checksumBits == 32) or_bits_mem(out, p, checksums[b] & 0xFFFFFFFFull, 32);
             else if (fp.checksumBits == 64) { or_bits_mem(out, p, checksums[b] >> 32, 32); or_bits_mem(out, p + 32, checksums[b] & 0xFFFFFFFFull, 32); }
@@ -271,9 +274,9 @@ void launch_block_sum(hipStream_t s, ChunkDesc* desc, BlockInfo* info, const u32
     { KScope ks_("k_block_sum"); hipLaunchKernelGGL(k_block_sum, dim3(nBlocks), dim3(256), 0, s, desc, info, blockLen, maxChunks, chunkSize, slotMul); }
 }
 
-void launch_block_scan(hipStream_t s, BlockInfo* info, const u32* blockLen, int nBlocks, FrameParams fp, u64* totalBits)
+void launch_block_scan(hipStream_t s, BlockInfo* info, const u32* blockLen, const u32* origLen, int nBlocks, FrameParams fp, u64* totalBits)
 {
-    { KScope ks_("k_block_scan"); hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(64), 0, s, info, blockLen, nBlocks, fp, totalBits); }
+    { KScope ks_("k_block_scan"); hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(64), 0, s, info, blockLen, origLen, nBlocks, fp, totalBits); }
 }
 
 void launch_assemble(hipStream_t s, const ChunkDesc* desc, const BlockInfo* info, const u32* blockLen, const u32* origLen, const u8* skipFlags,

@@ -63,6 +63,17 @@ __global__ void k_seq_fwd_null(SeqArrays a, int nBlocks, int stage)
     a.skip[b] &= (u8)~(1u << (7 - stage));
 }
 
+// A stage the HOST has run on the block already (knz_hip_encode_block_hosted): the data is where it was, in its new length; what is left
+// to do is what TransformSequence::forward does around a stage -- a swap of the buffers and a cleared skip flag when it succeeded
+__global__ void k_seq_fwd_hosted(SeqArrays a, int nBlocks, int stage, int applied)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nBlocks) return;
+    if (!a.active[b] || !applied) return;
+    a.swaps[b]++;
+    a.skip[b] &= (u8)~(1u << (7 - stage));
+}
+
 __global__ void k_seq_fwd_finish(SeqArrays a, int nBlocks, const u8* in, u64 inStride, u8* A, u8* B, u64 S, const u8** viewPtr)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -158,6 +169,8 @@ void launch_seq_fwd_commit(hipStream_t s, const SeqArrays& a, int nBlocks, int s
 { KScope ks_("k_seq_fwd_commit"); L1D(k_seq_fwd_commit, a, nBlocks, stage); }
 void launch_seq_fwd_null(hipStream_t s, const SeqArrays& a, int nBlocks, int stage)
 { KScope ks_("k_seq_fwd_null"); L1D(k_seq_fwd_null, a, nBlocks, stage); }
+void launch_seq_fwd_hosted(hipStream_t s, const SeqArrays& a, int nBlocks, int stage, int applied)
+{ KScope ks_("k_seq_fwd_hosted"); L1D(k_seq_fwd_hosted, a, nBlocks, stage, applied); }
 void launch_seq_fwd_finish(hipStream_t s, const SeqArrays& a, int nBlocks, const u8* in, u64 inStride, u8* A, u8* B, u64 S, const u8** viewPtr)
 { KScope ks_("k_seq_fwd_finish"); L1D(k_seq_fwd_finish, a, nBlocks, in, inStride, A, B, S, viewPtr); }
 void launch_seq_inv_entropy_dst(hipStream_t s, const SeqArrays& a, DecBlock* blocks, int nBlocks, u8* out, u64 outStride, u8* A, u64 S, u8** entDst, u32 realMask,

@@ -16,7 +16,7 @@ struct FrameParams {
 void launch_init_blocks(hipStream_t s, u64 n, u32 blockSize, int nBlocks, u32* origLen, u32* blockLen);
 // A block owns ceil(len / chunkSize) * slotMul consecutive ChunkDesc slots (slotMul > 1: ANS1, one slot per context table).
 void launch_block_sum(hipStream_t s, ChunkDesc* desc, BlockInfo* info, const u32* blockLen, int nBlocks, int maxChunks, u32 chunkSize, u32 slotMul);
-void launch_block_scan(hipStream_t s, BlockInfo* info, const u32* blockLen, int nBlocks, FrameParams fp, u64* totalBits);
+void launch_block_scan(hipStream_t s, BlockInfo* info, const u32* blockLen, const u32* origLen, int nBlocks, FrameParams fp, u64* totalBits);
 void launch_assemble(hipStream_t s, const ChunkDesc* desc, const BlockInfo* info, const u32* blockLen, const u32* origLen,
                      const u8* skipFlags, const u64* checksums, const u8* hdrBase, int nBlocks, int maxChunks, u32 chunkSize,
                      u32 slotMul, u32 hdrStride, FrameParams fp, u32* out);
@@ -125,6 +125,7 @@ struct SeqArrays {
 void launch_seq_fwd_direct(hipStream_t s, const SeqArrays& a, u32* origLen, u64 n, u32 blockSize, int nBlocks, int nStages, const u8* in, const u8** viewPtr);
 void launch_seq_fwd_prepare(hipStream_t s, const SeqArrays& a, int nBlocks, int stage, const u8* in, u64 inStride, u8* A, u8* B, u64 S);
 void launch_seq_fwd_null(hipStream_t s, const SeqArrays& a, int nBlocks, int stage);
+void launch_seq_fwd_hosted(hipStream_t s, const SeqArrays& a, int nBlocks, int stage, int applied);
 void launch_seq_fwd_commit(hipStream_t s, const SeqArrays& a, int nBlocks, int stage);
 void launch_seq_fwd_finish(hipStream_t s, const SeqArrays& a, int nBlocks, const u8* in, u64 inStride, u8* A, u8* B, u64 S, const u8** viewPtr);
 void launch_seq_inv_entropy_dst(hipStream_t s, const SeqArrays& a, DecBlock* blocks, int nBlocks, u8* out, u64 outStride, u8* A, u64 S, u8** entDst, u32 realMask, u32 unit, u64 outCap);

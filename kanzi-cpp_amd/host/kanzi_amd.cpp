@@ -4,6 +4,7 @@
 // the GPU. Reference semantics cited per function.
 #include "kanzi_amd.hpp"
 #include "kanzi_api.h"
+#include "host_stages.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -519,6 +520,160 @@ bool TransformSequence<T>::inverse(SliceArray<T>& input, SliceArray<T>& output, 
 
 template class TransformSequence<byte>;
 
+// ---- host transforms (text_codec.cpp) ----------------------------------------------------------------------
+TextCodec::TextCodec(Context& ctx) : _ctx(&ctx)
+{
+    _variant = ctx.getInt("textcodec", 1);
+    _blockSize = ctx.getInt("blockSize", 0);
+    _bsVersion = ctx.getInt("bsVersion", 6);
+}
+
+bool TextCodec::forward(SliceArray<byte>& src, SliceArray<byte>& dst, int length)
+{
+    if (length == 0) return true;
+    if (!SliceArray<byte>::isValid(src) || !SliceArray<byte>::isValid(dst)) throw std::invalid_argument("TextCodec: Invalid block");
+    if (src._array == dst._array) return false;
+    int dt = _ctx ? _ctx->getInt("dataType", hoststage::DT_UNDEFINED) : hoststage::DT_UNDEFINED;
+    int outLen = 0;
+    const bool ok = hoststage::textForward(_variant, reinterpret_cast<const uint8_t*>(&src._array[src._index]), length, reinterpret_cast<uint8_t*>(&dst._array[dst._index]),
+                                           dst._length - dst._index, _blockSize, _bsVersion, &dt, &outLen);
+    if (_ctx && length >= 1024) _ctx->putInt("dataType", dt);
+    if (!ok) return false;
+    src._index += length; dst._index += outLen;
+    return true;
+}
+
+bool TextCodec::inverse(SliceArray<byte>& src, SliceArray<byte>& dst, int length)
+{
+    if (length == 0) return true;
+    if (!SliceArray<byte>::isValid(src) || !SliceArray<byte>::isValid(dst)) throw std::invalid_argument("TextCodec: Invalid block");
+    if (src._array == dst._array || src._index + length > src._length) return false;
+    int outLen = 0;
+    const bool ok = hoststage::textInverse(_variant, reinterpret_cast<const uint8_t*>(&src._array[src._index]), length, reinterpret_cast<uint8_t*>(&dst._array[dst._index]),
+                                           dst._length - dst._index, _blockSize, _bsVersion, &outLen);
+    src._index += length; dst._index += outLen;
+    return ok;
+}
+
+bool UTFCodec::forward(SliceArray<byte>& src, SliceArray<byte>& dst, int length)
+{
+    if (length == 0) return true;
+    if (!SliceArray<byte>::isValid(src) || !SliceArray<byte>::isValid(dst)) throw std::invalid_argument("UTFCodec: Invalid block");
+    if (dst._length - dst._index < getMaxEncodedLength(length)) return false;
+    int dt = _ctx ? _ctx->getInt("dataType", hoststage::DT_UNDEFINED) : hoststage::DT_UNDEFINED;
+    int outLen = 0;
+    const bool ok = hoststage::utfForward(reinterpret_cast<const uint8_t*>(&src._array[src._index]), length, reinterpret_cast<uint8_t*>(&dst._array[dst._index]),
+                                          dst._length - dst._index, &dt, &outLen);
+    if (_ctx) _ctx->putInt("dataType", dt);
+    if (!ok) return false;
+    src._index += length; dst._index += outLen;
+    return true;
+}
+
+bool UTFCodec::inverse(SliceArray<byte>& src, SliceArray<byte>& dst, int length)
+{
+    if (length == 0) return true;
+    if (!SliceArray<byte>::isValid(src) || !SliceArray<byte>::isValid(dst)) throw std::invalid_argument("UTFCodec: Invalid block");
+    if (src._index + length > src._length) return false;
+    int outLen = 0;
+    const bool ok = hoststage::utfInverse(reinterpret_cast<const uint8_t*>(&src._array[src._index]), length, reinterpret_cast<uint8_t*>(&dst._array[dst._index]),
+                                          dst._length - dst._index, &outLen);
+    src._index += length; dst._index += outLen;
+    return ok;
+}
+
+// Leading stages of a chain that run on the host. TEXT / UTF anywhere else in a chain has no place to run: refused.
+static int hostedStagesOf(uint64 ttype, int ids[8])
+{
+    int n = 0, k = 0;
+    bool device = false;
+    for (int i = 0; i < 8; i++) {
+        const int t = int((ttype >> (42 - 6 * i)) & 63);
+        if (t == 0) continue;
+        ids[k++] = t;
+        const bool host = (t == KNZ_T_TEXT || t == KNZ_T_UTF);
+        if (host && device) throw std::invalid_argument("TEXT / UTF behind a device transform is not supported");
+        if (host) n++; else device = true;
+    }
+    return n;
+}
+
+// XXHash32 / XXHash64 of a block as the reference computes them (util/XXHash.hpp:61-115, :153-230; seed 0x4B414E5A; the 64-bit variant
+// merges its accumulators with 32-bit style shifts). The device has the same in csrc/xxhash.hip; blocks that pass through host stages
+// are hashed here, before the stages run.
+static uint64 hostChecksum(const uint8_t* d, int length, int bits)
+{
+    auto ld32 = [](const uint8_t* p) { return uint32_t(p[0]) | (uint32_t(p[1]) << 8) | (uint32_t(p[2]) << 16) | (uint32_t(p[3]) << 24); };
+    auto ld64 = [&](const uint8_t* p) { return uint64(ld32(p)) | (uint64(ld32(p + 4)) << 32); };
+    const uint32_t SEED = 0x4B414E5Au;
+    if (bits == 32) {
+        const uint32_t P1 = 2654435761u, P2 = 2246822519u, P3 = 3266489917u, P4 = 668265263u, P5 = 374761393u;
+        uint32_t h;
+        int i = 0;
+        if (length >= 16) {
+            uint32_t v[4] = { SEED + P1 + P2, SEED + P2, SEED, SEED - P1 };
+            const int end16 = length - 16;
+            do {
+                for (int j = 0; j < 4; j++) { v[j] += ld32(d + i + 4 * j) * P2; v[j] = ((v[j] << 13) | (v[j] >> 19)) * P1; }
+                i += 16;
+            } while (i <= end16);
+            h = ((v[0] << 1) | (v[0] >> 31)) + ((v[1] << 7) | (v[1] >> 25)) + ((v[2] << 12) | (v[2] >> 20)) + ((v[3] << 18) | (v[3] >> 14));
+        } else h = SEED + P5;
+        h += uint32_t(length);
+        while (i <= length - 4) { h += ld32(d + i) * P3; h = ((h << 17) | (h >> 15)) * P4; i += 4; }
+        while (i < length) { h += uint32_t(d[i]) * P5; h = ((h << 11) | (h >> 21)) * P1; i++; }
+        h ^= h >> 15; h *= P2; h ^= h >> 13; h *= P3;
+        return uint64(h ^ (h >> 16));
+    }
+    const uint64 P1 = 0x9E3779B185EBCA87ull, P2 = 0xC2B2AE3D27D4EB4Full, P3 = 0x165667B19E3779F9ull, P4 = 0x85EBCA77C2B2AE63ull, P5 = 0x27D4EB2F165667C5ull;
+    auto round = [&](uint64 acc, uint64 val) { acc += val * P2; return ((acc << 31) | (acc >> 33)) * P1; };
+    const uint64 seed = uint64(int64(int32_t(SEED)));
+    uint64 h;
+    int i = 0;
+    if (length >= 32) {
+        uint64 v[4] = { seed + P1 + P2, seed + P2, seed, seed - P1 };
+        const int end32 = length - 32;
+        do {
+            for (int j = 0; j < 4; j++) v[j] = round(v[j], ld64(d + i + 8 * j));
+            i += 32;
+        } while (i <= end32);
+        h = ((v[0] << 1) | (v[0] >> 31)) + ((v[1] << 7) | (v[1] >> 25)) + ((v[2] << 12) | (v[2] >> 20)) + ((v[3] << 18) | (v[3] >> 14));
+        for (int j = 0; j < 4; j++) h = (h ^ round(0, v[j])) * P1 + P4;
+    } else h = seed + P5;
+    h += uint64(int64(length));
+    while (i + 8 <= length) { h ^= round(0, ld64(d + i)); h = ((h << 27) | (h >> 37)) * P1 + P4; i += 8; }
+    while (i + 4 <= length) { h ^= uint64(ld32(d + i)) * P1; h = ((h << 23) | (h >> 41)) * P2 + P3; i += 4; }
+    while (i < length) { h ^= uint64(d[i]) * P5; h = ((h << 11) | (h >> 53)) * P1; i++; }
+    h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3;
+    return h ^ (h >> 32);
+}
+
+static int textVariantOfEntropy(int etype) { return (etype == 0 || etype == 1 || etype == 4 || etype == 5) ? 2 : 1; }      // NONE, HUFFMAN, RANGE, ANS0
+
+// the host stages of one block, in chain order: data ends up in `a` or `b`; returns the buffer that holds it
+struct HostedResult { const uint8_t* data; int len; uint32_t applied; };
+static HostedResult runHostStages(const int* ids, int count, const uint8_t* block, int n, int blockSize, int etype, std::vector<uint8_t>& a, std::vector<uint8_t>& b)
+{
+    HostedResult r{ block, n, 0u };
+    if (n <= 15) return r;                                  // copy block: no stage runs (io/CompressedOutputStream.cpp:691-695)
+    int dt = hoststage::presetDataType(block, n);
+    std::vector<uint8_t>* bufs[2] = { &a, &b };
+    int cur = 0;
+    for (int i = 0; i < count; i++) {
+        std::vector<uint8_t>& out = *bufs[cur];
+        const size_t need = size_t(r.len) + 8192 + 64;
+        if (out.size() < need) out.resize(need);
+        int outLen = 0;
+        bool ok;
+        if (ids[i] == KNZ_T_TEXT) ok = hoststage::textForward(textVariantOfEntropy(etype), r.data, r.len, out.data(), r.len, blockSize, 6, &dt, &outLen);
+        else ok = hoststage::utfForward(r.data, r.len, out.data(), r.len + 8192, &dt, &outLen);
+        if (!ok) continue;
+        r.data = out.data(); r.len = outLen; r.applied |= 1u << i;
+        cur ^= 1;
+    }
+    return r;
+}
+
 // ---- TransformFactory (transform/TransformFactory.hpp:100-308) ----------------------------------
 static const struct { const char* name; int type; } TNAMES[] = {
     {"NONE", 0}, {"BWT", 1}, {"BWTS", 2}, {"LZ", 3}, {"RLT", 5}, {"ZRLT", 6}, {"MTFT", 7}, {"RANK", 8}, {"EXE", 9}, {"TEXT", 10},
@@ -591,6 +746,11 @@ TransformSequence<T>* TransformFactory<T>::newTransform(Context& ctx, uint64 fun
             case RLT_TYPE: transforms[nbtr++] = new RLT(ctx); break;
             case LZ_TYPE: ctx.putInt("lz", LZ_TYPE); transforms[nbtr++] = new LZCodec(ctx); break;
             case LZX_TYPE: ctx.putInt("lz", LZX_TYPE); transforms[nbtr++] = new LZCodec(ctx); break;
+            case DICT_TYPE:
+                ctx.putInt("textcodec", hoststage::textVariantFor(ctx.has("entropy") ? ctx.getString("entropy").c_str() : ""));
+                transforms[nbtr++] = new TextCodec(ctx);
+                break;
+            case UTF_TYPE: transforms[nbtr++] = new UTFCodec(ctx); break;
             default: {
                 std::stringstream ss;
                 ss << "Transform type " << t << " has no device kernel (out of scope of the accelerated block pipeline)";
@@ -797,6 +957,10 @@ CompressedOutputStream::CompressedOutputStream(std::ostream& os, int tasks, cons
     if (e && atoi(e) > 0) _batchBlocks = atoi(e);
     // one device call takes at most 2 GiB of input (32-bit positions on the device side)
     { const int64_t lim = (int64_t(1) << 31) / int64_t(blockSize) - 1; if (_batchBlocks > lim) _batchBlocks = int(lim < 1 ? 1 : lim); }
+    // chains that start with TEXT / UTF (the level presets 5 and 6): those stages run on the host, block by block, and every block
+    // goes to the device on its own (its length after them differs from block to block)
+    _hosted = hostedStagesOf(_transformType, _hostIds);
+    if (_hosted) _batchBlocks = 1;
     _blockId = 0;
     _pendingByte = 0; _pendingBits = 0; _written = 0;
     _fillLane = 0; _nextSeq = 0; _sinkSeq = 0; _pubSeq = 0; _cumBits = 0; _stop = false;
@@ -991,6 +1155,21 @@ void CompressedOutputStream::submit(Lane& ln)
     devCheck(c, knz_hip_copy_wait(c, ln.ticket), "h2d");           // queued by enqueue(), normally long complete
     ln.ticket = 0;
     uint64_t bits = 0;
+    if (_hosted && n == 0) p.transform_type = 0;             // (the empty last batch: end marker only; the device call checks the chain before it looks at the size)
+    if (_hosted && n > 0) {
+        // host stages first (the original bytes are still in the lane's staging buffer), then the block in its new length to the device
+        if (n > size_t(_blockSize)) throw IOException("a chain with host stages takes one block per call", Error::ERR_PROCESS_BLOCK);
+        const uint8_t* orig = reinterpret_cast<const uint8_t*>(ln.in);
+        knz_host_stages hs;
+        memset(&hs, 0, sizeof(hs));
+        hs.stages = _hosted; hs.orig_len = uint32_t(n);
+        if (_checksum) hs.checksum = hostChecksum(orig, int(n), _checksum);
+        const HostedResult r = runHostStages(_hostIds, _hosted, orig, int(n), _blockSize, _entropyType, ln.hostA, ln.hostB);
+        hs.applied_mask = r.applied;
+        if (r.applied) devCheck(c, knz_hip_memcpy_h2d(c, ln.dIn, r.data, size_t(r.len)), "h2d");
+        devCheck(c, knz_hip_encode_block_hosted(c, &p, &hs, static_cast<const uint8_t*>(ln.dIn), size_t(r.len), pro.bytes.empty() ? nullptr : pro.bytes.data(), uint32_t(pro.nbits),
+                                                ln.firstBlock, ln.last ? 1 : 0, static_cast<uint8_t*>(ln.dOut), ln.dOutCap, &bits), "encode block");
+    } else
     devCheck(c, knz_hip_encode_blocks(c, &p, static_cast<const uint8_t*>(ln.dIn), n, pro.bytes.empty() ? nullptr : pro.bytes.data(), uint32_t(pro.nbits),
                                       ln.firstBlock, ln.last ? 1 : 0, static_cast<uint8_t*>(ln.dOut), ln.dOutCap, &bits), "encode blocks");
     // where the run starts: behind the runs of the batches before it, whose lengths are published in batch order
@@ -1076,6 +1255,7 @@ CompressedInputStream::CompressedInputStream(std::istream& is, int tasks, const 
     _jobs = tasks; _blockSize = blockSize; _checksum = checksum; _outputSize = originalSize;
     _headless = headerless; _closed = false; _headerDone = false; _ended = false;
     _entropyType = 0; _transformType = 0; _bsVersion = 6;
+    _hosted = 0;
     if (headerless) {
         // (io/CompressedInputStream.cpp:97-98 takes the caller's word for the version of a headerless stream)
         if (bsVersion < 0 || bsVersion > 6) throw std::invalid_argument("Invalid or missing bitstream version, cannot read this version of the stream");
@@ -1083,6 +1263,7 @@ CompressedInputStream::CompressedInputStream(std::istream& is, int tasks, const 
         if ((blockSize < 1024) || (blockSize > 1024 * 1024 * 1024) || ((blockSize & -16) != blockSize)) throw std::invalid_argument("Invalid block size");
         _entropyType = EntropyEncoderFactory::getType(entropy.c_str());
         _transformType = TransformFactory<byte>::getType(transform.c_str());
+        _hosted = hostedStagesOf(_transformType, _hostIds);
     }
     _batchBlocks = std::max(tasks, 64);               // clamped to 256 MiB / 2 GiB once the block size is known
     const char* e = getenv("KNZ_BATCH_BLOCKS");
@@ -1168,6 +1349,7 @@ void CompressedInputStream::readHeader()
     _entropyType = short(get(5));
     try { EntropyEncoderFactory::getName(_entropyType); } catch (const std::invalid_argument&) { throw IOException("Invalid bitstream, unknown entropy type", Error::ERR_INVALID_CODEC); }
     _transformType = get(48);
+    _hosted = hostedStagesOf(_transformType, _hostIds);
     try { TransformFactory<byte>::getName(_transformType); } catch (const std::invalid_argument&) { throw IOException("Invalid bitstream, unknown transform type", Error::ERR_INVALID_CODEC); }
     _blockSize = int(get(28) << 4);
     if ((_blockSize < 1024) || (_blockSize > 1024 * 1024 * 1024)) throw IOException("Invalid bitstream, incorrect block size", Error::ERR_BLOCK_SIZE);
@@ -1226,6 +1408,7 @@ void CompressedInputStream::prepareBatch(Prep& pr)
     const int wantBatch = _batchBlocks.load();
     int batch = (wantBatch > lim) ? int(lim < 1 ? 1 : lim) : wantBatch;
     if (!_batchFromEnv.load()) batch = int(std::min<int64_t>(batch, std::max<int64_t>(1, (int64_t(16) << 20) / bsz)));
+    if (_hosted) batch = 1;                                  // (the host undoes its stages block by block)
     while (nb < batch) {
         if (!fetch(size_t(((pos + 40) >> 3) + 1 - (_compBit >> 3)))) {
             if (uint64(_comp.size()) * 8 < pos + 8) { if (nb == 0) throw IOException("Unexpected end of stream", Error::ERR_READ_FILE); break; }
@@ -1303,6 +1486,41 @@ void CompressedInputStream::decodeBatch(Prep& pr, PSlot& sl)
     pr.ticket = 0;
     uint64_t outBytes = 0, endBit = 0;
     int64_t done = 0;
+    if (_hosted) {
+        // the device undoes its stages; the block comes back with its skip flags and the host undoes TEXT / UTF, last stage first
+        uint32_t skip = 0xFF;
+        uint64_t stored = 0;
+        int32_t got = 0;
+        devCheck(c, knz_hip_decode_block_hosted(c, &p, _hosted, static_cast<const uint8_t*>(pr.dIn), uint64(pr.inBytes) * 8, pr.startBit, static_cast<uint8_t*>(sl.dOut), outCap,
+                                                &outBytes, &endBit, &skip, &stored, &got), "decode block");
+        const size_t room = size_t(_blockSize) + 64;
+        if (sl.cap < room) { g_pinned.put(sl.buf, sl.cap); sl.buf = nullptr; sl.cap = 0; sl.buf = g_pinned.get(room, &sl.cap); }
+        std::vector<uint8_t> a(size_t(outBytes) + 64), b;
+        if (outBytes) devCheck(c, knz_hip_memcpy_d2h(c, a.data(), sl.dOut, size_t(outBytes)), "d2h");
+        const uint8_t* cur = a.data();
+        int len = int(outBytes);
+        std::vector<uint8_t>* spare = &b;
+        std::vector<uint8_t>* held = &a;
+        for (int i = _hosted - 1; i >= 0 && got; i--) {
+            if ((skip >> (7 - i)) & 1u) continue;
+            if (spare->size() < room) spare->resize(room);
+            int outLen = 0;
+            const bool ok = (_hostIds[i] == KNZ_T_TEXT)
+                ? hoststage::textInverse(textVariantOfEntropy(_entropyType), cur, len, spare->data(), int(room), _blockSize, _bsVersion == 0 ? 1 : _bsVersion, &outLen)
+                : hoststage::utfInverse(cur, len, spare->data(), int(room), &outLen);
+            if (ok && outLen > _blockSize) throw IOException("Invalid data: block larger than the block size", Error::ERR_PROCESS_BLOCK);
+            if (!ok) throw IOException("Invalid data: inverse transform failed", Error::ERR_PROCESS_BLOCK);
+            cur = spare->data(); len = outLen;
+            std::swap(spare, held);
+        }
+        if (_checksum && got) {
+            const uint64 sum = hostChecksum(cur, len, _checksum);
+            if (sum != (_checksum == 32 ? (stored & 0xFFFFFFFFull) : stored)) throw IOException("Corrupted bitstream: invalid block checksum", Error::ERR_CRC_CHECK);
+        }
+        memcpy(sl.buf, cur, size_t(len));
+        sl.len = size_t(len);
+        return;
+    }
     devCheck(c, knz_hip_decode_blocks(c, &p, static_cast<const uint8_t*>(pr.dIn), uint64(pr.inBytes) * 8, pr.startBit, pr.nb,
                                       static_cast<uint8_t*>(sl.dOut), outCap, &outBytes, &endBit, &done), "decode blocks");
     if (sl.cap < size_t(outBytes)) { g_pinned.put(sl.buf, sl.cap); sl.buf = nullptr; sl.cap = 0; sl.buf = g_pinned.get(std::max(size_t(outBytes), outCap), &sl.cap); }

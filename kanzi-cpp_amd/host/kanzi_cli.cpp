@@ -45,6 +45,7 @@ int main(int argc, char** argv)
 {
     std::string mode, in, out, transform, entropy;
     long long block = 4 << 20;
+    bool blockGiven = false;
     int jobs = 1, checksum = 0, level = -1, from = 1, to = 0x7FFFFFFF;
     bool force = false;
     for (int i = 1; i < argc; i++) {
@@ -65,7 +66,7 @@ int main(int argc, char** argv)
         else if (val("-o", "--output=", out)) {}
         else if (val("-t", "--transform=", transform)) {}
         else if (val("-e", "--entropy=", entropy)) {}
-        else if (val("-b", "--block=", v)) { block = parseSize(v); if (block < 0) return usage("invalid block size"); }
+        else if (val("-b", "--block=", v)) { block = parseSize(v); blockGiven = true; if (block < 0) return usage("invalid block size"); }
         else if (val("-j", "--jobs=", v)) jobs = atoi(v.c_str());
         else if (val("-l", "--level=", v)) level = atoi(v.c_str());
         else if (val("-v", "--verbose=", v)) {}
@@ -78,7 +79,9 @@ int main(int argc, char** argv)
         // BlockCompressor.cpp:556-613
         if (level == 0) { transform = "NONE"; entropy = "NONE"; }
         else if (level == 1) { transform = "LZX"; entropy = "NONE"; }
-        else { fprintf(stderr, "level %d needs transforms or entropy coders that only exist in the CPU reference (TEXT/UTF/EXE/PACK/MM/DNA/ROLZ/LZP, CM/TPAQ); use -t/-e\n", level); return Error::ERR_INVALID_CODEC; }
+        else if (level == 5) { transform = "TEXT+UTF+BWT+RANK+ZRLT"; entropy = "ANS0"; }      // TEXT and UTF run on the host, the rest on the device
+        else if (level == 6) { transform = "TEXT+UTF+BWT+SRT+ZRLT"; entropy = "FPAQ"; if (!blockGiven) block = 8 << 20; }      // (BlockCompressor.cpp:121-124: 8 MiB blocks by default)
+        else { fprintf(stderr, "level %d needs transforms or entropy coders that only exist in the CPU reference (EXE/PACK/MM/DNA/ROLZ/LZP, CM/TPAQ); use -t/-e\n", level); return Error::ERR_INVALID_CODEC; }
     }
     if (transform.empty()) transform = "NONE";
     if (entropy.empty()) entropy = "NONE";

@@ -59,6 +59,18 @@ def make(spec):
         return c.fibword(spec[1])
     if kind == "dna":
         return c.dna(spec[1], spec[2])
+    if kind == "utf8":                # code points of one, two, three and four bytes, skewed: what the UTF transform takes
+        rng = np.random.default_rng(spec[2])
+        cps = [int(x) for x in rng.integers(0x80, 0x7FF, 60)] + [int(x) for x in rng.integers(0x800, 0xD7FF, 40)] + [0x1F600, 0x10348, 0x20AC] + list(range(97, 123)) * 2 + [32] * 12 + [10]
+        w = np.array([1.0 / (1 + i % 37) for i in range(len(cps))])
+        idx = rng.choice(len(cps), size=spec[1] // 2 + 16, p=w / w.sum())
+        return "".join(chr(cps[int(i)]) for i in idx).encode("utf-8")[:spec[1]]
+    if kind == "crlf":                # text with DOS line ends and capitalised words
+        t = c.text(spec[1], spec[2]).replace(b".\n", b".\r\nThe ")
+        return t[:spec[1]]
+    if kind == "xml":                 # text inside tags, with entities
+        t = c.text(spec[1], spec[2]).replace(b".\n", b"</p>\n<p class=\"x\">&amp; ")
+        return (b"<doc>" + t)[:spec[1]]
     if kind == "bytes":
         return bytes.fromhex(spec[1])
     if kind == "str":
@@ -139,4 +151,22 @@ HARD_CASES = [
     ("hard:repeats_srt", ("repeats", 32 << 20, 5), "BWT+SRT+ZRLT", "ANS0", 32 << 20),
     # config 4's chain on four blocks of its own size: block ids 2 and 3 of a 32 MiB stream (slot model i % jobs, first_block_id)
     ("config4:4blocks", ("text", 128 << 20, 1), "BWT+SRT+ZRLT", "FPAQ", 32 << 20),
+]
+
+# The CLI's level presets that reach the device chain through host stages (TEXT + UTF): `kanzi -c -l N` of the reference, digests in
+# tests/golden/levels.json (tests/golden/make_levels.py)
+LEVEL_CASES = [
+    # (level, input spec, extra CLI arguments)
+    (5, ("text", 9 << 20, 1), []),
+    (6, ("text", 17 << 20, 2), []),
+    (5, ("mixed", 9 << 20, 2), []),
+    (6, ("mixed", 9 << 20, 3), ["-b", "2m"]),
+    (5, ("utf8", 5 << 20, 7), ["-b", "1m"]),
+    (6, ("utf8", 3 << 20, 8), ["-b", "1m", "-x64"]),
+    (5, ("crlf", 3 << 20, 4), ["-b", "1m", "-x"]),
+    (6, ("xml", 3 << 20, 5), ["-b", "1m"]),
+    (5, ("repeats", 5 << 20, 9), ["-b", "2m"]),
+    (5, ("text", 1500, 3), []),
+    (5, ("text", 700, 3), []),
+    (5, ("rand", 300000, 5), ["-b", "64k"]),
 ]
