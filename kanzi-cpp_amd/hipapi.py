@@ -19,7 +19,7 @@ SYMBOLS = [
     "knz_hip_encode_blocks", "knz_hip_decode_blocks", "knz_hip_entropy_encode", "knz_hip_entropy_decode",
     "knz_hip_transform_forward", "knz_hip_transform_inverse", "knz_hip_malloc", "knz_hip_free",
     "knz_hip_memcpy_h2d", "knz_hip_memcpy_d2h", "knz_hip_sync", "knz_hip_memcpy_h2d_async", "knz_hip_memcpy_d2h_async", "knz_hip_copy_wait", "knz_hip_host_alloc", "knz_hip_host_free", "knz_hip_set_profiling", "knz_hip_get_kernel_times",
-    "knz_hip_tune", "knz_hip_shift_bits",
+    "knz_hip_tune", "knz_hip_shift_bits", "knz_hip_encode_block_hosted", "knz_hip_decode_block_hosted",
 ]
 
 

@@ -190,6 +190,7 @@ static int max_encoded_len(int t, int n)
     case 13: return n + 1024;
     case 5: return (n <= 512) ? n + 32 : n;
     case 3: case 16: return knzo_lz_max_encoded(n);
+    case 17: return n + 8192;          /* UTFCodec.hpp:54 (only its share of a chain's buffer size: the stage itself is not restated here) */
     default: return n;
     }
 }
@@ -205,6 +206,15 @@ static int seq_required(const int* tok, int nb, int n)
 }
 
 static int supported_transform(int t) { return t == 0 || t == 1 || t == 3 || t == 5 || t == 6 || t == 7 || t == 8 || t == 13 || t == 16; }
+
+/* Stages a caller has run itself on a block before handing it over (the product's TEXT and UTF, ids 10 and 17, which this restatement
+ * does not contain): the stand-in for knz_hip_encode_block_hosted / knz_hip_decode_block_hosted in tests/stub. While `hosted` is
+ * non-zero the first `hosted` tokens of a chain are taken as done (encode: bit i of `applied` says whether stage i succeeded, the
+ * checksum and the original length come from the caller) or left to the caller (decode: the block's skip flags and stored checksum
+ * are handed back, nothing is verified). */
+static __thread struct { int hosted; unsigned applied; int origLen; uint64_t checksum; int skipOut; uint64_t checksumOut; } g_hosted;
+void knzo_set_hosted(int hosted, unsigned applied, int origLen, uint64_t checksum) { g_hosted.hosted = hosted; g_hosted.applied = applied; g_hosted.origLen = origLen; g_hosted.checksum = checksum; }
+void knzo_get_hosted(int* skipFlags, uint64_t* checksum) { *skipFlags = g_hosted.skipOut; *checksum = g_hosted.checksumOut; }
 static int supported_entropy(int e) { return e == 0 || e == 1 || e == 2 || e == 5 || e == 8; }
 
 /* TransformSequence::forward with explicit capacities. data = block input (capacity dataCap),
@@ -212,7 +222,8 @@ static int supported_entropy(int e) { return e == 0 || e == 1 || e == 2 || e == 
 static int seq_forward(const uint8_t* in, int count, const int* tok, int nb, int etype,
                        int dataCap, int bufCap, uint8_t* outbuf, int* skipFlagsOut)
 {
-    const int blockSize = count;
+    const int hosted = g_hosted.hosted;
+    const int blockSize = hosted ? g_hosted.origLen : count;
     const int requiredSize = seq_required(tok, nb, blockSize);
     int skip = 0xFF;
     /* physical buffers: 0 = input(data), 1 = output(buffer), 2 = temp */
@@ -223,7 +234,16 @@ static int seq_forward(const uint8_t* in, int count, const int* tok, int nb, int
     uint8_t* pin = A; uint8_t* pout = B;
     int capIn = capA, capOut = capB;
     int swaps = 0;
-    for (int i = 0; i < nb; i++) {
+    for (int i = 0; i < hosted && i < nb; i++) {
+        /* a stage the caller has run: a swap of the buffers and a cleared flag when it succeeded */
+        if (capOut < requiredSize) capOut = requiredSize;
+        if (!((g_hosted.applied >> i) & 1u)) continue;
+        skip &= ~(1 << (7 - i));
+        { uint8_t* tp = pin; pin = pout; pout = tp; const int tc = capIn; capIn = capOut; capOut = tc; }
+        swaps++;
+    }
+    if (swaps & 1) memcpy(pin, in, (size_t)count);          /* (the data sits where the last host stage left it) */
+    for (int i = hosted; i < nb; i++) {
         if (capOut < requiredSize) capOut = requiredSize;   /* reallocation path, :104-115 */
         int outLen = 0;
         if (!knzo_transform_forward(tok[i], pin, count, pout, capOut, etype, &outLen)) continue;
@@ -248,14 +268,15 @@ int64_t knzo_encode_block(const uint8_t* in, int n, uint64_t ttype, int etype, i
 {
     int mode = 0;
     uint64_t checksum = 0;
-    if (checksumBits == 32) checksum = knzo_xxhash32(in, (size_t)n, KNZ_MAGIC);
+    if (g_hosted.hosted && checksumBits) checksum = g_hosted.checksum;
+    else if (checksumBits == 32) checksum = knzo_xxhash32(in, (size_t)n, KNZ_MAGIC);
     else if (checksumBits == 64) checksum = knzo_xxhash64(in, (size_t)n, KNZ_MAGIC);
     if (n <= 15) { ttype = 0; etype = 0; mode |= 0x80; }
     int tok[8];
     const int nb = seq_tokens(ttype, tok);
-    for (int i = 0; i < nb; i++) if (!supported_transform(tok[i])) return -2;
+    for (int i = 0; i < nb; i++) if (!(i < g_hosted.hosted && n > 15) && !supported_transform(tok[i])) return -2;
     if (!supported_entropy(etype)) return -2;
-    const int requiredSize = seq_required(tok, nb, n);
+    const int requiredSize = seq_required(tok, nb, (g_hosted.hosted && n > 15) ? g_hosted.origLen : n);
     if (bufCap < requiredSize) bufCap = requiredSize;
     if (dataCap < n) dataCap = n;
     uint8_t* buffer = (uint8_t*)malloc((size_t)bufCap + 16);
@@ -316,8 +337,11 @@ int knzo_decode_block(const uint8_t* in, uint64_t nbits, uint64_t ttype, int ety
     else if (checksumBits == 64) checksum1 = knzo_br_bits(&r, 64);
     int tok[8];
     const int nb = seq_tokens(ttype, tok);
-    for (int i = 0; i < nb; i++) if (!supported_transform(tok[i])) return ERR_INVALID_CODEC;
+    const int hosted = (mode & 0x80) ? 0 : g_hosted.hosted;
+    for (int i = hosted; i < nb; i++) if (!supported_transform(tok[i])) return ERR_INVALID_CODEC;
     if (!supported_entropy(etype)) return ERR_INVALID_CODEC;
+    g_hosted.skipOut = (mode & 0x80) ? 0xFF : skipFlags;
+    g_hosted.checksumOut = checksum1;
     const int rbytes = (int)((nbits + 7) >> 3);
     int dataCap = (int)blkLen > rbytes ? (int)blkLen : rbytes;
     int bufCap = (int)blkLen > pre + 512 ? (int)blkLen : pre + 512;
@@ -339,7 +363,7 @@ int knzo_decode_block(const uint8_t* in, uint64_t nbits, uint64_t ttype, int ety
     uint8_t* pin = A; uint8_t* pout = B;
     if (count > dataCap) res = 0;
     if (res && skipFlags != 0xFF) {
-        for (int i = nb - 1; i >= 0; i--) {
+        for (int i = nb - 1; i >= hosted; i--) {
             if (skipFlags & (1 << (7 - i))) continue;
             int ol = 0;
             res = knzo_transform_inverse(tok[i], pin, count, pout, dataCap, &ol);
@@ -352,6 +376,7 @@ int knzo_decode_block(const uint8_t* in, uint64_t nbits, uint64_t ttype, int ety
     if (count > outCap) { free(A); free(B); return ERR_PROCESS_BLOCK; }
     memcpy(out, pin, (size_t)count);
     free(A); free(B);
+    if (g_hosted.hosted) { *outLen = count; return 0; }      /* (the caller undoes its stages and verifies the checksum) */
     if (checksumBits == 32) {
         if (knzo_xxhash32(out, (size_t)count, KNZ_MAGIC) != (uint32_t)checksum1) return ERR_CRC_CHECK;
     } else if (checksumBits == 64) {
@@ -445,7 +470,7 @@ int knzo_compress_run_ids(const uint8_t* in, size_t n, uint64_t ttype, int etype
         blockIdx++;
         int tok[8];
         const int nb = seq_tokens(len <= 15 ? 0 : ttype, tok);
-        const int req = seq_required(tok, nb, len);
+        const int req = seq_required(tok, nb, (g_hosted.hosted && len > 15) ? g_hosted.origLen : len);
         if (bufCap < req) bufCap = req;
         int skipFlags, postLen;
         const int64_t bits = knzo_encode_block(in + off, len, ttype, etype, checksum, dataCap, bufCap, tmp, tmpCap, &skipFlags, &postLen);

@@ -45,6 +45,37 @@ int knz_hip_encode_blocks(knz_ctx* c, const knz_params* p, const uint8_t* d_in, 
     return 0;
 }
 
+void knzo_set_hosted(int hosted, unsigned applied, int origLen, uint64_t checksum);
+void knzo_get_hosted(int* skipFlags, uint64_t* checksum);
+
+int knz_hip_encode_block_hosted(knz_ctx* c, const knz_params* p, const knz_host_stages* hs, const uint8_t* d_in, size_t n, const uint8_t* prologue,
+                                uint32_t prologue_bits, int64_t first_block_id, int finish, uint8_t* d_out, size_t out_cap, uint64_t* out_bits)
+{
+    if (!hs || n == 0 || n > (size_t)p->block_size) return fail(c, KNZ_ERR_INVALID_PARAM, "a hosted call takes exactly one block");
+    knzo_set_hosted(hs->stages, hs->applied_mask, (int)hs->orig_len, hs->checksum);
+    /* (a block size no smaller than the data makes the run encoder cut exactly one block; the slot capacities follow the stream's) */
+    const int rc = knz_hip_encode_blocks(c, p, d_in, n, prologue, prologue_bits, first_block_id, finish, d_out, out_cap, out_bits);
+    knzo_set_hosted(0, 0, 0, 0);
+    return rc;
+}
+
+int knz_hip_decode_blocks(knz_ctx* c, const knz_params* p, const uint8_t* d_in, uint64_t in_bits, uint64_t start_bit, int64_t max_blocks,
+                          uint8_t* d_out, size_t out_cap, uint64_t* out_bytes, uint64_t* end_bit, int64_t* blocks_done);
+int knz_hip_decode_block_hosted(knz_ctx* c, const knz_params* p, int32_t host_stages, const uint8_t* d_in, uint64_t in_bits, uint64_t start_bit,
+                                uint8_t* d_out, size_t out_cap, uint64_t* out_bytes, uint64_t* end_bit, uint32_t* skip_flags, uint64_t* checksum, int32_t* done)
+{
+    int64_t nb = 0;
+    knzo_set_hosted(host_stages, 0, 0, 0);
+    const int rc = knz_hip_decode_blocks(c, p, d_in, in_bits, start_bit, 1, d_out, out_cap, out_bytes, end_bit, &nb);
+    int sk = 0xFF; uint64_t ck = 0;
+    knzo_get_hosted(&sk, &ck);
+    knzo_set_hosted(0, 0, 0, 0);
+    if (skip_flags) *skip_flags = (uint32_t)sk;
+    if (checksum) *checksum = ck;
+    if (done) *done = (int32_t)nb;
+    return rc;
+}
+
 int knz_hip_decode_blocks(knz_ctx* c, const knz_params* p, const uint8_t* d_in, uint64_t in_bits, uint64_t start_bit, int64_t max_blocks,
                           uint8_t* d_out, size_t out_cap, uint64_t* out_bytes, uint64_t* end_bit, int64_t* blocks_done)
 {

@@ -299,6 +299,8 @@ def test_cli_levels_5_and_6_write_and_read_the_reference_files(tmp_path):
     cli = os.environ.get("KNZ_TEST_CLI", os.path.join(knzlib.PKG, "kanzi_amd_cli"))
     recs = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "levels.json")))
     for r in recs:
+        if os.environ.get("KNZ_TEST_KANZI_LIB") and r["input"][1] > (6 << 20):
+            continue                  # (the CPU run against the stand-in device keeps to the smaller inputs)
         d = vectors.make(tuple(r["input"]))
         assert hashlib.md5(d).hexdigest() == r["input_md5"]
         src, out, back = str(tmp_path / "in.bin"), str(tmp_path / "out.knz"), str(tmp_path / "back.bin")

@@ -21,7 +21,8 @@ def build_stub(tmp_path):
     ora = os.path.join(ROOT, "oracle")
     subprocess.check_call(["gcc", "-O1", "-std=c99", "-fPIC", "-Wall", "-c", os.path.join(ROOT, "tests", "stub", "knz_hip_stub.c"), "-o", obj])
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"), "-o", lib,
-                           os.path.join(ROOT, "kanzi-cpp_amd", "host", "kanzi_amd.cpp"), obj, "-L" + ora, "-lknz_oracle",
+                           os.path.join(ROOT, "kanzi-cpp_amd", "host", "kanzi_amd.cpp"), os.path.join(ROOT, "kanzi-cpp_amd", "host", "text_codec.cpp"),
+                           "-I" + os.path.join(ROOT, "kanzi-cpp_amd", "host"), obj, "-L" + ora, "-lknz_oracle",
                            "-Wl,-rpath," + ora, "-lpthread"])
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-o", exe,
                            os.path.join(ROOT, "tests", "cpp", "host_mirror_test.cpp"), lib, "-Wl,-rpath," + str(tmp_path), "-L" + ora,
@@ -34,8 +35,8 @@ def build_stub(tmp_path):
 
 
 def test_host_layer_against_stub_device(tmp_path):
-    lib, exe, _ = build_stub(tmp_path)
-    env = dict(os.environ, KNZ_TEST_KANZI_LIB=lib, KNZ_TEST_HOST_MIRROR_EXE=exe, KNZ_TEST_DEVICES="0,1")
+    lib, exe, cli = build_stub(tmp_path)
+    env = dict(os.environ, KNZ_TEST_KANZI_LIB=lib, KNZ_TEST_HOST_MIRROR_EXE=exe, KNZ_TEST_DEVICES="0,1", KNZ_TEST_CLI=cli)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_host_api.py"), "-m", "gpu", "-x", "-q",
                         "-p", "no:cacheprovider", "-k", "not threads_share_the_device"], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

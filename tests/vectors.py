@@ -170,3 +170,13 @@ LEVEL_CASES = [
     (5, ("text", 700, 3), []),
     (5, ("rand", 300000, 5), ["-b", "64k"]),
 ]
+
+# inputs of the host stages' own fixture (tests/golden/host_stages.json): text, DOS text, XML, UTF-8, words with the escape bytes in them,
+# data the stages refuse (random, DNA, digits, the mixed stand-in), at sizes around the 1,024-byte minimum and well above it
+HOST_STAGE_INPUTS = [
+    ("text", 1024, 1), ("text", 1023, 1), ("text", 20000, 2), ("text", 300000, 3), ("text", 2000000, 4),
+    ("crlf", 60000, 4), ("xml", 60000, 5), ("utf8", 60000, 7), ("utf8", 400000, 8), ("repeats", 200000, 9),
+    ("mixed", 300000, 2), ("mixedslice", 5 * 262144, 2, 262144, 262144 + 100000), ("rand", 50000, 7), ("dna", 50000, 4),
+    ("formula13", 4096), ("const", 5000, 32), ("str", "The quick brown fox \x0f jumps \x0e over The lazy dog. " * 60),
+    ("str", "caf\u00e9 na\u00efve \u20ac100 \U0001F600 r\u00e9sum\u00e9 \u4e2d\u6587 " * 90),
+]
