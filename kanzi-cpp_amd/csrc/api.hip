@@ -230,6 +230,7 @@ int knz_hip_tune(const char* name, int value)
 {
     if (name == nullptr) return -1;
     if (!strcmp(name, "mtf_tile")) return mtft_tune(value);
+    if (!strcmp(name, "lz_serial_decode")) { lz_serial_decode(value ? 1 : 0); return 0; }
     if (!strcmp(name, "bwt_split")) { bwt_split_knob().store(value < 1 ? 1 : (value > 4 ? 4 : value)); return 0; }
     return bwt_forward_tune(name, value);
 }
@@ -580,7 +581,16 @@ static int run_inverse_stage(Ctx* c, hipStream_t s, int t, const XfStage& st)
     case KNZ_T_RLT: launch_rlt_inverse(s, st); break;
     case KNZ_T_RANK: launch_sbrt_inverse(s, st, 2); break;
     case KNZ_T_TIMESTAMP: launch_sbrt_inverse(s, st, 3); break;
-    case KNZ_T_LZ: case KNZ_T_LZX: launch_lz_inverse(s, st); break;
+    case KNZ_T_LZ: case KNZ_T_LZX: {
+        void* sc = nullptr;
+        size_t bytes = 0;
+        if (st.maxCap != 0 && st.maxCap <= (1u << 30) && !lz_serial_decode(-1)) {
+            bytes = lz_inverse_scratch_bytes(st.nBlocks, st.maxCap);
+            if (int r = ws_get(c, "lzInvScratch", bytes, &sc)) return r;
+        }
+        launch_lz_inverse(s, st, sc, bytes, st.maxCap);
+        break;
+    }
     case KNZ_T_BWT: {
         if (const int parts = bwt_parts_wanted(c, st.nBlocks); parts > 1)
             return bwt_in_parts(c, s, st, parts, [&](int nb) { return bwt_inverse_scratch_bytes(nb, st.maxLen, (size_t)nb * st.maxLen); },
@@ -934,6 +944,7 @@ static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_
             XfStage st;
             st.src = w.a.src; st.dst = w.a.dst; st.len = w.a.alen; st.cap = w.a.cap; st.ok = w.a.ok; st.newLen = w.a.newLen;
             st.nBlocks = nBlocks; st.maxLen = (u32)S; st.scratchU32 = w.scratch; st.entropyType = p->entropy_type; st.bsVersion = bsVersion;
+            st.maxCap = std::max(capMid, capFinal);
             if (int r = run_inverse_stage(c, s, tok[i], st)) return r;
             launch_seq_inv_commit(s, w.a, d_blocks, nBlocks, i, tok[i]);
         }
@@ -1066,7 +1077,7 @@ static int transform_host(Ctx* c, int t, int forward, const uint8_t* in, int32_t
     HIPCHK(c, hipMemsetAsync(w.a.newLen, 0, 4, s));
     XfStage st;
     st.src = w.a.src; st.dst = w.a.dst; st.len = w.a.alen; st.cap = w.a.cap; st.ok = w.a.ok; st.newLen = w.a.newLen;
-    st.nBlocks = 1; st.maxLen = (u32)n; st.scratchU32 = w.scratch; st.entropyType = etype;
+    st.nBlocks = 1; st.maxLen = (u32)n; st.scratchU32 = w.scratch; st.entropyType = etype; st.maxCap = (u32)dstCap;
     if (int r = forward ? run_forward_stage(c, s, t, st) : run_inverse_stage(c, s, t, st)) return r;
     HIPCHK(c, hipGetLastError());
     u8 hok = 0; u32 hlen = 0;

@@ -923,6 +923,54 @@ __device__ __noinline__ void med_write_back(MedLds<THREADS, ROWS>& L, const FwdV
     }
 }
 
+// Write-back of a group whose majority key m is held by c members, with the nOth <= THREADS others sorted in oK / oV [0, nOth) and the
+// majority's members behind them in their old (position) order: the result is [others < m][majority][others > m], `less` others in front.
+template <int THREADS, int ROWS>
+__device__ __forceinline__ void med_majority_write_back(MedLds<THREADS, ROWS>& L, const FwdView& v, u32 gs, u32 n, u32 nOth, u32 c, u32 less, u32 m)
+{
+    const int tid = (int)threadIdx.x;
+    const u32 oldLab = L.oldLab;
+    (void)n; (void)m;
+    // ---- the majority: c members from slot gs + less on. It keeps the group's label when that slot is inside its range (see med_write_back)
+    const u32 mStart = gs + less;
+    const u32 rel = oldLab - gs;
+    const u32 mLab = (c <= SM_G) ? mStart : ((rel >= less && rel < less + c) ? oldLab : mStart + (c >> 1));
+    for (u32 i = (u32)tid; i < c; i += THREADS) {
+        const u32 gp = L.oV[nOth + i];
+        v.SA[mStart + i] = gp;
+        if (mLab != oldLab) v.ISA[gp] = mLab;
+    }
+    u32 surv = 0;
+    if (tid == 0) {
+        if (less != 0) atomicOr(&v.gnew[mStart >> 5], 1u << (mStart & 31));
+        if (c > SM_G) v.medStage[mStart >> 8] = make_uint2(mStart, c);      // (c <= n <= MED_CAP)
+        else if (c > 1) surv = 1;
+    }
+    // ---- the others: one thread each
+    if ((u32)tid < nOth) {
+        const u32 t = (u32)tid;
+        const u32 key = L.oK[t];
+        u32 hd = t, e = t + 1;
+        while (hd > 0 && L.oK[hd - 1] == key) hd--;
+        while (e < nOth && L.oK[e] == key) e++;
+        const u32 size = e - hd;
+        const u32 shift = (t < less) ? 0u : c;                          // (equal keys are on one side of the majority)
+        const u32 slot = gs + t + shift, hdSlot = gs + hd + shift;
+        const u32 relO = rel - shift;                                   // the parent's label in the others' own index space (wraps when it is not there)
+        const u32 lab = (size <= SM_G) ? hdSlot : ((oldLab >= hdSlot && oldLab < hdSlot + size) ? oldLab : hdSlot + (size >> 1));
+        (void)relO;
+        const u32 gp = L.oV[t];
+        v.SA[slot] = gp;
+        if (lab != oldLab) v.ISA[gp] = lab;
+        if (t == hd) {
+            if (hdSlot != gs) atomicOr(&v.gnew[hdSlot >> 5], 1u << (hdSlot & 31));
+            if (size > SM_G) v.medStage[hdSlot >> 8] = make_uint2(hdSlot, size);
+            else if (size > 1) surv = 1;
+        }
+    }
+    if (__ballot(surv != 0) != 0 && (tid & 63) == 0) v.counters[0] = 1;
+}
+
 // One workgroup refines one group of 257..ROWS*THREADS members (descriptors of other sizes are left to the other
 // instantiations of the kernel): keys and positions into LDS, sort, subgroup boundaries, SA / ISA / bit map / children.
 // A group in which one key holds the majority (periodic stretches and runs: every member but the ones near the end of the
@@ -1011,6 +1059,18 @@ __global__ __launch_bounds__(THREADS, THREADS / 128) void k_bwt_f_sort_medium(Fw
                     __syncthreads();
                     if ((u32)tid < nOth) { L.oK[at] = kk; L.oV[at] = vv; }
                     __syncthreads();
+                    // A group that keeps its majority and loses a handful of members (round after round, for a periodic stretch): the
+                    // majority is written where it goes straight from the split order and keeps its label, each of the few others finds the
+                    // members it stays with by looking left and right among the sorted others -- no rearranging of the whole group, no bit map
+                    // over it, no scans (med_write_back does all that for the general case)
+                    u32 lessQ = 0;
+                    if ((u32)tid < nOth) lessQ = (L.oK[tid] < m) ? 1u : 0u;
+                    lessQ = med_block_sum(L, lessQ);
+                    if (tid == 0) L.oldLab = info.y;
+                    __syncthreads();
+                    med_majority_write_back<THREADS, ROWS>(L, v, gs, n, nOth, c, lessQ, m);
+                    __syncthreads();
+                    continue;
                 } else {
                     med_radix_sort<THREADS, ROWS>(L, nOth, npass);
                 }
@@ -1663,6 +1723,114 @@ __global__ __launch_bounds__(256) void k_bwt_f_run_expand(const u64* __restrict_
     if (Rout != nullptr) Rout[j] = Rr;
 }
 
+// ---- the run round's last step without index arrays: where a tie starts among the sorted members is ONE BIT per member (a ballot per
+// wave), the windows of 2048 members find their heads and sizes the way round 0 does (k_bwt_f_r0_winsum + two scans over the windows),
+// and the placing kernel reads keys, positions and 64 words of bits -- where k_bwt_f_large_flags wrote two index arrays of the members'
+// size and two device-wide scans ran over them.
+__global__ __launch_bounds__(256) void k_bwt_f_run_flags(const u64* __restrict__ keys, u32 M, unsigned long long* __restrict__ bits64)
+{
+    const u32 j = blockIdx.x * 256 + threadIdx.x;
+    const u64 k = (j < M) ? keys[j] : 0ull;
+    u32 klo = (u32)__shfl_up((int)(u32)k, 1u, 64), khi = (u32)__shfl_up((int)(u32)(k >> 32), 1u, 64);
+    u64 kp = ((u64)khi << 32) | klo;
+    if ((threadIdx.x & 63) == 0 && j > 0 && j < M) kp = keys[j - 1];
+    const bool f = (j >= M) || (j == 0) || (k != kp);                  // (every bit from M on is set: the end of the last tie)
+    const unsigned long long m = __ballot(f);
+    if ((threadIdx.x & 63) == 0) bits64[j >> 6] = m;
+}
+
+__global__ __launch_bounds__(256) void k_bwt_f_run_place(FwdView v, const uint2* __restrict__ desc, const u32* __restrict__ loff, u32 M, int kbits, const u64* __restrict__ keys,
+                                                         const u32* __restrict__ vals, const u32* __restrict__ bits, const u32* __restrict__ winLastIncl,
+                                                         const u32* __restrict__ winFirstInclRev, u32 nWin, uint2* __restrict__ largeNext, const u32* __restrict__ memberR,
+                                                         u32* __restrict__ ovr, u32* __restrict__ rtbits)
+{
+    // one member per thread (the kernel is a scatter of labels: occupancy is what hides its latency); the 64 words of the member's window of
+    // 2048 are looked at by every one of the window's eight workgroups
+    __shared__ SmWindow W;
+    __shared__ ClassAgg A;
+    const int tid = (int)threadIdx.x;
+    const u32 jb = blockIdx.x * 256u;
+    const u32 win = jb / SM_WIN, j0 = win * SM_WIN;
+    agg_init(A);
+    if (tid < 64) {
+        const u32 w = bits[(j0 >> 5) + (u32)tid];
+        W.bw[tid] = w;
+        int pm = w ? (tid * 32 + 31 - __clz((int)w)) : -1;
+        u32 sm = w ? (u32)(tid * 32 + __ffs((int)w) - 1) : NO_BIT;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(pm, (unsigned)o, 64);
+            if (tid >= o) pm = t > pm ? t : pm;
+            const u32 u = (u32)__shfl_down((int)sm, (unsigned)o, 64);
+            if (tid + o < 64) sm = u < sm ? u : sm;
+        }
+        int pex = __shfl_up(pm, 1u, 64);
+        if (tid == 0) pex = -1;
+        u32 sex = (u32)__shfl_down((int)sm, 1u, 64);
+        if (tid == 63) sex = NO_BIT;
+        W.prevSet[tid] = pex;
+        W.nextSet[tid] = sex;
+    }
+    __syncthreads();
+    const u32 j = jb + (u32)tid;
+    u32 surv = 0, mySlot = 0, hLocal = 0, hSize = 0;
+    int hKind = -1;
+    bool setBit = false;
+    if (j < M) {
+        const u32 i = j - j0;
+        const u32 w = i >> 5, bit = i & 31;
+        const u32 lowmask = (bit == 31) ? 0xFFFFFFFFu : ((2u << bit) - 1u);
+        const u32 word = W.bw[w];
+        const u32 m = word & lowmask;
+        const int si = m ? (int)(w * 32 + 31 - (u32)__clz((int)m)) : W.prevSet[w];
+        const u32 nh = (si >= 0) ? j0 + (u32)si : (win ? winLastIncl[win - 1] : 0u);       // first member of my tie
+        const u32 di = (u32)(keys[j] >> kbits);
+        const u32 gs = desc[di].x, off = loff[di];
+        const u32 gp = vals[j];
+        mySlot = gs + (j - off);
+        v.SA[mySlot] = gp;
+        if (nh != off) v.ISA[gp] = gs + (nh - off);                      // (the first tie of a group keeps the group's label)
+        if (memberR != nullptr) ovr[mySlot] = memberR[j];
+        if (nh == j) {
+            const u32 m2 = word & ~lowmask;
+            const u32 ei = m2 ? (w * 32 + (u32)__ffs((int)m2) - 1) : W.nextSet[w];
+            u32 nxt = (ei != NO_BIT) ? j0 + ei : ((win + 1 < nWin) ? winFirstInclRev[nWin - 2 - win] : M);
+            if (nxt > M) nxt = M;
+            setBit = (j != off);
+            hSize = nxt - j;
+            hKind = agg_note(A, hSize, false, surv, hLocal);
+        }
+    }
+    if (__ballot(surv != 0) != 0 && (tid & 63) == 0) v.counters[0] = 1;
+    __syncthreads();
+    if (tid == 0) agg_reserve(A, v);
+    __syncthreads();
+    if (hKind >= 0) agg_write(A, v, hKind, hLocal, mySlot, hSize, largeNext, (uint2*)nullptr);
+    // bits: the lanes of a wave mostly hold consecutive slots (one group), so their bits leave as at most three word-wide ORs per wave
+    const int lane = tid & 63;
+    const bool live = j < M;
+    const u32 s0 = (u32)__shfl((int)mySlot, 0, 64);
+    const bool inLine = live && (mySlot == s0 + (u32)lane);
+    const unsigned long long hm = __ballot(setBit && inLine), rm = __ballot(inLine);
+    if (live && !inLine) {
+        if (setBit) atomicOr(&v.gnew[mySlot >> 5], 1u << (mySlot & 31));
+        if (rtbits != nullptr) atomicOr(&rtbits[mySlot >> 5], 1u << (mySlot & 31));
+    }
+    if (lane == 0) {
+        const u32 w0 = s0 >> 5, sh = s0 & 31;
+        for (int which = 0; which < 2; which++) {
+            const unsigned long long mask = which ? rm : hm;
+            u32* dst = which ? rtbits : v.gnew;
+            if (mask == 0 || dst == nullptr) continue;
+            const u32 p0 = (u32)(mask << sh);
+            const u32 p1 = sh ? (u32)(mask >> (32 - sh)) : (u32)(mask >> 32);
+            const u32 p2 = sh ? (u32)(mask >> (64 - sh)) : 0u;
+            if (p0) atomicOr(&dst[w0], p0);
+            if (p1) atomicOr(&dst[w0 + 1], p1);
+            if (p2) atomicOr(&dst[w0 + 2], p2);
+        }
+    }
+}
+
 // end of a round: the group starts found in it become visible
 __global__ __launch_bounds__(256) void k_bwt_f_merge_bits(u32* __restrict__ gbits, u32* __restrict__ gnew, u32 nWords)
 {
@@ -2005,14 +2173,21 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
           const u64* sortedM = r ? keysFree2 : keysFree;
           rk = r ? keysFree : keysFree2;
           hipLaunchKernelGGL(k_bwt_f_run_expand, GRID1(runElems), sortedM, runElems, w.sKey, w.sE, kbits, hbits, rk, rv, runOffsets ? w.valsB : (u32*)nullptr); }
-        { KScope ks_("k_bwt_f_large_flags"); hipLaunchKernelGGL(k_bwt_f_large_flags<u64>, GRID1(runElems), rk, runElems, w.t0, w.t2); }
-        { KScope ks_("k_bwt_f_scan_max"); prims::launch_scan<prims::SCAN_MAX_INCL>(s, w.t0, w.t1, runElems, nullptr, w.scanTmp); }
-        { KScope ks_("k_bwt_f_scan_min"); prims::launch_scan<prims::SCAN_MIN_INCL>(s, w.t2, w.t3, runElems, nullptr, w.scanTmp); }
-        { KScope ks_("k_bwt_f_large_place");
-          if (runOffsets) hipMemsetAsync(w.rtbits, 0, 4 * w.gbitsWords, s);
-          hipLaunchKernelGGL(k_bwt_f_large_place<u64>, GRID1(runElems), v, w.runList, w.loff, runElems, keyBits, rk, rv, w.t1, w.t3, w.med[cur], w.large[cur],
-                             runOffsets ? (const u32*)w.valsB : (const u32*)nullptr, runOffsets ? w.ovr : (u32*)nullptr, runOffsets ? w.rtbits : (u32*)nullptr);
-          if (runOffsets) { v.ovr = w.ovr; v.rtbits = w.rtbits; } }
+        {
+            // ties among the sorted members as a bit map, heads and sizes per window of 2048 members (the bit map reuses the run-end map,
+            // which nobody reads any more)
+            u32* mbits = w.ebits;
+            const u32 nWinM = (runElems + SM_WIN - 1) / SM_WIN;
+            { KScope ks_("k_bwt_f_large_flags"); hipLaunchKernelGGL(k_bwt_f_run_flags, dim3(nWinM * (SM_WIN / 256)), dim3(256), 0, s, rk, runElems, reinterpret_cast<unsigned long long*>(mbits)); }
+            { KScope ks_("k_bwt_f_r0_winsum"); hipLaunchKernelGGL(k_bwt_f_r0_winsum, GRID1(nWinM), mbits, runElems, nWinM, w.t0, w.t2, SM_WIN / 32); }
+            { KScope ks_("k_bwt_f_scan_max"); prims::launch_scan<prims::SCAN_MAX_INCL>(s, w.t0, w.t1, nWinM, nullptr, w.scanTmp); }
+            { KScope ks_("k_bwt_f_scan_min"); prims::launch_scan<prims::SCAN_MIN_INCL>(s, w.t2, w.t3, nWinM, nullptr, w.scanTmp); }
+            { KScope ks_("k_bwt_f_large_place");
+              if (runOffsets) hipMemsetAsync(w.rtbits, 0, 4 * w.gbitsWords, s);
+              hipLaunchKernelGGL(k_bwt_f_run_place, dim3((runElems + 255) / 256), dim3(256), 0, s, v, w.runList, w.loff, runElems, keyBits, rk, rv, mbits, w.t1, w.t3, nWinM, w.large[cur],
+                                 runOffsets ? (const u32*)w.valsB : (const u32*)nullptr, runOffsets ? w.ovr : (u32*)nullptr, runOffsets ? w.rtbits : (u32*)nullptr);
+              if (runOffsets) { v.ovr = w.ovr; v.rtbits = w.rtbits; } }
+        }
         { KScope ks_("k_bwt_f_merge_bits"); hipLaunchKernelGGL(k_bwt_f_merge_bits, GRID1(total / 32 + 2), w.gbits, w.gnew, total / 32 + 2); }
         compactMedium(w.med[cur]);
         probeScan();

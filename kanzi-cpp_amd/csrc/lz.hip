@@ -18,6 +18,8 @@
 #include "common.hpp"
 #include "stages.hpp"
 #include <cstring>
+#include <cstdlib>
+#include <atomic>
 #include <algorithm>
 #include "prims.hpp"
 
@@ -533,12 +535,13 @@ __device__ __forceinline__ u32 lz_get_len(LzByteWin& w, const u8* s, int& pos, i
 // length - minMatch (14: + extension; 15: repeat distance, bit 4 picks the older one, the length is all extension), bit 4 otherwise:
 // one distance byte more than the flag byte's bit 0 gives; minimum match { 4, 9, 6, 6 }[flag bits 2-1]; repeat distances start at 0.
 template <bool V5>
-__global__ __launch_bounds__(64) void k_lz_inverse(XfStage st)
+__global__ __launch_bounds__(64) void k_lz_inverse(XfStage st, const u32* __restrict__ leftOnly)
 {
     const int b = blockIdx.x;
     const int lane = lane_id();
     const int n = (int)st.len[b];
     if (n == 0) return;
+    if (leftOnly != nullptr && leftOnly[4 * (size_t)b + 2] == 0) return;        // decoded by the data-parallel path below
     const u8* __restrict__ src = st.src[b];
     u8* dst = st.dst[b];
     const int cap = (st.cap[b] > 0x7FFFFFFFu) ? 0x7FFFFFFF : (int)st.cap[b];
@@ -610,6 +613,263 @@ __global__ __launch_bounds__(64) void k_lz_inverse(XfStage st)
         ok = ok && (s == litEnd);
     } while (0);
     if (lane == 0) { st.ok[b] = (u8)(ok ? 1 : 0); st.newLen[b] = (u32)d; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decoder in two parts (round 4).  The serial kernel above spends most of a token on the copy it makes (a load, a store and, when
+// the next match reads what this one wrote, a fence: ~2.5 us per token).  Here the chain per block only PARSES: k_lz_parse walks the
+// four byte sequences exactly as k_lz_inverse does, with the same checks in the same order, and leaves one record per token
+// (output position, literal count, literal source, distance).  Everything that moves bytes is data parallel over the output:
+//   k_lz_tile_first  for every tile of 2048 output bytes the token its first byte belongs to
+//   k_lz_expand      one entry per output byte: where the byte comes from -- a literal (offset in the block's literal section) or the
+//                    output byte `distance` in front of it (dst[p] = dst[p - dist] holds for overlapping matches too: it is what the
+//                    reference's byte loop, its 16-byte steps for dist >= 16 and its memset for dist == 1 all compute)
+//   k_lz_jump        pointer jumping: an entry that points at a byte which itself points further back takes that byte's entry.
+//                    Entries only ever move towards their literal, so the rounds run in place without a barrier between readers
+//                    and writers; ceil(log2(longest chain)) + 1 rounds, tiles that are done drop out, and a round in which no tile
+//                    is left costs a launch of workgroups that read one flag
+//   k_lz_emit        dst[p] = literal section[entry]
+// A distance of 0 (damaged input only) leaves the byte as it is, as the reference's byte loop does: such entries are roots of their own.
+constexpr u32 LZI_T = 2048;                       // output bytes per tile
+constexpr u32 LZI_ROOT = 0x80000000u;             // entry = LZI_ROOT | offset of a literal in src
+constexpr u32 LZI_STALE = 0xC0000000u;            // entry = LZI_STALE | output position whose present content stays
+constexpr int LZI_ROUNDS = 32;
+constexpr u32 LZI_RECS = 1032;                    // records a tile can meet: every token but the last writes >= 2 bytes
+
+struct LzInvWs {
+    uint4* recs; size_t recStride;                // per block: (d, literal count, literal source, distance), then a sentinel (total, 0, 0, 0)
+    u32* P; size_t pStride;                       // per block: one entry per output byte
+    u32* tileFirst; u8* tileFlag; size_t tStride; // per block and tile
+    u32* info;                                    // per block 4 words: records (with the sentinel), output bytes, 1 = left to the serial kernel
+    u32* pending;                                 // LZI_ROUNDS + 1 words: tiles left after round r (index r + 1); [0] = tiles to start with
+};
+
+template <bool V5>
+__global__ __launch_bounds__(64) void k_lz_parse(XfStage st, LzInvWs w)
+{
+    const int b = blockIdx.x;
+    const int lane = lane_id();
+    const int n = (int)st.len[b];
+    u32* info = w.info + 4 * (size_t)b;
+    if (lane == 0) { info[0] = 0; info[1] = 0; info[2] = 0; }
+    if (n == 0) return;
+    const u8* __restrict__ src = st.src[b];
+    const int cap = (st.cap[b] > 0x7FFFFFFFu) ? 0x7FFFFFFF : (int)st.cap[b];
+    if ((size_t)cap > w.pStride || (size_t)cap / 2 + 4 > w.recStride) { if (lane == 0) info[2] = 1; return; }   // (sized by the caller's bound: does not happen)
+    uint4* recs = w.recs + (size_t)b * w.recStride;
+    int ok = 0, d = 0;
+    u32 nr = 0;
+    do {
+        if (n < 13) break;
+        const int litEnd = sgpr((int)ld32u(src)), nTok = sgpr((int)ld32u(src + 4)), nDist = sgpr((int)ld32u(src + 8));
+        if (litEnd < 0 || nTok < 0 || nDist < 0) break;
+        if (litEnd < 13 || litEnd > n || nTok > n - litEnd || nDist > n - litEnd - nTok) break;
+        int t = litEnd, m = litEnd + nTok, l = m + nDist;
+        const int flags = sgpr((int)src[12]);
+        const int maxDist = (flags & 1) ? LZ_MAXD2 : LZ_MAXD1;
+        const int mm = V5 ? ((((flags >> 1) & 3) == 0) ? 4 : ((((flags >> 1) & 3) == 1) ? 9 : 6)) : ((flags >> 1) & 7) + 2;
+        int s = 13, rep0 = V5 ? 0 : n, rep1 = V5 ? 0 : n;
+        LzByteWin wt, wm, wl, ws;
+        wt.refill(src, t, n, lane); wm.refill(src, m, n, lane); wl.refill(src, l, n, lane); ws.refill(src, s, n, lane);
+        ok = 1;
+        for (;;) {
+            const int token = (int)wt.at(src, t, n, lane);
+            t++;
+            int mlen, dist;
+            if (V5) {
+                mlen = token & 15;
+                if (mlen == 15) {
+                    mlen = mm + (int)lz_get_len(wl, src, l, n, lane);
+                    dist = (token & 0x10) ? rep1 : rep0;
+                } else {
+                    mlen = (mlen == 14) ? 14 + mm + (int)lz_get_len(wl, src, l, n, lane) : mlen + mm;
+                    const int nb = 1 + (flags & 1) + ((token >> 4) & 1);
+                    dist = (int)wm.at(src, m, n, lane);
+                    if (nb >= 2) dist = (dist << 8) | (int)wm.at(src, m + 1, n, lane);
+                    if (nb == 3) dist = (dist << 8) | (int)wm.at(src, m + 2, n, lane);
+                    m += nb;
+                }
+            } else if ((token & 0x18) == 0) {
+                mlen = token & 3;
+                mlen = (mlen == 3) ? 3 + mm + (int)lz_get_len(wl, src, l, n, lane) : mlen + mm;
+                dist = (token & 4) ? rep1 : rep0;
+            } else {
+                mlen = token & 7;
+                mlen = (mlen == 7) ? 7 + mm + (int)lz_get_len(wl, src, l, n, lane) : mlen + mm;
+                const int nb = (token >> 3) & 3;
+                dist = (int)wm.at(src, m, n, lane);
+                if (nb >= 2) dist = (dist << 8) | (int)wm.at(src, m + 1, n, lane);
+                if (nb == 3) dist = (dist << 8) | (int)wm.at(src, m + 2, n, lane);
+                m += nb;
+            }
+            int lit = 0, litSrc = s;
+            const int d0 = d;
+            if (token >= 32) {
+                const u32 ul = (token >= 0xE0) ? 7u + lz_get_len(ws, src, s, n, lane) : (u32)(token >> 5);
+                if (ul > (u32)(cap - d) || ul > (u32)(litEnd - s)) { ok = 0; break; }
+                lit = (int)ul; litSrc = s;
+                s += lit; d += lit;
+                if (s >= litEnd - 13) {
+                    if (lane == 0) recs[nr] = make_uint4((u32)d0, (u32)lit, (u32)litSrc, 1u);
+                    nr++;
+                    break;
+                }
+            }
+            rep1 = rep0; rep0 = dist;
+            const int end = d + mlen;
+            const int ref = d - dist;
+            if (ref < 0 || dist > maxDist || end > cap) { ok = 0; break; }
+            if (lane == 0) recs[nr] = make_uint4((u32)d0, (u32)lit, (u32)litSrc, (u32)dist);
+            nr++;
+            d = end;
+        }
+        ok = ok && (s == litEnd);
+    } while (0);
+    if (lane == 0) {
+        st.ok[b] = (u8)(ok ? 1 : 0); st.newLen[b] = (u32)d;
+        if (ok) { recs[nr] = make_uint4((u32)d, 0u, 0u, 1u); info[0] = nr + 1; info[1] = (u32)d; }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lz_tile_first(LzInvWs w, int wgPerBlock)
+{
+    const int b = blockIdx.x / wgPerBlock;
+    const u32 part = blockIdx.x - (u32)b * (u32)wgPerBlock;
+    const u32* info = w.info + 4 * (size_t)b;
+    const u32 nr = info[0];
+    if (nr < 2) return;
+    const uint4* recs = w.recs + (size_t)b * w.recStride;
+    u32* tf = w.tileFirst + (size_t)b * w.tStride;
+    for (u32 k = part * 256 + threadIdx.x; k + 1 < nr; k += (u32)wgPerBlock * 256) {
+        const u32 d0 = recs[k].x, d1 = recs[k + 1].x;
+        for (u32 t = (d0 + LZI_T - 1) / LZI_T; (u64)t * LZI_T < d1; t++) tf[t] = k;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lz_expand(LzInvWs w, int tilesPerBlock)
+{
+    const int b = blockIdx.x / tilesPerBlock;
+    const u32 tile = blockIdx.x - (u32)b * (u32)tilesPerBlock;
+    const u32* info = w.info + 4 * (size_t)b;
+    const u32 nr = info[0], total = info[1];
+    const u32 p0 = tile * LZI_T;
+    if (nr < 2 || p0 >= total) return;
+    const uint4* recs = w.recs + (size_t)b * w.recStride;
+    __shared__ uint4 R[LZI_RECS];
+    __shared__ u32 sDone[LZI_RECS / 256 + 3];                // one flag per batch of records (no flag is written again after it was read), one for the result
+    const u32 k0 = w.tileFirst[(size_t)b * w.tStride + tile];
+    if (threadIdx.x < LZI_RECS / 256 + 3) sDone[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 pEnd = (p0 + LZI_T < total) ? p0 + LZI_T : total;
+    // records k0 .. up to the first one that starts at or behind the tile's end (the sentinel starts at `total`)
+    u32 nLoaded = 0;
+    for (u32 base = 0; base < LZI_RECS; base += 256) {
+        const u32 idx = base + threadIdx.x;
+        if (idx < LZI_RECS) {
+            uint4 r = make_uint4(0xFFFFFFFFu, 0u, 0u, 1u);
+            if (k0 + idx < nr) r = recs[k0 + idx];
+            R[idx] = r;
+            if (r.x >= pEnd) sDone[base / 256] = 1;
+        }
+        nLoaded = (base + 256 < LZI_RECS) ? base + 256 : LZI_RECS;
+        __syncthreads();
+        if (sDone[base / 256]) break;
+    }
+    // thread: 8 consecutive bytes
+    const u32 p = p0 + 8 * threadIdx.x;
+    u32 out[8];
+    bool pend = false;
+    if (p < pEnd) {
+        u32 lo = 0, hi = nLoaded - 1;                           // largest i with R[i].x <= p (R[0].x <= p0)
+        while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if (R[mid].x <= p) lo = mid; else hi = mid - 1; }
+        u32 i = lo;
+        uint4 r = R[i];
+        u32 nextD = (i + 1 < nLoaded) ? R[i + 1].x : 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const u32 q = p + (u32)j;
+            while (q >= nextD) { i++; r = R[i]; nextD = (i + 1 < nLoaded) ? R[i + 1].x : 0xFFFFFFFFu; }
+            u32 e;
+            if (q < r.x + r.y) e = LZI_ROOT | (r.z + (q - r.x));
+            else if (r.w == 0) e = LZI_STALE | q;
+            else { e = q - r.w; pend = true; }
+            if (q >= pEnd) { e = LZI_STALE | q; }
+            out[j] = e;
+        }
+        u32* P = w.P + (size_t)b * w.pStride + p;
+        *reinterpret_cast<uint4*>(P) = make_uint4(out[0], out[1], out[2], out[3]);
+        *reinterpret_cast<uint4*>(P + 4) = make_uint4(out[4], out[5], out[6], out[7]);
+    }
+    if (pend) sDone[LZI_RECS / 256 + 2] = 1;
+    __syncthreads();
+    const bool any = sDone[LZI_RECS / 256 + 2] != 0;
+    if (threadIdx.x == 0) {
+        w.tileFlag[(size_t)b * w.tStride + tile] = any ? 1 : 0;
+        if (any) atomicAdd(&w.pending[0], 1u);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lz_jump(LzInvWs w, int tilesPerBlock, int round)
+{
+    if (w.pending[round] == 0) return;                       // nothing was left after the round before
+    const int b = blockIdx.x / tilesPerBlock;
+    const u32 tile = blockIdx.x - (u32)b * (u32)tilesPerBlock;
+    u8* flag = w.tileFlag + (size_t)b * w.tStride + tile;
+    const u32 total = w.info[4 * (size_t)b + 1];
+    if ((u64)tile * LZI_T >= total || *flag == 0) return;
+    u32* Pb = w.P + (size_t)b * w.pStride;
+    u32* P = Pb + (size_t)tile * LZI_T + 8 * threadIdx.x;
+    uint4 a = *reinterpret_cast<const uint4*>(P), c = *reinterpret_cast<const uint4*>(P + 4);
+    u32 e[8] = { a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w };
+    bool pend = false, changed = false;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        if (!(e[j] & LZI_ROOT)) {
+            const u32 v = Pb[e[j]];
+            e[j] = v; changed = true;
+            if (!(v & LZI_ROOT)) pend = true;
+        }
+    }
+    if (changed) {
+        *reinterpret_cast<uint4*>(P) = make_uint4(e[0], e[1], e[2], e[3]);
+        *reinterpret_cast<uint4*>(P + 4) = make_uint4(e[4], e[5], e[6], e[7]);
+    }
+    __shared__ u32 sPend;
+    if (threadIdx.x == 0) sPend = 0;
+    __syncthreads();
+    if (pend) sPend = 1;
+    __syncthreads();
+    const bool any = sPend != 0;
+    if (threadIdx.x == 0) {
+        *flag = any ? 1 : 0;
+        if (any) atomicAdd(&w.pending[round + 1], 1u);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lz_emit(XfStage st, LzInvWs w, int tilesPerBlock)
+{
+    const int b = blockIdx.x / tilesPerBlock;
+    const u32 tile = blockIdx.x - (u32)b * (u32)tilesPerBlock;
+    const u32 total = w.info[4 * (size_t)b + 1];
+    const u32 p = tile * LZI_T + 8 * threadIdx.x;
+    if (p >= total) return;
+    const u8* __restrict__ src = st.src[b];
+    u8* dst = st.dst[b];
+    const u32* P = w.P + (size_t)b * w.pStride + p;
+    const uint4 a = *reinterpret_cast<const uint4*>(P), c = *reinterpret_cast<const uint4*>(P + 4);
+    const u32 e[8] = { a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w };
+    u64 v = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const u32 x = e[j];
+        u8 by;
+        if ((x & LZI_STALE) == LZI_ROOT) by = src[x & 0x3FFFFFFFu];
+        else if ((x & LZI_STALE) == LZI_STALE) by = dst[x & 0x3FFFFFFFu];
+        else by = dst[p + j];                                 // (not reached: every chain ends within LZI_ROUNDS rounds)
+        v |= (u64)by << (8 * j);
+    }
+    if (p + 8 <= total && (reinterpret_cast<uintptr_t>(dst) & 7) == 0) *reinterpret_cast<u64*>(dst + p) = v;
+    else for (int j = 0; j < 8 && p + j < total; j++) dst[p + j] = (u8)(v >> (8 * j));
 }
 
 static int lz_group_blocks(int ttype, int nBlocks)
@@ -686,11 +946,59 @@ int launch_lz_forward(hipStream_t s, const XfStage& stAll, int ttype, void* scra
     return 0;
 }
 
-void launch_lz_inverse(hipStream_t s, const XfStage& st)
+int lz_serial_decode(int set)
 {
-    KScope ks_("k_lz_inverse");
-    if (st.bsVersion < 6) hipLaunchKernelGGL(k_lz_inverse<true>, dim3(st.nBlocks), dim3(64), 0, s, st);
-    else hipLaunchKernelGGL(k_lz_inverse<false>, dim3(st.nBlocks), dim3(64), 0, s, st);
+    static std::atomic<int> v{ getenv("KNZ_LZ_SERIAL_DECODE") ? atoi(getenv("KNZ_LZ_SERIAL_DECODE")) : 0 };
+    if (set >= 0) v.store(set);
+    return v.load();
+}
+
+static size_t lzi_tiles(u32 maxCap) { return ((size_t)maxCap + LZI_T - 1) / LZI_T + 1; }
+
+size_t lz_inverse_scratch_bytes(int nBlocks, u32 maxCap)
+{
+    const size_t tiles = lzi_tiles(maxCap);
+    return (size_t)nBlocks * (lz_align(((size_t)maxCap / 2 + 8) * sizeof(uint4)) + lz_align(tiles * LZI_T * 4) + lz_align(tiles * 4) + lz_align(tiles)) +
+           lz_align((size_t)nBlocks * 16) + lz_align((LZI_ROUNDS + 2) * 4) + 512;
+}
+
+// scratch == nullptr (or maxCap == 0): the one-wave-per-block decoder alone
+void launch_lz_inverse(hipStream_t s, const XfStage& st, void* scratch, size_t scratchBytes, u32 maxCap)
+{
+    if (scratch == nullptr || maxCap == 0 || maxCap > (1u << 30) || scratchBytes < lz_inverse_scratch_bytes(st.nBlocks, maxCap)) {
+        KScope ks_("k_lz_inverse");
+        if (st.bsVersion < 6) hipLaunchKernelGGL(k_lz_inverse<true>, dim3(st.nBlocks), dim3(64), 0, s, st, (const u32*)nullptr);
+        else hipLaunchKernelGGL(k_lz_inverse<false>, dim3(st.nBlocks), dim3(64), 0, s, st, (const u32*)nullptr);
+        return;
+    }
+    const size_t tiles = lzi_tiles(maxCap);
+    u8* p = reinterpret_cast<u8*>(scratch);
+    LzInvWs w;
+    w.recStride = (size_t)maxCap / 2 + 8;
+    w.recs = reinterpret_cast<uint4*>(p); p += (size_t)st.nBlocks * lz_align(w.recStride * sizeof(uint4));
+    w.recStride = lz_align(w.recStride * sizeof(uint4)) / sizeof(uint4);
+    w.pStride = lz_align(tiles * LZI_T * 4) / 4;
+    w.P = reinterpret_cast<u32*>(p); p += (size_t)st.nBlocks * w.pStride * 4;
+    w.tStride = lz_align(tiles * 4) / 4;
+    w.tileFirst = reinterpret_cast<u32*>(p); p += (size_t)st.nBlocks * w.tStride * 4;
+    w.tileFlag = p; p += lz_align((size_t)st.nBlocks * w.tStride);
+    w.info = reinterpret_cast<u32*>(p); p += lz_align((size_t)st.nBlocks * 16);
+    w.pending = reinterpret_cast<u32*>(p);
+    const int tilesPerBlock = (int)(tiles - 1);
+    hipMemsetAsync(w.pending, 0, (LZI_ROUNDS + 2) * 4, s);
+    { KScope ks_("k_lz_parse");
+      if (st.bsVersion < 6) hipLaunchKernelGGL(k_lz_parse<true>, dim3(st.nBlocks), dim3(64), 0, s, st, w);
+      else hipLaunchKernelGGL(k_lz_parse<false>, dim3(st.nBlocks), dim3(64), 0, s, st, w); }
+    const int wgPerBlock = 64;
+    { KScope ks_("k_lz_tile_first"); hipLaunchKernelGGL(k_lz_tile_first, dim3(st.nBlocks * wgPerBlock), dim3(256), 0, s, w, wgPerBlock); }
+    const dim3 grid((unsigned)((size_t)st.nBlocks * tilesPerBlock));
+    { KScope ks_("k_lz_expand"); hipLaunchKernelGGL(k_lz_expand, grid, dim3(256), 0, s, w, tilesPerBlock); }
+    { KScope ks_("k_lz_jump");
+      for (int r = 0; r < LZI_ROUNDS; r++) hipLaunchKernelGGL(k_lz_jump, grid, dim3(256), 0, s, w, tilesPerBlock, r); }
+    { KScope ks_("k_lz_emit"); hipLaunchKernelGGL(k_lz_emit, grid, dim3(256), 0, s, st, w, tilesPerBlock); }
+    { KScope ks_("k_lz_inverse");                               // blocks the parse left alone (none with a workspace sized by maxCap)
+      if (st.bsVersion < 6) hipLaunchKernelGGL(k_lz_inverse<true>, dim3(st.nBlocks), dim3(64), 0, s, st, (const u32*)w.info);
+      else hipLaunchKernelGGL(k_lz_inverse<false>, dim3(st.nBlocks), dim3(64), 0, s, st, (const u32*)w.info); }
 }
 
 }  // namespace knz

@@ -60,6 +60,7 @@ struct XfStage {
     u32* scratchU32;         // stage scratch (8-byte aligned)
     int entropyType;         // stream entropy id (RLT escape choice)
     int bsVersion = 6;       // bitstream version the blocks come from (inverse only: BWT block header of versions below 6)
+    u32 maxCap = 0;          // upper bound of cap[] when the host knows one (inverse stages that size scratch by their output)
 };
 
 // zrlt_mtft.hip
@@ -96,7 +97,9 @@ void launch_sbrt_inverse(hipStream_t s, const XfStage& st, int mode);
 
 // lz.hip (ttype = KNZ_T_LZ or KNZ_T_LZX)
 int launch_lz_forward(hipStream_t s, const XfStage& st, int ttype, void* scratch, size_t scratchBytes);
-void launch_lz_inverse(hipStream_t s, const XfStage& st);
+void launch_lz_inverse(hipStream_t s, const XfStage& st, void* scratch, size_t scratchBytes, u32 maxCap);   // no scratch: serial decoder only
+size_t lz_inverse_scratch_bytes(int nBlocks, u32 maxCap);
+int lz_serial_decode(int set);                               // knob "lz_serial_decode": >= 0 sets it, returns the value (1 = one wave per block only)
 size_t lz_forward_scratch_bytes(int ttype, int nBlocks, u32 maxLen);
 
 // xxhash.hip

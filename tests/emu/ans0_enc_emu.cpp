@@ -46,7 +46,7 @@ int main(int argc, char** argv)
         launch_ans0_encode(nullptr, view, 1, maxChunks, desc.data(), encTab.data(), tmp.data());
         FrameParams fp; fp.framing = 0; fp.nTransforms = 1; fp.checksumBits = 0; fp.finish = 0; fp.prologueBits = 0;
         launch_block_sum(nullptr, desc.data(), info.data(), &len, 1, maxChunks, ENT_CHUNK, 1u);
-        launch_block_scan(nullptr, info.data(), &len, 1, fp, &total);
+        launch_block_scan(nullptr, info.data(), &len, &origLen, 1, fp, &total);
         std::vector<u32> out(((size_t)((total + 7) >> 3) + 8 + 3) / 4 + 16, 0);
         launch_assemble(nullptr, desc.data(), info.data(), &len, &origLen, &skip, nullptr, tmp.data(), 1, maxChunks, ENT_CHUNK, 1u, TMP_STRIDE, fp, out.data());
         const u8* got = reinterpret_cast<const u8*>(out.data());

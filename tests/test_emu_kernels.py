@@ -300,6 +300,11 @@ def test_block_serial_transforms_emulated(tmp_path, name):
         # the token layout of bitstream versions below 6 (LZCodec.cpp:614-760), written by the oracle, read by k_lz_inverse<true>
         r = subprocess.run([exe, path, "5"], capture_output=True, text=True, timeout=1500)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        # the decoder is two: the data-parallel one (k_lz_parse, k_lz_expand, k_lz_jump, k_lz_emit; the default, above) and the
+        # one-wave-per-block k_lz_inverse it falls back to
+        for ver in ([], ["5"]):
+            r = subprocess.run([exe, path] + ver, capture_output=True, text=True, timeout=1500, env=dict(os.environ, KNZ_LZ_SERIAL_DECODE="1"))
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_huffman_encoder_and_bit_assembly_emulated(tmp_path):

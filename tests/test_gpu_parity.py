@@ -369,6 +369,19 @@ def test_stream_vs_oracle_ragged(hip, oracle):
                 assert gpu_decompress(hip, ref, t, e, bs, len(d), 0) == d, (spec, t, e)
 
 
+def test_chains_of_more_than_four_stages(hip, oracle):
+    """five, six and seven device stages (chains in which no even-numbered stage expands: those run into the reference's undefined behaviour, DESIGN.md 4): the block header carries the skip flags as a byte of its own (io/CompressedOutputStream.cpp:791-799);
+    the oracle's streams for these chains are pinned by the reference in tests/test_oracle_vs_ref.py"""
+    for spec, bs in [(("mixed", 700001, 11), 65536), (("text", 300000, 3), 262144), (("rand", 40000, 1), 16384)]:
+        d = vectors.make(spec)
+        for t, e, ck in [("BWT+RANK+ZRLT+RLT+MTFT", "ANS0", 0), ("RLT+BWT+RANK+ZRLT+MTFT+SRT", "HUFFMAN", 32), ("RLT+BWT+SRT+ZRLT+RLT+MTFT+ZRLT", "FPAQ", 64)]:
+            rc, ref = oracle.compress(d, t, e, bs, ck, headerless=1)
+            assert rc == 0
+            out, bits, hb = gpu_compress(hip, d, t, e, bs, checksum=ck, headerless=1)
+            assert out == ref, (spec, t, e)
+            assert gpu_decompress(hip, ref, t, e, bs, len(d), 0, checksum=ck) == d, (spec, t, e)
+
+
 def test_lz_block_groups_and_long_matches(hip, oracle):
     # the LZ encoder sorts (block, hash) keys in groups of at most 8190 (LZX) blocks: more blocks than one group
     d = vectors.make(("mixed", 9000 * 1024 + 321, 6))

@@ -104,7 +104,10 @@ def test_streams_match_reference(oracle, ref):
     d = vectors.make(("mixed", 700001, 11))
     for t, e, bs, ck in [("BWT+MTFT+ZRLT", "ANS0", 65536, 0), ("BWT+SRT+ZRLT", "FPAQ", 262144, 32),
                          ("RLT+ZRLT", "HUFFMAN", 16384, 64), ("NONE", "ANS1", 1 << 20, 0),
-                         ("LZX", "ANS1", 262144, 0), ("LZ+ZRLT", "HUFFMAN", 65536, 32)]:
+                         ("LZX", "ANS1", 262144, 0), ("LZ+ZRLT", "HUFFMAN", 65536, 32),
+                         # more than four stages: the skip flags get a byte of their own in the block header
+                         ("BWT+RANK+ZRLT+RLT+MTFT", "ANS0", 65536, 0), ("RLT+BWT+RANK+ZRLT+MTFT+SRT", "HUFFMAN", 262144, 32),
+                         ("RLT+BWT+SRT+ZRLT+RLT+MTFT+ZRLT", "FPAQ", 65536, 64)]:
         for jobs in (1, 3):
             # the job count selects buffer slots, hence capacities, hence ZRLT's success on short last blocks
             rc1, a = oracle.compress(d, t, e, bs, ck, jobs=jobs)
