@@ -53,7 +53,7 @@ STAGE_PREFIXES = [
     ("k_mtf_f", "mtft_forward"), ("k_mtf_i", "mtft_inverse"),
     ("k_zrlt_f", "zrlt_forward"), ("k_zrlt_i", "zrlt_inverse"), ("k_zero_dst", "zrlt_inverse"),
     ("k_srt_f", "srt_forward"), ("k_srt_zero", "srt_forward"), ("k_srt_i", "srt_inverse"),
-    ("k_lz_inverse", "lz_inverse"), ("k_lz", "lz_forward"),
+    ("k_lz_inverse", "lz_inverse"), ("k_lz_i", "lz_inverse"), ("k_lz", "lz_forward"),
     ("k_ans0_stats", "ans0_encode"), ("k_ans0_encode", "ans0_encode"),
     ("k_ans0_scan", "ans0_decode"), ("k_ans0_decode", "ans0_decode"),
     ("k_ans1_hist", "ans1_encode"), ("k_ans1_ctx", "ans1_encode"), ("k_ans1_encode", "ans1_encode"),

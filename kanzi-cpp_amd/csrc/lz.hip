@@ -617,18 +617,18 @@ __global__ __launch_bounds__(64) void k_lz_inverse(XfStage st, const u32* __rest
 
 // ------------------------------------------------------------------------------------------------
 // Decoder in two parts (round 4).  The serial kernel above spends most of a token on the copy it makes (a load, a store and, when
-// the next match reads what this one wrote, a fence: ~2.5 us per token).  Here the chain per block only PARSES: k_lz_parse walks the
+// the next match reads what this one wrote, a fence: ~2.5 us per token).  Here the chain per block only PARSES: k_lz_i_parse walks the
 // four byte sequences exactly as k_lz_inverse does, with the same checks in the same order, and leaves one record per token
 // (output position, literal count, literal source, distance).  Everything that moves bytes is data parallel over the output:
-//   k_lz_tile_first  for every tile of 2048 output bytes the token its first byte belongs to
-//   k_lz_expand      one entry per output byte: where the byte comes from -- a literal (offset in the block's literal section) or the
+//   k_lz_i_first  for every tile of 2048 output bytes the token its first byte belongs to
+//   k_lz_i_expand      one entry per output byte: where the byte comes from -- a literal (offset in the block's literal section) or the
 //                    output byte `distance` in front of it (dst[p] = dst[p - dist] holds for overlapping matches too: it is what the
 //                    reference's byte loop, its 16-byte steps for dist >= 16 and its memset for dist == 1 all compute)
-//   k_lz_jump        pointer jumping: an entry that points at a byte which itself points further back takes that byte's entry.
+//   k_lz_i_jump        pointer jumping: an entry that points at a byte which itself points further back takes that byte's entry.
 //                    Entries only ever move towards their literal, so the rounds run in place without a barrier between readers
 //                    and writers; ceil(log2(longest chain)) + 1 rounds, tiles that are done drop out, and a round in which no tile
 //                    is left costs a launch of workgroups that read one flag
-//   k_lz_emit        dst[p] = literal section[entry]
+//   k_lz_i_emit        dst[p] = literal section[entry]
 // A distance of 0 (damaged input only) leaves the byte as it is, as the reference's byte loop does: such entries are roots of their own.
 constexpr u32 LZI_T = 2048;                       // output bytes per tile
 constexpr u32 LZI_ROOT = 0x80000000u;             // entry = LZI_ROOT | offset of a literal in src
@@ -645,14 +645,16 @@ struct LzInvWs {
 };
 
 template <bool V5>
-__global__ __launch_bounds__(64) void k_lz_parse(XfStage st, LzInvWs w)
+__global__ __launch_bounds__(64) void k_lz_i_parse(XfStage st, LzInvWs w)
 {
     const int b = blockIdx.x;
     const int lane = lane_id();
     const int n = (int)st.len[b];
     u32* info = w.info + 4 * (size_t)b;
-    if (lane == 0) { info[0] = 0; info[1] = 0; info[2] = 0; }
-    if (n == 0) return;
+    if (n == 0 || info[3] == 0) return;                      // (k_lz_i_pparse has dealt with the block)
+#ifdef KNZ_EMU
+    if (lane == 0 && getenv("KNZ_EMU_VERBOSE")) fprintf(stderr, "k_lz_i_parse: block %d (n = %d) comes from the parallel parse\n", b, n);
+#endif
     const u8* __restrict__ src = st.src[b];
     const int cap = (st.cap[b] > 0x7FFFFFFFu) ? 0x7FFFFFFF : (int)st.cap[b];
     if ((size_t)cap > w.pStride || (size_t)cap / 2 + 4 > w.recStride) { if (lane == 0) info[2] = 1; return; }   // (sized by the caller's bound: does not happen)
@@ -731,7 +733,327 @@ __global__ __launch_bounds__(64) void k_lz_parse(XfStage st, LzInvWs w)
     }
 }
 
-__global__ __launch_bounds__(256) void k_lz_tile_first(LzInvWs w, int wgPerBlock)
+// ---- the parse without the chain (current block layout only) ---------------------------------------------------------------
+// What makes the parse serial is only WHERE each token's pieces sit: its distance bytes, its length extension, its literals. Three
+// of the four positions are prefix sums over token bytes (distance bytes: 0-3 per token; which tokens have a length extension, which
+// a literal extension; the literal counts below 7). The length extensions are self-delimiting (1, 3 or 4 bytes by the first byte):
+// their starts are the states "0" of a 4-state machine run over the section's bytes, and a machine with 4 states is a scan over
+// functions {0..3} -> {0..3}. The distances a token repeats are the previous token's or the one before: (rep0, rep1) after a token is
+// a function of (rep0, rep1) before it whose two outputs are a constant or one of the inputs -- closed under composition, so a scan
+// again. Only the literal extensions stay a chain (the extension bytes sit between the literals they count), but a short one: one
+// step per literal run of 7 bytes or more (1 token in 100 to 400). One workgroup of 1024 threads per block streams over the
+// sections with carries; anything out of the ordinary (a header that fails the checks, a stream the serial parse would stop early
+// or late on, a bound exceeded) is left to k_lz_i_parse, which then decides with the reference's own sequence of checks.
+struct LzPWs {
+    u32* extM; size_t extStride;              // per block: value of the e-th match-length extension
+    uint2* extL;                              // per block: e-th literal extension: (token, literals below 7 in front of it), later (first literal, count)
+    u32* xcum;                                // per block: bytes the first e literal extensions and their runs take
+};
+
+template <typename T>
+__device__ __forceinline__ T lzp_shfl_up(T v, int off)
+{
+    static_assert(sizeof(T) % 4 == 0, "");
+    u32 wds[sizeof(T) / 4];
+    __builtin_memcpy(wds, &v, sizeof(T));
+#pragma unroll
+    for (size_t i = 0; i < sizeof(T) / 4; i++) wds[i] = (u32)__shfl_up((int)wds[i], (unsigned)off);
+    T r;
+    __builtin_memcpy(&r, wds, sizeof(T));
+    return r;
+}
+
+// exclusive scan over the 1024 threads of the workgroup with a (non-commutative) combine(earlier, later); sm: 16 entries
+template <typename T, typename Op>
+__device__ __forceinline__ T lzp_scan(T v, const T ident, Op op, T* sm, T& total)
+{
+    const int lane = lane_id(), wv = (int)(threadIdx.x >> 6);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const T o = lzp_shfl_up(v, off);
+        if (lane >= off) v = op(o, v);
+    }
+    T ex = lzp_shfl_up(v, 1);
+    if (lane == 0) ex = ident;
+    if (lane == 63) sm[wv] = v;
+    __syncthreads();
+    T pre = ident, all = ident;
+    for (int i = 0; i < 16; i++) { if (i == wv) pre = all; all = op(all, sm[i]); }
+    __syncthreads();
+    total = all;
+    return op(pre, ex);
+}
+
+struct LzFsm { u32 fn; u32 c01, c23; };       // fn: 2 bits per incoming state; starts seen per incoming state (16 bits each)
+__device__ __forceinline__ u32 lzfsm_cnt(const LzFsm& f, u32 s) { return ((s & 2 ? f.c23 : f.c01) >> (16 * (s & 1))) & 0xFFFFu; }
+struct LzFsmOp {
+    __device__ __forceinline__ LzFsm operator()(const LzFsm& a, const LzFsm& b) const
+    {
+        LzFsm r; r.fn = 0;
+        u32 c[4];
+#pragma unroll
+        for (u32 s = 0; s < 4; s++) {
+            const u32 mid = (a.fn >> (2 * s)) & 3;
+            r.fn |= ((b.fn >> (2 * mid)) & 3) << (2 * s);
+            c[s] = lzfsm_cnt(a, s) + lzfsm_cnt(b, mid);
+        }
+        r.c01 = c[0] | (c[1] << 16); r.c23 = c[2] | (c[3] << 16);
+        return r;
+    }
+};
+struct LzRep { u32 a, b; };                   // (rep0, rep1) after, each: kind << 30 | value; kind 0 constant, 1 = rep0 before, 2 = rep1 before
+struct LzRepOp {
+    __device__ __forceinline__ LzRep operator()(const LzRep& f, const LzRep& g) const
+    {
+        LzRep r;
+        r.a = (g.a >> 30) == 0 ? g.a : ((g.a >> 30) == 1 ? f.a : f.b);
+        r.b = (g.b >> 30) == 0 ? g.b : ((g.b >> 30) == 1 ? f.a : f.b);
+        return r;
+    }
+};
+struct LzSum64 { __device__ __forceinline__ u64 operator()(u64 a, u64 b) const { return a + b; } };
+struct LzU64 { u32 lo, hi; };
+
+__device__ __forceinline__ u32 lzp_byte(const u8* s, int x, int limit) { return (x >= 0 && x < limit) ? (u32)s[x] : 0u; }
+// readLength at x (bytes at or behind `limit` read as zero): value, size
+__device__ __forceinline__ u32 lzp_len_at(const u8* s, int x, int limit, u32& size)
+{
+    const u32 b0 = lzp_byte(s, x, limit);
+    if (b0 < 254) { size = 1; return b0; }
+    const u32 b1 = lzp_byte(s, x + 1, limit), b2 = lzp_byte(s, x + 2, limit);
+    if (b0 == 254) { size = 3; return 254 + ((b1 << 8) | b2); }
+    size = 4;
+    return 255 + ((b1 << 16) | (b2 << 8) | lzp_byte(s, x + 3, limit));
+}
+
+// the four counts of a token, 16 bits each: distance bytes | length extension << 16 | literal extension << 32 | literals below 7 << 48
+__device__ __forceinline__ u64 lzp_counts(u32 tok)
+{
+    const bool rep = (tok & 0x18) == 0;
+    const u64 nb = rep ? 0 : (tok >> 3) & 3;
+    const u64 me = rep ? ((tok & 3) == 3) : ((tok & 7) == 7);
+    const u64 le = tok >= 0xE0;
+    const u64 ls = (tok >= 32 && tok < 0xE0) ? (tok >> 5) : 0;
+    return nb | (me << 16) | (le << 32) | (ls << 48);
+}
+
+__global__ __launch_bounds__(1024) void k_lz_i_pparse(XfStage st, LzInvWs w, LzPWs pw, int oldLayout)
+{
+    const int b = blockIdx.x;
+    const int tid = (int)threadIdx.x;
+    const int lane = lane_id();
+    const int n = (int)st.len[b];
+    u32* info = w.info + 4 * (size_t)b;
+    __shared__ u64 smSum[16];
+    __shared__ LzFsm smFsm[16];
+    __shared__ LzRep smRep[16];
+    __shared__ u32 sBad, sExtM;
+    if (tid == 0) { info[0] = 0; info[1] = 0; info[2] = 0; info[3] = 0; sBad = 0; }
+    if (n == 0) return;
+    __syncthreads();
+    const u8* __restrict__ src = st.src[b];
+    const int cap = (st.cap[b] > 0x7FFFFFFFu) ? 0x7FFFFFFF : (int)st.cap[b];
+    bool plain = !oldLayout && n >= 13 && n < (1 << 30) && (size_t)cap <= w.pStride && (size_t)cap / 2 + 4 <= w.recStride;
+    int litEnd = 0, nTok = 0, nDist = 0, flags = 0;
+    if (plain) {
+        litEnd = (int)ld32u(src); nTok = (int)ld32u(src + 4); nDist = (int)ld32u(src + 8); flags = (int)src[12];
+        if (litEnd < 13 || nTok < 1 || nDist < 0 || litEnd > n || nTok > n - litEnd || nDist > n - litEnd - nTok) plain = false;
+        if (plain && (size_t)nTok + 2 > w.recStride) plain = false;      // (more tokens than the output has room for: nothing that decodes)
+    }
+    if (!plain) { if (tid == 0) info[3] = 1; return; }
+    const int t0 = litEnd, m0 = litEnd + nTok, l0 = m0 + nDist;
+    const int maxDist = (flags & 1) ? LZ_MAXD2 : LZ_MAXD1;
+    const int mm = ((flags >> 1) & 7) + 2;
+    u32* extM = pw.extM + (size_t)b * pw.extStride;
+    uint2* extL = pw.extL + (size_t)b * pw.extStride;
+    u32* xcum = pw.xcum + (size_t)b * pw.extStride;
+    uint4* recs = w.recs + (size_t)b * w.recStride;
+
+    // ---- 1. match-length extensions: where they start, what they say
+    {
+        u32 state = 0, ordinal = 0;
+        for (int base = l0; base < n; base += 8192) {
+            const int x0 = base + 8 * tid;
+            u32 by[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) by[j] = lzp_byte(src, x0 + j, n);
+            LzFsm f; f.fn = 0;
+            u32 c[4];
+#pragma unroll
+            for (u32 s0 = 0; s0 < 4; s0++) {
+                u32 s = s0, cnt = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    if (x0 + j < n) {
+                        if (s == 0) { cnt++; s = by[j] < 254 ? 0 : (by[j] == 254 ? 2 : 3); }
+                        else s--;
+                    }
+                }
+                f.fn |= s << (2 * s0); c[s0] = cnt;
+            }
+            f.c01 = c[0] | (c[1] << 16); f.c23 = c[2] | (c[3] << 16);
+            LzFsm ident; ident.fn = 0xE4; ident.c01 = 0; ident.c23 = 0;
+            LzFsm tot;
+            const LzFsm pre = lzp_scan(f, ident, LzFsmOp(), smFsm, tot);
+            u32 s = (pre.fn >> (2 * state)) & 3;
+            u32 e = ordinal + lzfsm_cnt(pre, state);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if (x0 + j < n) {
+                    if (s == 0) {
+                        u32 size;
+                        const u32 v = lzp_len_at(src, x0 + j, n, size);
+                        if (e < (u32)nTok) extM[e] = v;
+                        e++; s = size - 1;
+                    } else s--;
+                }
+            }
+            ordinal += lzfsm_cnt(tot, state);
+            state = (tot.fn >> (2 * state)) & 3;
+        }
+        if (tid == 0) sExtM = ordinal - (state != 0 ? 1u : 0u);         // extensions that lie inside the block with all their bytes
+    }
+    __syncthreads();
+    const u32 extMComplete = sExtM;
+
+    // ---- 2. tokens, first pass: the literal extensions in order -- (token, literals of the short runs in front of it)
+    u32 cNb = 0, cMe = 0, cLe = 0, cLs = 0;
+    for (int base = 0; base < nTok; base += 4096) {
+        const int k0 = base + 4 * tid;
+        u64 c[4], mine = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { c[j] = (k0 + j < nTok) ? lzp_counts(src[t0 + k0 + j]) : 0; mine += c[j]; }
+        u64 tot;
+        u64 pre = lzp_scan(mine, (u64)0, LzSum64(), smSum, tot);        // (16-bit fields: a tile's sums stay below 65536)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if ((c[j] >> 32) & 1) extL[cLe + (u32)((pre >> 32) & 0xFFFFu)] = make_uint2((u32)(k0 + j), cLs + (u32)(pre >> 48));
+            pre += c[j];
+        }
+        cNb += (u32)(tot & 0xFFFFu); cMe += (u32)((tot >> 16) & 0xFFFFu); cLe += (u32)((tot >> 32) & 0xFFFFu); cLs += (u32)(tot >> 48);
+    }
+    const u32 leTot = cLe;
+    if (cNb > (u32)(n - m0) || cMe > extMComplete) { if (tid == 0) info[3] = 1; return; }   // pieces beyond the block's end (uniform)
+    // the literal section into this XCD's L2 before one wave walks through it with dependent loads
+    {
+        u32 sink = 0;
+        for (int off = 64 * tid; off < litEnd; off += 65536) sink += src[off];
+        if (sink == 0xFFFFFFFFu) sBad = 2;                              // (never: keeps the loads)
+    }
+    __syncthreads();
+
+    // ---- 3. the chain that is left: one step per literal run of 7 or more
+    if (tid < 64) {
+        u32 X = 0;
+        bool bad = false;
+        for (u32 i0 = 0; i0 < leTot && !bad; i0 += 64) {
+            const uint2 mine = (i0 + (u32)lane < leTot) ? extL[i0 + (u32)lane] : make_uint2(0u, 0u);
+            const u32 cnt = (leTot - i0 < 64u) ? leTot - i0 : 64u;
+            uint2 res = make_uint2(0u, 0u);
+            u32 resX = 0;
+            for (u32 j = 0; j < cnt; j++) {
+                const u32 S = (u32)__builtin_amdgcn_readlane((int)mine.y, (int)j);
+                const u32 sp = 13u + S + X;
+                if (sp >= (u32)litEnd) { bad = true; break; }
+                u32 size;
+                const u32 lit = 7u + lzp_len_at(src, sgpr((int)sp), n, size);
+                const u32 sa = sp + size;
+                if (sa > (u32)litEnd || lit > (u32)litEnd - sa) { bad = true; break; }
+                if ((u32)lane == j) { res = make_uint2(sa, lit); resX = X; }
+                X += size + lit;
+            }
+            if (i0 + (u32)lane < leTot) { extL[i0 + (u32)lane] = res; xcum[i0 + (u32)lane] = resX; }
+        }
+        if (lane == 0) { xcum[leTot] = X; if (bad) sBad = 1; }
+    }
+    __syncthreads();
+    if (sBad) { if (tid == 0) info[3] = 1; return; }
+
+    // ---- 4. tokens, second pass: lengths, output positions, distances; the checks of the serial parse
+    cNb = 0; cMe = 0; cLe = 0; cLs = 0;
+    u64 cD = 0;
+    u32 cRep0 = (u32)n, cRep1 = (u32)n;
+    bool bad = false;
+    for (int base = 0; base < nTok; base += 4096) {
+        const int k0 = base + 4 * tid;
+        u32 tk[4];
+        u64 c[4], mine = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { tk[j] = (k0 + j < nTok) ? (u32)src[t0 + k0 + j] : 0x100u; c[j] = (tk[j] < 0x100u) ? lzp_counts(tk[j]) : 0; mine += c[j]; }
+        u64 tot;
+        u64 pre = lzp_scan(mine, (u64)0, LzSum64(), smSum, tot);
+        u32 lit[4], lsrc[4], mlen[4], dsp[4];                           // dsp: the distance as kind << 30 | value
+        u64 lenSum = 0;
+        LzRep F; F.a = 1u << 30; F.b = 2u << 30;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            lit[j] = 0; lsrc[j] = 0; mlen[j] = 0; dsp[j] = 1u << 30;
+            if (tk[j] < 0x100u) {
+                const u32 M = cNb + (u32)(pre & 0xFFFFu), E = cMe + (u32)((pre >> 16) & 0xFFFFu), L = cLe + (u32)((pre >> 32) & 0xFFFFu), S = cLs + (u32)(pre >> 48);
+                const u32 t = tk[j];
+                if (t >= 0xE0) { const uint2 e = extL[L]; lsrc[j] = e.x; lit[j] = e.y; }
+                else { lsrc[j] = 13u + S + xcum[L]; lit[j] = (t >= 32) ? (t >> 5) : 0u; }
+                const bool rep = (t & 0x18) == 0;
+                const u32 mb = rep ? (t & 3) : (t & 7);
+                const bool me = rep ? (mb == 3) : (mb == 7);
+                mlen[j] = mb + (u32)mm + (me ? extM[E] : 0u);
+                if (rep) dsp[j] = (t & 4) ? (2u << 30) : (1u << 30);
+                else {
+                    const u32 nb = (t >> 3) & 3;
+                    u32 dv = src[m0 + M];
+                    if (nb >= 2) dv = (dv << 8) | src[m0 + M + 1];
+                    if (nb == 3) dv = (dv << 8) | src[m0 + M + 2];
+                    dsp[j] = dv;
+                }
+                if (k0 + j == nTok - 1) mlen[j] = 0;                    // the last token ends with its literals
+                lenSum += (u64)lit[j] + mlen[j];
+                LzRep g; g.a = dsp[j]; g.b = 1u << 30;                   // rep0 = this distance, rep1 = the rep0 before
+                F = LzRepOp()(F, g);
+                pre += c[j];
+            }
+        }
+        u64 dTot;
+        u64 d = cD + lzp_scan(lenSum, (u64)0, LzSum64(), smSum, dTot);
+        LzRep ident; ident.a = 1u << 30; ident.b = 2u << 30;
+        LzRep repTot;
+        const LzRep rp = lzp_scan(F, ident, LzRepOp(), smRep, repTot);
+        LzRep cst; cst.a = cRep0; cst.b = cRep1;                        // (n < 2^30: constants)
+        const LzRep in = LzRepOp()(cst, rp);
+        u32 rep0 = in.a, rep1 = in.b;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (tk[j] < 0x100u) {
+                const u32 t = tk[j];
+                const bool last = (k0 + j == nTok - 1);
+                const u32 dist = (dsp[j] >> 30) == 0 ? dsp[j] : ((dsp[j] >> 30) == 1 ? rep0 : rep1);
+                const u64 dl = d + lit[j];
+                if (t >= 32) {
+                    if (dl > (u64)cap) bad = true;
+                    const u32 sAfter = lsrc[j] + lit[j];
+                    if (last ? (sAfter != (u32)litEnd) : (sAfter >= (u32)litEnd - 13u)) bad = true;
+                } else if (last) bad = true;
+                if (!last) {
+                    if (dl < dist || dist > (u32)maxDist || dl + mlen[j] > (u64)cap) bad = true;
+                    rep1 = rep0; rep0 = dist;
+                }
+                recs[k0 + j] = make_uint4((u32)d, lit[j], lsrc[j], last ? 1u : dist);
+                d = dl + mlen[j];
+            }
+        }
+        cNb += (u32)(tot & 0xFFFFu); cMe += (u32)((tot >> 16) & 0xFFFFu); cLe += (u32)((tot >> 32) & 0xFFFFu); cLs += (u32)(tot >> 48);
+        cD += dTot;
+        const LzRep after = LzRepOp()(cst, repTot);
+        cRep0 = after.a; cRep1 = after.b;
+    }
+    if (bad) sBad = 1;
+    __syncthreads();
+    if (tid == 0) {
+        if (sBad || cD > (u64)cap) info[3] = 1;
+        else { recs[nTok] = make_uint4((u32)cD, 0u, 0u, 1u); info[0] = (u32)nTok + 1u; info[1] = (u32)cD; st.ok[b] = 1; st.newLen[b] = (u32)cD; }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lz_i_first(LzInvWs w, int wgPerBlock)
 {
     const int b = blockIdx.x / wgPerBlock;
     const u32 part = blockIdx.x - (u32)b * (u32)wgPerBlock;
@@ -746,7 +1068,7 @@ __global__ __launch_bounds__(256) void k_lz_tile_first(LzInvWs w, int wgPerBlock
     }
 }
 
-__global__ __launch_bounds__(256) void k_lz_expand(LzInvWs w, int tilesPerBlock)
+__global__ __launch_bounds__(256) void k_lz_i_expand(LzInvWs w, int tilesPerBlock)
 {
     const int b = blockIdx.x / tilesPerBlock;
     const u32 tile = blockIdx.x - (u32)b * (u32)tilesPerBlock;
@@ -809,7 +1131,7 @@ __global__ __launch_bounds__(256) void k_lz_expand(LzInvWs w, int tilesPerBlock)
     }
 }
 
-__global__ __launch_bounds__(256) void k_lz_jump(LzInvWs w, int tilesPerBlock, int round)
+__global__ __launch_bounds__(256) void k_lz_i_jump(LzInvWs w, int tilesPerBlock, int round)
 {
     if (w.pending[round] == 0) return;                       // nothing was left after the round before
     const int b = blockIdx.x / tilesPerBlock;
@@ -819,20 +1141,23 @@ __global__ __launch_bounds__(256) void k_lz_jump(LzInvWs w, int tilesPerBlock, i
     if ((u64)tile * LZI_T >= total || *flag == 0) return;
     u32* Pb = w.P + (size_t)b * w.pStride;
     u32* P = Pb + (size_t)tile * LZI_T + 8 * threadIdx.x;
-    uint4 a = *reinterpret_cast<const uint4*>(P), c = *reinterpret_cast<const uint4*>(P + 4);
-    u32 e[8] = { a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w };
-    bool pend = false, changed = false;
+    bool pend = false;
+    if (tile * LZI_T + 8 * threadIdx.x < total) {              // (entries behind the last group of 8 were never written)
+        uint4 a = *reinterpret_cast<const uint4*>(P), c = *reinterpret_cast<const uint4*>(P + 4);
+        u32 e[8] = { a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w };
+        bool changed = false;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        if (!(e[j] & LZI_ROOT)) {
-            const u32 v = Pb[e[j]];
-            e[j] = v; changed = true;
-            if (!(v & LZI_ROOT)) pend = true;
+        for (int j = 0; j < 8; j++) {
+            if (!(e[j] & LZI_ROOT)) {
+                const u32 v = Pb[e[j]];
+                e[j] = v; changed = true;
+                if (!(v & LZI_ROOT)) pend = true;
+            }
         }
-    }
-    if (changed) {
-        *reinterpret_cast<uint4*>(P) = make_uint4(e[0], e[1], e[2], e[3]);
-        *reinterpret_cast<uint4*>(P + 4) = make_uint4(e[4], e[5], e[6], e[7]);
+        if (changed) {
+            *reinterpret_cast<uint4*>(P) = make_uint4(e[0], e[1], e[2], e[3]);
+            *reinterpret_cast<uint4*>(P + 4) = make_uint4(e[4], e[5], e[6], e[7]);
+        }
     }
     __shared__ u32 sPend;
     if (threadIdx.x == 0) sPend = 0;
@@ -846,7 +1171,7 @@ __global__ __launch_bounds__(256) void k_lz_jump(LzInvWs w, int tilesPerBlock, i
     }
 }
 
-__global__ __launch_bounds__(256) void k_lz_emit(XfStage st, LzInvWs w, int tilesPerBlock)
+__global__ __launch_bounds__(256) void k_lz_i_emit(XfStage st, LzInvWs w, int tilesPerBlock)
 {
     const int b = blockIdx.x / tilesPerBlock;
     const u32 tile = blockIdx.x - (u32)b * (u32)tilesPerBlock;
@@ -958,7 +1283,7 @@ static size_t lzi_tiles(u32 maxCap) { return ((size_t)maxCap + LZI_T - 1) / LZI_
 size_t lz_inverse_scratch_bytes(int nBlocks, u32 maxCap)
 {
     const size_t tiles = lzi_tiles(maxCap);
-    return (size_t)nBlocks * (lz_align(((size_t)maxCap / 2 + 8) * sizeof(uint4)) + lz_align(tiles * LZI_T * 4) + lz_align(tiles * 4) + lz_align(tiles)) +
+    return (size_t)nBlocks * (2 * lz_align(((size_t)maxCap / 2 + 8) * sizeof(uint4)) + lz_align(tiles * LZI_T * 4) + lz_align(tiles * 4) + lz_align(tiles)) +
            lz_align((size_t)nBlocks * 16) + lz_align((LZI_ROUNDS + 2) * 4) + 512;
 }
 
@@ -977,6 +1302,11 @@ void launch_lz_inverse(hipStream_t s, const XfStage& st, void* scratch, size_t s
     w.recStride = (size_t)maxCap / 2 + 8;
     w.recs = reinterpret_cast<uint4*>(p); p += (size_t)st.nBlocks * lz_align(w.recStride * sizeof(uint4));
     w.recStride = lz_align(w.recStride * sizeof(uint4)) / sizeof(uint4);
+    LzPWs pw;                                                   // 16 bytes per possible token again: extension values, literal extensions, their sums
+    pw.extStride = w.recStride;
+    pw.extL = reinterpret_cast<uint2*>(p); p += (size_t)st.nBlocks * pw.extStride * 8;
+    pw.extM = reinterpret_cast<u32*>(p); p += (size_t)st.nBlocks * pw.extStride * 4;
+    pw.xcum = reinterpret_cast<u32*>(p); p += (size_t)st.nBlocks * pw.extStride * 4;
     w.pStride = lz_align(tiles * LZI_T * 4) / 4;
     w.P = reinterpret_cast<u32*>(p); p += (size_t)st.nBlocks * w.pStride * 4;
     w.tStride = lz_align(tiles * 4) / 4;
@@ -986,16 +1316,17 @@ void launch_lz_inverse(hipStream_t s, const XfStage& st, void* scratch, size_t s
     w.pending = reinterpret_cast<u32*>(p);
     const int tilesPerBlock = (int)(tiles - 1);
     hipMemsetAsync(w.pending, 0, (LZI_ROUNDS + 2) * 4, s);
-    { KScope ks_("k_lz_parse");
-      if (st.bsVersion < 6) hipLaunchKernelGGL(k_lz_parse<true>, dim3(st.nBlocks), dim3(64), 0, s, st, w);
-      else hipLaunchKernelGGL(k_lz_parse<false>, dim3(st.nBlocks), dim3(64), 0, s, st, w); }
+    { KScope ks_("k_lz_i_pparse"); hipLaunchKernelGGL(k_lz_i_pparse, dim3(st.nBlocks), dim3(1024), 0, s, st, w, pw, st.bsVersion < 6 ? 1 : 0); }
+    { KScope ks_("k_lz_i_parse");                               // blocks the parallel parse has passed on (old layout, anything irregular)
+      if (st.bsVersion < 6) hipLaunchKernelGGL(k_lz_i_parse<true>, dim3(st.nBlocks), dim3(64), 0, s, st, w);
+      else hipLaunchKernelGGL(k_lz_i_parse<false>, dim3(st.nBlocks), dim3(64), 0, s, st, w); }
     const int wgPerBlock = 64;
-    { KScope ks_("k_lz_tile_first"); hipLaunchKernelGGL(k_lz_tile_first, dim3(st.nBlocks * wgPerBlock), dim3(256), 0, s, w, wgPerBlock); }
+    { KScope ks_("k_lz_i_first"); hipLaunchKernelGGL(k_lz_i_first, dim3(st.nBlocks * wgPerBlock), dim3(256), 0, s, w, wgPerBlock); }
     const dim3 grid((unsigned)((size_t)st.nBlocks * tilesPerBlock));
-    { KScope ks_("k_lz_expand"); hipLaunchKernelGGL(k_lz_expand, grid, dim3(256), 0, s, w, tilesPerBlock); }
-    { KScope ks_("k_lz_jump");
-      for (int r = 0; r < LZI_ROUNDS; r++) hipLaunchKernelGGL(k_lz_jump, grid, dim3(256), 0, s, w, tilesPerBlock, r); }
-    { KScope ks_("k_lz_emit"); hipLaunchKernelGGL(k_lz_emit, grid, dim3(256), 0, s, st, w, tilesPerBlock); }
+    { KScope ks_("k_lz_i_expand"); hipLaunchKernelGGL(k_lz_i_expand, grid, dim3(256), 0, s, w, tilesPerBlock); }
+    { KScope ks_("k_lz_i_jump");
+      for (int r = 0; r < LZI_ROUNDS; r++) hipLaunchKernelGGL(k_lz_i_jump, grid, dim3(256), 0, s, w, tilesPerBlock, r); }
+    { KScope ks_("k_lz_i_emit"); hipLaunchKernelGGL(k_lz_i_emit, grid, dim3(256), 0, s, st, w, tilesPerBlock); }
     { KScope ks_("k_lz_inverse");                               // blocks the parse left alone (none with a workspace sized by maxCap)
       if (st.bsVersion < 6) hipLaunchKernelGGL(k_lz_inverse<true>, dim3(st.nBlocks), dim3(64), 0, s, st, (const u32*)w.info);
       else hipLaunchKernelGGL(k_lz_inverse<false>, dim3(st.nBlocks), dim3(64), 0, s, st, (const u32*)w.info); }

@@ -20,7 +20,7 @@ void lz_inv(const knz::XfStage& st)
     for (int b = 0; b < st.nBlocks; b++) maxCap = std::max(maxCap, st.cap[b]);
     if (knz::lz_serial_decode(-1)) { knz::launch_lz_inverse(nullptr, st, nullptr, 0, 0); return; }
     const size_t bytes = knz::lz_inverse_scratch_bytes(st.nBlocks, maxCap);
-    g_lzInvScratch.assign(bytes + 512, 0xA5);
+    g_lzInvScratch.assign(bytes + 512, 0x7F);            // (stale entries must not look like finished ones)
     void* sc = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(g_lzInvScratch.data()) + 255) & ~(uintptr_t)255);
     knz::launch_lz_inverse(nullptr, st, sc, bytes, maxCap);
 }

@@ -300,11 +300,18 @@ def test_block_serial_transforms_emulated(tmp_path, name):
         # the token layout of bitstream versions below 6 (LZCodec.cpp:614-760), written by the oracle, read by k_lz_inverse<true>
         r = subprocess.run([exe, path, "5"], capture_output=True, text=True, timeout=1500)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-        # the decoder is two: the data-parallel one (k_lz_parse, k_lz_expand, k_lz_jump, k_lz_emit; the default, above) and the
+        # the decoder is two: the data-parallel one (k_lz_i_parse, k_lz_i_expand, k_lz_i_jump, k_lz_i_emit; the default, above) and the
         # one-wave-per-block k_lz_inverse it falls back to
         for ver in ([], ["5"]):
             r = subprocess.run([exe, path] + ver, capture_output=True, text=True, timeout=1500, env=dict(os.environ, KNZ_LZ_SERIAL_DECODE="1"))
             assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    if name == "lzx":
+        # a block whose sections span several tiles of the parallel parse (more than 4096 tokens, more than 8192 bytes of length
+        # extensions); no block may need the serial parse (the harness says so under KNZ_EMU_VERBOSE)
+        path3 = str(tmp_path / "xf3.bin")
+        write_case(path3, [c.text(520000, 3)])
+        r = subprocess.run([exe, path3], capture_output=True, text=True, timeout=1500, env=dict(os.environ, KNZ_EMU_VERBOSE="1"))
+        assert r.returncode == 0 and "k_lz_i_parse" not in r.stderr, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_huffman_encoder_and_bit_assembly_emulated(tmp_path):
