@@ -697,6 +697,16 @@ __global__ __launch_bounds__(64) void k_ans1_tables(BitSrc src, DecBlock* __rest
     }
 }
 
+// a store that is a global store whatever the compiler knows about the pointer (a flat store also counts as an LDS operation)
+__device__ __forceinline__ void st_global_u32(u8* p, u32 v)
+{
+#ifdef KNZ_EMU
+    *reinterpret_cast<u32*>(p) = v;
+#else
+    *reinterpret_cast<__attribute__((address_space(1))) u32*>(reinterpret_cast<uintptr_t>(p)) = v;
+#endif
+}
+
 constexpr u32 A1_RN = 1024;                  // ring items (16-bit)
 constexpr u32 A1_INTERVAL = 64;              // steps between ring checks (<= 4 items per step)
 
@@ -704,11 +714,14 @@ constexpr u32 A1_INTERVAL = 64;              // steps between ring checks (<= 4 
 // of the same quarter), all lanes keep the payload ring filled
 __global__ __launch_bounds__(64) void k_ans1_decode(BitSrc src, DecBlock* __restrict__ blocks, int chunksPerBlock, int maxChunks,
                                                     const AnsDecChunk* __restrict__ chunks, const u32* __restrict__ slotTab,
-                                                    u8* const* __restrict__ outPtr)
+                                                    u8* const* __restrict__ outPtr, int nBlocks)
 {
-    const int gc = blockIdx.x;
-    const int b = gc / chunksPerBlock;
-    const int ci = gc - b * chunksPerBlock;
+    // Workgroups go to the XCDs round robin, and a chunk's table (2 MiB) lives in the L2 of the XCD that decodes it. The first
+    // chunk of a block is a full one (4 MiB of symbols), the last one usually short: numbered block by block, the long chunks of
+    // blocks with two chunks would all meet on the even XCDs (four tables in a 4 MiB L2). Chunk index first spreads them.
+    const int ci = (int)blockIdx.x / nBlocks;
+    const int b = (int)blockIdx.x - ci * nBlocks;
+    const int gc = b * chunksPerBlock + ci;
     const int lane = lane_id();
     if (blocks[b].error) return;
     const AnsDecChunk* cs = chunks + (size_t)b * maxChunks + (size_t)ci * 257;
@@ -761,9 +774,14 @@ __global__ __launch_bounds__(64) void k_ans1_decode(BitSrc src, DecBlock* __rest
     const u32 higherMask = (0xFu << (j + 1)) & 0xFu;
     const u16* ring16 = reinterpret_cast<const u16*>(ring);
     u8* myDst = dst + (size_t)j * quarter;
-    const bool aligned4 = (reinterpret_cast<uintptr_t>(myDst) & 3) == 0;
     u32 prv = 0;
     u32 acc = 0;
+    // Output goes through LDS: a store inside the step loop sits in the same counter as the table load of the next step (and, being a
+    // flat store, in the LDS counter too), so every fourth step waited for a write to reach memory. 64 steps of the four states are
+    // staged (16 dwords each) and written by the whole wave between two stretches.
+    __shared__ u32 stage[4 * (A1_INTERVAL / 4)];
+    u8* const q0 = dst;
+    const bool alignedAll = ((reinterpret_cast<uintptr_t>(dst) | quarter) & 3) == 0;
     for (u32 s0 = 0; s0 < quarter; s0 += A1_INTERVAL) {
         // ring upkeep (uniform): once the consumer is in the upper half of what the ring holds, replace the lower half
         const u32 qu = uni(q);
@@ -773,8 +791,8 @@ __global__ __launch_bounds__(64) void k_ans1_decode(BitSrc src, DecBlock* __rest
             base += A1_RN / 2;
             __syncthreads();
         }
+        const u32 s1 = (s0 + A1_INTERVAL < quarter) ? s0 + A1_INTERVAL : quarter;
         if (lane < 4) {
-            const u32 s1 = (s0 + A1_INTERVAL < quarter) ? s0 + A1_INTERVAL : quarter;
             for (u32 s = s0; s < s1; s++) {
                 const u32 slotv = st & mask;
                 const u32 e = tab[prv * A1_SLOTS_PER_CTX + slotv];
@@ -789,13 +807,21 @@ __global__ __launch_bounds__(64) void k_ans1_decode(BitSrc src, DecBlock* __rest
                 q += __popc(m);
                 prv = sym;
                 acc |= sym << (8 * (s & 3));
-                if ((s & 3) == 3) {
-                    if (aligned4) *reinterpret_cast<u32*>(myDst + (s & ~3u)) = acc;
-                    else { myDst[s - 3] = (u8)acc; myDst[s - 2] = (u8)(acc >> 8); myDst[s - 1] = (u8)(acc >> 16); myDst[s] = (u8)(acc >> 24); }
-                    acc = 0;
-                }
+                if ((s & 3) == 3) { stage[j * (A1_INTERVAL / 4) + ((s - s0) >> 2)] = acc; acc = 0; }
             }
         }
+        __syncthreads();
+        {
+            const u32 full = (s1 - s0) >> 2;                          // whole dwords per state in this stretch
+            const u32 jj = (u32)lane >> 4, dw = (u32)lane & 15;
+            if (dw < full) {
+                const u32 v = stage[jj * (A1_INTERVAL / 4) + dw];
+                u8* o = q0 + (size_t)jj * quarter + s0 + 4 * dw;
+                if (alignedAll) st_global_u32(o, v);
+                else { o[0] = (u8)v; o[1] = (u8)(v >> 8); o[2] = (u8)(v >> 16); o[3] = (u8)(v >> 24); }
+            }
+        }
+        __syncthreads();
     }
     if (lane < 4) {
         const u32 rem = quarter & 3;
@@ -819,7 +845,7 @@ void launch_ans1_decode(hipStream_t s, BitSrc src, DecBlock* blocks, int nBlocks
     const int nCh = nBlocks * chunksPerBlock;
     { KScope ks_("k_ans1_scan"); hipLaunchKernelGGL(k_ans_scan<1>, dim3(nBlocks), dim3(64), 0, s, src, blocks, nBlocks, maxChunks, chunks); }
     { KScope ks_("k_ans1_tables"); hipLaunchKernelGGL(k_ans1_tables, dim3(nCh * 256), dim3(64), 0, s, src, blocks, chunksPerBlock, maxChunks, chunks, ws.slotTab); }
-    { KScope ks_("k_ans1_decode"); hipLaunchKernelGGL(k_ans1_decode, dim3(nCh), dim3(64), 0, s, src, blocks, chunksPerBlock, maxChunks, chunks, ws.slotTab, outPtr); }
+    { KScope ks_("k_ans1_decode"); hipLaunchKernelGGL(k_ans1_decode, dim3(nCh), dim3(64), 0, s, src, blocks, chunksPerBlock, maxChunks, chunks, ws.slotTab, outPtr, nBlocks); }
 }
 
 size_t ans0_dec_chunk_bytes() { return sizeof(AnsDecChunk); }

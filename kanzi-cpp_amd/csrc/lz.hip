@@ -1149,7 +1149,9 @@ __global__ __launch_bounds__(256) void k_lz_i_jump(LzInvWs w, int tilesPerBlock,
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             if (!(e[j] & LZI_ROOT)) {
-                const u32 v = Pb[e[j]];
+                u32 v = Pb[e[j]];                                   // up to three hops a round (the loads of a thread's eight
+                if (!(v & LZI_ROOT)) v = Pb[v];                     // entries overlap): the rounds go down from log2 to log4
+                if (!(v & LZI_ROOT)) v = Pb[v];                     // of the longest chain and more
                 e[j] = v; changed = true;
                 if (!(v & LZI_ROOT)) pend = true;
             }

@@ -24,8 +24,13 @@ cpif $SRC/pmc_calibration.txt ${P}_pmc_calibration.txt
 cpif $SRC/trace3_bwt_forward.txt ${P}_config3_bwt_forward_trace.txt
 cpif $SRC/limits.jsonl ${P}_config3_limits.jsonl
 cpif $SRC/issue_rates.txt ${P}_issue_rates.txt
-if [ -s $SRC/pmc3_traffic.json ]; then
-  python - "$SRC/pmc3_traffic.json" <<'PY'
+for f in $SRC/pmc*_traffic.txt; do
+  [ -s "$f" ] || continue
+  c=$(basename $f | sed 's/pmc\([0-9]*\)_traffic.txt/\1/'); [ "$c" = "3" ] || cpif $f ${P}_config${c}_pmc_traffic.txt
+done
+for f in $SRC/pmc*_traffic.json; do
+  [ -s "$f" ] || continue
+  python - "$f" <<'PY'
 import json, sys
 new = json.load(open(sys.argv[1]))
 try:
@@ -36,4 +41,4 @@ cur.update(new)
 json.dump(cur, open("profiles/pmc_traffic.json", "w"), indent=1, sort_keys=True)
 print("  profiles/pmc_traffic.json (%s)" % ", ".join(sorted(new)))
 PY
-fi
+done
