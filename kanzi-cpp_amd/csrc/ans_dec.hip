@@ -297,6 +297,16 @@ constexpr u32 RSTRIDE = RB / 4 + 2;  // ring words per chunk incl. 8 mirrored by
 constexpr u32 CHECK_STEPS = 8;       // <= 8 bytes consumed per step -> <= RQ per interval
 constexpr u32 SYM_STRIDE = 260;
 
+// a store that is a global store whatever the compiler knows about the pointer (a flat store also counts as an LDS operation)
+__device__ __forceinline__ void st_global_u32(u8* p, u32 v)
+{
+#ifdef KNZ_EMU
+    *reinterpret_cast<u32*>(p) = v;
+#else
+    *reinterpret_cast<__attribute__((address_space(1))) u32*>(reinterpret_cast<uintptr_t>(p)) = v;
+#endif
+}
+
 template <int K>
 __device__ __forceinline__ u32 quad_bcast(u32 v)
 {
@@ -541,7 +551,7 @@ __global__ __launch_bounds__(64) void k_ans0_decode(BitSrc src, DecBlock* __rest
     };
     auto put_word = [&](u32 word, u32 stepIdx) {
         if (stepIdx < steps) {
-            if (aligned4) reinterpret_cast<u32*>(dst)[stepIdx] = word;
+            if (aligned4) st_global_u32(dst + 4 * (size_t)stepIdx, word);
             else { dst[4 * stepIdx] = (u8)word; dst[4 * stepIdx + 1] = (u8)(word >> 8); dst[4 * stepIdx + 2] = (u8)(word >> 16); dst[4 * stepIdx + 3] = (u8)(word >> 24); }
         }
     };
@@ -695,16 +705,6 @@ __global__ __launch_bounds__(64) void k_ans1_tables(BitSrc src, DecBlock* __rest
         while (cumArr[sr + 1] <= t) sr++;        // cumArr[asz] = scale > t
         tab[t] = ent[sr];
     }
-}
-
-// a store that is a global store whatever the compiler knows about the pointer (a flat store also counts as an LDS operation)
-__device__ __forceinline__ void st_global_u32(u8* p, u32 v)
-{
-#ifdef KNZ_EMU
-    *reinterpret_cast<u32*>(p) = v;
-#else
-    *reinterpret_cast<__attribute__((address_space(1))) u32*>(reinterpret_cast<uintptr_t>(p)) = v;
-#endif
 }
 
 constexpr u32 A1_RN = 1024;                  // ring items (16-bit)

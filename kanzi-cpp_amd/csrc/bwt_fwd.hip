@@ -151,17 +151,7 @@ struct TextSrc {
     {
         const u8* t = src[sgm];
         const u32 pos = pos_of(n, i);
-        u64 v = 0;
-        if (pos + 12 <= n) {
-            // eight bytes from three aligned dwords
-            const uintptr_t a = reinterpret_cast<uintptr_t>(t + pos);
-            const u32* w = reinterpret_cast<const u32*>(a & ~(uintptr_t)3);
-            const u32 sh = (u32)(a & 3) * 8;
-            const u64 lo = (u64)w[0] | ((u64)w[1] << 32);
-            v = sh ? ((lo >> sh) | ((u64)w[2] << (64 - sh))) : lo;
-        } else {
-            for (u32 k = 0; k < 8; k++) if (pos + k < n) v |= (u64)t[pos + k] << (8 * k);
-        }
+        const u64 v = text8(t, pos, n);
         u64 kb = __builtin_bswap64(v) >> (64 - 8 * P);
         const u32 left = n - pos;
         if (left < (u32)P) kb &= ~0ull << (8 * ((u32)P - left));
@@ -172,7 +162,7 @@ struct TextSrc {
     __device__ __forceinline__ u32 digit_at(int sgm, u32, u32 n, u32 i) const
     {
         const u32 q = pos_of(n, i) + (u32)(P - 1);
-        return q < n ? (u32)src[sgm][q] : 0u;
+        return q < n ? (u32)ldg<u8>(src[sgm] + q) : 0u;
     }
 };
 
@@ -448,16 +438,7 @@ __global__ __launch_bounds__(256) void k_bwt_f_r0_place_text(BwtView bv, FwdView
             const u32 bb = v.base[blk], n = v.base[blk + 1] - bb;
             const u32 q = gp[k] - bb + (u32)nsym;
             const u8* t = bv.src[blk];
-            u64 x = 0;
-            if (q + 12 <= n) {
-                const uintptr_t ad = reinterpret_cast<uintptr_t>(t + q);
-                const u32* w = reinterpret_cast<const u32*>(ad & ~(uintptr_t)3);
-                const u32 sh = (u32)(ad & 3) * 8;
-                const u64 lo = (u64)w[0] | ((u64)w[1] << 32);
-                x = sh ? ((lo >> sh) | ((u64)w[2] << (64 - sh))) : lo;
-            } else {
-                for (u32 j = 0; j < 8; j++) if (q + j < n) x |= (u64)t[q + j] << (8 * j);
-            }
+            const u64 x = text8(t, q, n);
             sSA[i] = gp[k];
             sK[i] = __builtin_bswap64(x);
         }
@@ -643,16 +624,7 @@ __global__ __launch_bounds__(256) void k_bwt_f_sort_small_text(BwtView bv, FwdVi
         const u32 gp = v.SA[slot];
         const u32 q = gp - bb + off;
         const u8* t = bv.src[b];
-        u64 x = 0;
-        if (q + 12 <= n) {
-            const uintptr_t a = reinterpret_cast<uintptr_t>(t + q);
-            const u32* w = reinterpret_cast<const u32*>(a & ~(uintptr_t)3);
-            const u32 sh = (u32)(a & 3) * 8;
-            const u64 lo = (u64)w[0] | ((u64)w[1] << 32);
-            x = sh ? ((lo >> sh) | ((u64)w[2] << (64 - sh))) : lo;
-        } else {
-            for (u32 j = 0; j < 8; j++) if (q + j < n) x |= (u64)t[q + j] << (8 * j);
-        }
+        const u64 x = text8(t, q, n);
         sSA[i] = gp;
         sK[i] = __builtin_bswap64(x);
     }
@@ -829,7 +801,7 @@ __device__ __forceinline__ void med_radix_sort(MedLds<THREADS, ROWS>& L, u32 n, 
 // Write-back of a group sorted in LDS (oK = keys in order, oV = positions): subgroup boundaries, SA, labels, the round's bit map
 // and the children's descriptors. Entered and left with the workgroup in step.
 template <int THREADS, int ROWS>
-__device__ __noinline__ void med_write_back(MedLds<THREADS, ROWS>& L, const FwdView& v, u32 gs, u32 n, uint2* __restrict__ medNext, uint2* __restrict__ largeNext)
+__device__ __forceinline__ void med_write_back(MedLds<THREADS, ROWS>& L, const FwdView& v, u32 gs, u32 n, uint2* __restrict__ medNext, uint2* __restrict__ largeNext)
 {
     constexpr u32 CAP = (u32)ROWS * THREADS;
     const int tid = (int)threadIdx.x, lane = tid & 63;
@@ -1322,7 +1294,7 @@ __global__ __launch_bounds__(512, 4) void k_bwt_f_probe(BwtView bv, FwdView v, u
         if (!take) continue;                                  // (uniform) the group goes on as it is
         const u32 bb = sInfo[0], be = sInfo[1];
         const u8* t = bv.src[sInfo[3]];
-        for (u32 j = (u32)tid; j < P; j += THREADS) pat[j] = t[pr - bb + j];
+        for (u32 j = (u32)tid; j < P; j += THREADS) pat[j] = ldg<u8>(t + (pr - bb + j));
         if (tid == 0) sInfo[2] = v.ISA[pr];
         __syncthreads();
         // ---- every member against the pattern: where and how it differs
@@ -1337,9 +1309,9 @@ __global__ __launch_bounds__(512, 4) void k_bwt_f_probe(BwtView bv, FwdView v, u
                 const u32* pw = patw;
                 while (l + 16 <= P && q0 + l + 20 <= be - bb) {
                     const uintptr_t ad = reinterpret_cast<uintptr_t>(t + q0 + l);
-                    const u32* w = reinterpret_cast<const u32*>(ad & ~(uintptr_t)3);
+                    const u8* w = reinterpret_cast<const u8*>(ad & ~(uintptr_t)3);
                     const u32 sh = (u32)(ad & 3) * 8;
-                    const u32 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
+                    const u32 w0 = ldg<u32>(w), w1 = ldg<u32>(w + 4), w2 = ldg<u32>(w + 8), w3 = ldg<u32>(w + 12), w4 = ldg<u32>(w + 16);
                     const u32 x0 = sh ? ((w0 >> sh) | (w1 << (32 - sh))) : w0, x1 = sh ? ((w1 >> sh) | (w2 << (32 - sh))) : w1;
                     const u32 x2 = sh ? ((w2 >> sh) | (w3 << (32 - sh))) : w2, x3 = sh ? ((w3 >> sh) | (w4 << (32 - sh))) : w3;
                     const u32 d0 = x0 ^ pw[l >> 2], d1 = x1 ^ pw[(l >> 2) + 1], d2 = x2 ^ pw[(l >> 2) + 2], d3 = x3 ^ pw[(l >> 2) + 3];
@@ -1350,7 +1322,7 @@ __global__ __launch_bounds__(512, 4) void k_bwt_f_probe(BwtView bv, FwdView v, u
             u32 code = MID;
             while (l < P) {
                 if (q0 + l >= be - bb) { code = l * 512u; break; }                        // the suffix ends here: a proper prefix sorts first
-                const u32 x = t[q0 + l], y = pat[l];
+                const u32 x = ldg<u8>(t + q0 + l), y = pat[l];
                 if (x != y) { code = (x < y) ? (l * 512u + x + 1u) : (MID + 1u + (P - l) * 512u + x + 1u); break; }
                 l++;
             }

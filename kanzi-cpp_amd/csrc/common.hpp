@@ -62,6 +62,43 @@ __device__ __forceinline__ u32 bitlen_u32(u32 v) { return v == 0 ? 0u : (u32)(32
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
+// A pointer read from an array of pointers (block sources, destinations) is a "flat" pointer to the compiler: it cannot know that the
+// memory is global, every access becomes a flat_load / flat_store, and those count as LDS operations too -- a wait for an LDS read
+// then also waits for the memory access. ldg / stg access through the global address space explicitly.
+template <typename T>
+__device__ __forceinline__ T ldg(const void* p)
+{
+#ifdef KNZ_EMU
+    T v; __builtin_memcpy(&v, p, sizeof(T)); return v;
+#else
+    return *(const __attribute__((address_space(1))) T*)(uintptr_t)p;
+#endif
+}
+template <typename T>
+__device__ __forceinline__ void stg(void* p, T v)
+{
+#ifdef KNZ_EMU
+    __builtin_memcpy(p, &v, sizeof(T));
+#else
+    *(__attribute__((address_space(1))) T*)(uintptr_t)p = v;
+#endif
+}
+// eight bytes of a block's text from position q (little endian; bytes at or behind n read as zero), from three aligned dwords
+__device__ __forceinline__ u64 text8(const u8* t, u32 q, u32 n)
+{
+    u64 x = 0;
+    if (q + 12 <= n) {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(t + q);
+        const u8* w = reinterpret_cast<const u8*>(a & ~(uintptr_t)3);
+        const u32 sh = (u32)(a & 3) * 8;
+        const u64 lo = (u64)ldg<u32>(w) | ((u64)ldg<u32>(w + 4) << 32);
+        x = sh ? ((lo >> sh) | ((u64)ldg<u32>(w + 8) << (64 - sh))) : lo;
+    } else {
+        for (u32 j = 0; j < 8; j++) if (q + j < n) x |= (u64)ldg<u8>(t + q + j) << (8 * j);
+    }
+    return x;
+}
+
 // Where a kernel relies on a wave executing its memory operations in program order across lanes (lane 0 stores, every lane loads
 // right after), the CPU emulation of tests/emu -- whose lanes only meet at wave intrinsics -- needs a rendezvous; on the GPU it is nothing.
 #ifdef KNZ_EMU
