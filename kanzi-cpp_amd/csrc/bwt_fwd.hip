@@ -166,6 +166,54 @@ struct TextSrc {
     }
 };
 
+// Digit counts of all round-0 passes from ONE byte histogram per block: the digit of pass k of the suffix at pos is the text byte at
+// pos + o, o = P - 1 - k, or 0 behind the block's end, so its histogram is the block's byte histogram minus the first o bytes, plus o
+// zeros (prims::k_rs_hist_all would build every key to count its bytes). part = blockIdx.x of gridDim.x slices of the block.
+__global__ __launch_bounds__(256) void k_bwt_f_r0_hist(BwtView bv, const u32* __restrict__ base, int P, prims::RsLayout L)
+{
+    __shared__ u32 cnt[4][256];
+    const int sgm = blockIdx.y;
+    const u32 n = base[sgm + 1] - base[sgm];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int q = tid; q < 4 * 256; q += 256) (&cnt[0][0])[q] = 0;
+    __syncthreads();
+    const u8* t = bv.src[sgm];
+    const u32 per = ((n + gridDim.x - 1) / gridDim.x + 15u) & ~15u;
+    const u32 lo = blockIdx.x * per, hi = (lo + per < n) ? lo + per : n;
+    // 16 bytes per lane and step (the block's text is 16-byte aligned or the slow path below takes it)
+    const bool al = (reinterpret_cast<uintptr_t>(t) & 15) == 0;
+    for (u32 i0 = lo; i0 < hi; i0 += 16u * 256u) {                 // (uniform trip count: the row ballots want whole waves)
+        const u32 i = i0 + 16u * (u32)tid;
+        u32 wds[4] = { 0, 0, 0, 0 };
+        const u32 m = (i >= hi) ? 0u : ((hi - i < 16u) ? hi - i : 16u);
+        if (al && m == 16u) { wds[0] = ldg<u32>(t + i); wds[1] = ldg<u32>(t + i + 4); wds[2] = ldg<u32>(t + i + 8); wds[3] = ldg<u32>(t + i + 12); }
+        else for (u32 j = 0; j < m; j++) wds[j >> 2] |= (u32)ldg<u8>(t + i + j) << (8 * (j & 3));
+#pragma unroll
+        for (u32 j = 0; j < 16; j++) {
+            const bool valid = j < m;
+            const u32 dg = (wds[j >> 2] >> (8 * (j & 3))) & 255u;
+            const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)dg);
+            const unsigned long long va = __ballot(valid);
+            if (__ballot(valid && dg != d0) == 0) { if (lane == 0 && va) cnt[wave][d0] += (u32)__popcll(va); }
+            else if (valid) atomicAdd(&cnt[wave][dg], 1u);
+            KNZ_WAVE_ORDER();
+        }
+    }
+    __syncthreads();
+    const u32 c = cnt[0][tid] + cnt[1][tid] + cnt[2][tid] + cnt[3][tid];
+    for (int k = 0; k < P; k++) {
+        const u32 o = (u32)(P - 1 - k);
+        u32 v = c;
+        if (blockIdx.x == 0) {
+            const u32 oo = o < n ? o : n;
+            u32 cut = 0;
+            for (u32 j = 0; j < oo; j++) cut += ((u32)ldg<u8>(t + j) == (u32)tid) ? 1u : 0u;
+            v = v - cut + ((tid == 0) ? oo : 0u);                  // (this slice holds the block's first bytes: never underflows)
+        }
+        if (v) atomicAdd(&L.histAll[((size_t)k * L.nSeg + sgm) * 256 + tid], v);
+    }
+}
+
 // group-start flags of the sorted keys as a bit map (one ballot per wave): a slot starts a group when its key bytes differ from
 // its left neighbour's, when it is the first slot of a block, or when it or its left neighbour is a short suffix
 __global__ __launch_bounds__(256) void k_bwt_f_r0_flags(const u64* __restrict__ keys, const u32* __restrict__ base, int nBlocks, u32 total, int P, int pbits,
@@ -1901,6 +1949,7 @@ static FwdTuning& fwd_tuning()
 int bwt_forward_tune(const char* key, int value)
 {
     FwdTuning& t = fwd_tuning();
+    if (!strcmp(key, "rs_onesweep")) { prims::rs_onesweep_knob().store(value); return 0; }
     if (!strcmp(key, "bwt_nsym")) t.nsym = value;
     else if (!strcmp(key, "bwt_no_run_round")) t.noRunRound = value;
     else if (!strcmp(key, "bwt_run_fallback")) t.runFallback = value;
@@ -2023,14 +2072,25 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     prims::RsWs rs = prims::rs_carve(w.rsMem, maxTotal, st.nBlocks + 1, w.base, st.nBlocks);
     { KScope ks_("k_bwt_f_r0_layout"); prims::rs_launch_layout(s, rs); }
     u64* kin = w.keysA; u64* kout = w.keysB;
+    const bool oneRead = prims::rs_onesweep_knob().load() != 0 && nsym <= prims::RS_MAXPASS;
+    if (oneRead) {                                                // the digits of all passes counted from the text, once
+        KScope ks_("k_bwt_f_r0_sort");
+        TextSrc src; src.src = bv.src; src.P = nsym; src.pbits = pbits; src.shift = pbits;
+        (void)src;
+        hipMemsetAsync(rs.L.histAll, 0, (size_t)nsym * rs.L.nSeg * 1024, s);
+        hipLaunchKernelGGL(k_bwt_f_r0_hist, dim3(64, (unsigned)rs.L.nSeg), dim3(256), 0, s, bv, w.base, nsym, rs.L);
+        hipLaunchKernelGGL(prims::k_rs_digit_bases, dim3((unsigned)rs.L.nSeg, (unsigned)nsym), dim3(256), 0, s, rs.L);
+    }
     for (int pass = 0; pass < nsym; pass++) {
         KScope ks_("k_bwt_f_r0_sort");
         if (pass == 0) {
             TextSrc src; src.src = bv.src; src.P = nsym; src.pbits = pbits; src.shift = pbits;
-            prims::rs_launch_pass<u64, false>(s, rs, src, (const u32*)nullptr, kout, (u32*)nullptr, (size_t)bv.VS);
+            if (oneRead) prims::rs_launch_pass_os<u64, false>(s, rs, src, (const u32*)nullptr, kout, (u32*)nullptr, (size_t)bv.VS, pass);
+            else prims::rs_launch_pass<u64, false>(s, rs, src, (const u32*)nullptr, kout, (u32*)nullptr, (size_t)bv.VS);
         } else {
             prims::DigitOfKey<u64> src; src.keys = kin; src.shift = pbits + 8 * pass; src.mask = 255u;
-            prims::rs_launch_pass<u64, false>(s, rs, src, (const u32*)nullptr, kout, (u32*)nullptr, (size_t)bv.VS);
+            if (oneRead) prims::rs_launch_pass_os<u64, false>(s, rs, src, (const u32*)nullptr, kout, (u32*)nullptr, (size_t)bv.VS, pass);
+            else prims::rs_launch_pass<u64, false>(s, rs, src, (const u32*)nullptr, kout, (u32*)nullptr, (size_t)bv.VS);
         }
         std::swap(kin, kout);
     }

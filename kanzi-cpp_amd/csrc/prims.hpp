@@ -9,6 +9,9 @@
 // scanned in (digit, wave) order), staged through LDS in sorted order and written out as runs of consecutive addresses.
 #pragma once
 #include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
 #include "common.hpp"
 
 namespace knz {
@@ -173,6 +176,7 @@ constexpr int RS_WAVES = KNZ_RS_WAVES;    // waves per workgroup: each owns 16 r
 constexpr int RS_THREADS = 64 * RS_WAVES;
 constexpr u32 RS_TILE = 1024u * RS_WAVES; // keys per tile
 constexpr u32 RS_GROUP = 64;             // tiles per group of the column scan
+constexpr int RS_MAXPASS = 8;            // passes the one-read variant counts ahead
 
 // lanes of the wave whose (valid) 8-bit digit equals mine
 __device__ __forceinline__ unsigned long long digit_peers(bool valid, u32 dg)
@@ -196,6 +200,7 @@ struct RsLayout {
     u32* tileHist;       // [tiles][256]: counts, then exclusive inside the tile's group
     u32* grpSum;         // [groups][256]: group totals, then exclusive over the groups of the segment
     u32* digitBase;      // [nSeg][256]: output position of the first key with that digit (includes base[g])
+    u32* histAll;        // [RS_MAXPASS][nSeg][256]: one-read variant: digit counts of every pass, then the digits' first output positions
     int nSeg;
 };
 
@@ -370,6 +375,159 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(SRC src, const u32* _
     }
 }
 
+// ---- one read per pass ("onesweep") ----------------------------------------------------------------------------------------
+// The pass above reads its keys twice (tile histograms, then the scatter) because a tile has to know how many keys with each digit
+// sit in the tiles in front of it. Digit totals do not depend on the order of the keys, so ONE kernel counts the digits of all passes
+// of a sort from its input (k_rs_hist_all), and a tile learns the counts of its predecessors while it runs: it publishes its own
+// counts (per digit one word: 2 flag bits + 30 bits) as soon as it has ranked its keys, then walks back over the tiles before it,
+// adding their counts until it meets one that already knows its prefix (decoupled look-back: 256 threads, one digit each). A tile only
+// ever waits for tiles with a lower index, and tile t is workgroup t of its segment: the dispatcher starts workgroups in index order,
+// so whoever is waited for is running or done. Flag and count travel in one word, read and written with device-scope atomics (the
+// tiles in front of this one run on other XCDs).
+constexpr u32 RS_FLAG_AGG = 1u << 30, RS_FLAG_PRE = 2u << 30, RS_VAL_MASK = (1u << 30) - 1u;
+#ifdef KNZ_EMU
+__device__ __forceinline__ u32 rs_ld_dev(const u32* p) { return *p; }
+__device__ __forceinline__ void rs_st_dev(u32* p, u32 v) { *p = v; }
+#define RS_SPIN() do { fprintf(stderr, "k_rs_onesweep: a tile in front of this one has not run (workgroup order)\n"); abort(); } while (0)
+#else
+#define RS_SPIN() __builtin_amdgcn_s_sleep(1)
+__device__ __forceinline__ u32 rs_ld_dev(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void rs_st_dev(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
+
+// digit counts of passes 0 .. nPass-1 (digit of pass p = (key >> (shift0 + 8 p)) & 255, the last pass masked with lastMask)
+template <class KEY, class SRC>
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist_all(SRC src, RsLayout L, int shift0, int nPass, u32 lastMask)
+{
+    __shared__ u32 cnt[RS_MAXPASS][256];
+    const int sgm = blockIdx.y;
+    const u32 b0 = L.base[sgm], len = L.base[sgm + 1] - b0;
+    const u32 nT = (len + RS_TILE - 1) / RS_TILE;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int q = tid; q < RS_MAXPASS * 256; q += RS_THREADS) (&cnt[0][0])[q] = 0;
+    __syncthreads();
+    for (u32 t = blockIdx.x; t < nT; t += gridDim.x) {
+#pragma unroll 4
+        for (int r = 0; r < 16; r++) {
+            const u32 i = t * RS_TILE + (u32)wave * 1024u + (u32)r * 64u + (u32)lane;
+            const bool valid = i < len;
+            const KEY k = valid ? src.load(sgm, b0, len, i) : (KEY)0;
+            for (int ps = 0; ps < nPass; ps++) {
+                const u32 dg = (u32)(k >> (shift0 + 8 * ps)) & ((ps + 1 == nPass) ? lastMask : 255u);
+                const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)dg);
+                const unsigned long long va = __ballot(valid);
+                if (__ballot(valid && dg != d0) == 0) { if (lane == 0 && va) atomicAdd(&cnt[ps][d0], (u32)__popcll(va)); }
+                else if (valid) atomicAdd(&cnt[ps][dg], 1u);
+                KNZ_WAVE_ORDER();
+            }
+        }
+    }
+    __syncthreads();
+    for (int q = tid; q < nPass * 256; q += RS_THREADS) {
+        const u32 c = (&cnt[0][0])[q];
+        if (c) atomicAdd(&L.histAll[((size_t)(q >> 8) * L.nSeg + sgm) * 256 + (q & 255)], c);
+    }
+}
+
+// counts -> first output position of every digit (per pass and segment)
+static __global__ __launch_bounds__(256) void k_rs_digit_bases(RsLayout L)
+{
+    __shared__ u32 wsum[4];
+    __shared__ u32 inclAll[256];
+    const int sgm = blockIdx.x, ps = blockIdx.y;
+    const int tid = (int)threadIdx.x;
+    u32* h = L.histAll + ((size_t)ps * L.nSeg + sgm) * 256;
+    const u32 c = h[tid];
+    u32 tot;
+    const u32 incl = sc_block_incl<SCAN_SUM_EXCL>(c, wsum, &tot);
+    inclAll[tid] = incl;
+    __syncthreads();
+    h[tid] = L.base[sgm] + (tid ? inclAll[tid - 1] : 0u);
+}
+
+template <class KEY, bool HAS_VAL, class SRC>
+__global__ __launch_bounds__(RS_THREADS) void k_rs_onesweep(SRC src, const u32* __restrict__ vin, KEY* __restrict__ kout, u32* __restrict__ vout, RsLayout L, int pass)
+{
+    __shared__ u32 cnt[RS_WAVES][256];
+    __shared__ u32 dStart[256];
+    __shared__ u32 gBase[256];
+    __shared__ u32 wsum[RS_WAVES];
+    __shared__ u32 inclAll[256];
+    __shared__ KEY sK[RS_TILE];
+    __shared__ u32 sV[HAS_VAL ? RS_TILE : 1];
+    const int sgm = blockIdx.y;
+    const u32 b0 = L.base[sgm], len = L.base[sgm + 1] - b0;
+    const u32 nT = (len + RS_TILE - 1) / RS_TILE;
+    const u32 t = blockIdx.x;
+    if (t >= nT) return;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    KEY key[16]; u32 val[16]; u32 dg[16], pos[16]; bool valid[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const u32 i = t * RS_TILE + (u32)wave * 1024u + (u32)r * 64u + (u32)lane;
+        valid[r] = i < len;
+        key[r] = valid[r] ? src.load(sgm, b0, len, i) : (KEY)0;
+        if (HAS_VAL) val[r] = valid[r] ? vin[b0 + i] : 0u;
+        dg[r] = valid[r] ? src.digit(key[r]) : 0u;
+    }
+    // rs_rank_tile in two halves: the tile's digit counts are known after the first one and are published right away, so that the
+    // tiles behind this one find them when they look back; this tile looks back only after it has staged its keys
+    const unsigned long long ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int q = tid; q < RS_WAVES * 256; q += RS_THREADS) (&cnt[0][0])[q] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const unsigned long long peers = digit_peers(valid[r], dg[r]);
+        const int leader = __ffsll((long long)peers) - 1;
+        u32 old = 0;
+        if (valid[r] && lane == leader) { old = cnt[wave][dg[r]]; cnt[wave][dg[r]] = old + (u32)__popcll(peers); }
+        KNZ_WAVE_ORDER();
+        old = (u32)__shfl((int)old, leader < 0 ? 0 : leader, 64);
+        pos[r] = old + (u32)__popcll(peers & ltMask);
+    }
+    __syncthreads();
+    u32 c[RS_WAVES];
+    u32 mine = 0;
+    if (tid < 256) { for (int w = 0; w < RS_WAVES; w++) { c[w] = cnt[w][tid]; mine += c[w]; } }
+    u32* stat = L.tileHist + ((size_t)L.tileOff[sgm] + t) * 256 + (tid & 255);     // this tile's status word for digit tid
+    if (tid < 256) rs_st_dev(stat, (t == 0 ? RS_FLAG_PRE : RS_FLAG_AGG) | mine);
+    u32 tot;
+    const u32 incl = sc_block_incl<SCAN_SUM_EXCL, RS_WAVES>(mine, wsum, &tot);
+    if (tid < 256) inclAll[tid] = incl;
+    __syncthreads();
+    if (tid < 256) {
+        u32 run = tid ? inclAll[tid - 1] : 0u;
+        dStart[tid] = run;
+        for (int w = 0; w < RS_WAVES; w++) { cnt[w][tid] = run; run += c[w]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; r++) if (valid[r]) { pos[r] += cnt[wave][dg[r]]; sK[pos[r]] = key[r]; if (HAS_VAL) sV[pos[r]] = val[r]; }
+    const u32 cntTile = (len - t * RS_TILE < RS_TILE) ? len - t * RS_TILE : RS_TILE;
+    if (tid < 256) {
+        u32 excl = 0;
+        if (t != 0) {
+            for (u32 q = 1; q <= t; q++) {
+                u32 v;
+                while (((v = rs_ld_dev(stat - (size_t)q * 256)) >> 30) == 0) RS_SPIN();
+                excl += v & RS_VAL_MASK;
+                if (v & RS_FLAG_PRE) break;
+            }
+            rs_st_dev(stat, RS_FLAG_PRE | (excl + mine));
+        }
+        gBase[tid] = L.histAll[((size_t)pass * L.nSeg + sgm) * 256 + tid] + excl;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (u32 j = (u32)tid; j < cntTile; j += RS_THREADS) {
+        const KEY k = sK[j];
+        const u32 d = src.digit(k);
+        const u32 at = gBase[d] + (j - dStart[d]);
+        kout[at] = k;
+        if (HAS_VAL) vout[at] = sV[j];
+    }
+}
+
 static __global__ void k_rs_one_segment(u32* seg2, u32 n) { if (threadIdx.x == 0 && blockIdx.x == 0) { seg2[0] = 0; seg2[1] = n; } }
 
 struct RsWs { RsLayout L; size_t maxTiles; };
@@ -380,7 +538,7 @@ static inline size_t rs_align(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline size_t rs_ws_bytes(size_t maxN, int maxSeg)
 {
     const size_t tiles = maxN / RS_TILE + (size_t)maxSeg + 1, groups = tiles / RS_GROUP + (size_t)maxSeg + 1;
-    return rs_align(tiles * 1024) + rs_align(groups * 1024) + rs_align((size_t)maxSeg * 1024) + 2 * rs_align(4ull * (maxSeg + 1)) + 256;
+    return rs_align(tiles * 1024) + rs_align(groups * 1024) + rs_align((size_t)maxSeg * 1024) + 2 * rs_align(4ull * (maxSeg + 1)) + rs_align((size_t)RS_MAXPASS * maxSeg * 1024) + 256;
 }
 
 static inline RsWs rs_carve(void* p, size_t maxN, int maxSeg, const u32* base, int nSeg)
@@ -394,6 +552,7 @@ static inline RsWs rs_carve(void* p, size_t maxN, int maxSeg, const u32* base, i
     w.L.digitBase = reinterpret_cast<u32*>(q); q += rs_align((size_t)maxSeg * 1024);
     w.L.tileOff = reinterpret_cast<u32*>(q); q += rs_align(4ull * (maxSeg + 1));
     w.L.grpOff = reinterpret_cast<u32*>(q); q += rs_align(4ull * (maxSeg + 1));
+    w.L.histAll = reinterpret_cast<u32*>(q); q += rs_align((size_t)RS_MAXPASS * maxSeg * 1024);
     w.maxTiles = tiles;
     return w;
 }
@@ -421,14 +580,55 @@ static inline void rs_launch_pass(hipStream_t s, const RsWs& w, SRC src, const u
     hipLaunchKernelGGL((k_rs_scatter<KEY, HAS_VAL, SRC>), grid, dim3(RS_THREADS), 0, s, src, vin, kout, vout, w.L);
 }
 
+// knob "rs_onesweep" (KNZ_RS_ONESWEEP): 1 = the one-read passes where a sort's passes are known ahead (default), 0 = count + scatter
+static inline std::atomic<int>& rs_onesweep_knob()
+{
+    static std::atomic<int> v{ getenv("KNZ_RS_ONESWEEP") ? atoi(getenv("KNZ_RS_ONESWEEP")) : 1 };
+    return v;
+}
+
+// digit counts of all passes of a sort on bits [loBit, loBit + 8 nPass) (the last digit masked) from its input, and the digits' bases
+template <class KEY, class SRC>
+static inline void rs_launch_hist_all(hipStream_t s, const RsWs& w, SRC src, size_t maxSegLen, int loBit, int nPass, u32 lastMask)
+{
+    hipMemsetAsync(w.L.histAll, 0, (size_t)nPass * w.L.nSeg * 1024, s);
+    size_t gx = ((maxSegLen + RS_TILE - 1) / RS_TILE + 7) / 8;                      // eight tiles per workgroup: few global atomics
+    if (gx < 1) gx = 1;
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL((k_rs_hist_all<KEY, SRC>), dim3((unsigned)gx, (unsigned)w.L.nSeg), dim3(RS_THREADS), 0, s, src, w.L, loBit, nPass, lastMask);
+    hipLaunchKernelGGL(k_rs_digit_bases, dim3((unsigned)w.L.nSeg, (unsigned)nPass), dim3(256), 0, s, w.L);
+}
+
+// pass number `pass` of a sort whose digits rs_launch_hist_all has counted
+template <class KEY, bool HAS_VAL, class SRC>
+static inline void rs_launch_pass_os(hipStream_t s, const RsWs& w, SRC src, const u32* vin, KEY* kout, u32* vout, size_t maxSegLen, int pass)
+{
+    const size_t tiles = (maxSegLen + RS_TILE - 1) / RS_TILE;
+    const size_t used = std::min<size_t>(w.maxTiles, (tiles + 1) * (size_t)w.L.nSeg);     // status words of the tiles this sort has
+    hipMemsetAsync(w.L.tileHist, 0, used * 1024, s);
+#ifdef KNZ_EMU
+    hipemu::g_index_order_once = 1;
+#endif
+    hipLaunchKernelGGL((k_rs_onesweep<KEY, HAS_VAL, SRC>), dim3((unsigned)(tiles ? tiles : 1), (unsigned)w.L.nSeg), dim3(RS_THREADS), 0, s, src, vin, kout, vout, w.L, pass);
+}
+
 // Stable LSD sort on key bits [loBit, hiBit). Returns 0 when the result is in (ka, va), 1 when in (kb, vb).
 template <class KEY, bool HAS_VAL>
 static inline int rs_sort(hipStream_t s, const RsWs& w, KEY* ka, KEY* kb, u32* va, u32* vb, size_t maxSegLen, int loBit, int hiBit)
 {
     int cur = 0;
-    for (int sh = loBit; sh < hiBit; sh += 8) {
+    const int nPass = (hiBit - loBit + 7) / 8;
+    const bool os = rs_onesweep_knob().load() != 0 && nPass >= 1 && nPass <= RS_MAXPASS;
+    if (os) {
+        DigitOfKey<KEY> src; src.keys = ka; src.shift = loBit; src.mask = 255u;
+        const int rem = hiBit - loBit - 8 * (nPass - 1);
+        rs_launch_hist_all<KEY>(s, w, src, maxSegLen, loBit, nPass, rem >= 8 ? 255u : ((1u << rem) - 1u));
+    }
+    int pass = 0;
+    for (int sh = loBit; sh < hiBit; sh += 8, pass++) {
         DigitOfKey<KEY> src; src.keys = cur ? kb : ka; src.shift = sh; src.mask = (hiBit - sh >= 8) ? 255u : ((1u << (hiBit - sh)) - 1u);
-        rs_launch_pass<KEY, HAS_VAL>(s, w, src, cur ? vb : va, cur ? ka : kb, cur ? va : vb, maxSegLen);
+        if (os) rs_launch_pass_os<KEY, HAS_VAL>(s, w, src, cur ? vb : va, cur ? ka : kb, cur ? va : vb, maxSegLen, pass);
+        else rs_launch_pass<KEY, HAS_VAL>(s, w, src, cur ? vb : va, cur ? ka : kb, cur ? va : vb, maxSegLen);
         cur ^= 1;
     }
     return cur;
@@ -440,10 +640,19 @@ template <class KEY, bool HAS_VAL>
 static inline int rs_sort_keep(hipStream_t s, const RsWs& w, const KEY* kin, const u32* vin, KEY* kb, KEY* kc, u32* vb, u32* vc, size_t maxSegLen, int loBit, int hiBit)
 {
     int cur = -1;                                            // -1: input, 0: b, 1: c
-    for (int sh = loBit; sh < hiBit; sh += 8) {
+    const int nPass = (hiBit - loBit + 7) / 8;
+    const bool os = rs_onesweep_knob().load() != 0 && nPass >= 1 && nPass <= RS_MAXPASS;
+    if (os) {
+        DigitOfKey<KEY> src; src.keys = kin; src.shift = loBit; src.mask = 255u;
+        const int rem = hiBit - loBit - 8 * (nPass - 1);
+        rs_launch_hist_all<KEY>(s, w, src, maxSegLen, loBit, nPass, rem >= 8 ? 255u : ((1u << rem) - 1u));
+    }
+    int pass = 0;
+    for (int sh = loBit; sh < hiBit; sh += 8, pass++) {
         DigitOfKey<KEY> src; src.keys = cur < 0 ? kin : (cur ? kc : kb); src.shift = sh; src.mask = (hiBit - sh >= 8) ? 255u : ((1u << (hiBit - sh)) - 1u);
         const int nxt = cur < 0 ? 0 : (cur ^ 1);
-        rs_launch_pass<KEY, HAS_VAL>(s, w, src, cur < 0 ? vin : (cur ? vc : vb), nxt ? kc : kb, nxt ? vc : vb, maxSegLen);
+        if (os) rs_launch_pass_os<KEY, HAS_VAL>(s, w, src, cur < 0 ? vin : (cur ? vc : vb), nxt ? kc : kb, nxt ? vc : vb, maxSegLen, pass);
+        else rs_launch_pass<KEY, HAS_VAL>(s, w, src, cur < 0 ? vin : (cur ? vc : vb), nxt ? kc : kb, nxt ? vc : vb, maxSegLen);
         cur = nxt;
     }
     return cur < 0 ? 0 : cur;
