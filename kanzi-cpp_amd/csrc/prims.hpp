@@ -614,11 +614,11 @@ static inline void rs_launch_pass_os(hipStream_t s, const RsWs& w, SRC src, cons
 
 // Stable LSD sort on key bits [loBit, hiBit). Returns 0 when the result is in (ka, va), 1 when in (kb, vb).
 template <class KEY, bool HAS_VAL>
-static inline int rs_sort(hipStream_t s, const RsWs& w, KEY* ka, KEY* kb, u32* va, u32* vb, size_t maxSegLen, int loBit, int hiBit)
+static inline int rs_sort(hipStream_t s, const RsWs& w, KEY* ka, KEY* kb, u32* va, u32* vb, size_t maxSegLen, int loBit, int hiBit, bool oneRead = true)
 {
     int cur = 0;
     const int nPass = (hiBit - loBit + 7) / 8;
-    const bool os = rs_onesweep_knob().load() != 0 && nPass >= 1 && nPass <= RS_MAXPASS;
+    const bool os = oneRead && rs_onesweep_knob().load() != 0 && nPass >= 1 && nPass <= RS_MAXPASS;
     if (os) {
         DigitOfKey<KEY> src; src.keys = ka; src.shift = loBit; src.mask = 255u;
         const int rem = hiBit - loBit - 8 * (nPass - 1);
