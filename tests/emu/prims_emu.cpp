@@ -71,20 +71,22 @@ static int check_scan(std::mt19937_64& rng, size_t n, bool dev)
     return 0;
 }
 
-int main()
+int main(int argc, char** argv)
 {
     std::mt19937_64 rng(12345);
     int bad = 0;
-    const std::vector<std::vector<u32>> layouts = { {1}, {4096}, {4097}, {100, 0, 5000, 4096, 1}, {20000}, {70000}, {33000, 33001} };      // (more than 16 tiles: two levels of the column scan)
+    const bool quick = argc > 1 && argv[1][0] == 'q';        // a short form for the runs under other switches (the sorts only)
+    const std::vector<std::vector<u32>> layouts = quick ? std::vector<std::vector<u32>>{ {100, 0, 5000, 4096, 1}, {20000} }
+        : std::vector<std::vector<u32>>{ {1}, {4096}, {4097}, {100, 0, 5000, 4096, 1}, {20000}, {70000}, {33000, 33001} };      // (more than 16 tiles: two levels of the column scan)
     for (const auto& lay : layouts) {
-        for (int kind = 0; kind < 4; kind++) {
+        for (int kind = 0; kind < (quick ? 2 : 4); kind++) {
             bad += check_sort<u64, false>(rng, lay, 0, 64, kind);
             bad += check_sort<u64, true>(rng, lay, 3, 45, kind);
             bad += check_sort<u32, true>(rng, lay, 0, 21, kind);
             bad += check_sort<u32, false>(rng, lay, 8, 32, kind);
         }
     }
-    for (size_t n : { (size_t)1, (size_t)15, (size_t)16, (size_t)4095, (size_t)4096, (size_t)4097, (size_t)100000, (size_t)300000 })
+    if (!quick) for (size_t n : { (size_t)1, (size_t)15, (size_t)16, (size_t)4095, (size_t)4096, (size_t)4097, (size_t)100000, (size_t)300000 })
         for (int dev = 0; dev < 2; dev++) {
             bad += check_scan<prims::SCAN_SUM_EXCL>(rng, n, dev != 0);
             bad += check_scan<prims::SCAN_MAX_INCL>(rng, n, dev != 0);

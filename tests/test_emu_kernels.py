@@ -41,8 +41,8 @@ def test_device_primitives_emulated(tmp_path):
     exe = build("prims_emu", tmp_path)
     # the passes read their keys once (k_rs_hist_all + k_rs_onesweep: tiles learn their predecessors' counts by look-back; the launcher
     # asks the emulator for index order, as the hardware dispatches) or twice (k_rs_count + k_rs_scatter, KNZ_RS_ONESWEEP=0)
-    for env in ({}, {"HIPEMU_ORDER": "2"}, {"KNZ_RS_ONESWEEP": "0", "HIPEMU_ORDER": "2"}):
-        r = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+    for args, env in (([], {}), (["quick"], {"HIPEMU_ORDER": "2"}), (["quick"], {"KNZ_RS_ONESWEEP": "0", "HIPEMU_ORDER": "2"})):
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
         assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
@@ -312,7 +312,7 @@ def test_block_serial_transforms_emulated(tmp_path, name):
         # a block whose sections span several tiles of the parallel parse (more than 4096 tokens, more than 8192 bytes of length
         # extensions); no block may need the serial parse (the harness says so under KNZ_EMU_VERBOSE)
         path3 = str(tmp_path / "xf3.bin")
-        write_case(path3, [c.text(520000, 3)])
+        write_case(path3, [c.text(440000, 3)])
         r = subprocess.run([exe, path3], capture_output=True, text=True, timeout=1500, env=dict(os.environ, KNZ_EMU_VERBOSE="1"))
         assert r.returncode == 0 and "k_lz_i_parse" not in r.stderr, r.stdout[-2000:] + r.stderr[-2000:]
 
