@@ -166,14 +166,15 @@ struct TextSrc {
     }
 };
 
-// Digit counts of all round-0 passes from ONE byte histogram per block: the digit of pass k of the suffix at pos is the text byte at
-// pos + o, o = P - 1 - k, or 0 behind the block's end, so its histogram is the block's byte histogram minus the first o bytes, plus o
-// zeros (prims::k_rs_hist_all would build every key to count its bytes). part = blockIdx.x of gridDim.x slices of the block.
-__global__ __launch_bounds__(256) void k_bwt_f_r0_hist(BwtView bv, const u32* __restrict__ base, int P, prims::RsLayout L)
+// Byte histogram of every block (slices of a block by blockIdx.x, summed with atomics into byteHist[block][256], zeroed by the caller).
+// Two things are read off it: the key length of round 0 (k_bwt_f_choose_nsym) and the digit counts of all round-0 passes
+// (k_bwt_f_r0_counts; prims::k_rs_hist_all would build every key to count its bytes).
+__global__ __launch_bounds__(256) void k_bwt_f_bytehist(BwtView bv, const u32* __restrict__ base, u32* __restrict__ byteHist)
 {
     __shared__ u32 cnt[4][256];
     const int sgm = blockIdx.y;
     const u32 n = base[sgm + 1] - base[sgm];
+    if (n == 0) return;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int q = tid; q < 4 * 256; q += 256) (&cnt[0][0])[q] = 0;
     __syncthreads();
@@ -201,16 +202,48 @@ __global__ __launch_bounds__(256) void k_bwt_f_r0_hist(BwtView bv, const u32* __
     }
     __syncthreads();
     const u32 c = cnt[0][tid] + cnt[1][tid] + cnt[2][tid] + cnt[3][tid];
+    if (c) atomicAdd(&byteHist[(size_t)sgm * 256 + tid], c);
+}
+
+// Key length of round 0 from the order-0 entropy H of the batch: four symbols tell suffixes apart when 4 H bits reach the
+// log2(block length) bits a position has (the mixed stand-in: H = 6.8); text (H = 4.1), DNA (2.0) leave most suffixes in groups then,
+// and a fifth symbol in the keys is cheaper than the doubling rounds those groups cost (measured on 212 MB of text at 8 MiB blocks:
+// suffix sort 33.3 -> 29.6 ms; on the stand-in 27.1 -> 27.3). The host caps the answer by what fits the key beside the position.
+__global__ __launch_bounds__(256) void k_bwt_f_choose_nsym(const u32* __restrict__ byteHist, int nBlocks, const u32* __restrict__ longest, u32* __restrict__ out)
+{
+    __shared__ float part[256];
+    __shared__ unsigned long long tot[256];
+    const int tid = (int)threadIdx.x;
+    unsigned long long c = 0;
+    for (int b = 0; b < nBlocks; b++) c += byteHist[(size_t)b * 256 + tid];
+    tot[tid] = c;
+    __syncthreads();
+    unsigned long long all = 0;
+    for (int i = 0; i < 256; i++) all += tot[i];
+    part[tid] = (c && all) ? (float)((double)c / (double)all) * log2f((float)((double)all / (double)c)) : 0.0f;
+    __syncthreads();
+    if (tid == 0) {
+        float H = 0.0f;
+        for (int i = 0; i < 256; i++) H += part[i];
+        const u32 n = longest[0] > 1 ? longest[0] : 2;
+        out[0] = (4.0f * H < log2f((float)n)) ? 5u : 4u;
+    }
+}
+
+// digit counts of the P round-0 passes of a block: the digit of pass k of the suffix at pos is the text byte at pos + o, o = P - 1 - k,
+// or 0 behind the block's end, so its histogram is the block's byte histogram minus the block's first o bytes, plus o zeros
+__global__ __launch_bounds__(256) void k_bwt_f_r0_counts(BwtView bv, const u32* __restrict__ base, const u32* __restrict__ byteHist, int P, prims::RsLayout L)
+{
+    const int sgm = blockIdx.x, tid = (int)threadIdx.x;
+    const u32 n = base[sgm + 1] - base[sgm];
+    const u32 c = n ? byteHist[(size_t)sgm * 256 + tid] : 0u;
+    const u8* t = bv.src[sgm];
     for (int k = 0; k < P; k++) {
         const u32 o = (u32)(P - 1 - k);
-        u32 v = c;
-        if (blockIdx.x == 0) {
-            const u32 oo = o < n ? o : n;
-            u32 cut = 0;
-            for (u32 j = 0; j < oo; j++) cut += ((u32)ldg<u8>(t + j) == (u32)tid) ? 1u : 0u;
-            v = v - cut + ((tid == 0) ? oo : 0u);                  // (this slice holds the block's first bytes: never underflows)
-        }
-        if (v) atomicAdd(&L.histAll[((size_t)k * L.nSeg + sgm) * 256 + tid], v);
+        const u32 oo = o < n ? o : n;
+        u32 cut = 0;
+        for (u32 j = 0; j < oo; j++) cut += ((u32)ldg<u8>(t + j) == (u32)tid) ? 1u : 0u;
+        L.histAll[((size_t)k * L.nSeg + sgm) * 256 + tid] = c - cut + ((tid == 0) ? oo : 0u);
     }
 }
 
@@ -1975,6 +2008,7 @@ struct FwdScratch {
     u32* seg2;
     void* scanTmp;
     void* rsMem;
+    u32* byteHist;       // [nBlocks][256]
     // run round: class table, run-start bit map (+ counts, prefix), run tables
     u32* classTab; u32* rbits; u32* rcount; u32* rprefix;
     u32* runPos; u32* runE; u32* runL; u32* sE; u32* rcnt; u32* moff;
@@ -2010,6 +2044,7 @@ static size_t fwd_carve(u8* p, int nBlocks, size_t total, FwdScratch* w)
     w->loff = (u32*)take(4 * (maxMed + 1));
     w->base = (u32*)take(4ull * (nBlocks + 2));
     w->counters = (u32*)take(256);
+    w->byteHist = (u32*)take(1024ull * (nBlocks + 1));
     w->seg2 = (u32*)take(64);
     w->scanTmp = take(prims::scan_tmp_bytes(total + 16));
     w->rsMem = take(prims::rs_ws_bytes(total, nBlocks + 1));
@@ -2042,8 +2077,12 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     const FwdTuning tune = fwd_tuning();
     { KScope ks_("k_bwt_f_bases"); hipLaunchKernelGGL(k_bwt_bases, dim3(1), dim3(64), 0, s, bv, w.base, st.ok, w.counters + 32); }
     hipMemsetAsync(st.newLen, 0, sizeof(u32) * st.nBlocks, s);
+    { KScope ks_("k_bwt_f_r0_hist");                                // byte histograms: the key length of round 0, later its digit counts
+      hipMemsetAsync(w.byteHist, 0, 1024ull * st.nBlocks, s);
+      hipLaunchKernelGGL(k_bwt_f_bytehist, dim3(64, (unsigned)st.nBlocks), dim3(256), 0, s, bv, w.base, w.byteHist);
+      hipLaunchKernelGGL(k_bwt_f_choose_nsym, dim3(1), dim3(256), 0, s, w.byteHist, st.nBlocks, w.counters + 32, w.counters + 33); }
     if (hipMemcpyAsync(h_pinned, w.base + st.nBlocks, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
-    if (hipMemcpyAsync(h_pinned + 1, w.counters + 32, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+    if (hipMemcpyAsync(h_pinned + 1, w.counters + 32, 8, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
     if (hipStreamSynchronize(s) != hipSuccess) return -1;
     const u32 total = h_pinned[0];
     if (total == 0) return 0;
@@ -2062,11 +2101,14 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     // one stable LSD pass per symbol, the first one reads the text, the blocks are the segments of the sort.
     int pbits = 1;
     while ((1ull << pbits) < (u64)h_pinned[1]) pbits++;           // positions inside the longest block the transform applies to
-    // Four symbols (as many as fit the key beside the position when the block is larger than 16 MiB). Measured on 212 MB with 8 MiB
-    // blocks, MB/s of the whole round trip: 4 symbols 4437 (mixed stand-in) / 3859 (text); 5 symbols with h = 5, 10, ...: 4243 / 4155;
-    // 5 symbols with h = 4, 8, ...: 4319 / 3970 -- text likes the deeper first round, periodic data the power-of-two offsets.
+    // Four or five symbols (as many as fit the key beside the position when the block is larger than 8 / 16 MiB), by the batch's order-0
+    // entropy (k_bwt_f_choose_nsym). Measured on 212 MB with 8 MiB blocks, MB/s of the whole round trip, round 3: 4 symbols 4437 (mixed
+    // stand-in) / 3859 (text); 5 symbols with h = 5, 10, ...: 4243 / 4155; 5 symbols with h = 4, 8, ...: 4319 / 3970. Round 4 (the
+    // doubling offsets stay 4, 8, ...): 4 symbols 5034 / 4314, 5 symbols 4961 / 4564 -- text likes the deeper first round, the stand-in
+    // (periodic and sparse stretches, noise) gains nothing from it and pays the fifth pass.
     const int fit = (64 - pbits) / 8;
-    int nsym = fit < 4 ? fit : 4;
+    const int want = (h_pinned[2] == 5u) ? 5 : 4;                   // (k_bwt_f_choose_nsym: the batch's order-0 entropy)
+    int nsym = fit < want ? fit : want;
     if (tune.nsym >= 1) nsym = tune.nsym < fit ? tune.nsym : fit;   // tuning knob: other round-0 key lengths
     if (nsym < 1) return -4;
     prims::RsWs rs = prims::rs_carve(w.rsMem, maxTotal, st.nBlocks + 1, w.base, st.nBlocks);
@@ -2077,8 +2119,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
         KScope ks_("k_bwt_f_r0_sort");
         TextSrc src; src.src = bv.src; src.P = nsym; src.pbits = pbits; src.shift = pbits;
         (void)src;
-        hipMemsetAsync(rs.L.histAll, 0, (size_t)nsym * rs.L.nSeg * 1024, s);
-        hipLaunchKernelGGL(k_bwt_f_r0_hist, dim3(64, (unsigned)rs.L.nSeg), dim3(256), 0, s, bv, w.base, nsym, rs.L);
+        hipLaunchKernelGGL(k_bwt_f_r0_counts, dim3((unsigned)rs.L.nSeg), dim3(256), 0, s, bv, w.base, w.byteHist, nsym, rs.L);
         hipLaunchKernelGGL(prims::k_rs_digit_bases, dim3((unsigned)rs.L.nSeg, (unsigned)nsym), dim3(256), 0, s, rs.L);
     }
     for (int pass = 0; pass < nsym; pass++) {
