@@ -1,6 +1,7 @@
 """Randomised CPU fuzz of the emulated stage kernels (tests/emu/*_emu.cpp): MTFT, ZRLT, ANS0, ANS1 and Huffman in both directions, SRT,
 RLT -- random blocks made of text, noise, runs, periodic and sparse pieces, checked against the oracle by the harnesses themselves
-(developer tool).   usage: emu_fuzz_stages.py SEED SECONDS"""
+(developer tool).   usage: emu_fuzz_stages.py SEED SECONDS [harness,harness,...]   e.g. lz_emu,lzx_emu for the LZ kernels (both block
+layouts: the harness is run with and without the old-layout argument)"""
 import os, subprocess, sys, tempfile, time, pathlib
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import numpy as np
@@ -11,6 +12,7 @@ budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
 rng = np.random.default_rng(seed)
 tmp = pathlib.Path(tempfile.mkdtemp())
 names = ["mtft_emu", "zrlt_emu", "ans0_emu", "ans0_enc_emu", "ans1_emu", "ans1_enc_emu", "huff_emu", "huff_enc_emu", "srt_emu", "rlt_emu"]
+if len(sys.argv) > 3: names = sys.argv[3].split(",")
 exes = {n: T.build(n, tmp) for n in names}
 c = knzlib.corpus()
 
@@ -42,7 +44,8 @@ while time.time() - t0 < budget:
     path = str(tmp / "case.bin")
     T.write_case(path, blocks)
     for n in names:
-        p = subprocess.run([exes[n], path], capture_output=True, text=True, timeout=1800, env=dict(os.environ, HIPEMU_ORDER=str(int(rng.integers(0, 3)))))
+        extra = ["5"] if n in ("lz_emu", "lzx_emu") and int(rng.integers(0, 3)) == 0 else []
+        p = subprocess.run([exes[n], path] + extra, capture_output=True, text=True, timeout=1800, env=dict(os.environ, HIPEMU_ORDER=str(int(rng.integers(0, 3)))))
         if p.returncode != 0:
             keep = "/tmp/emu_fuzz_stage_fail_%d_%d.bin" % (seed, cases)
             os.replace(path, keep)
