@@ -381,14 +381,14 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(SRC src, const u32* _
 // of a sort from its input (k_rs_hist_all), and a tile learns the counts of its predecessors while it runs: it publishes its own
 // counts (per digit one word: 2 flag bits + 30 bits) as soon as it has ranked its keys, then walks back over the tiles before it,
 // adding their counts until it meets one that already knows its prefix (decoupled look-back: 256 threads, one digit each). A tile only
-// ever waits for tiles with a lower index, and tile t is workgroup t of its segment: the dispatcher starts workgroups in index order,
-// so whoever is waited for is running or done. Flag and count travel in one word, read and written with device-scope atomics (the
+// ever waits for tiles with a lower index, and tiles are handed out by a ticket counter as workgroups start, so whoever is waited for
+// is running or done. Flag and count travel in one word, read and written with device-scope atomics (the
 // tiles in front of this one run on other XCDs).
 constexpr u32 RS_FLAG_AGG = 1u << 30, RS_FLAG_PRE = 2u << 30, RS_VAL_MASK = (1u << 30) - 1u;
 #ifdef KNZ_EMU
 __device__ __forceinline__ u32 rs_ld_dev(const u32* p) { return *p; }
 __device__ __forceinline__ void rs_st_dev(u32* p, u32 v) { *p = v; }
-#define RS_SPIN() do { fprintf(stderr, "k_rs_onesweep: a tile in front of this one has not run (workgroup order)\n"); abort(); } while (0)
+#define RS_SPIN() do { fprintf(stderr, "k_rs_onesweep: a tile in front of this one has not run\n"); abort(); } while (0)
 #else
 #define RS_SPIN() __builtin_amdgcn_s_sleep(1)
 __device__ __forceinline__ u32 rs_ld_dev(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -455,12 +455,18 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_onesweep(SRC src, const u32* 
     __shared__ u32 inclAll[256];
     __shared__ KEY sK[RS_TILE];
     __shared__ u32 sV[HAS_VAL ? RS_TILE : 1];
+    __shared__ u32 sTicket;
     const int sgm = blockIdx.y;
     const u32 b0 = L.base[sgm], len = L.base[sgm + 1] - b0;
     const u32 nT = (len + RS_TILE - 1) / RS_TILE;
-    const u32 t = blockIdx.x;
-    if (t >= nT) return;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // The tile is not blockIdx.x but a ticket drawn when the workgroup starts: a tile then only ever waits for tiles whose workgroups
+    // started before its own -- they are running or done -- whatever order the dispatcher, several queues or several XCDs start
+    // workgroups in.
+    if (tid == 0) sTicket = atomicAdd(&L.grpSum[sgm], 1u);
+    __syncthreads();
+    const u32 t = sTicket;
+    if (t >= nT) return;
     KEY key[16]; u32 val[16]; u32 dg[16], pos[16]; bool valid[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) {
@@ -606,9 +612,7 @@ static inline void rs_launch_pass_os(hipStream_t s, const RsWs& w, SRC src, cons
     const size_t tiles = (maxSegLen + RS_TILE - 1) / RS_TILE;
     const size_t used = std::min<size_t>(w.maxTiles, (tiles + 1) * (size_t)w.L.nSeg);     // status words of the tiles this sort has
     hipMemsetAsync(w.L.tileHist, 0, used * 1024, s);
-#ifdef KNZ_EMU
-    hipemu::g_index_order_once = 1;
-#endif
+    hipMemsetAsync(w.L.grpSum, 0, 4ull * (size_t)w.L.nSeg, s);                           // the segments' ticket counters
     hipLaunchKernelGGL((k_rs_onesweep<KEY, HAS_VAL, SRC>), dim3((unsigned)(tiles ? tiles : 1), (unsigned)w.L.nSeg), dim3(RS_THREADS), 0, s, src, vin, kout, vout, w.L, pass);
 }
 

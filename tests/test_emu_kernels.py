@@ -39,8 +39,8 @@ def test_device_primitives_emulated(tmp_path):
     std::stable_sort / plain loops: u32 and u64 keys, with and without values, partial digits, empty / tiny / ragged segments,
     constant and low-entropy digits (the one-digit fast path of the counting kernel), sizes from device memory."""
     exe = build("prims_emu", tmp_path)
-    # the passes read their keys once (k_rs_hist_all + k_rs_onesweep: tiles learn their predecessors' counts by look-back; the launcher
-    # asks the emulator for index order, as the hardware dispatches) or twice (k_rs_count + k_rs_scatter, KNZ_RS_ONESWEEP=0)
+    # the passes read their keys once (k_rs_hist_all + k_rs_onesweep: tiles learn their predecessors' counts by look-back; tiles are handed
+    # out by a ticket counter, so any workgroup order will do -- HIPEMU_ORDER=2 is a permutation) or twice (k_rs_count + k_rs_scatter, KNZ_RS_ONESWEEP=0)
     for args, env in (([], {}), (["quick"], {"HIPEMU_ORDER": "2"}), (["quick"], {"KNZ_RS_ONESWEEP": "0", "HIPEMU_ORDER": "2"})):
         r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
         assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
