@@ -39,15 +39,31 @@ struct XfView {
     const u32* cap;
 };
 
+// count of trailing zeros of a value that is never 0 (no select for the empty case: the chain is bound by the scalar unit)
+#define MTF_CTZ64(x) __builtin_ctzll((unsigned long long)(x))
+#define MTF_CTZ32(x) __builtin_ctz((unsigned)(x))
+
+// (a & m) | (b & ~m) with a uniform m: one v_bfi instead of a scalar complement and two vector operations
+__device__ __forceinline__ u32 mtf_bfi(u32 m, u32 a, u32 b)
+{
+#ifdef KNZ_EMU
+    return (a & m) | (b & ~m);
+#else
+    u32 r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(m), "v"(a), "v"(b));
+    return r;
+#endif
+}
+
 // rotate list positions [0, rank] right by one and put `front` at position 0.
 // w: my 4 entries (position 4*lane in byte 0). rank = 4*lane0 + byteIdx (uniform).
-__device__ __forceinline__ u32 mtf_rotate(u32 w, int lane, int lane0, int byteIdx, u32 front)
+__device__ __forceinline__ u32 mtf_rotate(u32 w, int lane, int lane0, u32 mask, u32 front)
 {
     // lane i takes lane i-1's entries, lane 0 the new front symbol (the `old` operand of the DPP move); then one funnel shift
     const u32 prev = (u32)__builtin_amdgcn_update_dpp((int)(front << 24), (int)w, 0x138, 0xF, 0xF, false);   // wave_shr:1
     const u32 shifted = __builtin_amdgcn_alignbit(w, prev, 24);                  // (w << 8) | (prev >> 24)
-    const u32 mask = (byteIdx == 3) ? 0xFFFFFFFFu : ((1u << (8 * (byteIdx + 1))) - 1u);      // uniform
-    const u32 merged = (shifted & mask) | (w & ~mask);
+    // mask (uniform): the bytes of lane0's word up to and including the symbol's old place
+    const u32 merged = mtf_bfi(mask, shifted, w);
     const u32 upTo = (lane == lane0) ? merged : w;
     return (lane < lane0) ? shifted : upTo;
 }
@@ -143,22 +159,24 @@ __global__ __launch_bounds__(64) void k_mtf_f_rank(XfView v, int perTiles, const
     u8* dst = d + tbase;
     const bool al = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 3) == 0;
     // four input bytes (uniform) -> four ranks
+    u32 front4 = front * 0x01010101u;           // (kept beside `front`: the chain is bound by the scalar unit, every instruction counts)
     auto rank4 = [&](u32 in4) -> u32 {
         u32 out4 = 0;
-        if (in4 != front * 0x01010101u) {       // runs (the common case after a BWT) keep the list unchanged: rank 0
+        if (in4 != front4) {                    // runs (the common case after a BWT) keep the list unchanged: rank 0
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const u32 c = (in4 >> (8 * q)) & 0xFF;
                 if (c == front) continue;
                 front = c;
-                const u32 x = w ^ (c * 0x01010101u);
+                front4 = c * 0x01010101u;
+                const u32 x = w ^ front4;
                 const u32 hz = (x - 0x01010101u) & ~x & 0x80808080u;
-                const u64 m = __ballot(hz != 0);
-                const int lane0 = __ffsll((long long)m) - 1;
+                const u64 m = __ballot(hz != 0);                        // (never 0: the list holds every symbol)
+                const int lane0 = MTF_CTZ64(m);
                 const u32 hz0 = (u32)__builtin_amdgcn_readlane((int)hz, lane0);
-                const int byteIdx = (__ffs((int)hz0) - 1) >> 3;
+                const int byteIdx = MTF_CTZ32(hz0) >> 3;
                 out4 |= (u32)(4 * lane0 + byteIdx) << (8 * q);
-                w = mtf_rotate(w, lane, lane0, byteIdx, c);
+                w = mtf_rotate(w, lane, lane0, ((hz0 & (0u - hz0)) << 1) - 1u, c);
             }
         }
         return out4;
@@ -201,11 +219,11 @@ __global__ __launch_bounds__(64) void k_mtf_f_rank(XfView v, int perTiles, const
         const u32 x = w ^ (c * 0x01010101u);
         const u32 hz = (x - 0x01010101u) & ~x & 0x80808080u;
         const u64 m = __ballot(hz != 0);
-        const int lane0 = __ffsll((long long)m) - 1;
+        const int lane0 = MTF_CTZ64(m);
         const u32 hz0 = (u32)__builtin_amdgcn_readlane((int)hz, lane0);
-        const int byteIdx = (__ffs((int)hz0) - 1) >> 3;
+        const int byteIdx = MTF_CTZ32(hz0) >> 3;
         if (lane == 0) dst[k] = (u8)(4 * lane0 + byteIdx);
-        w = mtf_rotate(w, lane, lane0, byteIdx, c);
+        w = mtf_rotate(w, lane, lane0, ((hz0 & (0u - hz0)) << 1) - 1u, c);
     }
 }
 
@@ -239,7 +257,7 @@ __global__ __launch_bounds__(64) void k_mtf_i_symbolic(XfView v, int perTiles, u
                 const u32 c = (wl >> (8 * byteIdx)) & 0xFF;
                 out4 |= c << (8 * q);
                 front = c;
-                w = mtf_rotate(w, lane, lane0, byteIdx, c);
+                w = mtf_rotate(w, lane, lane0, (u32)((1ull << (8 * (byteIdx + 1))) - 1ull), c);
             }
         }
         return out4;
@@ -282,7 +300,7 @@ __global__ __launch_bounds__(64) void k_mtf_i_symbolic(XfView v, int perTiles, u
         const u32 c = (wl >> (8 * byteIdx)) & 0xFF;
         if (lane == 0) dst[k] = (u8)c;
         front = c;
-        w = mtf_rotate(w, lane, lane0, byteIdx, c);
+        w = mtf_rotate(w, lane, lane0, (u32)((1ull << (8 * (byteIdx + 1))) - 1ull), c);
     }
     reinterpret_cast<u32*>(tilePerm + ((size_t)b * perTiles + blockIdx.x) * 256)[lane] = w;
 }
