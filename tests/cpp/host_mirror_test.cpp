@@ -168,6 +168,79 @@ static void testStreams()
     }
 }
 
+// TEXT and UTF run on the host in front of the device chain (levels 5 and 6 of the reference's CLI, app/BlockCompressor.cpp:583-591):
+// the two classes by themselves (src/test/TestTransforms.cpp's round trips) and through the stream classes
+static void testHostStages()
+{
+    std::vector<byte> text;
+    {
+        const char* words[] = { "the", "quick", "brown", "fox", "jumps", "over", "lazy", "dog", "compression", "transform", "entropy", "block" };
+        unsigned x = 99;
+        while (text.size() < 300000) {
+            x = x * 1664525u + 1013904223u;
+            const char* wd = words[(x >> 24) % 12];
+            text.insert(text.end(), reinterpret_cast<const byte*>(wd), reinterpret_cast<const byte*>(wd) + strlen(wd));
+            text.push_back(byte(((x >> 20) & 15) == 0 ? '\n' : ' '));
+        }
+    }
+    std::vector<byte> utf;
+    {
+        const char* units[] = { "\xC3\xA9", "\xE2\x82\xAC", "\xD0\x96", "a", "b", " ", "\xF0\x9F\x98\x80", "\xC3\xBC", "\xE4\xB8\xAD" };
+        unsigned x = 7;
+        while (utf.size() < 120000) { x = x * 1664525u + 1013904223u; const char* u = units[(x >> 24) % 9]; utf.insert(utf.end(), reinterpret_cast<const byte*>(u), reinterpret_cast<const byte*>(u) + strlen(u)); }
+    }
+    for (const char* ent : { "ANS0", "FPAQ" }) {                              // (the entropy codec picks the TEXT encoding: top-bit or escape-byte indexes)
+        Context ctx;
+        ctx.putInt("bsVersion", 6);
+        ctx.putString("entropy", ent);
+        ctx.putInt("blockSize", 1 << 20);
+        TextCodec f(ctx), g(ctx);
+        std::vector<byte> a(text), b(text.size() + 64), c(text.size() + 64);
+        SliceArray<byte> sa1(a.data(), int(a.size()), 0), sa2(b.data(), int(b.size()), 0), sa3(c.data(), int(c.size()), 0);
+        CHECK(f.forward(sa1, sa2, int(text.size())));
+        const int enc = sa2._index;
+        CHECK(enc < int(text.size()));                                        // words become dictionary indexes
+        sa2._index = 0;
+        CHECK(g.inverse(sa2, sa3, enc));
+        CHECK(sa3._index == int(text.size()) && memcmp(c.data(), text.data(), text.size()) == 0);
+    }
+    {
+        Context ctx;
+        ctx.putInt("bsVersion", 6);
+        UTFCodec f(ctx), g(ctx);
+        std::vector<byte> a(utf), b(size_t(f.getMaxEncodedLength(int(utf.size()))) + 64), c(utf.size() + 64);
+        SliceArray<byte> sa1(a.data(), int(a.size()), 0), sa2(b.data(), int(b.size()), 0), sa3(c.data(), int(c.size()), 0);
+        CHECK(f.forward(sa1, sa2, int(utf.size())));
+        const int enc = sa2._index;
+        sa2._index = 0;
+        CHECK(g.inverse(sa2, sa3, enc));
+        CHECK(sa3._index == int(utf.size()) && memcmp(c.data(), utf.data(), utf.size()) == 0);
+        // not UTF-8: the codec declines (UTFCodec.cpp: validation of the first bytes)
+        std::vector<byte> rnd = gen(0, 50000, 5), o(60000);
+        SliceArray<byte> r1(rnd.data(), int(rnd.size()), 0), r2(o.data(), int(o.size()), 0);
+        UTFCodec h(ctx);
+        CHECK(!h.forward(r1, r2, int(rnd.size())));
+    }
+    // the two published levels as stream parameters: host stages in front of the device chain, one block per device call
+    struct Cfg { const char* t; const char* e; int bs; } cfgs[] = { { "TEXT+UTF+BWT+RANK+ZRLT", "ANS0", 262144 }, { "TEXT+UTF+BWT+SRT+ZRLT", "FPAQ", 262144 }, { "TEXT", "HUFFMAN", 65536 } };
+    for (const Cfg& cf : cfgs) {
+        for (const std::vector<byte>* in : { &text, &utf }) {
+            std::stringstream ss;
+            {
+                CompressedOutputStream cos(ss, 2, cf.e, cf.t, cf.bs);
+                cos.write(reinterpret_cast<const char*>(in->data()), std::streamsize(in->size()));
+                cos.close();
+            }
+            std::vector<byte> out(in->size() + 16);
+            CompressedInputStream cis(ss, 2);
+            cis.read(reinterpret_cast<char*>(out.data()), std::streamsize(out.size()));
+            CHECK(size_t(cis.gcount()) == in->size());
+            CHECK(memcmp(out.data(), in->data(), in->size()) == 0);
+            cis.close();
+        }
+    }
+}
+
 static void testSeek()
 {
     // io/CompressedInputStream.hpp:329-384: block boundaries are the only valid positions; tell() hands them out
@@ -351,6 +424,7 @@ int main(int argc, char** argv)
         if (what == "all" || what == "transforms") testTransforms();
         if (what == "all" || what == "entropy") testEntropy();
         if (what == "all" || what == "streams") testStreams();
+        if (what == "all" || what == "hoststages") testHostStages();
         if (what == "all" || what == "seek") testSeek();
         if (what == "all" || what == "range") testBlockRange();
         if (what == "all" || what == "pipeline") testPipeline();
