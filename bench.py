@@ -9,11 +9,14 @@ A "step" = one pass of the hot path over the corpus resident in HBM: encode ever
 bit stream (device buffer -> device buffer) and decode that stream back (device -> device).
 value = corpus bytes / (t_enc + t_dec) in MB/s (MB = 1e6 B).
 
-Multi-GPU (--gpus N, one process per GPU under torch.distributed.run): the blocks of the ONE corpus are
-sharded over the ranks in contiguous ranges (kanzi-cpp_amd/sharded.py:block_ranges); every rank
-encodes and decodes its own range, there is no collective in the data path (only the timing barrier and the MAX
-all-reduce of the elapsed time). That is strong scaling: 26 blocks over 8 GPUs is 4,4,3,3,3,3,3,3, so the best
-possible speed-up is 6.5x. `--scaling weak` gives every rank the whole corpus instead.
+Multi-GPU (--gpus N, one process per GPU under torch.distributed.run): blocks are independent, so a job is sharded over
+the ranks by block index (kanzi-cpp_amd/sharded.py:block_ranges); every rank encodes and decodes its own
+blocks, there is no collective in the data path (only the timing barrier and the MAX all-reduce of the elapsed time).
+The line's `value` is WEAK scaling, as the rule for paths that partition asks: the job grows with N -- N corpora, rank r
+takes the r-th one (26 blocks each at config 3) -- and value = N * corpus bytes / MAX-over-ranks time. The same run then
+also times the ONE corpus sharded over the N ranks (strong scaling: 26 blocks over 8 GPUs is 4,4,3,3,3,3,3,3, so the
+best possible speed-up is 6.5x) and reports it as `one_corpus_sharded` in the same line, with that ceiling.
+`--scaling strong` makes the sharded corpus the line's value instead (and the N corpora the extra object).
 
     python bench.py                      # N=1, config 3
     python bench.py --config 2           # -t NONE -e ANS0 -b 4m
@@ -220,7 +223,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=3)
-    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="weak")
     ap.add_argument("--limit", type=int, default=0, help="use only the first LIMIT bytes of the corpus")
     ap.add_argument("--cpu-sample", type=int, default=256 << 20, help="bytes of the workload the CPU reference is timed on (the whole silesia corpus fits)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -332,6 +335,55 @@ def main():
     else:
         comp_total = comp_bytes
 
+    # ---- N > 1: the other way of giving N ranks work, timed the same way (every rank takes part: barrier and MAX reduce inside)
+    other = None
+    if world > 1:
+        omode = "strong" if args.scaling == "weak" else "weak"
+        fb2, c2 = sharded.block_ranges(n_total, bs, world)[rank] if omode == "strong" else (0, nblocks_total)
+        lo2, hi2 = fb2 * bs, min(n_total, (fb2 + c2) * bs)
+        n2 = max(hi2 - lo2, 0)
+        d_in2 = torch.empty(n2 + 64, dtype=torch.uint8, device=dev)
+        if n2:
+            d_in2[:n2].copy_(torch.from_numpy(np.frombuffer(data, dtype=np.uint8, count=n2, offset=lo2).copy()))
+        cap2 = ctx.encode_bound(p, n2)
+        d_enc2 = torch.zeros(cap2, dtype=torch.uint8, device=dev)
+        d_dec2 = torch.empty(n2 + bs + 64, dtype=torch.uint8, device=dev)
+        hdr2, hdr_bits2 = framing.make_header(p.entropy_type, p.transform_type, bs, 0, n_total) if fb2 == 0 else (b"", 0)
+        fin2 = 1 if (fb2 + c2 == nblocks_total) else 0
+        st2 = {"bits": 0, "out": 0}
+
+        def step2():
+            if c2:
+                st2["bits"] = ctx.encode_blocks(p, d_in2.data_ptr(), n2, d_enc2.data_ptr(), cap2, prologue=hdr2, prologue_bits=hdr_bits2,
+                                                first_block=fb2, finish=fin2)
+                st2["out"] = ctx.decode_blocks(p, d_enc2.data_ptr(), st2["bits"], hdr_bits2, d_dec2.data_ptr(), n2 + bs, max_blocks=max(c2, 1))[0]
+
+        for _ in range(args.warmup):
+            step2()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        a2 = time.perf_counter()
+        for _ in range(args.steps):
+            step2()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        e2 = time.perf_counter() - a2
+        t = torch.tensor([e2], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        e2 = float(t.item())
+        if c2:
+            assert st2["out"] == n2 and torch.equal(d_dec2[:n2], d_in2[:n2]), "round trip mismatch (second measurement)"
+        most = max(c for _, c in sharded.block_ranges(n_total, bs, world))
+        job2 = n_total if omode == "strong" else world * n_total
+        other = {"scaling": omode, "value": round(job2 / (e2 / args.steps) / 1e6, 2), "unit": "MB/s", "ms_per_step": round(e2 / args.steps * 1e3, 4),
+                 "steps": args.steps, "bytes_rank0": n2, "blocks_rank0": c2}
+        if omode == "strong":
+            other["block_count_ceiling"] = round(nblocks_total / most, 3) if most else None
+            other["blocks_largest_share"] = most
+        del d_in2, d_enc2, d_dec2
+
     result = None
     if rank == 0:
         # ---- separate encode / decode timing + per-kernel HIP-event timing (same stream), rank 0's share
@@ -432,7 +484,7 @@ def main():
                        "bytes_rank0": n, "blocks_rank0": cnt,
                        "parallelism": ("1 GPU" if world == 1 else
                                        "blocks of one corpus sharded over %d ranks in contiguous ranges, no collective" % world if args.scaling == "strong"
-                                       else "%d replicas of the corpus, no collective" % world)},
+                                       else "a job of %d corpora sharded by block index: rank r takes the r-th corpus (%d blocks), no collective" % (world, nblocks_total))},
             "enc_MBps": round(n / t_enc / 1e6, 2), "dec_MBps": round(n / t_dec / 1e6, 2),
             "bit_exact_vs_reference": bit_exact,
             "roofline": roofline,
@@ -445,6 +497,8 @@ def main():
             most = max(c for _, c in sharded.block_ranges(n_total, bs, world))
             result["config"]["block_count_ceiling"] = round(nblocks_total / most, 3) if most else None
             result["config"]["blocks_largest_share"] = most
+        if other is not None:
+            result["one_corpus_sharded" if other["scaling"] == "strong" else "n_corpora"] = other
         print(json.dumps(result))
     if world > 1:
         dist.barrier()
