@@ -57,10 +57,23 @@ __device__ __forceinline__ u32 mtf_bfi(u32 m, u32 a, u32 b)
 
 // rotate list positions [0, rank] right by one and put `front` at position 0.
 // w: my 4 entries (position 4*lane in byte 0). rank = 4*lane0 + byteIdx (uniform).
-__device__ __forceinline__ u32 mtf_rotate(u32 w, int lane, int lane0, u32 mask, u32 front)
+// v << 24 on the vector unit although v is uniform (the scalar unit is the busy one in these chains)
+__device__ __forceinline__ u32 mtf_top(u32 v)
+{
+#ifdef KNZ_EMU
+    return v << 24;
+#else
+    u32 r;
+    asm("v_lshlrev_b32 %0, 24, %1" : "=v"(r) : "s"(v));
+    return r;
+#endif
+}
+
+// frontTop: any word with the new front symbol in its top byte
+__device__ __forceinline__ u32 mtf_rotate(u32 w, int lane, int lane0, u32 mask, u32 frontTop)
 {
     // lane i takes lane i-1's entries, lane 0 the new front symbol (the `old` operand of the DPP move); then one funnel shift
-    const u32 prev = (u32)__builtin_amdgcn_update_dpp((int)(front << 24), (int)w, 0x138, 0xF, 0xF, false);   // wave_shr:1
+    const u32 prev = (u32)__builtin_amdgcn_update_dpp((int)frontTop, (int)w, 0x138, 0xF, 0xF, false);   // wave_shr:1
     const u32 shifted = __builtin_amdgcn_alignbit(w, prev, 24);                  // (w << 8) | (prev >> 24)
     // mask (uniform): the bytes of lane0's word up to and including the symbol's old place
     const u32 merged = mtf_bfi(mask, shifted, w);
@@ -176,7 +189,7 @@ __global__ __launch_bounds__(64) void k_mtf_f_rank(XfView v, int perTiles, const
                 const u32 hz0 = (u32)__builtin_amdgcn_readlane((int)hz, lane0);
                 const int byteIdx = MTF_CTZ32(hz0) >> 3;
                 out4 |= (u32)(4 * lane0 + byteIdx) << (8 * q);
-                w = mtf_rotate(w, lane, lane0, ((hz0 & (0u - hz0)) << 1) - 1u, c);
+                w = mtf_rotate(w, lane, lane0, ((hz0 & (0u - hz0)) << 1) - 1u, front4);
             }
         }
         return out4;
@@ -223,7 +236,7 @@ __global__ __launch_bounds__(64) void k_mtf_f_rank(XfView v, int perTiles, const
         const u32 hz0 = (u32)__builtin_amdgcn_readlane((int)hz, lane0);
         const int byteIdx = MTF_CTZ32(hz0) >> 3;
         if (lane == 0) dst[k] = (u8)(4 * lane0 + byteIdx);
-        w = mtf_rotate(w, lane, lane0, ((hz0 & (0u - hz0)) << 1) - 1u, c);
+        w = mtf_rotate(w, lane, lane0, ((hz0 & (0u - hz0)) << 1) - 1u, c << 24);
     }
 }
 
@@ -253,11 +266,11 @@ __global__ __launch_bounds__(64) void k_mtf_i_symbolic(XfView v, int perTiles, u
                 if (r == 0) { out4 |= front << (8 * q); continue; }
                 const int lane0 = (int)(r >> 2);
                 const int byteIdx = (int)(r & 3);
-                const u32 wl = (u32)__builtin_amdgcn_readlane((int)w, lane0);
-                const u32 c = (wl >> (8 * byteIdx)) & 0xFF;
+                // (the byte is cut out on the vector unit, in every lane, before lane0's copy is read: two scalar instructions less)
+                const u32 c = (u32)__builtin_amdgcn_readlane((int)((w >> (8 * byteIdx)) & 0xFFu), lane0);
                 out4 |= c << (8 * q);
                 front = c;
-                w = mtf_rotate(w, lane, lane0, (u32)((1ull << (8 * (byteIdx + 1))) - 1ull), c);
+                w = mtf_rotate(w, lane, lane0, (u32)((1ull << (8 * (byteIdx + 1))) - 1ull), mtf_top(c));
             }
         }
         return out4;
@@ -300,7 +313,7 @@ __global__ __launch_bounds__(64) void k_mtf_i_symbolic(XfView v, int perTiles, u
         const u32 c = (wl >> (8 * byteIdx)) & 0xFF;
         if (lane == 0) dst[k] = (u8)c;
         front = c;
-        w = mtf_rotate(w, lane, lane0, (u32)((1ull << (8 * (byteIdx + 1))) - 1ull), c);
+        w = mtf_rotate(w, lane, lane0, (u32)((1ull << (8 * (byteIdx + 1))) - 1ull), c << 24);
     }
     reinterpret_cast<u32*>(tilePerm + ((size_t)b * perTiles + blockIdx.x) * 256)[lane] = w;
 }
