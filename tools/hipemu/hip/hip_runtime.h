@@ -67,7 +67,6 @@ void block_barrier();
 void wave_exchange(unsigned long long v, unsigned long long out[64], unsigned long long* activeMask);
 // the same rendezvous for a wave that polls memory written by another wave of its block: the other waves run before it returns
 void wave_spin();
-extern int g_index_order_once;          // 1: the next launch runs its workgroups in index order whatever HIPEMU_ORDER says
 // a rendezvous of the named lanes only (wave intrinsics inside divergent control flow)
 void wave_exchange_subset(unsigned long long v, unsigned long long out[64], unsigned long long lanes);
 

@@ -32,7 +32,6 @@ namespace hipemu {
 static const size_t STACK = 256 << 10;
 static Block g_blk;
 static std::vector<char*> g_stacks;
-int g_index_order_once = 0;
 
 // per-wave rendezvous state
 struct WaveX {
@@ -206,11 +205,7 @@ void launch(const std::function<void()>& body, dim3 grid, dim3 block)
     g_blk.bDim = block; g_blk.gDim = grid;
     // HIPEMU_ORDER: 0 = workgroups in index order, 1 = reverse, 2 = a fixed pseudo-random permutation. HIP promises no
     // dispatch order; running a test under several orders exposes kernels that depend on one.
-    static const int orderEnv = getenv("HIPEMU_ORDER") ? atoi(getenv("HIPEMU_ORDER")) : 0;
-    // (a kernel whose workgroups wait for workgroups with a lower index -- decoupled look-back -- counts on the dispatcher starting
-    // them in index order, which the hardware does; its launcher asks for that here, for one launch)
-    const int order = g_index_order_once ? 0 : orderEnv;
-    g_index_order_once = 0;
+    static const int order = getenv("HIPEMU_ORDER") ? atoi(getenv("HIPEMU_ORDER")) : 0;
     const size_t nb = (size_t)grid.x * grid.y * grid.z;
     std::vector<size_t> seq(nb);
     for (size_t i = 0; i < nb; i++) seq[i] = (order == 1) ? nb - 1 - i : i;
