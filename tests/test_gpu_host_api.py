@@ -311,3 +311,33 @@ def test_cli_levels_5_and_6_write_and_read_the_reference_files(tmp_path):
         assert len(enc) == r["out"]["len"] and hashlib.md5(enc).hexdigest() == r["out"]["md5"], (r["level"], r["input"], len(enc))
         p = subprocess.run([cli, "-d", "-i", out, "-o", back, "-f"], capture_output=True, text=True)
         assert p.returncode == 0 and open(back, "rb").read() == d, (r, p.stderr)
+
+
+def test_bench_line_contract(tmp_path):
+    """bench.py's one JSON line on a small slice of the headline workload: the keys the driver reads, the roofline and cpu_baseline
+    objects, the bit-exact flag; and the N-rank path (two ranks on this one GPU over gloo): weak scaling in `value`, the one sharded
+    corpus beside it with its block-count ceiling."""
+    import json
+    import sys
+    root = knzlib.ROOT
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "1", "--limit", str(16 << 20), "--no-e2e",
+                        "--cpu-sample", str(16 << 20)], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["unit"] == "MB/s" and d["dtype"] == "u8" and d["value"] > 0
+    assert d["bit_exact_vs_reference"] is True
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1 and rf["achieved"] > 0 and "traffic" in rf
+    assert d["cpu_baseline"]["kind"] == "reference" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29631",
+                        os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--dist-backend", "gloo", "--share-device",
+                        "--limit", str(32 << 20)], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    d = json.loads([x for x in r.stdout.strip().splitlines() if x.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["blocks_rank0"] == 4
+    o = d["one_corpus_sharded"]
+    assert o["scaling"] == "strong" and o["blocks_rank0"] == 2 and o["block_count_ceiling"] == 2.0 and o["value"] > 0

@@ -38,7 +38,7 @@ def test_host_layer_against_stub_device(tmp_path):
     lib, exe, cli = build_stub(tmp_path)
     env = dict(os.environ, KNZ_TEST_KANZI_LIB=lib, KNZ_TEST_HOST_MIRROR_EXE=exe, KNZ_TEST_DEVICES="0,1", KNZ_TEST_CLI=cli)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_host_api.py"), "-m", "gpu", "-x", "-q",
-                        "-p", "no:cacheprovider", "-k", "not threads_share_the_device"], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+                        "-p", "no:cacheprovider", "-k", "not threads_share_the_device and not bench_line_contract"], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
 
