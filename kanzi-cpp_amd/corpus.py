@@ -14,6 +14,8 @@ and mozilla have), used by the parity tests at full block size and by `bench.py 
   periodic(N, seed, p)   -- a random unit of p bytes repeated (p = 3, 5, 7: periods no power of two divides)
   fibword(N)             -- the Fibonacci word over {a, b} (every prefix doubling round keeps groups alive)
   dna(N, seed)           -- random ACGT with ~25 % copied spans
+  records(N, seed, r, k) -- rows of r bytes, each a copy of the row before with r - k bytes redrawn (a database table)
+  gradient(N, seed, w)   -- rows of w samples of a slow ramp with two bits of noise (an image plane)
 """
 import os
 
@@ -184,6 +186,35 @@ def fibword(n):
 def dna(n, seed):
     a = np.frombuffer(b"ACGT", dtype=np.uint8)[(_sm(seed ^ 0xD7A, n) >> np.uint64(33)) % np.uint64(4)].copy()
     return _copy_spans(a, seed + 1, 0.25, 256, 32768, 4 << 20, b"ACGT").tobytes()
+
+
+def records(n, seed, rec, keep):
+    """A table: rows of `rec` bytes, every row a copy of the one before with rec - keep of its bytes redrawn (which columns change
+    is drawn per row) -- the fixed-length records of a database dump: a period that is no power of two, matches that break at
+    different columns."""
+    rows = (n + rec - 1) // rec
+    r = _sm(seed ^ 0x7AB1E, rows * (rec - keep + 1) + rec)
+    out = np.empty((rows, rec), dtype=np.uint8)
+    cur = (r[:rec] % np.uint64(64) + np.uint64(32)).astype(np.uint8)
+    k = rec
+    for i in range(rows):
+        d = r[k:k + rec - keep + 1]
+        k += rec - keep + 1
+        start = int(d[0] % np.uint64(rec))
+        cols = (start + np.arange(rec - keep) * 7) % rec
+        cur = cur.copy()
+        cur[cols] = (d[1:] % np.uint64(64) + np.uint64(32)).astype(np.uint8)
+        out[i] = cur
+    return out.reshape(-1)[:n].tobytes()
+
+
+def gradient(n, seed, width):
+    """An image: rows of `width` samples of a slow ramp in x and y with two bits of noise (the smooth planes of a medical image or a
+    scan: long near-matches one row back, at a distance that is no power of two)."""
+    i = np.arange(n, dtype=np.int64)
+    x, y = i % width, i // width
+    noise = (_sm(seed ^ 0x6AAD, n) >> np.uint64(40)) & np.uint64(3)
+    return (((x * 3 + y * 5) >> 2) + noise.astype(np.int64) & 255).astype(np.uint8).tobytes()
 
 
 _REAL = {"silesia": "silesia.tar", "enwik9": "enwik9", "enwik8": "enwik8"}

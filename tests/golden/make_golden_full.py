@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generates tests/golden/golden_full.json: md5 + length of the UNMODIFIED reference's .knz (oracle/_ref) for the
 BASELINE.json configurations at their own block sizes (vectors.FULL_CASES), 64 MiB inputs, -j 1, and for the long-common-prefix
-inputs of vectors.HARD_CASES at 8 MiB / 32 MiB blocks.
+inputs of vectors.HARD_CASES at 8 MiB / 32 MiB blocks (copies, periods, DNA; table- and image-shaped blocks).
 
     make -C oracle ref && python tests/golden/make_golden_full.py
 

@@ -90,7 +90,7 @@ def test_bwt_forward_long_common_prefixes_emulated(tmp_path):
     """The shapes of tests/vectors.HARD_CASES at emulator size: copies with edits, X || X, periods 3 / 5 / 7 (large groups all the way),
     period 700 and 520 in medium groups (k_bwt_f_probe: one doubling round instead of ~16), ramps of period 256 and 64 (chain round),
     the Fibonacci word, DNA with repeats, sparse values in zero runs and runs of random lengths (groups the run round leaves tied look
-    behind their run)."""
+    behind their run), fixed-length records and an image plane."""
     exe = build("bwt_fwd_emu", tmp_path)
     c = knzlib.corpus()
     rng = np.random.default_rng(5)
@@ -109,6 +109,7 @@ def test_bwt_forward_long_common_prefixes_emulated(tmp_path):
         [ramp(80000, 256) + c.text(3000, 1) + ramp(70000, 256, 7), ramp(30000, 64) + c.text(500, 2) + ramp(20000, 64, 3)],
         [c.fibword(60000), c.dna(100000, 4)],
         [bytes(z), bytes(runs[:100000])],
+        [c.records(60000, 11, 24, 20), c.records(60000, 12, 100, 93), c.gradient(80000, 13, 1000)],      # a table, an image plane
     ]
     for i, blocks in enumerate(cases):
         path = str(tmp_path / ("hard%d.bin" % i))

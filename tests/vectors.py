@@ -59,6 +59,10 @@ def make(spec):
         return c.fibword(spec[1])
     if kind == "dna":
         return c.dna(spec[1], spec[2])
+    if kind == "records":             # rows of spec[3] bytes, spec[4] of them kept from the row before
+        return c.records(spec[1], spec[2], spec[3], spec[4])
+    if kind == "gradient":            # image rows of spec[3] samples
+        return c.gradient(spec[1], spec[2], spec[3])
     if kind == "utf8":                # code points of one, two, three and four bytes, skewed: what the UTF transform takes
         rng = np.random.default_rng(spec[2])
         cps = [int(x) for x in rng.integers(0x80, 0x7FF, 60)] + [int(x) for x in rng.integers(0x800, 0xD7FF, 40)] + [0x1F600, 0x10348, 0x20AC] + list(range(97, 123)) * 2 + [32] * 12 + [10]
@@ -149,6 +153,10 @@ HARD_CASES = [
     ("hard:dna", ("dna", 16 << 20, 4), "BWT+MTFT+ZRLT", "ANS0", 8 << 20),
     ("hard:const", ("const", 8 << 20, 65), "BWT+MTFT+ZRLT", "ANS0", 8 << 20),
     ("hard:repeats_srt", ("repeats", 32 << 20, 5), "BWT+SRT+ZRLT", "ANS0", 32 << 20),
+    # shapes of silesia members that are no text: fixed-length records (osdb), an image plane (mr, x-ray)
+    ("hard:records24", ("records", 8 << 20, 11, 24, 20), "BWT+MTFT+ZRLT", "ANS0", 8 << 20),
+    ("hard:records100", ("records", 8 << 20, 12, 100, 93), "BWT+MTFT+ZRLT", "ANS0", 8 << 20),
+    ("hard:gradient", ("gradient", 8 << 20, 13, 1000), "BWT+MTFT+ZRLT", "ANS0", 8 << 20),
     # config 4's chain on four blocks of its own size: block ids 2 and 3 of a 32 MiB stream (slot model i % jobs, first_block_id)
     ("config4:4blocks", ("text", 128 << 20, 1), "BWT+SRT+ZRLT", "FPAQ", 32 << 20),
 ]
