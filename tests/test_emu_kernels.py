@@ -81,6 +81,8 @@ def test_bwt_forward_kernels_emulated(tmp_path):
         # handed back to the ordinary lists (the path taken when a batch has more run groups than the sort key has index bits),
         # without the "look behind the run" offsets of the groups the run round leaves tied, without the periodic-stretch probe, and
         # with round-0 placement and text round as two kernels
+        if i in (0, 6):                      # (the switches below on the cases with runs, periods and tiny blocks; the two text cases keep the default path)
+            continue
         for var in ("KNZ_BWT_NO_RUN_ROUND", "KNZ_BWT_RUN_FALLBACK", "KNZ_BWT_NO_RUN_OFFSETS", "KNZ_BWT_NO_PROBE", "KNZ_BWT_NO_TEXT_ROUND"):
             r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900, env=dict(os.environ, **{var: "2" if var == "KNZ_BWT_NO_TEXT_ROUND" else "1"}))
             assert r.returncode == 0, (i, var, r.stdout[-2000:] + r.stderr[-2000:])
