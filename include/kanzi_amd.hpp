@@ -10,8 +10,13 @@
 //   Default{Output,Input}BitStream src/bitstream/DefaultOutputBitStream.hpp, DefaultInputBitStream.hpp
 //   TransformFactory / Sequence   src/transform/TransformFactory.hpp:49-137,208-308, TransformSequence.hpp:88-265
 //   Entropy{En,De}coderFactory    src/entropy/EntropyEncoderFactory.hpp:37-175, EntropyDecoderFactory.hpp
-//   CompressedOutputStream        src/io/CompressedOutputStream.hpp:140-172
-//   CompressedInputStream         src/io/CompressedInputStream.hpp:180-230
+//   CompressedOutputStream        src/io/CompressedOutputStream.hpp:140-172 (both constructors incl. the ThreadPool*
+//                                 positional of the concurrent build, listeners, flush/tellp/seekp :228-243)
+//   CompressedInputStream         src/io/CompressedInputStream.hpp:180-230 (same; tellg/seekg/putback/unget :306-327)
+//   Listener<T> / Event           src/Listener.hpp:24-32, src/Event.hpp:29-100 (accepted and kept; the device path raises no
+//                                 per-block events -- SURVEY.md marks listeners out of scope)
+//   ThreadPool                    src/concurrent.hpp (opaque here: accepted where the reference takes one, never used --
+//                                 the device is the pool)
 // Every forward/inverse/encode/decode call runs on the GPU through the C ABI in knz_hip.h
 // (libknz_hip.so). There is no CPU implementation behind these classes: without a GPU the
 // constructors throw.
@@ -90,6 +95,40 @@ public:
 private:
     std::map<std::string, int64> _ints;
     std::map<std::string, std::string> _strs;
+};
+
+// src/concurrent.hpp: the reference's stream constructors take a thread pool for their per-block tasks. Here the blocks of a batch
+// run on the device, so the type only has to exist for the call forms of src/api/Compressor.cpp:230-237 and
+// Decompressor.cpp:159-166 (positional nullptr) to compile; a non-null pool is accepted and ignored.
+class ThreadPool;
+
+// src/Listener.hpp:24-32
+template <class T>
+class Listener {
+public:
+    Listener() {}
+    virtual void processEvent(const T& evt) = 0;
+    virtual ~Listener() {}
+};
+
+// src/Event.hpp:29-100, the part callers of addListener() need to compile: the event types, ids, sizes and hashes.
+class Event {
+public:
+    enum Type { COMPRESSION_START, COMPRESSION_END, BEFORE_TRANSFORM, AFTER_TRANSFORM, BEFORE_ENTROPY, AFTER_ENTROPY,
+                DECOMPRESSION_START, DECOMPRESSION_END, AFTER_HEADER_DECODING, BLOCK_INFO };
+    enum HashType { NO_HASH, SIZE_32, SIZE_64 };
+    Event(Type type, int id, const std::string& msg) : _type(type), _id(id), _size(0), _hash(0), _hashType(NO_HASH), _msg(msg) {}
+    Event(Type type, int id, int64 size, uint64 hash = 0, HashType hashType = NO_HASH)
+        : _type(type), _id(id), _size(size), _hash(hash), _hashType(hashType) {}
+    virtual ~Event() {}
+    int getId() const { return _id; }
+    int64 getSize() const { return _size; }
+    Type getType() const { return _type; }
+    uint64 getHash() const { return _hashType != NO_HASH ? _hash : 0; }
+    HashType getHashType() const { return _hashType; }
+    std::string toString() const { return _msg; }
+private:
+    Type _type; int _id; int64 _size; uint64 _hash; HashType _hashType; std::string _msg;
 };
 
 class OutputBitStream {
@@ -209,6 +248,7 @@ public:
 protected:
     int _type;
     int _entropy;     // stream entropy id from the context (RLT escape choice), -1 if absent
+    int _bsVersion;   // "bsVersion" of the context (inverse of BWT / LZ / LZX blocks of streams older than version 6), default 6
 };
 
 class BWTBlockCodec : public DeviceTransform { public: explicit BWTBlockCodec(Context& ctx) : DeviceTransform(KNZ_T_BWT, &ctx) {} BWTBlockCodec() : DeviceTransform(KNZ_T_BWT, nullptr) {} };
@@ -311,19 +351,34 @@ private:
 
 class DeviceEntropyDecoder : public EntropyDecoder {
 public:
-    DeviceEntropyDecoder(InputBitStream& ibs, int type) : _ibs(ibs), _type(type) {}
+    DeviceEntropyDecoder(InputBitStream& ibs, int type, int bsVersion = 6) : _ibs(ibs), _type(type), _bsVersion(bsVersion) {}
     int decode(byte block[], uint blkptr, uint len);
     InputBitStream& getBitStream() const { return _ibs; }
     void dispose() {}
 private:
     InputBitStream& _ibs;
     int _type;
+    int _bsVersion;
 };
 
-class ANSRangeEncoder : public DeviceEntropyEncoder { public: ANSRangeEncoder(OutputBitStream& obs, int order = 0); };
-class ANSRangeDecoder : public DeviceEntropyDecoder { public: ANSRangeDecoder(InputBitStream& ibs, int order = 0); };
-class HuffmanEncoder : public DeviceEntropyEncoder { public: explicit HuffmanEncoder(OutputBitStream& obs) : DeviceEntropyEncoder(obs, KNZ_E_HUFFMAN) {} };
-class HuffmanDecoder : public DeviceEntropyDecoder { public: explicit HuffmanDecoder(InputBitStream& ibs) : DeviceEntropyDecoder(ibs, KNZ_E_HUFFMAN) {} };
+// Constructor parameters as in the reference (entropy/ANSRangeEncoder.hpp:48-51, ANSRangeDecoder.hpp:45-47,
+// HuffmanEncoder.hpp:32, HuffmanDecoder.hpp:32): the same range checks with the same messages. The device kernels are
+// built for the values the stream classes and the factories use (16 KiB chunks, scaled by 256 for order 1; logRange 12) --
+// a valid value other than the default is refused with std::invalid_argument instead of being silently ignored.
+// HuffmanDecoder takes "bsVersion" from its Context (chunk layout of versions below 6, HuffmanDecoder.cpp:349-352).
+class ANSRangeEncoder : public DeviceEntropyEncoder {
+public:
+    static const int DEFAULT_ANS0_CHUNK_SIZE = 16384, DEFAULT_LOG_RANGE = 12, MIN_CHUNK_SIZE = 1024, MAX_CHUNK_SIZE = 1 << 27;
+    ANSRangeEncoder(OutputBitStream& obs, int order = 0, int chunkSize = DEFAULT_ANS0_CHUNK_SIZE, int logRange = DEFAULT_LOG_RANGE);
+};
+class ANSRangeDecoder : public DeviceEntropyDecoder {
+public:
+    static const int DEFAULT_ANS0_CHUNK_SIZE = 16384, MIN_CHUNK_SIZE = 1024, MAX_CHUNK_SIZE = 1 << 27;
+    ANSRangeDecoder(InputBitStream& ibs, int order = 0, int chunkSize = DEFAULT_ANS0_CHUNK_SIZE);
+};
+struct HuffmanCommon { static const int LOG_MAX_CHUNK_SIZE = 14, MAX_CHUNK_SIZE = 1 << 14; };
+class HuffmanEncoder : public DeviceEntropyEncoder { public: HuffmanEncoder(OutputBitStream& obs, int chunkSize = HuffmanCommon::MAX_CHUNK_SIZE); };
+class HuffmanDecoder : public DeviceEntropyDecoder { public: HuffmanDecoder(InputBitStream& ibs, Context* pCtx = nullptr, int chunkSize = HuffmanCommon::MAX_CHUNK_SIZE); };
 class FPAQEncoder : public DeviceEntropyEncoder { public: explicit FPAQEncoder(OutputBitStream& obs) : DeviceEntropyEncoder(obs, KNZ_E_FPAQ) {} };
 class FPAQDecoder : public DeviceEntropyDecoder { public: explicit FPAQDecoder(InputBitStream& ibs) : DeviceEntropyDecoder(ibs, KNZ_E_FPAQ) {} };
 class NullEntropyEncoder : public DeviceEntropyEncoder { public: explicit NullEntropyEncoder(OutputBitStream& obs) : DeviceEntropyEncoder(obs, KNZ_E_NONE) {} };
@@ -346,13 +401,33 @@ public:
 };
 
 // ---- block framing ------------------------------------------------------------------------------
+typedef std::ostream OutputStream;     // src/types.hpp
+typedef std::istream InputStream;
+
 class CompressedOutputStream : public std::ostream {
 public:
+    // io/CompressedOutputStream.hpp:140-152 as the concurrent build declares it: the thread pool sits in front of `headerless`
+    // (src/api/Compressor.cpp:230-237 passes nullptr there). Accepted and ignored: the blocks of a batch run on the device.
     CompressedOutputStream(std::ostream& os, int jobs = 1, const std::string& entropy = "NONE", const std::string& transform = "NONE",
-                           int blockSize = 4 * 1024 * 1024, int checksum = 0, uint64 originalSize = 0, bool headerless = false);
+                           int blockSize = 4 * 1024 * 1024, int checksum = 0, uint64 originalSize = 0, ThreadPool* pool = nullptr,
+                           bool headerless = false);
+    // the same without the pool: the reference's declaration when CONCURRENCY_ENABLED is not defined
+    CompressedOutputStream(std::ostream& os, int jobs, const std::string& entropy, const std::string& transform,
+                           int blockSize, int checksum, uint64 originalSize, bool headerless);
+    // io/CompressedOutputStream.hpp:154, .cpp:148-240 (what app/BlockCompressor.cpp:757 calls): "jobs" (default 1), "blockSize",
+    // "entropy", "transform", "checksum" (default 0), "fileSize" (default 0) from the context
+    CompressedOutputStream(std::ostream& os, Context& ctx, bool headerless = false);
     ~CompressedOutputStream();
+    // io/CompressedOutputStream.cpp:243-260: kept (a listener is registered once, removal reports whether it was there); the
+    // device path raises no per-block events
+    bool addListener(Listener<Event>& bl);
+    bool removeListener(Listener<Event>& bl);
     std::ostream& write(const char* s, std::streamsize n);
     std::ostream& put(char c);
+    // io/CompressedOutputStream.hpp:228-243
+    std::ostream& flush() { return *this; }                                   // NOOP: the underlying stream flushes itself
+    std::streampos tellp() { throw std::ios_base::failure("Not supported"); }
+    std::ostream& seekp(std::streampos) { throw std::ios_base::failure("Not supported"); }
     void close();
     uint64 getWritten() const { return _written.load(); }
     // number of blocks handed to the device per call (default: jobs, like the reference keeps `jobs` blocks in flight)
@@ -404,6 +479,8 @@ private:
     std::condition_variable _cv;
     bool _stop;
     std::exception_ptr _err;
+    std::vector<Listener<Event>*> _listeners;
+    void init(int jobs, const std::string& entropy, const std::string& transform, int blockSize, int checksum, uint64 originalSize, bool headerless);
     bool drainOne(std::unique_lock<std::mutex>& l);
     void enqueue(bool last);
     void workerLoop(int lane);
@@ -413,14 +490,27 @@ private:
 
 class CompressedInputStream : public std::istream {
 public:
+    // io/CompressedInputStream.hpp:183-196 as the concurrent build declares it (src/api/Decompressor.cpp:159-166 passes nullptr for
+    // the pool). Accepted and ignored.
     CompressedInputStream(std::istream& is, int jobs = 1, const std::string& entropy = "NONE", const std::string& transform = "NONE",
-                          int blockSize = 4 * 1024 * 1024, int checksum = 0, uint64 originalSize = 0, bool headerless = false,
-                          int bsVersion = 6);
+                          int blockSize = 4 * 1024 * 1024, int checksum = 0, uint64 originalSize = 0, ThreadPool* pool = nullptr,
+                          bool headerless = false, int bsVersion = 6);
+    // the same without the pool: the reference's declaration when CONCURRENCY_ENABLED is not defined
+    CompressedInputStream(std::istream& is, int jobs, const std::string& entropy, const std::string& transform,
+                          int blockSize, int checksum, uint64 originalSize, bool headerless, int bsVersion = 6);
     // io/CompressedInputStream.hpp:189 / .cpp:121-212: parameters from a Context -- "jobs", for a headerless stream "entropy",
     // "transform", "blockSize", "checksum", "outputSize", "bsVersion", and the block range "from" / "to" (1-based block ids, blocks
     // from <= id < to are decoded, the ones before are skipped on the host, io/CompressedInputStream.cpp:836-868)
     CompressedInputStream(std::istream& is, Context& ctx, bool headerless = false);
     ~CompressedInputStream();
+    // io/CompressedInputStream.cpp:482-499 (see CompressedOutputStream::addListener)
+    bool addListener(Listener<Event>& bl);
+    bool removeListener(Listener<Event>& bl);
+    // io/CompressedInputStream.hpp:306-327
+    std::streampos tellg() { throw std::ios_base::failure("Not supported"); }
+    std::istream& seekg(std::streampos) { throw std::ios_base::failure("Not supported"); }
+    std::istream& putback(char) { setstate(std::ios::badbit); throw std::ios_base::failure("Not supported"); }
+    std::istream& unget() { setstate(std::ios::badbit); throw std::ios_base::failure("Not supported"); }
     void setBlockRange(int from, int to) { _from = from < 1 ? 1 : from; _to = to; }
     std::istream& read(char* s, std::streamsize n);
     int get();
@@ -482,6 +572,9 @@ private:
     int64 _tellBit;
     uint64 _readBits;
     std::streamsize _gcount;
+    std::vector<Listener<Event>*> _listeners;
+    void init(int jobs, const std::string& entropy, const std::string& transform, int blockSize, int checksum, uint64 originalSize, bool headerless,
+              int bsVersion);
     void ensureStarted();
     void stopReader();
     void readerLoop();

@@ -136,6 +136,11 @@ KNZ_API int knz_hip_entropy_encode(knz_ctx* ctx, int entropy_type, const uint8_t
 KNZ_API int knz_hip_entropy_decode(knz_ctx* ctx, int entropy_type, const uint8_t* in, uint64_t in_bits,
                                    uint64_t start_bit, uint8_t* out, uint32_t n, int32_t* decoded,
                                    uint64_t* used_bits);
+/* The same with the bitstream version the bits come from (knz_params.bs_version: 0 / 6 current, 1..5 the old Huffman chunk
+ * layout): what HuffmanDecoder takes from its Context (entropy/HuffmanDecoder.hpp:32, HuffmanDecoder.cpp:349-352). */
+KNZ_API int knz_hip_entropy_decode_v(knz_ctx* ctx, int entropy_type, int bs_version, const uint8_t* in, uint64_t in_bits,
+                                     uint64_t start_bit, uint8_t* out, uint32_t n, int32_t* decoded,
+                                     uint64_t* used_bits);
 
 /* Transform<byte>::forward / inverse for one buffer (src/Transform.hpp:38-45). dst_cap mirrors
  * SliceArray::_length - _index of the destination (it changes results for ZRLT/RLT; LZ/LZX refuse a
@@ -153,6 +158,11 @@ KNZ_API int knz_hip_transform_forward(knz_ctx* ctx, int transform_type, const ui
                                       uint8_t* out, int32_t dst_cap, int entropy_type, int32_t* out_len, int32_t* ok);
 KNZ_API int knz_hip_transform_inverse(knz_ctx* ctx, int transform_type, const uint8_t* in, int32_t n,
                                       uint8_t* out, int32_t dst_cap, int32_t* out_len, int32_t* ok);
+/* The same for a block of an older stream (bs_version as in knz_params: the BWT block header of versions below 6,
+ * transform/BWTBlockCodec.cpp:140-164, and the LZ / LZX token layout, transform/LZCodec.cpp:614-760): what the transform
+ * classes take from the "bsVersion" entry of their Context. */
+KNZ_API int knz_hip_transform_inverse_v(knz_ctx* ctx, int transform_type, int bs_version, const uint8_t* in, int32_t n,
+                                        uint8_t* out, int32_t dst_cap, int32_t* out_len, int32_t* ok);
 
 /* Device-memory helpers so that non-HIP hosts (ctypes, cgo, JNI) can stage data. */
 KNZ_API int knz_hip_malloc(knz_ctx* ctx, size_t bytes, void** d_ptr);

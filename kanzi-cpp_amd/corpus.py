@@ -217,6 +217,58 @@ def gradient(n, seed, width):
     return (((x * 3 + y * 5) >> 2) + noise.astype(np.int64) & 255).astype(np.uint8).tobytes()
 
 
+# Real bytes that exist on every box of this image (round 5): no corpus can be fetched, but ELF objects, C/C++ headers, Python
+# sources and the mixed bag under /usr/share are real files with the zero padding, string tables, licence headers repeated a
+# thousand times and near-duplicate functions the generators above lack. Sections in this order, each capped, files in sorted
+# path order, regular files only (no symlinks), at most _LOCAL_FILE_CAP bytes from one file so that no single library dominates.
+_LOCAL_SECTIONS = [
+    ("/usr/lib/x86_64-linux-gnu", (".so",), 56 << 20),        # ELF shared objects (CPU code, symbol and string tables)
+    ("/opt/rocm/include", None, 56 << 20),                     # C / C++ headers
+    ("/usr/lib/python3.10", (".py",), 40 << 20),              # Python sources
+    ("/usr/share", None, 48 << 20),                            # man pages (gzip), locale catalogues, icons, licences, terminfo, ...
+    ("/usr/include", None, 48 << 20),
+    ("/opt/rocm/lib", (".so",), 64 << 20),                    # ELF with embedded gfx code objects
+]
+_LOCAL_FILE_CAP = 8 << 20
+
+
+def _local_files(root, suffixes):
+    for d, dirs, files in os.walk(root):
+        dirs.sort()
+        for f in sorted(files):
+            if suffixes is not None and not any(f.endswith(x) or (x + ".") in f for x in suffixes):
+                continue
+            p = os.path.join(d, f)
+            if os.path.islink(p) or not os.path.isfile(p):
+                continue
+            yield p
+
+
+def local(limit=211957760):
+    """Deterministic concatenation of real files of this image, up to `limit` bytes. Returns (bytes, files used, description).
+    The md5 is printed by bench.py (`config.input_md5`): two boxes of the same image give the same bytes."""
+    parts, used, total = [], 0, 0
+    for root, suffixes, cap in _LOCAL_SECTIONS:
+        if total >= limit or not os.path.isdir(root):
+            continue
+        sec = 0
+        for p in _local_files(root, suffixes):
+            room = min(cap - sec, limit - total, _LOCAL_FILE_CAP)
+            if room <= 0:
+                break
+            try:
+                with open(p, "rb") as f:
+                    b = f.read(room)
+            except OSError:
+                continue
+            if not b:
+                continue
+            parts.append(b)
+            sec += len(b); total += len(b); used += 1
+    data = b"".join(parts)
+    return data, used, "real files of this image (%d files: ELF .so + C/C++ headers + Python sources + /usr/share), %d B" % (used, len(data))
+
+
 _REAL = {"silesia": "silesia.tar", "enwik9": "enwik9", "enwik8": "enwik8"}
 
 
@@ -243,6 +295,9 @@ def load(name, limit=None):
             with open(p, "rb") as f:
                 return f.read(4194304), "enwik8[:4MiB] (real)"
         return text(4194304, 1), "text(4194304,1) stand-in for enwik8 head"
+    if name == "local":                # real files of this image (bench.py --config 9)
+        d, _, desc = local(211957760 if limit is None else limit)
+        return d, desc
     if name == "repeats":              # (no real counterpart: the long-common-prefix stand-in, bench.py --config 8)
         n = 211957760 if limit is None else min(limit, 211957760)
         return repeats(n, 3), "repeats(%d,3) stand-in for long-common-prefix data (text with 30%% copied spans of 1-64 KiB)" % n

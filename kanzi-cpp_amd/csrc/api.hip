@@ -585,8 +585,20 @@ static int run_inverse_stage(Ctx* c, hipStream_t s, int t, const XfStage& st)
         void* sc = nullptr;
         size_t bytes = 0;
         if (st.maxCap != 0 && st.maxCap <= (1u << 30) && !lz_serial_decode(-1)) {
+            // about 20 bytes per output byte; when the device cannot spare that (1 GiB blocks, a 2 GiB batch), or the workspace would
+            // exceed the budget below, the blocks are decoded by the one-wave-per-block decoder, which needs no scratch
             bytes = lz_inverse_scratch_bytes(st.nBlocks, st.maxCap);
-            if (int r = ws_get(c, "lzInvScratch", bytes, &sc)) return r;
+            static const size_t budget = getenv("KNZ_LZ_INV_SCRATCH_MAX") ? (size_t)atoll(getenv("KNZ_LZ_INV_SCRATCH_MAX")) : ((size_t)48 << 30);
+            WsBuf& wb = c->ws["lzInvScratch"];
+            if (bytes > budget) { bytes = 0; }
+            else if (wb.cap >= bytes) sc = wb.p;
+            else {
+                if (wb.p) { HIPCHK(c, hipFree(wb.p)); wb.p = nullptr; wb.cap = 0; }
+                const size_t want = bytes + (bytes >> 3) + 4096;
+                void* p = nullptr;
+                if (hipMalloc(&p, want) == hipSuccess) { wb.p = p; wb.cap = want; sc = p; }
+                else { (void)hipGetLastError(); bytes = 0; }           // out of memory: the serial decoder
+            }
         }
         launch_lz_inverse(s, st, sc, bytes, st.maxCap);
         break;
@@ -1030,11 +1042,17 @@ int knz_hip_entropy_encode(knz_ctx* ctx, int entropy_type, const uint8_t* in, ui
 int knz_hip_entropy_decode(knz_ctx* ctx, int entropy_type, const uint8_t* in, uint64_t in_bits, uint64_t start_bit,
                            uint8_t* out, uint32_t n, int32_t* decoded, uint64_t* used_bits)
 {
+    return knz_hip_entropy_decode_v(ctx, entropy_type, 0, in, in_bits, start_bit, out, n, decoded, used_bits);
+}
+
+int knz_hip_entropy_decode_v(knz_ctx* ctx, int entropy_type, int bs_version, const uint8_t* in, uint64_t in_bits, uint64_t start_bit,
+                             uint8_t* out, uint32_t n, int32_t* decoded, uint64_t* used_bits)
+{
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     CTX_LOCK(c);
     if (n == 0) { *decoded = 0; if (used_bits) *used_bits = 0; return 0; }
     knz_params p; memset(&p, 0, sizeof(p));
-    p.entropy_type = entropy_type; p.block_size = (int32_t)((n + 15) & ~15u);
+    p.entropy_type = entropy_type; p.block_size = (int32_t)((n + 15) & ~15u); p.bs_version = bs_version;
     const size_t inBytes = (size_t)((in_bits + 7) >> 3);
     u8 *d_in, *d_out;
     if (int r = ws_get(c, "stageIn", inBytes + 64, (void**)&d_in)) return r;
@@ -1050,7 +1068,7 @@ int knz_hip_entropy_decode(knz_ctx* ctx, int entropy_type, const uint8_t* in, ui
 }
 
 static int transform_host(Ctx* c, int t, int forward, const uint8_t* in, int32_t n, uint8_t* out, int32_t dstCap, int etype,
-                          int32_t* outLen, int32_t* ok)
+                          int32_t* outLen, int32_t* ok, int bsVersion = 6)
 {
     CTX_LOCK(c);
     ProfInstall pi_(c);
@@ -1078,6 +1096,7 @@ static int transform_host(Ctx* c, int t, int forward, const uint8_t* in, int32_t
     XfStage st;
     st.src = w.a.src; st.dst = w.a.dst; st.len = w.a.alen; st.cap = w.a.cap; st.ok = w.a.ok; st.newLen = w.a.newLen;
     st.nBlocks = 1; st.maxLen = (u32)n; st.scratchU32 = w.scratch; st.entropyType = etype; st.maxCap = (u32)dstCap;
+    st.bsVersion = bsVersion;
     if (int r = forward ? run_forward_stage(c, s, t, st) : run_inverse_stage(c, s, t, st)) return r;
     HIPCHK(c, hipGetLastError());
     u8 hok = 0; u32 hlen = 0;
@@ -1103,6 +1122,15 @@ int knz_hip_transform_inverse(knz_ctx* ctx, int transform_type, const uint8_t* i
                               int32_t* out_len, int32_t* ok)
 {
     return transform_host(reinterpret_cast<Ctx*>(ctx), transform_type, 0, in, n, out, dst_cap, -1, out_len, ok);
+}
+
+int knz_hip_transform_inverse_v(knz_ctx* ctx, int transform_type, int bs_version, const uint8_t* in, int32_t n, uint8_t* out,
+                                int32_t dst_cap, int32_t* out_len, int32_t* ok)
+{
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    const int v = (bs_version == 0) ? 6 : bs_version;
+    if (v < 0 || v > 6) return fail(c, KNZ_ERR_STREAM_VERSION, "cannot read bitstream version %d", v);
+    return transform_host(c, transform_type, 0, in, n, out, dst_cap, -1, out_len, ok, v);
 }
 
 }  // extern "C"

@@ -2114,7 +2114,8 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     prims::RsWs rs = prims::rs_carve(w.rsMem, maxTotal, st.nBlocks + 1, w.base, st.nBlocks);
     { KScope ks_("k_bwt_f_r0_layout"); prims::rs_launch_layout(s, rs); }
     u64* kin = w.keysA; u64* kout = w.keysB;
-    const bool oneRead = prims::rs_onesweep_knob().load() != 0 && nsym <= prims::RS_MAXPASS;
+    const bool oneRead = prims::rs_onesweep_knob().load() != 0 && nsym <= prims::RS_MAXPASS
+                         && (size_t)bv.VS < (size_t)prims::RS_VAL_MASK;   // 30-bit counts in the look-back words (a 1 GiB block: count + scatter)
     if (oneRead) {                                                // the digits of all passes counted from the text, once
         KScope ks_("k_bwt_f_r0_sort");
         TextSrc src; src.src = bv.src; src.P = nsym; src.pbits = pbits; src.shift = pbits;

@@ -171,11 +171,16 @@ static inline void launch_scan(hipStream_t s, const u32* in, u32* out, size_t nM
 // ------------------------------------------------------------------------------------------------
 // Eight waves (tiles of 8,192 keys) since the end of round 4: half as many tiles to rank, publish and look back over; round 0 of the
 // suffix sort 5.06 -> 4.57 ms, the run round's member sort 2.06 -> 1.86 ms on the headline workload. (The kernels are templates with
-// one name per instantiation whatever the tile size: every translation unit of the library has to be built with the same value.)
-#ifndef KNZ_RS_WAVES
-#define KNZ_RS_WAVES 8
-#endif
-constexpr int RS_WAVES = KNZ_RS_WAVES;    // waves per workgroup: each owns 16 rows of 64 consecutive keys
+// one name per instantiation whatever the tile size, so two translation units built with different values would share one
+// symbol and fault on the device -- which happened once, through a -D on one object file. The value is therefore a constant of this
+// header, not a build option; tests/test_host_abi.py checks that every object file of the library carries the same tile size.)
+constexpr int RS_WAVES = 8;               // waves per workgroup: each owns 16 rows of 64 consecutive keys
+// k_rs_onesweep<u64, true>: sK 64 KiB + sV 32 KiB + counters 8 KiB + flags: gfx950 has 160 KiB of LDS per CU; fail the build elsewhere
+static_assert(sizeof(unsigned long long) * 1024u * RS_WAVES + 4u * 1024u * RS_WAVES + 4u * 256u * RS_WAVES + 4096u <= 160u * 1024u,
+              "radix tile does not fit the LDS of gfx950");
+// every translation unit that includes this header emits the symbol rs_tile_tag<keys per tile>(): one name in all of them or the build is mixed
+template <unsigned KEYS> __attribute__((used, visibility("default"))) void rs_tile_tag() {}
+template void rs_tile_tag<1024u * RS_WAVES>();
 constexpr int RS_THREADS = 64 * RS_WAVES;
 constexpr u32 RS_TILE = 1024u * RS_WAVES; // keys per tile
 constexpr u32 RS_GROUP = 64;             // tiles per group of the column scan
@@ -625,7 +630,9 @@ static inline int rs_sort(hipStream_t s, const RsWs& w, KEY* ka, KEY* kb, u32* v
 {
     int cur = 0;
     const int nPass = (hiBit - loBit + 7) / 8;
-    const bool os = oneRead && rs_onesweep_knob().load() != 0 && nPass >= 1 && nPass <= RS_MAXPASS;
+    // the look-back words of the one-read passes hold 2 flag bits + a 30-bit count of keys in front of a tile (RS_VAL_MASK): a
+    // segment of 2^30 keys or more (one LZ block of 1 GiB; the run sorts of a 2 GiB batch) takes the count + scatter passes
+    const bool os = oneRead && rs_onesweep_knob().load() != 0 && nPass >= 1 && nPass <= RS_MAXPASS && maxSegLen < (size_t)RS_VAL_MASK;
     if (os) {
         DigitOfKey<KEY> src; src.keys = ka; src.shift = loBit; src.mask = 255u;
         const int rem = hiBit - loBit - 8 * (nPass - 1);
@@ -648,7 +655,7 @@ static inline int rs_sort_keep(hipStream_t s, const RsWs& w, const KEY* kin, con
 {
     int cur = -1;                                            // -1: input, 0: b, 1: c
     const int nPass = (hiBit - loBit + 7) / 8;
-    const bool os = rs_onesweep_knob().load() != 0 && nPass >= 1 && nPass <= RS_MAXPASS;
+    const bool os = rs_onesweep_knob().load() != 0 && nPass >= 1 && nPass <= RS_MAXPASS && maxSegLen < (size_t)RS_VAL_MASK;
     if (os) {
         DigitOfKey<KEY> src; src.keys = kin; src.shift = loBit; src.mask = 255u;
         const int rem = hiBit - loBit - 8 * (nPass - 1);

@@ -1,21 +1,14 @@
-// ZRLT and MTFT byte transforms on gfx950, batched over all blocks of a call.
+// ZRLT byte transform on gfx950, batched over all blocks of a call (the MTFT kernels that used to share this file live in mtft.hip).
 //
 // Reference being replaced (bit-identical results, same success/failure decisions):
 //   ZRLT  transform/ZRLT.cpp:27-117 (forward), :119-215 (inverse)
-//   MTFT  transform/SBRT.cpp:46-97, :99-145 with MODE_MTF (:28-31) == classic move-to-front
 //
-// Both CPU loops are sequential; here they are rebuilt from scans:
+// The CPU loops are sequential; here they are rebuilt from scans:
 //   ZRLT forward   zero-run starts need the run end = next non-zero position: per-tile first-nonzero +
 //                  suffix-min over tiles; token sizes -> per-tile sums -> exclusive scan -> scatter.
 //   ZRLT inverse   tokens are classified by two prefix-max scans (parity inside 0xFF streaks decides
 //                  escape markers; "last non run-bit" gives each bit group); output offsets from a
 //                  scan; the output is pre-zeroed so zero runs cost no stores.
-//   MTFT forward   the recency list at a tile start is the symbols ordered by last occurrence
-//                  (prefix-max over tiles per symbol) -> rank-by-counting sort per tile; then one
-//                  lane per 1 KiB tile runs the short sequential search (ranks after BWT are tiny).
-//   MTFT inverse   the list permutation of a tile does not depend on its content: every lane decodes
-//                  its tile symbolically (initial-position ids), permutations are prefix-composed
-//                  per block, then a parallel gather resolves ids to symbols.
 #include "common.hpp"
 #include "stages.hpp"
 

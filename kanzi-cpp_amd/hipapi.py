@@ -20,6 +20,7 @@ SYMBOLS = [
     "knz_hip_transform_forward", "knz_hip_transform_inverse", "knz_hip_malloc", "knz_hip_free",
     "knz_hip_memcpy_h2d", "knz_hip_memcpy_d2h", "knz_hip_sync", "knz_hip_memcpy_h2d_async", "knz_hip_memcpy_d2h_async", "knz_hip_copy_wait", "knz_hip_host_alloc", "knz_hip_host_free", "knz_hip_set_profiling", "knz_hip_get_kernel_times",
     "knz_hip_tune", "knz_hip_shift_bits", "knz_hip_encode_block_hosted", "knz_hip_decode_block_hosted",
+    "knz_hip_entropy_decode_v", "knz_hip_transform_inverse_v",
 ]
 
 
@@ -76,6 +77,10 @@ def lib():
         L.knz_hip_entropy_encode.argtypes = [vp, C.c_int, C.c_char_p, C.c_uint32, u8p, sz, C.POINTER(C.c_uint64)]
         L.knz_hip_entropy_decode.argtypes = [vp, C.c_int, C.c_char_p, C.c_uint64, C.c_uint64, u8p, C.c_uint32,
                                              C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
+        L.knz_hip_entropy_decode_v.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_uint64, C.c_uint64, u8p, C.c_uint32,
+                                               C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
+        L.knz_hip_transform_inverse_v.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_int32, u8p, C.c_int32,
+                                                  C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.knz_hip_transform_forward.argtypes = [vp, C.c_int, C.c_char_p, C.c_int32, u8p, C.c_int32, C.c_int,
                                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.knz_hip_transform_inverse.argtypes = [vp, C.c_int, C.c_char_p, C.c_int32, u8p, C.c_int32,
@@ -175,13 +180,13 @@ class Context:
         self._chk(self.L.knz_hip_entropy_encode(self.h, e, data, len(data), out, cap, C.byref(bits)))
         return C.string_at(out, (bits.value + 7) // 8), bits.value
 
-    def entropy_decode(self, entropy, enc, n, start_bit=0, in_bits=None):
+    def entropy_decode(self, entropy, enc, n, start_bit=0, in_bits=None, bs_version=0):
         e = ENTROPY_IDS[entropy.upper()]
         out = (C.c_uint8 * max(1, n))()
         dec, used = C.c_int32(0), C.c_uint64(0)
         if in_bits is None:
             in_bits = 8 * len(enc)
-        self._chk(self.L.knz_hip_entropy_decode(self.h, e, enc, in_bits, start_bit, out, n, C.byref(dec), C.byref(used)))
+        self._chk(self.L.knz_hip_entropy_decode_v(self.h, e, bs_version, enc, in_bits, start_bit, out, n, C.byref(dec), C.byref(used)))
         return dec.value, C.string_at(out, n), used.value
 
     def transform_forward(self, transform, data, dst_cap, entropy=None):
@@ -192,11 +197,11 @@ class Context:
         self._chk(self.L.knz_hip_transform_forward(self.h, t, data, len(data), out, dst_cap, e, C.byref(ol), C.byref(ok)))
         return ok.value, C.string_at(out, ol.value)
 
-    def transform_inverse(self, transform, data, dst_cap):
+    def transform_inverse(self, transform, data, dst_cap, bs_version=0):
         t = TRANSFORM_IDS[transform.upper()]
         out = (C.c_uint8 * (dst_cap + 64))()
         ol, ok = C.c_int32(0), C.c_int32(0)
-        self._chk(self.L.knz_hip_transform_inverse(self.h, t, data, len(data), out, dst_cap, C.byref(ol), C.byref(ok)))
+        self._chk(self.L.knz_hip_transform_inverse_v(self.h, t, bs_version, data, len(data), out, dst_cap, C.byref(ol), C.byref(ok)))
         return ok.value, C.string_at(out, ol.value)
 
     # ---- profiling

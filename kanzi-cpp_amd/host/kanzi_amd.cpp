@@ -312,9 +312,10 @@ static int entropyIdFromName(const std::string& nm)
     return -1;
 }
 
-DeviceTransform::DeviceTransform(int type, Context* ctx) : _type(type), _entropy(-1)
+DeviceTransform::DeviceTransform(int type, Context* ctx) : _type(type), _entropy(-1), _bsVersion(6)
 {
     if (ctx != nullptr && ctx->has("entropy")) _entropy = entropyIdFromName(ctx->getString("entropy"));
+    if (ctx != nullptr) _bsVersion = ctx->getInt("bsVersion", 6);       // BWTBlockCodec.cpp:34-36, LZCodec.cpp:101-104
     deviceContext();        // fail early (and loudly) when there is no GPU
 }
 
@@ -357,8 +358,8 @@ bool DeviceTransform::inverse(SliceArray<byte>& src, SliceArray<byte>& dst, int 
     if ((_type == KNZ_T_LZ || _type == KNZ_T_LZX) && (length > src._length - src._index - 2)) return false;
     knz_ctx* c = deviceContext();
     int32_t outLen = 0, ok = 0;
-    devCheck(c, knz_hip_transform_inverse(c, _type, src._array + src._index, length, dst._array + dst._index,
-                                          dst._length - dst._index, &outLen, &ok), "transform inverse");
+    devCheck(c, knz_hip_transform_inverse_v(c, _type, _bsVersion == 0 ? 1 : _bsVersion, src._array + src._index, length, dst._array + dst._index,
+                                            dst._length - dst._index, &outLen, &ok), "transform inverse");
     if (!ok) return false;
     src._index += length;
     dst._index += outLen;
@@ -797,6 +798,7 @@ int DeviceEntropyDecoder::decode(byte block[], uint blkptr, uint len)
     knz_ctx* c = deviceContext();
     int32_t decoded = 0;
     uint64_t used = 0;
+    const int ver = (_bsVersion == 0) ? 1 : _bsVersion;     // a declared version 0 is an old layout (knz_params.bs_version: 0 = unset)
     DefaultInputBitStream* dibs = dynamic_cast<DefaultInputBitStream*>(&_ibs);
     if (dibs != nullptr) {
         // The device needs the block's bits in one buffer. Only as much of the stream as `len` symbols can occupy is handed
@@ -805,10 +807,10 @@ int DeviceEntropyDecoder::decode(byte block[], uint blkptr, uint len)
         const uint64 bound = 8 * (2ull * len + (uint64(len) / 16384 + 2) * 640 + (_type == KNZ_E_ANS1 ? (uint64(len) / (4u << 20) + 1) * 256 * 576 : 0) + 4096);
         const byte* data; uint64 startBit, endBit;
         dibs->peekAhead(bound, &data, &startBit, &endBit);
-        devCheck(c, knz_hip_entropy_decode(c, _type, data, endBit, startBit, &block[blkptr], len, &decoded, &used), "entropy decode");
+        devCheck(c, knz_hip_entropy_decode_v(c, _type, ver, data, endBit, startBit, &block[blkptr], len, &decoded, &used), "entropy decode");
         if (decoded != int32_t(len) && endBit - startBit >= bound) {
             dibs->peekRemaining(&data, &startBit, &endBit);
-            devCheck(c, knz_hip_entropy_decode(c, _type, data, endBit, startBit, &block[blkptr], len, &decoded, &used), "entropy decode");
+            devCheck(c, knz_hip_entropy_decode_v(c, _type, ver, data, endBit, startBit, &block[blkptr], len, &decoded, &used), "entropy decode");
         }
         if (decoded == int32_t(len)) dibs->skip(used);
         return int(decoded);
@@ -817,18 +819,46 @@ int DeviceEntropyDecoder::decode(byte block[], uint blkptr, uint len)
     // only ONE decode() per stream is possible through such an object; DefaultInputBitStream has no such limit
     std::vector<byte> rest;
     try { while (_ibs.hasMoreToRead()) rest.push_back(byte(_ibs.readBits(8))); } catch (const BitStreamException&) {}
-    devCheck(c, knz_hip_entropy_decode(c, _type, rest.data(), uint64(rest.size()) * 8, 0, &block[blkptr], len, &decoded, &used), "entropy decode");
+    devCheck(c, knz_hip_entropy_decode_v(c, _type, ver, rest.data(), uint64(rest.size()) * 8, 0, &block[blkptr], len, &decoded, &used), "entropy decode");
     return int(decoded);
 }
 
-ANSRangeEncoder::ANSRangeEncoder(OutputBitStream& obs, int order) : DeviceEntropyEncoder(obs, order == 1 ? KNZ_E_ANS1 : KNZ_E_ANS0)
+// entropy/ANSRangeEncoder.cpp:36-68, ANSRangeDecoder.cpp:36-64, HuffmanEncoder.cpp:32-44, HuffmanDecoder.cpp:32-48: the reference's checks,
+// then the one this implementation adds (the kernels exist for the default chunk size and range only)
+static void checkAnsArgs(int order, int chunkSize, int logRange)
 {
     if ((order != 0) && (order != 1)) throw std::invalid_argument("ANS Codec: The order must be 0 or 1");
+    if (chunkSize < ANSRangeEncoder::MIN_CHUNK_SIZE) throw std::invalid_argument("ANS Codec: The chunk size must be at least " + std::to_string(ANSRangeEncoder::MIN_CHUNK_SIZE));
+    if (chunkSize > ANSRangeEncoder::MAX_CHUNK_SIZE) throw std::invalid_argument("ANS Codec: The chunk size must be at most " + std::to_string(ANSRangeEncoder::MAX_CHUNK_SIZE));
+    if ((logRange < 8) || (logRange > 15)) throw std::invalid_argument("ANS Codec: Invalid range: " + std::to_string(logRange) + " (must be in [8..15])");
+    if (chunkSize != ANSRangeEncoder::DEFAULT_ANS0_CHUNK_SIZE || logRange != ANSRangeEncoder::DEFAULT_LOG_RANGE)
+        throw std::invalid_argument("ANS Codec: the device kernels are built for the default chunk size (16384) and range (12)");
 }
 
-ANSRangeDecoder::ANSRangeDecoder(InputBitStream& ibs, int order) : DeviceEntropyDecoder(ibs, order == 1 ? KNZ_E_ANS1 : KNZ_E_ANS0)
+static void checkHuffmanArgs(int chunkSize)
 {
-    if ((order != 0) && (order != 1)) throw std::invalid_argument("ANS Codec: The order must be 0 or 1");
+    if (chunkSize < 1024) throw std::invalid_argument("Huffman codec: The chunk size must be at least 1024");
+    if (chunkSize > HuffmanCommon::MAX_CHUNK_SIZE) throw std::invalid_argument("Huffman codec: The chunk size must be at most " + std::to_string(HuffmanCommon::MAX_CHUNK_SIZE));
+    if (chunkSize != HuffmanCommon::MAX_CHUNK_SIZE) throw std::invalid_argument("Huffman codec: the device kernels are built for the default chunk size (16384)");
+}
+
+ANSRangeEncoder::ANSRangeEncoder(OutputBitStream& obs, int order, int chunkSize, int logRange)
+    : DeviceEntropyEncoder(obs, order == 1 ? KNZ_E_ANS1 : KNZ_E_ANS0)
+{
+    checkAnsArgs(order, chunkSize, logRange);
+}
+
+ANSRangeDecoder::ANSRangeDecoder(InputBitStream& ibs, int order, int chunkSize) : DeviceEntropyDecoder(ibs, order == 1 ? KNZ_E_ANS1 : KNZ_E_ANS0)
+{
+    checkAnsArgs(order, chunkSize, ANSRangeEncoder::DEFAULT_LOG_RANGE);
+}
+
+HuffmanEncoder::HuffmanEncoder(OutputBitStream& obs, int chunkSize) : DeviceEntropyEncoder(obs, KNZ_E_HUFFMAN) { checkHuffmanArgs(chunkSize); }
+
+HuffmanDecoder::HuffmanDecoder(InputBitStream& ibs, Context* pCtx, int chunkSize)
+    : DeviceEntropyDecoder(ibs, KNZ_E_HUFFMAN, pCtx != nullptr ? pCtx->getInt("bsVersion", 6) : 6)
+{
+    checkHuffmanArgs(chunkSize);
 }
 
 static const struct { const char* name; short type; } ENAMES[] = {
@@ -860,10 +890,10 @@ EntropyEncoder* EntropyEncoderFactory::newEncoder(OutputBitStream& obs, Context&
     }
 }
 
-EntropyDecoder* EntropyDecoderFactory::newDecoder(InputBitStream& ibs, Context&, short entropyType)
+EntropyDecoder* EntropyDecoderFactory::newDecoder(InputBitStream& ibs, Context& ctx, short entropyType)
 {
     switch (entropyType) {
-    case EntropyEncoderFactory::HUFFMAN_TYPE: return new HuffmanDecoder(ibs);
+    case EntropyEncoderFactory::HUFFMAN_TYPE: return new HuffmanDecoder(ibs, &ctx);      // EntropyDecoderFactory.hpp:66-67
     case EntropyEncoderFactory::ANS0_TYPE: return new ANSRangeDecoder(ibs, 0);
     case EntropyEncoderFactory::ANS1_TYPE: return new ANSRangeDecoder(ibs, 1);
     case EntropyEncoderFactory::FPAQ_TYPE: return new FPAQDecoder(ibs);
@@ -936,10 +966,41 @@ PinnedPool g_pinned;
 }
 
 CompressedOutputStream::CompressedOutputStream(std::ostream& os, int tasks, const std::string& entropy, const std::string& transform,
+                                               int blockSize, int checksum, uint64 fileSize, ThreadPool*, bool headerless)
+    : std::ostream(os.rdbuf()), _os(os)
+{
+    init(tasks, entropy, transform, blockSize, checksum, fileSize, headerless);
+}
+
+CompressedOutputStream::CompressedOutputStream(std::ostream& os, int tasks, const std::string& entropy, const std::string& transform,
                                                int blockSize, int checksum, uint64 fileSize, bool headerless)
     : std::ostream(os.rdbuf()), _os(os)
 {
-    if ((tasks <= 0) || (tasks > 64)) throw std::invalid_argument("The number of jobs must be in [1..64]");
+    init(tasks, entropy, transform, blockSize, checksum, fileSize, headerless);
+}
+
+CompressedOutputStream::CompressedOutputStream(std::ostream& os, Context& ctx, bool headerless)
+    : std::ostream(os.rdbuf()), _os(os)
+{
+    const int64 fileSize = ctx.getLong("fileSize", 0);
+    init(ctx.getInt("jobs", 1), ctx.getString("entropy"), ctx.getString("transform"), ctx.getInt("blockSize"), ctx.getInt("checksum", 0),
+         fileSize < 0 ? 0 : uint64(fileSize), headerless);
+}
+
+bool CompressedOutputStream::addListener(Listener<Event>& bl) { _listeners.push_back(&bl); return true; }
+
+bool CompressedOutputStream::removeListener(Listener<Event>& bl)
+{
+    auto it = std::find(_listeners.begin(), _listeners.end(), &bl);
+    if (it == _listeners.end()) return false;
+    _listeners.erase(it);
+    return true;
+}
+
+void CompressedOutputStream::init(int tasks, const std::string& entropy, const std::string& transform, int blockSize, int checksum, uint64 fileSize,
+                                  bool headerless)
+{
+    if ((tasks <= 0) || (tasks > 64)) throw std::invalid_argument("The number of jobs must be in [1..64], got " + std::to_string(tasks));
     if (blockSize > 1024 * 1024 * 1024) throw std::invalid_argument("The block size must be at most 1024 MB");
     if (blockSize < 1024) throw std::invalid_argument("The block size must be at least 1024");
     if ((blockSize & -16) != blockSize) throw std::invalid_argument("The block size must be a multiple of 16");
@@ -1248,10 +1309,33 @@ void CompressedOutputStream::close()
 // CompressedInputStream
 // ------------------------------------------------------------------------------------------------
 CompressedInputStream::CompressedInputStream(std::istream& is, int tasks, const std::string& entropy, const std::string& transform,
+                                             int blockSize, int checksum, uint64 originalSize, ThreadPool*, bool headerless, int bsVersion)
+    : std::istream(is.rdbuf()), _is(is)
+{
+    init(tasks, entropy, transform, blockSize, checksum, originalSize, headerless, bsVersion);
+}
+
+CompressedInputStream::CompressedInputStream(std::istream& is, int tasks, const std::string& entropy, const std::string& transform,
                                              int blockSize, int checksum, uint64 originalSize, bool headerless, int bsVersion)
     : std::istream(is.rdbuf()), _is(is)
 {
-    if ((tasks <= 0) || (tasks > 64)) throw std::invalid_argument("The number of jobs must be in [1..64]");
+    init(tasks, entropy, transform, blockSize, checksum, originalSize, headerless, bsVersion);
+}
+
+bool CompressedInputStream::addListener(Listener<Event>& bl) { _listeners.push_back(&bl); return true; }
+
+bool CompressedInputStream::removeListener(Listener<Event>& bl)
+{
+    auto it = std::find(_listeners.begin(), _listeners.end(), &bl);
+    if (it == _listeners.end()) return false;
+    _listeners.erase(it);
+    return true;
+}
+
+void CompressedInputStream::init(int tasks, const std::string& entropy, const std::string& transform, int blockSize, int checksum, uint64 originalSize,
+                                 bool headerless, int bsVersion)
+{
+    if ((tasks <= 0) || (tasks > 64)) throw std::invalid_argument("The number of jobs must be in [1..64], got " + std::to_string(tasks));
     _jobs = tasks; _blockSize = blockSize; _checksum = checksum; _outputSize = originalSize;
     _headless = headerless; _closed = false; _headerDone = false; _ended = false;
     _entropyType = 0; _transformType = 0; _bsVersion = 6;
@@ -1288,8 +1372,8 @@ CompressedInputStream::CompressedInputStream(std::istream& is, int tasks, const 
 
 CompressedInputStream::CompressedInputStream(std::istream& is, Context& ctx, bool headerless)
     : CompressedInputStream(is, ctx.getInt("jobs", 1), ctx.getString("entropy", "NONE"), ctx.getString("transform", "NONE"),
-                            ctx.getInt("blockSize", 4 * 1024 * 1024), ctx.getInt("checksum", 0), uint64(ctx.getLong("outputSize", 0)), headerless,
-                            ctx.getInt("bsVersion", 6))
+                            ctx.getInt("blockSize", 4 * 1024 * 1024), ctx.getInt("checksum", 0), uint64(ctx.getLong("outputSize", 0)),
+                            static_cast<ThreadPool*>(nullptr), headerless, ctx.getInt("bsVersion", 6))
 {
     setBlockRange(ctx.getInt("from", 1), ctx.getInt("to", 0x7FFFFFFF));
 }
@@ -1812,8 +1896,9 @@ int initCompressor(struct cData* pData, FILE* dst, struct cContext** pCtx)
         cctx->buf = new FileOutBuf(dst);
         cctx->os = new std::ostream(cctx->buf);
         cctx->pCos = nullptr;
+        // the call form of src/api/Compressor.cpp:230-237 (concurrent build: a null thread pool in front of `headerless`)
         cctx->pCos = new CompressedOutputStream(*cctx->os, int(pData->jobs), pData->entropy, pData->transform, int(pData->blockSize),
-                                                pData->checksum, uint64(fileSize), pData->headerless != 0);
+                                                pData->checksum, uint64(fileSize), nullptr, pData->headerless != 0);
         cctx->blockSize = pData->blockSize;
         *pCtx = cctx;
     } catch (const std::exception&) {
@@ -1895,8 +1980,9 @@ int initDecompressor(struct dData* pData, FILE* src, struct dContext** pCtx)
             memset(pData->entropy, 0, sizeof(pData->entropy));
             strncpy(pData->entropy, entropy.c_str(), sizeof(pData->entropy) - 1);
             pData->blockSize = (pData->blockSize + 15) & unsigned(-16);
+            // the call form of src/api/Decompressor.cpp:159-166
             dctx->pCis = new CompressedInputStream(*dctx->is, int(pData->jobs), pData->entropy, pData->transform, int(pData->blockSize),
-                                                   pData->checksum, uint64(pData->originalSize), true, pData->bsVersion);
+                                                   pData->checksum, uint64(pData->originalSize), nullptr, true, pData->bsVersion);
         } else {
             dctx->pCis = new CompressedInputStream(*dctx->is, int(pData->jobs));
         }

@@ -4,8 +4,9 @@
 //   kanzi_amd_cli -c -i FILE [-o FILE.knz] [-t TRANSFORMS] [-e ENTROPY] [-l LEVEL] [-b SIZE] [-j JOBS] [-x | -x32 | -x64] [-f]
 //   kanzi_amd_cli -d -i FILE.knz [-o FILE] [-j JOBS] [--from=N] [--to=N] [-f]
 //
+// Levels 0, 1, 5 and 6 are in (5 and 6: TEXT and UTF on the host in front of the device chain, host/text_codec.cpp).
 // What it does not do (and says so instead of guessing): directories, stdin/stdout, `-y` info, levels whose chains need the
-// reference's CPU-only transforms (TEXT, UTF, EXE, PACK, MM, DNA, ROLZ, LZP) or entropy coders (CM, TPAQ): levels 2-9.
+// reference's CPU-only transforms (EXE, PACK, MM, DNA, ROLZ, LZP) or entropy coders (CM, TPAQ): levels 2-4 and 7-9.
 // Files written here are byte-identical to `kanzi -c` with the same -t/-e/-b/-x/-j, and either tool reads the other's files
 // (tests/test_host_stub.py, tests/test_gpu_host_api.py).
 #include <cstdio>
@@ -37,7 +38,7 @@ static long long parseSize(const std::string& v)
 static int usage(const char* msg)
 {
     if (msg) fprintf(stderr, "%s\n", msg);
-    fprintf(stderr, "usage: kanzi_amd_cli -c|-d -i FILE [-o FILE] [-t TRANSFORMS] [-e ENTROPY] [-l 0|1] [-b SIZE] [-j JOBS] [-x|-x32|-x64] [--from=N] [--to=N] [-f]\n");
+    fprintf(stderr, "usage: kanzi_amd_cli -c|-d -i FILE [-o FILE] [-t TRANSFORMS] [-e ENTROPY] [-l 0|1|5|6] [-b SIZE] [-j JOBS] [-x|-x32|-x64] [--from=N] [--to=N] [-f]\n");
     return Error::ERR_MISSING_PARAM;
 }
 

@@ -446,6 +446,9 @@ static bool wordsInverse(const uint8_t* src, int count, uint8_t* dst, int dstCap
     int i = 1, o = 0, at = dict.fixed;
     int delim = isLetter(src[i]) ? i - 1 : i;
     bool afterWord = false, ok = true;
+    // the bytes of a word index (and the literal behind an escape) may be cut off by the end of a damaged block: nothing is
+    // read behind src[end - 1] (the caller's slice has no padding); a block that ends inside an index fails the final i == end
+    auto rd = [src, end](int k) -> int { return k < end ? int(src[k]) : 0; };
     while (i < end && o < room) {
         uint8_t c = src[i];
         const int8_t t = cls[c];
@@ -468,10 +471,10 @@ static bool wordsInverse(const uint8_t* src, int count, uint8_t* dst, int dstCap
         if (E::escapes) {
             isRef = (c == ESC1 || c == ESC2);
             if (isRef) {
-                idx = src[i++];
+                idx = rd(i++);
                 if (idx >= 128) {
-                    const int b2 = src[i++];
-                    if (b2 >= 128) { idx = ((idx & 0x1F) << 14) | ((b2 & 0x7F) << 7) | int(src[i]); i++; }
+                    const int b2 = rd(i++);
+                    if (b2 >= 128) { idx = ((idx & 0x1F) << 14) | ((b2 & 0x7F) << 7) | rd(i); i++; }
                     else idx = ((idx & 0x7F) << 7) | b2;
                     if (idx >= dict.size()) { ok = false; break; }
                 }
@@ -484,19 +487,22 @@ static bool wordsInverse(const uint8_t* src, int count, uint8_t* dst, int dstCap
                     flip = c & 0x20;
                     idx = c & 0x1F;
                     if (c & 0x40) {
-                        const int b2 = src[i++];
-                        if (b2 >= 128) { idx = (idx << 14) | ((b2 & 0x7F) << 7) | int(src[i]); i++; }
+                        const int b2 = rd(i++);
+                        if (b2 >= 128) { idx = (idx << 14) | ((b2 & 0x7F) << 7) | rd(i); i++; }
                         else idx = (idx << 7) | b2;
                         if (idx >= dict.size()) { ok = false; break; }
                     }
                 } else {
-                    if (c == 0x80) { flip = 0x20; c = src[i++]; }
+                    if (c == 0x80) { flip = 0x20; c = uint8_t(rd(i++)); }
                     idx = c & 0x7F;
                     if (idx >= 64) {
-                        if (idx >= 112) { idx = ((idx & 0x0F) << 16) | (int(src[i]) << 8) | int(src[i + 1]); i += 2; }
-                        else { idx = ((idx & 0x1F) << 8) | int(src[i]); i++; }
+                        if (idx >= 112) { idx = ((idx & 0x0F) << 16) | (rd(i) << 8) | rd(i + 1); i += 2; }
+                        else { idx = ((idx & 0x1F) << 8) | rd(i); i++; }
                         if (idx > dict.size()) { ok = false; break; }
-                    } else if (idx == 0) { ok = false; break; }
+                    }
+                    // an index of 0 in any of its encodings names no word: the reference checks the one-byte form only
+                    // (TextCodec.cpp:1507-1518) and reads _dictList[-1] for C0 00 / F0 00 00; refused here
+                    if (idx == 0) { ok = false; break; }
                     idx--;
                 }
             }
@@ -519,7 +525,7 @@ static bool wordsInverse(const uint8_t* src, int count, uint8_t* dst, int dstCap
             o += len;
         } else {
             if (!E::escapes && c == ESC1) {
-                dst[o++] = src[i++];
+                dst[o++] = uint8_t(rd(i++));
             } else {
                 if (crlf && c == LF) {
                     dst[o++] = CR;

@@ -416,6 +416,153 @@ static void testPipeline()
     }
 }
 
+// The call forms the reference's own callers use (boundary row): src/api/Compressor.cpp:230-237 and
+// src/api/Decompressor.cpp:159-166 (positional nullptr for the thread pool), src/app/BlockCompressor.cpp:757 /
+// BlockDecompressor.cpp (Context form + addListener), io/CompressedOutputStream.hpp:228-243, CompressedInputStream.hpp:306-327,
+// and the codec constructors with their trailing parameters (entropy/HuffmanDecoder.hpp:32, HuffmanEncoder.hpp:32,
+// ANSRangeEncoder.hpp:48-51, ANSRangeDecoder.hpp:45-47).
+struct CountingListener : public Listener<Event> {
+    int seen = 0;
+    void processEvent(const Event&) { seen++; }
+};
+
+static void testReferenceCallForms()
+{
+    const int bs = 65536;
+    std::vector<byte> in = gen(4, size_t(3 * bs + 1234), 77);
+    std::string viaPool, viaCtx, plain;
+    {   // Compressor.cpp:230-237
+        std::stringstream ss;
+        OutputStream& fos = ss;
+        CompressedOutputStream* pCos = new CompressedOutputStream(fos, 2, "ANS0", "BWT+MTFT+ZRLT", bs, 32, uint64(in.size()),
+                                                                  nullptr,
+                                                                  false);
+        pCos->write(reinterpret_cast<const char*>(in.data()), std::streamsize(in.size()));
+        CHECK(&pCos->flush() == pCos);                                   // NOOP, returns the stream
+        bool threw = false;
+        try { pCos->tellp(); } catch (const std::ios_base::failure&) { threw = true; }
+        CHECK(threw);
+        threw = false;
+        try { pCos->seekp(0); } catch (const std::ios_base::failure&) { threw = true; }
+        CHECK(threw);
+        pCos->close();
+        delete pCos;
+        viaPool = ss.str();
+    }
+    {   // BlockCompressor.cpp:757: Context form, listeners added right after construction
+        std::stringstream ss;
+        Context ctx;
+        ctx.putInt("jobs", 2); ctx.putInt("blockSize", bs); ctx.putString("entropy", "ANS0"); ctx.putString("transform", "BWT+MTFT+ZRLT");
+        ctx.putInt("checksum", 32); ctx.putLong("fileSize", int64(in.size()));
+        CountingListener l1, l2;
+        CompressedOutputStream cos(ss, ctx);
+        CHECK(cos.addListener(l1));
+        CHECK(cos.addListener(l2));
+        CHECK(cos.removeListener(l1));
+        CHECK(!cos.removeListener(l1));                                  // CompressedOutputStream.cpp:350-359
+        cos.write(reinterpret_cast<const char*>(in.data()), std::streamsize(in.size()));
+        cos.close();
+        viaCtx = ss.str();
+        bool threw = false;
+        Context bad;                                                      // no block size: the reference's message
+        try { CompressedOutputStream c2(ss, bad); } catch (const std::invalid_argument& e) { threw = std::string(e.what()).find("block size must be at least") != std::string::npos; }
+        CHECK(threw);
+    }
+    {
+        std::stringstream ss;
+        CompressedOutputStream cos(ss, 2, "ANS0", "BWT+MTFT+ZRLT", bs, 32, uint64(in.size()));
+        cos.write(reinterpret_cast<const char*>(in.data()), std::streamsize(in.size()));
+        cos.close();
+        plain = ss.str();
+    }
+    CHECK(!plain.empty() && viaPool == plain && viaCtx == plain);
+    {   // Decompressor.cpp:159-166: headerless form with the pool positional and the bitstream version behind it
+        std::stringstream hs;
+        {
+            CompressedOutputStream cos(hs, 1, "HUFFMAN", "RLT", bs, 0, 0, nullptr, true);
+            cos.write(reinterpret_cast<const char*>(in.data()), std::streamsize(in.size()));
+            cos.close();
+        }
+        InputStream& fis = hs;
+        CompressedInputStream* pCis = new CompressedInputStream(fis, 1, "HUFFMAN", "RLT", bs, 0, uint64(in.size()),
+                                                                nullptr,
+                                                                true, 6);
+        std::vector<byte> out(in.size() + 8);
+        pCis->read(reinterpret_cast<char*>(out.data()), std::streamsize(out.size()));
+        CHECK(size_t(pCis->gcount()) == in.size() && memcmp(out.data(), in.data(), in.size()) == 0);
+        bool threw = false;
+        try { pCis->tellg(); } catch (const std::ios_base::failure&) { threw = true; }
+        CHECK(threw);
+        threw = false;
+        try { pCis->seekg(0); } catch (const std::ios_base::failure&) { threw = true; }
+        CHECK(threw);
+        threw = false;
+        try { pCis->putback('x'); } catch (const std::ios_base::failure&) { threw = true; }
+        CHECK(threw && pCis->bad());
+        pCis->clear();
+        threw = false;
+        try { pCis->unget(); } catch (const std::ios_base::failure&) { threw = true; }
+        CHECK(threw && pCis->bad());
+        pCis->close();
+        delete pCis;
+    }
+    {   // Context form of the reader + listeners, default stream (header present)
+        std::stringstream ss(plain);
+        Context ctx;
+        ctx.putInt("jobs", 3);
+        CountingListener l;
+        CompressedInputStream cis(ss, ctx);
+        CHECK(cis.addListener(l) && cis.removeListener(l) && !cis.removeListener(l));
+        std::vector<byte> out(in.size() + 8);
+        cis.read(reinterpret_cast<char*>(out.data()), std::streamsize(out.size()));
+        CHECK(size_t(cis.gcount()) == in.size() && memcmp(out.data(), in.data(), in.size()) == 0);
+    }
+    // codec constructors: trailing parameters as the reference declares them; the reference's range checks and messages
+    {
+        std::stringstream ss;
+        std::vector<byte> blk = gen(1, 50000, 5);
+        {
+            DefaultOutputBitStream obs(ss);
+            HuffmanEncoder he(obs, HuffmanCommon::MAX_CHUNK_SIZE);
+            CHECK(he.encode(blk.data(), 0, uint(blk.size())) == int(blk.size()));
+            ANSRangeEncoder ae(obs, 0, 16384, 12);
+            CHECK(ae.encode(blk.data(), 0, uint(blk.size())) == int(blk.size()));
+            ANSRangeEncoder a1(obs, 1, 16384, 12);
+            CHECK(a1.encode(blk.data(), 0, uint(blk.size())) == int(blk.size()));
+            obs.close();
+        }
+        DefaultInputBitStream ibs(ss);
+        Context ctx;
+        ctx.putInt("bsVersion", 6);
+        std::vector<byte> out(blk.size());
+        HuffmanDecoder hd(ibs, &ctx, HuffmanCommon::MAX_CHUNK_SIZE);
+        CHECK(hd.decode(out.data(), 0, uint(out.size())) == int(out.size()) && out == blk);
+        std::fill(out.begin(), out.end(), byte(0));
+        ANSRangeDecoder ad(ibs, 0, 16384);
+        CHECK(ad.decode(out.data(), 0, uint(out.size())) == int(out.size()) && out == blk);
+        std::fill(out.begin(), out.end(), byte(0));
+        ANSRangeDecoder ad1(ibs, 1, 16384);
+        CHECK(ad1.decode(out.data(), 0, uint(out.size())) == int(out.size()) && out == blk);
+        auto throwsWith = [](auto&& f, const char* what) {
+            try { f(); } catch (const std::invalid_argument& e) { return std::string(e.what()).find(what) != std::string::npos; }
+            return false;
+        };
+        std::stringstream s2;
+        DefaultOutputBitStream o2(s2);
+        DefaultInputBitStream i2(s2);
+        CHECK(throwsWith([&] { HuffmanEncoder x(o2, 512); }, "at least 1024"));
+        CHECK(throwsWith([&] { HuffmanEncoder x(o2, 1 << 15); }, "at most 16384"));
+        CHECK(throwsWith([&] { HuffmanDecoder x(i2, nullptr, 512); }, "at least 1024"));
+        CHECK(throwsWith([&] { ANSRangeEncoder x(o2, 2); }, "order must be 0 or 1"));
+        CHECK(throwsWith([&] { ANSRangeEncoder x(o2, 0, 512); }, "at least 1024"));
+        CHECK(throwsWith([&] { ANSRangeEncoder x(o2, 0, (1 << 27) + 1); }, "at most"));
+        CHECK(throwsWith([&] { ANSRangeEncoder x(o2, 0, 16384, 16); }, "Invalid range: 16"));
+        CHECK(throwsWith([&] { ANSRangeDecoder x(i2, 0, 100); }, "at least 1024"));
+        CHECK(throwsWith([&] { ANSRangeEncoder x(o2, 0, 32768); }, "default chunk size"));      // valid for the reference, no kernel here: refused loudly
+        o2.close();
+    }
+}
+
 int main(int argc, char** argv)
 {
     const std::string what = argc > 1 ? argv[1] : "all";
@@ -424,6 +571,7 @@ int main(int argc, char** argv)
         if (what == "all" || what == "transforms") testTransforms();
         if (what == "all" || what == "entropy") testEntropy();
         if (what == "all" || what == "streams") testStreams();
+        if (what == "all" || what == "callforms") testReferenceCallForms();
         if (what == "all" || what == "hoststages") testHostStages();
         if (what == "all" || what == "seek") testSeek();
         if (what == "all" || what == "range") testBlockRange();

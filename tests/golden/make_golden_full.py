@@ -3,7 +3,9 @@
 BASELINE.json configurations at their own block sizes (vectors.FULL_CASES), 64 MiB inputs, -j 1, and for the long-common-prefix
 inputs of vectors.HARD_CASES at 8 MiB / 32 MiB blocks (copies, periods, DNA; table- and image-shaped blocks).
 
-    make -C oracle ref && python tests/golden/make_golden_full.py
+    make -C oracle ref && python tests/golden/make_golden_full.py [config ...]
+
+With config names given only those records are (re)generated; the others are kept as they are.
 
 Data only (input specs + digests of the reference's output); nothing of the reference's sources is stored.
 """
@@ -21,7 +23,13 @@ import vectors  # noqa: E402
 def main():
     R = knzlib.Ref()
     out = []
+    only = set(sys.argv[1:])
+    path = os.path.join(HERE, "golden_full.json")
+    old = {str(r["config"]): r for r in json.load(open(path))} if only and os.path.exists(path) else {}
     for cfg, spec, t, e, bs in vectors.FULL_CASES + vectors.HARD_CASES:
+        if only and str(cfg) not in only and str(cfg) in old:
+            out.append(old[str(cfg)])
+            continue
         d = vectors.make(spec)
         rc, o = R.compress(d, t, e, bs, jobs=1, orig_size=len(d))
         assert rc == 0, (cfg, rc)
@@ -30,7 +38,7 @@ def main():
         out.append({"config": cfg, "input": list(spec), "input_md5": hashlib.md5(d).hexdigest(), "transform": t, "entropy": e,
                     "block": bs, "orig_size": len(d), "out": {"len": len(o), "md5": hashlib.md5(o).hexdigest()}})
         print(out[-1], flush=True)
-    json.dump(out, open(os.path.join(HERE, "golden_full.json"), "w"), indent=1)
+    json.dump(out, open(path, "w"), indent=1)
 
 
 if __name__ == "__main__":

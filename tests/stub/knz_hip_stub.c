@@ -103,6 +103,17 @@ int knz_hip_entropy_encode(knz_ctx* c, int entropy_type, const uint8_t* in, uint
     return 0;
 }
 
+int knz_hip_entropy_decode_v(knz_ctx* c, int entropy_type, int bs_version, const uint8_t* in, uint64_t in_bits, uint64_t start_bit, uint8_t* out,
+                             uint32_t n, int32_t* decoded, uint64_t* used_bits)
+{
+    const int ver = bs_version == 0 ? 6 : bs_version;
+    if (ver < 0 || ver > 6) return fail(c, KNZ_ERR_STREAM_VERSION, "unknown bitstream version");
+    knzo_set_bs_version(ver);
+    const int rc = knz_hip_entropy_decode(c, entropy_type, in, in_bits, start_bit, out, n, decoded, used_bits);
+    knzo_set_bs_version(6);
+    return rc;
+}
+
 int knz_hip_entropy_decode(knz_ctx* c, int entropy_type, const uint8_t* in, uint64_t in_bits, uint64_t start_bit, uint8_t* out, uint32_t n,
                            int32_t* decoded, uint64_t* used_bits)
 {
@@ -140,6 +151,17 @@ int knz_hip_transform_inverse(knz_ctx* c, int t, const uint8_t* in, int32_t n, u
     *ok = knzo_transform_inverse(t, in, n, out, dst_cap, &ol) == 1;
     *out_len = *ok ? ol : 0;
     return 0;
+}
+
+int knz_hip_transform_inverse_v(knz_ctx* c, int t, int bs_version, const uint8_t* in, int32_t n, uint8_t* out, int32_t dst_cap, int32_t* out_len,
+                                int32_t* ok)
+{
+    const int ver = bs_version == 0 ? 6 : bs_version;
+    if (ver < 0 || ver > 6) return fail(c, KNZ_ERR_STREAM_VERSION, "unknown bitstream version");
+    knzo_set_bs_version(ver);
+    const int rc = knz_hip_transform_inverse(c, t, in, n, out, dst_cap, out_len, ok);
+    knzo_set_bs_version(6);
+    return rc;
 }
 
 int knz_hip_malloc(knz_ctx* c, size_t bytes, void** p) { (void)c; *p = malloc(bytes ? bytes : 1); return *p ? 0 : -1; }

@@ -440,6 +440,44 @@ def test_full_size_reference_stream_config4_four_blocks_of_32m(hip):
     _full_case(hip, "config4:4blocks")
 
 
+def test_full_size_reference_stream_config4_six_blocks_of_copied_spans(hip):
+    """block ids 4 and 5 of a 32 MiB stream (the slot model i % jobs / first_block_id beyond four blocks) on text with 30 % copied
+    spans: long common prefixes through SRT and FPAQ"""
+    _full_case(hip, "config4:6blocks_repeats")
+
+
+def test_real_files_of_this_image_against_the_reference(hip, oracle):
+    """REAL bytes: 64 MiB of corpus.local() -- ELF shared objects with their zero padding and string tables, then
+    C/C++ headers with the same licence text in front of thousands of them -- through the headline chain at 8 MiB blocks. The
+    expected stream is computed on this box by the unmodified reference (oracle/_ref, which travels with the repository); a
+    checkout without it falls back to the C restatement. No fixture: the files belong to the image, not to the repository."""
+    corpus = importlib.import_module("kanzi_amd.corpus")
+    data, files, desc = corpus.local(64 << 20)
+    assert len(data) == 64 << 20 and files > 20, desc
+    # 56 MiB of ELF, then headers: blocks 0-6 are machine code and tables, block 7 is source text
+    t, e, bs = "BWT+MTFT+ZRLT", "ANS0", 8 << 20
+    if knzlib.ensure_ref() is not None:
+        rc, want = knzlib.Ref().compress(data, t, e, bs, jobs=1, orig_size=len(data))
+    else:
+        rc, want = oracle.compress(data, t, e, bs, orig_size=len(data))
+    assert rc == 0
+    out, bits, hb = gpu_compress(hip, data, t, e, bs, orig_size=len(data))
+    assert len(out) == len(want) and out == want
+    assert gpu_decompress(hip, out, t, e, bs, len(data), hb) == data
+    # and the part of the concatenation where the file kinds change (headers, Python, /usr/share), as config 4's chain sees it
+    data2, _, _ = corpus.local(130 << 20)
+    part = data2[100 << 20:116 << 20]
+    t2, e2 = "BWT+SRT+ZRLT", "ANS0"
+    if knzlib.ensure_ref() is not None:
+        rc, want = knzlib.Ref().compress(part, t2, e2, bs, jobs=1, orig_size=len(part))
+    else:
+        rc, want = oracle.compress(part, t2, e2, bs, orig_size=len(part))
+    assert rc == 0
+    out, bits, hb = gpu_compress(hip, part, t2, e2, bs, orig_size=len(part))
+    assert out == want
+    assert gpu_decompress(hip, out, t2, e2, bs, len(part), hb) == part
+
+
 @pytest.mark.parametrize("name", [c[0] for c in vectors.HARD_CASES if c[0].startswith("hard:")])
 def test_long_common_prefix_inputs_at_full_block_size(hip, name):
     """Inputs a prefix-doubling sorter finds hard (copies with edits, X || X, periods 3 / 5 / 7 / 768, the Fibonacci word, DNA with

@@ -65,3 +65,33 @@ def test_corpus_generators_are_pinned():
     assert hashlib.md5(c.text(4194304, 1)).hexdigest() == "533763267af795f681817771bd17d0cc"
     assert hashlib.md5(c.mixed(4194304, 2)).hexdigest() == "4f3716bf4e8db9d931141d3c144dfc8c"
     assert c.mixed(600000, 2) == c.mixed(4194304, 2)[:600000]
+
+
+def test_radix_tile_size_is_one_value_across_the_library():
+    """The radix-sort kernels (csrc/prims.hpp) are templates whose symbol names do not carry the tile size; two object files built with
+    different sizes once shared one kernel symbol and faulted on the device. The size is a header constant now and
+    every translation unit that includes the header emits rs_tile_tag<keys>(): exactly one such name may exist in the library, every
+    object file with radix kernels must carry it, and every k_rs_* instantiation must have a single definition in the .so."""
+    import glob
+    import subprocess
+    nm = "/opt/rocm/lib/llvm/bin/llvm-nm" if os.path.exists("/opt/rocm/lib/llvm/bin/llvm-nm") else "nm"
+    so = os.path.join(knzlib.PKG, "libknz_hip.so")
+    assert os.path.exists(so), "run __graft_entry__.build() first"
+
+    def syms(path):
+        out = subprocess.run([nm, "-C", path], capture_output=True, text=True, check=True).stdout
+        return [ln.split(None, 2) for ln in out.splitlines() if len(ln.split(None, 2)) == 3]
+
+    tags = {name for _, _, name in syms(so) if "rs_tile_tag<" in name}
+    assert len(tags) == 1, tags
+    assert re.search(r"rs_tile_tag<8192u?>", next(iter(tags))), tags
+    defs = {}
+    for _, kind, name in syms(so):
+        if "prims::k_rs_" in name and "__device_stub__" not in name and kind in "TtWwVv":
+            defs[name] = defs.get(name, 0) + 1
+    assert defs and all(v == 1 for v in defs.values()), {k: v for k, v in defs.items() if v != 1}
+    for obj in glob.glob(os.path.join(knzlib.PKG, "csrc", "*.o")):
+        names = [name for _, _, name in syms(obj)]
+        if any("prims::k_rs_" in n for n in names):
+            t = {n for n in names if "rs_tile_tag<" in n}
+            assert t == tags, (obj, t)

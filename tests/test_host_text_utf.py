@@ -134,3 +134,34 @@ def test_host_stages_against_the_compiled_reference(stages):
             n_utf += 1
             assert out == ref_out, (kind, n)
     assert n_text >= 40 and n_utf >= 8, (n_text, n_utf)
+
+
+def test_text_inverse_refuses_zero_and_truncated_word_indexes(stages):
+    """a 2- or 3-byte word index that decodes to 0 (C0 00, F0 00 00 in the top-bit encoding) must be refused -- the
+    reference reads _dictList[-1] there (transform/TextCodec.cpp:1494-1521) -- and an index cut off by the end of the block must not
+    read behind the caller's slice. The slices are exact-size heap copies so that an over-read would be caught by a sanitizer build
+    and at least cannot be fed by padding."""
+    t = knzlib.corpus().text(6000, 3)
+    ok, enc, _ = stages.text(2, t)
+    assert ok == 1
+    k, back = stages.text_inv(2, enc, len(t))
+    assert k == 1 and back == t
+    head = enc[:40]
+    for tail in (b"\xc0\x00", b"\xf0\x00\x00", b"\x80\xc0\x00", b"\x80\xf0\x00\x00"):
+        k, _ = stages.text_inv(2, head + tail + b" abc", len(t))
+        assert k == 0, tail
+    for tail in (b"\xc0", b"\xf0", b"\xf0\x01", b"\x80", b"\x80\xf0", b"\xe5"):       # the block ends inside an index
+        k, _ = stages.text_inv(2, head + tail, len(t))
+        assert k == 0, tail
+    ok, enc1, _ = stages.text(1, t)
+    assert ok == 1
+    for tail in (b"\x0f", b"\x0f\x80", b"\x0f\x80\x80", b"\x0e\xff\xff"):             # escape encoding: cut off / beyond the dictionary
+        k, _ = stages.text_inv(1, enc1[:40] + tail, len(t))
+        assert k == 0, tail
+    rng = np.random.default_rng(5)
+    for enc_v, v in ((enc, 2), (enc1, 1)):                                              # random damage: never a crash, refusal or some output
+        for _ in range(300):
+            b = bytearray(enc_v[:int(rng.integers(2, len(enc_v)))])
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(1, len(b)))] = int(rng.integers(0, 256))
+            stages.text_inv(v, bytes(b), len(t) + 64)

@@ -159,6 +159,8 @@ HARD_CASES = [
     ("hard:gradient", ("gradient", 8 << 20, 13, 1000), "BWT+MTFT+ZRLT", "ANS0", 8 << 20),
     # config 4's chain on four blocks of its own size: block ids 2 and 3 of a 32 MiB stream (slot model i % jobs, first_block_id)
     ("config4:4blocks", ("text", 128 << 20, 1), "BWT+SRT+ZRLT", "FPAQ", 32 << 20),
+    # the same chain on SIX blocks of text with copied spans: block ids >= 4 of a 32 MiB stream, long common prefixes through SRT and FPAQ
+    ("config4:6blocks_repeats", ("repeats", 6 * (32 << 20), 5), "BWT+SRT+ZRLT", "FPAQ", 32 << 20),
 ]
 
 # The CLI's level presets that reach the device chain through host stages (TEXT + UTF): `kanzi -c -l N` of the reference, digests in
