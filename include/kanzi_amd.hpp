@@ -401,6 +401,27 @@ public:
 };
 
 // ---- block framing ------------------------------------------------------------------------------
+// Compressed bytes fetched from the source and not yet handed to the device: a byte buffer that keeps its memory (page-locked,
+// from the process-wide pool: a std::vector would zero-fill and page-fault every byte it grows by, which cost as much as reading
+// the file) and always has 16 readable bytes behind its end.
+class FetchBuf {
+public:
+    FetchBuf() : _p(nullptr), _n(0), _cap(0) {}
+    ~FetchBuf();
+    size_t size() const { return _n; }
+    byte& operator[](size_t i) { return _p[i]; }
+    const byte& operator[](size_t i) const { return _p[i]; }
+    void resize(size_t n);                 // new bytes are NOT initialised
+    void resize(size_t n, byte fill);      // new bytes are set to `fill`
+    void dropFront(size_t n);
+    void clear() { _n = 0; }
+private:
+    FetchBuf(const FetchBuf&);
+    FetchBuf& operator=(const FetchBuf&);
+    byte* _p; size_t _n, _cap;
+    void reserve(size_t n);
+};
+
 typedef std::ostream OutputStream;     // src/types.hpp
 typedef std::istream InputStream;
 
@@ -472,6 +493,12 @@ private:
         int state;                // 0 free (the caller may fill it), 1 queued / in the kernels, 2 compressed bytes wait for the sink
     };
     std::vector<Lane> _lanes;
+    // The finished runs are appended to the sink by a thread of their own (KNZ_SINK_THREAD=0: by the caller's thread, between two
+    // batches, as in round 4): the caller only fills staging slots, so the lanes are refilled while the sink is being written.
+    std::thread _sink;
+    bool _sinkThread;
+    bool _spreadCopies;           // staging copies over the helper threads (chains the device runs faster than one thread copies)
+    void sinkLoop();
     int _fillLane;
     int64 _nextSeq, _sinkSeq, _pubSeq;    // batches handed out / appended to the sink / whose end position is known
     uint64 _cumBits;                      // end position (bits) of the batches published so far
@@ -480,6 +507,10 @@ private:
     bool _stop;
     std::exception_ptr _err;
     std::vector<Listener<Event>*> _listeners;
+    // where the wall time of a stream goes (nanoseconds; printed by close() when KNZ_HOST_TIMING is set): caller's thread
+    // [0] copy into the staging slot [1] waiting for a free lane [2] writing to the sink; lane workers [3] upload wait [4] kernels
+    // [5] waiting for the run's start position [6] bit shift + download
+    std::atomic<uint64_t> _tns[8];
     void init(int jobs, const std::string& entropy, const std::string& transform, int blockSize, int checksum, uint64 originalSize, bool headerless);
     bool drainOne(std::unique_lock<std::mutex>& l);
     void enqueue(bool last);
@@ -540,7 +571,8 @@ private:
     std::atomic<int> _batchBlocks;
     std::atomic<bool> _batchFromEnv;
     // owned by the reader thread once it runs
-    std::vector<byte> _comp;      // compressed bytes fetched and not yet decoded
+    FetchBuf _comp;               // compressed bytes fetched and not yet decoded
+    bool _spreadCopies;           // see CompressedOutputStream (decided when the stream parameters are known)
     uint64 _compBit;              // next unread bit in _comp
     uint64 _consumedBits;
     int64 _originBit;             // bit position in the underlying stream that _compBit == 0 corresponds to
@@ -573,6 +605,9 @@ private:
     uint64 _readBits;
     std::streamsize _gcount;
     std::vector<Listener<Event>*> _listeners;
+    // see CompressedOutputStream: reader thread [0] reading the source [1] prefix walk + staging copy; decoder threads [2] upload
+    // wait [3] kernels; caller's thread [4] waiting for a decoded batch [5] download wait [6] copy into the caller's buffer
+    std::atomic<uint64_t> _tns[8];
     void init(int jobs, const std::string& entropy, const std::string& transform, int blockSize, int checksum, uint64 originalSize, bool headerless,
               int bsVersion);
     void ensureStarted();

@@ -32,6 +32,7 @@
 #include <algorithm>
 #include <cmath>
 #include "prims.hpp"
+#include <chrono>
 
 namespace knz {
 
@@ -2293,6 +2294,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     }
     if (tune.stats) fprintf(stderr, "after round 0 (nsym %d, total %u): run groups %u (%u members); small left %u, medium %u, large %u (%u members)\n",
                             nsym, total, nRun, runElems, surv, nMed, nLarge, largeElems);
+    std::chrono::steady_clock::time_point statT = std::chrono::steady_clock::now();
 
     const int npass = (kbits + 7) / 8;
     const u32 nTiles = (total + SM_TS - 1) / SM_TS;
@@ -2361,8 +2363,12 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
         if (hipMemcpyAsync(h_pinned, w.counters, 64, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
         if (hipStreamSynchronize(s) != hipSuccess) return -1;
         surv = h_pinned[0]; nMed = h_pinned[1]; nLarge = h_pinned[2]; largeElems = h_pinned[3];
-        if (tune.stats) fprintf(stderr, "round h=%u: small members worked on %u in %u groups, medium members %u; after it: small left %u, medium groups %u, large %u (%u members); %u groups took the chain round\n",
-                                h, h_pinned[10], h_pinned[11], h_pinned[12], surv, nMed, nLarge, largeElems, h_pinned[7]);
+        if (tune.stats) {
+            const std::chrono::steady_clock::time_point now = std::chrono::steady_clock::now();
+            fprintf(stderr, "round h=%u (%.3f ms): small members worked on %u in %u groups, medium members %u; after it: small left %u, medium groups %u, large %u (%u members); %u groups took the chain round\n",
+                    h, std::chrono::duration<double, std::milli>(now - statT).count(), h_pinned[10], h_pinned[11], h_pinned[12], surv, nMed, nLarge, largeElems, h_pinned[7]);
+            statT = now;
+        }
         cur = nxt;
         h <<= 1;
     }

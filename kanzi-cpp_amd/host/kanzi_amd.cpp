@@ -10,9 +10,15 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <sstream>
 #include <sys/stat.h>
+#include <chrono>
+#include <deque>
+#include <fcntl.h>
+#include <functional>
+#include <unistd.h>
 
 namespace kanzi_amd {
 
@@ -113,6 +119,92 @@ static std::vector<knz_ctx*> openLanes(const std::vector<int>& devs)
     std::map<int, int> used;
     for (int d : devs) { const int idx = used[d]++; out.push_back(laneContext(d, idx)); }
     return out;
+}
+
+// KNZ_HOST_TIMING=1: the stream classes print where their wall time went when they are closed (developer aid)
+namespace {
+struct ScopedNs {
+    std::atomic<uint64_t>& acc; std::chrono::steady_clock::time_point t0;
+    explicit ScopedNs(std::atomic<uint64_t>& a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+    ~ScopedNs() { acc += uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count()); }
+};
+bool hostTiming() { static const bool on = getenv("KNZ_HOST_TIMING") != nullptr && atoi(getenv("KNZ_HOST_TIMING")) != 0; return on; }
+
+// A few helper threads for the byte moving the host layer does on somebody's critical path: the copies between the caller's memory
+// and the page-locked staging slots, and the C API's file reads / writes (pread / pwrite of slices). KNZ_COPY_THREADS = threads a
+// large copy is spread over, the calling thread included (default 4, 1 = everything on the calling thread). The pool lives as long
+// as the process; a thread that waits for its slices runs queued slices of others meanwhile, so concurrent users never wait idle.
+class HelperPool {
+public:
+    static HelperPool& get() { static HelperPool* p = new HelperPool(); return *p; }
+    int width() const { return _width; }
+    // fn(part) for part = 0 .. parts-1, part 0 on the calling thread; returns when all are done
+    void run(int parts, const std::function<void(int)>& fn)
+    {
+        if (parts <= 1 || _width <= 1) { for (int i = 0; i < parts; i++) fn(i); return; }
+        struct Job { std::atomic<int> left; };
+        std::shared_ptr<Job> job = std::make_shared<Job>();
+        job->left = parts - 1;
+        {
+            std::lock_guard<std::mutex> l(_mu);
+            for (int i = 1; i < parts; i++) _q.push_back([job, i, &fn] { fn(i); job->left.fetch_sub(1, std::memory_order_acq_rel); });
+        }
+        _cv.notify_all();
+        fn(0);
+        while (job->left.load(std::memory_order_acquire) != 0) {
+            std::function<void()> t;
+            {
+                std::lock_guard<std::mutex> l(_mu);
+                if (!_q.empty()) { t = std::move(_q.front()); _q.pop_front(); }
+            }
+            if (t) t(); else std::this_thread::yield();
+        }
+    }
+private:
+    HelperPool()
+    {
+        const char* e = getenv("KNZ_COPY_THREADS");
+        _width = e ? std::max(1, std::min(16, atoi(e))) : 4;
+        for (int i = 1; i < _width; i++) std::thread([this] { loop(); }).detach();
+    }
+    void loop()
+    {
+        for (;;) {
+            std::function<void()> t;
+            {
+                std::unique_lock<std::mutex> l(_mu);
+                _cv.wait(l, [&] { return !_q.empty(); });
+                t = std::move(_q.front());
+                _q.pop_front();
+            }
+            t();
+        }
+    }
+    int _width;
+    std::mutex _mu;
+    std::condition_variable _cv;
+    std::deque<std::function<void()>> _q;
+};
+
+const size_t PAR_MIN = size_t(2) << 20;          // below this a copy is not worth waking anybody for
+
+// how many slices n bytes are cut into (at least 1 MiB each)
+int parParts(size_t n)
+{
+    if (n < PAR_MIN) return 1;
+    return int(std::min<size_t>(size_t(HelperPool::get().width()), n >> 20));
+}
+
+void parCopy(void* dst, const void* src, size_t n, bool spread = true)
+{
+    const int parts = spread ? parParts(n) : 1;
+    if (parts <= 1) { memcpy(dst, src, n); return; }
+    const size_t slice = ((n / size_t(parts)) + 4095) & ~size_t(4095);
+    HelperPool::get().run(parts, [&](int i) {
+        const size_t a = std::min(n, size_t(i) * slice), b = (i == parts - 1) ? n : std::min(n, a + slice);
+        if (b > a) memcpy(static_cast<char*>(dst) + a, static_cast<const char*>(src) + a, b - a);
+    });
+}
 }
 
 static void devCheck(knz_ctx* c, int rc, const char* what)
@@ -584,6 +676,19 @@ bool UTFCodec::inverse(SliceArray<byte>& src, SliceArray<byte>& dst, int length)
 }
 
 // Leading stages of a chain that run on the host. TEXT / UTF anywhere else in a chain has no place to run: refused.
+// Chains the device runs far faster than one host thread copies memory (entropy coders alone, the byte transforms: tens of GB/s):
+// the staging copies of such a stream are spread over the helper threads. With a sorting or matching stage in the chain (BWT, LZ,
+// LZX; SRT / RANK are chains per block) the device is what a batch waits for and the extra threads only got in the way (measured,
+// config 3 end to end: 2.94-3.14 GB/s with the copies on the caller's thread, 2.72-2.94 with four threads; config 2: 3.1 -> 3.9).
+static bool chainIsHostBound(uint64 ttype)
+{
+    for (int i = 0; i < 8; i++) {
+        const int t = int((ttype >> (42 - 6 * i)) & 63);
+        if (t == KNZ_T_BWT || t == KNZ_T_LZ || t == KNZ_T_LZX || t == KNZ_T_SRT || t == KNZ_T_RANK || t == KNZ_T_TEXT || t == KNZ_T_UTF) return false;
+    }
+    return true;
+}
+
 static int hostedStagesOf(uint64 ttype, int ids[8])
 {
     int n = 0, k = 0;
@@ -923,7 +1028,8 @@ struct BitPacker {
     void put(uint64 v, uint n) { for (int i = int(n) - 1; i >= 0; i--) { if ((nbits & 7) == 0) bytes.push_back(0); bytes.back() |= byte(((v >> i) & 1) << (7 - (nbits & 7))); nbits++; } }
 };
 
-static uint64 getBitsAt(const std::vector<byte>& d, uint64 pos, uint n)
+template <class BUF>
+static uint64 getBitsAt(const BUF& d, uint64 pos, uint n)
 {
     uint64 v = 0;
     for (uint i = 0; i < n; i++, pos++) v = (v << 1) | ((d[size_t(pos >> 3)] >> (7 - (pos & 7))) & 1);
@@ -963,6 +1069,73 @@ struct PinnedPool {
     }
 };
 PinnedPool g_pinned;
+
+// Device buffers of the lanes go back to a pool per context as well: hipMalloc / hipFree cost tens to hundreds of microseconds
+// each (hipFree waits for the device), and a stream has a dozen of them.
+struct DevPool {
+    std::mutex mu;
+    std::map<knz_ctx*, std::vector<std::pair<void*, size_t>>> idle;
+    void* get(knz_ctx* c, size_t bytes, size_t* cap)
+    {
+        {
+            std::lock_guard<std::mutex> l(mu);
+            auto& v = idle[c];
+            size_t best = v.size();
+            for (size_t i = 0; i < v.size(); i++)
+                if (v[i].second >= bytes && v[i].second <= 2 * bytes + (size_t(1) << 20) && (best == v.size() || v[i].second < v[best].second)) best = i;
+            if (best != v.size()) { void* p = v[best].first; *cap = v[best].second; v.erase(v.begin() + long(best)); return p; }
+        }
+        void* p = nullptr;
+        if (knz_hip_malloc(c, bytes, &p) != 0 || p == nullptr) {
+            // make room: whatever idles in this context's pool goes first
+            std::vector<std::pair<void*, size_t>> drop;
+            { std::lock_guard<std::mutex> l(mu); drop.swap(idle[c]); }
+            for (auto& d : drop) knz_hip_free(c, d.first);
+            devCheck(c, knz_hip_malloc(c, bytes, &p), "malloc");
+        }
+        *cap = bytes;
+        return p;
+    }
+    void put(knz_ctx* c, void* p, size_t cap)
+    {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> l(mu);
+            auto& v = idle[c];
+            if (v.size() < 12) { v.push_back(std::make_pair(p, cap)); return; }
+        }
+        knz_hip_free(c, p);
+    }
+};
+DevPool g_devPool;
+}
+
+FetchBuf::~FetchBuf() { g_pinned.put(_p, _cap); }
+
+void FetchBuf::reserve(size_t n)
+{
+    if (n + 16 <= _cap) return;
+    size_t cap = 0;
+    byte* q = g_pinned.get(std::max(n + 16, _cap + (_cap >> 1)), &cap);
+    if (_n) memcpy(q, _p, _n);
+    g_pinned.put(_p, _cap);
+    _p = q; _cap = cap;
+}
+
+void FetchBuf::resize(size_t n) { reserve(n); _n = n; }
+
+void FetchBuf::resize(size_t n, byte fill)
+{
+    reserve(n);
+    if (n > _n) memset(_p + _n, fill, n - _n);
+    _n = n;
+}
+
+void FetchBuf::dropFront(size_t n)
+{
+    if (n >= _n) { _n = 0; return; }
+    memmove(_p, _p + n, _n - n);
+    _n -= n;
 }
 
 CompressedOutputStream::CompressedOutputStream(std::ostream& os, int tasks, const std::string& entropy, const std::string& transform,
@@ -1026,6 +1199,9 @@ void CompressedOutputStream::init(int tasks, const std::string& entropy, const s
     _pendingByte = 0; _pendingBits = 0; _written = 0;
     _fillLane = 0; _nextSeq = 0; _sinkSeq = 0; _pubSeq = 0; _cumBits = 0; _stop = false;
     _batchBytes = 0;
+    for (auto& t : _tns) t = 0;
+    { const char* st = getenv("KNZ_SINK_THREAD"); _sinkThread = !(st && atoi(st) == 0); }
+    _spreadCopies = chainIsHostBound(_transformType);
     // lanes per device bounded by the block size: a lane holds a batch's input, output and the suffix sort's scratch (about 64
     // bytes per input byte), so that with 1 GiB blocks one lane per GPU is what fits comfortably, with blocks up to 256 MiB four
     std::vector<int> devs = laneDevices();
@@ -1052,12 +1228,13 @@ CompressedOutputStream::~CompressedOutputStream()
     try { close(); } catch (...) {}
     { std::lock_guard<std::mutex> l(_mu); _stop = true; }
     _cv.notify_all();
+    if (_sink.joinable()) _sink.join();
     for (Lane& ln : _lanes) if (ln.worker.joinable()) ln.worker.join();
     for (Lane& ln : _lanes) {
         knz_hip_copy_wait(ln.ctx, ln.ticket);
-        if (ln.dIn) knz_hip_free(ln.ctx, ln.dIn);
-        if (ln.dOut) knz_hip_free(ln.ctx, ln.dOut);
-        if (ln.dShift) knz_hip_free(ln.ctx, ln.dShift);
+        g_devPool.put(ln.ctx, ln.dIn, ln.dInCap);
+        g_devPool.put(ln.ctx, ln.dOut, ln.dOutCap);
+        g_devPool.put(ln.ctx, ln.dShift, ln.dShiftCap);
         g_pinned.put(ln.in, ln.inCap);
         g_pinned.put(ln.out, ln.outCap);
     }
@@ -1082,7 +1259,7 @@ std::ostream& CompressedOutputStream::write(const char* data, std::streamsize le
         Lane& ln = _lanes[size_t(_fillLane)];                  // free: enqueue() waited for it
         if (ln.in == nullptr) ln.in = g_pinned.get(batchBytes + 64, &ln.inCap);
         const size_t take = std::min(size_t(length) - off, batchBytes - ln.n);
-        memcpy(ln.in + ln.n, data + off, take);
+        { ScopedNs t_(_tns[0]); parCopy(ln.in + ln.n, data + off, take, _spreadCopies); }
         ln.n += take;
         off += take;
         if (ln.n == batchBytes) enqueue(false);
@@ -1108,6 +1285,7 @@ bool CompressedOutputStream::drainOne(std::unique_lock<std::mutex>& l)
         const uint rem = uint(totalBits & 7);
         const size_t toWrite = (ln.last && rem) ? full + 1 : full;          // close(): the last byte is zero padded
         if (toWrite) {
+            ScopedNs t_(_tns[2]);
             _os.write(reinterpret_cast<const char*>(ln.out), std::streamsize(toWrite));
             bad = _os.fail();
             if (!bad) _written += toWrite;
@@ -1135,11 +1313,10 @@ void CompressedOutputStream::enqueue(bool last)
         // the device buffer of this lane was last read by the batch that freed the lane: safe to overwrite
         knz_ctx* c = ln.ctx;
         if (ln.dInCap < ln.n + 64) {
-            if (ln.dIn) knz_hip_free(c, ln.dIn);
+            g_devPool.put(c, ln.dIn, ln.dInCap);
             ln.dIn = nullptr; ln.dInCap = 0;
-            const size_t want = ln.n + 64;                  // a full batch, except for a stream shorter than one
-            devCheck(c, knz_hip_malloc(c, want, &ln.dIn), "malloc");
-            ln.dInCap = want;
+            const size_t want = std::max(ln.n, _batchBytes) + 64;       // a full batch (a stream shorter than one still gets a slot others can reuse)
+            ln.dIn = g_devPool.get(c, want, &ln.dInCap);
         }
         ln.ticket = 0;
         if (ln.n) devCheck(c, knz_hip_memcpy_h2d_async(c, ln.dIn, ln.in, ln.n, &ln.ticket), "h2d");
@@ -1153,14 +1330,34 @@ void CompressedOutputStream::enqueue(bool last)
         ln.state = 1;
         _fillLane = (_fillLane + 1) % int(_lanes.size());
         _cv.notify_all();
+        if (_sinkThread) {
+            if (!_sink.joinable()) _sink = std::thread(&CompressedOutputStream::sinkLoop, this);
+            ScopedNs t_(_tns[1]);
+            _cv.wait(l, [&] { return _lanes[size_t(_fillLane)].state == 0 || _err; });
+        } else
         for (;;) {
-            _cv.wait(l, [&] { const Lane& nx = _lanes[size_t(_fillLane)];
-                              const Lane& sk = _lanes[size_t(_sinkSeq % int64(_lanes.size()))];
-                              return nx.state == 0 || _err || (sk.state == 2 && sk.seq == _sinkSeq); });
+            {
+                ScopedNs t_(_tns[1]);
+                _cv.wait(l, [&] { const Lane& nx = _lanes[size_t(_fillLane)];
+                                  const Lane& sk = _lanes[size_t(_sinkSeq % int64(_lanes.size()))];
+                                  return nx.state == 0 || _err || (sk.state == 2 && sk.seq == _sinkSeq); });
+            }
             if (!drainOne(l)) break;
         }
     }
     rethrow();
+}
+
+// sink thread: the runs go to the sink in batch order as their bytes arrive; ends with the stream (close() sets _stop once
+// everything is out) or behind a failed batch
+void CompressedOutputStream::sinkLoop()
+{
+    std::unique_lock<std::mutex> l(_mu);
+    for (;;) {
+        _cv.wait(l, [&] { const Lane& sk = _lanes[size_t(_sinkSeq % int64(_lanes.size()))];
+                          return _stop || _err || (sk.state == 2 && sk.seq == _sinkSeq); });
+        if (!drainOne(l)) { if (_stop || _err) return; }
+    }
 }
 
 void CompressedOutputStream::workerLoop(int lane)
@@ -1212,10 +1409,11 @@ void CompressedOutputStream::submit(Lane& ln)
         pro.put(headerChecksum(ckSize, uint32_t(_entropyType), _transformType, uint32_t(_blockSize), szMask, _inputSize), 24);
     }
     const size_t cap = knz_hip_encode_bound(&p, n) + pro.bytes.size() + 256;
-    if (ln.dOutCap < cap) { if (ln.dOut) knz_hip_free(c, ln.dOut); ln.dOut = nullptr; ln.dOutCap = 0; devCheck(c, knz_hip_malloc(c, cap + (cap >> 2), &ln.dOut), "malloc"); ln.dOutCap = cap + (cap >> 2); }
-    devCheck(c, knz_hip_copy_wait(c, ln.ticket), "h2d");           // queued by enqueue(), normally long complete
+    if (ln.dOutCap < cap) { g_devPool.put(c, ln.dOut, ln.dOutCap); ln.dOut = nullptr; ln.dOutCap = 0; ln.dOut = g_devPool.get(c, cap + (cap >> 2), &ln.dOutCap); }
+    { ScopedNs t_(_tns[3]); devCheck(c, knz_hip_copy_wait(c, ln.ticket), "h2d"); }          // queued by enqueue(), normally long complete
     ln.ticket = 0;
     uint64_t bits = 0;
+    std::chrono::steady_clock::time_point tk0 = std::chrono::steady_clock::now();
     if (_hosted && n == 0) p.transform_type = 0;             // (the empty last batch: end marker only; the device call checks the chain before it looks at the size)
     if (_hosted && n > 0) {
         // host stages first (the original bytes are still in the lane's staging buffer), then the block in its new length to the device
@@ -1233,9 +1431,11 @@ void CompressedOutputStream::submit(Lane& ln)
     } else
     devCheck(c, knz_hip_encode_blocks(c, &p, static_cast<const uint8_t*>(ln.dIn), n, pro.bytes.empty() ? nullptr : pro.bytes.data(), uint32_t(pro.nbits),
                                       ln.firstBlock, ln.last ? 1 : 0, static_cast<uint8_t*>(ln.dOut), ln.dOutCap, &bits), "encode blocks");
+    _tns[4] += uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tk0).count());
     // where the run starts: behind the runs of the batches before it, whose lengths are published in batch order
     uint64 start;
     {
+        ScopedNs t_(_tns[5]);
         std::unique_lock<std::mutex> l(_mu);
         _cv.wait(l, [&] { return _pubSeq == ln.seq || _stop || _err; });
         if (_pubSeq != ln.seq) return;
@@ -1244,6 +1444,7 @@ void CompressedOutputStream::submit(Lane& ln)
         _pubSeq++;
     }
     _cv.notify_all();
+    ScopedNs t6_(_tns[6]);
     const uint r = uint(start & 7);
     const size_t bytes = size_t((uint64(r) + bits + 7) >> 3);
     const void* src = ln.dOut;
@@ -1252,10 +1453,9 @@ void CompressedOutputStream::submit(Lane& ln)
             // sized by what a batch actually produced (plus a quarter, so that batches of similar size do not reallocate), never
             // beyond the encode bound: with large blocks the bound is several GiB per lane, the compressed run a fraction of it
             const size_t want = std::min(ln.dOutCap + 8, std::max(bytes + 8 + (bytes >> 2), size_t(1) << 20));
-            if (ln.dShift) knz_hip_free(c, ln.dShift);
+            g_devPool.put(c, ln.dShift, ln.dShiftCap);
             ln.dShift = nullptr; ln.dShiftCap = 0;
-            devCheck(c, knz_hip_malloc(c, want, &ln.dShift), "malloc");
-            ln.dShiftCap = want;
+            ln.dShift = g_devPool.get(c, want, &ln.dShiftCap);
         }
         devCheck(c, knz_hip_shift_bits(c, static_cast<const uint8_t*>(ln.dOut), bits, r, static_cast<uint8_t*>(ln.dShift)), "shift");
         src = ln.dShift;
@@ -1284,17 +1484,23 @@ void CompressedOutputStream::close()
         if (!failed) enqueue(true);         // the last batch (possibly empty) carries the end marker; nothing follows a failed batch
         {
             std::unique_lock<std::mutex> l(_mu);
+            if (_sinkThread) _cv.wait(l, [&] { return _sinkSeq == _nextSeq || _err; });
+            else
             for (;;) {
                 _cv.wait(l, [&] { const Lane& sk = _lanes[size_t(_sinkSeq % int64(_lanes.size()))];
                                   return _sinkSeq == _nextSeq || _err || (sk.state == 2 && sk.seq == _sinkSeq); });
                 if (!drainOne(l)) break;
             }
-            _stop = true;                     // releases the workers (all of them idle, or stuck behind a failed batch)
+            _stop = true;                     // releases the workers (all of them idle, or stuck behind a failed batch) and the sink thread
         }
         _cv.notify_all();
+        if (_sink.joinable()) _sink.join();
         for (Lane& ln : _lanes) if (ln.worker.joinable()) ln.worker.join();
         rethrow();
         _os.flush();
+        if (hostTiming())
+            fprintf(stderr, "[knz out] lanes %zu batch %zu B: caller copy-in %.2f ms, wait-lane %.2f, sink-write %.2f | workers upload-wait %.2f, kernels %.2f, order-wait %.2f, shift+download %.2f\n",
+                    _lanes.size(), _batchBytes, _tns[0] / 1e6, _tns[1] / 1e6, _tns[2] / 1e6, _tns[3] / 1e6, _tns[4] / 1e6, _tns[5] / 1e6, _tns[6] / 1e6);
     } catch (const IOException&) {
         setstate(std::ios::badbit);
         throw;
@@ -1348,6 +1554,7 @@ void CompressedInputStream::init(int tasks, const std::string& entropy, const st
         _entropyType = EntropyEncoderFactory::getType(entropy.c_str());
         _transformType = TransformFactory<byte>::getType(transform.c_str());
         _hosted = hostedStagesOf(_transformType, _hostIds);
+        _spreadCopies = chainIsHostBound(_transformType);
     }
     _batchBlocks = std::max(tasks, 64);               // clamped to 256 MiB / 2 GiB once the block size is known
     const char* e = getenv("KNZ_BATCH_BLOCKS");
@@ -1367,6 +1574,8 @@ void CompressedInputStream::init(int tasks, const std::string& entropy, const st
     _pprod = 0;
     _cons = 0; _rstop = false; _started = false; _cur = nullptr; _lastTaken = false; _tellBit = 0; _readBits = 0;
     _from = 1; _to = 0x7FFFFFFF; _nextBlockId = 1;
+    for (auto& t : _tns) t = 0;
+    if (!headerless) _spreadCopies = false;          // until the header says what the chain is
     { _is.clear(); const std::streamoff at = std::streamoff(_is.tellg()); _originBit = (at < 0) ? 0 : 8 * int64(at); _is.clear(); }
 }
 
@@ -1382,8 +1591,8 @@ CompressedInputStream::~CompressedInputStream()
 {
     stopReader();
     for (size_t i = 0; i < _ps.size(); i++) {
-        if (_prep[i].dIn) knz_hip_free(_prep[i].ctx, _prep[i].dIn);
-        if (_ps[i].dOut) knz_hip_free(_ps[i].ctx, _ps[i].dOut);
+        g_devPool.put(_prep[i].ctx, _prep[i].dIn, _prep[i].dInCap);
+        g_devPool.put(_ps[i].ctx, _ps[i].dOut, _ps[i].dOutCap);
         g_pinned.put(_ps[i].buf, _ps[i].cap); g_pinned.put(_prep[i].stage, _prep[i].stageCap);
     }
 }
@@ -1394,8 +1603,13 @@ bool CompressedInputStream::fetch(size_t minBytes)
     const size_t have = _comp.size() - size_t(_compBit >> 3);
     if (have >= minBytes) return true;
     if (_srcEof) return false;
-    size_t want = std::max<size_t>(minBytes - have, size_t(1) << 20);
+    // KNZ_READ_AHEAD bytes at least per read (default 1 MiB). Large pieces (16 MiB, which the C API's file buffer reads with several
+    // threads, FileInBuf::xsgetn) were measured and lost: the first batch waits for the whole piece (config 3 end to end: decompress
+    // 6.9-7.9 -> 5.3-5.7 GB/s), and the source is not what a lane waits for afterwards
+    static const size_t readAhead = []() { const char* e = getenv("KNZ_READ_AHEAD"); const long long v = e ? atoll(e) : 0; return v > 0 ? size_t(v) : (size_t(1) << 20); }();
+    size_t want = std::max<size_t>(minBytes - have, readAhead);
     const size_t old = _comp.size();
+    ScopedNs t_(_tns[0]);
     _comp.resize(old + want);
     _is.read(reinterpret_cast<char*>(&_comp[old]), std::streamsize(want));
     const size_t got = size_t(_is.gcount());
@@ -1434,6 +1648,7 @@ void CompressedInputStream::readHeader()
     try { EntropyEncoderFactory::getName(_entropyType); } catch (const std::invalid_argument&) { throw IOException("Invalid bitstream, unknown entropy type", Error::ERR_INVALID_CODEC); }
     _transformType = get(48);
     _hosted = hostedStagesOf(_transformType, _hostIds);
+    _spreadCopies = chainIsHostBound(_transformType);
     try { TransformFactory<byte>::getName(_transformType); } catch (const std::invalid_argument&) { throw IOException("Invalid bitstream, unknown transform type", Error::ERR_INVALID_CODEC); }
     _blockSize = int(get(28) << 4);
     if ((_blockSize < 1024) || (_blockSize > 1024 * 1024 * 1024)) throw IOException("Invalid bitstream, incorrect block size", Error::ERR_BLOCK_SIZE);
@@ -1478,7 +1693,7 @@ void CompressedInputStream::prepareBatch(Prep& pr)
     // is taken: the walk keeps positions relative to _comp, so nothing may rebase them while it runs.
     if ((_compBit >> 3) > (size_t(1) << 20)) {   // keep 16-byte alignment of the remainder
         const size_t drop = size_t(_compBit >> 3) & ~size_t(15);
-        _comp.erase(_comp.begin(), _comp.begin() + drop);
+        _comp.dropFront(drop);
         _compBit -= uint64(drop) * 8;
         _originBit += int64(drop) * 8;
     }
@@ -1526,14 +1741,13 @@ void CompressedInputStream::prepareBatch(Prep& pr)
         const size_t lastByte = size_t((pos + 7) >> 3);
         const size_t inBytes = lastByte - firstByte;
         if (pr.dInCap < inBytes + 64) {
-            if (pr.dIn) knz_hip_free(c, pr.dIn);
+            g_devPool.put(c, pr.dIn, pr.dInCap);
             pr.dIn = nullptr; pr.dInCap = 0;
-            devCheck(c, knz_hip_malloc(c, inBytes + 64 + (inBytes >> 2), &pr.dIn), "malloc");
-            pr.dInCap = inBytes + 64 + (inBytes >> 2);
+            pr.dIn = g_devPool.get(c, inBytes + 64 + (inBytes >> 2), &pr.dInCap);
         }
         // through page-locked staging: the pageable vector would be bounced by the runtime at a fraction of the PCIe rate
         if (pr.stageCap < inBytes) { g_pinned.put(pr.stage, pr.stageCap); pr.stage = nullptr; pr.stageCap = 0; pr.stage = g_pinned.get(inBytes, &pr.stageCap); }
-        memcpy(pr.stage, &_comp[firstByte], inBytes);
+        { ScopedNs t_(_tns[1]); parCopy(pr.stage, &_comp[firstByte], inBytes, _spreadCopies); }
         devCheck(c, knz_hip_memcpy_h2d_async(c, pr.dIn, pr.stage, inBytes, &pr.ticket), "h2d");
         pr.inBytes = inBytes;
         pr.startBit = _compBit - uint64(firstByte) * 8;
@@ -1561,14 +1775,14 @@ void CompressedInputStream::decodeBatch(Prep& pr, PSlot& sl)
     const size_t outCap = size_t(pr.nb) * size_t(_blockSize) + 64;
     // the slot is free, so the copy out of its device buffer (two batches ago) has been waited for
     if (sl.dOutCap < outCap) {
-        if (sl.dOut) knz_hip_free(c, sl.dOut);
+        g_devPool.put(c, sl.dOut, sl.dOutCap);
         sl.dOut = nullptr; sl.dOutCap = 0;
-        devCheck(c, knz_hip_malloc(c, outCap, &sl.dOut), "malloc");
-        sl.dOutCap = outCap;
+        sl.dOut = g_devPool.get(c, outCap, &sl.dOutCap);
     }
-    devCheck(c, knz_hip_copy_wait(c, pr.ticket), "h2d");
+    { ScopedNs t_(_tns[2]); devCheck(c, knz_hip_copy_wait(c, pr.ticket), "h2d"); }
     pr.ticket = 0;
     uint64_t outBytes = 0, endBit = 0;
+    ScopedNs t3_(_tns[3]);
     int64_t done = 0;
     if (_hosted) {
         // the device undoes its stages; the block comes back with its skip flags and the host undoes TEXT / UTF, last stage first
@@ -1718,6 +1932,7 @@ bool CompressedInputStream::advance()
         ensureStarted();
         PSlot* sl;
         {
+            ScopedNs t_(_tns[4]);
             std::unique_lock<std::mutex> l(_rmu);
             _rcv.wait(l, [&] { return _ps[size_t(_cons)].state == 2; });
             sl = &_ps[size_t(_cons)];
@@ -1734,7 +1949,8 @@ bool CompressedInputStream::advance()
         _tellBit = sl->endBit;
         _readBits = sl->consumedBits;
         if (sl->len != 0 && sl->ticket != 0) {               // the device-to-host copy the decoder thread queued
-            const int rc = knz_hip_copy_wait(sl->ctx, sl->ticket);
+            int rc;
+            { ScopedNs t_(_tns[5]); rc = knz_hip_copy_wait(sl->ctx, sl->ticket); }
             sl->ticket = 0;
             if (rc != 0) {
                 { std::lock_guard<std::mutex> l(_rmu); sl->state = 0; }
@@ -1762,7 +1978,7 @@ std::istream& CompressedInputStream::read(char* data, std::streamsize length)
             if (!advance()) { setstate(std::ios::eofbit); break; }
         }
         const size_t take = std::min<size_t>(size_t(remaining), _cur->len - _plainPos);
-        memcpy(data + _gcount, _cur->buf + _plainPos, take);
+        { ScopedNs t_(_tns[6]); parCopy(data + _gcount, _cur->buf + _plainPos, take, _spreadCopies); }
         _plainPos += take;
         _gcount += std::streamsize(take);
         remaining -= std::streamsize(take);
@@ -1824,6 +2040,9 @@ void CompressedInputStream::close()
     if (_closed) return;
     _closed = true;
     stopReader();
+    if (hostTiming())
+        fprintf(stderr, "[knz in] lanes %zu: reader source-read %.2f ms, stage-copy %.2f | decoders upload-wait %.2f, kernels %.2f | caller wait-batch %.2f, download-wait %.2f, copy-out %.2f\n",
+                _ps.size(), _tns[0] / 1e6, _tns[1] / 1e6, _tns[2] / 1e6, _tns[3] / 1e6, _tns[4] / 1e6, _tns[5] / 1e6, _tns[6] / 1e6);
     setstate(std::ios::eofbit);
 }
 
@@ -1836,25 +2055,96 @@ using namespace kanzi_amd;
 
 namespace {
 
+// The C API's sink and source: the caller's FILE. Large pieces go through the descriptor in slices, pwrite / pread from the helper
+// threads (the reference's FileOutputStream / FileInputStream work on the descriptor too, src/api/Compressor.cpp:226-229): a tmpfs
+// or page-cache copy runs at a few GB/s per thread, which is below what the device delivers. Anything that is not a regular file
+// opened without O_APPEND takes the stdio calls.
 class FileOutBuf : public std::streambuf {
 public:
-    explicit FileOutBuf(FILE* f) : _f(f) {}
+    explicit FileOutBuf(FILE* f) : _f(f), _bulk(false)
+    {
+        const int fd = fileno(f);
+        struct stat sb;
+        if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode)) {
+            const int fl = fcntl(fd, F_GETFL);
+            _bulk = fl >= 0 && !(fl & O_APPEND);
+        }
+    }
 protected:
-    std::streamsize xsputn(const char* s, std::streamsize n) override { return std::streamsize(fwrite(s, 1, size_t(n), _f)); }
+    std::streamsize xsputn(const char* s, std::streamsize n) override
+    {
+        // KNZ_PAR_WRITE=1: slices through pwrite. Off by default: writers of ONE file take its inode lock in turn, so on tmpfs / ext4
+        // four writers were half as fast as one fwrite (measured: 59 MB in 18.8 ms against 8.8 ms). Reads do scale (FileInBuf).
+        static const bool parWrite = getenv("KNZ_PAR_WRITE") != nullptr && atoi(getenv("KNZ_PAR_WRITE")) != 0;
+        const int parts = (_bulk && parWrite) ? parParts(size_t(n)) : 1;
+        if (parts > 1 && fflush(_f) == 0) {
+            const off_t at = ftello(_f);
+            const int fd = fileno(_f);
+            if (at >= 0) {
+                std::atomic<bool> ok(true);
+                const size_t total = size_t(n), slice = ((total / size_t(parts)) + 4095) & ~size_t(4095);
+                HelperPool::get().run(parts, [&](int i) {
+                    size_t a = std::min(total, size_t(i) * slice);
+                    const size_t b = (i == parts - 1) ? total : std::min(total, a + slice);
+                    while (a < b) {
+                        const ssize_t w = pwrite(fd, s + a, b - a, at + off_t(a));
+                        if (w <= 0) { ok = false; return; }
+                        a += size_t(w);
+                    }
+                });
+                if (!ok || fseeko(_f, at + off_t(total), SEEK_SET) != 0) return 0;
+                return n;
+            }
+        }
+        return std::streamsize(fwrite(s, 1, size_t(n), _f));
+    }
     int_type overflow(int_type ch) override { if (ch == traits_type::eof()) return traits_type::not_eof(ch); const char c = char(ch); return fwrite(&c, 1, 1, _f) == 1 ? ch : traits_type::eof(); }
     int sync() override { return fflush(_f) == 0 ? 0 : -1; }
 private:
     FILE* _f;
+    bool _bulk;
 };
 
 class FileInBuf : public std::streambuf {
 public:
-    explicit FileInBuf(FILE* f) : _f(f) {}
+    explicit FileInBuf(FILE* f) : _f(f), _bulk(false)
+    {
+        const int fd = fileno(f);
+        struct stat sb;
+        _bulk = fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode);
+    }
 protected:
-    std::streamsize xsgetn(char* s, std::streamsize n) override { return std::streamsize(fread(s, 1, size_t(n), _f)); }
+    std::streamsize xsgetn(char* s, std::streamsize n) override
+    {
+        static const bool parRead = !(getenv("KNZ_PAR_READ") != nullptr && atoi(getenv("KNZ_PAR_READ")) == 0);
+        if (_bulk && parRead && size_t(n) >= PAR_MIN) {
+            const off_t at = ftello(_f);                    // (accounts for what stdio holds in its buffer)
+            const int fd = fileno(_f);
+            struct stat sb;
+            if (at >= 0 && fstat(fd, &sb) == 0 && sb.st_size > at) {
+                const size_t total = std::min<size_t>(size_t(n), size_t(sb.st_size - at));
+                const int parts = std::max(1, parParts(total));
+                std::atomic<bool> ok(true);
+                const size_t slice = ((total / size_t(parts)) + 4095) & ~size_t(4095);
+                HelperPool::get().run(parts, [&](int i) {
+                    size_t a = std::min(total, size_t(i) * slice);
+                    const size_t b = (i == parts - 1) ? total : std::min(total, a + slice);
+                    while (a < b) {
+                        const ssize_t r = pread(fd, s + a, b - a, at + off_t(a));
+                        if (r <= 0) { ok = false; return; }
+                        a += size_t(r);
+                    }
+                });
+                if (ok && fseeko(_f, at + off_t(total), SEEK_SET) == 0) return std::streamsize(total);
+                if (fseeko(_f, at, SEEK_SET) != 0) return 0;      // a slice failed (the file shrank?): the plain way from where we were
+            }
+        }
+        return std::streamsize(fread(s, 1, size_t(n), _f));
+    }
     int_type underflow() override { const size_t r = fread(&_c, 1, 1, _f); if (r != 1) return traits_type::eof(); setg(&_c, &_c, &_c + 1); return traits_type::to_int_type(_c); }
 private:
     FILE* _f; char _c;
+    bool _bulk;
 };
 
 }  // namespace

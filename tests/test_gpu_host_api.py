@@ -405,3 +405,66 @@ def test_two_or_more_physical_devices(tmp_path, oracle, monkeypatch):
     o = d["one_corpus_sharded"]
     assert o["scaling"] == "strong" and o["block_count_ceiling"] == 2.0 and 0 < o["efficiency_vs_ceiling"] <= 1.2
     assert d["many_blocks_sharded"]["value"] > 0
+
+
+def test_large_transfers_through_the_host_layer(tmp_path, oracle, monkeypatch):
+    """Pieces of several MiB take the host layer's parallel paths (round 5): staging copies and the C API's file writes / reads are cut
+    into slices for the helper threads (pwrite / pread on the FILE's descriptor), the runs are appended by a sink thread, the source is
+    read 16 MiB ahead. Whatever the knobs, the file is the reference's and comes back as the input; a FILE opened for appending and a
+    file written in the middle of another (an offset that is not 0) take the same code."""
+    kz = _kanzi()
+    data = vectors.make(("mixed", 11 * (4 << 20) + 12345, 17))
+    bs = 4 << 20
+    rc, ref = oracle.compress(data, "NONE", "HUFFMAN", bs, orig_size=0, jobs=1)
+    assert rc == 0
+    for copy_threads, sink, ahead in [("4", "1", None), ("1", "0", None), ("3", "1", str(3 << 20)), ("8", "1", str(1 << 20))]:
+        # (the helper pool is created once per process with the first value; the other values still run the slicing arithmetic)
+        monkeypatch.setenv("KNZ_COPY_THREADS", copy_threads)
+        monkeypatch.setenv("KNZ_SINK_THREAD", sink)
+        if ahead:
+            monkeypatch.setenv("KNZ_READ_AHEAD", ahead)
+        path = str(tmp_path / "big.knz")
+        c = kz.Compressor(path, "NONE", "HUFFMAN", bs, 1)
+        for off in range(0, len(data), bs):
+            c.compress(data[off:off + bs])
+        total = c.close()
+        enc = open(path, "rb").read()
+        assert total == len(enc) and enc == ref, (copy_threads, sink)
+        d = kz.Decompressor(path, buffer_size=bs, jobs=1)
+        out = bytearray()
+        while True:
+            chunk = d.decompress(bs)
+            out += chunk
+            if len(chunk) < bs:
+                break
+        d.close()
+        assert bytes(out) == data, (copy_threads, sink)
+    # the C API on a FILE that does not start at offset 0 and on one opened for appending (no positional writes there)
+    import ctypes as C
+    L = kz.lib()
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    libc.fwrite.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.c_void_p]
+    for mode, lead in ((b"wb", b"0123456789"), (b"ab", b"")):
+        path = str(tmp_path / "off.knz")
+        if mode == b"ab":
+            open(path, "wb").write(b"leading bytes")
+            lead = b"leading bytes"
+        f = libc.fopen(path.encode(), mode)
+        if mode == b"wb":
+            libc.fwrite(lead, 1, len(lead), f)
+        cd = kz.cData(b"NONE", b"HUFFMAN", bs, 1, 0, 0)
+        ctx = C.c_void_p()
+        assert L.initCompressor(C.byref(cd), f, C.byref(ctx)) == 0
+        out = C.c_size_t(0)
+        for off in range(0, len(data), bs):
+            blk = data[off:off + bs]
+            assert L.compress(ctx, blk, len(blk), C.byref(out)) == 0
+        assert L.disposeCompressor(C.byref(ctx), C.byref(out)) == 0
+        libc.fclose(f)
+        got = open(path, "rb").read()
+        # (src/api/Compressor.cpp:218-224: the size field of the header is the size the DESTINATION had when the compressor was created)
+        want = ref if mode == b"wb" else oracle.compress(data, "NONE", "HUFFMAN", bs, orig_size=len(lead), jobs=1)[1]
+        assert got[:len(lead)] == lead and got[len(lead):] == want, mode
