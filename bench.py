@@ -30,6 +30,12 @@ import os
 import sys
 import time
 
+# HIP maps the streams of a process onto 4 hardware queues unless told otherwise; a context of this library runs the BWT stages of a
+# batch on three streams beside torch's, and the stream classes have six lanes with two copy streams each. Eight queues: +1.5 % on
+# the device-resident step, +5 % end to end (profiles/r05_host_layer_sweeps.txt). An application that embeds the library sets the same
+# variable before its first HIP call; the library does not touch the environment of its host process.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -589,7 +589,7 @@ private:
     std::vector<Prep> _prep;
     int _pprod;
     struct PSlot { knz_ctx* ctx; byte* buf; size_t cap; size_t len; int64 endBit; uint64 consumedBits; bool last; std::exception_ptr err;
-                   void* dOut; size_t dOutCap; uint64 ticket; int state; };                                                    // state: 0 free, 2 ready
+                   void* dOut; size_t dOutCap; uint64 ticket; int state; int device; };                                        // state: 0 free, 2 ready
     std::vector<PSlot> _ps;
     int _cons;
     std::thread _reader;

@@ -90,8 +90,8 @@ std::vector<int> laneDevices()
             }
             dev = g_defaultDevice;
         }
-        int lanes = 4;
-        if (const char* e = getenv("KNZ_LANES")) lanes = std::max(1, std::min(8, atoi(e)));
+        int lanes = 6;                               // three in the kernels (DeviceGate), the others moving bytes
+        if (const char* e = getenv("KNZ_LANES")) lanes = std::max(1, std::min(12, atoi(e)));
         v.assign(size_t(lanes), dev);
     }
     return v;
@@ -1052,7 +1052,7 @@ struct PinnedPool {
             size_t best = idle.size();
             for (size_t i = 0; i < idle.size(); i++)
                 if (idle[i].second >= bytes && (best == idle.size() || idle[i].second < idle[best].second)) best = i;
-            if (best != idle.size()) { void* p = idle[best].first; *cap = idle[best].second; idle.erase(idle.begin() + long(best)); return static_cast<byte*>(p); }
+            if (best != idle.size()) { void* p = idle[best].first; *cap = idle[best].second; idleBytes -= *cap; idle.erase(idle.begin() + long(best)); return static_cast<byte*>(p); }
         }
         void* p = nullptr;
         const size_t want = bytes + (bytes >> 3) + 4096;
@@ -1060,12 +1060,17 @@ struct PinnedPool {
         *cap = want;
         return static_cast<byte*>(p);
     }
+    // what idles here is bounded by bytes (2 GiB) and entries (64), not by a handful of buffers: a stream with six lanes has a
+    // dozen staging buffers, and pinning 16 MiB again costs milliseconds (with a pool of eight, every lane beyond the fourth paid
+    // that on every stream: the lane sweeps of round 5 got slower with every lane for this reason alone)
+    size_t idleBytes = 0;
     void put(byte* p, size_t cap)
     {
         if (!p) return;
         std::lock_guard<std::mutex> l(mu);
-        if (idle.size() >= 8) { knz_hip_host_free(p); return; }
+        if (idle.size() >= 64 || idleBytes + cap > (size_t(2) << 30)) { knz_hip_host_free(p); return; }
         idle.push_back(std::make_pair(static_cast<void*>(p), cap));
+        idleBytes += cap;
     }
 };
 PinnedPool g_pinned;
@@ -1108,6 +1113,42 @@ struct DevPool {
     }
 };
 DevPool g_devPool;
+
+// How many device calls of the stream classes run on one GPU at a time (KNZ_DEVICE_CONCURRENCY, default 3). A stream has more lanes
+// than that: three concurrent batches are what saturates the device (measured: 3, 4 and 6 concurrent two-block encodes all deliver
+// about 7.7 GB/s), and the lanes beyond them hold the batches that are being filled, uploaded, downloaded or written meanwhile --
+// with as many lanes as concurrent calls, every lane's kernels waited for its own staging traffic. First come, first served.
+struct DeviceGate {
+    std::mutex mu; std::condition_variable cv; int inUse = 0; uint64_t next = 0, serving = 0; int cap;
+    DeviceGate()
+    {
+        const char* e = getenv("KNZ_DEVICE_CONCURRENCY");
+        cap = e ? std::max(1, std::min(16, atoi(e))) : 3;
+    }
+    void acquire()
+    {
+        std::unique_lock<std::mutex> l(mu);
+        const uint64_t my = next++;
+        cv.wait(l, [&] { return my == serving && inUse < cap; });
+        serving++; inUse++;
+        cv.notify_all();
+    }
+    void release() { { std::lock_guard<std::mutex> l(mu); inUse--; } cv.notify_all(); }
+};
+struct GateHold {
+    DeviceGate& g;
+    explicit GateHold(DeviceGate& gate) : g(gate) { g.acquire(); }
+    ~GateHold() { g.release(); }
+};
+DeviceGate& gateOf(int device)
+{
+    static std::mutex mu;
+    static std::map<int, DeviceGate*> gates;
+    std::lock_guard<std::mutex> l(mu);
+    DeviceGate*& g = gates[device];
+    if (!g) g = new DeviceGate();
+    return *g;
+}
 }
 
 FetchBuf::~FetchBuf() { g_pinned.put(_p, _cap); }
@@ -1185,8 +1226,8 @@ void CompressedOutputStream::init(int tasks, const std::string& entropy, const s
     _headless = headerless; _closed = false; _headerDone = false;
     // Blocks per device call.  `jobs` only selects the reference's buffer-slot capacities in the bitstream; the
     // GPU wants many blocks per launch and the host wants several batches in flight (one per lane: the caller fills a staging
-    // slot while the lanes work), so by default a batch is 16 MiB (at least one block, at most 64; measured best with four lanes: short tail, decode batches overlap).
-    { const int64_t want = (int64_t(16) << 20) / int64_t(blockSize); _batchBlocks = int(std::min<int64_t>(64, std::max<int64_t>(1, want))); }
+    // slot while the lanes work), so by default a batch is 24 MiB (at least one block, at most 64; measured best with six lanes of which three are in the kernels at a time: short tail, decode batches overlap; round 4: 16 MiB with four lanes).
+    { const int64_t want = (int64_t(24) << 20) / int64_t(blockSize); _batchBlocks = int(std::min<int64_t>(64, std::max<int64_t>(1, want))); }
     const char* e = getenv("KNZ_BATCH_BLOCKS");
     if (e && atoi(e) > 0) _batchBlocks = atoi(e);
     // one device call takes at most 2 GiB of input (32-bit positions on the device side)
@@ -1413,6 +1454,8 @@ void CompressedOutputStream::submit(Lane& ln)
     { ScopedNs t_(_tns[3]); devCheck(c, knz_hip_copy_wait(c, ln.ticket), "h2d"); }          // queued by enqueue(), normally long complete
     ln.ticket = 0;
     uint64_t bits = 0;
+    GateHold* gate = new GateHold(gateOf(ln.device));       // released as soon as the kernels are done (below), whatever happens
+    std::unique_ptr<GateHold> gateOwner(gate);
     std::chrono::steady_clock::time_point tk0 = std::chrono::steady_clock::now();
     if (_hosted && n == 0) p.transform_type = 0;             // (the empty last batch: end marker only; the device call checks the chain before it looks at the size)
     if (_hosted && n > 0) {
@@ -1431,6 +1474,7 @@ void CompressedOutputStream::submit(Lane& ln)
     } else
     devCheck(c, knz_hip_encode_blocks(c, &p, static_cast<const uint8_t*>(ln.dIn), n, pro.bytes.empty() ? nullptr : pro.bytes.data(), uint32_t(pro.nbits),
                                       ln.firstBlock, ln.last ? 1 : 0, static_cast<uint8_t*>(ln.dOut), ln.dOutCap, &bits), "encode blocks");
+    gateOwner.reset();
     _tns[4] += uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tk0).count());
     // where the run starts: behind the runs of the batches before it, whose lengths are published in batch order
     uint64 start;
@@ -1562,9 +1606,11 @@ void CompressedInputStream::init(int tasks, const std::string& entropy, const st
     if (e && atoi(e) > 0) { _batchBlocks = atoi(e); _batchFromEnv = true; }
     _compBit = 0; _consumedBits = 0; _plainPos = 0; _gcount = 0; _srcEof = false;
     {
-        const std::vector<knz_ctx*> ctxs = openLanes(laneDevices());
+        const std::vector<int> devs = laneDevices();
+        const std::vector<knz_ctx*> ctxs = openLanes(devs);
         _ps.resize(ctxs.size()); _prep.resize(ctxs.size());
         for (size_t i = 0; i < ctxs.size(); i++) {
+            _ps[i].device = devs[i];
             _ps[i].ctx = ctxs[i]; _ps[i].buf = nullptr; _ps[i].cap = 0; _ps[i].len = 0; _ps[i].endBit = 0; _ps[i].consumedBits = 0; _ps[i].last = false; _ps[i].state = 0;
             _ps[i].dOut = nullptr; _ps[i].dOutCap = 0; _ps[i].ticket = 0;
             _prep[i].ctx = ctxs[i]; _prep[i].dIn = nullptr; _prep[i].dInCap = 0; _prep[i].stage = nullptr; _prep[i].stageCap = 0; _prep[i].inBytes = 0; _prep[i].startBit = 0;
@@ -1706,7 +1752,7 @@ void CompressedInputStream::prepareBatch(Prep& pr)
     const int64_t lim = (int64_t(1) << 31) / bsz - 1;
     const int wantBatch = _batchBlocks.load();
     int batch = (wantBatch > lim) ? int(lim < 1 ? 1 : lim) : wantBatch;
-    if (!_batchFromEnv.load()) batch = int(std::min<int64_t>(batch, std::max<int64_t>(1, (int64_t(16) << 20) / bsz)));
+    if (!_batchFromEnv.load()) batch = int(std::min<int64_t>(batch, std::max<int64_t>(1, (int64_t(24) << 20) / bsz)));
     if (_hosted) batch = 1;                                  // (the host undoes its stages block by block)
     while (nb < batch) {
         if (!fetch(size_t(((pos + 40) >> 3) + 1 - (_compBit >> 3)))) {
@@ -1782,6 +1828,7 @@ void CompressedInputStream::decodeBatch(Prep& pr, PSlot& sl)
     { ScopedNs t_(_tns[2]); devCheck(c, knz_hip_copy_wait(c, pr.ticket), "h2d"); }
     pr.ticket = 0;
     uint64_t outBytes = 0, endBit = 0;
+    GateHold gate_(gateOf(sl.device));
     ScopedNs t3_(_tns[3]);
     int64_t done = 0;
     if (_hosted) {

@@ -1,16 +1,11 @@
-OUT=gpurun_out/r05d; mkdir -p $OUT
+OUT=gpurun_out/r05h; mkdir -p $OUT
+export GPU_MAX_HW_QUEUES=8
 run() { # name config lanes batch env...
   n=$1; shift
   timeout 300 python tools/host_e2e_sweep.py "$@" > $OUT/$n.jsonl 2> $OUT/$n.err; echo "== $n $* rc=$?"; cat $OUT/$n.jsonl
   grep "knz \(out\|in\)" $OUT/$n.err | tail -2 | cut -c1-330
 }
-run a3 3 4,4 2 KNZ_SINK_THREAD=0 KNZ_COPY_THREADS=1 KNZ_PAR_READ=0 KNZ_READ_AHEAD=1048576
-run b3 3 4,4 2 KNZ_SINK_THREAD=1 KNZ_COPY_THREADS=1 KNZ_PAR_READ=0 KNZ_READ_AHEAD=1048576
-run c3 3 4,4 2 KNZ_SINK_THREAD=0 KNZ_COPY_THREADS=4 KNZ_PAR_READ=0 KNZ_READ_AHEAD=1048576
-run d3 3 4,4 2 KNZ_SINK_THREAD=0 KNZ_COPY_THREADS=1 KNZ_PAR_READ=0
-run e3 3 4,4 2 KNZ_SINK_THREAD=1 KNZ_COPY_THREADS=4
-run a2 2 4,4 0 KNZ_SINK_THREAD=0 KNZ_COPY_THREADS=1 KNZ_PAR_READ=0 KNZ_READ_AHEAD=1048576
-run b2 2 4,4 0 KNZ_SINK_THREAD=1 KNZ_COPY_THREADS=1 KNZ_PAR_READ=0 KNZ_READ_AHEAD=1048576
-run c2 2 4,4 0 KNZ_SINK_THREAD=0 KNZ_COPY_THREADS=4 KNZ_PAR_READ=0 KNZ_READ_AHEAD=1048576
-run d2 2 4,4 0 KNZ_SINK_THREAD=0 KNZ_COPY_THREADS=1 KNZ_PAR_READ=1
-run e2 2 4,4 0 KNZ_SINK_THREAD=1 KNZ_COPY_THREADS=4
+run g3 3 6 2,3,4,6 KNZ_DEVICE_CONCURRENCY=3
+run g2 3 6 3,4,6 KNZ_DEVICE_CONCURRENCY=2
+run g2l4 3 4 3,4 KNZ_DEVICE_CONCURRENCY=2
+run g1 3 4 4,6,9 KNZ_DEVICE_CONCURRENCY=1
