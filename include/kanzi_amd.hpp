@@ -24,6 +24,7 @@
 #define KANZI_AMD_HPP
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <exception>
@@ -511,6 +512,7 @@ private:
     // [0] copy into the staging slot [1] waiting for a free lane [2] writing to the sink; lane workers [3] upload wait [4] kernels
     // [5] waiting for the run's start position [6] bit shift + download
     std::atomic<uint64_t> _tns[8];
+    std::chrono::steady_clock::time_point _t0;      // construction (KNZ_HOST_TIMING=2 prints a line per batch, times relative to it)
     void init(int jobs, const std::string& entropy, const std::string& transform, int blockSize, int checksum, uint64 originalSize, bool headerless);
     bool drainOne(std::unique_lock<std::mutex>& l);
     void enqueue(bool last);

@@ -129,6 +129,8 @@ struct ScopedNs {
     ~ScopedNs() { acc += uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count()); }
 };
 bool hostTiming() { static const bool on = getenv("KNZ_HOST_TIMING") != nullptr && atoi(getenv("KNZ_HOST_TIMING")) != 0; return on; }
+bool hostTimeline() { static const bool on = getenv("KNZ_HOST_TIMING") != nullptr && atoi(getenv("KNZ_HOST_TIMING")) >= 2; return on; }
+double msSince(std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 
 // A few helper threads for the byte moving the host layer does on somebody's critical path: the copies between the caller's memory
 // and the page-locked staging slots, and the C API's file reads / writes (pread / pwrite of slices). KNZ_COPY_THREADS = threads a
@@ -1241,6 +1243,7 @@ void CompressedOutputStream::init(int tasks, const std::string& entropy, const s
     _fillLane = 0; _nextSeq = 0; _sinkSeq = 0; _pubSeq = 0; _cumBits = 0; _stop = false;
     _batchBytes = 0;
     for (auto& t : _tns) t = 0;
+    _t0 = std::chrono::steady_clock::now();
     { const char* st = getenv("KNZ_SINK_THREAD"); _sinkThread = !(st && atoi(st) == 0); }
     _spreadCopies = chainIsHostBound(_transformType);
     // lanes per device bounded by the block size: a lane holds a batch's input, output and the suffix sort's scratch (about 64
@@ -1333,6 +1336,7 @@ bool CompressedOutputStream::drainOne(std::unique_lock<std::mutex>& l)
         }
         _pendingBits = ln.last ? 0 : rem;
         _pendingByte = (rem && !ln.last) ? ln.out[full] : 0;
+        if (hostTimeline()) fprintf(stderr, "[knz out batch %lld] in the sink at %.2f ms\n", (long long)ln.seq, msSince(_t0));
     }
     l.lock();
     ln.state = 0;
@@ -1366,6 +1370,7 @@ void CompressedOutputStream::enqueue(bool last)
         std::unique_lock<std::mutex> l(_mu);
         ln.last = last;
         ln.seq = _nextSeq++;
+        if (hostTimeline()) fprintf(stderr, "[knz out batch %lld] enqueued at %.2f ms\n", (long long)ln.seq, msSince(_t0));
         ln.firstBlock = _blockId;
         _blockId += int64((ln.n + size_t(_blockSize) - 1) / size_t(_blockSize));
         ln.state = 1;
@@ -1454,7 +1459,9 @@ void CompressedOutputStream::submit(Lane& ln)
     { ScopedNs t_(_tns[3]); devCheck(c, knz_hip_copy_wait(c, ln.ticket), "h2d"); }          // queued by enqueue(), normally long complete
     ln.ticket = 0;
     uint64_t bits = 0;
+    const double tlUp = hostTimeline() ? msSince(_t0) : 0;
     GateHold* gate = new GateHold(gateOf(ln.device));       // released as soon as the kernels are done (below), whatever happens
+    const double tlGate = hostTimeline() ? msSince(_t0) : 0;
     std::unique_ptr<GateHold> gateOwner(gate);
     std::chrono::steady_clock::time_point tk0 = std::chrono::steady_clock::now();
     if (_hosted && n == 0) p.transform_type = 0;             // (the empty last batch: end marker only; the device call checks the chain before it looks at the size)
@@ -1475,6 +1482,7 @@ void CompressedOutputStream::submit(Lane& ln)
     devCheck(c, knz_hip_encode_blocks(c, &p, static_cast<const uint8_t*>(ln.dIn), n, pro.bytes.empty() ? nullptr : pro.bytes.data(), uint32_t(pro.nbits),
                                       ln.firstBlock, ln.last ? 1 : 0, static_cast<uint8_t*>(ln.dOut), ln.dOutCap, &bits), "encode blocks");
     gateOwner.reset();
+    const double tlKern = hostTimeline() ? msSince(_t0) : 0;
     _tns[4] += uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tk0).count());
     // where the run starts: behind the runs of the batches before it, whose lengths are published in batch order
     uint64 start;
@@ -1515,6 +1523,7 @@ void CompressedOutputStream::submit(Lane& ln)
         if (bits == 0 && r != 0) { ln.shiftR = r; ln.outBytes = 1; }       // (an empty run in the middle of a byte: only the shared byte)
         ln.state = 2;
     }
+    if (hostTimeline()) fprintf(stderr, "[knz out batch %lld] %zu B lane-uploaded %.2f gate %.2f kernels-done %.2f downloaded %.2f ms\n", (long long)ln.seq, n, tlUp, tlGate, tlKern, msSince(_t0));
     _cv.notify_all();
 }
 
@@ -1542,6 +1551,7 @@ void CompressedOutputStream::close()
         for (Lane& ln : _lanes) if (ln.worker.joinable()) ln.worker.join();
         rethrow();
         _os.flush();
+        if (hostTimeline()) fprintf(stderr, "[knz out] closed at %.2f ms\n", msSince(_t0));
         if (hostTiming())
             fprintf(stderr, "[knz out] lanes %zu batch %zu B: caller copy-in %.2f ms, wait-lane %.2f, sink-write %.2f | workers upload-wait %.2f, kernels %.2f, order-wait %.2f, shift+download %.2f\n",
                     _lanes.size(), _batchBytes, _tns[0] / 1e6, _tns[1] / 1e6, _tns[2] / 1e6, _tns[3] / 1e6, _tns[4] / 1e6, _tns[5] / 1e6, _tns[6] / 1e6);
