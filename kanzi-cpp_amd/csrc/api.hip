@@ -230,6 +230,7 @@ int knz_hip_tune(const char* name, int value)
 {
     if (name == nullptr) return -1;
     if (!strcmp(name, "mtf_tile")) return mtft_tune(value);
+    if (!strcmp(name, "mtf_chain")) return mtft_tune_chain(value);
     if (!strcmp(name, "lz_serial_decode")) { lz_serial_decode(value ? 1 : 0); return 0; }
     if (!strcmp(name, "bwt_split")) { bwt_split_knob().store(value < 1 ? 1 : (value > 4 ? 4 : value)); return 0; }
     return bwt_forward_tune(name, value);

@@ -24,6 +24,9 @@ namespace knz {
 // bytes per tile (one wave): 4096, or 1024 when the batch has fewer 4 KiB tiles than the device has wave slots -- the tile kernels
 // are one dependent chain per tile, so a small batch finishes in the time of ONE chain and shorter chains are what shortens it
 // (2 blocks of 8 MiB: k_mtf_f_rank 0.82 -> see DESIGN.md)
+// knob "mtf_chain" (KNZ_MTF_CHAIN=1): forward ranks by the byte-serial chain kernel of rounds 2-4 instead of the data-parallel one
+static std::atomic<int> g_mtfChainKnob([]() { const char* e = getenv("KNZ_MTF_CHAIN"); return e ? atoi(e) : 0; }());
+int mtft_tune_chain(int on) { g_mtfChainKnob.store(on ? 1 : 0); return 0; }
 static std::atomic<int> g_mtfTileKnob([]() { const char* e = getenv("KNZ_MTF_TILE"); return e ? atoi(e) : 0; }());      // 0 = by batch size; 1024 / 4096 force
 int mtft_tune(int tileBytes) { g_mtfTileKnob.store((tileBytes == 1024 || tileBytes == 4096) ? tileBytes : 0); return 0; }
 static inline u32 mtf_tile_bytes(int nBlocks, u32 maxLen)
@@ -95,7 +98,24 @@ __global__ __launch_bounds__(64) void k_mtf_f_last(XfView v, int perTiles, u32* 
     for (int i = lane; i < 256; i += 64) last[i] = 0;
     __syncthreads();
     const u32 end = (tbase + MT < n) ? tbase + MT : n;
-    for (u32 i = tbase + lane; i < end; i += 64) atomicMax(&last[s[i]], i + 1);
+    if ((reinterpret_cast<uintptr_t>(s) & 3) == 0) {
+        // four bytes per lane; a byte that is followed by its like is not the last of its symbol (behind a BWT most bytes are), the
+        // fourth is always entered (its successor sits in another lane)
+        const u32* s4 = reinterpret_cast<const u32*>(s + tbase);
+        const u32 full = (end - tbase) / 4;
+        for (u32 q = (u32)lane; q < full; q += 64) {
+            const u32 x = s4[q];
+            const u32 i = tbase + 4 * q;
+            const u32 b0 = x & 0xFF, b1 = (x >> 8) & 0xFF, b2 = (x >> 16) & 0xFF, b3 = x >> 24;
+            if (b0 != b1) atomicMax(&last[b0], i + 1);
+            if (b1 != b2) atomicMax(&last[b1], i + 2);
+            if (b2 != b3) atomicMax(&last[b2], i + 3);
+            atomicMax(&last[b3], i + 4);
+        }
+        for (u32 i = tbase + 4 * full + (u32)lane; i < end; i += 64) atomicMax(&last[s[i]], i + 1);
+    } else {
+        for (u32 i = tbase + lane; i < end; i += 64) atomicMax(&last[s[i]], i + 1);
+    }
     __syncthreads();
     u32* o = tileLast + ((size_t)b * perTiles + blockIdx.x) * 256;
     for (int i = lane; i < 256; i += 64) o[i] = last[i];
@@ -238,6 +258,148 @@ __global__ __launch_bounds__(64) void k_mtf_f_rank(XfView v, int perTiles, const
         if (lane == 0) dst[k] = (u8)(4 * lane0 + byteIdx);
         w = mtf_rotate(w, lane, lane0, ((hz0 & (0u - hz0)) << 1) - 1u, c << 24);
     }
+}
+
+// ---- forward ranks, data parallel inside the tile (round 5) -------------------------------------------------------------------
+// k_mtf_f_rank walks a tile byte by byte: one dependent chain of ~14 instructions per byte that changes the front of the list. The
+// rank of a byte does not need the list, only counts: with j the previous occurrence of s[i],
+//     rank(i) = number of distinct symbols in s(j, i)                      = #{k in (j, i) : prev(k) <= j}
+// (k is the first occurrence of its symbol inside the window iff the occurrence before it lies at or in front of j). For a CHUNK of
+// 64 consecutive bytes, one per lane, with v = (previous occurrence inside the chunk) + 1, 0 when there is none, this is
+//     rank(i) = #{k < i : v(k) <= v(i)} - v(i)
+// (every k <= j has v(k) <= k <= j, which is where the subtracted term comes from; a byte that repeats its predecessor gets 0 by the
+// same formula) -- a count over earlier lanes with a smaller or equal 6-bit value: six ballots. A symbol that is new to the chunk
+// starts from its place L in the list at the chunk's start and has been overtaken by the symbols that were behind it and came
+// earlier in the chunk: rank(i) = L(s[i]) + #{first occurrences k < i : L(s[k]) > L(s[i])}, eight ballots over the lanes that are
+// first occurrences. The list itself is only ever needed as "place of symbol c" (a 256-byte table per wave): after the chunk its
+// distinct symbols stand in front in order of their last occurrence, and every other symbol has moved back by the number of chunk
+// symbols that were behind it. About 300 instructions per 64 bytes, none of them on a chain longer than the chunk; the result is the
+// reference's byte for byte (transform/SBRT.cpp:46-97), checked against the chain kernel and the oracle in the emulator.
+__device__ __forceinline__ u32 mtf_popc64(u64 m) { return (u32)__popcll((unsigned long long)m); }
+
+template <u32 MT>
+__global__ __launch_bounds__(64) void k_mtf_f_rank_par(XfView v, int perTiles, const u32* __restrict__ tileState, u32 segT, u32 nSeg,
+                                                       const u32* __restrict__ segMax)
+{
+    const int b = blockIdx.y;
+    const u32 n = (v.len[b] <= v.cap[b]) ? v.len[b] : 0;
+    const u32 tbase = blockIdx.x * MT;
+    if (tbase >= n) return;
+    const u8* s = v.src[b];
+    u8* d = v.dst[b];
+    __shared__ u32 keys[256];
+    __shared__ u32 posW[64];                 // byte c = place of symbol c in the list
+    __shared__ u32 Mw[8], Sx[8];             // places the chunk's symbols held (bit map), set bits in the words above
+    __shared__ u32 tileW[MT / 4];            // the tile: symbols in, ranks out
+    const int lane = lane_id();
+    const u32* st = tileState + ((size_t)b * perTiles + blockIdx.x) * 256;
+    const u32* sg = segMax + ((size_t)b * nSeg + blockIdx.x / segT) * 256;
+    for (int i = lane; i < 256; i += 64) { const u32 x = st[i], y = sg[i]; keys[i] = x > y ? x : y; }
+    const u32 cnt = (n - tbase < MT) ? (n - tbase) : MT;
+    const u8* src = s + tbase;
+    u8* dst = d + tbase;
+    const bool al = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 3) == 0;
+    u8* tileB = reinterpret_cast<u8*>(tileW);
+    if (al) { for (u32 q = (u32)lane; q < (cnt + 3) / 4; q += 64) tileW[q] = reinterpret_cast<const u32*>(src)[q]; }   // (the block's buffer is padded)
+    else { for (u32 q = (u32)lane; q < cnt; q += 64) tileB[q] = src[q]; }
+    __syncthreads();
+    u8* posB = reinterpret_cast<u8*>(posW);
+    // start list: symbols by last occurrence, latest first; never-seen symbols (key 0) ascending. Keys made unique first (a block has
+    // at most 2^30 positions), so that a place is one compare per other symbol.
+    for (int i = lane; i < 256; i += 64) { const u32 x = keys[i]; keys[i] = x ? x + 256u : 255u - (u32)i; }
+    __syncthreads();
+    {
+        const u32 k0 = keys[lane], k1 = keys[lane + 64], k2 = keys[lane + 128], k3 = keys[lane + 192];
+        u32 r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        for (int q = 0; q < 256; q++) {
+            const u32 kq = keys[q];
+            r0 += (kq > k0) ? 1u : 0u; r1 += (kq > k1) ? 1u : 0u; r2 += (kq > k2) ? 1u : 0u; r3 += (kq > k3) ? 1u : 0u;
+        }
+        posB[lane] = (u8)r0; posB[lane + 64] = (u8)r1; posB[lane + 128] = (u8)r2; posB[lane + 192] = (u8)r3;
+    }
+    __syncthreads();
+    const u64 below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const u64 above = (lane == 63) ? 0ull : (~0ull << (lane + 1));
+    for (u32 k = 0; k < cnt; k += 64) {
+        const bool valid = k + (u32)lane < cnt;
+        const u32 c = valid ? (u32)tileB[k + (u32)lane] : 0u;
+        u64 peers = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 8; bit++) {
+            const bool one = (c >> bit) & 1u;
+            const u64 bal = __ballot(valid && one);
+            peers &= one ? bal : ~bal;
+        }
+        const u64 pm = peers & below;
+        const u32 vv = pm ? 64u - (u32)__clzll((long long)pm) : 0u;            // previous occurrence in the chunk + 1
+        u32 rank;
+        {
+            u64 P = below;
+            u32 C = 0;
+#pragma unroll
+            for (int bit = 5; bit >= 0; bit--) {
+                const bool one = (vv >> bit) & 1u;
+                const u64 B = __ballot(one);
+                if (one) { C += mtf_popc64(P & ~B); P &= B; } else P &= ~B;
+            }
+            rank = C + mtf_popc64(P) - vv;
+        }
+        const bool first = valid && vv == 0;
+        const u32 Lc = posB[c];
+        const u64 F = __ballot(first);
+        const u32 nF = mtf_popc64(F);
+        if (nF <= 16) {
+            // few new symbols (what the output of a BWT looks like): one step per new symbol, lanes behind it compare places
+            u32 G = 0;
+            u64 rem = F;
+            while (rem) {
+                const int kf = __builtin_ctzll((unsigned long long)rem);
+                rem &= rem - 1;
+                const u32 Lk = (u32)__builtin_amdgcn_readlane((int)Lc, kf);
+                G += (Lk > Lc && lane > kf) ? 1u : 0u;
+            }
+            if (first) rank = Lc + G;
+        } else {
+            u64 Q = F & below;
+            u32 G = 0;
+#pragma unroll
+            for (int bit = 7; bit >= 0; bit--) {
+                const bool one = (Lc >> bit) & 1u;
+                const u64 B = __ballot(first && one);
+                if (one) Q &= B; else { G += mtf_popc64(Q & B); Q &= ~B; }
+            }
+            if (first) rank = Lc + G;
+        }
+        if (valid) tileB[k + (u32)lane] = (u8)rank;
+        // The list behind the chunk. When the chunk's symbols held the front places anyway (the usual case behind a BWT: the same few
+        // symbols come again and again) nobody else moves; else every symbol moves back by the chunk symbols that were behind it.
+        if (__ballot(first && Lc >= nF) != 0) {
+            if (lane < 8) Mw[lane] = 0;
+            __syncthreads();
+            if (first) atomicOr(&Mw[Lc >> 5], 1u << (Lc & 31));
+            __syncthreads();
+            if (lane < 8) { u32 a = 0; for (int w = lane + 1; w < 8; w++) a += (u32)__popc(Mw[w]); Sx[lane] = a; }
+            __syncthreads();
+            const u32 pw = posW[lane];                // places of the symbols 4 * lane .. 4 * lane + 3
+            u32 npw = 0;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const u32 p = (pw >> (8 * t)) & 0xFFu;
+                const u32 w = p >> 5;
+                const u32 add = Sx[w] + (u32)__popc(Mw[w] & ~((2u << (p & 31)) - 1u));
+                npw |= ((p + add) & 0xFFu) << (8 * t);
+            }
+            posW[lane] = npw;
+            __syncthreads();
+        }
+        const bool last = valid && (peers & above) == 0;
+        const u64 Lm = __ballot(last);
+        if (last) posB[c] = (u8)mtf_popc64(Lm & above);
+        __syncthreads();
+    }
+    __syncthreads();
+    if (al && (cnt & 3) == 0) { for (u32 q = (u32)lane; q < cnt / 4; q += 64) reinterpret_cast<u32*>(dst)[q] = tileW[q]; }
+    else { for (u32 q = (u32)lane; q < cnt; q += 64) dst[q] = tileB[q]; }
 }
 
 // inverse, pass 1: symbolic decode from the identity list; ids -> dst, final list (ids) -> tilePerm
@@ -414,7 +576,9 @@ static void mtft_forward_t(hipStream_t s, const XfStage& st)
     { KScope ks_("k_mtf_f_last"); hipLaunchKernelGGL((k_mtf_f_last<MT>), grid, dim3(64), 0, s, v, perTiles, tileLast); }
     { KScope ks_("k_mtf_f_scan"); hipLaunchKernelGGL((k_mtf_f_scan<MT>), dim3(nSeg, st.nBlocks), dim3(256), 0, s, tileLast, perTiles, segT, nSeg, st.len, segMax);
       hipLaunchKernelGGL(k_mtf_f_scan2, dim3(st.nBlocks), dim3(256), 0, s, segMax, nSeg); }
-    { KScope ks_("k_mtf_f_rank"); hipLaunchKernelGGL((k_mtf_f_rank<MT>), grid, dim3(64), 0, s, v, perTiles, tileLast, segT, nSeg, segMax); }
+    { KScope ks_("k_mtf_f_rank");
+      if (g_mtfChainKnob.load()) hipLaunchKernelGGL((k_mtf_f_rank<MT>), grid, dim3(64), 0, s, v, perTiles, tileLast, segT, nSeg, segMax);
+      else hipLaunchKernelGGL((k_mtf_f_rank_par<MT>), grid, dim3(64), 0, s, v, perTiles, tileLast, segT, nSeg, segMax); }
 }
 
 void launch_mtft_forward(hipStream_t s, const XfStage& st)

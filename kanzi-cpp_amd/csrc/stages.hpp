@@ -70,6 +70,7 @@ void launch_mtft_forward(hipStream_t s, const XfStage& st);
 void launch_mtft_inverse(hipStream_t s, const XfStage& st);
 size_t zrlt_scratch_u32(int nBlocks, u32 maxLen);
 size_t mtft_scratch_u32(int nBlocks, u32 maxLen);
+int mtft_tune_chain(int on);                                 // 1 = forward ranks by the byte-serial chain kernel (knz_hip_tune "mtf_chain")
 int mtft_tune(int tileBytes);                                // 0 = tile size by batch size, 1024 / 4096 force it (knz_hip_tune "mtf_tile")
 
 // bwt.hip (these synchronise the stream: active-set sizes are read back through h_pinned)

@@ -181,11 +181,20 @@ def test_mtft_kernels_emulated(tmp_path):
     blocks = [c.text(300000, 1)[:287000], bytes(9000), rng.integers(0, 256, 4096, dtype=np.uint8).tobytes(), rng.integers(0, 256, 4097, dtype=np.uint8).tobytes(),
               c.mixed(300000, 2)[250000:270481], b"a", b"abracadabra", bytes(range(256)) * 33, rng.integers(0, 3, 12289, dtype=np.uint8).tobytes(),
               c.text(20000, 9)[:16384]]
+    # round 5: shapes for the data-parallel forward kernel (k_mtf_f_rank_par: ranks from counts over the 64 bytes of a chunk) -- every symbol
+    # once per chunk, one symbol per chunk, two symbols alternating, 64 distinct symbols cycling with period 65 (a chunk border inside every
+    # period), all 256 symbols in descending order, a block that ends inside a chunk
+    blocks += [bytes(range(64)) * 200, b"z" * 5000, b"xy" * 3000, bytes(list(range(65)) * 130), bytes(range(255, -1, -1)) * 20,
+               rng.integers(0, 256, 64 * 7 + 13, dtype=np.uint8).tobytes(), rng.integers(0, 8, 4096 * 2 + 63, dtype=np.uint8).tobytes()]
     path = str(tmp_path / "mtft.bin")
     write_case(path, blocks)
     for order in ("0", "2"):
-        r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900, env=dict(os.environ, HIPEMU_ORDER=order))
-        assert r.returncode == 0, (order, r.stdout[-2000:] + r.stderr[-2000:])
+        for chain in ("0", "1"):          # KNZ_MTF_CHAIN=1: the byte-serial forward kernel of rounds 2-4
+            r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900, env=dict(os.environ, HIPEMU_ORDER=order, KNZ_MTF_CHAIN=chain))
+            assert r.returncode == 0, (order, chain, r.stdout[-2000:] + r.stderr[-2000:])
+    # 1 KiB tiles (what small batches get)
+    r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900, env=dict(os.environ, KNZ_MTF_TILE="1024"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_huffman_decoder_kernels_emulated(tmp_path):
