@@ -297,6 +297,15 @@ __global__ __launch_bounds__(256) void k_zrlt_i_lastnonff(XfView v, int per, u32
     __syncthreads();
     const u32 i0 = base + threadIdx.x * ZPT;
     u32 mine = 0;
+    if (ZPT == 16 && i0 + ZPT <= n && ((reinterpret_cast<uintptr_t>(s) + i0) & 15) == 0) {
+        // the thread's 16 bytes as one load; the last byte that is not 0xFF = the highest zero bit of the inverted words
+        const uint4 x = *reinterpret_cast<const uint4*>(s + i0);
+        const u32 a = ~x.x, bq = ~x.y, cq = ~x.z, dq = ~x.w;
+        if (dq) mine = i0 + 12 + (31u - (u32)__clz((int)dq)) / 8 + 1;
+        else if (cq) mine = i0 + 8 + (31u - (u32)__clz((int)cq)) / 8 + 1;
+        else if (bq) mine = i0 + 4 + (31u - (u32)__clz((int)bq)) / 8 + 1;
+        else if (a) mine = i0 + (31u - (u32)__clz((int)a)) / 8 + 1;
+    } else
     for (u32 k = 0; k < ZPT; k++) { const u32 i = i0 + k; if (i < n && s[i] != 0xFF) mine = i + 1; }
     if (mine) atomicMax(&m, mine);
     __syncthreads();
@@ -357,11 +366,21 @@ __global__ __launch_bounds__(256) void k_zrlt_i_pass(XfView v, int per, const u3
     const u32 i0 = base + threadIdx.x * ZPT;
     u8 c[ZPT];
     u32 lastNonFF = 0;               // position+1 of last non-FF within my bytes
+    if (ZPT == 16 && i0 + ZPT <= n && ((reinterpret_cast<uintptr_t>(s) + i0) & 15) == 0) {
+        const uint4 x = *reinterpret_cast<const uint4*>(s + i0);       // the thread's 16 bytes as one load
+        const u32 w[4] = { x.x, x.y, x.z, x.w };
 #pragma unroll
-    for (u32 k = 0; k < ZPT; k++) {
-        const u32 i = i0 + k;
-        c[k] = (i < n) ? s[i] : (u8)2;
-        if (i < n && c[k] != 0xFF) lastNonFF = i + 1;
+        for (u32 k = 0; k < ZPT; k++) {
+            c[k] = (u8)(w[k >> 2] >> (8 * (k & 3)));
+            if (c[k] != 0xFF) lastNonFF = i0 + k + 1;
+        }
+    } else {
+#pragma unroll
+        for (u32 k = 0; k < ZPT; k++) {
+            const u32 i = i0 + k;
+            c[k] = (i < n) ? s[i] : (u8)2;
+            if (i < n && c[k] != 0xFF) lastNonFF = i + 1;
+        }
     }
     // exclusive prefix max over threads of lastNonFF
     scan[threadIdx.x] = lastNonFF;
