@@ -607,6 +607,7 @@ private:
     uint64 _readBits;
     std::streamsize _gcount;
     std::vector<Listener<Event>*> _listeners;
+    std::chrono::steady_clock::time_point _t0;      // see CompressedOutputStream
     // see CompressedOutputStream: reader thread [0] reading the source [1] prefix walk + staging copy; decoder threads [2] upload
     // wait [3] kernels; caller's thread [4] waiting for a decoded batch [5] download wait [6] copy into the caller's buffer
     std::atomic<uint64_t> _tns[8];

@@ -1631,6 +1631,7 @@ void CompressedInputStream::init(int tasks, const std::string& entropy, const st
     _cons = 0; _rstop = false; _started = false; _cur = nullptr; _lastTaken = false; _tellBit = 0; _readBits = 0;
     _from = 1; _to = 0x7FFFFFFF; _nextBlockId = 1;
     for (auto& t : _tns) t = 0;
+    _t0 = std::chrono::steady_clock::now();
     if (!headerless) _spreadCopies = false;          // until the header says what the chain is
     { _is.clear(); const std::streamoff at = std::streamoff(_is.tellg()); _originBit = (at < 0) ? 0 : 8 * int64(at); _is.clear(); }
 }
@@ -1815,6 +1816,7 @@ void CompressedInputStream::prepareBatch(Prep& pr)
     pr.endBit = _originBit + int64(_compBit);
     pr.consumedBits = _consumedBits;
     pr.last = sawEnd || nb == 0;
+    if (hostTimeline()) fprintf(stderr, "[knz in batch] %d blocks, %zu B prepared (upload queued) at %.2f ms\n", nb, pr.inBytes, msSince(_t0));
 }
 
 // decoder thread: the kernels over a prepared batch; the plain bytes start their way back into `sl`
@@ -1838,7 +1840,11 @@ void CompressedInputStream::decodeBatch(Prep& pr, PSlot& sl)
     { ScopedNs t_(_tns[2]); devCheck(c, knz_hip_copy_wait(c, pr.ticket), "h2d"); }
     pr.ticket = 0;
     uint64_t outBytes = 0, endBit = 0;
+    const double tlUp = hostTimeline() ? msSince(_t0) : 0;
     GateHold gate_(gateOf(sl.device));
+    const double tlGate = hostTimeline() ? msSince(_t0) : 0;
+    struct TlEnd { bool on; double a, b; std::chrono::steady_clock::time_point t0; int nb;
+                   ~TlEnd() { if (on) fprintf(stderr, "[knz in batch] %d blocks uploaded %.2f gate %.2f kernels-done (download queued) %.2f ms\n", nb, a, b, msSince(t0)); } } tlEnd{ hostTimeline(), tlUp, tlGate, _t0, pr.nb };
     ScopedNs t3_(_tns[3]);
     int64_t done = 0;
     if (_hosted) {
@@ -2021,6 +2027,7 @@ bool CompressedInputStream::advance()
             continue;
         }
         _cur = sl;
+        if (hostTimeline()) fprintf(stderr, "[knz in batch] %zu B handed to the caller at %.2f ms\n", sl->len, msSince(_t0));
         return true;
     }
 }
@@ -2097,6 +2104,7 @@ void CompressedInputStream::close()
     if (_closed) return;
     _closed = true;
     stopReader();
+    if (hostTimeline()) fprintf(stderr, "[knz in] closed at %.2f ms\n", msSince(_t0));
     if (hostTiming())
         fprintf(stderr, "[knz in] lanes %zu: reader source-read %.2f ms, stage-copy %.2f | decoders upload-wait %.2f, kernels %.2f | caller wait-batch %.2f, download-wait %.2f, copy-out %.2f\n",
                 _ps.size(), _tns[0] / 1e6, _tns[1] / 1e6, _tns[2] / 1e6, _tns[3] / 1e6, _tns[4] / 1e6, _tns[5] / 1e6, _tns[6] / 1e6);

@@ -1,4 +1,4 @@
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "zrlt or transform_stage or stream_golden or config3 or ragged or capacity" 2>&1 | tail -3
-timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu --no-e2e 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['roofline']['kernels_ms']; print('bench3', d['value'], d['ms_per_step'], {x:k[x] for x in k if 'zrlt' in x}, d['roofline']['stages_ms'])"
+OUT=gpurun_out/r05u; mkdir -p $OUT
+export GPU_MAX_HW_QUEUES=8
+KNZ_HOST_TIMING=2 timeout 300 python tools/host_e2e_sweep.py 3 6 0 > $OUT/tl.jsonl 2> $OUT/tl.err
+cat $OUT/tl.jsonl; grep "knz in" $OUT/tl.err | tail -34 | cut -c1-200
