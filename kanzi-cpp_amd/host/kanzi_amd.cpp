@@ -1103,13 +1103,16 @@ struct DevPool {
         *cap = bytes;
         return p;
     }
+    // kept per context: at most 12 buffers and 1 GiB, nothing above 256 MiB (a stream with 1 GiB blocks gives its memory back)
     void put(knz_ctx* c, void* p, size_t cap)
     {
         if (!p) return;
-        {
+        if (cap <= (size_t(256) << 20)) {
             std::lock_guard<std::mutex> l(mu);
             auto& v = idle[c];
-            if (v.size() < 12) { v.push_back(std::make_pair(p, cap)); return; }
+            size_t held = 0;
+            for (auto& e : v) held += e.second;
+            if (v.size() < 12 && held + cap <= (size_t(1) << 30)) { v.push_back(std::make_pair(p, cap)); return; }
         }
         knz_hip_free(c, p);
     }
