@@ -590,6 +590,7 @@ private:
                   int64 endBit; uint64 consumedBits; std::exception_ptr err; uint64 ticket; int state; };                    // state: 0 free, 1 prepared
     std::vector<Prep> _prep;
     int _pprod;
+    std::vector<int> _activeIdx;  // the lanes that get batches, in turn (per device bounded by the block size once it is known)
     struct PSlot { knz_ctx* ctx; byte* buf; size_t cap; size_t len; int64 endBit; uint64 consumedBits; bool last; std::exception_ptr err;
                    void* dOut; size_t dOutCap; uint64 ticket; int state; int device; };                                        // state: 0 free, 2 ready
     std::vector<PSlot> _ps;

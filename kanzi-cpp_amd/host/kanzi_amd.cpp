@@ -1631,6 +1631,8 @@ void CompressedInputStream::init(int tasks, const std::string& entropy, const st
         }
     }
     _pprod = 0;
+    _activeIdx.clear();
+    for (size_t i = 0; i < _ps.size(); i++) _activeIdx.push_back(int(i));
     _cons = 0; _rstop = false; _started = false; _cur = nullptr; _lastTaken = false; _tellBit = 0; _readBits = 0;
     _from = 1; _to = 0x7FFFFFFF; _nextBlockId = 1;
     for (auto& t : _tns) t = 0;
@@ -1898,10 +1900,10 @@ void CompressedInputStream::readerLoop()
     for (;;) {
         {
             std::unique_lock<std::mutex> l(_rmu);
-            _rcv.wait(l, [&] { return _rstop || _prep[_pprod].state == 0; });
+            _rcv.wait(l, [&] { return _rstop || _prep[size_t(_activeIdx[size_t(_pprod)])].state == 0; });
             if (_rstop) return;
         }
-        Prep& pr = _prep[_pprod];
+        Prep& pr = _prep[size_t(_activeIdx[size_t(_pprod)])];
         pr.err = nullptr; pr.last = false;
         try {
             prepareBatch(pr);
@@ -1913,7 +1915,7 @@ void CompressedInputStream::readerLoop()
         {
             std::lock_guard<std::mutex> l(_rmu);
             pr.state = 1;
-            _pprod = (_pprod + 1) % int(_prep.size());
+            _pprod = (_pprod + 1) % int(_activeIdx.size());
         }
         _rcv.notify_all();
         if (last) return;
@@ -1960,9 +1962,19 @@ void CompressedInputStream::ensureStarted()
     _readBits = _consumedBits;
     _rstop = false;
     _started = true;
+    // lanes per device bounded by the block size, as in CompressedOutputStream: a lane holds a batch (at least one block), its output
+    // and the inverse stages' scratch, so that with 1 GiB blocks one lane per GPU is what fits comfortably, with blocks up to 256 MiB
+    // four. The block size is known now (header read, or given); lanes beyond the bound get no batches.
+    {
+        const size_t perDev = std::max<size_t>(1, (size_t(1) << 30) / size_t(std::max(_blockSize, 1)));
+        std::map<int, size_t> seen;
+        _activeIdx.clear();
+        for (size_t i = 0; i < _ps.size(); i++) if (seen[_ps[i].device]++ < perDev) _activeIdx.push_back(int(i));
+        if (_activeIdx.empty()) _activeIdx.push_back(0);
+    }
     _reader = std::thread(&CompressedInputStream::readerLoop, this);
     _decoders.clear();
-    for (size_t i = 0; i < _ps.size(); i++) _decoders.emplace_back(&CompressedInputStream::decoderLoop, this, int(i));
+    for (int i : _activeIdx) _decoders.emplace_back(&CompressedInputStream::decoderLoop, this, i);
 }
 
 void CompressedInputStream::stopReader()
@@ -2000,9 +2012,9 @@ bool CompressedInputStream::advance()
         {
             ScopedNs t_(_tns[4]);
             std::unique_lock<std::mutex> l(_rmu);
-            _rcv.wait(l, [&] { return _ps[size_t(_cons)].state == 2; });
-            sl = &_ps[size_t(_cons)];
-            _cons = (_cons + 1) % int(_ps.size());
+            _rcv.wait(l, [&] { return _ps[size_t(_activeIdx[size_t(_cons)])].state == 2; });
+            sl = &_ps[size_t(_activeIdx[size_t(_cons)])];
+            _cons = (_cons + 1) % int(_activeIdx.size());
         }
         if (sl->last) _lastTaken = true;
         if (sl->err) {
