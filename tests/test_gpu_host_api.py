@@ -417,10 +417,14 @@ def test_large_transfers_through_the_host_layer(tmp_path, oracle, monkeypatch):
     bs = 4 << 20
     rc, ref = oracle.compress(data, "NONE", "HUFFMAN", bs, orig_size=0, jobs=1)
     assert rc == 0
-    for copy_threads, sink, ahead in [("4", "1", None), ("1", "0", None), ("3", "1", str(3 << 20)), ("8", "1", str(1 << 20))]:
-        # (the helper pool is created once per process with the first value; the other values still run the slicing arithmetic)
+    for copy_threads, sink, ahead, lanes, gate in [("4", "1", None, "6", "3"), ("1", "0", None, "1", "1"), ("3", "1", str(3 << 20), "12", "2"),
+                                                   ("8", "1", str(1 << 20), "3", "5")]:
+        # (the helper pool and the device gate are created once per process with the first values; the other values still run the
+        # slicing arithmetic, and the lane count is read per stream: 1, 3, 6 and 12 lanes behind the gate)
         monkeypatch.setenv("KNZ_COPY_THREADS", copy_threads)
         monkeypatch.setenv("KNZ_SINK_THREAD", sink)
+        monkeypatch.setenv("KNZ_LANES", lanes)
+        monkeypatch.setenv("KNZ_DEVICE_CONCURRENCY", gate)
         if ahead:
             monkeypatch.setenv("KNZ_READ_AHEAD", ahead)
         path = str(tmp_path / "big.knz")
