@@ -382,6 +382,102 @@ __global__ __launch_bounds__(256) void k_bwt_i_jump(const u32* __restrict__ next
     nextOut[j] = nextIn[nx];
 }
 
+// ---- ranking the rows through rulers (round 5) ----------------------------------------------------------------------------------
+// Pointer jumping over all rows is 17-18 rounds of two random gathers per row: 119 M gathers for the 3.3 M rows of the headline
+// workload, 0.9 ms. One row in 32 (by a hash of its number; chain heads and terminals on top) is a RULER: a ruler walks to the next
+// one, ONCE, and tells every row it passes which ruler owns it and how far behind that ruler it lies; only the rulers (1/32 of the rows,
+// in dense arrays) are ranked by pointer jumping; a row's distance to the end is its ruler's minus its offset. 3.3 M walked hops
+// instead of 119 M gathers. Damaged input (a cycle without a ruler, a row that points at itself) ends a walk after RULER_LIMIT steps
+// or at the self-loop: such rows get distances without meaning, never an access outside a buffer -- as with pointer jumping.
+constexpr u32 RULER_LIMIT = 1u << 16;
+__device__ __forceinline__ bool ruler_hash(u32 c) { return ((c * 2654435761u) >> 27) == 0; }
+__device__ __forceinline__ bool ruler_bit(const u32* __restrict__ rbits, u32 c) { return (rbits[c >> 5] >> (c & 31)) & 1u; }
+
+__global__ __launch_bounds__(256) void k_bwt_i_ruler_flags(const BwtHdr* __restrict__ hd, const u32* __restrict__ base, const u32* __restrict__ rowNode,
+                                                           const u32* __restrict__ rowBlk, const u32* __restrict__ succ, const InvInfo* __restrict__ info,
+                                                           u32 maxRows, u32* __restrict__ rbits, u32* __restrict__ rcount)
+{
+    const u32 w = blockIdx.x * 256 + threadIdx.x;
+    u32 rowsTotal = info->count + info->dyn;
+    if (rowsTotal > maxRows) rowsTotal = maxRows;
+    if (32u * w >= ((maxRows + 31u) & ~31u)) return;
+    u32 count = info->count;
+    if (count > maxRows) count = maxRows;
+    u32 word = 0;
+    for (u32 k = 0; k < 32; k++) {
+        const u32 c = 32u * w + k;
+        if (c >= count) break;                                   // (rows made on the way -- continuations of long sub-lists -- are never rulers)
+        bool r = ruler_hash(c) || succ[c] == c;
+        if (!r) { const u32 b = rowBlk[c]; r = rowNode[c] == base[b] + hd[b].pIdx - 1; }     // the first row of the block's chain
+        word |= (r ? 1u : 0u) << k;
+    }
+    rbits[w] = word;
+    rcount[w] = (u32)__popc(word);
+}
+
+__device__ __forceinline__ u32 ruler_rank(const u32* __restrict__ rbits, const u32* __restrict__ rprefix, u32 c)
+{
+    return rprefix[c >> 5] + (u32)__popc(rbits[c >> 5] & ((1u << (c & 31)) - 1u));
+}
+
+__global__ __launch_bounds__(256) void k_bwt_i_ruler_walk(const u32* __restrict__ succ, const u32* __restrict__ dist, const u32* __restrict__ rbits,
+                                                          const u32* __restrict__ rprefix, const InvInfo* __restrict__ info, u32 maxRows, u32 maxRulers,
+                                                          u32* __restrict__ owner, u32* __restrict__ pre, u32* __restrict__ rS, u32* __restrict__ rD)
+{
+    const u32 c = blockIdx.x * 256 + threadIdx.x;
+    u32 count = info->count;
+    if (count > maxRows) count = maxRows;
+    if (c >= count || !ruler_bit(rbits, c)) return;
+    u32 rowsTotal = info->count + info->dyn;
+    if (rowsTotal > maxRows) rowsTotal = maxRows;
+    const u32 idx = ruler_rank(rbits, rprefix, c);
+    if (idx >= maxRulers) return;
+    u32 x = succ[c];
+    u32 acc = dist[c];
+    if (x == c) { rS[idx] = idx; rD[idx] = acc; return; }       // terminal (dist 0)
+    u32 to = idx;                                                // where the walk ends when it does not meet a ruler
+    for (u32 steps = 0; steps < RULER_LIMIT; steps++) {
+        if (x >= rowsTotal) break;                               // (damaged input)
+        if (x < count && ruler_bit(rbits, x)) { const u32 r = ruler_rank(rbits, rprefix, x); to = r < maxRulers ? r : idx; break; }
+        owner[x] = idx;
+        pre[x] = acc;
+        acc += dist[x];
+        const u32 nx = succ[x];
+        if (nx == x) break;
+        x = nx;
+    }
+    rS[idx] = to;
+    rD[idx] = (to == idx) ? 0u : acc;                            // a walk that found no ruler ends the chain there
+}
+
+__global__ __launch_bounds__(256) void k_bwt_i_ruler_jump(const u32* __restrict__ nextIn, const u32* __restrict__ distIn, const u32* __restrict__ nPtr, u32 cap,
+                                                          u32* __restrict__ nextOut, u32* __restrict__ distOut)
+{
+    const u32 j = blockIdx.x * 256 + threadIdx.x;
+    u32 n = *nPtr;
+    if (n > cap) n = cap;
+    if (j >= n) return;
+    const u32 nx = nextIn[j];
+    distOut[j] = distIn[j] + distIn[nx];
+    nextOut[j] = nextIn[nx];
+}
+
+__global__ __launch_bounds__(256) void k_bwt_i_ruler_finish(const u32* __restrict__ rbits, const u32* __restrict__ rprefix, const u32* __restrict__ owner,
+                                                            const u32* __restrict__ pre, const u32* __restrict__ rD, const InvInfo* __restrict__ info,
+                                                            u32 maxRows, u32 maxRulers, u32* __restrict__ dEnd)
+{
+    const u32 c = blockIdx.x * 256 + threadIdx.x;
+    u32 rowsTotal = info->count + info->dyn;
+    if (rowsTotal > maxRows) rowsTotal = maxRows;
+    if (c >= rowsTotal) return;
+    u32 count = info->count;
+    if (count > maxRows) count = maxRows;
+    u32 d = 0xFFFFFFFFu;                                         // (a row no walk came by: damaged input; the copy kernel skips it)
+    if (c < count && ruler_bit(rbits, c)) { const u32 r = ruler_rank(rbits, rprefix, c); if (r < maxRulers) d = rD[r]; }
+    else { const u32 o = owner[c]; if (o < maxRulers) { const u32 t = rD[o], p = pre[c]; d = t >= p ? t - p : 0xFFFFFFFFu; } }
+    dEnd[c] = d;
+}
+
 // every row to its place: 32 lanes per row, a lane makes one aligned dword of the output from two aligned dwords of the row.
 // Round 5: a half-wave takes FOUR rows at a time and keeps going (grid-stride) -- with one row per half-wave the kernel was three
 // dependent loads and one store per wave, 750 K workgroups of which half had nothing to do: 0.95 ms for a copy of 212 MB. The loads of
@@ -468,7 +564,9 @@ struct InvScratch {
     u32* tileHist; u32* segSum; u32* Cb; u32* term; u64* rec; u32* bits; u32* wcount; u32* wprefix; u32* wblk;
     u32* rowNode; u32* rowBlk; u32* nA; u32* nB; u32* dA; u32* dB; u8* rowLen; u8* rows;
     BwtHdr* hd; u32* base; InvInfo* info; void* scanTmp;
-    u32 maxRows; int perTiles; u32 segT, nSeg;
+    u32* rS[2]; u32* rD[2];      // rulers, dense: successor ruler and distance to it (two copies for the pointer jumping)
+    u32* rbits; u32* rprefix;    // which rows are rulers (bit map over the rows), rulers in the words before
+    u32 maxRows, maxRulers; int perTiles; u32 segT, nSeg;
 };
 
 static size_t inv_carve(u8* p, int nBlocks, u32 VS, size_t maxTotal, InvScratch* w)
@@ -497,7 +595,12 @@ static size_t inv_carve(u8* p, int nBlocks, u32 VS, size_t maxTotal, InvScratch*
     w->hd = (BwtHdr*)take(sizeof(BwtHdr) * (size_t)nBlocks);
     w->base = (u32*)take(4ull * (nBlocks + 2));
     w->info = (InvInfo*)take(sizeof(InvInfo));
-    w->scanTmp = take(prims::scan_tmp_bytes(nWordsMax));
+    w->scanTmp = take(prims::scan_tmp_bytes(std::max(nWordsMax, maxRows / 32 + 2)));
+    // one row in 32 is a ruler, two more per block; four times that is room no input reaches (the hash picks by row NUMBER)
+    const size_t maxRulers = maxRows / 8 + 64 + 2 * (size_t)nBlocks;
+    w->maxRulers = (u32)maxRulers;
+    for (int k = 0; k < 2; k++) { w->rS[k] = (u32*)take(4 * maxRulers); w->rD[k] = (u32*)take(4 * maxRulers); }
+    w->rbits = (u32*)take(4 * (maxRows / 32 + 2)); w->rprefix = (u32*)take(4 * (maxRows / 32 + 2));
     return (size_t)(q - p);
 }
 
@@ -538,9 +641,31 @@ int launch_bwt_inverse(hipStream_t s, const XfStage& st, void* scratch, size_t s
     u32* nA = w.nA; u32* nB = w.nB; u32* dA = w.dA; u32* dB = w.dB;
     // chains never leave a block: a chain has at most rows-per-block rows
     const u64 chainRows = (u64)v.VS / 48 + (u64)v.VS / ROW + 4096 + 3;
-    for (u64 span = 1; span < chainRows; span <<= 1) {
-        { KScope ks_("k_bwt_i_jump"); hipLaunchKernelGGL(k_bwt_i_jump, GRID1(w.maxRows), nA, dA, w.info, w.maxRows, nB, dB); }
-        std::swap(nA, nB); std::swap(dA, dB);
+    static const bool allRowsJump = getenv("KNZ_BWT_I_JUMP_ALL") != nullptr && atoi(getenv("KNZ_BWT_I_JUMP_ALL")) != 0;   // the ranking of rounds 3-4
+    if (allRowsJump) {
+        for (u64 span = 1; span < chainRows; span <<= 1) {
+            { KScope ks_("k_bwt_i_jump"); hipLaunchKernelGGL(k_bwt_i_jump, GRID1(w.maxRows), nA, dA, w.info, w.maxRows, nB, dB); }
+            std::swap(nA, nB); std::swap(dA, dB);
+        }
+    } else {
+        // rulers (see k_bwt_i_ruler_walk): nB / dB hold every row's owner and offset, the rows' distances to the end come out where their
+        // successors were
+        KScope ks_("k_bwt_i_jump");
+        u32* rbits = w.rbits; u32* rprefix = w.rprefix;
+        const u32 rWords = (w.maxRows + 31) / 32;
+        u32* nRulers = &w.info->pad[0];
+        hipLaunchKernelGGL(k_bwt_i_ruler_flags, GRID1(rWords), w.hd, w.base, w.rowNode, w.rowBlk, nA, w.info, w.maxRows, rbits, rprefix);
+        prims::launch_scan<prims::SCAN_SUM_EXCL>(s, rprefix, rprefix, rWords, nullptr, w.scanTmp, nRulers);
+        hipMemsetAsync(nB, 0xFF, 4 * (size_t)w.maxRows, s);                      // owner: none
+        hipLaunchKernelGGL(k_bwt_i_ruler_walk, GRID1(w.maxRows), nA, dA, rbits, rprefix, w.info, w.maxRows, w.maxRulers, nB, dB, w.rS[0], w.rD[0]);
+        int cur = 0;
+        const u64 chainRulers = chainRows / 16 + 64;                                // (twice the expected rulers of the longest chain)
+        for (u64 span = 1; span < chainRulers; span <<= 1) {
+            hipLaunchKernelGGL(k_bwt_i_ruler_jump, GRID1(w.maxRulers), w.rS[cur], w.rD[cur], nRulers, w.maxRulers, w.rS[cur ^ 1], w.rD[cur ^ 1]);
+            cur ^= 1;
+        }
+        hipLaunchKernelGGL(k_bwt_i_ruler_finish, GRID1(w.maxRows), rbits, rprefix, nB, dB, w.rD[cur], w.info, w.maxRows, w.maxRulers, nA);
+        dA = nA;                                                                    // (the successor array is not needed any more: distances to the end)
     }
     { KScope ks_("k_bwt_i_place");
       const u32 wantWg = (w.maxRows + 8 * PLACE_U - 1) / (8 * PLACE_U);
