@@ -390,12 +390,12 @@ __global__ __launch_bounds__(256) void k_bwt_i_jump(const u32* __restrict__ next
 // instead of 119 M gathers. Damaged input (a cycle without a ruler, a row that points at itself) ends a walk after RULER_LIMIT steps
 // or at the self-loop: such rows get distances without meaning, never an access outside a buffer -- as with pointer jumping.
 constexpr u32 RULER_LIMIT = 1u << 16;
-__device__ __forceinline__ bool ruler_hash(u32 c) { return ((c * 2654435761u) >> 27) == 0; }
+__device__ __forceinline__ bool ruler_hash(u32 c, u32 rlog) { return ((c * 2654435761u) >> (32 - rlog)) == 0; }
 __device__ __forceinline__ bool ruler_bit(const u32* __restrict__ rbits, u32 c) { return (rbits[c >> 5] >> (c & 31)) & 1u; }
 
 __global__ __launch_bounds__(256) void k_bwt_i_ruler_flags(const BwtHdr* __restrict__ hd, const u32* __restrict__ base, const u32* __restrict__ rowNode,
                                                            const u32* __restrict__ rowBlk, const u32* __restrict__ succ, const InvInfo* __restrict__ info,
-                                                           u32 maxRows, u32* __restrict__ rbits, u32* __restrict__ rcount)
+                                                           u32 maxRows, u32* __restrict__ rbits, u32* __restrict__ rcount, u32 rlog)
 {
     const u32 w = blockIdx.x * 256 + threadIdx.x;
     u32 rowsTotal = info->count + info->dyn;
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void k_bwt_i_ruler_flags(const BwtHdr* __restr
     for (u32 k = 0; k < 32; k++) {
         const u32 c = 32u * w + k;
         if (c >= count) break;                                   // (rows made on the way -- continuations of long sub-lists -- are never rulers)
-        bool r = ruler_hash(c) || succ[c] == c;
+        bool r = ruler_hash(c, rlog) || succ[c] == c;
         if (!r) { const u32 b = rowBlk[c]; r = rowNode[c] == base[b] + hd[b].pIdx - 1; }     // the first row of the block's chain
         word |= (r ? 1u : 0u) << k;
     }
@@ -597,7 +597,7 @@ static size_t inv_carve(u8* p, int nBlocks, u32 VS, size_t maxTotal, InvScratch*
     w->info = (InvInfo*)take(sizeof(InvInfo));
     w->scanTmp = take(prims::scan_tmp_bytes(std::max(nWordsMax, maxRows / 32 + 2)));
     // one row in 32 is a ruler, two more per block; four times that is room no input reaches (the hash picks by row NUMBER)
-    const size_t maxRulers = maxRows / 8 + 64 + 2 * (size_t)nBlocks;
+    const size_t maxRulers = maxRows / 2 + 64 + 2 * (size_t)nBlocks;
     w->maxRulers = (u32)maxRulers;
     for (int k = 0; k < 2; k++) { w->rS[k] = (u32*)take(4 * maxRulers); w->rD[k] = (u32*)take(4 * maxRulers); }
     w->rbits = (u32*)take(4 * (maxRows / 32 + 2)); w->rprefix = (u32*)take(4 * (maxRows / 32 + 2));
@@ -654,12 +654,13 @@ int launch_bwt_inverse(hipStream_t s, const XfStage& st, void* scratch, size_t s
         u32* rbits = w.rbits; u32* rprefix = w.rprefix;
         const u32 rWords = (w.maxRows + 31) / 32;
         u32* nRulers = &w.info->pad[0];
-        hipLaunchKernelGGL(k_bwt_i_ruler_flags, GRID1(rWords), w.hd, w.base, w.rowNode, w.rowBlk, nA, w.info, w.maxRows, rbits, rprefix);
+        static const u32 rlog = []() { const char* e = getenv("KNZ_BWT_I_RULER_LOG"); const int v = e ? atoi(e) : 0; return (v >= 2 && v <= 8) ? (u32)v : 3u; }();
+        hipLaunchKernelGGL(k_bwt_i_ruler_flags, GRID1(rWords), w.hd, w.base, w.rowNode, w.rowBlk, nA, w.info, w.maxRows, rbits, rprefix, rlog);
         prims::launch_scan<prims::SCAN_SUM_EXCL>(s, rprefix, rprefix, rWords, nullptr, w.scanTmp, nRulers);
         hipMemsetAsync(nB, 0xFF, 4 * (size_t)w.maxRows, s);                      // owner: none
         hipLaunchKernelGGL(k_bwt_i_ruler_walk, GRID1(w.maxRows), nA, dA, rbits, rprefix, w.info, w.maxRows, w.maxRulers, nB, dB, w.rS[0], w.rD[0]);
         int cur = 0;
-        const u64 chainRulers = chainRows / 16 + 64;                                // (twice the expected rulers of the longest chain)
+        const u64 chainRulers = (chainRows >> (rlog - 1)) + 64;                     // (twice the expected rulers of the longest chain)
         for (u64 span = 1; span < chainRulers; span <<= 1) {
             hipLaunchKernelGGL(k_bwt_i_ruler_jump, GRID1(w.maxRulers), w.rS[cur], w.rD[cur], nRulers, w.maxRulers, w.rS[cur ^ 1], w.rD[cur ^ 1]);
             cur ^= 1;
