@@ -1669,7 +1669,8 @@ bool CompressedInputStream::fetch(size_t minBytes)
     // threads, FileInBuf::xsgetn) were measured and lost: the first batch waits for the whole piece (config 3 end to end: decompress
     // 6.9-7.9 -> 5.3-5.7 GB/s), and the source is not what a lane waits for afterwards
     static const size_t readAhead = []() { const char* e = getenv("KNZ_READ_AHEAD"); const long long v = e ? atoll(e) : 0; return v > 0 ? size_t(v) : (size_t(1) << 20); }();
-    size_t want = std::max<size_t>(minBytes - have, readAhead);
+    // (chains the device runs faster than a thread reads the source: 4 MiB pieces, which the C API's file buffer reads with the helper threads)
+    size_t want = std::max<size_t>(minBytes - have, (_spreadCopies && getenv("KNZ_READ_AHEAD") == nullptr) ? (size_t(4) << 20) : readAhead);
     const size_t old = _comp.size();
     ScopedNs t_(_tns[0]);
     _comp.resize(old + want);

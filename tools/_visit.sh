@@ -1,8 +1,9 @@
-for r in 2 3; do
-KNZ_BWT_I_RULER_LOG=$r timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu --no-e2e 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['roofline']['kernels_ms']; print('rlog $r', d['value'], d['ms_per_step'], d['dec_MBps'], 'jump', k.get('k_bwt_i_jump'), 'inv', d['roofline']['stages_ms']['bwt_inverse'])"
-KNZ_BWT_I_RULER_LOG=$r timeout 300 python bench.py --limit 33554432 --steps 8 --warmup 2 --no-cpu --no-e2e 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['roofline']['kernels_ms']; print('  4 blocks', d['value'], d['ms_per_step'], 'jump', k.get('k_bwt_i_jump'))"
-done
+OUT=gpurun_out/r05w; mkdir -p $OUT
+export GPU_MAX_HW_QUEUES=8
+run() { n=$1; shift
+  timeout 300 python tools/host_e2e_sweep.py "$@" > $OUT/$n.jsonl 2> $OUT/$n.err; echo "== $n $* rc=$?"; cat $OUT/$n.jsonl
+  grep "knz \(out\|in\)" $OUT/$n.err | tail -2 | cut -c1-330
+}
+run c2 2 6,6 0
+run c2old 2 6,6 0 KNZ_READ_AHEAD=1048576
+run c2b 2 6 0 KNZ_READ_AHEAD=8388608
