@@ -300,8 +300,10 @@ __global__ __launch_bounds__(64) void k_mtf_f_rank_par(XfView v, int perTiles, c
     u8* dst = d + tbase;
     const bool al = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 3) == 0;
     u8* tileB = reinterpret_cast<u8*>(tileW);
-    if (al) { for (u32 q = (u32)lane; q < (cnt + 3) / 4; q += 64) tileW[q] = reinterpret_cast<const u32*>(src)[q]; }   // (the block's buffer is padded)
-    else { for (u32 q = (u32)lane; q < cnt; q += 64) tileB[q] = src[q]; }
+    if (al) {
+        for (u32 q = (u32)lane; q < cnt / 4; q += 64) tileW[q] = reinterpret_cast<const u32*>(src)[q];
+        for (u32 q = (cnt & ~3u) + (u32)lane; q < cnt; q += 64) tileB[q] = src[q];            // (nothing is read behind the block's last byte)
+    } else { for (u32 q = (u32)lane; q < cnt; q += 64) tileB[q] = src[q]; }
     __syncthreads();
     u8* posB = reinterpret_cast<u8*>(posW);
     // start list: symbols by last occurrence, latest first; never-seen symbols (key 0) ascending. Keys made unique first (a block has
