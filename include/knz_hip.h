@@ -196,7 +196,7 @@ KNZ_API int knz_hip_get_kernel_times(knz_ctx* ctx, knz_kernel_time* out, int cap
 /* Developer / test knobs, process-wide (the same names in upper case with a KNZ_ prefix are read from the environment once, when
  * the library first needs them): "bwt_nsym" (symbols of the suffix sort's first round, 0 = four or five by the data's entropy),
  * "bwt_no_run_round", "bwt_run_fallback" (1: force the general path for runs), "bwt_no_super", "bwt_no_text_round", "bwt_no_run_offsets",
- * "bwt_no_probe", "bwt_stats", "bwt_split" (parts of a batch the BWT stages run in, 1..4), "rs_onesweep" (0: radix passes with a
+ * "bwt_no_probe", "bwt_link" (0: the suffix sort's link step for groups inside long repeats off), "bwt_stats", "bwt_split" (parts of a batch the BWT stages run in, 1..4), "rs_onesweep" (0: radix passes with a
  * counting kernel of their own), "lz_serial_decode" (1: LZ / LZX blocks decoded by one wave each), "mtf_tile" (0: MTFT tile size by
  * batch size, 1024 / 4096 force it), "mtf_chain" (1: MTFT forward ranks by the byte-serial kernel of rounds 2-4).
  * Returns 0, or -1 for an unknown name. No knob changes a result. */

@@ -626,15 +626,16 @@ __global__ __launch_bounds__(256) void k_bwt_f_gather_small(FwdView v, u32 h, in
     }
 }
 
-__global__ __launch_bounds__(256) void k_bwt_f_sort_small(FwdView v)
+__global__ __launch_bounds__(256) void k_bwt_f_sort_small(FwdView v, u32* __restrict__ survTile)
 {
     __shared__ SmWindow W;
     __shared__ int sAny;
     __shared__ u32 sSA[SM_WIN];
     __shared__ u32 sK[SM_WIN];
     __shared__ u32 sNew[64];
+    __shared__ u32 sWs[4];
     const u32 slot0 = blockIdx.x * SM_TS;
-    if (!sm_load_window(v, slot0, W, &sAny)) return;
+    if (!sm_load_window(v, slot0, W, &sAny)) { if (threadIdx.x == 0 && survTile) survTile[blockIdx.x] = 0; return; }
     if (threadIdx.x < 64) sNew[threadIdx.x] = 0;
     u32 gs[SM_WIN / 256], ge[SM_WIN / 256];
     bool act[SM_WIN / 256];
@@ -666,10 +667,16 @@ __global__ __launch_bounds__(256) void k_bwt_f_sort_small(FwdView v)
             v.ISA[gp] = slot0 + headIdx;
             if (eqBefore == 0) atomicOr(&sNew[headIdx >> 5], 1u << (headIdx & 31));
         }
-        if (eq > 1) surv = 1;
+        if (eq > 1) surv++;
     }
-    if (__ballot(surv != 0) != 0 && (threadIdx.x & 63) == 0) v.counters[0] = 1;
+    {
+        // members that are still tied, per window (summed by a scan: the host decides by their number whether the next round looks for
+        // links first; one counter for all windows would be an atomic per wave on one address)
+        const u32 ws = wave_sum(surv);
+        if ((threadIdx.x & 63) == 0) { sWs[threadIdx.x >> 6] = ws; if (ws) v.counters[0] = 1; }
+    }
     __syncthreads();
+    if (threadIdx.x == 0 && survTile) survTile[blockIdx.x] = sWs[0] + sWs[1] + sWs[2] + sWs[3];
     if (threadIdx.x < 64 && sNew[threadIdx.x]) atomicOr(&v.gnew[(slot0 >> 5) + threadIdx.x], sNew[threadIdx.x]);
 }
 
@@ -737,6 +744,160 @@ __global__ __launch_bounds__(256) void k_bwt_f_sort_small_text(BwtView bv, FwdVi
     if (__ballot(surv != 0) != 0 && (threadIdx.x & 63) == 0) v.counters[0] = 1;
     __syncthreads();
     if (threadIdx.x < 64 && sNew[threadIdx.x]) atomicOr(&v.gnew[(slot0 >> 5) + threadIdx.x], sNew[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// small groups inside long repeats: the link step (round 5)
+// ------------------------------------------------------------------------------------------------
+// A repeat of length L is L tied groups {p + i, q + i, ...}, i = 0 .. L - 1, and prefix doubling visits each of them log2(L - i) times:
+// real files (the same licence text in front of thousands of headers, string tables, duplicate objects) spend most of the suffix sort
+// there. All those groups are ordered alike -- by what follows the repeat's end. A small group G is LINKED when the successors p + 1 of
+// all its members lie in one group (which may hold other suffixes as well). Every member of a linked group is flagged at its own
+// position in a bit map over the positions, so the groups of one repeat are runs of consecutive set bits, and a run's end -- the first
+// position that is not flagged -- is c positions on, the same c for every member of G (they stay together all the way): the members of
+// G share c symbols more than their depth says, and the group at the run's end is what tells them apart. The existing "look max(R, h)
+// positions on" of the key kernels (FwdView::ovr, rtbits) does the rest: ovr = c + h for the members of G, and G is sorted in this
+// round by the labels c + h positions on -- together with the group at the end of its run, instead of log2 c rounds later. Exact: a
+// link means the successors are in ONE group, i.e. equal in at least their first symbol; c links in a row mean c equal symbols, and the
+// group at the end has depth h. Only groups whose positions lie below posEnd take part (0: below the end of the first block -- the trial
+// of the host policy covers that block only, and its bit map ends there: the window of the next block that rides along must neither
+// flag nor look up anything).
+__global__ __launch_bounds__(256) void k_bwt_f_link_small(FwdView v, u32* __restrict__ posflag, u32* __restrict__ linked, int stats, u32 tileStep,
+                                                          u32* __restrict__ linkedTile, u32 posEnd)
+{
+    __shared__ SmWindow W;
+    __shared__ int sAny;
+    __shared__ int sBlk;
+    __shared__ u32 sP[SM_WIN];
+    __shared__ u32 sK[SM_WIN];
+    __shared__ u32 sLinked[64];
+    __shared__ u32 sCnt[4];
+    const u32 tile = blockIdx.x * tileStep;
+    const u32 slot0 = tile * SM_TS;
+    if (!sm_load_window(v, slot0, W, &sAny)) { if (threadIdx.x == 0) linkedTile[tile] = 0; return; }
+    if (threadIdx.x < 64) sLinked[threadIdx.x] = 0;
+    if (threadIdx.x == 64) sBlk = find_block(v.base, v.nBlocks, slot0 < v.total ? slot0 : v.total - 1);
+    __syncthreads();
+    const int b0 = sBlk;
+    u32 gs[SM_WIN / 256], ge[SM_WIN / 256];
+    bool act[SM_WIN / 256];
+#pragma unroll
+    for (int k = 0; k < (int)(SM_WIN / 256); k++) {
+        const u32 i = threadIdx.x + 256u * k;
+        act[k] = sm_group_of(W, i, gs[k], ge[k]);
+        if (!act[k]) continue;
+        const u32 slot = slot0 + i;
+        int b = b0;
+        while (slot >= v.base[b + 1]) b++;
+        const u32 gp = v.SA[slot];
+        sP[i] = gp;
+        sK[i] = (gp + 1 < v.base[b + 1]) ? v.ISA[gp + 1] : 0xFFFFFFFFu;          // the label of the successor; none at the block's end
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < (int)(SM_WIN / 256); k++) {
+        const u32 i = threadIdx.x + 256u * k;
+        if (!act[k] || i != gs[k]) continue;
+        const u32 lab = sK[i];
+        bool ok = lab != 0xFFFFFFFFu && sP[i] < (posEnd ? posEnd : v.base[1]);   // (one group, one block: its first member speaks for all)
+        for (u32 j = gs[k] + 1; j < ge[k] && ok; j++) ok = sK[j] == lab;
+        if (ok) atomicOr(&sLinked[i >> 5], 1u << (i & 31));
+    }
+    __syncthreads();
+    u32 mine = 0;
+    // every member of a linked group is flagged at its own position: the group one position on may hold other suffixes as well (they do
+    // not matter: what counts is that THESE members stay together), so a run is followed member by member, not group by group
+#pragma unroll
+    for (int k = 0; k < (int)(SM_WIN / 256); k++) {
+        if (!act[k]) continue;
+        if (!((sLinked[gs[k] >> 5] >> (gs[k] & 31)) & 1u)) continue;
+        const u32 gp = sP[threadIdx.x + 256u * k];
+        atomicOr(&posflag[gp >> 5], 1u << (gp & 31));
+        mine++;
+    }
+    (void)stats;
+    {
+        const u32 ws = wave_sum(mine);
+        if ((threadIdx.x & 63) == 0) sCnt[threadIdx.x >> 6] = ws;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) linkedTile[tile] = sCnt[0] + sCnt[1] + sCnt[2] + sCnt[3];       // members in linked groups: what the step may pay for
+    if (threadIdx.x < 64 && sLinked[threadIdx.x]) atomicOr(&linked[(slot0 >> 5) + threadIdx.x], sLinked[threadIdx.x]);
+}
+
+// what the link step bought: members it linked against members still tied after the round, over the windows it was applied to
+// (slotEnd: the trial's windows are those that begin inside the first block, whose length the host does not know)
+__global__ __launch_bounds__(256) void k_bwt_f_link_payoff(const u32* __restrict__ linkedTile, const u32* __restrict__ survTile, u32 nTiles, u32 tileStep,
+                                                           u32* __restrict__ out, const u32* __restrict__ slotEnd)
+{
+    __shared__ u32 sA[256], sB[256];
+    u32 a = 0, b = 0;
+    const u32 tEnd = slotEnd ? (*slotEnd + SM_TS - 1) / SM_TS : nTiles;
+    if (tEnd < nTiles) nTiles = tEnd;
+    for (u32 t = threadIdx.x * tileStep; t < nTiles; t += 256u * tileStep) { a += linkedTile[t]; b += survTile[t]; }
+    sA[threadIdx.x] = a; sB[threadIdx.x] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) { sA[threadIdx.x] += sA[threadIdx.x + o]; sB[threadIdx.x] += sB[threadIdx.x + o]; } __syncthreads(); }
+    if (threadIdx.x == 0) { out[0] = sA[0]; out[1] = sB[0]; }
+}
+
+// first zero bit of every word of the link bit map, by word, in reversed order (an inclusive minimum scan over it gives, for every word,
+// the first zero bit at or behind it)
+__global__ __launch_bounds__(256) void k_bwt_f_link_zeros(const u32* __restrict__ posflag, u32 nW, u32* __restrict__ rev)
+{
+    const u32 w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= nW) return;
+    const u32 x = ~posflag[w];
+    rev[nW - 1 - w] = x ? 32u * w + (u32)__ffs((int)x) - 1u : 0xFFFFFFFFu;
+}
+
+__device__ __forceinline__ u32 link_next_zero(const u32* __restrict__ posflag, const u32* __restrict__ sufRev, u32 nW, u32 p)
+{
+    const u32 w = p >> 5;
+    const u32 x = ~posflag[w] & (0xFFFFFFFFu << (p & 31));
+    if (x) return 32u * w + (u32)__ffs((int)x) - 1u;
+    return (w + 1 < nW) ? sufRev[nW - 2 - w] : 0xFFFFFFFFu;
+}
+
+__global__ __launch_bounds__(256) void k_bwt_f_link_apply(FwdView v, const u32* __restrict__ posflag, const u32* __restrict__ sufRev, u32 nW,
+                                                          const u32* __restrict__ linked, u32 h, u32* __restrict__ ovr, u32* __restrict__ rtbits, u32 tileStep)
+{
+    __shared__ SmWindow W;
+    __shared__ int sAny;
+    __shared__ u32 sLinked[64];
+    __shared__ u32 sRt[64];
+    __shared__ u32 sOff[SM_WIN];
+    const u32 slot0 = blockIdx.x * tileStep * SM_TS;
+    if (threadIdx.x >= 64 && threadIdx.x < 128) { sLinked[threadIdx.x - 64] = linked[(slot0 >> 5) + threadIdx.x - 64]; sRt[threadIdx.x - 64] = 0; }
+    if (!sm_load_window(v, slot0, W, &sAny)) return;
+    __syncthreads();
+    u32 gs[SM_WIN / 256], ge[SM_WIN / 256];
+    bool act[SM_WIN / 256];
+#pragma unroll
+    for (int k = 0; k < (int)(SM_WIN / 256); k++) {
+        const u32 i = threadIdx.x + 256u * k;
+        act[k] = sm_group_of(W, i, gs[k], ge[k]) && ((sLinked[gs[k] >> 5] >> (gs[k] & 31)) & 1u);
+        if (act[k] && i == gs[k]) {
+            const u32 gp = v.SA[slot0 + i];                                      // (any member: the run is as long for all of them)
+            const u32 e = link_next_zero(posflag, sufRev, nW, gp);
+            sOff[i] = (e != 0xFFFFFFFFu && e > gp) ? (e - gp) + h : 0u;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < (int)(SM_WIN / 256); k++) {
+        if (!act[k]) continue;
+        const u32 i = threadIdx.x + 256u * k;
+        const u32 off = sOff[gs[k]];
+        if (off == 0) continue;
+        const u32 slot = slot0 + i;
+        const bool had = (rtbits[slot >> 5] >> (slot & 31)) & 1u;
+        const u32 old = had ? ovr[slot] : 0u;
+        if (off > old) ovr[slot] = off;
+        if (!had) atomicOr(&sRt[i >> 5], 1u << (i & 31));
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 && sRt[threadIdx.x]) atomicOr(&rtbits[(slot0 >> 5) + threadIdx.x], sRt[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1963,12 +2124,13 @@ __global__ __launch_bounds__(256) void k_bwt_f_med_compact(uint2* __restrict__ s
 }
 
 // knobs (tests, tuning): read from the environment once per process, or set through knz_hip_tune()
-struct FwdTuning { int nsym; int noRunRound; int runFallback; int noSuper; int noTextRound; int stats; int noRunOffsets; int noProbe; };
+struct FwdTuning { int nsym; int noRunRound; int runFallback; int noSuper; int noTextRound; int stats; int noRunOffsets; int noProbe; int link; };
 static FwdTuning& fwd_tuning()
 {
     static FwdTuning t = [] {
-        FwdTuning x; x.nsym = 0; x.noRunRound = 0; x.runFallback = 0; x.noSuper = 0; x.noTextRound = 0; x.stats = 0; x.noRunOffsets = 0; x.noProbe = 0;
+        FwdTuning x; x.nsym = 0; x.noRunRound = 0; x.runFallback = 0; x.noSuper = 0; x.noTextRound = 0; x.stats = 0; x.noRunOffsets = 0; x.noProbe = 0; x.link = 1;     // link: 0 off, 1 on (from h = 32), n > 1: from h = n
         if (getenv("KNZ_BWT_NO_PROBE")) x.noProbe = 1;
+        if (const char* e = getenv("KNZ_BWT_LINK")) x.link = atoi(e);
         if (getenv("KNZ_BWT_NO_RUN_OFFSETS")) x.noRunOffsets = 1;
         if (getenv("KNZ_BWT_STATS")) x.stats = 1;
         if (const char* e = getenv("KNZ_BWT_NSYM")) x.nsym = atoi(e);
@@ -1992,6 +2154,7 @@ int bwt_forward_tune(const char* key, int value)
     else if (!strcmp(key, "bwt_stats")) t.stats = value;
     else if (!strcmp(key, "bwt_no_run_offsets")) t.noRunOffsets = value;
     else if (!strcmp(key, "bwt_no_probe")) t.noProbe = value;
+    else if (!strcmp(key, "bwt_link")) t.link = value;
     else return -1;
     return 0;
 }
@@ -2004,6 +2167,8 @@ struct FwdScratch {
     u32* gbits; u32* gnew; u32* rtbits; u32* ovr; size_t gbitsWords;
     uint2* med[2]; uint2* medStage; u32* medFlags; u32* medPrefix; size_t medSlots; uint2* descInfo; uint2* large[2]; uint2* runList; uint4* superList; u32* ebits;
     u32* loff;
+    u32* survTile;       // members still tied after a round's small-group sort, per window
+    u32* linkedTile;     // members the link step linked, per window
     u32* base;
     u32* counters;
     u32* seg2;
@@ -2043,6 +2208,8 @@ static size_t fwd_carve(u8* p, int nBlocks, size_t total, FwdScratch* w)
     w->descInfo = (uint2*)take(8 * maxMed);
     w->ebits = (u32*)take(4 * w->gbitsWords);
     w->loff = (u32*)take(4 * (maxMed + 1));
+    w->survTile = (u32*)take(4 * (total / SM_TS + 64));
+    w->linkedTile = (u32*)take(4 * (total / SM_TS + 64));
     w->base = (u32*)take(4ull * (nBlocks + 2));
     w->counters = (u32*)take(256);
     w->byteHist = (u32*)take(1024ull * (nBlocks + 1));
@@ -2051,7 +2218,7 @@ static size_t fwd_carve(u8* p, int nBlocks, size_t total, FwdScratch* w)
     w->rsMem = take(prims::rs_ws_bytes(total, nBlocks + 1));
     w->maxRuns = total / 4 + 64;                                   // (runs of at least 4 symbols; with a shorter round-0 key there can be more: fallback)
     w->classTab = (u32*)take(1024ull * (size_t)nBlocks);
-    const size_t rw = total / 32 + SM_WIN / 32 + 8;
+    const size_t rw = total / 32 + SM_WIN / 32 + 136;           // (+ the link step's bit map over the slots, whole windows)
     w->rbits = (u32*)take(4 * rw); w->rcount = (u32*)take(4 * rw); w->rprefix = (u32*)take(4 * rw);
     w->runPos = (u32*)take(4 * w->maxRuns); w->runE = (u32*)take(4 * w->maxRuns); w->runL = (u32*)take(4 * w->maxRuns);
     w->sE = (u32*)take(4 * w->maxRuns); w->rcnt = (u32*)take(4 * w->maxRuns); w->moff = (u32*)take(4 * w->maxRuns + 64);
@@ -2303,10 +2470,54 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     // not), which is what lets the chain round (k_bwt_f_super) see a group look at itself.
     u32 h = 1;
     while (2 * h <= (u32)nsym) h <<= 1;
+    u32 survMembers = total;                                        // (not counted before the first round: assume many)
+    int linkMode = 0;                                               // 0 not tried, 1 sampled, 2 on, 3 applied (to be judged), 4 off
+    u32 linkStepUsed = 1, linkTiles = 0, linkRetryH = 0xFFFFFFFFu;
+    int linkTrials = 0;
     while (surv || nMed || nLarge) {
         if (h > bv.VS) return -5;                                    // cannot happen: suffixes of one block differ in length
         { KScope ks_("k_bwt_f_round"); hipMemsetAsync(w.counters, 0, 64, s); }      // (the scope counts the doubling rounds for the profile)
         const int nxt = cur ^ 1;
+        // -- small groups inside long repeats: links first (k_bwt_f_link_small), once the rounds are past the depth where most ties are chance
+        // Whether it pays is a property of the data (it does where groups are whole repeats: copied spans, files that hold a part twice;
+        // it does not where every group has members that leave it one by one, as in the file mix of config 9): the first application, at
+        // h = 32, is a trial; what it linked against what was still tied after the round decides whether the rounds that follow apply it
+        // too, and every application is judged again. The trial is made on the windows of the batch's FIRST BLOCK only (a run never
+        // leaves its block, so the block's runs are complete; a sample of windows all over the batch would cut every run): 0.15 ms per
+        // 8 MiB where the step applied to a 212 MB batch costs 2-4 ms -- 6 % of the suffix sort of the real files, which it does not help.
+        bool linkNow = false;
+        u32 linkStep = 1;
+        if (surv && tune.link && h >= (u32)(tune.link > 1 ? tune.link : 32)) {
+            if (linkMode == 1 || linkMode == 3) {                    // judge the application of the round before
+                const u32 linkedN = h_pinned[14], tiedN = h_pinned[15];
+                const bool paid = linkedN >= 4096 && tiedN < linkedN / 2;
+                linkMode = paid ? 2 : 4;                              // 2: apply, 4: not now
+                if (!paid) linkRetryH = (linkTrials < 3) ? h * 8 : 0xFFFFFFFFu;    // (chance ties of the early rounds may have hidden the repeats: twice more, three rounds on)
+                if (tune.stats) fprintf(stderr, "link step: %u members linked, %u of the windows' members still tied after the round -> %s\n", linkedN, tiedN, paid ? "on" : "off");
+            }
+            if (linkMode == 4 && h >= linkRetryH) linkMode = 0;
+            if (linkMode == 0 && survMembers >= total / 8) { linkNow = true; linkMode = 1; linkTrials++; }              // the trial
+            else if (linkMode == 2 && survMembers >= total / 64) { linkNow = true; linkMode = 3; }
+        }
+        if (linkNow) {
+            KScope ks_("k_bwt_f_link");
+            u32* posflag = w.ebits; u32* linked = w.rbits; u32* rev = w.rcount; u32* sufRev = w.rprefix;
+            // (the trial looks at block 0 only: positions below its length <= VS)
+            const u32 nW = (linkMode == 1) ? (u32)std::min<u64>((u64)total / 32 + 1, ((u64)bv.VS + 4 * SM_WIN) / 32 + 2) : total / 32 + 1;
+            hipMemsetAsync(posflag, 0, 4 * (size_t)nW, s);
+            hipMemsetAsync(linked, 0, 4 * ((size_t)nTiles * (SM_TS / 32) + 64), s);
+            if (!v.rtbits) { hipMemsetAsync(w.rtbits, 0, 4 * w.gbitsWords, s); v.ovr = w.ovr; v.rtbits = w.rtbits; }
+            // (block 0 ends at slot base[1] <= VS: whole windows up to there; the window of block 1 that rides along links nothing: posEnd)
+            const u32 nTrial = (u32)std::min<u64>((u64)nTiles, ((u64)bv.VS + SM_TS - 1) / SM_TS + 1);
+            const u32 nT = (linkMode == 1) ? nTrial : (nTiles + linkStep - 1) / linkStep;
+            linkTiles = nT;
+            const u32 posEnd = (linkMode == 1) ? 0u : total;                    // (0: the first block only)
+            hipLaunchKernelGGL(k_bwt_f_link_small, dim3(nT), dim3(256), 0, s, v, posflag, linked, tune.stats, linkStep, w.linkedTile, posEnd);
+            hipLaunchKernelGGL(k_bwt_f_link_zeros, GRID1(nW), posflag, nW, rev);
+            prims::launch_scan<prims::SCAN_MIN_INCL>(s, rev, sufRev, nW, nullptr, w.scanTmp);
+            hipLaunchKernelGGL(k_bwt_f_link_apply, dim3(nT), dim3(256), 0, s, v, posflag, sufRev, nW, linked, h, w.ovr, w.rtbits, linkStep);
+            linkStepUsed = linkStep;
+        }
         // -- all keys first
         if (surv) { KScope ks_("k_bwt_f_gather_small"); hipLaunchKernelGGL(k_bwt_f_gather_small, dim3(nTiles), dim3(256), 0, s, v, h, tune.stats); }
         if (nMed) {
@@ -2326,7 +2537,10 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
             else hipLaunchKernelGGL(k_bwt_f_large_keys<u64>, GRID1(largeElems), v, w.large[cur], nLarge, w.loff, largeElems, h, kbits, lkA, w.valsA);
         }
         // -- then the refinements
-        if (surv) { KScope ks_("k_bwt_f_sort_small"); hipLaunchKernelGGL(k_bwt_f_sort_small, dim3(nTiles), dim3(256), 0, s, v); }
+        if (surv) { KScope ks_("k_bwt_f_sort_small"); hipLaunchKernelGGL(k_bwt_f_sort_small, dim3(nTiles), dim3(256), 0, s, v, tune.link ? w.survTile : (u32*)nullptr);
+                    if (linkNow) hipLaunchKernelGGL(k_bwt_f_link_payoff, dim3(1), dim3(256), 0, s, w.linkedTile, w.survTile, linkTiles, linkStepUsed, w.counters + 14,
+                                                   (linkMode == 1) ? v.base + 1 : (const u32*)nullptr);
+                    if (tune.link) prims::launch_scan<prims::SCAN_SUM_EXCL>(s, w.survTile, w.survTile, nTiles, nullptr, w.scanTmp, w.counters + 13); }
         if (nMed) {
             // two workgroup shapes over the same list, each takes the groups of its size class: 256 threads x 8 elements (21 KB of LDS,
             // groups up to 2048) and 512 threads x 16 elements (76 KB: two groups per CU in flight)
@@ -2363,10 +2577,11 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
         if (hipMemcpyAsync(h_pinned, w.counters, 64, hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
         if (hipStreamSynchronize(s) != hipSuccess) return -1;
         surv = h_pinned[0]; nMed = h_pinned[1]; nLarge = h_pinned[2]; largeElems = h_pinned[3];
+        survMembers = h_pinned[13];
         if (tune.stats) {
             const std::chrono::steady_clock::time_point now = std::chrono::steady_clock::now();
-            fprintf(stderr, "round h=%u (%.3f ms): small members worked on %u in %u groups, medium members %u; after it: small left %u, medium groups %u, large %u (%u members); %u groups took the chain round\n",
-                    h, std::chrono::duration<double, std::milli>(now - statT).count(), h_pinned[10], h_pinned[11], h_pinned[12], surv, nMed, nLarge, largeElems, h_pinned[7]);
+            fprintf(stderr, "round h=%u (%.3f ms): small members worked on %u in %u groups, medium members %u; after it: small left %u, medium groups %u, large %u (%u members); %u groups took the chain round; %u small members still tied\n",
+                    h, std::chrono::duration<double, std::milli>(now - statT).count(), h_pinned[10], h_pinned[11], h_pinned[12], surv, nMed, nLarge, largeElems, h_pinned[7], h_pinned[13]);
             statT = now;
         }
         cur = nxt;

@@ -121,6 +121,24 @@ def test_bwt_forward_long_common_prefixes_emulated(tmp_path):
             assert r.returncode == 0, (i, order, r.stdout[-2000:] + r.stderr[-2000:])
             if i == 2:
                 assert r.stderr.count("round h=") <= 2, r.stderr[-1500:]          # the probe took the periodic groups
+    # the link step for small groups inside long repeats (round 5): text with copied spans, X || X and a block that holds a text three times
+    # with edits, with the step tried from the first doubling round on (KNZ_BWT_LINK=4) and with it off -- the same suffix array either way,
+    # and X || X in far fewer rounds with it
+    t = c.text(40000, 9)
+    ed = bytearray(t); ed[777] = 1; ed[22222] = 2
+    for name, blocks in (("link_mixed", [c.repeats(100000, 3), c.tile(60000, 1, 30000), t + bytes(ed) + t[:30000], c.dna(100000, 4)]),
+                         ("link_xx", [c.tile(60000, 1, 30000), t + bytes(ed) + t[:30000]])):
+        path = str(tmp_path / (name + ".bin"))
+        write_case(path, blocks)
+        rounds, said = {}, {}
+        for link in ("4", "0", "1"):
+            r = subprocess.run([exe, path], capture_output=True, text=True, timeout=1800, env=dict(os.environ, HIPEMU_ORDER="2", KNZ_BWT_STATS="1", KNZ_BWT_LINK=link))
+            assert r.returncode == 0, (name, link, r.stdout[-2000:] + r.stderr[-2000:])
+            rounds[link] = r.stderr.count("round h=")
+            said[link] = "link step:" in r.stderr
+        assert said["4"] and not said["0"], (name, said)
+        if name == "link_xx":
+            assert rounds["4"] < rounds["0"], rounds
 
 
 def test_fpaq_kernels_emulated(tmp_path):
