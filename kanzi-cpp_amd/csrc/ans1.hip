@@ -104,6 +104,24 @@ __global__ __launch_bounds__(64) void k_ans1_ctx(BlockView view, int chunksPerBl
 
 // ANSRangeEncoder.cpp:194-261 (order-1 branch): state j walks quarter j backwards; the symbol at position p is
 // coded in the context of the byte before it, the first byte of a quarter in context 0.
+//
+// One wave per chunk, lanes 0-3 are the four states. What the states need -- the (reciprocal, frequency, shift, bias) record of
+// every (context, symbol) pair they will meet -- is known up front, so all 64 lanes fetch it a stretch of 64 steps ahead (bytes
+// two stretches ahead, records one) into LDS, unpacked into the operands the recurrence uses, and the serial part is the state
+// recurrence alone: compare, shift, multiply-high, multiply, add, and one LDS write of (low 16 bits | flag). Where the 16-bit
+// emissions go is settled after the stretch by the whole wave (lane = step: a scan over the flags), which also writes them out:
+// a store inside the step loop shares the memory counter with the record loads, so every wait for a load was a wait for the store
+// before it to reach memory (round 4: 2.2 us per 16 steps, 142 ms per 4 MiB chunk); the text is read through the global address
+// space for the same reason (a flat load counts as an LDS operation, and the wait for the next record then waited for memory).
+// every load issued so far has arrived (used before a burst of stores, so that the wait for a load that follows in program order is not
+// a wait for the stores: one counter for both on this hardware)
+#ifdef KNZ_EMU
+#define KNZ_LOADS_DONE() ((void)0)
+#else
+#define KNZ_LOADS_DONE() __builtin_amdgcn_s_waitcnt(0x0F70)       /* vmcnt(0), the other counters left alone */
+#endif
+constexpr u32 A1E_ST = 64;                     // steps per stretch (= lanes: one step per lane when the emissions are placed)
+
 __global__ __launch_bounds__(64) void k_ans1_encode(BlockView view, int chunksPerBlock, ChunkDesc* __restrict__ desc,
                                                     const uint2* __restrict__ encTab, u8* __restrict__ payBase, u64 payStride)
 {
@@ -132,58 +150,88 @@ __global__ __launch_bounds__(64) void k_ans1_encode(BlockView view, int chunksPe
     // emission lands on an even address
     const u32 top = (u32)payStride - (tail & 1);
     if (lane == 0) for (u32 t = 0; t < tail; t++) pay[top - tail + t] = blk[end4 + t];   // ANSRangeEncoder.cpp:204-205
-    u32 q = top - tail;
+    const u32 itemsTop = top - tail;                 // item i (in emission order) lies at itemsTop - 2 (i + 1)
+    u32 nOut = 0;                                    // items emitted so far (the same in all lanes)
     u32 st = A1_TOP;
     const uint2* tab = encTab + (size_t)gc * 65536;
 
-    __shared__ uint2 ebuf[2][16][4];
-    const u32 j = (u32)lane & 3, t = (u32)lane >> 2;
+    __shared__ uint4 ebuf[2][A1E_ST][4];             // per (step, state): reciprocal, xMax, 2^11 - freq, bias | shift << 16
+    __shared__ u32 obuf[A1E_ST][4];                  // per (step, state): low 16 bits of the state before the step | emitted << 16
+    const u32 j = (u32)lane & 3, t4 = ((u32)lane >> 2) * 4;
     const u32 total = quarter;                       // steps per state
     const u32 qs = j * quarter;
-    // bytes of step s for state j (clamped so that idle lanes still load inside the chunk)
-    auto load_bytes = [&](u32 s, u32& sym, u32& ctx) {
+    // table index of step s for state j (clamped so that idle lanes still load inside the chunk)
+    auto step_index = [&](u32 s) -> u32 {
         const u32 sc = (s < total) ? s : total - 1;
         const u32 pos = qs + quarter - 1 - sc;
-        sym = blk[pos];
-        const u32 cb = blk[pos > qs ? pos - 1 : pos];
-        ctx = (pos > qs) ? cb : 0u;
+        const u32 sym = ldg<u8>(blk + pos);
+        const u32 cb = ldg<u8>(blk + (pos > qs ? pos - 1 : pos));
+        return ((pos > qs) ? cb : 0u) * 256 + sym;
     };
-    const u32 lowMask = (1u << j) - 1u;
+    auto operands = [](uint2 e) -> uint4 {
+        const u32 fr = e.y & 0x1FFF;
+        // xMax = ((TOP >> 11) << 16) * freq
+        return make_uint4(e.x, fr << 20, A1_SCALE - fr, (e.y >> 17) | (((e.y >> 13) & 0xF) << 16));
+    };
     if (total) {
-        const u32 nb = (total + 15) >> 4;
-        u32 s1, c1, s2, c2;
-        load_bytes(t, s1, c1);
-        uint2 eCur = tab[c1 * 256 + s1];
-        load_bytes(16 + t, s1, c1);
-        for (u32 it = 0; it < nb; it++) {
-            ebuf[it & 1][t][j] = eCur;
-            const uint2 eNext = tab[c1 * 256 + s1];              // batch it + 1
-            load_bytes(16 * (it + 2) + t, s2, c2);               // batch it + 2
-            __syncthreads();
+        const u32 nStretch = (total + A1E_ST - 1) / A1E_ST;
+        u32 idx1[4];
+        uint2 e1[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) ebuf[0][t4 + k][j] = operands(tab[step_index(t4 + k)]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) idx1[k] = step_index(A1E_ST + t4 + k);
+        __syncthreads();
+        for (u32 r = 0; r < nStretch; r++) {
+            const u32 buf = r & 1;
+            const u32 sBase = A1E_ST * r;
+            const u32 cnt = (total - sBase < A1E_ST) ? (total - sBase) : A1E_ST;
+            // in flight during the serial part: the records of stretch r + 1, the bytes of stretch r + 2
+            u32 idx2[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) e1[k] = tab[idx1[k]];
+#pragma unroll
+            for (int k = 0; k < 4; k++) idx2[k] = step_index(A1E_ST * (r + 2) + t4 + k);
             if (lane < 4) {
-                const u32 sBase = 16 * it;
-                const u32 cnt = (total - sBase < 16) ? (total - sBase) : 16;
+                uint4 e = ebuf[buf][0][lane];
                 for (u32 tt = 0; tt < cnt; tt++) {
-                    const uint2 e = ebuf[it & 1][tt][lane];
-                    const u32 fr = e.y & 0x1FFF;
-                    const u32 sh = (e.y >> 13) & 0xF;
-                    const u32 bias = e.y >> 17;
-                    const bool flag = st >= (fr << 20);          // xMax = ((TOP >> 11) << 16) * freq
-                    const u32 m = (u32)KNZ_BALLOT_OF(flag, 0xFull) & 0xF;    // (lanes 0-3 are in here)
-                    if (flag) {
-                        const u32 before = __popc(m & lowMask);
-                        const u32 a = q - 2 * (before + 1);
-                        *reinterpret_cast<u16*>(pay + a) = (u16)(((st >> 8) & 0xFF) | ((st & 0xFF) << 8));
-                        st >>= 16;
-                    }
-                    q -= 2 * __popc(m);
-                    const u32 qd = __umulhi(st, e.x) >> sh;
-                    st = st + bias + qd * (A1_SCALE - fr);
+                    const uint4 eN = ebuf[buf][(tt + 1) & (A1E_ST - 1)][lane];       // (the record of the next step: its LDS latency is off the chain)
+                    const bool flag = st >= e.y;
+                    obuf[tt][lane] = (st & 0xFFFFu) | (flag ? 0x10000u : 0u);
+                    st = flag ? (st >> 16) : st;
+                    const u32 qd = __umulhi(st, e.x) >> (e.w >> 16);
+                    st = st + (e.w & 0xFFFFu) + qd * e.z;
+                    e = eN;
                 }
             }
-            eCur = eNext; s1 = s2; c1 = c2;
+            __syncthreads();
+            // the records of the next stretch go to LDS BEFORE this stretch's emissions are stored: the wait for the loads then does
+            // not include those stores (they have the whole next stretch to reach memory)
+            KNZ_LOADS_DONE();
+#pragma unroll
+            for (int k = 0; k < 4; k++) ebuf[buf ^ 1][t4 + k][j] = operands(e1[k]);
+#pragma unroll
+            for (int k = 0; k < 4; k++) idx1[k] = idx2[k];
+            // lane = step: lower states write first, i.e. at the higher addresses of the payload that grows downwards
+            {
+                const uint4 o = ((u32)lane < cnt) ? *reinterpret_cast<const uint4*>(&obuf[lane][0]) : make_uint4(0, 0, 0, 0);
+                const u32 ov[4] = { o.x, o.y, o.z, o.w };
+                const u32 mine = (o.x >> 16) + (o.y >> 16) + (o.z >> 16) + (o.w >> 16);
+                const u32 incl = wave_incl_scan(mine);
+                u32 i = nOut + incl - mine;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (ov[k] >> 16) {
+                        stg<u16>(pay + (itemsTop - 2 * (i + 1)), (u16)(((ov[k] >> 8) & 0xFF) | ((ov[k] & 0xFF) << 8)));
+                        i++;
+                    }
+                }
+                nOut += (u32)__shfl((int)incl, 63, 64);
+            }
+            __syncthreads();
         }
     }
+    const u32 q = itemsTop - 2 * nOut;
     // varint(size) + 4 states -> mid ; payload piece
     const u32 s0 = (u32)__shfl((int)st, 0, 64);
     const u32 s1v = (u32)__shfl((int)st, 1, 64);

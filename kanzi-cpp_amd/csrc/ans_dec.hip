@@ -56,6 +56,13 @@ typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 #endif
 
 __device__ __forceinline__ u32 rl(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
+// values the compiler must have in registers at this point (it would otherwise move an LDS read it thinks is optional behind the
+// condition that picks it, i.e. behind the memory load the read is meant to overlap)
+#ifdef KNZ_EMU
+#define KNZ_KEEP4(a, b, c, d) ((void)0)
+#else
+#define KNZ_KEEP4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+#endif
 __device__ __forceinline__ u32 uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ u64 uni64(u64 v) { return ((u64)uni((u32)(v >> 32)) << 32) | uni((u32)v); }
 
@@ -796,14 +803,18 @@ __global__ __launch_bounds__(64) void k_ans1_decode(BitSrc src, DecBlock* __rest
             for (u32 s = s0; s < s1; s++) {
                 const u32 slotv = st & mask;
                 const u32 e = tab[prv * A1_SLOTS_PER_CTX + slotv];
+                // the four items this step may take (which one depends on the other states' flags) are read while the table load is in
+                // flight: the LDS latency is off the chain state -> slot -> table -> state (the ring mirrors its first 4 items behind its end)
+                const u32 qi = q & (A1_RN - 1);
+                u32 i0 = ring16[qi], i1 = ring16[qi + 1], i2 = ring16[qi + 2], i3 = ring16[qi + 3];
+                KNZ_KEEP4(i0, i1, i2, i3);                                   // (read here, not where one of them is picked)
                 const u32 sym = e & 0xFF;
                 st = ((e >> 8) & 0xFFF) * (st >> lr) + slotv - (e >> 20);
                 const bool flag = st < ANS_TOP;
                 const u32 m = (u32)KNZ_BALLOT_OF(flag, 0xFull) & 0xF;        // (lanes 0-3 are in here)
-                if (flag) {
-                    const u32 kk = __popc(m & higherMask);
-                    st = (st << 16) | (u32)ring16[(q + kk) & (A1_RN - 1)];
-                }
+                const u32 kk = __popc(m & higherMask);
+                const u32 it = (kk & 2) ? ((kk & 1) ? i3 : i2) : ((kk & 1) ? i1 : i0);
+                st = flag ? ((st << 16) | it) : st;
                 q += __popc(m);
                 prv = sym;
                 acc |= sym << (8 * (s & 3));

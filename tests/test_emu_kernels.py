@@ -255,6 +255,7 @@ def test_ans1_decoder_kernels_emulated(tmp_path):
     rng = np.random.default_rng(19)
     blocks = [c.text(30000, 1), rng.integers(0, 256, 20000, dtype=np.uint8).tobytes(), bytes(9000), b"ab" * 5000, c.mixed(300000, 2)[250000:270000],
               rng.integers(0, 3, 7001, dtype=np.uint8).tobytes(), b"x" * 31, b"q" * 33, c.text(4099, 3)]
+    blocks += [c.text(n, 5) for n in (34, 37, 255, 256, 259, 260, 263, 511, 516)]        # quarters around one and two stretches of 64 steps
     path = str(tmp_path / "ans1.bin")
     write_case(path, blocks)
     r = subprocess.run([exe, path], capture_output=True, text=True, timeout=1500)
@@ -268,6 +269,7 @@ def test_ans1_encoder_and_bit_assembly_emulated(tmp_path):
     rng = np.random.default_rng(23)
     blocks = [c.text(30000, 1), rng.integers(0, 256, 12000, dtype=np.uint8).tobytes(), bytes(9000), b"ab" * 5000, c.mixed(300000, 2)[250000:265000],
               rng.integers(0, 3, 7001, dtype=np.uint8).tobytes(), b"x" * 31, b"q" * 33, c.text(4099, 3)]
+    blocks += [c.text(n, 5) for n in (34, 37, 255, 256, 259, 260, 263, 511, 516)]        # quarters around one and two stretches of 64 steps
     path = str(tmp_path / "ans1e.bin")
     write_case(path, blocks)
     r = subprocess.run([exe, path], capture_output=True, text=True, timeout=1500)
