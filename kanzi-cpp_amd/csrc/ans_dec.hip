@@ -19,7 +19,7 @@
 //                  filled by the chunk's own lanes (loads issued 8 steps ahead), so that no global load
 //                  sits on the dependent chain; 4x4 symbols are transposed with DPP so that every lane
 //                  stores one aligned dword.
-//   k_ans1_*       order 1: per-context slot tables in HBM, one wave per 4 MiB chunk (see below).
+//   k_ans1_*       order 1: one wave per 4 MiB chunk, the chunk's cumulative frequencies in LDS, a wave-wide search per step (see below).
 #include "common.hpp"
 #include "stages.hpp"
 
@@ -59,9 +59,9 @@ __device__ __forceinline__ u32 rl(u32 v, u32 l) { return (u32)__builtin_amdgcn_r
 // values the compiler must have in registers at this point (it would otherwise move an LDS read it thinks is optional behind the
 // condition that picks it, i.e. behind the memory load the read is meant to overlap)
 #ifdef KNZ_EMU
-#define KNZ_KEEP4(a, b, c, d) ((void)0)
+#define KNZ_KEEP3(a, b, c) ((void)0)
 #else
-#define KNZ_KEEP4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+#define KNZ_KEEP3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
 #endif
 __device__ __forceinline__ u32 uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ u64 uni64(u64 v) { return ((u64)uni((u32)(v >> 32)) << 32) | uni((u32)v); }
@@ -616,11 +616,17 @@ void launch_ans0_decode(hipStream_t s, BitSrc src, DecBlock* blocks, int nBlocks
 // ------------------------------------------------------------------------------------------------
 // order 1 (ANSRangeDecoder.cpp:80-175 with 256 contexts, :218-292 order-1 branch)
 // ------------------------------------------------------------------------------------------------
-constexpr u32 A1_SLOTS_PER_CTX = 2048;       // 1 << 11
+// Round 5: the tables of a chunk are the CUMULATIVE FREQUENCIES of its 256 contexts, 257 16-bit values each = 129 KiB, and live in the
+// LDS of the CU that decodes the chunk. The slot tables of the rounds before (symbol | frequency | cumulative per slot: 2 MiB per chunk,
+// 6-7 chunks per XCD against 4 MiB of L2, every context hot in LZ output) made every step wait for a load from beyond the L2: 245 ns per
+// step, 257 ms per 4 MiB chunk. A step now finds its symbol by searching the context's row with the wave: 16 lanes per state, two levels
+// of 16 (every 16th value, then the 16 values of the block that holds the slot), each one LDS read and one ballot.
+constexpr u32 A1_ROW = 258;                  // 16-bit values per context row: cum[0 .. 256] (cum[256] = 1 << lr) and one of padding
+constexpr u32 A1_TAB_WORDS = 256 * A1_ROW / 2;
 
-// one wave per (chunk, context): slotTab[slot] = sym | freq << 8 | cum << 20
+// one wave per (chunk, context): row[s] = sum of the frequencies of the symbols below s
 __global__ __launch_bounds__(64) void k_ans1_tables(BitSrc src, DecBlock* __restrict__ blocks, int chunksPerBlock, int maxChunks,
-                                                    const AnsDecChunk* __restrict__ chunks, u32* __restrict__ slotTab)
+                                                    const AnsDecChunk* __restrict__ chunks, u32* __restrict__ cumTab)
 {
     const int gc = blockIdx.x >> 8;
     const u32 ctx = blockIdx.x & 255;
@@ -632,8 +638,6 @@ __global__ __launch_bounds__(64) void k_ans1_tables(BitSrc src, DecBlock* __rest
     const AnsDecChunk& c = cs[ctx];
     if (c.kind != 0) return;
     const int lane = lane_id();
-    __shared__ u32 ent[260];
-    __shared__ u16 cumArr[260];
     const u32 lr = c.lr;
     const u32 scale = 1u << lr;
     const u32 asz = c.asz;
@@ -681,51 +685,22 @@ __global__ __launch_bounds__(64) void k_ans1_tables(BitSrc src, DecBlock* __rest
     }
     const u32 tot = f[0] + f[1] + f[2] + f[3];
     const u32 cincl = wave_incl_scan(tot);
-    u32 cum = cincl - tot;
-    {
-        u32 rr = rank0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if ((present >> k) & 1) {
-                const u32 fr = f[k];
-                const u32 fclip = (fr >= scale) ? scale - 1 : fr;       // ANSRangeDecoder.hpp:47-49
-                ent[rr] = (4u * (u32)lane + (u32)k) | (fclip << 8) | (cum << 20);
-                cumArr[rr] = (u16)cum;
-                if (rr + 1 == asz) cumArr[rr + 1] = (u16)scale;
-                cum += fr;
-                rr++;
-            }
-        }
-    }
-    __syncthreads();
-    u32* tab = slotTab + ((size_t)gc * 256 + ctx) * A1_SLOTS_PER_CTX;
-    const u32 per = scale >> 6;                  // slots per lane (scale >= 256)
-    const u32 base = (u32)lane * per;
-    u32 lo = 0, hi = asz - 1;
-    while (lo < hi) {
-        const u32 mid = (lo + hi + 1) >> 1;
-        if (cumArr[mid] <= base) lo = mid; else hi = mid - 1;
-    }
-    u32 sr = lo;
-    for (u32 k = 0; k < per; k++) {
-        const u32 t = base + k;
-        while (cumArr[sr + 1] <= t) sr++;        // cumArr[asz] = scale > t
-        tab[t] = ent[sr];
-    }
+    const u32 c0 = cincl - tot, c1 = c0 + f[0], c2 = c1 + f[1], c3 = c2 + f[2];
+    u32* row = cumTab + (size_t)gc * A1_TAB_WORDS + ctx * (A1_ROW / 2);
+    row[2 * lane] = c0 | (c1 << 16);
+    row[2 * lane + 1] = c2 | (c3 << 16);
+    if (lane == 63) row[128] = scale;            // (= c3 + f[3])
 }
 
 constexpr u32 A1_RN = 1024;                  // ring items (16-bit)
 constexpr u32 A1_INTERVAL = 64;              // steps between ring checks (<= 4 items per step)
 
-// one wave per chunk: lanes 0-3 are the 4 states (state j decodes quarter j forwards, context = previous symbol
-// of the same quarter), all lanes keep the payload ring filled
+// one wave per chunk: lanes 16 j .. 16 j + 15 are state j (state j decodes quarter j forwards, context = previous symbol of the same
+// quarter); every lane of a group holds the group's state, and all lanes keep the payload ring filled
 __global__ __launch_bounds__(64) void k_ans1_decode(BitSrc src, DecBlock* __restrict__ blocks, int chunksPerBlock, int maxChunks,
-                                                    const AnsDecChunk* __restrict__ chunks, const u32* __restrict__ slotTab,
+                                                    const AnsDecChunk* __restrict__ chunks, const u32* __restrict__ cumTab,
                                                     u8* const* __restrict__ outPtr, int nBlocks)
 {
-    // Workgroups go to the XCDs round robin, and a chunk's table (2 MiB) lives in the L2 of the XCD that decodes it. The first
-    // chunk of a block is a full one (4 MiB of symbols), the last one usually short: numbered block by block, the long chunks of
-    // blocks with two chunks would all meet on the even XCDs (four tables in a 4 MiB L2). Chunk index first spreads them.
     const int ci = (int)blockIdx.x / nBlocks;
     const int b = (int)blockIdx.x - ci * nBlocks;
     const int gc = b * chunksPerBlock + ci;
@@ -749,9 +724,16 @@ __global__ __launch_bounds__(64) void k_ans1_decode(BitSrc src, DecBlock* __rest
     const u32 mask = (1u << lr) - 1;
     const u64 payBit = rec.payloadBit;
     const u32 sz = rec.sz;
-    const u32* tab = slotTab + (size_t)gc * 256 * A1_SLOTS_PER_CTX;
 
-    __shared__ u32 ring[A1_RN / 2 + 2];          // 16-bit items in value form, 2 per word, + 4 mirrored items
+    __shared__ u32 cumL[A1_TAB_WORDS];           // 129 KiB: the chunk's 256 rows
+    {
+        const u32* tab = cumTab + (size_t)gc * A1_TAB_WORDS;
+        for (u32 i = (u32)lane * 4; i < A1_TAB_WORDS; i += 256)
+            *reinterpret_cast<uint4*>(&cumL[i]) = *reinterpret_cast<const uint4*>(&tab[i]);       // (A1_TAB_WORDS is a multiple of 4)
+    }
+    const u16* cum16 = reinterpret_cast<const u16*>(cumL);
+
+    __shared__ u32 ring[A1_RN / 2 + 4];          // 16-bit items in value form, 2 per word, + 4 mirrored items (+ 2 words a read may touch)
     const u64 lastWord = ((src.nBytes + 3) >> 2) - 1;
     // lane loads stream bytes [off + 16*lane, +16) -> 8 items
     auto fill_half = [&](u32 streamOff) {
@@ -775,55 +757,66 @@ __global__ __launch_bounds__(64) void k_ans1_decode(BitSrc src, DecBlock* __rest
     fill_half(A1_RN);                            // bytes: one half = A1_RN/2 items = A1_RN bytes
     __syncthreads();
     u32 base = 0;                                // item index of ring slot 0's current content start (multiple of RN/2)
-    u32 q = 0;                                   // items consumed
-    u32 st = (lane < 4) ? rec.st[lane & 3] : 0u;
-    const u32 j = (u32)lane & 3;
-    const u32 higherMask = (0xFu << (j + 1)) & 0xFu;
-    const u16* ring16 = reinterpret_cast<const u16*>(ring);
-    u8* myDst = dst + (size_t)j * quarter;
-    u32 prv = 0;
-    u32 acc = 0;
-    // Output goes through LDS: a store inside the step loop sits in the same counter as the table load of the next step (and, being a
-    // flat store, in the LDS counter too), so every fourth step waited for a write to reach memory. 64 steps of the four states are
-    // staged (16 dwords each) and written by the whole wave between two stretches.
+    u32 q = 0;                                   // items consumed (the same in every lane)
+    const u32 g = (u32)lane >> 4, l16 = (u32)lane & 15;
+    const u32 gsh = 16 * g;
+    u32 st = rec.st[g];
+    const u64 GROUPS = 0x0001000100010001ull;    // one lane of every group
+    const u64 higher = GROUPS & ~((2ull << gsh) - 1ull);           // the states above this one take their items first
+    const u32 higherLo = (u32)higher, higherHi = (u32)(higher >> 32);
+    u32 row = 0;                                 // first value of the context's row (context 0 at the start of a quarter)
+    // Output goes through LDS: the symbols of 64 steps of the four states are staged (64 bytes each) and written by the whole wave
+    // between two stretches (a store inside the step loop would sit in the same counter as the loads of the ring refill).
     __shared__ u32 stage[4 * (A1_INTERVAL / 4)];
+    u8* const stage8 = reinterpret_cast<u8*>(stage) + g * A1_INTERVAL;
     u8* const q0 = dst;
     const bool alignedAll = ((reinterpret_cast<uintptr_t>(dst) | quarter) & 3) == 0;
+    u32 cC = cum16[16 * l16];                    // every 16th value of the row: the coarse level of the first step
     for (u32 s0 = 0; s0 < quarter; s0 += A1_INTERVAL) {
         // ring upkeep (uniform): once the consumer is in the upper half of what the ring holds, replace the lower half
-        const u32 qu = uni(q);
-        if (qu - base >= A1_RN / 2) {
+        if (q - base >= A1_RN / 2) {
             __syncthreads();
             fill_half(2 * (base + A1_RN));       // next half in stream order lands on the slots of the oldest half
             base += A1_RN / 2;
             __syncthreads();
         }
-        const u32 s1 = (s0 + A1_INTERVAL < quarter) ? s0 + A1_INTERVAL : quarter;
-        if (lane < 4) {
-            for (u32 s = s0; s < s1; s++) {
-                const u32 slotv = st & mask;
-                const u32 e = tab[prv * A1_SLOTS_PER_CTX + slotv];
-                // the four items this step may take (which one depends on the other states' flags) are read while the table load is in
-                // flight: the LDS latency is off the chain state -> slot -> table -> state (the ring mirrors its first 4 items behind its end)
-                const u32 qi = q & (A1_RN - 1);
-                u32 i0 = ring16[qi], i1 = ring16[qi + 1], i2 = ring16[qi + 2], i3 = ring16[qi + 3];
-                KNZ_KEEP4(i0, i1, i2, i3);                                   // (read here, not where one of them is picked)
-                const u32 sym = e & 0xFF;
-                st = ((e >> 8) & 0xFFF) * (st >> lr) + slotv - (e >> 20);
-                const bool flag = st < ANS_TOP;
-                const u32 m = (u32)KNZ_BALLOT_OF(flag, 0xFull) & 0xF;        // (lanes 0-3 are in here)
-                const u32 kk = __popc(m & higherMask);
-                const u32 it = (kk & 2) ? ((kk & 1) ? i3 : i2) : ((kk & 1) ? i1 : i0);
-                st = flag ? ((st << 16) | it) : st;
-                q += __popc(m);
-                prv = sym;
-                acc |= sym << (8 * (s & 3));
-                if ((s & 3) == 3) { stage[j * (A1_INTERVAL / 4) + ((s - s0) >> 2)] = acc; acc = 0; }
-            }
+        const u32 cnt = (quarter - s0 < A1_INTERVAL) ? (quarter - s0) : A1_INTERVAL;
+        // One wave issues an instruction every four cycles whatever the instruction is: the step is written for few instructions. Both
+        // levels test ONE bound (rows do not decrease, so "first value above the slot" finds the block and then the symbol).
+        for (u32 t = 0; t < cnt; t++) {
+            const u32 slotv = st & mask;
+            // the four items this step may take (which one depends on the other states' flags), read before they are needed
+            // (three aligned words and a shift: an LDS read that is not aligned to its size costs about 40 cycles more)
+            const u32 qw = (q & (A1_RN - 1)) >> 1;
+            u32 w0 = ring[qw], w1 = ring[qw + 1], w2 = ring[qw + 2];
+            // coarse: blocks of 16 symbols that begin at or below the slot (cum[0] = 0: at least one), the last of them holds the symbol
+            const u64 bC = __ballot(cC <= slotv);
+            const u32 nblk = (u32)__popc((u32)(bC >> gsh) & 0xFFFFu);
+            // fine: the first symbol of that block whose interval ends above the slot (intervals of absent symbols are empty)
+            const u32 hi = cum16[row + 16 * nblk + l16 - 15];
+            const u64 bF = __ballot(hi > slotv);
+            const u32 sym = (16 * nblk - 17 + (u32)__ffs((int)(((u32)(bF >> gsh) & 0xFFFFu) | 0x10000u))) & 0xFFu;     // (none: a damaged table; any symbol will do)
+            // its interval for every lane of the group, and the coarse level of the NEXT step (it depends on the symbol alone)
+            const u32 cl = cum16[row + sym], ch = cum16[row + sym + 1];     // (two 16-bit reads: one unaligned 32-bit read is slower)
+            row = __umul24(sym, A1_ROW);
+            cC = cum16[row + 16 * l16];
+            const u32 ish = 16 * (q & 1);
+            KNZ_KEEP3(w0, w1, w2);                                       // (read by now, not where one of them is picked: behind a branch)
+            const u32 itLo = (u32)((((u64)w1 << 32) | w0) >> ish), itHi = (u32)((((u64)w2 << 32) | w1) >> ish);
+            u32 fr = ch - cl;
+            fr = (fr > mask) ? mask : fr;                                // ANSRangeDecoder.hpp:47-49 (a frequency of 1 << lr is kept as (1 << lr) - 1)
+            st = __umul24(fr, st >> lr) + (slotv - cl);                  // (fr < 2^11, st >> lr < 2^21)
+            const bool flag = st < ANS_TOP;
+            const u64 bR = __ballot(flag);
+            const u32 kk = (u32)__popc((u32)bR & higherLo) + (u32)__popc((u32)(bR >> 32) & higherHi);
+            const u32 it = (u32)((((u64)itHi << 32) | itLo) >> (16 * kk)) & 0xFFFFu;
+            st = flag ? ((st << 16) | it) : st;
+            q += (u32)__popcll(bR & GROUPS);
+            if (l16 == 0) stage8[t] = (u8)sym;                             // (measured: the branch is cheaper than a write by all lanes)
         }
         __syncthreads();
         {
-            const u32 full = (s1 - s0) >> 2;                          // whole dwords per state in this stretch
+            const u32 full = cnt >> 2;                                // whole dwords per state in this stretch
             const u32 jj = (u32)lane >> 4, dw = (u32)lane & 15;
             if (dw < full) {
                 const u32 v = stage[jj * (A1_INTERVAL / 4) + dw];
@@ -831,12 +824,13 @@ __global__ __launch_bounds__(64) void k_ans1_decode(BitSrc src, DecBlock* __rest
                 if (alignedAll) st_global_u32(o, v);
                 else { o[0] = (u8)v; o[1] = (u8)(v >> 8); o[2] = (u8)(v >> 16); o[3] = (u8)(v >> 24); }
             }
+            // the last bytes of a quarter that is not a multiple of four
+            if (dw == 0 && (cnt & 3)) {
+                u8* o = q0 + (size_t)jj * quarter + s0 + 4 * full;
+                for (u32 k = 0; k < (cnt & 3); k++) o[k] = reinterpret_cast<const u8*>(stage)[jj * A1_INTERVAL + 4 * full + k];
+            }
         }
         __syncthreads();
-    }
-    if (lane < 4) {
-        const u32 rem = quarter & 3;
-        for (u32 k = 0; k < rem; k++) myDst[(quarter & ~3u) + k] = (u8)(acc >> (8 * k));
     }
     if (lane == 0) {
         const u32 p = 2 * q;
@@ -847,7 +841,7 @@ __global__ __launch_bounds__(64) void k_ans1_decode(BitSrc src, DecBlock* __rest
 }
 
 size_t ans1_meta_bytes(size_t nChunks) { return nChunks * 257 * sizeof(AnsDecChunk); }
-size_t ans1_slottab_bytes(size_t nChunks) { return nChunks * 256 * A1_SLOTS_PER_CTX * sizeof(u32); }
+size_t ans1_slottab_bytes(size_t nChunks) { return nChunks * A1_TAB_WORDS * sizeof(u32) + 64; }
 
 void launch_ans1_decode(hipStream_t s, BitSrc src, DecBlock* blocks, int nBlocks, int chunksPerBlock, const Ans1DecWs& ws, u8* const* outPtr)
 {
@@ -855,6 +849,7 @@ void launch_ans1_decode(hipStream_t s, BitSrc src, DecBlock* blocks, int nBlocks
     const int maxChunks = chunksPerBlock * 257;
     const int nCh = nBlocks * chunksPerBlock;
     { KScope ks_("k_ans1_scan"); hipLaunchKernelGGL(k_ans_scan<1>, dim3(nBlocks), dim3(64), 0, s, src, blocks, nBlocks, maxChunks, chunks); }
+    (void)hipMemsetAsync(ws.slotTab, 0, ans1_slottab_bytes((size_t)nCh), s);      // (rows of contexts a chunk does not have stay empty)
     { KScope ks_("k_ans1_tables"); hipLaunchKernelGGL(k_ans1_tables, dim3(nCh * 256), dim3(64), 0, s, src, blocks, chunksPerBlock, maxChunks, chunks, ws.slotTab); }
     { KScope ks_("k_ans1_decode"); hipLaunchKernelGGL(k_ans1_decode, dim3(nCh), dim3(64), 0, s, src, blocks, chunksPerBlock, maxChunks, chunks, ws.slotTab, outPtr, nBlocks); }
 }
