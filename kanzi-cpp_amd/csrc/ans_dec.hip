@@ -524,7 +524,6 @@ __global__ __launch_bounds__(64) void k_ans0_decode(BitSrc src, DecBlock* __rest
     const u32 maxSteps = wave_max(steps);
     const u8* bkt = bktAll + g * 1024;
     const u32* symt = symAll + g * SYM_STRIDE;
-    const u16* ring16 = reinterpret_cast<const u16*>(ringW);
     u32 q = 0;                            // 16-bit items consumed (shared by the chunk's 4 lanes)
     u32 F = RB;                           // stream bytes [F - RB, F) are in the ring
     u32 pend[5];                          // raw words of stream bytes [F + 16j, +16), loaded one interval ago
@@ -532,12 +531,16 @@ __global__ __launch_bounds__(64) void k_ans0_decode(BitSrc src, DecBlock* __rest
     const u32 higherMask = (0xFu << (j + 1)) & 0xFu;
     const bool aligned4 = act && ((reinterpret_cast<uintptr_t>(dst) & 3) == 0);
 
-    typedef u64 __attribute__((aligned(2))) u64_a2;
     // one decode step; returns the symbol in the low byte of `e`
     auto step = [&](u32 s) -> u32 {
         const u32 slotv = st & mask;
         const u32 rk = bkt[slotv >> 2];
-        const u64 items = *reinterpret_cast<const u64_a2*>(ring16 + (q & (RB / 2 - 1)));
+        // (three aligned words and a shift instead of one 64-bit read at a 2-byte-aligned address: LDS reads return in order, the wait for
+        // the bucket read above waits for this one too, and a read that is not aligned to its size costs about 40 cycles more)
+        const u32 qw = (q & (RB / 2 - 1)) >> 1;
+        const u32 rw0 = ringW[qw], rw1 = ringW[qw + 1], rw2 = ringW[qw + 2];
+        const u32 ish = 16 * (q & 1);
+        const u64 items = ((u64)(u32)((((u64)rw2 << 32) | rw1) >> ish) << 32) | (u32)((((u64)rw1 << 32) | rw0) >> ish);
         const u32 e0 = symt[rk], e1 = symt[rk + 1], e2 = symt[rk + 2], e3 = symt[rk + 3];
         const u32 key = (slotv << 20) | 0xFFFFFu;
         u32 e = e0;
