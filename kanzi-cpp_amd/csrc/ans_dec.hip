@@ -303,6 +303,7 @@ constexpr u32 RQ = 64;               // refill quantum (16 bytes per lane)
 constexpr u32 RSTRIDE = RB / 4 + 2;  // ring words per chunk incl. 8 mirrored bytes
 constexpr u32 CHECK_STEPS = 8;       // <= 8 bytes consumed per step -> <= RQ per interval
 constexpr u32 SYM_STRIDE = 260;
+constexpr u32 OST = 32;              // steps of output staged in LDS per chunk (dwords)
 
 // a store that is a global store whatever the compiler knows about the pointer (a flat store also counts as an LDS operation)
 __device__ __forceinline__ void st_global_u32(u8* p, u32 v)
@@ -313,6 +314,21 @@ __device__ __forceinline__ void st_global_u32(u8* p, u32 v)
     *reinterpret_cast<__attribute__((address_space(1))) u32*>(reinterpret_cast<uintptr_t>(p)) = v;
 #endif
 }
+
+__device__ __forceinline__ void st_global_u32x4(u8* p, u32x4 v)
+{
+#ifdef KNZ_EMU
+    *reinterpret_cast<u32x4*>(p) = v;
+#else
+    *reinterpret_cast<__attribute__((address_space(1))) u32x4*>(reinterpret_cast<uintptr_t>(p)) = v;
+#endif
+}
+// every load issued so far has arrived (before a burst of stores: one counter for loads and stores, counted in issue order)
+#ifdef KNZ_EMU
+#define KNZ_LOADS_DONE() ((void)0)
+#else
+#define KNZ_LOADS_DONE() __builtin_amdgcn_s_waitcnt(0x0F70)       /* vmcnt(0), the other counters left alone */
+#endif
 
 template <int K>
 __device__ __forceinline__ u32 quad_bcast(u32 v)
@@ -337,6 +353,7 @@ __global__ __launch_bounds__(64) void k_ans0_decode(BitSrc src, DecBlock* __rest
     __shared__ u32 ringAll[DCH * RSTRIDE];                     // payload as 16-bit items (value form)
     __shared__ u16 cumArr[260];
     __shared__ int chunkErr[DCH];
+    __shared__ __attribute__((aligned(16))) u32 stageAll[DCH * OST];                        // output of OST steps per chunk
     const int lane = lane_id();
     const int slotBase = blockIdx.x * DCH;
     if (lane < DCH) chunkErr[lane] = 0;
@@ -561,29 +578,57 @@ __global__ __launch_bounds__(64) void k_ans0_decode(BitSrc src, DecBlock* __rest
     };
     auto put_word = [&](u32 word, u32 stepIdx) {
         if (stepIdx < steps) {
-            if (aligned4) st_global_u32(dst + 4 * (size_t)stepIdx, word);
-            else { dst[4 * stepIdx] = (u8)word; dst[4 * stepIdx + 1] = (u8)(word >> 8); dst[4 * stepIdx + 2] = (u8)(word >> 16); dst[4 * stepIdx + 3] = (u8)(word >> 24); }
+            u8* o = dst + 4 * (size_t)stepIdx;
+            if (aligned4) st_global_u32(o, word);
+            else { stg<u8>(o, (u8)word); stg<u8>(o + 1, (u8)(word >> 8)); stg<u8>(o + 2, (u8)(word >> 16)); stg<u8>(o + 3, (u8)(word >> 24)); }
         }
+    };
+    // Output is staged in LDS, 32 steps (128 bytes) per chunk (more would cost the fourth workgroup of a CU its LDS), and leaves between two intervals, BEFORE the interval's refill loads are
+    // issued: loads and stores share one counter that counts in issue order, so a store inside the interval made the wait for the
+    // refill data of the next interval a wait for that store to reach memory -- once per 8 steps, ~ 100 ns per step (round 5; found
+    // with the order-1 coders). Now three intervals of four have no store in front of their loads, and the fourth has had 8 steps.
+    u32* stgw = stageAll + g * OST;
+    const bool aligned16 = act && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+    auto flush = [&](u32 base, u32 upto) {                // this chunk's output dwords [base, upto), base a multiple of OST
+        KNZ_WAVE_ORDER();
+        if (act) {
+            const u32 lim = (upto < steps) ? upto : steps;
+#pragma unroll
+            for (u32 k = 0; k < OST / 16; k++) {
+                const u32 d0 = base + (OST / 4) * (u32)j + 4u * k;     // lane j of the chunk writes a quarter of the staged dwords
+                if (d0 >= lim) continue;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(&stgw[(OST / 4) * (u32)j + 4u * k]);
+                if (aligned16 && d0 + 4 <= lim) st_global_u32x4(dst + 4 * (size_t)d0, v);
+                else {
+                    const u32 w[4] = { v.x, v.y, v.z, v.w };
+                    for (u32 i = 0; i < 4; i++) put_word(w[i], d0 + i);
+                }
+            }
+        }
+        KNZ_WAVE_ORDER();
     };
     load5(F + 16u * (u32)j, pend);
     u32 s0 = 0;
-    u32 heldWord = 0, heldIdx = 0xFFFFFFFFu;          // second quad of an interval, stored one step into the next
     for (; s0 + CHECK_STEPS <= maxSteps; s0 += CHECK_STEPS) {
         // ring upkeep.  Every interval every lane loads the next quantum at F (plain loads, no divergence, so
         // the compiler pipelines them across the interval); one interval later the data is committed to the
         // ring if the consumer has made room for it, else it is simply loaded again.
+        // (the refill data was asked for a whole interval ago: waiting for it here, on every path, costs nothing and tells the compiler
+        // that no load is outstanding when the stores of a flush are issued -- else it waits for them where it reuses a register)
+        KNZ_LOADS_DONE();
         if (s0 && act && F < sz && F + RQ <= 2 * q + RB) { store4(F + 16u * (u32)j, pend); F += RQ; }
+        if (s0 && (s0 & (OST - 1)) == 0) flush(s0 - OST, s0);
         load5(F + 16u * (u32)j, pend);
         u32 acc = 0;
 #pragma unroll
         for (u32 u = 0; u < CHECK_STEPS; u++) {
             acc |= step(s0 + u) << (8 * (u & 3));
-            if (u == 1) put_word(heldWord, heldIdx);
-            if (u == 3) { put_word(quad_transpose_word(acc, j), s0 + (u32)j); acc = 0; }
-            if (u == 7) { heldWord = quad_transpose_word(acc, j); heldIdx = s0 + 4 + (u32)j; }
+            if (u == 3) { stgw[(s0 & (OST - 1)) + (u32)j] = quad_transpose_word(acc, j); acc = 0; }
+            if (u == 7) stgw[(s0 & (OST - 1)) + 4 + (u32)j] = quad_transpose_word(acc, j);
         }
     }
-    put_word(heldWord, heldIdx);
+    if (s0 & (OST - 1)) flush(s0 & ~(OST - 1), s0);
+    else if (s0) flush(s0 - OST, s0);
     // remaining (< 8) steps; the ring still holds >= 64 unread bytes or everything up to the chunk's end
     if (s0 && act && F < sz && F + RQ <= 2 * q + RB) { store4(F + 16u * (u32)j, pend); F += RQ; }
     {
