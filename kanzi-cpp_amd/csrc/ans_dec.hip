@@ -211,16 +211,31 @@ __global__ __launch_bounds__(64) void k_ans_scan(BitSrc src, DecBlock* __restric
                 const u32 a1 = win[wi + (u32)lane + 64], b1 = win[wi + (u32)lane + 65];
                 const u32 r0 = sh ? ((a0 << sh) | (b0 >> (32 - sh))) : a0;
                 const u32 r1 = sh ? ((a1 << sh) | (b1 >> (32 - sh))) : a1;
+                // (per group: two readlanes, a shift, a scalar maximum for the width check and the lane write -- the walk is the scan's
+                // chain, 512 chunks x up to 32 groups per block, on a wave that issues one instruction per four cycles; the last group,
+                // whose count differs, is peeled so that the loop body has no select)
                 u32 rel = 0;
-                for (u32 g = 0; g < nGroups; g++) {
-                    const u32 i = rel >> 5;
+                u32 worst = 0;
+                auto width_at = [&](u32 r) -> u32 {
+                    const u32 i = r >> 5;
                     const u32 wlo = rl(r0, i & 63), whi = rl(r1, i & 63);
                     const u32 wsel = (i < 64) ? wlo : whi;
-                    const u32 logMax = (i < 128) ? ((wsel >> (28 - (rel & 31))) & 15u) : 15u;   // past the window: invalid
-                    tooBig |= (logMax > lr) ? 1u : 0u;
+                    return (i < 128) ? ((wsel >> (28 - (r & 31))) & 15u) : 15u;                  // past the window: invalid
+                };
+                u32 g = 0;
+                for (; g + 1 < nGroups; g++) {
+                    const u32 logMax = width_at(rel);
+                    worst = (logMax > worst) ? logMax : worst;
                     if ((u32)lane == g) myGrp = rel | (logMax << 12);
-                    rel += llr + ((g + 1 == nGroups) ? lastCnt : chk) * logMax;
+                    rel += llr + chk * logMax;
                 }
+                {
+                    const u32 logMax = width_at(rel);
+                    worst = (logMax > worst) ? logMax : worst;
+                    if ((u32)lane == g) myGrp = rel | (logMax << 12);
+                    rel += llr + lastCnt * logMax;
+                }
+                tooBig |= (worst > lr) ? 1u : 0u;
                 q = p + rel;
             } else {
                 for (u32 g = 0; g < nGroups; g++) {
