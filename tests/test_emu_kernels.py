@@ -250,6 +250,8 @@ def test_ans0_decoder_kernels_emulated(tmp_path):
     rng = np.random.default_rng(9)
     blocks = [c.text(50000, 1), rng.integers(0, 256, 40000, dtype=np.uint8).tobytes(), bytes(20000), b"ab" * 9000, c.mixed(300000, 2)[250000:299000],
               rng.integers(0, 3, 16385, dtype=np.uint8).tobytes(), b"x" * 31, c.text(16384, 3), bytes(range(256)) * 70, b"q" * 33, c.text(70001, 4)]
+    # more than 64 chunks in one block (the scan writes its chunk records out 64 at a time), and one exactly at the border
+    blocks += [c.text(16384 * 66 + 5, 6), c.text(16384 * 64, 7)]
     path = str(tmp_path / "ans0.bin")
     write_case(path, blocks)
     r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900)
