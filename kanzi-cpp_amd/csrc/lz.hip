@@ -33,8 +33,17 @@ constexpr int LZ_MINBLOCK = 24;
 
 __host__ __device__ inline int lz_max_encoded(int n) { return ((n <= 1024) ? n + 16 : n + n / 64) + 2; }
 
+// unaligned loads of block text, through the GLOBAL address space: a block's pointer comes out of an array of pointers, so the compiler
+// would make every access a flat load, which counts as an LDS operation too -- and the walk waits for its LDS windows all the time
+#ifdef KNZ_EMU
 __device__ __forceinline__ u64 ld64u(const u8* p) { u64 v; __builtin_memcpy(&v, p, 8); return v; }
 __device__ __forceinline__ u32 ld32u(const u8* p) { u32 v; __builtin_memcpy(&v, p, 4); return v; }
+#else
+typedef u64 __attribute__((aligned(1))) lz_u64_u;
+typedef u32 __attribute__((aligned(1))) lz_u32_u;
+__device__ __forceinline__ u64 ld64u(const u8* p) { return *(const __attribute__((address_space(1))) lz_u64_u*)(uintptr_t)p; }
+__device__ __forceinline__ u32 ld32u(const u8* p) { return *(const __attribute__((address_space(1))) lz_u32_u*)(uintptr_t)p; }
+#endif
 __device__ __forceinline__ void st64u(u8* p, u64 v) { __builtin_memcpy(p, &v, 8); }
 __device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ u64 sgpr64(u64 v)
@@ -409,7 +418,7 @@ __global__ __launch_bounds__(64) void k_lz_walk(XfStage st, LzWs ws)
                 }
                 // extend backwards, 64 bytes per step
                 for (;;) {
-                    const bool c = (pos - lane > anchor) && (ref - lane > lo) && (src[pos - 1 - lane] == src[ref - 1 - lane]);
+                    const bool c = (pos - lane > anchor) && (ref - lane > lo) && (ldg<u8>(src + (pos - 1 - lane)) == ldg<u8>(src + (ref - 1 - lane)));
                     const u64 fail = __ballot(!c);
                     const int k = fail ? __ffsll((long long)fail) - 1 : 64;
                     best += k; ref -= k; pos -= k;
