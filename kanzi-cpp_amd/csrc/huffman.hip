@@ -709,6 +709,12 @@ __global__ __launch_bounds__(64) void k_huff_scan(BitSrc src, DecBlock* __restri
     }
 }
 
+// every load issued so far has arrived (before a burst of stores: one counter for loads and stores, counted in issue order)
+#ifdef KNZ_EMU
+#define KNZ_HUF_LOADS_DONE() ((void)0)
+#else
+#define KNZ_HUF_LOADS_DONE() __builtin_amdgcn_s_waitcnt(0x0F70)   /* vmcnt(0), the other counters left alone */
+#endif
 constexpr int HUF_DEC_CHUNKS = 8;   // chunks per wave (4 lanes = 4 fragments each)
 
 // 8 chunks per wave.  Phase 1: the whole wave builds each chunk's 4096-entry table (canonical order by counting:
@@ -725,6 +731,7 @@ __global__ __launch_bounds__(64) void k_huff_decode(BitSrc src, DecBlock* __rest
     __shared__ u16 rStart[260];                       // table index where canonical rank r starts
     __shared__ u16 rVal[260];
     __shared__ int chunkErr[HUF_DEC_CHUNKS];
+    __shared__ u32 ringAll[64 * 32];                  // the fragments' streams: 32 words per lane
     const int lane = lane_id();
     const int slotBase = blockIdx.x * HUF_DEC_CHUNKS;
     if (lane < HUF_DEC_CHUNKS) chunkErr[lane] = 0;
@@ -828,60 +835,86 @@ __global__ __launch_bounds__(64) void k_huff_decode(BitSrc src, DecBlock* __rest
     const u64 lastWord = ((src.nBytes + 3) >> 2) - 1;
     const u64 w0 = fbeg >> 5;
     const u32 sh = (u32)fbeg & 31;
-    auto raw_word = [&](u32 k) -> u32 { const u64 w = w0 + k; return bswap32(src.words[w < lastWord ? w : lastWord]); };
-    // 32 stream bits starting at fragment bit 32*(k-1), bits past the fragment's end are zero (the reference
-    // decodes from a zero-padded copy of the fragment)
-    auto frag_word = [&](u32 k, u32 prevRaw, u32 raw) -> u32 {
-        const u32 v = sh ? ((prevRaw << sh) | (raw >> (32 - sh))) : prevRaw;
-        const u32 done = 32u * (k - 1);
-        const u32 valid = (fragBits > done) ? ((fragBits - done < 32u) ? fragBits - done : 32u) : 0u;
-        return valid == 32u ? v : (valid ? (v & ~((1u << (32 - valid)) - 1u)) : 0u);
+    // Round 5. The stream of a fragment reaches its lane through a ring of 32 words in LDS, as in k_ans0_decode: every 16 steps the lane
+    // asks for the 8 words behind what the ring holds (plain loads, issued unconditionally) and puts the 8 it asked for 16 steps earlier
+    // into the ring if there is room (else they are simply asked for again). The decode loop itself touches LDS only: the version before
+    // loaded the next word two steps before it was needed and stored every 4 symbols from inside the loop, and since loads and stores
+    // share one counter that counts in issue order (and a store through a pointer out of an array of pointers is a flat store, which
+    // counts as an LDS operation as well), every two steps waited for a load and every four for a store: 2.8 ms per 212 MB for a chain
+    // of four table lookups. Output: 64 steps in registers, written after an explicit wait for the loads, before the next are issued.
+    constexpr u32 HR = 32, HQ = 8;                     // ring words per lane, words per refill
+    u32* ring = ringAll + (u32)lane * HR;
+    // words [f, f + 8) of the fragment (32 stream bits each, bits past the fragment's end zero: the reference decodes from a zero-padded copy)
+    auto load9 = [&](u32 f, u32 raw[9]) {
+#pragma unroll
+        for (int t = 0; t < 9; t++) { const u64 w = w0 + f + t; raw[t] = src.words[w < lastWord ? w : lastWord]; }
+    };
+    auto store8 = [&](u32 f, const u32 raw[9]) {
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const u32 a = bswap32(raw[t]), c = bswap32(raw[t + 1]);
+            const u32 v = sh ? ((a << sh) | (c >> (32 - sh))) : a;
+            const u32 done = 32u * (f + t);
+            const u32 valid = (fragBits > done) ? ((fragBits - done < 32u) ? fragBits - done : 32u) : 0u;
+            ring[(f + t) & (HR - 1)] = valid == 32u ? v : (valid ? (v & ~((1u << (32 - valid)) - 1u)) : 0u);
+        }
     };
     const u16* tab = tables[g < HUF_DEC_CHUNKS ? g : 0];
-    u32 rawPrev = raw_word(0);
-    u32 k = 1;
-    u32 rawNext = raw_word(k);
-    u64 bitbuf = (u64)frag_word(k, rawPrev, rawNext) << 32;
-    rawPrev = rawNext; k++;
-    rawNext = raw_word(k);
-    bitbuf |= (u64)frag_word(k, rawPrev, rawNext);
-    rawPrev = rawNext; k++;
+    u32 pend[9];
+    load9(0, pend); store8(0, pend);
+    load9(HQ, pend); store8(HQ, pend);
+    u32 F = 2 * HQ;                                    // fragment words the ring has seen
+    u64 bitbuf = ((u64)ring[0] << 32) | ring[1];
+    u32 k = 2;                                         // next fragment word to take
+    u32 nv = ring[2];
     u32 cnt = 64;
-    rawNext = raw_word(k);
     u32 used = 0;
     bool bad = false;
     const u32 steps = act ? szFrag : 0;
     const u32 maxSteps = wave_max(steps);
     const bool al4 = act && ((reinterpret_cast<uintptr_t>(dst) & 3) == 0);
-    for (u32 i = 0; i < maxSteps; i += 4) {
-        u32 acc = 0;
+    load9(F, pend);
+    for (u32 i = 0; i < maxSteps; i += 64) {
+        u32 out[16];
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            // commit the word loaded two steps ago if there is room for it, then load the next candidate
-            const bool room = cnt <= 32;
-            const u32 v = frag_word(k, rawPrev, rawNext);
-            bitbuf |= room ? ((u64)v << (32 - cnt)) : 0ull;
-            cnt += room ? 32u : 0u;
-            rawPrev = room ? rawNext : rawPrev;
-            k += room ? 1u : 0u;
-            rawNext = raw_word(k);
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                const u32 val = tab[(u32)(bitbuf >> 52)];
-                const u32 len = val & 0xFF;
-                const bool on = (i + 2 * h + t) < steps;
-                acc |= (val >> 8) << (8 * (2 * h + t));
-                bitbuf = on ? (bitbuf << len) : bitbuf;
-                cnt -= on ? len : 0u;
-                used += on ? len : 0u;
+        for (int it = 0; it < 16; it++) {
+            if ((it & 3) == 0 && (i | (u32)it)) {
+                // (16 steps take at most 6 words; the ring never holds fewer than 10)
+                if (F - k <= HR - HQ) { store8(F, pend); F += HQ; }
+                load9(F, pend);
             }
+            u32 acc = 0;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const bool room = cnt <= 32;
+                bitbuf |= room ? ((u64)nv << (32 - cnt)) : 0ull;
+                cnt += room ? 32u : 0u;
+                k += room ? 1u : 0u;
+                nv = ring[k & (HR - 1)];                // (for the next half: off the lookup chain)
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const u32 val = tab[(u32)(bitbuf >> 52)];
+                    const u32 len = val & 0xFF;
+                    const bool on = (i + 4 * (u32)it + 2 * h + t) < steps;
+                    acc |= (val >> 8) << (8 * (2 * h + t));
+                    bitbuf = on ? (bitbuf << len) : bitbuf;
+                    cnt -= on ? len : 0u;
+                    used += on ? len : 0u;
+                }
+            }
+            out[it] = acc;
         }
         if (used > (V5 ? (u32)(ENT_CHUNK * HUF_MAX_LEN) : (8192u << 3))) bad = true;
-        if (i + 4 <= steps) {
-            if (al4) *reinterpret_cast<u32*>(dst + i) = acc;
-            else { dst[i] = (u8)acc; dst[i + 1] = (u8)(acc >> 8); dst[i + 2] = (u8)(acc >> 16); dst[i + 3] = (u8)(acc >> 24); }
-        } else {
-            for (u32 t = 0; i + t < steps; t++) dst[i + t] = (u8)(acc >> (8 * t));
+        KNZ_HUF_LOADS_DONE();
+#pragma unroll
+        for (int it = 0; it < 16; it++) {
+            const u32 o = i + 4 * (u32)it;
+            if (o + 4 <= steps) {
+                if (al4) stg<u32>(dst + o, out[it]);
+                else { stg<u8>(dst + o, (u8)out[it]); stg<u8>(dst + o + 1, (u8)(out[it] >> 8)); stg<u8>(dst + o + 2, (u8)(out[it] >> 16)); stg<u8>(dst + o + 3, (u8)(out[it] >> 24)); }
+            } else {
+                for (u32 t = 0; o + t < steps; t++) stg<u8>(dst + o + t, (u8)(out[it] >> (8 * t)));
+            }
         }
     }
     if (act) {
