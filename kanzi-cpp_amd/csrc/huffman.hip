@@ -161,7 +161,7 @@ __global__ __launch_bounds__(64) void k_huff_encode(BlockView view, int maxChunk
     __shared__ u16 sizes[256];
     __shared__ u16 codes[256];       // (len << 12) | code
     __shared__ u32 fragw[HUF_FRAG_WORDS];
-    __shared__ u32 sh_hdrBits;
+    __shared__ u32 sh_maxCodeLen;
 
     for (int i = lane; i < 8 * 264; i += 64) (&hist[0][0])[i] = 0;
     for (int i = lane; i < (int)HDR_WORDS; i += 64) hdrw[i] = 0;
@@ -330,40 +330,65 @@ __global__ __launch_bounds__(64) void k_huff_encode(BlockView view, int maxChunk
                     }
                 }
             }
-            if (maxCodeLen > HUF_MAX_LEN) {
-                for (u32 i = 0; i < asz; i++) { codes[alpha[i]] = (u16)i; sizes[alpha[i]] = 8; }
-            } else {
-                // generateCanonicalCodes (HuffmanCommon.cpp:29-63): symbols ordered by (length, symbol)
-                int code = 0, curLen = 0, first = 1;
-                for (int l = 1; l <= HUF_MAX_LEN; l++) {
-                    for (u32 i = 0; i < asz; i++) {
-                        const u32 s = alpha[i];
-                        if (sizes[s] != l) continue;
-                        if (first) { curLen = l; first = 0; }
-                        code <<= (l - curLen);
-                        curLen = l;
-                        codes[s] = (u16)code;
-                        code++;
-                    }
-                }
-            }
+            sh_maxCodeLen = maxCodeLen;
         }
-        // length deltas (HuffmanEncoder.cpp:111-123)
-        u32 p = pos;
-        int prevSize = 2;
-        for (u32 i = 0; i < asz; i++) {
-            const u32 s = alpha[i];
-            codes[s] |= (u16)(sizes[s] << 12);
-            u32 c, nb;
-            eg_signed((int)(int8_t)(u8)(sizes[s] - prevSize), c, nb);
-            or_bits_words(hdrw, p, c, nb);
-            p += nb;
-            prevSize = sizes[s];
-        }
-        sh_hdrBits = p;
     }
     __syncthreads();
-    const u32 hdrBits = sh_hdrBits;
+    if (asz > 1) {
+        if (sh_maxCodeLen > (u32)HUF_MAX_LEN) {
+            for (u32 i = lane; i < asz; i += 64) { codes[alpha[i]] = (u16)i; sizes[alpha[i]] = 8; }
+        } else {
+            // generateCanonicalCodes (HuffmanCommon.cpp:29-63): symbols ordered by (length, symbol). Round 5: by the whole wave -- per
+            // length a prefix count over the lanes' four symbols (the symbols of a length in symbol order), the first code of a length
+            // from the one before; as one lane's loop over 12 lengths x the alphabet this was 40 % of the kernel.
+            u32 sz4[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) sz4[k] = sizes[4 * lane + k];
+            u32 code = 0, curLen = 0;
+            bool first = true;
+            for (u32 l = 1; l <= (u32)HUF_MAX_LEN; l++) {
+                u32 mineCount = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) mineCount += (sz4[k] == l) ? 1u : 0u;
+                const u32 incl = wave_incl_scan(mineCount);
+                const u32 total = (u32)__shfl((int)incl, 63, 64);
+                if (total == 0) continue;
+                if (first) { curLen = l; first = false; }
+                code <<= (l - curLen);
+                curLen = l;
+                u32 r = code + incl - mineCount;
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (sz4[k] == l) codes[4 * lane + k] = (u16)(r++);
+                code += total;
+            }
+        }
+    }
+    __syncthreads();
+    // length deltas (HuffmanEncoder.cpp:111-123), by the whole wave: lane l codes the alphabet entries 4 l .. 4 l + 3 (each against the
+    // length of the entry before it), the bit positions are a prefix sum
+    u32 hdrBits;
+    {
+        u32 cc[4], nn[4], nbSum = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const u32 r = 4 * (u32)lane + t;
+            cc[t] = 0; nn[t] = 0;
+            if (r < asz) {
+                const u32 sy = alpha[r];
+                const u32 szr = sizes[sy];
+                const u32 prevSize = r ? (u32)sizes[alpha[r - 1]] : 2u;
+                eg_signed((int)(int8_t)(u8)(szr - prevSize), cc[t], nn[t]);
+                codes[sy] = (u16)(codes[sy] | (szr << 12));
+                nbSum += nn[t];
+            }
+        }
+        const u32 incl = wave_incl_scan(nbSum);
+        u32 p = pos + incl - nbSum;
+#pragma unroll
+        for (int t = 0; t < 4; t++) { or_bits_words(hdrw, p, cc[t], nn[t]); p += nn[t]; }
+        hdrBits = pos + (u32)__shfl((int)incl, 63, 64);
+    }
+    __syncthreads();
     u32* hdrOut = reinterpret_cast<u32*>(tmp + (size_t)slot * TMP_STRIDE);
     for (u32 i = lane; i < ((hdrBits + 31) >> 5); i += 64) hdrOut[i] = bswap32(hdrw[i]);
 
