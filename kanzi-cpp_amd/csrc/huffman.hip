@@ -756,10 +756,16 @@ __global__ __launch_bounds__(64) void k_huff_scan(BitSrc src, DecBlock* __restri
 #else
 #define KNZ_HUF_LOADS_DONE() __builtin_amdgcn_s_waitcnt(0x0F70)   /* vmcnt(0), the other counters left alone */
 #endif
-constexpr int HUF_DEC_CHUNKS = 8;   // chunks per wave (4 lanes = 4 fragments each)
+constexpr int HUF_DEC_CHUNKS = 16;  // chunks per wave (4 lanes = 4 fragments each)
+constexpr u32 HUF_PRIM_BITS = 10;   // codes of up to 10 bits are looked up by the top 10 bits of the window
+constexpr u32 HUF_OVF = 512;        // table entries of the longer codes: at most 256 codes of 11 or 12 bits, two or one 12-bit slots each
 
-// 8 chunks per wave.  Phase 1: the whole wave builds each chunk's 4096-entry table (canonical order by counting:
-// per code length a wave prefix sum of how many of my 4 symbols have it).  Phase 2: one lane per fragment keeps
+// 16 chunks per wave.  Phase 1: the whole wave builds each chunk's table (canonical order by counting: per code length a wave prefix sum
+// of how many of my 4 symbols have it).  The table of the reference has 4096 entries (12 bits, 8 KiB per chunk: 16 chunks per CU, 3.2
+// rounds of workgroups over the 12.9 k chunks of a 212 MB job); here it is two: 1024 entries for the top 10 bits (every code of up to 10
+// bits covers whole groups of four 12-bit slots, and so does the unassigned tail behind the last code) and up to 512 for the 12-bit slots
+// of the codes of 11 and 12 bits, which are consecutive (canonical codes grow with their length) -- 3 KiB per chunk, twice the chunks
+// per CU, every lane of the wave a fragment. A step reads both (the second at a clamped index) and picks by one unsigned compare.  Phase 2: one lane per fragment keeps
 // 32..64 bits of its stream in a register pair; the next 32 bits are loaded every 2 steps without a branch and
 // only committed when there is room (the load is simply repeated otherwise), so no global access sits on the
 // table-lookup chain.
@@ -768,7 +774,9 @@ template <bool V5>
 __global__ __launch_bounds__(64) void k_huff_decode(BitSrc src, DecBlock* __restrict__ blocks, int maxChunks, int nSlots,
                                                     const HufDecChunk* __restrict__ chunks, u8* const* __restrict__ outPtr)
 {
-    __shared__ u16 tables[HUF_DEC_CHUNKS][4096];      // (sym << 8) | len
+    __shared__ u16 prim[HUF_DEC_CHUNKS][1u << HUF_PRIM_BITS];   // (sym << 8) | len of 12-bit slot 4 q + 3
+    __shared__ u16 ovf[HUF_DEC_CHUNKS][HUF_OVF];                // ... of 12-bit slot longBase + i
+    __shared__ u16 longBase[HUF_DEC_CHUNKS], longCnt[HUF_DEC_CHUNKS];
     __shared__ u16 rStart[260];                       // table index where canonical rank r starts
     __shared__ u16 rVal[260];
     __shared__ int chunkErr[HUF_DEC_CHUNKS];
@@ -802,8 +810,9 @@ __global__ __launch_bounds__(64) void k_huff_decode(BitSrc src, DecBlock* __rest
 #pragma unroll
         for (int k = 0; k < 4; k++) sz[k] = (packed >> (8 * k)) & 0xFF;
         u32 rank[4] = { 0, 0, 0, 0 }, start[4] = { 0, 0, 0, 0 };
-        u32 rankBase = 0, startBase = 0;
+        u32 rankBase = 0, startBase = 0, lb = 0;
         for (u32 l = 1; l <= (u32)HUF_MAX_LEN; l++) {
+            if (l == HUF_PRIM_BITS + 1) lb = startBase;                  // the first 12-bit slot of a code longer than 10 bits
             u32 mine = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) mine += (sz[k] == l) ? 1u : 0u;
@@ -823,11 +832,11 @@ __global__ __launch_bounds__(64) void k_huff_decode(BitSrc src, DecBlock* __rest
         for (int k = 0; k < 4; k++) {
             if (sz[k]) { rStart[rank[k]] = (u16)start[k]; rVal[rank[k]] = (u16)(((4u * (u32)lane + (u32)k) << 8) | sz[k]); }
         }
-        if (lane == 0) { rStart[asz] = (u16)startBase; rVal[asz] = 0x0707; rStart[asz + 1] = 4097; }
+        if (lane == 0) { rStart[asz] = (u16)startBase; rVal[asz] = 0x0707; rStart[asz + 1] = 4097; longBase[gg] = (u16)lb; longCnt[gg] = (u16)(startBase - lb); }
         __syncthreads();
         {
-            // lane fills table slots [64*lane, 64*lane+64): find the rank covering the first slot, then walk
-            u16* tab = tables[gg];
+            // lane walks the 12-bit slots [64*lane, 64*lane+64): find the rank covering the first slot, then walk
+            const u32 nLongs = startBase - lb;                            // (<= 512: see HUF_OVF)
             const u32 base = (u32)lane * 64;
             u32 lo = 0, hi = asz;                     // rank asz = the unassigned tail (0x0707)
             while (lo < hi) {
@@ -835,12 +844,12 @@ __global__ __launch_bounds__(64) void k_huff_decode(BitSrc src, DecBlock* __rest
                 if (rStart[mid] <= base) lo = mid; else hi = mid - 1;
             }
             u32 r = lo;
-            u32 word = 0;
             for (u32 k = 0; k < 64; k++) {
                 const u32 t = base + k;
                 while (rStart[r + 1] <= t) r++;
-                word |= (u32)rVal[r] << (16 * (k & 1));
-                if (k & 1) { *reinterpret_cast<u32*>(tab + base + (k & ~1u)) = word; word = 0; }
+                const u32 v = rVal[r];
+                if ((k & 3) == 3) prim[gg][t >> 2] = (u16)v;
+                if (t - lb < nLongs) ovf[gg][t - lb] = (u16)v;
             }
         }
         __syncthreads();
@@ -900,7 +909,9 @@ __global__ __launch_bounds__(64) void k_huff_decode(BitSrc src, DecBlock* __rest
             ring[(f + t) & (HR - 1)] = valid == 32u ? v : (valid ? (v & ~((1u << (32 - valid)) - 1u)) : 0u);
         }
     };
-    const u16* tab = tables[g < HUF_DEC_CHUNKS ? g : 0];
+    const u16* tabP = prim[g];
+    const u16* tabO = ovf[g];
+    const u32 lb12 = longBase[g], nL12 = act ? (u32)longCnt[g] : 0u;
     u32 pend[9];
     load9(0, pend); store8(0, pend);
     load9(HQ, pend); store8(HQ, pend);
@@ -934,7 +945,11 @@ __global__ __launch_bounds__(64) void k_huff_decode(BitSrc src, DecBlock* __rest
                 nv = ring[k & (HR - 1)];                // (for the next half: off the lookup chain)
 #pragma unroll
                 for (int t = 0; t < 2; t++) {
-                    const u32 val = tab[(u32)(bitbuf >> 52)];
+                    const u32 t12 = (u32)(bitbuf >> 52);
+                    const u32 oi = t12 - lb12;
+                    const bool isLong = oi < nL12;
+                    const u32 pv = tabP[t12 >> 2], ov = tabO[isLong ? oi : 0u];
+                    const u32 val = isLong ? ov : pv;
                     const u32 len = val & 0xFF;
                     const bool on = (i + 4 * (u32)it + 2 * h + t) < steps;
                     acc |= (val >> 8) << (8 * (2 * h + t));
