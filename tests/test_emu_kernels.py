@@ -233,6 +233,12 @@ def test_huffman_decoder_kernels_emulated(tmp_path):
     blocks = [c.text(50000, 1), rng.integers(0, 256, 40000, dtype=np.uint8).tobytes(), bytes(20000), b"ab" * 9000, c.mixed(300000, 2)[250000:299000],
               rng.integers(0, 3, 16385, dtype=np.uint8).tobytes(), b"x" * 31, c.text(16384, 3), bytes(range(256)) * 70,
               (rng.integers(0, 256, 30000, dtype=np.uint8) & 0x55).tobytes()]
+    # geometric frequencies: codes of 11 and 12 bits and the length limiter (the decoder keeps those in a table of their own), with 40, 120
+    # and 256 symbols; and two symbols that are all but absent beside one that fills the chunk
+    for nsym, seed in ((40, 21), (120, 22), (256, 23)):
+        g = np.random.default_rng(seed).geometric(0.35, 40000)
+        blocks.append((np.minimum(g - 1, nsym - 1).astype(np.uint8) * (255 // (nsym - 1)) if nsym < 256 else np.minimum((g - 1) * 7 % 256, 255).astype(np.uint8)).tobytes())
+    blocks.append(bytes(16000) + b"\x01\x02" + bytes(16766))
     path = str(tmp_path / "huff.bin")
     write_case(path, blocks)
     r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900)
@@ -369,6 +375,10 @@ def test_huffman_encoder_and_bit_assembly_emulated(tmp_path):
     blocks = [t[:16384], t[16384:20000], t, rng.integers(0, 256, 33000, dtype=np.uint8).tobytes(), bytes(20000), b"ab" * 9000,
               c.mixed(300000, 2)[250000:283000], rng.integers(0, 3, 16385, dtype=np.uint8).tobytes(), b"x" * 31, b"q" * 33, bytes(range(256)) * 70,
               (rng.integers(0, 256, 30000, dtype=np.uint8) & 0x0F).tobytes()]
+    # geometric frequencies: long codes, the length limiter, canonical codes over many lengths
+    for nsym, seed in ((40, 31), (120, 32), (256, 33)):
+        g = np.random.default_rng(seed).geometric(0.35, 40000)
+        blocks.append((np.minimum(g - 1, nsym - 1).astype(np.uint8) * (255 // (nsym - 1)) if nsym < 256 else np.minimum((g - 1) * 7 % 256, 255).astype(np.uint8)).tobytes())
     path = str(tmp_path / "huffe.bin")
     write_case(path, blocks)
     r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900)
