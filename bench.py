@@ -229,6 +229,58 @@ def end_to_end(data, cfg):
     return best
 
 
+def real_bytes_leg(ctx, torch, np, hipapi, corpus, framing, dev, steps=3, with_cpu=True):
+    """Config 9 inside the default run: config 3's chain on REAL bytes (files of this image, kanzi-cpp_amd/corpus.py:local -- no corpus
+    can be fetched and silesia.tar is on no box), `steps` timed encode+decode passes after one warm-up, device resident like `value`.
+    The driver's line is measured on the synthetic stand-in, whose repeats are shorter than those of real files; this object is the same
+    measurement on bytes nobody generated."""
+    cfg = CONFIGS[9]
+    data, desc = corpus.load(cfg["corpus"], None)
+    n = len(data)
+    bs = cfg["block"]
+    import hashlib
+    d_in = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+    d_in[:n].copy_(torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()))
+    p = ctx.params(cfg["transform"], cfg["entropy"], bs)
+    cap = ctx.encode_bound(p, n)
+    d_enc = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    d_dec = torch.empty(n + bs + 64, dtype=torch.uint8, device=dev)
+    hdr, hb = framing.make_header(p.entropy_type, p.transform_type, bs, 0, 0)
+    nb = (n + bs - 1) // bs
+    st = {}
+
+    def one():
+        st["bits"] = ctx.encode_blocks(p, d_in.data_ptr(), n, d_enc.data_ptr(), cap, prologue=hdr, prologue_bits=hb)
+        st["out"] = ctx.decode_blocks(p, d_enc.data_ptr(), st["bits"], hb, d_dec.data_ptr(), n + bs, max_blocks=max(nb, 1))[0]
+
+    one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    assert st["out"] == n and torch.equal(d_dec[:n], d_in[:n]), "round trip mismatch (real bytes)"
+    # doubling rounds and stage time of the suffix sort, one profiled encode
+    ctx.set_profiling(True)
+    ctx.encode_blocks(p, d_in.data_ptr(), n, d_enc.data_ptr(), cap, prologue=hdr, prologue_bits=hb)
+    kt = ctx.kernel_times()
+    ctx.set_profiling(False)
+    rounds = sum(l for nm, ms, l in kt if nm == "k_bwt_f_round")
+    fwd_ms = sum(ms for nm, ms, l in kt if stage_of(nm, "encode") == "bwt_forward")
+    out = {"value": round(n / el / 1e6, 2), "unit": "MB/s", "ms_per_step": round(el * 1e3, 4), "steps": steps, "warmup": 1,
+           "workload": "-t %s -e %s -b %dm, %s" % (cfg["transform"], cfg["entropy"], bs >> 20, desc), "corpus_bytes": n, "blocks": nb,
+           "input_md5": hashlib.md5(data).hexdigest(), "compressed_bytes": (st["bits"] + 7) // 8,
+           "bwt_doubling_rounds": rounds, "bwt_forward_stage_ms": round(fwd_ms, 4), "bit_exact_vs_reference": None, "cpu_baseline": None}
+    if with_cpu:
+        cpu, ref_enc = cpu_baseline(data, n, cfg, os.cpu_count() or 1)
+        out["cpu_baseline"] = cpu
+        if ref_enc is not None:
+            got = bytes(d_enc[:(st["bits"] + 7) // 8].cpu().numpy())
+            out["bit_exact_vs_reference"] = (got == ref_enc)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -240,6 +292,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=256 << 20, help="bytes of the workload the CPU reference is timed on (the whole silesia corpus fits)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-real", action="store_true", help="skip the real_bytes object (config 9, 3 steps) of the default single-GPU run")
     ap.add_argument("--reps", type=int, default=0, help="repetitions of the separate encode / decode / per-kernel timing passes (default: 2..5 by --steps)")
     ap.add_argument("--dist-backend", default="nccl", help="gloo + --share-device: the N-rank code path on a 1-GPU box (developer check)")
     ap.add_argument("--share-device", action="store_true", help="every rank uses cuda:0")
@@ -547,6 +600,12 @@ def main():
                     e2e = end_to_end(data, cfg)
                 except Exception as ex:      # the host library is a separate .so; its absence must not hide the device line
                     e2e = dict(error=str(ex))
+        real_bytes = None
+        if world == 1 and args.config == 3 and not args.limit and not args.no_real:
+            try:
+                real_bytes = real_bytes_leg(ctx, torch, np, hipapi, corpus, framing, dev, steps=3, with_cpu=not args.no_cpu)
+            except Exception as ex:          # (a box without the files of this image: the line must still come out)
+                real_bytes = dict(error=str(ex))
         if "k_bwt_f_round" in kern:
             roofline["bwt_doubling_rounds"] = round(kern["k_bwt_f_round"]["launches_per_step"], 1)
         ms_per_step = elapsed / args.steps * 1e3
@@ -570,6 +629,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "end_to_end": e2e,
+            "real_bytes": real_bytes,
         }
         if world > 1 and args.scaling == "strong":
             # what block granularity allows: the largest share is ceil(blocks / N) blocks, so N ranks can be at most blocks / ceil(blocks / N)

@@ -496,6 +496,10 @@ private:
     std::vector<Lane> _lanes;
     // The finished runs are appended to the sink by a thread of their own (KNZ_SINK_THREAD=0: by the caller's thread, between two
     // batches, as in round 4): the caller only fills staging slots, so the lanes are refilled while the sink is being written.
+    // THREADING CONTRACT (differs from the reference, which writes to the sink from the caller's thread only): between the first
+    // write() and the return of close() the std::ostream handed to the constructor is written from that thread -- the caller must not
+    // touch it meanwhile (tellp() of this class is safe: it reads a counter). An exception the sink throws there (exceptions() set, a
+    // streambuf that throws) is kept and rethrown, as it is, by the next write() / close() on the caller's thread.
     std::thread _sink;
     bool _sinkThread;
     bool _spreadCopies;           // staging copies over the helper threads (chains the device runs faster than one thread copies)

@@ -115,11 +115,7 @@ __global__ __launch_bounds__(64) void k_ans1_ctx(BlockView view, int chunksPerBl
 // space for the same reason (a flat load counts as an LDS operation, and the wait for the next record then waited for memory).
 // every load issued so far has arrived (used before a burst of stores, so that the wait for a load that follows in program order is not
 // a wait for the stores: one counter for both on this hardware)
-#ifdef KNZ_EMU
-#define KNZ_LOADS_DONE() ((void)0)
-#else
-#define KNZ_LOADS_DONE() __builtin_amdgcn_s_waitcnt(0x0F70)       /* vmcnt(0), the other counters left alone */
-#endif
+// (KNZ_LOADS_DONE: common.hpp)
 constexpr u32 A1E_ST = 64;                     // steps per stretch (= lanes: one step per lane when the emissions are placed)
 
 __global__ __launch_bounds__(64) void k_ans1_encode(BlockView view, int chunksPerBlock, ChunkDesc* __restrict__ desc,

@@ -339,11 +339,7 @@ __device__ __forceinline__ void st_global_u32x4(u8* p, u32x4 v)
 #endif
 }
 // every load issued so far has arrived (before a burst of stores: one counter for loads and stores, counted in issue order)
-#ifdef KNZ_EMU
-#define KNZ_LOADS_DONE() ((void)0)
-#else
-#define KNZ_LOADS_DONE() __builtin_amdgcn_s_waitcnt(0x0F70)       /* vmcnt(0), the other counters left alone */
-#endif
+// (KNZ_LOADS_DONE: common.hpp)
 
 template <int K>
 __device__ __forceinline__ u32 quad_bcast(u32 v)
@@ -831,6 +827,7 @@ __global__ __launch_bounds__(64) void k_ans1_decode(BitSrc src, DecBlock* __rest
     // Output goes through LDS: the symbols of 64 steps of the four states are staged (64 bytes each) and written by the whole wave
     // between two stretches (a store inside the step loop would sit in the same counter as the loads of the ring refill).
     __shared__ u32 stage[4 * (A1_INTERVAL / 4)];
+    static_assert(sizeof(cumL) + sizeof(ring) + sizeof(stage) + 1024 <= KNZ_LDS_BYTES, "k_ans1_decode: table + ring + stage must fit the LDS of one gfx950 workgroup");
     u8* const stage8 = reinterpret_cast<u8*>(stage) + g * A1_INTERVAL;
     u8* const q0 = dst;
     const bool alignedAll = ((reinterpret_cast<uintptr_t>(dst) | quarter) & 3) == 0;

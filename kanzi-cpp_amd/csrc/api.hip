@@ -1051,6 +1051,7 @@ int knz_hip_entropy_decode_v(knz_ctx* ctx, int entropy_type, int bs_version, con
 {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     CTX_LOCK(c);
+    if (bs_version < 0 || bs_version > 6) return fail(c, KNZ_ERR_STREAM_VERSION, "cannot read bitstream version %d", bs_version);   // (as knz_hip_transform_inverse_v)
     if (n == 0) { *decoded = 0; if (used_bits) *used_bits = 0; return 0; }
     knz_params p; memset(&p, 0, sizeof(p));
     p.entropy_type = entropy_type; p.block_size = (int32_t)((n + 15) & ~15u); p.bs_version = bs_version;

@@ -384,11 +384,15 @@ __global__ __launch_bounds__(256) void k_bwt_i_jump(const u32* __restrict__ next
 
 // ---- ranking the rows through rulers (round 5) ----------------------------------------------------------------------------------
 // Pointer jumping over all rows is 17-18 rounds of two random gathers per row: 119 M gathers for the 3.3 M rows of the headline
-// workload, 0.9 ms. One row in 32 (by a hash of its number; chain heads and terminals on top) is a RULER: a ruler walks to the next
-// one, ONCE, and tells every row it passes which ruler owns it and how far behind that ruler it lies; only the rulers (1/32 of the rows,
+// workload, 0.9 ms. One row in 8 (by a hash of its number, rlog = 3; chain heads and terminals on top) is a RULER: a ruler walks to the next
+// one, ONCE, and tells every row it passes which ruler owns it and how far behind that ruler it lies; only the rulers (1/8 of the rows,
 // in dense arrays) are ranked by pointer jumping; a row's distance to the end is its ruler's minus its offset. 3.3 M walked hops
 // instead of 119 M gathers. Damaged input (a cycle without a ruler, a row that points at itself) ends a walk after RULER_LIMIT steps
-// or at the self-loop: such rows get distances without meaning, never an access outside a buffer -- as with pointer jumping.
+// or at the self-loop: such rows get distances without meaning, never an access outside a buffer -- as with pointer jumping. A walk
+// that runs out of steps marks its BLOCK as failed (the stage's ok flag -> ERR_PROCESS_BLOCK, what the reference reports for a block
+// its inverse rejects): rulers are one row in eight by a hash of the row number (rlog = 3), so RULER_LIMIT rows in a row without one do
+// not happen by chance (7/8 to the 65,536th), but a block built on purpose to lead its chain through such rows must be refused, not
+// decoded to wrong bytes. KNZ_BWT_I_JUMP_ALL=1 (pointer jumping over all rows, rounds 3-4) decodes such a block.
 constexpr u32 RULER_LIMIT = 1u << 16;
 __device__ __forceinline__ bool ruler_hash(u32 c, u32 rlog) { return ((c * 2654435761u) >> (32 - rlog)) == 0; }
 __device__ __forceinline__ bool ruler_bit(const u32* __restrict__ rbits, u32 c) { return (rbits[c >> 5] >> (c & 31)) & 1u; }
@@ -422,7 +426,8 @@ __device__ __forceinline__ u32 ruler_rank(const u32* __restrict__ rbits, const u
 
 __global__ __launch_bounds__(256) void k_bwt_i_ruler_walk(const u32* __restrict__ succ, const u32* __restrict__ dist, const u32* __restrict__ rbits,
                                                           const u32* __restrict__ rprefix, const InvInfo* __restrict__ info, u32 maxRows, u32 maxRulers,
-                                                          u32* __restrict__ owner, u32* __restrict__ pre, u32* __restrict__ rS, u32* __restrict__ rD)
+                                                          u32* __restrict__ owner, u32* __restrict__ pre, u32* __restrict__ rS, u32* __restrict__ rD,
+                                                          const u32* __restrict__ rowBlk, u8* __restrict__ ok)
 {
     const u32 c = blockIdx.x * 256 + threadIdx.x;
     u32 count = info->count;
@@ -436,7 +441,8 @@ __global__ __launch_bounds__(256) void k_bwt_i_ruler_walk(const u32* __restrict_
     u32 acc = dist[c];
     if (x == c) { rS[idx] = idx; rD[idx] = acc; return; }       // terminal (dist 0)
     u32 to = idx;                                                // where the walk ends when it does not meet a ruler
-    for (u32 steps = 0; steps < RULER_LIMIT; steps++) {
+    u32 steps = 0;
+    for (; steps < RULER_LIMIT; steps++) {
         if (x >= rowsTotal) break;                               // (damaged input)
         if (x < count && ruler_bit(rbits, x)) { const u32 r = ruler_rank(rbits, rprefix, x); to = r < maxRulers ? r : idx; break; }
         owner[x] = idx;
@@ -446,6 +452,7 @@ __global__ __launch_bounds__(256) void k_bwt_i_ruler_walk(const u32* __restrict_
         if (nx == x) break;
         x = nx;
     }
+    if (steps == RULER_LIMIT) ok[rowBlk[c]] = 0;                 // out of steps: the block is not decoded (see above)
     rS[idx] = to;
     rD[idx] = (to == idx) ? 0u : acc;                            // a walk that found no ruler ends the chain there
 }
@@ -658,7 +665,7 @@ int launch_bwt_inverse(hipStream_t s, const XfStage& st, void* scratch, size_t s
         hipLaunchKernelGGL(k_bwt_i_ruler_flags, GRID1(rWords), w.hd, w.base, w.rowNode, w.rowBlk, nA, w.info, w.maxRows, rbits, rprefix, rlog);
         prims::launch_scan<prims::SCAN_SUM_EXCL>(s, rprefix, rprefix, rWords, nullptr, w.scanTmp, nRulers);
         hipMemsetAsync(nB, 0xFF, 4 * (size_t)w.maxRows, s);                      // owner: none
-        hipLaunchKernelGGL(k_bwt_i_ruler_walk, GRID1(w.maxRows), nA, dA, rbits, rprefix, w.info, w.maxRows, w.maxRulers, nB, dB, w.rS[0], w.rD[0]);
+        hipLaunchKernelGGL(k_bwt_i_ruler_walk, GRID1(w.maxRows), nA, dA, rbits, rprefix, w.info, w.maxRows, w.maxRulers, nB, dB, w.rS[0], w.rD[0], w.rowBlk, st.ok);
         int cur = 0;
         const u64 chainRulers = (chainRows >> (rlog - 1)) + 64;                     // (twice the expected rulers of the longest chain)
         for (u64 span = 1; span < chainRulers; span <<= 1) {

@@ -762,8 +762,20 @@ __global__ __launch_bounds__(256) void k_bwt_f_sort_small_text(BwtView bv, FwdVi
 // group at the end has depth h. Only groups whose positions lie below posEnd take part (0: below the end of the first block -- the trial
 // of the host policy covers that block only, and its bit map ends there: the window of the next block that rides along must neither
 // flag nor look up anything).
+// a trial looks at up to four whole blocks of the batch (a run never leaves its block, so the blocks' runs are complete)
+struct LinkTrial { int n; int blk[4]; };
+
+__device__ __forceinline__ bool link_tile(const FwdView& v, const LinkTrial& tr, u32 tileStep, u32& tile, u32& posLo, u32& posHi)
+{
+    if (tr.n == 0) { tile = blockIdx.x * tileStep; posLo = 0; posHi = v.total; return true; }
+    const int b = tr.blk[blockIdx.y];
+    posLo = v.base[b]; posHi = v.base[b + 1];
+    tile = posLo / SM_TS + blockIdx.x;                        // (the window that holds the block's first slot, and the ones behind it)
+    return tile * SM_TS < posHi;
+}
+
 __global__ __launch_bounds__(256) void k_bwt_f_link_small(FwdView v, u32* __restrict__ posflag, u32* __restrict__ linked, int stats, u32 tileStep,
-                                                          u32* __restrict__ linkedTile, u32 posEnd)
+                                                          u32* __restrict__ linkedTile, LinkTrial tr)
 {
     __shared__ SmWindow W;
     __shared__ int sAny;
@@ -772,7 +784,8 @@ __global__ __launch_bounds__(256) void k_bwt_f_link_small(FwdView v, u32* __rest
     __shared__ u32 sK[SM_WIN];
     __shared__ u32 sLinked[64];
     __shared__ u32 sCnt[4];
-    const u32 tile = blockIdx.x * tileStep;
+    u32 tile, posLo, posHi;
+    if (!link_tile(v, tr, tileStep, tile, posLo, posHi)) return;
     const u32 slot0 = tile * SM_TS;
     if (!sm_load_window(v, slot0, W, &sAny)) { if (threadIdx.x == 0) linkedTile[tile] = 0; return; }
     if (threadIdx.x < 64) sLinked[threadIdx.x] = 0;
@@ -799,7 +812,7 @@ __global__ __launch_bounds__(256) void k_bwt_f_link_small(FwdView v, u32* __rest
         const u32 i = threadIdx.x + 256u * k;
         if (!act[k] || i != gs[k]) continue;
         const u32 lab = sK[i];
-        bool ok = lab != 0xFFFFFFFFu && sP[i] < (posEnd ? posEnd : v.base[1]);   // (one group, one block: its first member speaks for all)
+        bool ok = lab != 0xFFFFFFFFu && sP[i] >= posLo && sP[i] < posHi;         // (one group, one block: its first member speaks for all)
         for (u32 j = gs[k] + 1; j < ge[k] && ok; j++) ok = sK[j] == lab;
         if (ok) atomicOr(&sLinked[i >> 5], 1u << (i & 31));
     }
@@ -825,20 +838,30 @@ __global__ __launch_bounds__(256) void k_bwt_f_link_small(FwdView v, u32* __rest
     if (threadIdx.x < 64 && sLinked[threadIdx.x]) atomicOr(&linked[(slot0 >> 5) + threadIdx.x], sLinked[threadIdx.x]);
 }
 
-// what the link step bought: members it linked against members still tied after the round, over the windows it was applied to
-// (slotEnd: the trial's windows are those that begin inside the first block, whose length the host does not know)
-__global__ __launch_bounds__(256) void k_bwt_f_link_payoff(const u32* __restrict__ linkedTile, const u32* __restrict__ survTile, u32 nTiles, u32 tileStep,
-                                                           u32* __restrict__ out, const u32* __restrict__ slotEnd)
+// what the link step bought: members it linked against members still tied after the round, over the windows it was applied to. A trial
+// on sample blocks pays when it pays in EVERY one of them (a batch of different files: the first block of the real-file corpus is one
+// shared object whose groups are whole repeats, the header files behind it are not -- applied to the whole batch the step cost 3.5 ms
+// there and bought 1.7): a block that does not pay is reported as "everything still tied".
+__global__ __launch_bounds__(256) void k_bwt_f_link_payoff(FwdView v, const u32* __restrict__ linkedTile, const u32* __restrict__ survTile, u32 nTiles, u32 tileStep,
+                                                           u32* __restrict__ out, LinkTrial tr)
 {
     __shared__ u32 sA[256], sB[256];
-    u32 a = 0, b = 0;
-    const u32 tEnd = slotEnd ? (*slotEnd + SM_TS - 1) / SM_TS : nTiles;
-    if (tEnd < nTiles) nTiles = tEnd;
-    for (u32 t = threadIdx.x * tileStep; t < nTiles; t += 256u * tileStep) { a += linkedTile[t]; b += survTile[t]; }
-    sA[threadIdx.x] = a; sB[threadIdx.x] = b;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) { sA[threadIdx.x] += sA[threadIdx.x + o]; sB[threadIdx.x] += sB[threadIdx.x + o]; } __syncthreads(); }
-    if (threadIdx.x == 0) { out[0] = sA[0]; out[1] = sB[0]; }
+    u32 totA = 0, totB = 0;
+    bool every = true;
+    const int nPart = tr.n ? tr.n : 1;
+    for (int q = 0; q < nPart; q++) {
+        u32 t0 = 0, t1 = nTiles, step = tileStep;
+        if (tr.n) { t0 = v.base[tr.blk[q]] / SM_TS; t1 = (v.base[tr.blk[q] + 1] + SM_TS - 1) / SM_TS; step = 1; if (t1 > nTiles) t1 = nTiles; }
+        u32 a = 0, b = 0;
+        for (u32 t = t0 + threadIdx.x * step; t < t1; t += 256u * step) { a += linkedTile[t]; b += survTile[t]; }
+        sA[threadIdx.x] = a; sB[threadIdx.x] = b;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) { sA[threadIdx.x] += sA[threadIdx.x + o]; sB[threadIdx.x] += sB[threadIdx.x + o]; } __syncthreads(); }
+        totA += sA[0]; totB += sB[0];
+        if (tr.n && !(sA[0] >= 1024u && sB[0] < sA[0] / 2)) every = false;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = totA; out[1] = every ? totB : (totA > totB ? totA : totB); }
 }
 
 // first zero bit of every word of the link bit map, by word, in reversed order (an inclusive minimum scan over it gives, for every word,
@@ -860,14 +883,16 @@ __device__ __forceinline__ u32 link_next_zero(const u32* __restrict__ posflag, c
 }
 
 __global__ __launch_bounds__(256) void k_bwt_f_link_apply(FwdView v, const u32* __restrict__ posflag, const u32* __restrict__ sufRev, u32 nW,
-                                                          const u32* __restrict__ linked, u32 h, u32* __restrict__ ovr, u32* __restrict__ rtbits, u32 tileStep)
+                                                          const u32* __restrict__ linked, u32 h, u32* __restrict__ ovr, u32* __restrict__ rtbits, u32 tileStep, LinkTrial tr)
 {
     __shared__ SmWindow W;
     __shared__ int sAny;
     __shared__ u32 sLinked[64];
     __shared__ u32 sRt[64];
     __shared__ u32 sOff[SM_WIN];
-    const u32 slot0 = blockIdx.x * tileStep * SM_TS;
+    u32 tile, posLo, posHi;
+    if (!link_tile(v, tr, tileStep, tile, posLo, posHi)) return;
+    const u32 slot0 = tile * SM_TS;
     if (threadIdx.x >= 64 && threadIdx.x < 128) { sLinked[threadIdx.x - 64] = linked[(slot0 >> 5) + threadIdx.x - 64]; sRt[threadIdx.x - 64] = 0; }
     if (!sm_load_window(v, slot0, W, &sAny)) return;
     __syncthreads();
@@ -2472,7 +2497,8 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     while (2 * h <= (u32)nsym) h <<= 1;
     u32 survMembers = total;                                        // (not counted before the first round: assume many)
     int linkMode = 0;                                               // 0 not tried, 1 sampled, 2 on, 3 applied (to be judged), 4 off
-    u32 linkStepUsed = 1, linkTiles = 0, linkRetryH = 0xFFFFFFFFu;
+    u32 linkStepUsed = 1, linkRetryH = 0xFFFFFFFFu;
+    LinkTrial linkTr; linkTr.n = 0;
     int linkTrials = 0;
     while (surv || nMed || nLarge) {
         if (h > bv.VS) return -5;                                    // cannot happen: suffixes of one block differ in length
@@ -2482,9 +2508,11 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
         // Whether it pays is a property of the data (it does where groups are whole repeats: copied spans, files that hold a part twice;
         // it does not where every group has members that leave it one by one, as in the file mix of config 9): the first application, at
         // h = 32, is a trial; what it linked against what was still tied after the round decides whether the rounds that follow apply it
-        // too, and every application is judged again. The trial is made on the windows of the batch's FIRST BLOCK only (a run never
-        // leaves its block, so the block's runs are complete; a sample of windows all over the batch would cut every run): 0.15 ms per
-        // 8 MiB where the step applied to a 212 MB batch costs 2-4 ms -- 6 % of the suffix sort of the real files, which it does not help.
+        // too, and every application is judged again. The trial is made on the windows of up to THREE WHOLE BLOCKS of the batch, the first,
+        // the middle and the last one (a run never leaves its block, so a block's runs are complete; a sample of windows all over the
+        // batch would cut every run), and must pay in each of them: 0.15 ms per 8 MiB where the step applied to a 212 MB batch costs
+        // 2-4 ms. (Round 5 looked at the first block only: in the real-file corpus that is one shared object, the trial said yes, and
+        // the application to the whole batch cost 3.5 ms for 1.7 ms of later rounds.)
         bool linkNow = false;
         u32 linkStep = 1;
         if (surv && tune.link && h >= (u32)(tune.link > 1 ? tune.link : 32)) {
@@ -2492,7 +2520,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
                 const u32 linkedN = h_pinned[14], tiedN = h_pinned[15];
                 const bool paid = linkedN >= 4096 && tiedN < linkedN / 2;
                 linkMode = paid ? 2 : 4;                              // 2: apply, 4: not now
-                if (!paid) linkRetryH = (linkTrials < 3) ? h * 8 : 0xFFFFFFFFu;    // (chance ties of the early rounds may have hidden the repeats: twice more, three rounds on)
+                if (!paid) linkRetryH = (linkTrials < 2) ? h * 8 : 0xFFFFFFFFu;    // (chance ties of the early rounds may have hidden the repeats: once more, three rounds on)
                 if (tune.stats) fprintf(stderr, "link step: %u members linked, %u of the windows' members still tied after the round -> %s\n", linkedN, tiedN, paid ? "on" : "off");
             }
             if (linkMode == 4 && h >= linkRetryH) linkMode = 0;
@@ -2502,20 +2530,24 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
         if (linkNow) {
             KScope ks_("k_bwt_f_link");
             u32* posflag = w.ebits; u32* linked = w.rbits; u32* rev = w.rcount; u32* sufRev = w.rprefix;
-            // (the trial looks at block 0 only: positions below its length <= VS)
-            const u32 nW = (linkMode == 1) ? (u32)std::min<u64>((u64)total / 32 + 1, ((u64)bv.VS + 4 * SM_WIN) / 32 + 2) : total / 32 + 1;
+            // the trial looks at whole blocks: the first, the middle and the last one of the batch (blocks next to each other would share a window)
+            linkTr.n = 0;
+            if (linkMode == 1) {
+                linkTr.blk[linkTr.n++] = 0;
+                if (st.nBlocks >= 5) linkTr.blk[linkTr.n++] = st.nBlocks / 2;
+                if (st.nBlocks >= 3) linkTr.blk[linkTr.n++] = st.nBlocks - 1;
+            }
+            const u32 nW = total / 32 + 1;
             hipMemsetAsync(posflag, 0, 4 * (size_t)nW, s);
             hipMemsetAsync(linked, 0, 4 * ((size_t)nTiles * (SM_TS / 32) + 64), s);
             if (!v.rtbits) { hipMemsetAsync(w.rtbits, 0, 4 * w.gbitsWords, s); v.ovr = w.ovr; v.rtbits = w.rtbits; }
-            // (block 0 ends at slot base[1] <= VS: whole windows up to there; the window of block 1 that rides along links nothing: posEnd)
-            const u32 nTrial = (u32)std::min<u64>((u64)nTiles, ((u64)bv.VS + SM_TS - 1) / SM_TS + 1);
-            const u32 nT = (linkMode == 1) ? nTrial : (nTiles + linkStep - 1) / linkStep;
-            linkTiles = nT;
-            const u32 posEnd = (linkMode == 1) ? 0u : total;                    // (0: the first block only)
-            hipLaunchKernelGGL(k_bwt_f_link_small, dim3(nT), dim3(256), 0, s, v, posflag, linked, tune.stats, linkStep, w.linkedTile, posEnd);
+            // (a block covers at most VS / SM_TS + 2 windows)
+            const u32 nTrial = (u32)std::min<u64>((u64)nTiles, ((u64)bv.VS + SM_TS - 1) / SM_TS + 2);
+            const dim3 gridL(linkMode == 1 ? nTrial : (nTiles + linkStep - 1) / linkStep, (unsigned)(linkTr.n ? linkTr.n : 1));
+            hipLaunchKernelGGL(k_bwt_f_link_small, gridL, dim3(256), 0, s, v, posflag, linked, tune.stats, linkStep, w.linkedTile, linkTr);
             hipLaunchKernelGGL(k_bwt_f_link_zeros, GRID1(nW), posflag, nW, rev);
             prims::launch_scan<prims::SCAN_MIN_INCL>(s, rev, sufRev, nW, nullptr, w.scanTmp);
-            hipLaunchKernelGGL(k_bwt_f_link_apply, dim3(nT), dim3(256), 0, s, v, posflag, sufRev, nW, linked, h, w.ovr, w.rtbits, linkStep);
+            hipLaunchKernelGGL(k_bwt_f_link_apply, gridL, dim3(256), 0, s, v, posflag, sufRev, nW, linked, h, w.ovr, w.rtbits, linkStep, linkTr);
             linkStepUsed = linkStep;
         }
         // -- all keys first
@@ -2538,8 +2570,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
         }
         // -- then the refinements
         if (surv) { KScope ks_("k_bwt_f_sort_small"); hipLaunchKernelGGL(k_bwt_f_sort_small, dim3(nTiles), dim3(256), 0, s, v, tune.link ? w.survTile : (u32*)nullptr);
-                    if (linkNow) hipLaunchKernelGGL(k_bwt_f_link_payoff, dim3(1), dim3(256), 0, s, w.linkedTile, w.survTile, linkTiles, linkStepUsed, w.counters + 14,
-                                                   (linkMode == 1) ? v.base + 1 : (const u32*)nullptr);
+                    if (linkNow) hipLaunchKernelGGL(k_bwt_f_link_payoff, dim3(1), dim3(256), 0, s, v, w.linkedTile, w.survTile, nTiles, linkStepUsed, w.counters + 14, linkTr);
                     if (tune.link) prims::launch_scan<prims::SCAN_SUM_EXCL>(s, w.survTile, w.survTile, nTiles, nullptr, w.scanTmp, w.counters + 13); }
         if (nMed) {
             // two workgroup shapes over the same list, each takes the groups of its size class: 256 threads x 8 elements (21 KB of LDS,

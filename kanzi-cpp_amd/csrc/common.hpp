@@ -99,6 +99,21 @@ __device__ __forceinline__ u64 text8(const u8* t, u32 q, u32 n)
     return x;
 }
 
+// This library is written for ONE target: gfx950 (MI355X, 160 KiB of LDS per workgroup, wave64, gfx9-style s_waitcnt encoding). A device
+// pass for anything else stops here instead of failing at launch or waiting on the wrong counters (KNZ_EMU: the CPU emulation of tests/emu).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(KNZ_EMU)
+#error "kanzi-cpp_amd kernels are written for gfx950 only (LDS sizes, s_waitcnt encoding, wave64)"
+#endif
+constexpr unsigned KNZ_LDS_BYTES = 160u * 1024u;      // what one workgroup may declare on gfx950
+// every load issued so far has arrived: vmcnt(0) in the gfx9 encoding, the other counters left alone. Used before a burst of stores --
+// loads and stores share one counter that counts in issue order, so a wait for a load that follows a store is a wait for the store.
+// Through the builtin (the compiler's own counter pass understands it; an asm wait leaves its conservative waits in place).
+#ifdef KNZ_EMU
+#define KNZ_LOADS_DONE() ((void)0)
+#else
+#define KNZ_LOADS_DONE() __builtin_amdgcn_s_waitcnt(0x0F70)
+#endif
+
 // Where a kernel relies on a wave executing its memory operations in program order across lanes (lane 0 stores, every lane loads
 // right after), the CPU emulation of tests/emu -- whose lanes only meet at wave intrinsics -- needs a rendezvous; on the GPU it is nothing.
 #ifdef KNZ_EMU

@@ -751,11 +751,7 @@ __global__ __launch_bounds__(64) void k_huff_scan(BitSrc src, DecBlock* __restri
 }
 
 // every load issued so far has arrived (before a burst of stores: one counter for loads and stores, counted in issue order)
-#ifdef KNZ_EMU
-#define KNZ_HUF_LOADS_DONE() ((void)0)
-#else
-#define KNZ_HUF_LOADS_DONE() __builtin_amdgcn_s_waitcnt(0x0F70)   /* vmcnt(0), the other counters left alone */
-#endif
+// (KNZ_LOADS_DONE: common.hpp)
 constexpr int HUF_DEC_CHUNKS = 16;  // chunks per wave (4 lanes = 4 fragments each)
 constexpr u32 HUF_PRIM_BITS = 10;   // codes of up to 10 bits are looked up by the top 10 bits of the window
 constexpr u32 HUF_OVF = 512;        // table entries of the longer codes: at most 256 codes of 11 or 12 bits, two or one 12-bit slots each
@@ -961,7 +957,7 @@ __global__ __launch_bounds__(64) void k_huff_decode(BitSrc src, DecBlock* __rest
             out[it] = acc;
         }
         if (used > (V5 ? (u32)(ENT_CHUNK * HUF_MAX_LEN) : (8192u << 3))) bad = true;
-        KNZ_HUF_LOADS_DONE();
+        KNZ_LOADS_DONE();
 #pragma unroll
         for (int it = 0; it < 16; it++) {
             const u32 o = i + 4 * (u32)it;

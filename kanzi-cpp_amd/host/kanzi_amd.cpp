@@ -524,6 +524,60 @@ int TransformSequence<T>::getMaxEncodedLength(int srcLength) const
     return req;
 }
 
+// The data of a block travels through the chain between two views: a stage reads the one that holds the data and writes the other, and
+// the two change roles behind every stage that applied. The views start out as the caller's input and output; one of them that is too
+// small for what a stage may write is replaced by memory of this object (the reference reallocates the caller's SliceArray with
+// delete[] / new[] there, transform/TransformSequence.hpp:112-121; this mirror never frees an array it did not allocate, so the
+// result is copied into the caller's output at the end wherever it ended up).
+namespace {
+template <class T>
+class Relay {
+public:
+    Relay(SliceArray<T>& input, SliceArray<T>& output) : _data(&input), _spare(&output), _callerIn(&input), _callerOut(&output), _own(nullptr, 0, 0) {}
+
+    // the view the next stage writes can take `need` elements
+    void spareHolds(int need)
+    {
+        if (_spare->_length >= need) return;
+        if (_spare == _callerIn || _spare == _callerOut) _spare = &_own;
+        if (_own._length < need) { _mem.resize(size_t(need)); _own._array = _mem.data(); _own._length = need; }
+    }
+
+    // one stage over `count` elements: true when it applied (count becomes what it wrote, the views change roles); the indexes of both
+    // views are where they were either way
+    template <class Stage>
+    bool run(Stage&& stage, int& count)
+    {
+        const int at = _data->_index, to = _spare->_index;
+        const bool applied = stage(*_data, *_spare, count);
+        if (applied) count = _spare->_index - to;
+        _data->_index = at;
+        _spare->_index = to;
+        if (applied) std::swap(_data, _spare);
+        return applied;
+    }
+
+    // the block, `count` elements, into the caller's output (false: it does not fit)
+    bool deliver(int count) const
+    {
+        if (_data == _callerOut) return true;
+        if ((count > _callerOut->_length - _callerOut->_index) || (count > _data->_length - _data->_index)) return false;
+        memmove(&_callerOut->_array[_callerOut->_index], &_data->_array[_data->_index], size_t(count) * sizeof(T));
+        return true;
+    }
+
+private:
+    SliceArray<T>* _data;
+    SliceArray<T>* _spare;
+    SliceArray<T>* const _callerIn;
+    SliceArray<T>* const _callerOut;
+    SliceArray<T> _own;
+    std::vector<T> _mem;
+};
+}
+
+// transform/TransformSequence.hpp:88-162: every stage on the output of the one before it; a stage that declines is skipped and its bit
+// stays set in the skip flags; "all skipped" (0xFF) means the block is stored as it is
 template <class T>
 bool TransformSequence<T>::forward(SliceArray<T>& input, SliceArray<T>& output, int count)
 {
@@ -532,41 +586,23 @@ bool TransformSequence<T>::forward(SliceArray<T>& input, SliceArray<T>& output, 
     if ((count < 0) || (count > input._length - input._index)) return false;
     _skipFlags = 0xFF;
     if (count == 0) return true;
-    const int blockSize = count;
-    const int requiredSize = getMaxEncodedLength(blockSize);
-    std::vector<T> scratch;
-    SliceArray<T> buffer(nullptr, 0, 0);
-    SliceArray<T>* in = &input;
-    SliceArray<T>* out = &output;
-    int swaps = 0;
+    const int taken = count;
+    const int worst = getMaxEncodedLength(taken);
+    Relay<T> relay(input, output);
     for (int i = 0; i < _length; i++) {
-        if (_transforms[i] == nullptr) continue;
-        if (out->_length < requiredSize) {
-            if ((out == &input) || (out == &output)) out = &buffer;
-            if (out->_length < requiredSize) { scratch.resize(size_t(requiredSize)); out->_array = scratch.data(); out->_length = requiredSize; }
-        }
-        const int savedIIdx = in->_index, savedOIdx = out->_index;
-        if (_transforms[i]->forward(*in, *out, count) == false) {
-            in->_index = savedIIdx;
-            out->_index = savedOIdx;
-            continue;
-        }
-        _skipFlags &= byte(~(1 << (7 - i)));
-        count = out->_index - savedOIdx;
-        in->_index = savedIIdx;
-        out->_index = savedOIdx;
-        std::swap(in, out);
-        swaps++;
+        Transform<T>* stage = _transforms[i];
+        if (stage == nullptr) continue;
+        relay.spareHolds(worst);
+        if (relay.run([stage](SliceArray<T>& src, SliceArray<T>& dst, int n) { return stage->forward(src, dst, n); }, count))
+            _skipFlags &= byte(~(1 << (7 - i)));
     }
-    if ((swaps & 1) == 0) {
-        if ((count > output._length - output._index) || (count > in->_length - in->_index)) _skipFlags = 0xFF;
-        else memmove(&output._array[output._index], &in->_array[in->_index], size_t(count));
-    }
-    input._index += blockSize;
+    if (!relay.deliver(count)) _skipFlags = 0xFF;
+    input._index += taken;
     output._index += count;
     return _skipFlags != 0xFF;
 }
 
+// transform/TransformSequence.hpp:165-235: the stages whose bit is clear, last one first; the first failure ends the block
 template <class T>
 bool TransformSequence<T>::inverse(SliceArray<T>& input, SliceArray<T>& output, int count)
 {
@@ -575,42 +611,21 @@ bool TransformSequence<T>::inverse(SliceArray<T>& input, SliceArray<T>& output, 
     if ((count < 0) || (count > input._length - input._index)) return false;
     if (count == 0) return true;
     if (count > output._length - output._index) return false;
-    if (_skipFlags == 0xFF) {
-        memmove(&output._array[output._index], &input._array[input._index], size_t(count));
-        input._index += count;
-        output._index += count;
-        return true;
-    }
-    const int blockSize = count;
-    bool res = true;
-    std::vector<T> scratch;
-    SliceArray<T> buffer(nullptr, 0, 0);
-    SliceArray<T>* in = &input;
-    SliceArray<T>* out = &output;
-    int swaps = 0;
-    for (int i = _length - 1; i >= 0; i--) {
-        if ((_skipFlags & byte(1 << (7 - i))) != 0) continue;
-        if (_transforms[i] == nullptr) continue;
-        if (out->_length < output._length) {
-            if ((out == &input) || (out == &output)) out = &buffer;
-            if (out->_length < output._length) { scratch.resize(size_t(output._length)); out->_array = scratch.data(); out->_length = output._length; }
+    const int taken = count;
+    bool good = true;
+    Relay<T> relay(input, output);
+    if (_skipFlags != 0xFF) {
+        for (int i = _length - 1; i >= 0 && good; i--) {
+            Transform<T>* stage = _transforms[i];
+            if (stage == nullptr || (_skipFlags & byte(1 << (7 - i))) != 0) continue;
+            relay.spareHolds(output._length);
+            good = relay.run([stage](SliceArray<T>& src, SliceArray<T>& dst, int n) { return stage->inverse(src, dst, n); }, count);
         }
-        const int savedIIdx = in->_index, savedOIdx = out->_index;
-        res = _transforms[i]->inverse(*in, *out, count);
-        if (!res) break;
-        count = out->_index - savedOIdx;
-        in->_index = savedIIdx;
-        out->_index = savedOIdx;
-        std::swap(in, out);
-        swaps++;
     }
-    if (res && ((swaps & 1) == 0)) {
-        if ((count > output._length - output._index) || (count > in->_length - in->_index)) res = false;
-        else memmove(&output._array[output._index], &in->_array[in->_index], size_t(count));
-    }
-    input._index += blockSize;
+    if (good) good = relay.deliver(count);
+    input._index += taken;
     output._index += count;
-    return res;
+    return good;
 }
 
 template class TransformSequence<byte>;
@@ -1324,7 +1339,9 @@ bool CompressedOutputStream::drainOne(std::unique_lock<std::mutex>& l)
     if (ln.state != 2 || ln.seq != _sinkSeq) return false;
     l.unlock();
     bool bad = false;
-    {
+    std::exception_ptr thrown;               // a sink with exceptions() set, or a streambuf that throws (disk full, a custom sink): on the
+                                             // sink thread nothing is above this frame, so the exception is kept for the caller's next call
+    try {
         // the run starts with shiftR zero bits: the place of the previous run's last bits
         if (ln.shiftR != 0 && ln.outBytes != 0) ln.out[0] |= _pendingByte;
         const uint64 totalBits = uint64(ln.shiftR) + ln.bits;
@@ -1340,11 +1357,14 @@ bool CompressedOutputStream::drainOne(std::unique_lock<std::mutex>& l)
         _pendingBits = ln.last ? 0 : rem;
         _pendingByte = (rem && !ln.last) ? ln.out[full] : 0;
         if (hostTimeline()) fprintf(stderr, "[knz out batch %lld] in the sink at %.2f ms\n", (long long)ln.seq, msSince(_t0));
+    } catch (...) {
+        thrown = std::current_exception();
     }
     l.lock();
     ln.state = 0;
     ln.n = 0;
     _sinkSeq++;
+    if (thrown && !_err) _err = thrown;      // (rethrown as it is by write() / close() on the caller's thread: rethrow())
     if (bad && !_err) _err = std::make_exception_ptr(IOException("Write to bitstream failed", Error::ERR_WRITE_FILE));
     _cv.notify_all();
     return true;

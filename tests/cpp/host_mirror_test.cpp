@@ -7,6 +7,7 @@
 #include <cstring>
 #include <iostream>
 #include <sstream>
+#include <stdexcept>
 #include <vector>
 
 #include "kanzi_amd.hpp"
@@ -563,6 +564,46 @@ static void testReferenceCallForms()
     }
 }
 
+// A sink that throws (a streambuf whose medium is full, an ostream with exceptions() set): the runs are appended by the sink thread
+// (kanzi_amd.hpp, CompressedOutputStream), and what the sink throws there must reach the caller's thread as an exception of
+// write() / close() -- not leave the thread function (std::terminate). The same with the sink on the caller's thread.
+struct FullBuf : std::streambuf {
+    size_t room;
+    explicit FullBuf(size_t n) : room(n) {}
+    std::streamsize xsputn(const char*, std::streamsize n) override
+    {
+        if (size_t(n) > room) throw std::runtime_error("medium full");
+        room -= size_t(n);
+        return n;
+    }
+    int overflow(int c) override { if (room == 0) throw std::runtime_error("medium full"); room--; return c; }
+};
+
+static void testThrowingSink()
+{
+    const std::vector<byte> data = gen(0, 40 * 16384, 5);              // incompressible: every batch is larger than the sink's room
+    for (int onThread = 0; onThread < 2; onThread++) {
+        setenv("KNZ_SINK_THREAD", onThread ? "1" : "0", 1);
+        setenv("KNZ_BATCH_BLOCKS", "2", 1);
+        for (int mode = 0; mode < 2; mode++) {                        // 0: the streambuf throws, 1: failbit + exceptions()
+            FullBuf fb(20000);
+            std::ostream os(&fb);
+            if (mode) os.exceptions(std::ios::failbit | std::ios::badbit);
+            bool caught = false;
+            try {
+                CompressedOutputStream cos(os, 1, "NONE", "NONE", 16384, 0, 0);
+                for (size_t off = 0; off < data.size(); off += 16384) cos.write(reinterpret_cast<const char*>(&data[off]), 16384);
+                cos.close();
+            } catch (const std::exception&) {
+                caught = true;
+            }
+            CHECK(caught);
+        }
+    }
+    unsetenv("KNZ_SINK_THREAD");
+    unsetenv("KNZ_BATCH_BLOCKS");
+}
+
 int main(int argc, char** argv)
 {
     const std::string what = argc > 1 ? argv[1] : "all";
@@ -576,6 +617,7 @@ int main(int argc, char** argv)
         if (what == "all" || what == "seek") testSeek();
         if (what == "all" || what == "range") testBlockRange();
         if (what == "all" || what == "pipeline") testPipeline();
+        if (what == "all" || what == "sink") testThrowingSink();
     } catch (const std::exception& e) {
         printf("EXCEPTION %s\n", e.what());
         return 2;

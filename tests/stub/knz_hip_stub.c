@@ -2,6 +2,7 @@
  * (kanzi-cpp_amd/host/kanzi_amd.cpp: stream classes, batching, staging slots and worker thread, header parsing, seek, the C API)
  * can be exercised by the CPU-only test suite. "Device" pointers are host pointers. Never shipped, never loaded by the product:
  * tests/test_host_stub.py links it into a private copy of the host library. */
+#define _POSIX_C_SOURCE 200809L
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -9,10 +10,50 @@
 #include "../../include/knz_hip.h"
 #include "../../oracle/knz_oracle.h"
 
-struct knz_ctx { char err[256]; };
+#include <pthread.h>
+#include <time.h>
 
-int knz_hip_device_count(int* count) { *count = 1; return 0; }
-int knz_hip_create(int device, void* stream, knz_ctx** out) { (void)device; (void)stream; *out = (knz_ctx*)calloc(1, sizeof(knz_ctx)); return *out ? 0 : -1; }
+struct knz_ctx { char err[256]; int device; };
+
+/* A model of SEVERAL devices (tests/test_host_stub.py: the 8-lane stream): KNZ_STUB_DEVICES devices, each of which runs one block
+ * call at a time (a mutex per device) and takes KNZ_STUB_NS_PER_BYTE nanoseconds per input byte of the call, slept, so that what the
+ * clock sees is how the host layer spreads its batches over the devices and not how fast the oracle is on the cores of the test box. */
+#define STUB_MAX_DEV 16
+static pthread_mutex_t g_dev_mu[STUB_MAX_DEV];
+static pthread_once_t g_dev_once = PTHREAD_ONCE_INIT;
+static int g_ndev = 1;
+static long g_ns_per_byte = 0;
+static void stub_init(void)
+{
+    const char* e = getenv("KNZ_STUB_DEVICES");
+    g_ndev = e ? atoi(e) : 1;
+    if (g_ndev < 1) g_ndev = 1;
+    if (g_ndev > STUB_MAX_DEV) g_ndev = STUB_MAX_DEV;
+    e = getenv("KNZ_STUB_NS_PER_BYTE");
+    g_ns_per_byte = e ? atol(e) : 0;
+    for (int i = 0; i < STUB_MAX_DEV; i++) pthread_mutex_init(&g_dev_mu[i], NULL);
+}
+static void stub_device_busy(const knz_ctx* c, size_t bytes)
+{
+    pthread_once(&g_dev_once, stub_init);
+    if (g_ns_per_byte <= 0) return;
+    const long long ns = (long long)bytes * g_ns_per_byte;
+    struct timespec ts; ts.tv_sec = (time_t)(ns / 1000000000LL); ts.tv_nsec = (long)(ns % 1000000000LL);
+    pthread_mutex_lock(&g_dev_mu[c->device]);
+    nanosleep(&ts, NULL);
+    pthread_mutex_unlock(&g_dev_mu[c->device]);
+}
+
+int knz_hip_device_count(int* count) { pthread_once(&g_dev_once, stub_init); *count = g_ndev; return 0; }
+int knz_hip_create(int device, void* stream, knz_ctx** out)
+{
+    (void)stream;
+    pthread_once(&g_dev_once, stub_init);
+    if (device < 0 || device >= g_ndev) { *out = NULL; return -1; }
+    *out = (knz_ctx*)calloc(1, sizeof(knz_ctx));
+    if (*out) (*out)->device = device;
+    return *out ? 0 : -1;
+}
 void knz_hip_destroy(knz_ctx* c) { free(c); }
 const char* knz_hip_last_error(knz_ctx* c) { return c ? c->err : "null context"; }
 size_t knz_hip_encode_bound(const knz_params* p, size_t n)
@@ -30,6 +71,7 @@ int knz_hip_encode_blocks(knz_ctx* c, const knz_params* p, const uint8_t* d_in, 
                           int64_t first_block_id, int finish, uint8_t* d_out, size_t out_cap, uint64_t* out_bits)
 {
     if (p->block_size < 1024 || (p->block_size & 15)) return fail(c, KNZ_ERR_INVALID_PARAM, "invalid block size");
+    stub_device_busy(c, n);
     knzo_bw w;
     knzo_bw_init(&w, d_out, out_cap);
     for (uint32_t i = 0; i < prologue_bits; i += 8) {
@@ -89,6 +131,7 @@ int knz_hip_decode_blocks(knz_ctx* c, const knz_params* p, const uint8_t* d_in, 
                                    max_blocks > 0 ? max_blocks : -1, d_out, out_cap, &ol, &eb, &done);
     knzo_set_bs_version(6);
     if (rc) return fail(c, rc, "decode failed");
+    stub_device_busy(c, ol);
     if (out_bytes) *out_bytes = ol;
     if (end_bit) *end_bit = eb;
     if (blocks_done) *blocks_done = done;

@@ -13,7 +13,7 @@ ctx = hipapi.Context(0)
 L = hipapi.lib()
 L.knz_hip_tune(b"bwt_split", 1)
 for kind in kinds:
-    d = {"mixed": lambda: c.mixed(n, 2), "text": lambda: c.text(n, 1), "repeats": lambda: c.repeats(n, 3)}[kind]()
+    d = {"mixed": lambda: c.mixed(n, 2), "text": lambda: c.text(n, 1), "repeats": lambda: c.repeats(n, 3), "local": lambda: c.local(n)[0]}[kind]()
     p = ctx.params("BWT", "NONE", 8 << 20)
     cap = ctx.encode_bound(p, len(d)) + 64
     d_in, d_out = ctx.malloc(len(d) + 64), ctx.malloc(cap)
@@ -39,5 +39,5 @@ for kind in kinds:
         print("%-8s %-44s bwt_forward %7.2f ms rounds %2d %s | %s" % (kind, st or "(defaults)", bwt, rounds, "same" if out == ref else "DIFFERENT OUTPUT",
               ", ".join("%s %.2f" % (nm[8:], ms) for ms, nm, l in top)), flush=True)
         for k in names:
-            L.knz_hip_tune(k.encode(), 0)
+            L.knz_hip_tune(k.encode(), 1 if k == "bwt_link" else 0)      # (back to the default)
     ctx.free(d_in); ctx.free(d_out)
