@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Generates tests/golden/golden_full.json: md5 + length of the UNMODIFIED reference's .knz (oracle/_ref) for the
 BASELINE.json configurations at their own block sizes (vectors.FULL_CASES), 64 MiB inputs, -j 1, and for the long-common-prefix
-inputs of vectors.HARD_CASES at 8 MiB / 32 MiB blocks (copies, periods, DNA; table- and image-shaped blocks).
+inputs of vectors.HARD_CASES at 8 MiB / 32 MiB blocks (copies, periods, DNA; table- and image-shaped blocks), and for single blocks of
+256 MiB and 1 GiB (vectors.BIG_CASES; the 1 GiB suffix sort takes the reference a few minutes and about 6 GB).
 
     make -C oracle ref && python tests/golden/make_golden_full.py [config ...]
 
@@ -24,13 +25,15 @@ def main():
     R = knzlib.Ref()
     out = []
     only = set(sys.argv[1:])
+    cache = {}
     path = os.path.join(HERE, "golden_full.json")
     old = {str(r["config"]): r for r in json.load(open(path))} if only and os.path.exists(path) else {}
-    for cfg, spec, t, e, bs in vectors.FULL_CASES + vectors.HARD_CASES:
+    for cfg, spec, t, e, bs in vectors.FULL_CASES + vectors.HARD_CASES + vectors.BIG_CASES:
         if only and str(cfg) not in only and str(cfg) in old:
             out.append(old[str(cfg)])
             continue
-        d = vectors.make(spec)
+        d = cache[spec] if spec in cache else vectors.make(spec)
+        cache.clear(); cache[spec] = d                     # (consecutive cases on the same input: one generation)
         rc, o = R.compress(d, t, e, bs, jobs=1, orig_size=len(d))
         assert rc == 0, (cfg, rc)
         rc, back = R.decompress(o, len(d))

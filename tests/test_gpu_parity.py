@@ -446,6 +446,50 @@ def test_full_size_reference_stream_config4_six_blocks_of_copied_spans(hip):
     _full_case(hip, "config4:6blocks_repeats")
 
 
+_BIG_INPUT = {}
+
+
+def _big_case(hip, config):
+    """ONE block of 256 MiB / 1 GiB (vectors.BIG_CASES): the device stream is the reference's .knz (md5 + length from oracle/_ref,
+    tests/golden/golden_full.json) and decodes back to the input. The input of the three 1 GiB cases is generated once."""
+    import json
+    recs = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_full.json")))
+    rec = [r for r in recs if r["config"] == config][0]
+    spec = tuple(rec["input"])
+    if spec not in _BIG_INPUT:
+        _BIG_INPUT.clear()
+        _BIG_INPUT[spec] = vectors.make(spec)
+        assert hashlib.md5(_BIG_INPUT[spec]).hexdigest() == rec["input_md5"]
+    d = _BIG_INPUT[spec]
+    out, bits, hb = gpu_compress(hip, d, rec["transform"], rec["entropy"], rec["block"], orig_size=rec["orig_size"])
+    assert len(out) == rec["out"]["len"], (config, len(out), rec["out"]["len"])
+    assert hashlib.md5(out).hexdigest() == rec["out"]["md5"], config
+    back = gpu_decompress(hip, out, rec["transform"], rec["entropy"], rec["block"], len(d), hb)
+    assert len(back) == len(d) and back == d, config
+
+
+def test_big_block_256m_headline_chain(hip):
+    """io/CompressedOutputStream.cpp:69-82 accepts blocks up to 1 GiB; one block of 256 MiB through BWT+MTFT+ZRLT / ANS0: 28-bit positions,
+    32 sub-lists per inverse tile row, ANS0 on 16,384 chunks of one block"""
+    _big_case(hip, "big:bwt_chain_256m")
+
+
+def test_big_block_1g_ans0(hip):
+    _big_case(hip, "big:ans0_1g")
+
+
+def test_big_block_1g_huffman(hip):
+    _big_case(hip, "big:huffman_1g")
+
+
+def test_big_block_1g_suffix_sort(hip):
+    """transform/BWT.cpp:32 (MAX_BLOCK_SIZE = 1 GiB): the suffix sorter and its inverse on one block of 2^30 bytes -- 30-bit positions
+    beside four symbols in the round-0 keys, the count + scatter passes (the one-sweep look-back words hold 30-bit counts), labels and
+    slots up to 2^30, run-round keys of 63 bits"""
+    _big_case(hip, "big:bwt_1g")
+    _BIG_INPUT.clear()
+
+
 def test_real_files_of_this_image_against_the_reference(hip, oracle):
     """REAL bytes: 64 MiB of corpus.local() -- ELF shared objects with their zero padding and string tables, then
     C/C++ headers with the same licence text in front of thousands of them -- through the headline chain at 8 MiB blocks. The

@@ -163,6 +163,17 @@ HARD_CASES = [
     ("config4:6blocks_repeats", ("repeats", 6 * (32 << 20), 5), "BWT+SRT+ZRLT", "FPAQ", 32 << 20),
 ]
 
+# Block sizes the reference accepts and the other cases never reach (io/CompressedOutputStream.cpp:69-82: up to 1 GiB; transform/BWT.cpp:32:
+# MAX_BLOCK_SIZE 1 GiB): ONE block of 256 MiB through the headline chain, one block of 1 GiB through the entropy coders and through the
+# suffix sorter alone -- 30-bit positions in the round-0 keys, the count + scatter passes instead of the one-sweep ones (RS_VAL_MASK),
+# slot arithmetic near 2^30, the 2 GiB-per-call limit of the C ABI. Same fixture file, config "big:<name>" (VERDICT r5 item 5).
+BIG_CASES = [
+    ("big:bwt_chain_256m", ("mixed", 256 << 20, 3), "BWT+MTFT+ZRLT", "ANS0", 256 << 20),
+    ("big:ans0_1g", ("mixed", 1 << 30, 4), "NONE", "ANS0", 1 << 30),
+    ("big:huffman_1g", ("mixed", 1 << 30, 4), "NONE", "HUFFMAN", 1 << 30),
+    ("big:bwt_1g", ("mixed", 1 << 30, 4), "BWT", "NONE", 1 << 30),
+]
+
 # The CLI's level presets that reach the device chain through host stages (TEXT + UTF): `kanzi -c -l N` of the reference, digests in
 # tests/golden/levels.json (tests/golden/make_levels.py)
 LEVEL_CASES = [
