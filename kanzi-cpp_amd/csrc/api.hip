@@ -226,9 +226,17 @@ static std::atomic<int>& bwt_split_knob()
     return v;
 }
 
+// fewest blocks a part of a split BWT stage may have (KNZ_BWT_PART_MIN / knob "bwt_part_min"; see bwt_parts_wanted)
+static std::atomic<int>& bwt_part_min_knob()
+{
+    static std::atomic<int> v([] { const char* e = getenv("KNZ_BWT_PART_MIN"); const int x = e ? atoi(e) : 2; return x < 1 ? 1 : x; }());
+    return v;
+}
+
 int knz_hip_tune(const char* name, int value)
 {
     if (name == nullptr) return -1;
+    if (!strcmp(name, "bwt_part_min")) { bwt_part_min_knob().store(value < 1 ? 1 : value); return 0; }
     if (!strcmp(name, "mtf_tile")) return mtft_tune(value);
     if (!strcmp(name, "mtf_chain")) return mtft_tune_chain(value);
     if (!strcmp(name, "lz_serial_decode")) { lz_serial_decode(value ? 1 : 0); return 0; }
@@ -486,7 +494,8 @@ static int bwt_parts_wanted(const Ctx* c, int nBlocks)
 {
     if (c->profiling) return 1;
     int parts = bwt_split_knob().load();
-    while (parts > 1 && nBlocks < 2 * parts) parts--;            // at least two blocks per part
+    const int least = bwt_part_min_knob().load();
+    while (parts > 1 && nBlocks < least * parts) parts--;        // at least `least` blocks per part
     return parts;
 }
 

@@ -33,6 +33,7 @@
 #include <cmath>
 #include "prims.hpp"
 #include <chrono>
+#include <vector>
 
 namespace knz {
 
@@ -933,7 +934,8 @@ __global__ __launch_bounds__(256) void k_bwt_f_link_apply(FwdView v, const u32* 
 // The 32 workgroups that run on one XCD (workgroup index mod 8 -- an observed placement, used for speed only) walk through one
 // contiguous eighth of the list side by side, so that a line of ISA fetched for one group is found in that XCD's L2 by the
 // 31 groups next to it, instead of being fetched from memory once per group.
-__global__ __launch_bounds__(1024) void k_bwt_f_gather_desc(FwdView v, const uint2* __restrict__ desc, u32 nDesc, u32 h, uint2* __restrict__ descInfo, int stats)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_bwt_f_gather_desc(FwdView v, const uint2* __restrict__ desc, u32 nDesc, u32 h, uint2* __restrict__ descInfo, int stats)
 {
     __shared__ int sBlk;
     const u32 xcd = blockIdx.x & 7, lanesPerXcd = gridDim.x >> 3, slot = blockIdx.x >> 3;      // the grid is a multiple of 8 workgroups
@@ -950,14 +952,14 @@ __global__ __launch_bounds__(1024) void k_bwt_f_gather_desc(FwdView v, const uin
         if (threadIdx.x == 0) { descInfo[g] = make_uint2(bb, v.ISA[v.SA[d.x]]); if (stats) atomicAdd(&v.counters[12], d.y); }
         // eight members per thread at a time: all position loads, then all key loads, then the stores -- two memory
         // latencies per batch instead of two per member
-        for (u32 i0 = 0; i0 < d.y; i0 += 8 * 1024) {
+        for (u32 i0 = 0; i0 < d.y; i0 += 8 * THREADS) {
             u32 gp[8], key[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) { const u32 i = i0 + (u32)k * 1024u + threadIdx.x; gp[k] = (i < d.y) ? v.SA[d.x + i] : bb; }
+            for (int k = 0; k < 8; k++) { const u32 i = i0 + (u32)k * THREADS + threadIdx.x; gp[k] = (i < d.y) ? v.SA[d.x + i] : bb; }
 #pragma unroll
-            for (int k = 0; k < 8; k++) { const u32 i = i0 + (u32)k * 1024u + threadIdx.x; key[k] = (i < d.y) ? gather_key(v.ISA, gp[k], off, bb, be) : 0u; }
+            for (int k = 0; k < 8; k++) { const u32 i = i0 + (u32)k * THREADS + threadIdx.x; key[k] = (i < d.y) ? gather_key(v.ISA, gp[k], off, bb, be) : 0u; }
 #pragma unroll
-            for (int k = 0; k < 8; k++) { const u32 i = i0 + (u32)k * 1024u + threadIdx.x; if (i < d.y) v.K[d.x + i] = key[k]; }
+            for (int k = 0; k < 8; k++) { const u32 i = i0 + (u32)k * THREADS + threadIdx.x; if (i < d.y) v.K[d.x + i] = key[k]; }
         }
         __syncthreads();
     }
@@ -2149,11 +2151,11 @@ __global__ __launch_bounds__(256) void k_bwt_f_med_compact(uint2* __restrict__ s
 }
 
 // knobs (tests, tuning): read from the environment once per process, or set through knz_hip_tune()
-struct FwdTuning { int nsym; int noRunRound; int runFallback; int noSuper; int noTextRound; int stats; int noRunOffsets; int noProbe; int link; };
+struct FwdTuning { int nsym; int noRunRound; int runFallback; int noSuper; int noTextRound; int stats; int noRunOffsets; int noProbe; int link; int gatherWg; };
 static FwdTuning& fwd_tuning()
 {
     static FwdTuning t = [] {
-        FwdTuning x; x.nsym = 0; x.noRunRound = 0; x.runFallback = 0; x.noSuper = 0; x.noTextRound = 0; x.stats = 0; x.noRunOffsets = 0; x.noProbe = 0; x.link = 1;     // link: 0 off, 1 on (from h = 32), n > 1: from h = n
+        FwdTuning x; x.nsym = 0; x.noRunRound = 0; x.runFallback = 0; x.noSuper = 0; x.noTextRound = 0; x.stats = 0; x.noRunOffsets = 0; x.noProbe = 0; x.link = 1; x.gatherWg = 512;     // link: 0 off, 1 on (from h = 32), n > 1: from h = n
         if (getenv("KNZ_BWT_NO_PROBE")) x.noProbe = 1;
         if (const char* e = getenv("KNZ_BWT_LINK")) x.link = atoi(e);
         if (getenv("KNZ_BWT_NO_RUN_OFFSETS")) x.noRunOffsets = 1;
@@ -2180,6 +2182,7 @@ int bwt_forward_tune(const char* key, int value)
     else if (!strcmp(key, "bwt_no_run_offsets")) t.noRunOffsets = value;
     else if (!strcmp(key, "bwt_no_probe")) t.noProbe = value;
     else if (!strcmp(key, "bwt_link")) t.link = value;
+    else if (!strcmp(key, "bwt_gather_wg")) t.gatherWg = value;
     else return -1;
     return 0;
 }
@@ -2555,7 +2558,11 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
         if (nMed) {
             // (the list is in slot order: k_bwt_f_med_compact)
             KScope ks_("k_bwt_f_gather_desc");
-            hipLaunchKernelGGL(k_bwt_f_gather_desc, dim3(256), dim3(1024), 0, s, v, w.med[cur], nMed, h, w.descInfo, tune.stats);
+            // Threads per workgroup (knob bwt_gather_wg, default 512): a group's keys are three dependent loads, and more, smaller workgroups keep
+            // more groups in flight per CU. Real files 4.13 -> 2.99 ms (512) / 3.16 (256), text 3.26 -> 2.39 / 2.46, the stand-in 2.54 -> 2.56 / 2.71.
+            if (tune.gatherWg == 256) hipLaunchKernelGGL(k_bwt_f_gather_desc<256>, dim3(2048), dim3(256), 0, s, v, w.med[cur], nMed, h, w.descInfo, tune.stats);
+            else if (tune.gatherWg == 1024) hipLaunchKernelGGL(k_bwt_f_gather_desc<1024>, dim3(256), dim3(1024), 0, s, v, w.med[cur], nMed, h, w.descInfo, tune.stats);
+            else hipLaunchKernelGGL(k_bwt_f_gather_desc<512>, dim3(1024), dim3(512), 0, s, v, w.med[cur], nMed, h, w.descInfo, tune.stats);
         }
         int lbits = 0;
         bool small32 = false;
@@ -2610,6 +2617,13 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
         surv = h_pinned[0]; nMed = h_pinned[1]; nLarge = h_pinned[2]; largeElems = h_pinned[3];
         survMembers = h_pinned[13];
         if (tune.stats) {
+            // windows that still hold tied small groups (from the scanned per-window counts; developer statistics only)
+            std::vector<u32> hs(nTiles);
+            u32 activeTiles = 0;
+            if (tune.link && hipMemcpy(hs.data(), w.survTile, 4 * (size_t)nTiles, hipMemcpyDeviceToHost) == hipSuccess) {
+                for (u32 t = 0; t + 1 < nTiles; t++) activeTiles += hs[t + 1] != hs[t] ? 1u : 0u;
+                fprintf(stderr, "  windows with tied small groups after the round: %u of %u\n", activeTiles, nTiles);
+            }
             const std::chrono::steady_clock::time_point now = std::chrono::steady_clock::now();
             fprintf(stderr, "round h=%u (%.3f ms): small members worked on %u in %u groups, medium members %u; after it: small left %u, medium groups %u, large %u (%u members); %u groups took the chain round; %u small members still tied\n",
                     h, std::chrono::duration<double, std::milli>(now - statT).count(), h_pinned[10], h_pinned[11], h_pinned[12], surv, nMed, nLarge, largeElems, h_pinned[7], h_pinned[13]);
