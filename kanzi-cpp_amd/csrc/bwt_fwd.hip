@@ -21,8 +21,9 @@
 //     * a group whose majority key is its OWN label (a periodic stretch whose period divides h) is finished in one round by pointer
 //       jumping along its chains (k_bwt_f_super),
 //     * large groups go through one global radix sort of (descriptor index, key) pairs.
-//   Keys are gathered by separate kernels before any kernel of the round moves a position or changes ISA (a refined
-//   head read beside an unrefined one would order two suffixes that are still equal).
+//   A round sorts on the labels as they stood when it began (a refined head read beside an unrefined one would order two suffixes that
+//   are still equal): the keys of medium and large groups are gathered by kernels of their own before anything moves; the small groups
+//   read theirs in the kernel that sorts them (k_bwt_f_small_fused, round 6), which the VERSIONED labels make safe (lab_old / lab_set below).
 #include "common.hpp"
 #include "stages.hpp"
 #include "bwt_common.hpp"
@@ -48,7 +49,9 @@ struct FwdView {
     int nBlocks;
     u32 total;
     u32* SA;             // [total]
-    u32* ISA;            // [total]
+    u32* ISA;            // [total] labels as 32-bit words (blocks above 256 MiB), or
+    u64* ISA2;           // [total] VERSIONED labels (null: the plain words above): see lab_old / lab_set below
+    u32 round;           // number of the doubling round under way (0: in front of the first one)
     u32* K;              // [total] keys of the round, by slot
     u32* gbits;          // group-start bit per slot (bit k of word w = slot 32 w + k); set for every slot >= total
     u32* gnew;           // group starts found in the current round; merged into gbits when the round is over (a window must
@@ -63,10 +66,45 @@ struct FwdView {
                          // into the next round's descriptor list by k_bwt_f_med_compact
 };
 
-__device__ __forceinline__ u32 gather_key(const u32* __restrict__ ISA, u32 gp, u32 h, u32 blkBase, u32 blkEnd)
+// ---- labels --------------------------------------------------------------------------------------------------------------------------
+// A round must sort on the labels as they stood when it began: a refined label read beside one that is still to be refined would order two
+// suffixes that are equal so far (the old label of a group says nothing about where its members go). Rounds 1-5 therefore gathered all keys
+// of a round (k_bwt_f_gather_*) before any kernel of it changed a label. With VERSIONED labels a kernel may read keys and write labels in the
+// same launch: an entry of ISA2 holds, in one 64-bit word that is read and written whole,
+//     bits 0-27 the label, bits 28-55 the label it replaced, bits 56-63 the round in which it was written,
+// labels as slots relative to their block's first slot (blocks up to 2^28 bytes; larger ones use the plain words and separate key
+// kernels). A reader of round r takes the replaced label when the entry carries r's number -- whatever kernel of the round wrote it, before
+// or beside the reader -- and the label otherwise. A position changes its label at most once per round (it is a member of one group).
+// Writers outside the rounds (round 0, text round, run round, probe: nobody reads beside them) write label = replaced label, number 0.
+constexpr u32 LAB_BITS = 28;
+constexpr u64 LAB_MASK = (1ull << LAB_BITS) - 1ull;
+
+// label of position q as of the end of the previous round (global slot); bb = first slot of q's block
+__device__ __forceinline__ u32 lab_old(const FwdView& v, u32 q, u32 bb)
+{
+    if (v.ISA2 == nullptr) return v.ISA[q];
+    const u64 e = v.ISA2[q];
+    const u32 rel = ((u32)(e >> 56) == v.round && v.round != 0) ? (u32)((e >> LAB_BITS) & LAB_MASK) : (u32)(e & LAB_MASK);
+    return bb + rel;
+}
+// the latest label (for kernels that run where no label changes)
+__device__ __forceinline__ u32 lab_cur(const FwdView& v, u32 q, u32 bb)
+{
+    if (v.ISA2 == nullptr) return v.ISA[q];
+    return bb + (u32)(v.ISA2[q] & LAB_MASK);
+}
+// position p of the block that starts at slot bb goes from label `was` to label `lab` (global slots)
+__device__ __forceinline__ void lab_set(const FwdView& v, u32 p, u32 bb, u32 lab, u32 was)
+{
+    if (v.ISA2 == nullptr) { v.ISA[p] = lab; return; }
+    const u64 nw = (u64)(lab - bb), ow = (v.round == 0) ? nw : (u64)(was - bb);
+    v.ISA2[p] = nw | (ow << LAB_BITS) | ((u64)v.round << 56);
+}
+
+__device__ __forceinline__ u32 gather_key(const FwdView& v, u32 gp, u32 h, u32 blkBase, u32 blkEnd)
 {
     const u32 q = gp + h;
-    return (q < blkEnd) ? ISA[q] - blkBase + 1u : 0u;
+    return (q < blkEnd) ? lab_old(v, q, blkBase) - blkBase + 1u : 0u;
 }
 
 __device__ __forceinline__ void classify_child(const FwdView& v, uint2* __restrict__ medNext, uint2* __restrict__ largeNext, u32 start, u32 size, u32& surv)
@@ -416,7 +454,7 @@ __global__ __launch_bounds__(256) void k_bwt_f_r0_place(FwdView v, const u32* __
         const u32 pos = (u32)(kk & ((1ull << pbits) - 1ull));
         const u32 gp = v.base[blk] + pos;
         v.SA[a] = gp;
-        v.ISA[gp] = hd;
+        lab_set(v, gp, v.base[blk], hd, hd);
         if (hd == a) {
             const u32 m2 = word & ~lowmask;
             const u32 ei = m2 ? (w * 32 + (u32)__ffs((int)m2) - 1) : W.nextSet[w];
@@ -549,7 +587,7 @@ __global__ __launch_bounds__(256) void k_bwt_f_r0_place_text(BwtView bv, FwdView
             }
             const u32 headIdx = gs[k] + less;
             v.SA[slot0 + headIdx + eqBefore] = gp[k];
-            v.ISA[gp[k]] = slot0 + headIdx;
+            lab_set(v, gp[k], v.base[blkOf[k]], slot0 + headIdx, slot0 + headIdx);
             if (less != 0 && eqBefore == 0) atomicOr(&sNew[headIdx >> 5], 1u << (headIdx & 31));
             if (eq > 1) surv = 1;
             continue;
@@ -570,7 +608,7 @@ __global__ __launch_bounds__(256) void k_bwt_f_r0_place_text(BwtView bv, FwdView
             if (endSlot - hd <= SM_G) continue;
         }
         v.SA[a] = gp[k];
-        v.ISA[gp[k]] = hd;
+        lab_set(v, gp[k], v.base[blkOf[k]], hd, hd);
         if (hd == a) {
             const u32 m2 = word & ~lowmask;
             const u32 ei = m2 ? (w * 32 + (u32)__ffs((int)m2) - 1) : W.nextSet[w];
@@ -622,7 +660,7 @@ __global__ __launch_bounds__(256) void k_bwt_f_gather_small(FwdView v, u32 h, in
         while (slot >= v.base[b + 1]) b++;
         u32 off = h;
         if ((sRt[i >> 5] >> (i & 31)) & 1u) { const u32 r = v.ovr[slot]; off = r > h ? r : h; }
-        v.K[slot] = gather_key(v.ISA, v.SA[slot], off, v.base[b], v.base[b + 1]);
+        v.K[slot] = gather_key(v, v.SA[slot], off, v.base[b], v.base[b + 1]);
         if (stats) { atomicAdd(&v.counters[10], 1u); if (i == s) atomicAdd(&v.counters[11], 1u); }      // (developer statistics, knob bwt_stats)
     }
 }
@@ -635,9 +673,11 @@ __global__ __launch_bounds__(256) void k_bwt_f_sort_small(FwdView v, u32* __rest
     __shared__ u32 sK[SM_WIN];
     __shared__ u32 sNew[64];
     __shared__ u32 sWs[4];
+    __shared__ int sBlk;
     const u32 slot0 = blockIdx.x * SM_TS;
     if (!sm_load_window(v, slot0, W, &sAny)) { if (threadIdx.x == 0 && survTile) survTile[blockIdx.x] = 0; return; }
     if (threadIdx.x < 64) sNew[threadIdx.x] = 0;
+    if (threadIdx.x == 64) sBlk = find_block(v.base, v.nBlocks, slot0 < v.total ? slot0 : v.total - 1);
     u32 gs[SM_WIN / 256], ge[SM_WIN / 256];
     bool act[SM_WIN / 256];
 #pragma unroll
@@ -645,6 +685,83 @@ __global__ __launch_bounds__(256) void k_bwt_f_sort_small(FwdView v, u32* __rest
         const u32 i = threadIdx.x + 256u * k;
         act[k] = sm_group_of(W, i, gs[k], ge[k]);
         if (act[k]) { sSA[i] = v.SA[slot0 + i]; sK[i] = v.K[slot0 + i]; }
+    }
+    __syncthreads();
+    const int b0 = sBlk;
+    u32 surv = 0;
+#pragma unroll
+    for (int k = 0; k < (int)(SM_WIN / 256); k++) {
+        if (!act[k]) continue;
+        const u32 i = threadIdx.x + 256u * k;
+        const u32 ki = sK[i];
+        u32 less = 0, eq = 0, eqBefore = 0;
+        for (u32 j = gs[k]; j < ge[k]; j++) {
+            const u32 kj = sK[j];
+            less += (kj < ki) ? 1u : 0u;
+            const u32 same = (kj == ki) ? 1u : 0u;
+            eq += same;
+            eqBefore += (j < i) ? same : 0u;
+        }
+        const u32 gp = sSA[i];
+        const u32 headIdx = gs[k] + less;
+        v.SA[slot0 + headIdx + eqBefore] = gp;
+        if (less != 0) {
+            u32 bbase = 0;
+            if (v.ISA2) { int b = b0; while (slot0 + i >= v.base[b + 1]) b++; bbase = v.base[b]; }
+            lab_set(v, gp, bbase, slot0 + headIdx, slot0 + gs[k]);             // (a small group's label is its first slot)
+            if (eqBefore == 0) atomicOr(&sNew[headIdx >> 5], 1u << (headIdx & 31));
+        }
+        if (eq > 1) surv++;
+    }
+    {
+        // members that are still tied, per window (summed by a scan: the host decides by their number whether the next round looks for
+        // links first; one counter for all windows would be an atomic per wave on one address)
+        const u32 ws = wave_sum(surv);
+        if ((threadIdx.x & 63) == 0) { sWs[threadIdx.x >> 6] = ws; if (ws) v.counters[0] = 1; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && survTile) survTile[blockIdx.x] = sWs[0] + sWs[1] + sWs[2] + sWs[3];
+    if (threadIdx.x < 64 && sNew[threadIdx.x]) atomicOr(&v.gnew[(slot0 >> 5) + threadIdx.x], sNew[threadIdx.x]);
+}
+
+// Keys and refinement of the small groups in ONE sweep (versioned labels, see lab_old): k_bwt_f_gather_small + k_bwt_f_sort_small without the
+// key array in between -- a window's bit-map words, positions and keys are read once and stay in LDS (the two kernels read the bit map and
+// SA twice and wrote and read K: 24 of the 40 KiB a dense window moved per round).
+__global__ __launch_bounds__(256) void k_bwt_f_small_fused(FwdView v, u32 h, u32* __restrict__ survTile, int stats)
+{
+    __shared__ SmWindow W;
+    __shared__ int sAny;
+    __shared__ int sBlk;
+    __shared__ u32 sRt[64];
+    __shared__ u32 sSA[SM_WIN];
+    __shared__ u32 sK[SM_WIN];
+    __shared__ u32 sNew[64];
+    __shared__ u32 sWs[4];
+    const u32 slot0 = blockIdx.x * SM_TS;
+    if (threadIdx.x >= 64 && threadIdx.x < 128) sRt[threadIdx.x - 64] = v.rtbits ? v.rtbits[(slot0 >> 5) + threadIdx.x - 64] : 0u;
+    if (!sm_load_window(v, slot0, W, &sAny)) { if (threadIdx.x == 0 && survTile) survTile[blockIdx.x] = 0; return; }
+    if (threadIdx.x < 64) sNew[threadIdx.x] = 0;
+    if (threadIdx.x == 64) sBlk = find_block(v.base, v.nBlocks, slot0 < v.total ? slot0 : v.total - 1);
+    __syncthreads();
+    const int b0 = sBlk;
+    u32 gs[SM_WIN / 256], ge[SM_WIN / 256], bb[SM_WIN / 256];
+    bool act[SM_WIN / 256];
+#pragma unroll
+    for (int k = 0; k < (int)(SM_WIN / 256); k++) {
+        const u32 i = threadIdx.x + 256u * k;
+        act[k] = sm_group_of(W, i, gs[k], ge[k]);
+        bb[k] = 0;
+        if (!act[k]) continue;
+        const u32 slot = slot0 + i;
+        int b = b0;
+        while (slot >= v.base[b + 1]) b++;
+        bb[k] = v.base[b];
+        u32 off = h;
+        if ((sRt[i >> 5] >> (i & 31)) & 1u) { const u32 r = v.ovr[slot]; off = r > h ? r : h; }
+        const u32 gp = v.SA[slot];
+        sSA[i] = gp;
+        sK[i] = gather_key(v, gp, off, bb[k], v.base[b + 1]);
+        if (stats) { atomicAdd(&v.counters[10], 1u); if (i == gs[k]) atomicAdd(&v.counters[11], 1u); }      // (developer statistics, knob bwt_stats)
     }
     __syncthreads();
     u32 surv = 0;
@@ -665,14 +782,12 @@ __global__ __launch_bounds__(256) void k_bwt_f_sort_small(FwdView v, u32* __rest
         const u32 headIdx = gs[k] + less;
         v.SA[slot0 + headIdx + eqBefore] = gp;
         if (less != 0) {
-            v.ISA[gp] = slot0 + headIdx;
+            lab_set(v, gp, bb[k], slot0 + headIdx, slot0 + gs[k]);             // (a small group's label is its first slot)
             if (eqBefore == 0) atomicOr(&sNew[headIdx >> 5], 1u << (headIdx & 31));
         }
         if (eq > 1) surv++;
     }
     {
-        // members that are still tied, per window (summed by a scan: the host decides by their number whether the next round looks for
-        // links first; one counter for all windows would be an atomic per wave on one address)
         const u32 ws = wave_sum(surv);
         if ((threadIdx.x & 63) == 0) { sWs[threadIdx.x >> 6] = ws; if (ws) v.counters[0] = 1; }
     }
@@ -737,7 +852,9 @@ __global__ __launch_bounds__(256) void k_bwt_f_sort_small_text(BwtView bv, FwdVi
         const u32 headIdx = gs[k] + less;
         v.SA[slot0 + headIdx + eqBefore] = gp;
         if (less != 0) {
-            v.ISA[gp] = slot0 + headIdx;
+            int b = b0;
+            while (slot0 + i >= v.base[b + 1]) b++;
+            lab_set(v, gp, v.base[b], slot0 + headIdx, slot0 + gs[k]);
             if (eqBefore == 0) atomicOr(&sNew[headIdx >> 5], 1u << (headIdx & 31));
         }
         if (eq > 1) surv = 1;
@@ -805,7 +922,7 @@ __global__ __launch_bounds__(256) void k_bwt_f_link_small(FwdView v, u32* __rest
         while (slot >= v.base[b + 1]) b++;
         const u32 gp = v.SA[slot];
         sP[i] = gp;
-        sK[i] = (gp + 1 < v.base[b + 1]) ? v.ISA[gp + 1] : 0xFFFFFFFFu;          // the label of the successor; none at the block's end
+        sK[i] = (gp + 1 < v.base[b + 1]) ? lab_old(v, gp + 1, v.base[b]) : 0xFFFFFFFFu;      // the label of the successor; none at the block's end
     }
     __syncthreads();
 #pragma unroll
@@ -949,7 +1066,7 @@ __global__ __launch_bounds__(THREADS) void k_bwt_f_gather_desc(FwdView v, const 
         u32 off = h;                                        // (uniform for the group)
         if (v.rtbits && ((v.rtbits[d.x >> 5] >> (d.x & 31)) & 1u)) { const u32 r = v.ovr[d.x]; off = r > h ? r : h; }
         // (block base, label the members carry): what the sorting kernel needs per group without a chain of dependent loads of its own
-        if (threadIdx.x == 0) { descInfo[g] = make_uint2(bb, v.ISA[v.SA[d.x]]); if (stats) atomicAdd(&v.counters[12], d.y); }
+        if (threadIdx.x == 0) { descInfo[g] = make_uint2(bb, lab_old(v, v.SA[d.x], bb)); if (stats) atomicAdd(&v.counters[12], d.y); }
         // eight members per thread at a time: all position loads, then all key loads, then the stores -- two memory
         // latencies per batch instead of two per member
         for (u32 i0 = 0; i0 < d.y; i0 += 8 * THREADS) {
@@ -957,7 +1074,7 @@ __global__ __launch_bounds__(THREADS) void k_bwt_f_gather_desc(FwdView v, const 
 #pragma unroll
             for (int k = 0; k < 8; k++) { const u32 i = i0 + (u32)k * THREADS + threadIdx.x; gp[k] = (i < d.y) ? v.SA[d.x + i] : bb; }
 #pragma unroll
-            for (int k = 0; k < 8; k++) { const u32 i = i0 + (u32)k * THREADS + threadIdx.x; key[k] = (i < d.y) ? gather_key(v.ISA, gp[k], off, bb, be) : 0u; }
+            for (int k = 0; k < 8; k++) { const u32 i = i0 + (u32)k * THREADS + threadIdx.x; key[k] = (i < d.y) ? gather_key(v, gp[k], off, bb, be) : 0u; }
 #pragma unroll
             for (int k = 0; k < 8; k++) { const u32 i = i0 + (u32)k * THREADS + threadIdx.x; if (i < d.y) v.K[d.x + i] = key[k]; }
         }
@@ -978,7 +1095,8 @@ struct MedLds {
     u32 pn[CAP / 32];
     u32 wtot[WAVES];
     u32 wtot2[WAVES];
-    u32 oldLab;                 // the label (ISA value) the group's members carry
+    u32 oldLab;                 // the label the group's members carry
+    u32 blkBase;                // first slot of the group's block (labels are stored relative to it: lab_set)
 };
 
 template <int THREADS, int ROWS>
@@ -1143,7 +1261,7 @@ __device__ __forceinline__ void med_write_back(MedLds<THREADS, ROWS>& L, const F
         const u32 size = e - hd;
         const u32 rel = oldLab - gs;
         const u32 lab = (size <= SM_G) ? gs + hd : ((rel >= hd && rel < e) ? oldLab : gs + hd + (size >> 1));
-        if (lab != oldLab) v.ISA[gp] = lab;
+        if (lab != oldLab) lab_set(v, gp, L.blkBase, lab, oldLab);
         if (hd == i) {
 #pragma unroll
             for (int r = 0; r < ROWS; r++) if (r == row) { hSize[r] = size; hKind[r] = agg_note(A, size, false, surv, hLocal[r]); }
@@ -1180,7 +1298,7 @@ __device__ __forceinline__ void med_majority_write_back(MedLds<THREADS, ROWS>& L
     for (u32 i = (u32)tid; i < c; i += THREADS) {
         const u32 gp = L.oV[nOth + i];
         v.SA[mStart + i] = gp;
-        if (mLab != oldLab) v.ISA[gp] = mLab;
+        if (mLab != oldLab) lab_set(v, gp, L.blkBase, mLab, oldLab);
     }
     u32 surv = 0;
     if (tid == 0) {
@@ -1203,7 +1321,7 @@ __device__ __forceinline__ void med_majority_write_back(MedLds<THREADS, ROWS>& L
         (void)relO;
         const u32 gp = L.oV[t];
         v.SA[slot] = gp;
-        if (lab != oldLab) v.ISA[gp] = lab;
+        if (lab != oldLab) lab_set(v, gp, L.blkBase, lab, oldLab);
         if (t == hd) {
             if (hdSlot != gs) atomicOr(&v.gnew[hdSlot >> 5], 1u << (hdSlot & 31));
             if (size > SM_G) v.medStage[hdSlot >> 8] = make_uint2(hdSlot, size);
@@ -1218,6 +1336,9 @@ __device__ __forceinline__ void med_majority_write_back(MedLds<THREADS, ROWS>& L
 // A group in which one key holds the majority (periodic stretches and runs: every member but the ones near the end of the
 // stretch looks at the same group h further on) is first split, stably, into "that key" and "the others"; only the
 // others are sorted.
+// (Round 6 measured the keys fetched inside this kernel, versioned labels as in k_bwt_f_small_fused: gather + sort of the medium groups
+// 9.1 -> 11.0 ms on the real files, 5.5 -> 6.9 on the stand-in -- a sorting workgroup waits for its own three dependent loads, the gather kernel
+// keeps eight groups per CU in flight and walks the list XCD by XCD. The keys stay a kernel of their own.)
 template <int THREADS, int ROWS>
 __global__ __launch_bounds__(THREADS, THREADS / 128) void k_bwt_f_sort_medium(FwdView v, const uint2* __restrict__ desc, u32 nDesc, int npass, u32 minLen,
                                                                uint2* __restrict__ medNext, uint2* __restrict__ largeNext, const uint2* __restrict__ descInfo,
@@ -1243,7 +1364,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 128) void k_bwt_f_sort_medium(Fw
             for (int r = 0; r < ROWS; r++) { const u32 i = (u32)tid + (u32)r * THREADS; if (i < n) { L.oK[i] = k[r]; L.oV[i] = p[r]; } }
         }
         __syncthreads();
-        if (tid == 0) L.oldLab = info.y;
+        if (tid == 0) { L.oldLab = info.y; L.blkBase = info.x; }
         // majority candidate: the key two of three probes agree on, else the middle one
         const u32 ka = L.oK[n >> 2], kb = L.oK[n >> 1], kc = L.oK[(n >> 2) * 3];
         const u32 m = (ka == kc) ? ka : kb;
@@ -1308,7 +1429,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 128) void k_bwt_f_sort_medium(Fw
                     u32 lessQ = 0;
                     if ((u32)tid < nOth) lessQ = (L.oK[tid] < m) ? 1u : 0u;
                     lessQ = med_block_sum(L, lessQ);
-                    if (tid == 0) L.oldLab = info.y;
+                    if (tid == 0) { L.oldLab = info.y; L.blkBase = info.x; }
                     __syncthreads();
                     med_majority_write_back<THREADS, ROWS>(L, v, gs, n, nOth, c, lessQ, m);
                     __syncthreads();
@@ -1379,7 +1500,7 @@ __global__ __launch_bounds__(1024) void k_bwt_f_super(FwdView v, const uint4* __
 #pragma unroll
             for (int r = 0; r < ROWS; r++) { const u32 i = (u32)tid + (u32)r * THREADS; if (i < n) { L.oK[i] = k[r]; L.oV[i] = p[r]; } }
         }
-        if (tid == 0) { sEnds = 0; sCmax = 0; L.oldLab = d.w; }
+        if (tid == 0) { sEnds = 0; sCmax = 0; L.oldLab = d.w; L.blkBase = d.z; }
         __syncthreads();
         const u32 m = d.w - d.z + 1u;
         // the offset the group's keys were gathered at (k_bwt_f_gather_desc): h, or what the group is known to share beyond it
@@ -1565,7 +1686,7 @@ __global__ __launch_bounds__(512, 4) void k_bwt_f_probe(BwtView bv, FwdView v, u
         const u32 bb = sInfo[0], be = sInfo[1];
         const u8* t = bv.src[sInfo[3]];
         for (u32 j = (u32)tid; j < P; j += THREADS) pat[j] = ldg<u8>(t + (pr - bb + j));
-        if (tid == 0) sInfo[2] = v.ISA[pr];
+        if (tid == 0) sInfo[2] = lab_cur(v, pr, sInfo[0]);
         __syncthreads();
         // ---- every member against the pattern: where and how it differs
         constexpr u32 MID = 1u << 21;
@@ -1604,7 +1725,7 @@ __global__ __launch_bounds__(512, 4) void k_bwt_f_probe(BwtView bv, FwdView v, u
         nBelow = med_block_sum(L, nBelow);
         if (2 * nEq < n) continue;                            // the pattern was not the stretches' (or there are none): nothing was written
         // the parts of the group are staged for the next round's list (med_write_back); this round's descriptor is void
-        if (tid == 0) { L.oldLab = sInfo[2]; desc[g].y = 0; }
+        if (tid == 0) { L.oldLab = sInfo[2]; L.blkBase = sInfo[0]; desc[g].y = 0; }
         med_radix_sort<THREADS, ROWS>(L, n, 3);
         med_write_back<THREADS, ROWS>(L, v, gs, n, medNext, largeNext);
         // what every member is now known to share with the members it stays together with: the ones that equal the pattern P symbols
@@ -1622,13 +1743,15 @@ __global__ __launch_bounds__(512, 4) void k_bwt_f_probe(BwtView bv, FwdView v, u
 // large groups: one global sort of (descriptor index, key) pairs
 // ------------------------------------------------------------------------------------------------
 // loff[i] = sum of the lengths of the descriptors before i; loff[n] = total
-__global__ __launch_bounds__(1024) void k_bwt_f_large_prefix(const uint2* __restrict__ desc, u32 nDesc, u32* __restrict__ loff)
+// (+ lbase[i] = first slot of the block descriptor i lies in: the placing kernels store labels relative to it, lab_set)
+__global__ __launch_bounds__(1024) void k_bwt_f_large_prefix(const uint2* __restrict__ desc, u32 nDesc, u32* __restrict__ loff, const u32* __restrict__ base, int nBlocks,
+                                                             u32* __restrict__ lbase)
 {
     __shared__ u32 part[1024];
     const u32 per = (nDesc + 1023) / 1024;
     const u32 lo = threadIdx.x * per, hi = (lo + per < nDesc) ? lo + per : nDesc;
     u32 sum = 0;
-    for (u32 i = lo; i < hi; i++) sum += desc[i].y;
+    for (u32 i = lo; i < hi; i++) { sum += desc[i].y; lbase[i] = base[find_block(base, nBlocks, desc[i].x)]; }
     part[threadIdx.x] = sum;
     __syncthreads();
     if (threadIdx.x == 0) { u32 run = 0; for (int t = 0; t < 1024; t++) { const u32 x = part[t]; part[t] = run; run += x; } loff[nDesc] = run; }
@@ -1652,7 +1775,7 @@ __global__ __launch_bounds__(256) void k_bwt_f_large_keys(FwdView v, const uint2
     const u32 gp = v.SA[slot];
     u32 off = h;
     if (v.rtbits && ((v.rtbits[d.x >> 5] >> (d.x & 31)) & 1u)) { const u32 r = v.ovr[d.x]; off = r > h ? r : h; }
-    const u32 key = gather_key(v.ISA, gp, off, v.base[b], v.base[b + 1]);
+    const u32 key = gather_key(v, gp, off, v.base[b], v.base[b + 1]);
     keys[j] = (KEY)(((u64)lo << kbits) | (u64)key);
     vals[j] = gp;
 }
@@ -1671,7 +1794,7 @@ template <class KEY>
 __global__ __launch_bounds__(256) void k_bwt_f_large_place(FwdView v, const uint2* __restrict__ desc, const u32* __restrict__ loff, u32 L, int kbits,
                                                            const KEY* __restrict__ keys, const u32* __restrict__ vals, const u32* __restrict__ head,
                                                            const u32* __restrict__ nextRev, uint2* __restrict__ medNext, uint2* __restrict__ largeNext,
-                                                           const u32* __restrict__ memberR, u32* __restrict__ ovr, u32* __restrict__ rtbits)
+                                                           const u32* __restrict__ memberR, u32* __restrict__ ovr, u32* __restrict__ rtbits, const u32* __restrict__ lbase)
 {
     const u32 j = blockIdx.x * 256 + threadIdx.x;
     u32 surv = 0;
@@ -1688,7 +1811,8 @@ __global__ __launch_bounds__(256) void k_bwt_f_large_place(FwdView v, const uint
         const u32 gp = vals[j];
         const u32 nh = head[j];
         v.SA[gs + (j - off)] = gp;
-        if (nh != off) v.ISA[gp] = gs + (nh - off);
+        // (a large group's label is its first slot: round 0 and this kernel are the only ones that make large groups)
+        if (nh != off) lab_set(v, gp, lbase[di], gs + (nh - off), gs);
         mySlot = gs + (j - off);
         if (memberR != nullptr) ovr[mySlot] = memberR[j];          // the run round: what the doubling rounds need to look behind the run
         if (nh == j) {
@@ -1891,7 +2015,7 @@ __global__ __launch_bounds__(256) void k_bwt_f_run_table(BwtView bv, FwdView v, 
     const u8* t = bv.src[b];
     const u32 c = t[p - bb], L = R[p], e = p + L;
     const bool below = (e >= be) || (t[e - bb] < c);                 // the block end sorts in front of every byte
-    const u64 T = (e < be) ? (u64)(v.ISA[e] - bb + 1u) : 0ull;
+    const u64 T = (e < be) ? (u64)(lab_cur(v, e, bb) - bb + 1u) : 0ull;
     const u64 cls = classTab[(u32)b * 256u + c];
     runKeys[k] = ((((cls << 1) | (below ? 0ull : 1ull)) << kbits | T) << idxBits) | (u64)k;
     runE[k] = e;
@@ -1984,7 +2108,7 @@ __global__ __launch_bounds__(256) void k_bwt_f_run_flags(const u64* __restrict__
 __global__ __launch_bounds__(256) void k_bwt_f_run_place(FwdView v, const uint2* __restrict__ desc, const u32* __restrict__ loff, u32 M, int kbits, const u64* __restrict__ keys,
                                                          const u32* __restrict__ vals, const u32* __restrict__ bits, const u32* __restrict__ winLastIncl,
                                                          const u32* __restrict__ winFirstInclRev, u32 nWin, uint2* __restrict__ largeNext, const u32* __restrict__ memberR,
-                                                         u32* __restrict__ ovr, u32* __restrict__ rtbits)
+                                                         u32* __restrict__ ovr, u32* __restrict__ rtbits, const u32* __restrict__ lbase)
 {
     // one member per thread (the kernel is a scatter of labels: occupancy is what hides its latency); the 64 words of the member's window of
     // 2048 are looked at by every one of the window's eight workgroups
@@ -2030,7 +2154,7 @@ __global__ __launch_bounds__(256) void k_bwt_f_run_place(FwdView v, const uint2*
         const u32 gp = vals[j];
         mySlot = gs + (j - off);
         v.SA[mySlot] = gp;
-        if (nh != off) v.ISA[gp] = gs + (nh - off);                      // (the first tie of a group keeps the group's label)
+        if (nh != off) lab_set(v, gp, lbase[di], gs + (nh - off), gs);      // (the first tie of a group keeps the group's label)
         if (memberR != nullptr) ovr[mySlot] = memberR[j];
         if (nh == j) {
             const u32 m2 = word & ~lowmask;
@@ -2086,7 +2210,7 @@ __global__ __launch_bounds__(256) void k_bwt_f_merge_bits(u32* __restrict__ gbit
 // final: BWT bytes + header (BWTBlockCodec.cpp:58-86)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_bwt_f_emit(BwtView v, const u32* __restrict__ base, const u8* __restrict__ ok, const u32* __restrict__ SA,
-                                                    const u32* __restrict__ ISA, u32* __restrict__ newLen)
+                                                    FwdView fv, u32* __restrict__ newLen)
 {
     const int b = blockIdx.y;
     if (!ok[b]) return;
@@ -2098,7 +2222,7 @@ __global__ __launch_bounds__(256) void k_bwt_f_emit(BwtView v, const u32* __rest
     const u8* s = v.src[b];
     u8* d = v.dst[b];
     const u32 bb = base[b];
-    const u32 r0 = ISA[bb] - bb;                           // rank of suffix 0
+    const u32 r0 = lab_cur(fv, bb, bb) - bb;               // rank of suffix 0
     // output byte q (hdr + 1 <= q < hdr + n) is the symbol in front of the suffix of rank r' = q - hdr - 1, ranks from r0 on moved
     // up by one (suffix 0 has nothing in front of it); a thread gathers the four bytes of one aligned dword of the output
     const u32 qLo = hdr + 1, qHi = hdr + n;
@@ -2127,7 +2251,7 @@ __global__ __launch_bounds__(256) void k_bwt_f_emit(BwtView v, const u32* __rest
         d[0] = (u8)((logNbChunks << 2) | (pIndexSize - 1));
         u32 idx = 1;
         for (int k = 0; k < chunks; k++) {
-            const u32 prim = ISA[bb + (u32)k * step] - bb;   // primaryIndex - 1
+            const u32 prim = lab_cur(fv, bb + (u32)k * step, bb) - bb;   // primaryIndex - 1
             for (int sh = (int)(pIndexSize - 1) * 8; sh >= 0; sh -= 8) d[idx++] = (u8)(prim >> sh);
         }
         newLen[b] = hdr + n;
@@ -2151,12 +2275,14 @@ __global__ __launch_bounds__(256) void k_bwt_f_med_compact(uint2* __restrict__ s
 }
 
 // knobs (tests, tuning): read from the environment once per process, or set through knz_hip_tune()
-struct FwdTuning { int nsym; int noRunRound; int runFallback; int noSuper; int noTextRound; int stats; int noRunOffsets; int noProbe; int link; int gatherWg; };
+struct FwdTuning { int nsym; int noRunRound; int runFallback; int noSuper; int noTextRound; int stats; int noRunOffsets; int noProbe; int link; int gatherWg; int plainLabels; int noFuse; };
 static FwdTuning& fwd_tuning()
 {
     static FwdTuning t = [] {
-        FwdTuning x; x.nsym = 0; x.noRunRound = 0; x.runFallback = 0; x.noSuper = 0; x.noTextRound = 0; x.stats = 0; x.noRunOffsets = 0; x.noProbe = 0; x.link = 1; x.gatherWg = 512;     // link: 0 off, 1 on (from h = 32), n > 1: from h = n
+        FwdTuning x; x.nsym = 0; x.noRunRound = 0; x.runFallback = 0; x.noSuper = 0; x.noTextRound = 0; x.stats = 0; x.noRunOffsets = 0; x.noProbe = 0; x.link = 1; x.gatherWg = 512; x.plainLabels = 0; x.noFuse = 0;     // link: 0 off, 1 on (from h = 32), n > 1: from h = n
         if (getenv("KNZ_BWT_NO_PROBE")) x.noProbe = 1;
+        if (getenv("KNZ_BWT_PLAIN_LABELS")) x.plainLabels = 1;
+        if (getenv("KNZ_BWT_NO_FUSE")) x.noFuse = 1;
         if (const char* e = getenv("KNZ_BWT_LINK")) x.link = atoi(e);
         if (getenv("KNZ_BWT_NO_RUN_OFFSETS")) x.noRunOffsets = 1;
         if (getenv("KNZ_BWT_STATS")) x.stats = 1;
@@ -2183,6 +2309,8 @@ int bwt_forward_tune(const char* key, int value)
     else if (!strcmp(key, "bwt_no_probe")) t.noProbe = value;
     else if (!strcmp(key, "bwt_link")) t.link = value;
     else if (!strcmp(key, "bwt_gather_wg")) t.gatherWg = value;
+    else if (!strcmp(key, "bwt_plain_labels")) t.plainLabels = value;
+    else if (!strcmp(key, "bwt_no_fuse")) t.noFuse = value;
     else return -1;
     return 0;
 }
@@ -2190,11 +2318,11 @@ int bwt_forward_tune(const char* key, int value)
 struct FwdScratch {
     u64* keysA; u64* keysB;
     u32* valsA; u32* valsB;
-    u32* SA; u32* ISA; u32* K;
+    u32* SA; u32* ISA; u32* K; u64* ISA2;
     u32* t0; u32* t1; u32* t2; u32* t3;
     u32* gbits; u32* gnew; u32* rtbits; u32* ovr; size_t gbitsWords;
     uint2* med[2]; uint2* medStage; u32* medFlags; u32* medPrefix; size_t medSlots; uint2* descInfo; uint2* large[2]; uint2* runList; uint4* superList; u32* ebits;
-    u32* loff;
+    u32* loff; u32* lbase;
     u32* survTile;       // members still tied after a round's small-group sort, per window
     u32* linkedTile;     // members the link step linked, per window
     u32* base;
@@ -2222,6 +2350,7 @@ static size_t fwd_carve(u8* p, int nBlocks, size_t total, FwdScratch* w)
     w->keysA = (u64*)take(8 * total); w->keysB = (u64*)take(8 * total);
     w->valsA = (u32*)take(4 * total); w->valsB = (u32*)take(4 * total);
     w->SA = (u32*)take(4 * total); w->ISA = (u32*)take(4 * total); w->K = (u32*)take(4 * total);
+    w->ISA2 = (u64*)take(8 * total);                               // versioned labels (lab_old / lab_set)
     w->t0 = (u32*)take(4 * total); w->t1 = (u32*)take(4 * total); w->t2 = (u32*)take(4 * total); w->t3 = (u32*)take(4 * total);
     w->gbits = (u32*)take(4 * w->gbitsWords);
     w->gnew = (u32*)take(4 * w->gbitsWords);
@@ -2236,6 +2365,7 @@ static size_t fwd_carve(u8* p, int nBlocks, size_t total, FwdScratch* w)
     w->descInfo = (uint2*)take(8 * maxMed);
     w->ebits = (u32*)take(4 * w->gbitsWords);
     w->loff = (u32*)take(4 * (maxMed + 1));
+    w->lbase = (u32*)take(4 * (maxMed + 1));
     w->survTile = (u32*)take(4 * (total / SM_TS + 64));
     w->linkedTile = (u32*)take(4 * (total / SM_TS + 64));
     w->base = (u32*)take(4ull * (nBlocks + 2));
@@ -2282,7 +2412,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     if (hipStreamSynchronize(s) != hipSuccess) return -1;
     const u32 total = h_pinned[0];
     if (total == 0) return 0;
-    FwdView v; v.base = w.base; v.nBlocks = st.nBlocks; v.total = total; v.SA = w.SA; v.ISA = w.ISA; v.K = w.K; v.gbits = w.gbits; v.gnew = w.gnew; v.counters = w.counters; v.medStage = w.medStage; v.ovr = nullptr; v.rtbits = nullptr;
+    FwdView v; v.base = w.base; v.nBlocks = st.nBlocks; v.total = total; v.SA = w.SA; v.ISA = w.ISA; v.K = w.K; v.ISA2 = (bv.VS <= (1u << LAB_BITS) && !tune.plainLabels) ? w.ISA2 : (u64*)nullptr; v.round = 0; v.gbits = w.gbits; v.gnew = w.gnew; v.counters = w.counters; v.medStage = w.medStage; v.ovr = nullptr; v.rtbits = nullptr;
     const u32 medSlots = (u32)((size_t)total / 256 + 1);
     hipMemsetAsync(w.medStage, 0, 8ull * w.medSlots, s);
     // the medium groups staged by the kernels of a round -> descriptor list `dst` (in slot order) and counters[1]
@@ -2423,7 +2553,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
             nRun = 0;
         }
       if (nRun) {
-        { KScope ks_("k_bwt_f_large_prefix"); hipLaunchKernelGGL(k_bwt_f_large_prefix, dim3(1), dim3(1024), 0, s, w.runList, nRun, w.loff); }
+        { KScope ks_("k_bwt_f_large_prefix"); hipLaunchKernelGGL(k_bwt_f_large_prefix, dim3(1), dim3(1024), 0, s, w.runList, nRun, w.loff, w.base, st.nBlocks, w.lbase); }
         { KScope ks_("k_bwt_f_run_table"); hipLaunchKernelGGL(k_bwt_f_run_table, GRID1(nRuns), bv, v, w.runPos, nRuns, w.K, w.classTab, kbits, idxBits, w.runKeysA, w.runE, w.runL); }
         const u64* rkSorted;
         { KScope ks_("k_bwt_f_sort_runs");
@@ -2455,7 +2585,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
             { KScope ks_("k_bwt_f_large_place");
               if (runOffsets) hipMemsetAsync(w.rtbits, 0, 4 * w.gbitsWords, s);
               hipLaunchKernelGGL(k_bwt_f_run_place, dim3((runElems + 255) / 256), dim3(256), 0, s, v, w.runList, w.loff, runElems, keyBits, rk, rv, mbits, w.t1, w.t3, nWinM, w.large[cur],
-                                 runOffsets ? (const u32*)w.valsB : (const u32*)nullptr, runOffsets ? w.ovr : (u32*)nullptr, runOffsets ? w.rtbits : (u32*)nullptr);
+                                 runOffsets ? (const u32*)w.valsB : (const u32*)nullptr, runOffsets ? w.ovr : (u32*)nullptr, runOffsets ? w.rtbits : (u32*)nullptr, w.lbase);
               if (runOffsets) { v.ovr = w.ovr; v.rtbits = w.rtbits; } }
         }
         { KScope ks_("k_bwt_f_merge_bits"); hipLaunchKernelGGL(k_bwt_f_merge_bits, GRID1(total / 32 + 2), w.gbits, w.gnew, total / 32 + 2); }
@@ -2506,6 +2636,8 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     while (surv || nMed || nLarge) {
         if (h > bv.VS) return -5;                                    // cannot happen: suffixes of one block differ in length
         { KScope ks_("k_bwt_f_round"); hipMemsetAsync(w.counters, 0, 64, s); }      // (the scope counts the doubling rounds for the profile)
+        v.round++;                                                   // (the number the round's label writes carry; at most log2(block) + a few)
+        if (v.round > 255) return -5;
         const int nxt = cur ^ 1;
         // -- small groups inside long repeats: links first (k_bwt_f_link_small), once the rounds are past the depth where most ties are chance
         // Whether it pays is a property of the data (it does where groups are whole repeats: copied spans, files that hold a part twice;
@@ -2553,8 +2685,9 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
             hipLaunchKernelGGL(k_bwt_f_link_apply, gridL, dim3(256), 0, s, v, posflag, sufRev, nW, linked, h, w.ovr, w.rtbits, linkStep, linkTr);
             linkStepUsed = linkStep;
         }
-        // -- all keys first
-        if (surv) { KScope ks_("k_bwt_f_gather_small"); hipLaunchKernelGGL(k_bwt_f_gather_small, dim3(nTiles), dim3(256), 0, s, v, h, tune.stats); }
+        // -- all keys first (with versioned labels the small groups fetch theirs in the kernel that sorts them: k_bwt_f_small_fused)
+        const bool fused = v.ISA2 != nullptr && !tune.noFuse;
+        if (surv && !fused) { KScope ks_("k_bwt_f_gather_small"); hipLaunchKernelGGL(k_bwt_f_gather_small, dim3(nTiles), dim3(256), 0, s, v, h, tune.stats); }
         if (nMed) {
             // (the list is in slot order: k_bwt_f_med_compact)
             KScope ks_("k_bwt_f_gather_desc");
@@ -2570,13 +2703,15 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
         if (nLarge) {
             while ((1u << lbits) < nLarge) lbits++;
             small32 = (kbits + lbits) <= 32;
-            { KScope ks_("k_bwt_f_large_prefix"); hipLaunchKernelGGL(k_bwt_f_large_prefix, dim3(1), dim3(1024), 0, s, w.large[cur], nLarge, w.loff); }
+            { KScope ks_("k_bwt_f_large_prefix"); hipLaunchKernelGGL(k_bwt_f_large_prefix, dim3(1), dim3(1024), 0, s, w.large[cur], nLarge, w.loff, w.base, st.nBlocks, w.lbase); }
             KScope ks_("k_bwt_f_large_keys");
             if (small32) hipLaunchKernelGGL(k_bwt_f_large_keys<u32>, GRID1(largeElems), v, w.large[cur], nLarge, w.loff, largeElems, h, kbits, reinterpret_cast<u32*>(lkA), w.valsA);
             else hipLaunchKernelGGL(k_bwt_f_large_keys<u64>, GRID1(largeElems), v, w.large[cur], nLarge, w.loff, largeElems, h, kbits, lkA, w.valsA);
         }
         // -- then the refinements
-        if (surv) { KScope ks_("k_bwt_f_sort_small"); hipLaunchKernelGGL(k_bwt_f_sort_small, dim3(nTiles), dim3(256), 0, s, v, tune.link ? w.survTile : (u32*)nullptr);
+        if (surv) { KScope ks_("k_bwt_f_sort_small");
+                    if (fused) hipLaunchKernelGGL(k_bwt_f_small_fused, dim3(nTiles), dim3(256), 0, s, v, h, tune.link ? w.survTile : (u32*)nullptr, tune.stats);
+                    else hipLaunchKernelGGL(k_bwt_f_sort_small, dim3(nTiles), dim3(256), 0, s, v, tune.link ? w.survTile : (u32*)nullptr);
                     if (linkNow) hipLaunchKernelGGL(k_bwt_f_link_payoff, dim3(1), dim3(256), 0, s, v, w.linkedTile, w.survTile, nTiles, linkStepUsed, w.counters + 14, linkTr);
                     if (tune.link) prims::launch_scan<prims::SCAN_SUM_EXCL>(s, w.survTile, w.survTile, nTiles, nullptr, w.scanTmp, w.counters + 13); }
         if (nMed) {
@@ -2607,8 +2742,8 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
             { KScope ks_("k_bwt_f_scan_max"); prims::launch_scan<prims::SCAN_MAX_INCL>(s, w.t0, w.t1, largeElems, nullptr, w.scanTmp); }
             { KScope ks_("k_bwt_f_scan_min"); prims::launch_scan<prims::SCAN_MIN_INCL>(s, w.t2, w.t3, largeElems, nullptr, w.scanTmp); }
             { KScope ks_("k_bwt_f_large_place");
-              if (small32) hipLaunchKernelGGL(k_bwt_f_large_place<u32>, GRID1(largeElems), v, w.large[cur], w.loff, largeElems, kbits, sk32, sv, w.t1, w.t3, w.med[nxt], w.large[nxt], (const u32*)nullptr, (u32*)nullptr, (u32*)nullptr);
-              else hipLaunchKernelGGL(k_bwt_f_large_place<u64>, GRID1(largeElems), v, w.large[cur], w.loff, largeElems, kbits, sk64, sv, w.t1, w.t3, w.med[nxt], w.large[nxt], (const u32*)nullptr, (u32*)nullptr, (u32*)nullptr); }
+              if (small32) hipLaunchKernelGGL(k_bwt_f_large_place<u32>, GRID1(largeElems), v, w.large[cur], w.loff, largeElems, kbits, sk32, sv, w.t1, w.t3, w.med[nxt], w.large[nxt], (const u32*)nullptr, (u32*)nullptr, (u32*)nullptr, w.lbase);
+              else hipLaunchKernelGGL(k_bwt_f_large_place<u64>, GRID1(largeElems), v, w.large[cur], w.loff, largeElems, kbits, sk64, sv, w.t1, w.t3, w.med[nxt], w.large[nxt], (const u32*)nullptr, (u32*)nullptr, (u32*)nullptr, w.lbase); }
         }
         { KScope ks_("k_bwt_f_merge_bits"); hipLaunchKernelGGL(k_bwt_f_merge_bits, GRID1(total / 32 + 2), w.gbits, w.gnew, total / 32 + 2); }
         compactMedium(w.med[nxt]);
@@ -2620,7 +2755,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
             // windows that still hold tied small groups (from the scanned per-window counts; developer statistics only)
             std::vector<u32> hs(nTiles);
             u32 activeTiles = 0;
-            if (tune.link && hipMemcpy(hs.data(), w.survTile, 4 * (size_t)nTiles, hipMemcpyDeviceToHost) == hipSuccess) {
+            if (tune.link && hipMemcpyAsync(hs.data(), w.survTile, 4 * (size_t)nTiles, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) {
                 for (u32 t = 0; t + 1 < nTiles; t++) activeTiles += hs[t + 1] != hs[t] ? 1u : 0u;
                 fprintf(stderr, "  windows with tied small groups after the round: %u of %u\n", activeTiles, nTiles);
             }
@@ -2633,7 +2768,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
         h <<= 1;
     }
     const dim3 gridB((unsigned)std::min<size_t>(((size_t)bv.VS + 255) / 256, 4096), st.nBlocks);
-    { KScope ks_("k_bwt_f_emit"); hipLaunchKernelGGL(k_bwt_f_emit, gridB, dim3(256), 0, s, bv, w.base, st.ok, w.SA, w.ISA, st.newLen); }
+    { KScope ks_("k_bwt_f_emit"); hipLaunchKernelGGL(k_bwt_f_emit, gridB, dim3(256), 0, s, bv, w.base, st.ok, w.SA, v, st.newLen); }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -37,9 +37,13 @@ def main():
         rc, o = R.compress(d, t, e, bs, jobs=1, orig_size=len(d))
         assert rc == 0, (cfg, rc)
         rc, back = R.decompress(o, len(d))
-        assert rc == 0 and back == d, cfg
-        out.append({"config": cfg, "input": list(spec), "input_md5": hashlib.md5(d).hexdigest(), "transform": t, "entropy": e,
-                    "block": bs, "orig_size": len(d), "out": {"len": len(o), "md5": hashlib.md5(o).hexdigest()}})
+        rec = {"config": cfg, "input": list(spec), "input_md5": hashlib.md5(d).hexdigest(), "transform": t, "entropy": e,
+               "block": bs, "orig_size": len(d), "out": {"len": len(o), "md5": hashlib.md5(o).hexdigest()}}
+        if rc != 0 and cfg == "big:bwt_1g":
+            rec["ref_decode_error"] = rc               # the reference cannot read this stream of its own (see vectors.BIG_CASES)
+        else:
+            assert rc == 0 and back == d, cfg
+        out.append(rec)
         print(out[-1], flush=True)
     json.dump(out, open(path, "w"), indent=1)
 

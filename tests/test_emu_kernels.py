@@ -83,7 +83,9 @@ def test_bwt_forward_kernels_emulated(tmp_path):
         # with round-0 placement and text round as two kernels
         if i in (0, 6):                      # (the switches below on the cases with runs, periods and tiny blocks; the two text cases keep the default path)
             continue
-        for var in ("KNZ_BWT_NO_RUN_ROUND", "KNZ_BWT_RUN_FALLBACK", "KNZ_BWT_NO_RUN_OFFSETS", "KNZ_BWT_NO_PROBE", "KNZ_BWT_NO_TEXT_ROUND"):
+        # (round 6: KNZ_BWT_PLAIN_LABELS = 32-bit labels with separate key kernels, the path of blocks above 256 MiB; KNZ_BWT_NO_FUSE = versioned
+        # labels with the small groups' keys and refinement as two kernels)
+        for var in ("KNZ_BWT_NO_RUN_ROUND", "KNZ_BWT_RUN_FALLBACK", "KNZ_BWT_NO_RUN_OFFSETS", "KNZ_BWT_NO_PROBE", "KNZ_BWT_NO_TEXT_ROUND", "KNZ_BWT_PLAIN_LABELS", "KNZ_BWT_NO_FUSE"):
             r = subprocess.run([exe, path], capture_output=True, text=True, timeout=900, env=dict(os.environ, **{var: "2" if var == "KNZ_BWT_NO_TEXT_ROUND" else "1"}))
             assert r.returncode == 0, (i, var, r.stdout[-2000:] + r.stderr[-2000:])
 
@@ -121,6 +123,9 @@ def test_bwt_forward_long_common_prefixes_emulated(tmp_path):
             assert r.returncode == 0, (i, order, r.stdout[-2000:] + r.stderr[-2000:])
             if i == 2:
                 assert r.stderr.count("round h=") <= 2, r.stderr[-1500:]          # the probe took the periodic groups
+        if i in (0, 4):                      # copies / Fibonacci word and DNA once more with 32-bit labels and separate key kernels
+            r = subprocess.run([exe, path], capture_output=True, text=True, timeout=1800, env=dict(os.environ, HIPEMU_ORDER="2", KNZ_BWT_PLAIN_LABELS="1"))
+            assert r.returncode == 0, (i, "plain labels", r.stdout[-2000:] + r.stderr[-2000:])
     # the link step for small groups inside long repeats (round 5): text with copied spans, X || X and a block that holds a text three times
     # with edits, with the step tried from the first doubling round on (KNZ_BWT_LINK=4) and with it off -- the same suffix array either way,
     # and X || X in far fewer rounds with it

@@ -464,6 +464,13 @@ def _big_case(hip, config):
     out, bits, hb = gpu_compress(hip, d, rec["transform"], rec["entropy"], rec["block"], orig_size=rec["orig_size"])
     assert len(out) == rec["out"]["len"], (config, len(out), rec["out"]["len"])
     assert hashlib.md5(out).hexdigest() == rec["out"]["md5"], config
+    if "ref_decode_error" in rec:
+        # a stream the reference writes and cannot read (vectors.BIG_CASES): the device refuses it with the reference's error code
+        hipapi = importlib.import_module("kanzi_amd.hipapi")
+        with pytest.raises(hipapi.KnzError) as ei:
+            gpu_decompress(hip, out, rec["transform"], rec["entropy"], rec["block"], len(d), hb)
+        assert ei.value.code == rec["ref_decode_error"], (config, ei.value.code)
+        return
     back = gpu_decompress(hip, out, rec["transform"], rec["entropy"], rec["block"], len(d), hb)
     assert len(back) == len(d) and back == d, config
 
@@ -487,6 +494,12 @@ def test_big_block_1g_suffix_sort(hip):
     beside four symbols in the round-0 keys, the count + scatter passes (the one-sweep look-back words hold 30-bit counts), labels and
     slots up to 2^30, run-round keys of 63 bits"""
     _big_case(hip, "big:bwt_1g")
+
+
+def test_big_block_1g_less_64k_suffix_sort_round_trip(hip):
+    """the largest BWT block the reference reads back (2^30 - 65,536 bytes: the stored length 2^30 - 65,503 stays below the decoder's limit):
+    suffix sort and inverse on the device, stream and round trip against the reference"""
+    _big_case(hip, "big:bwt_1g_less_64k")
     _BIG_INPUT.clear()
 
 
