@@ -235,6 +235,11 @@ knz_ctx* deviceContext(int device = -1);
 // setLaneDevices() overrides the environment for streams created afterwards (empty vector: back to the environment).
 void setLaneDevices(const std::vector<int>& devices);
 std::vector<int> laneDevices();
+// The stream classes keep finished streams' staging and device buffers in process-wide pools (re-pinning 16 MiB costs milliseconds):
+// at most 2 GiB of page-locked host memory and 1 GiB of device memory per lane context. An application that compresses once and then
+// needs the memory calls this; buffers of live streams are not touched. Returns the bytes given back. (C callers: kanzi_api.h has no
+// such call -- the reference has no pools; `KNZ_LANES=1` bounds what one GPU's lanes can hold.)
+size_t releaseIdleBuffers();
 knz_ctx* laneContext(int device, int index);
 void setDefaultDevice(int device);
 

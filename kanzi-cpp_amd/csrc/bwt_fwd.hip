@@ -2275,11 +2275,11 @@ __global__ __launch_bounds__(256) void k_bwt_f_med_compact(uint2* __restrict__ s
 }
 
 // knobs (tests, tuning): read from the environment once per process, or set through knz_hip_tune()
-struct FwdTuning { int nsym; int noRunRound; int runFallback; int noSuper; int noTextRound; int stats; int noRunOffsets; int noProbe; int link; int gatherWg; int plainLabels; int noFuse; };
+struct FwdTuning { int nsym; int noRunRound; int runFallback; int noSuper; int noTextRound; int stats; int noRunOffsets; int noProbe; int link; int gatherWg; int plainLabels; int noFuse; int largeOs; };
 static FwdTuning& fwd_tuning()
 {
     static FwdTuning t = [] {
-        FwdTuning x; x.nsym = 0; x.noRunRound = 0; x.runFallback = 0; x.noSuper = 0; x.noTextRound = 0; x.stats = 0; x.noRunOffsets = 0; x.noProbe = 0; x.link = 1; x.gatherWg = 512; x.plainLabels = 0; x.noFuse = 0;     // link: 0 off, 1 on (from h = 32), n > 1: from h = n
+        FwdTuning x; x.nsym = 0; x.noRunRound = 0; x.runFallback = 0; x.noSuper = 0; x.noTextRound = 0; x.stats = 0; x.noRunOffsets = 0; x.noProbe = 0; x.link = 1; x.gatherWg = 512; x.plainLabels = 0; x.noFuse = 0; x.largeOs = 1000000;     // link: 0 off, 1 on (from h = 32), n > 1: from h = n
         if (getenv("KNZ_BWT_NO_PROBE")) x.noProbe = 1;
         if (getenv("KNZ_BWT_PLAIN_LABELS")) x.plainLabels = 1;
         if (getenv("KNZ_BWT_NO_FUSE")) x.noFuse = 1;
@@ -2311,6 +2311,7 @@ int bwt_forward_tune(const char* key, int value)
     else if (!strcmp(key, "bwt_gather_wg")) t.gatherWg = value;
     else if (!strcmp(key, "bwt_plain_labels")) t.plainLabels = value;
     else if (!strcmp(key, "bwt_no_fuse")) t.noFuse = value;
+    else if (!strcmp(key, "bwt_large_os")) t.largeOs = value;
     else return -1;
     return 0;
 }
@@ -2733,8 +2734,11 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
               prims::rs_launch_layout(s, rs1);
               // (count + scatter passes here: with the many passes of these keys, most of them on constant digits, counting all of
               // them ahead costs more than it saves -- period 3 / 5 / 7 / 768 at 8 MiB: 11.1-17.6 ms against 11.8-18.2)
-              r = small32 ? prims::rs_sort<u32, true>(s, rs1, k32a, k32b, w.valsA, w.valsB, (size_t)largeElems, 0, kbits + lbits, false)
-                          : prims::rs_sort<u64, true>(s, rs1, lkA, lkB, w.valsA, w.valsB, (size_t)largeElems, 0, kbits + lbits, false); }
+              // (knob bwt_large_os: from that many members on the passes are the one-sweep ones; real files' 27 M members in the first round: 4.11 -> 3.94 ms,
+              // and counted for every sort they cost the many small ones of periodic data more than they save: 4.11 -> 4.56)
+              const bool os = tune.largeOs != 0 && largeElems >= (u32)tune.largeOs;
+              r = small32 ? prims::rs_sort<u32, true>(s, rs1, k32a, k32b, w.valsA, w.valsB, (size_t)largeElems, 0, kbits + lbits, os)
+                          : prims::rs_sort<u64, true>(s, rs1, lkA, lkB, w.valsA, w.valsB, (size_t)largeElems, 0, kbits + lbits, os); }
             const u32* sk32 = r ? k32b : k32a; const u64* sk64 = r ? lkB : lkA; const u32* sv = r ? w.valsB : w.valsA;
             { KScope ks_("k_bwt_f_large_flags");
               if (small32) hipLaunchKernelGGL(k_bwt_f_large_flags<u32>, GRID1(largeElems), sk32, largeElems, w.t0, w.t2);

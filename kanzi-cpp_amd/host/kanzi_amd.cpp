@@ -1089,6 +1089,15 @@ struct PinnedPool {
         idle.push_back(std::make_pair(static_cast<void*>(p), cap));
         idleBytes += cap;
     }
+    // everything that idles goes back to the system (releaseIdleBuffers)
+    size_t trim()
+    {
+        std::vector<std::pair<void*, size_t>> drop;
+        { std::lock_guard<std::mutex> l(mu); drop.swap(idle); idleBytes = 0; }
+        size_t n = 0;
+        for (auto& d : drop) { knz_hip_host_free(d.first); n += d.second; }
+        return n;
+    }
 };
 PinnedPool g_pinned;
 
@@ -1109,14 +1118,20 @@ struct DevPool {
         }
         void* p = nullptr;
         if (knz_hip_malloc(c, bytes, &p) != 0 || p == nullptr) {
-            // make room: whatever idles in this context's pool goes first
-            std::vector<std::pair<void*, size_t>> drop;
-            { std::lock_guard<std::mutex> l(mu); drop.swap(idle[c]); }
-            for (auto& d : drop) knz_hip_free(c, d.first);
+            // make room: whatever idles goes first -- in every context's pool (the lanes of one GPU are several contexts on the same memory)
+            trim();
             devCheck(c, knz_hip_malloc(c, bytes, &p), "malloc");
         }
         *cap = bytes;
         return p;
+    }
+    size_t trim()
+    {
+        std::map<knz_ctx*, std::vector<std::pair<void*, size_t>>> drop;
+        { std::lock_guard<std::mutex> l(mu); drop.swap(idle); }
+        size_t n = 0;
+        for (auto& kv : drop) for (auto& d : kv.second) { knz_hip_free(kv.first, d.first); n += d.second; }
+        return n;
     }
     // kept per context: at most 12 buffers and 1 GiB, nothing above 256 MiB (a stream with 1 GiB blocks gives its memory back)
     void put(knz_ctx* c, void* p, size_t cap)
@@ -1170,6 +1185,10 @@ DeviceGate& gateOf(int device)
     return *g;
 }
 }
+
+// Page-locked staging buffers and device buffers that finished streams have left in the process-wide pools (up to 2 GiB of pinned host
+// memory, up to 1 GiB of device memory per lane context) go back to the system. Buffers of live streams are not touched. Returns the bytes freed.
+size_t releaseIdleBuffers() { return g_pinned.trim() + g_devPool.trim(); }
 
 FetchBuf::~FetchBuf() { g_pinned.put(_p, _cap); }
 
