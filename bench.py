@@ -12,6 +12,9 @@ value = corpus bytes / (t_enc + t_dec) in MB/s (MB = 1e6 B).
 Multi-GPU (--gpus N, one process per GPU under torch.distributed.run): blocks are independent, so a job is sharded over
 the ranks by block index (kanzi-cpp_amd/sharded.py:block_ranges); every rank encodes and decodes its own
 blocks, there is no collective in the data path (only the timing barrier and the MAX all-reduce of the elapsed time).
+READ FIRST at N > 1: `one_corpus_sharded` (the ONE corpus in contiguous block ranges, with `block_count_ceiling` and
+`efficiency_vs_ceiling`) and `many_blocks_sharded` (five corpora back to back = 127 blocks, ceiling 7.94 at N = 8): they answer the
+metric's question, "MB/s on one input at 1/2/4/8 GPUs". The line's `value` is linear by construction:
 The line's `value` is WEAK scaling, as the rule for paths that partition asks: the job grows with N -- N corpora, rank r
 takes the r-th one (26 blocks each at config 3) -- and value = N * corpus bytes / MAX-over-ranks time. The same run then
 also times the ONE corpus sharded over the N ranks (strong scaling: 26 blocks over 8 GPUs is 4,4,3,3,3,3,3,3, so the

@@ -41,7 +41,11 @@ namespace knz {
 constexpr u32 SM_TS = 1792;        // slots owned by one window
 constexpr u32 SM_WIN = 2048;       // slots a window looks at (owned + halo)
 constexpr u32 SM_G = 256;          // largest "small" group
-constexpr u32 MED_CAP = 8192;      // largest "medium" group (one workgroup of 1024 threads, LDS resident)
+// largest "medium" group (one workgroup, LDS resident). Round 6 measured 16,384 with a 1024 x 16 instantiation of k_bwt_f_sort_medium (150 KiB of
+// LDS, one workgroup per CU): period-768 blocks 19.0 -> 9.8 ms, but real files 51.7 -> 52.6, the stand-in 26.6 -> 26.9 -- for groups of that
+// size the global sort of (descriptor, key) pairs is no slower than one workgroup per CU. Stays 8,192.
+constexpr u32 MED_CAP = 8192;
+constexpr u32 SUPER_CAP = 8192;    // largest group the chain round and the periodic-stretch probe take
 constexpr u32 NO_BIT = 0x7FFFFFFFu;
 
 struct FwdView {
@@ -1340,7 +1344,7 @@ __device__ __forceinline__ void med_majority_write_back(MedLds<THREADS, ROWS>& L
 // 9.1 -> 11.0 ms on the real files, 5.5 -> 6.9 on the stand-in -- a sorting workgroup waits for its own three dependent loads, the gather kernel
 // keeps eight groups per CU in flight and walks the list XCD by XCD. The keys stay a kernel of their own.)
 template <int THREADS, int ROWS>
-__global__ __launch_bounds__(THREADS, THREADS / 128) void k_bwt_f_sort_medium(FwdView v, const uint2* __restrict__ desc, u32 nDesc, int npass, u32 minLen,
+__global__ __launch_bounds__(THREADS, (THREADS >= 1024 ? 4 : THREADS / 128)) void k_bwt_f_sort_medium(FwdView v, const uint2* __restrict__ desc, u32 nDesc, int npass, u32 minLen,
                                                                uint2* __restrict__ medNext, uint2* __restrict__ largeNext, const uint2* __restrict__ descInfo,
                                                                uint4* __restrict__ superList)
 {
@@ -1371,7 +1375,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 128) void k_bwt_f_sort_medium(Fw
         u32 c = 0;
         for (u32 i = (u32)tid; i < n; i += THREADS) c += (L.oK[i] == m) ? 1u : 0u;
         c = med_block_sum(L, c);
-        if (c < n && 2 * c >= n && superList != nullptr && m == info.y - info.x + 1u) {
+        if (c < n && 2 * c >= n && n <= SUPER_CAP && superList != nullptr && m == info.y - info.x + 1u) {
             // the majority looks at the group itself (a periodic stretch whose period divides h): k_bwt_f_super finishes it in one round
             if (tid == 0) { const u32 at = atomicAdd(&v.counters[7], 1u); superList[at] = make_uint4(gs, n, info.x, info.y); }
             __syncthreads();
@@ -1638,7 +1642,7 @@ __global__ __launch_bounds__(256) void k_bwt_f_probe_scan(FwdView v, const uint2
     for (u32 g = blockIdx.x * 256 + threadIdx.x; g < nDesc; g += gridDim.x * 256) {
         const uint2 d = desc[g];
         const u32 gs = d.x, n = d.y;
-        if (n <= SM_G || n > MED_CAP) continue;
+        if (n <= SM_G || n > SUPER_CAP) continue;
         if (rtbits != nullptr && ((rtbits[gs >> 5] >> (gs & 31)) & 1u)) continue;         // (groups of the run round know their offset already)
         const u32 a0 = v.SA[gs + (n >> 1) - 2], a1 = v.SA[gs + (n >> 1) - 1], a2 = v.SA[gs + (n >> 1)], a3 = v.SA[gs + (n >> 1) + 1];
         const u32 pd = a2 - a1;
@@ -2341,7 +2345,7 @@ struct FwdScratch {
 
 static size_t fwd_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
-static size_t fwd_carve(u8* p, int nBlocks, size_t total, FwdScratch* w)
+static size_t fwd_carve(u8* p, int nBlocks, size_t total, FwdScratch* w, u32 VS)
 {
     u8* q = p;
     auto take = [&](size_t sz) { u8* r = q; q += fwd_align(sz); return r; };
@@ -2351,7 +2355,7 @@ static size_t fwd_carve(u8* p, int nBlocks, size_t total, FwdScratch* w)
     w->keysA = (u64*)take(8 * total); w->keysB = (u64*)take(8 * total);
     w->valsA = (u32*)take(4 * total); w->valsB = (u32*)take(4 * total);
     w->SA = (u32*)take(4 * total); w->ISA = (u32*)take(4 * total); w->K = (u32*)take(4 * total);
-    w->ISA2 = (u64*)take(8 * total);                               // versioned labels (lab_old / lab_set)
+    w->ISA2 = (VS <= (1u << LAB_BITS)) ? (u64*)take(8 * total) : (u64*)nullptr;     // versioned labels (lab_old / lab_set; blocks up to 2^LAB_BITS bytes)
     w->t0 = (u32*)take(4 * total); w->t1 = (u32*)take(4 * total); w->t2 = (u32*)take(4 * total); w->t3 = (u32*)take(4 * total);
     w->gbits = (u32*)take(4 * w->gbitsWords);
     w->gnew = (u32*)take(4 * w->gbitsWords);
@@ -2387,9 +2391,8 @@ static size_t fwd_carve(u8* p, int nBlocks, size_t total, FwdScratch* w)
 
 size_t bwt_forward_scratch_bytes(int nBlocks, u32 VS, size_t total)
 {
-    (void)VS;
     FwdScratch w;
-    return fwd_carve(nullptr, nBlocks, total, &w) + 4096;
+    return fwd_carve(nullptr, nBlocks, total, &w, VS) + 4096;
 }
 
 #define GRID1(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256), 0, s
@@ -2400,7 +2403,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     BwtView bv; bv.src = st.src; bv.dst = st.dst; bv.len = st.len; bv.cap = st.cap; bv.VS = st.maxLen; bv.nBlocks = st.nBlocks;
     const size_t maxTotal = (size_t)st.nBlocks * bv.VS;
     FwdScratch w;
-    if (fwd_carve(reinterpret_cast<u8*>(scratch), st.nBlocks, maxTotal, &w) > scratchBytes) return -2;
+    if (fwd_carve(reinterpret_cast<u8*>(scratch), st.nBlocks, maxTotal, &w, bv.VS) > scratchBytes) return -2;
     const FwdTuning tune = fwd_tuning();
     { KScope ks_("k_bwt_f_bases"); hipLaunchKernelGGL(k_bwt_bases, dim3(1), dim3(64), 0, s, bv, w.base, st.ok, w.counters + 32); }
     hipMemsetAsync(st.newLen, 0, sizeof(u32) * st.nBlocks, s);
@@ -2413,7 +2416,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     if (hipStreamSynchronize(s) != hipSuccess) return -1;
     const u32 total = h_pinned[0];
     if (total == 0) return 0;
-    FwdView v; v.base = w.base; v.nBlocks = st.nBlocks; v.total = total; v.SA = w.SA; v.ISA = w.ISA; v.K = w.K; v.ISA2 = (bv.VS <= (1u << LAB_BITS) && !tune.plainLabels) ? w.ISA2 : (u64*)nullptr; v.round = 0; v.gbits = w.gbits; v.gnew = w.gnew; v.counters = w.counters; v.medStage = w.medStage; v.ovr = nullptr; v.rtbits = nullptr;
+    FwdView v; v.base = w.base; v.nBlocks = st.nBlocks; v.total = total; v.SA = w.SA; v.ISA = w.ISA; v.K = w.K; v.ISA2 = (w.ISA2 != nullptr && !tune.plainLabels) ? w.ISA2 : (u64*)nullptr; v.round = 0; v.gbits = w.gbits; v.gnew = w.gnew; v.counters = w.counters; v.medStage = w.medStage; v.ovr = nullptr; v.rtbits = nullptr;
     const u32 medSlots = (u32)((size_t)total / 256 + 1);
     hipMemsetAsync(w.medStage, 0, 8ull * w.medSlots, s);
     // the medium groups staged by the kernels of a round -> descriptor list `dst` (in slot order) and counters[1]

@@ -24,14 +24,14 @@ for s in "$@"; do
     hard) timeout 420 python tools/gpu_hard.py > $OUT/hard.txt 2>&1; echo "hard rc=$?" >> $OUT/summary.txt; cat $OUT/hard.txt ;;
     bench4) timeout 900 python bench.py --config 4 --limit 134217728 --steps 1 --warmup 1 --no-e2e > $OUT/bench4.json 2> $OUT/bench4.err; echo "bench4 rc=$?" >> $OUT/summary.txt; cat $OUT/bench4.json ;;
     bench5) timeout 900 python bench.py --config 5 --steps 2 --warmup 1 --no-e2e > $OUT/bench5.json 2> $OUT/bench5.err; echo "bench5 rc=$?" >> $OUT/summary.txt; cat $OUT/bench5.json ;;
-    prof3) (cd /tmp && export KNZ_BWT_SPLIT=1 && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof3 -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-e2e > $GRAFT_REPO_ROOT/$OUT/prof3.log 2>&1); echo "prof3 rc=$?" >> $OUT/summary.txt
+    prof3) (cd /tmp && export KNZ_BWT_SPLIT=1 && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof3 -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-e2e --no-real > $GRAFT_REPO_ROOT/$OUT/prof3.log 2>&1); echo "prof3 rc=$?" >> $OUT/summary.txt
            f=$(find $OUT/prof3 -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && python tools/rocprof_csv_summary.py $f > $OUT/prof3_kernel_stats.txt && cp $f $OUT/prof3_kernel_stats.csv && head -30 $OUT/prof3_kernel_stats.txt ;;
     prof2) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof2 -- python $GRAFT_REPO_ROOT/bench.py --config 2 --steps 5 --warmup 2 --no-cpu --no-e2e > $GRAFT_REPO_ROOT/$OUT/prof2.log 2>&1); echo "prof2 rc=$?" >> $OUT/summary.txt
            f=$(find $OUT/prof2 -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && python tools/rocprof_csv_summary.py $f > $OUT/prof2_kernel_stats.txt && cp $f $OUT/prof2_kernel_stats.csv && head -20 $OUT/prof2_kernel_stats.txt ;;
-    pmc3) for c in FETCH_SIZE WRITE_SIZE; do (cd /tmp && export KNZ_BWT_SPLIT=1 && timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc3_$c -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu --no-e2e > $GRAFT_REPO_ROOT/$OUT/pmc3_$c.log 2>&1); echo "pmc3 $c rc=$?" >> $OUT/summary.txt; done
+    pmc3) for c in FETCH_SIZE WRITE_SIZE; do (cd /tmp && export KNZ_BWT_SPLIT=1 && timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc3_$c -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu --no-e2e --no-real > $GRAFT_REPO_ROOT/$OUT/pmc3_$c.log 2>&1); echo "pmc3 $c rc=$?" >> $OUT/summary.txt; done
           ff=$(find $OUT/pmc3_FETCH_SIZE -name '*counter_collection.csv' | head -1); fw=$(find $OUT/pmc3_WRITE_SIZE -name '*counter_collection.csv' | head -1)
           [ -n "$ff" ] && [ -n "$fw" ] && python tools/pmc_stage_summary.py $ff $fw 3 $OUT/pmc3_traffic.json $OUT/pmc3_traffic.txt && cat $OUT/pmc3_traffic.txt | head -40 ;;
-    trace3) (cd /tmp && export KNZ_BWT_SPLIT=1 && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/trace3 -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu --no-e2e > $GRAFT_REPO_ROOT/$OUT/trace3.log 2>&1); echo "trace3 rc=$?" >> $OUT/summary.txt
+    trace3) (cd /tmp && export KNZ_BWT_SPLIT=1 && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/trace3 -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu --no-e2e --no-real > $GRAFT_REPO_ROOT/$OUT/trace3.log 2>&1); echo "trace3 rc=$?" >> $OUT/summary.txt
            f=$(find $OUT/trace3 -name '*kernel_trace.csv' | head -1); [ -n "$f" ] && python tools/rocprof_trace_list.py $f 1 > $OUT/trace3_bwt_forward.txt && tail -3 $OUT/trace3_bwt_forward.txt ;;
     prof4) (cd /tmp && export KNZ_BWT_SPLIT=1 && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof4 -- python $GRAFT_REPO_ROOT/bench.py --config 4 --limit 134217728 --steps 1 --warmup 1 --no-cpu --no-e2e > $GRAFT_REPO_ROOT/$OUT/prof4.log 2>&1); echo "prof4 rc=$?" >> $OUT/summary.txt
            f=$(find $OUT/prof4 -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && python tools/rocprof_csv_summary.py $f > $OUT/prof4_kernel_stats.txt && cp $f $OUT/prof4_kernel_stats.csv && head -14 $OUT/prof4_kernel_stats.txt ;;
@@ -41,21 +41,21 @@ for s in "$@"; do
            for c in FETCH_SIZE WRITE_SIZE; do (cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/calib_$c -- $GRAFT_REPO_ROOT/tools/bin/membench pmc > /dev/null 2>&1); echo "calib $c rc=$?" >> $OUT/summary.txt; done
            ff=$(find $OUT/calib_FETCH_SIZE -name '*counter_collection.csv' | head -1); fw=$(find $OUT/calib_WRITE_SIZE -name '*counter_collection.csv' | head -1)
            [ -n "$ff" ] && [ -n "$fw" ] && python tools/pmc_calibration.py $ff $fw $OUT/membench.txt > $OUT/pmc_calibration.txt && head -24 $OUT/pmc_calibration.txt ;;
-    limits) for L in 33554432 58720256 109051904 211957760; do timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu --no-e2e --limit $L 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps({'blocks': d['config']['blocks'], 'bytes': d['config']['corpus_bytes'], 'ms_per_step': d['ms_per_step'], 'MBps': d['value'], 'enc_MBps': d['enc_MBps'], 'dec_MBps': d['dec_MBps']}))" >> $OUT/limits.jsonl; done; echo "limits rc=$?" >> $OUT/summary.txt; cat $OUT/limits.jsonl ;;
+    limits) for L in 33554432 58720256 109051904 211957760; do timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu --no-e2e --no-real --limit $L 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps({'blocks': d['config']['blocks'], 'bytes': d['config']['corpus_bytes'], 'ms_per_step': d['ms_per_step'], 'MBps': d['value'], 'enc_MBps': d['enc_MBps'], 'dec_MBps': d['dec_MBps']}))" >> $OUT/limits.jsonl; done; echo "limits rc=$?" >> $OUT/summary.txt; cat $OUT/limits.jsonl ;;
     issue) timeout 120 tools/bin/issuebench > $OUT/issue_rates.txt 2>&1; echo "issue rc=$?" >> $OUT/summary.txt; cat $OUT/issue_rates.txt ;;
     srtprobe) timeout 200 python tools/srt_probe.py 32 > $OUT/srt_probe.txt 2>&1; echo "srtprobe rc=$?" >> $OUT/summary.txt; tail -4 $OUT/srt_probe.txt ;;
     pmcx:*) # pmcx:<config>:<bytes or 0>: two counter passes of one configuration -> $OUT/pmc<config>_traffic.{json,txt}
           IFS=: read -r _ C LIM <<< "$s"; LARG=""; NB=211957760
           [ "$LIM" != "0" ] && [ -n "$LIM" ] && { LARG="--limit $LIM"; NB=$LIM; }
           [ "$C" = "4" ] && [ -z "$LARG" ] && NB=1000000000
-          for c in FETCH_SIZE WRITE_SIZE; do (cd /tmp && export KNZ_BWT_SPLIT=${PMC_SPLIT:-1} && timeout 1500 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc${C}_$c -- python $GRAFT_REPO_ROOT/bench.py --config $C $LARG --steps 1 --warmup 1 --reps 1 --no-cpu --no-e2e > $GRAFT_REPO_ROOT/$OUT/pmc${C}_$c.log 2>&1); echo "pmc$C $c rc=$?" >> $OUT/summary.txt; done
+          for c in FETCH_SIZE WRITE_SIZE; do (cd /tmp && export KNZ_BWT_SPLIT=${PMC_SPLIT:-1} && timeout 1500 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc${C}_$c -- python $GRAFT_REPO_ROOT/bench.py --config $C $LARG --steps 1 --warmup 1 --reps 1 --no-cpu --no-e2e --no-real > $GRAFT_REPO_ROOT/$OUT/pmc${C}_$c.log 2>&1); echo "pmc$C $c rc=$?" >> $OUT/summary.txt; done
           ff=$(find $OUT/pmc${C}_FETCH_SIZE -name '*counter_collection.csv' | head -1); fw=$(find $OUT/pmc${C}_WRITE_SIZE -name '*counter_collection.csv' | head -1)
           [ -n "$ff" ] && [ -n "$fw" ] && KNZ_PMC_NBYTES=$NB python tools/pmc_stage_summary.py $ff $fw $C $OUT/pmc${C}_traffic.json $OUT/pmc${C}_traffic.txt && head -16 $OUT/pmc${C}_traffic.txt ;;
     benchx:*) # benchx:<config>:<bytes or 0>:<steps>:<extra flags with + for spaces>
           IFS=: read -r _ C LIM ST EX <<< "$s"; LARG=""; [ "$LIM" != "0" ] && [ -n "$LIM" ] && LARG="--limit $LIM"
           timeout 1500 python bench.py --config $C $LARG --steps ${ST:-3} --warmup 1 ${EX//+/ } > $OUT/bench$C.json 2> $OUT/bench$C.err; echo "bench$C rc=$?" >> $OUT/summary.txt; cut -c1-400 $OUT/bench$C.json ;;
     profx:*) IFS=: read -r _ C LIM <<< "$s"; LARG=""; [ "$LIM" != "0" ] && [ -n "$LIM" ] && LARG="--limit $LIM"
-          (cd /tmp && export KNZ_BWT_SPLIT=1 && timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof$C -- python $GRAFT_REPO_ROOT/bench.py --config $C $LARG --steps 1 --warmup 1 --reps 1 --no-cpu --no-e2e > $GRAFT_REPO_ROOT/$OUT/prof$C.log 2>&1); echo "prof$C rc=$?" >> $OUT/summary.txt
+          (cd /tmp && export KNZ_BWT_SPLIT=1 && timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof$C -- python $GRAFT_REPO_ROOT/bench.py --config $C $LARG --steps 1 --warmup 1 --reps 1 --no-cpu --no-e2e --no-real > $GRAFT_REPO_ROOT/$OUT/prof$C.log 2>&1); echo "prof$C rc=$?" >> $OUT/summary.txt
           f=$(find $OUT/prof$C -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && python tools/rocprof_csv_summary.py $f > $OUT/prof${C}_kernel_stats.txt && cp $f $OUT/prof${C}_kernel_stats.csv && head -14 $OUT/prof${C}_kernel_stats.txt ;;
     cmd:*) echo "running custom: ${s#cmd:}"; timeout 600 bash -c "${s#cmd:}" < /dev/null > $OUT/custom.log 2>&1; echo "custom rc=$?" >> $OUT/summary.txt; tail -40 $OUT/custom.log ;;
     *) echo "unknown step: $s" ;;

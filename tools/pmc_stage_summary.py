@@ -25,7 +25,7 @@ from bench import stage_of  # noqa: E402
 OPEN = {"k_bwt_bases": "bwt_forward", "k_bwt_i_header": "bwt_inverse"}
 CLOSE = {"k_bwt_f_emit": "bwt_forward", "k_bwt_i_place": "bwt_inverse"}
 # read traffic of these kernels is random 4/8-byte gathers: FETCH_SIZE is not doubled (see above)
-GATHER = ("k_bwt_f_gather_small", "k_bwt_f_gather_desc", "k_bwt_i_walk", "k_bwt_f_large_keys", "k_bwt_f_run_table", "k_bwt_i_jump", "k_bwt_f_emit")
+GATHER = ("k_bwt_f_gather_small", "k_bwt_f_small_fused", "k_bwt_f_gather_desc", "k_bwt_i_walk", "k_bwt_f_large_keys", "k_bwt_f_run_table", "k_bwt_i_jump", "k_bwt_f_emit")
 
 
 def read_factor(name):
