@@ -446,6 +446,32 @@ def test_full_size_reference_stream_config4_six_blocks_of_copied_spans(hip):
     _full_case(hip, "config4:6blocks_repeats")
 
 
+def test_suffix_sort_label_paths_give_one_stream(hip):
+    """Round 6: the suffix sort keeps its labels as versioned 64-bit entries and refines small groups in one kernel (k_bwt_f_small_fused); blocks
+    above 256 MiB use 32-bit labels with separate key kernels (KNZ_BWT_PLAIN_LABELS), and KNZ_BWT_NO_FUSE keeps versioned labels with the
+    two kernels. The three paths must write the same bytes -- the reference's (tests/golden/golden_full.json, hard:repeats and hard:dna)."""
+    import json
+    hipapi = importlib.import_module("kanzi_amd.hipapi")
+    recs = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_full.json")))
+    L = hipapi.lib()
+    try:
+        for config in ("hard:repeats", "hard:dna", "hard:fibword"):
+            rec = [r for r in recs if r["config"] == config][0]
+            d = vectors.make(tuple(rec["input"]))
+            for knob in (None, "bwt_no_fuse", "bwt_plain_labels"):
+                if knob:
+                    assert L.knz_hip_tune(knob.encode(), 1) == 0
+                try:
+                    out, bits, hb = gpu_compress(hip, d, rec["transform"], rec["entropy"], rec["block"], orig_size=rec["orig_size"])
+                finally:
+                    if knob:
+                        L.knz_hip_tune(knob.encode(), 0)
+                assert len(out) == rec["out"]["len"] and hashlib.md5(out).hexdigest() == rec["out"]["md5"], (config, knob)
+    finally:
+        L.knz_hip_tune(b"bwt_no_fuse", 0)
+        L.knz_hip_tune(b"bwt_plain_labels", 0)
+
+
 _BIG_INPUT = {}
 
 
