@@ -249,26 +249,41 @@ __global__ __launch_bounds__(256) void k_bwt_f_bytehist(BwtView bv, const u32* _
     if (c) atomicAdd(&byteHist[(size_t)sgm * 256 + tid], c);
 }
 
-// Key length of round 0 from the order-0 entropy H of the batch: four symbols tell suffixes apart when 4 H bits reach the
+// Key length of round 0 from the order-0 entropy H of the blocks: four symbols tell suffixes apart when 4 H bits reach the
 // log2(block length) bits a position has (the mixed stand-in: H = 6.8); text (H = 4.1), DNA (2.0) leave most suffixes in groups then,
 // and a fifth symbol in the keys is cheaper than the doubling rounds those groups cost (measured on 212 MB of text at 8 MiB blocks:
 // suffix sort 33.3 -> 29.6 ms; on the stand-in 27.1 -> 27.3). The host caps the answer by what fits the key beside the position.
+// Round 6: H is the MEAN OF THE BLOCKS' entropies, weighted by their lengths, not the entropy of the batch's summed histogram -- a batch of
+// different files (shared objects at 6-7 bits beside headers and scripts at 4.3-4.9) has a flat sum (6.1 for the real-file corpus) although
+// most of its blocks are text-like: five symbols are worth 1.0 ms of 51.7 there. Batches of more than 64 blocks keep the summed histogram.
 __global__ __launch_bounds__(256) void k_bwt_f_choose_nsym(const u32* __restrict__ byteHist, int nBlocks, const u32* __restrict__ longest, u32* __restrict__ out)
 {
     __shared__ float part[256];
     __shared__ unsigned long long tot[256];
     const int tid = (int)threadIdx.x;
-    unsigned long long c = 0;
-    for (int b = 0; b < nBlocks; b++) c += byteHist[(size_t)b * 256 + tid];
-    tot[tid] = c;
-    __syncthreads();
-    unsigned long long all = 0;
-    for (int i = 0; i < 256; i++) all += tot[i];
-    part[tid] = (c && all) ? (float)((double)c / (double)all) * log2f((float)((double)all / (double)c)) : 0.0f;
-    __syncthreads();
+    float Hsum = 0.0f;                                   // (thread 0: sum of length x entropy over the blocks)
+    unsigned long long lenSum = 0;
+    const int nParts = nBlocks <= 64 ? nBlocks : 1;
+    for (int q = 0; q < nParts; q++) {
+        unsigned long long c = 0;
+        if (nParts == 1) { for (int b = 0; b < nBlocks; b++) c += byteHist[(size_t)b * 256 + tid]; }
+        else c = byteHist[(size_t)q * 256 + tid];
+        tot[tid] = c;
+        __syncthreads();
+        unsigned long long all = 0;
+        for (int i = 0; i < 256; i++) all += tot[i];
+        part[tid] = (c && all) ? (float)((double)c / (double)all) * log2f((float)((double)all / (double)c)) : 0.0f;
+        __syncthreads();
+        if (tid == 0) {
+            float H = 0.0f;
+            for (int i = 0; i < 256; i++) H += part[i];
+            Hsum += H * (float)all;
+            lenSum += all;
+        }
+        __syncthreads();
+    }
     if (tid == 0) {
-        float H = 0.0f;
-        for (int i = 0; i < 256; i++) H += part[i];
+        const float H = lenSum ? Hsum / (float)lenSum : 8.0f;
         const u32 n = longest[0] > 1 ? longest[0] : 2;
         out[0] = (4.0f * H < log2f((float)n)) ? 5u : 4u;
     }
