@@ -69,7 +69,7 @@ def test_corpus_generators_are_pinned():
 
 def test_radix_tile_size_is_one_value_across_the_library():
     """The radix-sort kernels (csrc/prims.hpp) are templates whose symbol names do not carry the tile size; two object files built with
-    different sizes once shared one kernel symbol and faulted on the device. The size is a header constant now and
+    different sizes once shared one kernel symbol and faulted on the device (DESIGN_HISTORY.md section 7, round 4). The size is a header constant now and
     every translation unit that includes the header emits rs_tile_tag<keys>(): exactly one such name may exist in the library, every
     object file with radix kernels must carry it, and every k_rs_* instantiation must have a single definition in the .so."""
     import glob

@@ -1,4 +1,4 @@
-"""Study for the LZ decoder plan: how deep is the dependency graph of the match copies?
+"""Study for the LZ decoder plan (DESIGN_HISTORY.md section 7): how deep is the dependency graph of the match copies?
 Level of a match = 1 + the highest level among the matches that wrote its source bytes (CPU only, uses the oracle)."""
 import sys, bisect
 sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "..", "tests"))

@@ -1,4 +1,4 @@
-"""Study for DESIGN.md section 7: SBRT forward (MTF, RANK, TIMESTAMP) has a closed form that is independent across
+"""Study for DESIGN_HISTORY.md section 7: SBRT forward (MTF, RANK, TIMESTAMP) has a closed form that is independent across
 positions -- the rank of c at i is the number of symbols whose (key, time of last update, -symbol) is larger, and
 keys/times depend only on each symbol's last two occurrences before i. Checked here against the oracle (CPU only)."""
 import sys
