@@ -233,9 +233,17 @@ static std::atomic<int>& bwt_part_min_knob()
     return v;
 }
 
+// ranges of a batch that knz_hip_decode_blocks runs side by side on streams of their own (KNZ_DEC_PARTS / knob "dec_parts"; decode_impl)
+static std::atomic<int>& dec_parts_knob()
+{
+    static std::atomic<int> v([] { const char* e = getenv("KNZ_DEC_PARTS"); const int x = e ? atoi(e) : 3; return x < 1 ? 1 : (x > 3 ? 3 : x); }());
+    return v;
+}
+
 int knz_hip_tune(const char* name, int value)
 {
     if (name == nullptr) return -1;
+    if (!strcmp(name, "dec_parts")) { dec_parts_knob().store(value < 1 ? 1 : (value > 3 ? 3 : value)); return 0; }
     if (!strcmp(name, "bwt_part_min")) { bwt_part_min_knob().store(value < 1 ? 1 : value); return 0; }
     if (!strcmp(name, "mtf_tile")) return mtft_tune(value);
     if (!strcmp(name, "mtf_chain")) return mtft_tune_chain(value);
@@ -438,13 +446,15 @@ struct SeqWs {
     u32* scratch;
 };
 
-static int seq_alloc(Ctx* c, int nBlocks, u64 S, bool needAB, size_t scratchU32, SeqWs* w)
+// (sfx: "" or the suffix of a decode lane -- the parts of a pipelined decode have workspaces of their own)
+static int seq_alloc(Ctx* c, int nBlocks, u64 S, bool needAB, size_t scratchU32, SeqWs* w, const char* sfx = "")
 {
     u8* base;
     const size_t nb = (size_t)nBlocks;
+    const std::string nSmall = std::string("seqSmall") + sfx, nA = std::string("xfA") + sfx, nB = std::string("xfB") + sfx, nScr = std::string("xfScratch") + sfx;
     // one slab for all small per-block arrays
     const size_t bytes = nb * (5 * 1 + 4 * 6 + 8 * 4) + 1024;
-    if (int r = ws_get(c, "seqSmall", bytes + 256, (void**)&base)) return r;
+    if (int r = ws_get(c, nSmall.c_str(), bytes + 256, (void**)&base)) return r;
     size_t off = 0;
     auto take = [&](size_t sz, size_t align) { off = (off + align - 1) & ~(align - 1); u8* p = base + off; off += sz; return p; };
     w->a.src = (const u8**)take(nb * 8, 16);
@@ -467,11 +477,11 @@ static int seq_alloc(Ctx* c, int nBlocks, u64 S, bool needAB, size_t scratchU32,
     w->S = S;
     w->A = w->B = nullptr;
     if (needAB) {
-        if (int r = ws_get(c, "xfA", (size_t)S * nb + 256, (void**)&w->A)) return r;
-        if (int r = ws_get(c, "xfB", (size_t)S * nb + 256, (void**)&w->B)) return r;
+        if (int r = ws_get(c, nA.c_str(), (size_t)S * nb + 256, (void**)&w->A)) return r;
+        if (int r = ws_get(c, nB.c_str(), (size_t)S * nb + 256, (void**)&w->B)) return r;
     }
     w->scratch = nullptr;
-    if (scratchU32) { if (int r = ws_get(c, "xfScratch", scratchU32 * 4 + 64, (void**)&w->scratch)) return r; }
+    if (scratchU32) { if (int r = ws_get(c, nScr.c_str(), scratchU32 * 4 + 64, (void**)&w->scratch)) return r; }
     return 0;
 }
 
@@ -582,7 +592,9 @@ static int run_forward_stage(Ctx* c, hipStream_t s, int t, const XfStage& st)
     return 0;
 }
 
-static int run_inverse_stage(Ctx* c, hipStream_t s, int t, const XfStage& st)
+// lane >= 0: one part of a pipelined decode (decode_impl): the BWT inverse of the part is not split further and uses the scratch and the
+// read-back area of split part `lane`
+static int run_inverse_stage(Ctx* c, hipStream_t s, int t, const XfStage& st, int lane = -1)
 {
     switch (t) {
     case KNZ_T_ZRLT: launch_zrlt_inverse(s, st); break;
@@ -614,13 +626,17 @@ static int run_inverse_stage(Ctx* c, hipStream_t s, int t, const XfStage& st)
         break;
     }
     case KNZ_T_BWT: {
-        if (const int parts = bwt_parts_wanted(c, st.nBlocks); parts > 1)
-            return bwt_in_parts(c, s, st, parts, [&](int nb) { return bwt_inverse_scratch_bytes(nb, st.maxLen, (size_t)nb * st.maxLen); },
-                                 [](hipStream_t q, const XfStage& h, void* sc, size_t bytes, u32* pin) { return launch_bwt_inverse(q, h, sc, bytes, pin); }, "BWT inverse", false);
+        if (lane < 0) {
+            if (const int parts = bwt_parts_wanted(c, st.nBlocks); parts > 1)
+                return bwt_in_parts(c, s, st, parts, [&](int nb) { return bwt_inverse_scratch_bytes(nb, st.maxLen, (size_t)nb * st.maxLen); },
+                                     [](hipStream_t q, const XfStage& h, void* sc, size_t bytes, u32* pin) { return launch_bwt_inverse(q, h, sc, bytes, pin); }, "BWT inverse", false);
+        }
+        static const char* const wsName[4] = { "bwtScratch", "bwtScratch2", "bwtScratch3", "bwtScratch4" };
+        const int k = lane < 0 ? 0 : (lane & 3);
         const size_t bytes = bwt_inverse_scratch_bytes(st.nBlocks, st.maxLen, (size_t)st.nBlocks * st.maxLen);
         void* sc;
-        if (int r = ws_get(c, "bwtScratch", bytes, &sc)) return r;
-        if (launch_bwt_inverse(s, st, sc, bytes, reinterpret_cast<u32*>(c->pinned)) != 0) return fail(c, -1, "BWT inverse failed: %s", hipGetErrorString(hipGetLastError()));
+        if (int r = ws_get(c, wsName[k], bytes, &sc)) return r;
+        if (launch_bwt_inverse(s, st, sc, bytes, reinterpret_cast<u32*>(c->pinned) + 32768 * k) != 0) return fail(c, -1, "BWT inverse failed: %s", hipGetErrorString(hipGetLastError()));
         break;
     }
     default: break;
@@ -920,61 +936,110 @@ static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_
     const u64 S = ((u64)required + 255) & ~255ull;
     const u32 maxPre = (u32)S;
     bool realStages = false;
-    size_t scratch = 0;
-    for (int i = 0; i < nTok; i++) if (tok[i] != KNZ_T_NONE) { realStages = true; const size_t q = stage_scratch_u32(tok[i], nBlocks, (u32)S, false); if (q > scratch) scratch = q; }
-    SeqWs w;
-    if (int r = seq_alloc(c, nBlocks, S, realStages, scratch, &w)) return r;
+    for (int i = 0; i < nTok; i++) if (tok[i] != KNZ_T_NONE) realStages = true;
     const int maxChunks = (int)((S + ENT_CHUNK - 1) / ENT_CHUNK);
-    const size_t nSlots = (size_t)nBlocks * maxChunks;
     const u64 outStride = framing ? bs : 0;
-
-    // entropy stage decodes into workspace A (or straight into d_out when no transform applies)
-    // with inverse stages the entropy decoder writes into the workspace (any valid preTransformLength fits);
-    // the room in the caller's buffer is enforced where the last inverse stage gets its capacity
-    launch_check_prelen(s, d_blocks, nBlocks, realStages ? maxPre : unit, realStages ? ~0ull : (u64)outCap, outStride);
     u32 realMask = 0;
     for (int i = 0; i < nTok; i++) if (tok[i] != KNZ_T_NONE) realMask |= 1u << (7 - i);
-    launch_seq_inv_entropy_dst(s, w.a, d_blocks, nBlocks, d_out, outStride, w.A, S, w.d_entDst, realMask, unit, (u64)outCap);
-    if (p->entropy_type == KNZ_E_ANS0) {
-        void* d_meta;
-        if (int r = ws_get(c, "ansDecChunks", ans0_dec_chunk_bytes() * nSlots, &d_meta)) return r;
-        launch_ans0_decode(s, src, d_blocks, nBlocks, maxChunks, d_meta, w.d_entDst);
-    } else if (p->entropy_type == KNZ_E_ANS1) {
-        const int chunksPerBlock = (int)((S + ANS1_CHUNK - 1) / ANS1_CHUNK);
-        const size_t nCh = (size_t)nBlocks * chunksPerBlock;
-        Ans1DecWs aw;
-        if (int r = ws_get(c, "ans1Meta", ans1_meta_bytes(nCh), &aw.meta)) return r;
-        if (int r = ws_get(c, "ans1SlotTab", ans1_slottab_bytes(nCh), (void**)&aw.slotTab)) return r;
-        launch_ans1_decode(s, src, d_blocks, nBlocks, chunksPerBlock, aw, w.d_entDst);
-    } else if (p->entropy_type == KNZ_E_HUFFMAN) {
-        void* d_meta;
-        if (int r = ws_get(c, "hufDecChunks", huffman_dec_chunk_bytes() * nSlots, &d_meta)) return r;
-        launch_huffman_decode(s, src, d_blocks, nBlocks, maxChunks, d_meta, w.d_entDst, bsVersion);
-    } else if (p->entropy_type == KNZ_E_FPAQ) {
-        launch_fpaq_decode(s, src, d_blocks, nBlocks, w.d_entDst);
-    } else {
-        launch_none_decode(s, src, d_blocks, nBlocks, w.d_entDst);
-    }
-    // inverse transforms, last stage first (TransformSequence.hpp:197-224)
-    if (realStages) {
-        const u32 capFinal = framing ? bs : (u32)p->jobs;           // per-stage API passes its capacity in p->jobs
-        const u32 blkLenModel = std::max(bs + 512u, bs + (bs >> 4));
-        const u32 capMid = framing ? (u32)std::min<u64>(S, blkLenModel) : (u32)p->jobs;
-        for (int i = nTok - 1; i >= 0; i--) {
-            if (tok[i] == KNZ_T_NONE) continue;
-            launch_seq_inv_prepare(s, w.a, d_blocks, nBlocks, i, d_out, outStride, w.A, w.B, S, capMid, capFinal, realMask, framing ? (u64)outCap : ~0ull);
-            XfStage st;
-            st.src = w.a.src; st.dst = w.a.dst; st.len = w.a.alen; st.cap = w.a.cap; st.ok = w.a.ok; st.newLen = w.a.newLen;
-            st.nBlocks = nBlocks; st.maxLen = (u32)S; st.scratchU32 = w.scratch; st.entropyType = p->entropy_type; st.bsVersion = bsVersion;
-            st.maxCap = std::max(capMid, capFinal);
-            if (int r = run_inverse_stage(c, s, tok[i], st)) return r;
-            launch_seq_inv_commit(s, w.a, d_blocks, nBlocks, i, tok[i]);
+
+    // One range of the batch's blocks through entropy decoder and inverse chain, on stream `sp` with the workspaces of lane `lane` (-1: the
+    // whole batch on the context's stream, the BWT inverse split into parts as before). The blocks are independent and the walk above has
+    // left every block's place in the stream in d_blocks, so a range is a smaller decode of its own: its entries of d_blocks, its part of
+    // the caller's output.
+    auto issue = [&](int lane, int b0, int nb, hipStream_t sp) -> int {
+        const std::string sfxS = lane <= 0 ? std::string() : std::string("#") + std::to_string(lane);
+        const char* sfx = sfxS.c_str();
+        auto wsName = [&](const char* base) { return std::string(base) + sfx; };
+        DecBlock* blk = d_blocks + b0;
+        uint8_t* out = d_out + (size_t)b0 * outStride;
+        const u64 room = (u64)outCap - (u64)b0 * outStride;
+        size_t scratch = 0;
+        for (int i = 0; i < nTok; i++) if (tok[i] != KNZ_T_NONE) { const size_t q = stage_scratch_u32(tok[i], nb, (u32)S, false); if (q > scratch) scratch = q; }
+        SeqWs w;
+        if (int r = seq_alloc(c, nb, S, realStages, scratch, &w, sfx)) return r;
+        const size_t nSlots = (size_t)nb * maxChunks;
+        // entropy stage decodes into workspace A (or straight into the output when no transform applies)
+        // with inverse stages the entropy decoder writes into the workspace (any valid preTransformLength fits);
+        // the room in the caller's buffer is enforced where the last inverse stage gets its capacity
+        launch_check_prelen(sp, blk, nb, realStages ? maxPre : unit, realStages ? ~0ull : room, outStride);
+        launch_seq_inv_entropy_dst(sp, w.a, blk, nb, out, outStride, w.A, S, w.d_entDst, realMask, unit, room);
+        if (p->entropy_type == KNZ_E_ANS0) {
+            void* d_meta;
+            if (int r = ws_get(c, wsName("ansDecChunks").c_str(), ans0_dec_chunk_bytes() * nSlots, &d_meta)) return r;
+            launch_ans0_decode(sp, src, blk, nb, maxChunks, d_meta, w.d_entDst);
+        } else if (p->entropy_type == KNZ_E_ANS1) {
+            const int chunksPerBlock = (int)((S + ANS1_CHUNK - 1) / ANS1_CHUNK);
+            const size_t nCh = (size_t)nb * chunksPerBlock;
+            Ans1DecWs aw;
+            if (int r = ws_get(c, wsName("ans1Meta").c_str(), ans1_meta_bytes(nCh), &aw.meta)) return r;
+            if (int r = ws_get(c, wsName("ans1SlotTab").c_str(), ans1_slottab_bytes(nCh), (void**)&aw.slotTab)) return r;
+            launch_ans1_decode(sp, src, blk, nb, chunksPerBlock, aw, w.d_entDst);
+        } else if (p->entropy_type == KNZ_E_HUFFMAN) {
+            void* d_meta;
+            if (int r = ws_get(c, wsName("hufDecChunks").c_str(), huffman_dec_chunk_bytes() * nSlots, &d_meta)) return r;
+            launch_huffman_decode(sp, src, blk, nb, maxChunks, d_meta, w.d_entDst, bsVersion);
+        } else if (p->entropy_type == KNZ_E_FPAQ) {
+            launch_fpaq_decode(sp, src, blk, nb, w.d_entDst);
+        } else {
+            launch_none_decode(sp, src, blk, nb, w.d_entDst);
         }
+        // inverse transforms, last stage first (TransformSequence.hpp:197-224)
+        if (realStages) {
+            const u32 capFinal = framing ? bs : (u32)p->jobs;           // per-stage API passes its capacity in p->jobs
+            const u32 blkLenModel = std::max(bs + 512u, bs + (bs >> 4));
+            const u32 capMid = framing ? (u32)std::min<u64>(S, blkLenModel) : (u32)p->jobs;
+            for (int i = nTok - 1; i >= 0; i--) {
+                if (tok[i] == KNZ_T_NONE) continue;
+                launch_seq_inv_prepare(sp, w.a, blk, nb, i, out, outStride, w.A, w.B, S, capMid, capFinal, realMask, framing ? room : ~0ull);
+                XfStage st;
+                st.src = w.a.src; st.dst = w.a.dst; st.len = w.a.alen; st.cap = w.a.cap; st.ok = w.a.ok; st.newLen = w.a.newLen;
+                st.nBlocks = nb; st.maxLen = (u32)S; st.scratchU32 = w.scratch; st.entropyType = p->entropy_type; st.bsVersion = bsVersion;
+                st.maxCap = std::max(capMid, capFinal);
+                if (int r = run_inverse_stage(c, sp, tok[i], st, lane)) return r;
+                launch_seq_inv_commit(sp, w.a, blk, nb, i, tok[i]);
+            }
+        }
+        if (p->checksum_bits && framing && nHosted == 0) {
+            u64* d_sums;
+            if (int r = ws_get(c, wsName("sums").c_str(), sizeof(u64) * nb, (void**)&d_sums)) return r;
+            launch_verify_checksums(sp, blk, nb, p->checksum_bits, out, outStride, w.d_viewPtr, w.a.alen, d_sums);
+        }
+        return 0;
+    };
+
+    // Up to three ranges side by side (knob dec_parts / KNZ_DEC_PARTS, default 3, from 4 blocks per range on; chains with inverse stages only; not
+    // while per-kernel timing is on, not for chains with an LZ stage, whose scratch has one name): the entropy decoders are chains with a few
+    // waves per CU and the row ranking of the BWT inverse is latency as well -- they run under the other ranges' bandwidth-bound kernels instead
+    // of in front of them. Measured (26 blocks of 8 MiB, 1 / 2 / 3 ranges): decode 9.96 / 9.76 / 9.63 ms on the stand-in, 10.49 / 10.17 / 9.86 on the
+    // real files; entropy-only chains (configs 1, 2) lose 2-5 % to the extra launches and stay one range.
+    int lanes = 1;
+    {
+        bool lz = false;
+        for (int i = 0; i < nTok; i++) if (tok[i] == KNZ_T_LZ || tok[i] == KNZ_T_LZX) lz = true;
+        const int want = dec_parts_knob().load();
+        if (framing && realStages && !c->profiling && !lz && nHosted == 0 && want > 1 && nBlocks >= 4 * want) lanes = want > 3 ? 3 : want;
+        else if (framing && realStages && !c->profiling && !lz && nHosted == 0 && want > 1 && nBlocks >= 8) lanes = 2;
     }
-    if (p->checksum_bits && framing && nHosted == 0) {
-        u64* d_sums;
-        if (int r = ws_get(c, "sums", sizeof(u64) * nBlocks, (void**)&d_sums)) return r;
-        launch_verify_checksums(s, d_blocks, nBlocks, p->checksum_bits, d_out, outStride, w.d_viewPtr, w.a.alen, d_sums);
+    if (lanes == 1) {
+        if (int r = issue(-1, 0, nBlocks, s)) return r;
+    } else {
+        for (int k = 1; k < lanes; k++)
+            if (c->stream2[k - 1] == nullptr) HIPCHK(c, hipStreamCreateWithFlags(&c->stream2[k - 1], hipStreamNonBlocking));
+        if (c->evFork == nullptr) {
+            HIPCHK(c, hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
+            for (int k = 0; k < 3; k++) HIPCHK(c, hipEventCreateWithFlags(&c->evJoin[k], hipEventDisableTiming));
+        }
+        HIPCHK(c, hipEventRecord(c->evFork, s));
+        int first = 0, rc = 0;
+        for (int k = 0; k < lanes; k++) {
+            const int nb = nBlocks / lanes + (k < nBlocks % lanes ? 1 : 0);
+            hipStream_t sp = k ? c->stream2[k - 1] : s;
+            if (k) HIPCHK(c, hipStreamWaitEvent(sp, c->evFork, 0));
+            if (rc == 0) rc = issue(k, first, nb, sp);
+            first += nb;
+            if (k) { HIPCHK(c, hipEventRecord(c->evJoin[k - 1], sp)); HIPCHK(c, hipStreamWaitEvent(s, c->evJoin[k - 1], 0)); }
+        }
+        if (rc) { hipStreamSynchronize(s); return rc; }
     }
     HIPCHK(c, hipGetLastError());
     // results

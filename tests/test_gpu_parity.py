@@ -446,6 +446,32 @@ def test_full_size_reference_stream_config4_six_blocks_of_copied_spans(hip):
     _full_case(hip, "config4:6blocks_repeats")
 
 
+def test_decode_in_ranges_side_by_side(hip, oracle):
+    """knz_hip_decode_blocks runs a batch of 8 or more blocks with inverse stages as two or three block ranges on streams of their own (knob
+    dec_parts, csrc/api.hip decode_impl): every range is a smaller decode with its own workspaces. Whatever the number of ranges, the output is
+    the input -- chains with BWT, SRT, RLT, checksums of both widths, a short last block, and a damaged block in the last range reported."""
+    hipapi = importlib.import_module("kanzi_amd.hipapi")
+    L = hipapi.lib()
+    d = vectors.make(("mixed", 17 * 65536 + 12345, 41))
+    try:
+        for t, e, bs, ck in [("BWT+MTFT+ZRLT", "ANS0", 65536, 0), ("BWT+SRT+ZRLT", "FPAQ", 65536, 32), ("RLT", "HUFFMAN", 65536, 64), ("BWT", "ANS1", 131072, 0)]:
+            rc, enc = oracle.compress(d, t, e, bs, checksum=ck, headerless=1)
+            assert rc == 0
+            for parts in (1, 2, 3):
+                assert L.knz_hip_tune(b"dec_parts", parts) == 0
+                assert gpu_decompress(hip, enc, t, e, bs, len(d), 0, checksum=ck) == d, (t, e, parts)
+        # a flipped bit near the end of the stream: the range that holds the block reports it
+        t, e, bs, ck = "BWT+MTFT+ZRLT", "ANS0", 65536, 32
+        rc, enc = oracle.compress(d, t, e, bs, checksum=ck, headerless=1)
+        bad = bytearray(enc); bad[len(bad) - 3000] ^= 0x10
+        for parts in (1, 3):
+            L.knz_hip_tune(b"dec_parts", parts)
+            with pytest.raises(hipapi.KnzError):
+                gpu_decompress(hip, bytes(bad), t, e, bs, len(d), 0, checksum=ck)
+    finally:
+        L.knz_hip_tune(b"dec_parts", 3)
+
+
 def test_suffix_sort_label_paths_give_one_stream(hip):
     """Round 6: the suffix sort keeps its labels as versioned 64-bit entries and refines small groups in one kernel (k_bwt_f_small_fused); blocks
     above 256 MiB use 32-bit labels with separate key kernels (KNZ_BWT_PLAIN_LABELS), and KNZ_BWT_NO_FUSE keeps versioned labels with the
