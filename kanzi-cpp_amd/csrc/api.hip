@@ -1007,7 +1007,8 @@ static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_
         return 0;
     };
 
-    // Up to three ranges side by side (knob dec_parts / KNZ_DEC_PARTS, default 3, from 4 blocks per range on; chains with inverse stages only; not
+    // Up to three ranges side by side (knob dec_parts / KNZ_DEC_PARTS, default 3, at least KNZ_DEC_PART_MIN = 2 blocks per range -- 7 blocks: decode
+    // 4.42 -> 4.04 ms; 4 blocks: no difference --; chains with inverse stages only; not
     // while per-kernel timing is on, not for chains with an LZ stage, whose scratch has one name): the entropy decoders are chains with a few
     // waves per CU and the row ranking of the BWT inverse is latency as well -- they run under the other ranges' bandwidth-bound kernels instead
     // of in front of them. Measured (26 blocks of 8 MiB, 1 / 2 / 3 ranges): decode 9.96 / 9.76 / 9.63 ms on the stand-in, 10.49 / 10.17 / 9.86 on the
@@ -1017,8 +1018,11 @@ static int decode_impl(Ctx* c, const knz_params* p, const uint8_t* d_in, uint64_
         bool lz = false;
         for (int i = 0; i < nTok; i++) if (tok[i] == KNZ_T_LZ || tok[i] == KNZ_T_LZX) lz = true;
         const int want = dec_parts_knob().load();
-        if (framing && realStages && !c->profiling && !lz && nHosted == 0 && want > 1 && nBlocks >= 4 * want) lanes = want > 3 ? 3 : want;
-        else if (framing && realStages && !c->profiling && !lz && nHosted == 0 && want > 1 && nBlocks >= 8) lanes = 2;
+        static const int least = [] { const char* e = getenv("KNZ_DEC_PART_MIN"); const int x = e ? atoi(e) : 2; return x < 1 ? 1 : x; }();      // fewest blocks per range
+        if (framing && realStages && !c->profiling && !lz && nHosted == 0 && want > 1) {
+            lanes = want > 3 ? 3 : want;
+            while (lanes > 1 && nBlocks < least * lanes) lanes--;
+        }
     }
     if (lanes == 1) {
         if (int r = issue(-1, 0, nBlocks, s)) return r;

@@ -448,7 +448,7 @@ def test_full_size_reference_stream_config4_six_blocks_of_copied_spans(hip):
 
 def test_decode_in_ranges_side_by_side(hip, oracle):
     """knz_hip_decode_blocks runs a batch of 8 or more blocks with inverse stages as two or three block ranges on streams of their own (knob
-    dec_parts, csrc/api.hip decode_impl): every range is a smaller decode with its own workspaces. Whatever the number of ranges, the output is
+    dec_parts, csrc/api.hip decode_impl; at least two blocks per range): every range is a smaller decode with its own workspaces. Whatever the number of ranges, the output is
     the input -- chains with BWT, SRT, RLT, checksums of both widths, a short last block, and a damaged block in the last range reported."""
     hipapi = importlib.import_module("kanzi_amd.hipapi")
     L = hipapi.lib()
