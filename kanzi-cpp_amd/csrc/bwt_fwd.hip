@@ -184,6 +184,7 @@ __global__ void k_bwt_bases(BwtView v, u32* __restrict__ base, u8* __restrict__ 
 // sort is stable -- so among equal padded keys they come first, shortest first, which is their place ("a proper prefix sorts
 // first"); the flag kernel makes each of them a group of its own.
 struct TextSrc {
+    static constexpr bool STAGED = true;
     const u8* const* src;
     int P, pbits, shift;
     __device__ __forceinline__ u32 pos_of(u32 n, u32 i) const
@@ -196,6 +197,42 @@ struct TextSrc {
         const u8* t = src[sgm];
         const u32 pos = pos_of(n, i);
         const u64 v = text8(t, pos, n);
+        u64 kb = __builtin_bswap64(v) >> (64 - 8 * P);
+        const u32 left = n - pos;
+        if (left < (u32)P) kb &= ~0ull << (8 * ((u32)P - left));
+        return (kb << pbits) | (u64)pos;
+    }
+    // The tile's stretch of the text in LDS (round 6; the pass took 1.57 ms against 0.97 for a pass over keys: a key was three dword loads
+    // that overlap the neighbours'). Elements tile0 .. tile0 + RS_TILE - 1 are consecutive positions from pos0 on (the short suffixes in
+    // front of the first tile keep the loads above): the dwords from the one that holds pos0 to the one behind pos0 + RS_TILE + 7, zero from
+    // the block's end on, which is what text8 delivers there. A block whose text is not dword aligned is not staged.
+    __device__ __forceinline__ bool stage(int sgm, u32 n, u32 tile0, u32* lds, int tid) const
+    {
+        const u8* t = src[sgm];
+        if (reinterpret_cast<uintptr_t>(t) & 3) return false;
+        const u32 nShort = (u32)(P - 1) < n ? (u32)(P - 1) : n;
+        const u32 pos0 = (tile0 > nShort ? tile0 : nShort) - nShort;
+        const u32 a0 = pos0 & ~3u;
+        constexpr u32 NW = (prims::RS_TILE + 8u + 3u) / 4u + 2u;
+        for (u32 w = (u32)tid; w < NW; w += (u32)prims::RS_THREADS) {
+            const u32 q = a0 + 4u * w;
+            u32 x = 0;
+            if (q + 4u <= n) x = ldg<u32>(t + q);
+            else for (u32 j = 0; j < 4u; j++) if (q + j < n) x |= (u32)ldg<u8>(t + q + j) << (8u * j);
+            lds[w] = x;
+        }
+        return true;
+    }
+    __device__ __forceinline__ u64 load_staged(int sgm, u32 b0, u32 n, u32 i, const u32* lds, u32 tile0) const
+    {
+        const u32 nShort = (u32)(P - 1) < n ? (u32)(P - 1) : n;
+        if (i < nShort) return load(sgm, b0, n, i);
+        const u32 pos0 = (tile0 > nShort ? tile0 : nShort) - nShort;
+        const u32 pos = i - nShort;
+        const u32 o = pos - (pos0 & ~3u);
+        const u32 w = o >> 2, sh = (o & 3u) * 8u;
+        const u64 lo = (u64)lds[w] | ((u64)lds[w + 1] << 32);
+        const u64 v = sh ? ((lo >> sh) | ((u64)lds[w + 2] << (64u - sh))) : lo;
         u64 kb = __builtin_bswap64(v) >> (64 - 8 * P);
         const u32 left = n - pos;
         if (left < (u32)P) kb &= ~0ull << (8 * ((u32)P - left));
@@ -215,18 +252,21 @@ struct TextSrc {
 // (k_bwt_f_r0_counts; prims::k_rs_hist_all would build every key to count its bytes).
 __global__ __launch_bounds__(256) void k_bwt_f_bytehist(BwtView bv, const u32* __restrict__ base, u32* __restrict__ byteHist)
 {
-    __shared__ u32 cnt[4][256];
+    // four counter sets per wave (lane & 3 picks one; 257 words apart so that equal symbols of different sets fall into different banks):
+    // lanes that show the same symbol in one step serialise on its counter, and text shows its few frequent symbols in most steps
+    __shared__ u32 cnt[4][4][257];
     const int sgm = blockIdx.y;
     const u32 n = base[sgm + 1] - base[sgm];
     if (n == 0) return;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int q = tid; q < 4 * 256; q += 256) (&cnt[0][0])[q] = 0;
+    for (int q = tid; q < 4 * 4 * 257; q += 256) (&cnt[0][0][0])[q] = 0;
     __syncthreads();
     const u8* t = bv.src[sgm];
     const u32 per = ((n + gridDim.x - 1) / gridDim.x + 15u) & ~15u;
     const u32 lo = blockIdx.x * per, hi = (lo + per < n) ? lo + per : n;
     // 16 bytes per lane and step (the block's text is 16-byte aligned or the slow path below takes it)
     const bool al = (reinterpret_cast<uintptr_t>(t) & 15) == 0;
+    u32* mine = cnt[wave][lane & 3];
     for (u32 i0 = lo; i0 < hi; i0 += 16u * 256u) {                 // (uniform trip count: the row ballots want whole waves)
         const u32 i = i0 + 16u * (u32)tid;
         u32 wds[4] = { 0, 0, 0, 0 };
@@ -239,13 +279,14 @@ __global__ __launch_bounds__(256) void k_bwt_f_bytehist(BwtView bv, const u32* _
             const u32 dg = (wds[j >> 2] >> (8 * (j & 3))) & 255u;
             const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)dg);
             const unsigned long long va = __ballot(valid);
-            if (__ballot(valid && dg != d0) == 0) { if (lane == 0 && va) cnt[wave][d0] += (u32)__popcll(va); }
-            else if (valid) atomicAdd(&cnt[wave][dg], 1u);
+            if (__ballot(valid && dg != d0) == 0) { if (lane == 0 && va) mine[d0] += (u32)__popcll(va); }
+            else if (valid) atomicAdd(&mine[dg], 1u);
             KNZ_WAVE_ORDER();
         }
     }
     __syncthreads();
-    const u32 c = cnt[0][tid] + cnt[1][tid] + cnt[2][tid] + cnt[3][tid];
+    u32 c = 0;
+    for (int w = 0; w < 4; w++) for (int q = 0; q < 4; q++) c += cnt[w][q][tid];
     if (c) atomicAdd(&byteHist[(size_t)sgm * 256 + tid], c);
 }
 

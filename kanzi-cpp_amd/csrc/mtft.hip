@@ -322,8 +322,45 @@ __global__ __launch_bounds__(64) void k_mtf_f_rank_par(XfView v, int perTiles, c
     __syncthreads();
     const u64 below = lane ? (~0ull >> (64 - lane)) : 0ull;
     const u64 above = (lane == 63) ? 0ull : (~0ull << (lane + 1));
-    for (u32 k = 0; k < cnt; k += 64) {
-        const bool valid = k + (u32)lane < cnt;
+    // Run heads only (round 6). A byte that repeats its predecessor has rank 0 and leaves the list alone, so the ranks of a tile are the ranks
+    // of its RUN HEADS (bytes that differ from the byte in front of them; the tile's first byte counts as one) with zeros in between -- and
+    // behind a BWT seven bytes in ten are no heads. Lane c keeps the head flags of chunk c (a tile has at most 64 chunks); the heads are packed
+    // to the front of the tile in place (a head never moves up), ranked by the chunk loop below as a tile of nH bytes, and spread out again
+    // from the back. A tile with few repeats (under one byte in eight) is ranked as it stands.
+    u64 headMask = 0;
+    u32 headBase = 0;
+    u32 cntR = cnt;
+    {
+        u32 carry = 0x100u;
+        for (u32 k = 0, c = 0; k < cnt; k += 64, c++) {
+            const bool valid = k + (u32)lane < cnt;
+            const u32 bv = valid ? (u32)tileB[k + (u32)lane] : 0x200u;
+            u32 pb = (u32)__shfl_up((int)bv, 1u, 64);
+            if (lane == 0) pb = carry;
+            const u64 m = __ballot(valid && bv != pb);
+            if (lane == (int)c) headMask = m;
+            carry = (u32)__builtin_amdgcn_readlane((int)bv, 63);
+        }
+        const u32 mine = mtf_popc64(headMask);
+        const u32 incl = wave_incl_scan(mine);
+        headBase = incl - mine;
+        const u32 nH = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        if (nH * 8u <= cnt * 7u) {
+            for (u32 k = 0, c = 0; k < cnt; k += 64, c++) {
+                const u64 m = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(headMask >> 32), (int)c) << 32) | (u64)(u32)__builtin_amdgcn_readlane((int)(u32)headMask, (int)c);
+                const u32 base = (u32)__builtin_amdgcn_readlane((int)headBase, (int)c);
+                const bool head = (m >> lane) & 1ull;
+                const u32 bv = head ? (u32)tileB[k + (u32)lane] : 0u;
+                KNZ_WAVE_ORDER();                        // (every lane has read its byte before one is overwritten)
+                if (head) tileB[base + mtf_popc64(m & below)] = (u8)bv;
+            }
+            cntR = nH;
+            __syncthreads();
+        }
+    }
+    const bool packed = cntR != cnt;
+    for (u32 k = 0; k < cntR; k += 64) {
+        const bool valid = k + (u32)lane < cntR;
         const u32 c = valid ? (u32)tileB[k + (u32)lane] : 0u;
         u64 peers = __ballot(valid);
 #pragma unroll
@@ -400,6 +437,21 @@ __global__ __launch_bounds__(64) void k_mtf_f_rank_par(XfView v, int perTiles, c
         __syncthreads();
     }
     __syncthreads();
+    if (packed) {
+        // the ranks of the heads back to their places, last chunk first: chunk c reads tile bytes below 64 c + 64 and writes [64 c, 64 c + 64),
+        // the chunks in front of it read below 64 c
+        for (int c = (int)((cnt + 63u) / 64u) - 1; c >= 0; c--) {
+            const u64 m = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(headMask >> 32), c) << 32) | (u64)(u32)__builtin_amdgcn_readlane((int)(u32)headMask, c);
+            const u32 base = (u32)__builtin_amdgcn_readlane((int)headBase, c);
+            const bool head = (m >> lane) & 1ull;
+            u32 r = 0;
+            if (head) r = (u32)tileB[base + mtf_popc64(m & below)];
+            KNZ_WAVE_ORDER();
+            if (64u * (u32)c + (u32)lane < cnt) tileB[64u * (u32)c + (u32)lane] = (u8)r;
+            KNZ_WAVE_ORDER();
+        }
+        __syncthreads();
+    }
     if (al && (cnt & 3) == 0) { for (u32 q = (u32)lane; q < cnt / 4; q += 64) reinterpret_cast<u32*>(dst)[q] = tileW[q]; }
     else { for (u32 q = (u32)lane; q < cnt; q += 64) dst[q] = tileB[q]; }
 }
@@ -444,14 +496,25 @@ __global__ __launch_bounds__(64) void k_mtf_i_symbolic(XfView v, int perTiles, u
         u32 inr[MT / 256], outr[MT / 256];
 #pragma unroll
         for (int t = 0; t < (int)(MT / 256); t++) inr[t] = reinterpret_cast<const u32*>(src)[64 * t + lane];
+        // Only the words that hold a rank other than 0 walk the chain (round 6: behind a BWT two words in three are four zeros, and each cost
+        // the chain a readlane, a compare and a select); a word of zeros repeats the front as it stood, which is the last id of the nearest
+        // word in front of it that went through the chain, or the front the row began with.
+        const u64 belowL = lane ? (~0ull >> (64 - lane)) : 0ull;
 #pragma unroll
         for (int t = 0; t < (int)(MT / 256); t++) {
+            const u32 x = inr[t];
+            const u64 nz = __ballot(x != 0);
+            const u32 frontIn = front;
             u32 acc = 0;
-            for (int l = 0; l < 64; l++) {
-                const u32 o = ids4((u32)__builtin_amdgcn_readlane((int)inr[t], l));
+            for (u64 m = nz; m != 0; m &= m - 1) {
+                const int l = MTF_CTZ64(m);
+                const u32 o = ids4((u32)__builtin_amdgcn_readlane((int)x, l));
                 acc = (lane == l) ? o : acc;
             }
-            outr[t] = acc;
+            const u64 bel = nz & belowL;
+            const int from = bel ? 63 - __clzll((long long)bel) : 0;
+            const u32 prevTop = (u32)__shfl((int)acc, from, 64) >> 24;
+            outr[t] = (x != 0) ? acc : (bel ? prevTop : frontIn) * 0x01010101u;
         }
 #pragma unroll
         for (int t = 0; t < (int)(MT / 256); t++) reinterpret_cast<u32*>(dst)[64 * t + lane] = outr[t];

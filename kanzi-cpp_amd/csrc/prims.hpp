@@ -228,8 +228,12 @@ static __global__ void k_rs_layout(RsLayout L)
 // Source of a pass: element i of segment sgm (which starts at b0 and has len elements) as a key, the digit of a key, and the
 // digit of element i alone (what the counting kernel needs). The functor may read anything: a key array, or the text for the
 // first pass of the suffix sort.
+// STAGED: the source wants the tile's input staged in LDS first (stage() by the whole workgroup, then load_staged() per element).
 template <class KEY> struct DigitOfKey {
+    static constexpr bool STAGED = false;
     const KEY* keys; int shift; u32 mask;
+    __device__ __forceinline__ bool stage(int, u32, u32, u32*, int) const { return false; }
+    __device__ __forceinline__ KEY load_staged(int, u32, u32, u32, const u32*, u32) const { return (KEY)0; }
     __device__ __forceinline__ KEY load(int, u32 b0, u32, u32 i) const { return keys[b0 + i]; }
     __device__ __forceinline__ u32 digit(KEY k) const { return (u32)(k >> shift) & mask; }
     __device__ __forceinline__ u32 digit_at(int, u32 b0, u32, u32 i) const { return (u32)(keys[b0 + i] >> shift) & mask; }
@@ -476,11 +480,15 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_onesweep(SRC src, const u32* 
     const u32 t = sTicket;
     if (t >= nT) return;
     KEY key[16]; u32 val[16]; u32 dg[16], pos[16]; bool valid[16];
+    // (a staged source borrows sK, which takes the keys only behind the next barrier but one)
+    bool staged = false;
+    if (SRC::STAGED) { staged = src.stage(sgm, len, t * RS_TILE, reinterpret_cast<u32*>(sK), tid); __syncthreads(); }
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const u32 i = t * RS_TILE + (u32)wave * 1024u + (u32)r * 64u + (u32)lane;
         valid[r] = i < len;
-        key[r] = valid[r] ? src.load(sgm, b0, len, i) : (KEY)0;
+        if (SRC::STAGED && staged) key[r] = valid[r] ? src.load_staged(sgm, b0, len, i, reinterpret_cast<const u32*>(sK), t * RS_TILE) : (KEY)0;
+        else key[r] = valid[r] ? src.load(sgm, b0, len, i) : (KEY)0;
         if (HAS_VAL) val[r] = valid[r] ? vin[b0 + i] : 0u;
         dg[r] = valid[r] ? src.digit(key[r]) : 0u;
     }

@@ -218,6 +218,14 @@ def test_mtft_kernels_emulated(tmp_path):
     # period), all 256 symbols in descending order, a block that ends inside a chunk
     blocks += [bytes(range(64)) * 200, b"z" * 5000, b"xy" * 3000, bytes(list(range(65)) * 130), bytes(range(255, -1, -1)) * 20,
                rng.integers(0, 256, 64 * 7 + 13, dtype=np.uint8).tobytes(), rng.integers(0, 8, 4096 * 2 + 63, dtype=np.uint8).tobytes()]
+    # round 6: the forward kernel ranks run heads only (packs them to the front of the tile, spreads the ranks out again): what a BWT leaves
+    # behind (long runs, few heads), tiles just under and over the one-in-eight threshold, runs that cross chunk and tile borders
+    o = knzlib.Oracle()
+    bw = o.forward("BWT", c.text(70000, 3))[1]
+    assert len(bw) >= 70000
+    blocks += [bytes(bw), b"".join(bytes([rng.integers(0, 256)]) * int(rng.integers(1, 40)) for _ in range(2000)),
+               b"".join(bytes([i & 255]) * 8 for i in range(1024)), b"".join(bytes([i & 255]) * 9 for i in range(1024)),
+               b"q" * 63 + b"r" * 65 + b"q" * 4096 + b"s" * 4095 + b"t", bytes(4096) + b"\x01" + bytes(4095)]
     path = str(tmp_path / "mtft.bin")
     write_case(path, blocks)
     for order in ("0", "2"):
