@@ -24,7 +24,7 @@ namespace knz {
 // bytes per tile (one wave): 4096, or 1024 when the batch has fewer 4 KiB tiles than the device has wave slots -- the tile kernels
 // are one dependent chain per tile, so a small batch finishes in the time of ONE chain and shorter chains are what shortens it
 // (2 blocks of 8 MiB: k_mtf_f_rank 0.82 -> see DESIGN.md)
-// knob "mtf_chain" (KNZ_MTF_CHAIN=1): forward ranks by the byte-serial chain kernel of rounds 2-4 instead of the data-parallel one
+// knob "mtf_chain" (KNZ_MTF_CHAIN=1): forward ranks / inverse ids by the byte-serial chain kernels of rounds 2-5 instead of the data-parallel ones
 static std::atomic<int> g_mtfChainKnob([]() { const char* e = getenv("KNZ_MTF_CHAIN"); return e ? atoi(e) : 0; }());
 int mtft_tune_chain(int on) { g_mtfChainKnob.store(on ? 1 : 0); return 0; }
 static std::atomic<int> g_mtfTileKnob([]() { const char* e = getenv("KNZ_MTF_TILE"); return e ? atoi(e) : 0; }());      // 0 = by batch size; 1024 / 4096 force
@@ -545,6 +545,156 @@ __global__ __launch_bounds__(64) void k_mtf_i_symbolic(XfView v, int perTiles, u
     reinterpret_cast<u32*>(tilePerm + ((size_t)b * perTiles + blockIdx.x) * 256)[lane] = w;
 }
 
+// ---- inverse, pass 1, data parallel inside the tile (round 6) ---------------------------------------------------------------------
+// k_mtf_i_symbolic walks the tile rank by rank: about 21 instructions (half of them scalar) per rank that is not 0, one dependent chain.
+// A rank 0 repeats the id in front of it and leaves the list alone, so the tile is decoded from its EVENTS (ranks other than 0, three
+// bytes in ten behind a BWT), 64 at a time, one per lane, and no lane waits for another:
+//   * lane i wants the id at place q = rank_i of the list as it stands before event i. Going back over the events j = i-1 .. 0 of the
+//     chunk: event j moved place rank_j to the front and places 0 .. rank_j - 1 one back, so a place q of the list behind event j was
+//     place q - 1 in front of it when 1 <= q <= rank_j, place q when q > rank_j, and q = 0 is the id event j itself delivered. A lane
+//     ends with "the id of event j" or with a place of the list at the chunk's start; every lane runs the same <= 63 steps of one
+//     readlane, two compares, a select and a conditional decrement;
+//   * ids copied from an earlier event are resolved by pointer jumping over the lanes (six shuffles at most);
+//   * the list behind the chunk: its distinct ids by last occurrence, latest first, then the places no event touched in their old order
+//     -- when the touched places were the front ones anyway (the usual case: the same few symbols come again and again), only those
+//     are rewritten.
+// The ids of the events are packed at the front of the tile in LDS and spread out again from the back, every byte in between
+// repeating the event in front of it (the forward kernel's run heads, mirrored). Checked against the chain kernel and the oracle in
+// the emulator (tests/emu/mtft_emu.cpp, KNZ_MTF_CHAIN=0/1) and on the device by every MTFT case of the GPU suite.
+template <u32 MT>
+__global__ __launch_bounds__(64) void k_mtf_i_symbolic_par(XfView v, int perTiles, u8* __restrict__ tilePerm)
+{
+    const int b = blockIdx.y;
+    const u32 n = (v.len[b] <= v.cap[b]) ? v.len[b] : 0;
+    const u32 tbase = blockIdx.x * MT;
+    if (tbase >= n) return;
+    const u8* src = v.src[b] + tbase;
+    u8* dst = v.dst[b] + tbase;
+    const int lane = lane_id();
+    __shared__ u32 tileW[MT / 4];            // ranks in, ids out
+    __shared__ u32 listW[2][64];             // place -> id, two copies in turn
+    __shared__ u32 Mw[8], Sx[8];             // places the chunk's events took their ids from (bit map), set bits in the words above
+    __shared__ u32 lastW[256];               // per id: 1 + the last lane of the chunk that delivered it
+    u8* tileB = reinterpret_cast<u8*>(tileW);
+    const u32 cnt = (n - tbase < MT) ? (n - tbase) : MT;
+    const bool al = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 3) == 0;
+    if (al) {
+        for (u32 q = (u32)lane; q < cnt / 4; q += 64) tileW[q] = reinterpret_cast<const u32*>(src)[q];
+        for (u32 q = (cnt & ~3u) + (u32)lane; q < cnt; q += 64) tileB[q] = src[q];
+    } else { for (u32 q = (u32)lane; q < cnt; q += 64) tileB[q] = src[q]; }
+    listW[0][lane] = (u32)(4 * lane) | ((u32)(4 * lane + 1) << 8) | ((u32)(4 * lane + 2) << 16) | ((u32)(4 * lane + 3) << 24);
+    __syncthreads();
+    const u64 below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const u64 above = (lane == 63) ? 0ull : (~0ull << (lane + 1));
+    // ---- events of every chunk (lane c keeps the flags of chunk c), packed to the front of the tile
+    u64 evMask = 0;
+    for (u32 k = 0, c = 0; k < cnt; k += 64, c++) {
+        const bool valid = k + (u32)lane < cnt;
+        const u32 r = valid ? (u32)tileB[k + (u32)lane] : 0u;
+        const u64 m = __ballot(r != 0);
+        if (lane == (int)c) evMask = m;
+    }
+    const u32 evMine = mtf_popc64(evMask);
+    const u32 evIncl = wave_incl_scan(evMine);
+    const u32 evBase = evIncl - evMine;
+    const u32 nEv = (u32)__builtin_amdgcn_readlane((int)evIncl, 63);
+    for (u32 k = 0, c = 0; k < cnt; k += 64, c++) {
+        const u64 m = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(evMask >> 32), (int)c) << 32) | (u64)(u32)__builtin_amdgcn_readlane((int)(u32)evMask, (int)c);
+        const u32 base = (u32)__builtin_amdgcn_readlane((int)evBase, (int)c);
+        const bool ev = (m >> lane) & 1ull;
+        const u32 r = ev ? (u32)tileB[k + (u32)lane] : 0u;
+        KNZ_WAVE_ORDER();                            // (every lane has read its byte before one is overwritten)
+        if (ev) tileB[base + mtf_popc64(m & below)] = (u8)r;
+    }
+    __syncthreads();
+    int cur = 0;
+    for (u32 k = 0; k < nEv; k += 64) {
+        u8* listB = reinterpret_cast<u8*>(listW[cur]);
+        const u32 nv = (nEv - k < 64u) ? nEv - k : 64u;           // events of this chunk (uniform)
+        const bool valid = (u32)lane < nv;
+        const u32 rho = valid ? (u32)tileB[k + (u32)lane] : 0u;     // >= 1 for an event
+        // ---- back over the earlier events of the chunk
+        // (step t looks at event lane - t: the ranks move up one lane per step, 0 comes in below the chunk's first event. The place is a
+        // SIGNED number: a lane whose place has come to 0 has found its event and counts the steps since below 0 -- 0 and everything
+        // under it is "<= rank" for every rank --, so a step is a DPP move, a compare and a conditional decrement and the step of the
+        // find is read off at the end. Past its first event -- rank 0 from below -- a lane does nothing, except that a place 0 "finds"
+        // an event in front of the chunk, which the step number tells. The trip count is uniform and rounded up: extra steps see rank 0)
+        int q = (int)rho, rs = (int)rho;
+        const u32 steps = ((u32)__builtin_amdgcn_readfirstlane((int)nv) + 2u) & ~3u;      // >= nv - 1, a multiple of 4
+        for (u32 t = 0; t < steps; t += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                rs = __builtin_amdgcn_update_dpp(0, rs, 0x138, 0xF, 0xF, true);           // wave_shr:1, 0 into lane 0
+                q -= (q <= rs) ? 1 : 0;
+            }
+        }
+        const u32 hitT = (q < 0) ? (u32)((int)steps + 1 + q) : 0u;                        // the step that began with place 0
+        int from = (hitT != 0 && hitT <= (u32)lane) ? lane - (int)hitT : -1;            // the event whose id this one repeats
+        q = (q < 0) ? 0 : q;                                                              // (found in front of the chunk: place 0 of the list)
+        const bool fromList = valid && from < 0;
+        u32 id = fromList ? (u32)listB[(u32)q] : 0u;
+        // ---- ids that repeat an earlier event of the chunk
+        for (int it = 0; it < 6; it++) {
+            if (__ballot(valid && from >= 0) == 0) break;
+            const int at = from < 0 ? lane : from;
+            const u32 tid2 = (u32)__shfl((int)id, at, 64);
+            const int tf = __shfl(from, at, 64);
+            if (from >= 0) { if (tf < 0) { id = tid2; from = -1; } else from = tf; }
+        }
+        KNZ_WAVE_ORDER();
+        if (valid) tileB[k + (u32)lane] = (u8)id;
+        // ---- the list behind the chunk
+        // (the last event of every id: the highest lane that shows it, through one LDS maximum per lane)
+        lastW[lane] = 0; lastW[lane + 64] = 0; lastW[lane + 128] = 0; lastW[lane + 192] = 0;
+        __syncthreads();
+        if (valid) atomicMax(&lastW[id], (u32)lane + 1u);
+        __syncthreads();
+        const bool last = valid && lastW[id] == (u32)lane + 1u;
+        const u64 Lm = __ballot(last);
+        const u32 D = mtf_popc64(Lm);                              // distinct ids of the chunk = places that gave an id
+        const u32 newPlace = mtf_popc64(Lm & above);
+        if (__ballot(fromList && (u32)q >= D) == 0) {
+            // the ids came from the front D places: nobody else moves
+            if (last) listB[newPlace] = (u8)id;
+        } else {
+            u8* nextB = reinterpret_cast<u8*>(listW[cur ^ 1]);
+            if (lane < 8) Mw[lane] = 0;
+            __syncthreads();
+            if (fromList) atomicOr(&Mw[(u32)q >> 5], 1u << ((u32)q & 31));
+            __syncthreads();
+            if (lane < 8) { u32 a = 0; for (int w = lane + 1; w < 8; w++) a += (u32)__popc(Mw[w]); Sx[lane] = a; }
+            __syncthreads();
+            const u32 lw = listW[cur][lane];                       // ids at the places 4 * lane .. 4 * lane + 3
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const u32 p = 4u * (u32)lane + (u32)t;
+                const u32 w = p >> 5;
+                const u32 mw = Mw[w];
+                if ((mw >> (p & 31)) & 1u) continue;               // this place gave its id to an event
+                const u32 add = Sx[w] + (u32)__popc(mw & ~((2u << (p & 31)) - 1u));
+                nextB[p + add] = (u8)(lw >> (8 * t));
+            }
+            if (last) nextB[newPlace] = (u8)id;
+            cur ^= 1;
+        }
+        __syncthreads();
+    }
+    // ---- every byte of the tile: the id of the last event at or in front of it (none: the list's first id, 0)
+    for (int c = (int)((cnt + 63u) / 64u) - 1; c >= 0; c--) {
+        const u64 m = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(evMask >> 32), c) << 32) | (u64)(u32)__builtin_amdgcn_readlane((int)(u32)evMask, c);
+        const u32 base = (u32)__builtin_amdgcn_readlane((int)evBase, c);
+        const u32 upto = base + mtf_popc64(m & (below | (1ull << lane)));       // events up to and including this byte
+        const u32 id = upto ? (u32)tileB[upto - 1] : 0u;
+        KNZ_WAVE_ORDER();
+        if (64u * (u32)c + (u32)lane < cnt) tileB[64u * (u32)c + (u32)lane] = (u8)id;
+        KNZ_WAVE_ORDER();
+    }
+    __syncthreads();
+    if (al && (cnt & 3) == 0) { for (u32 q = (u32)lane; q < cnt / 4; q += 64) reinterpret_cast<u32*>(dst)[q] = tileW[q]; }
+    else { for (u32 q = (u32)lane; q < cnt; q += 64) dst[q] = tileB[q]; }
+    reinterpret_cast<u32*>(tilePerm + ((size_t)b * perTiles + blockIdx.x) * 256)[lane] = listW[cur][lane];
+}
+
 // inverse, pass 2: state before tile t: S_0 = identity, S_{t+1}[j] = S_t[perm_t[j]]. Composition is associative, so it runs in two
 // levels like the forward scan: inside a segment from the identity (L_t, stored in place, and the segment's total in segPerm), then
 // over the segment totals (A_g = state before segment g, in place); the state a tile needs is S_t[j] = A_g[L_t[j]] (pass 3).
@@ -661,7 +811,9 @@ static void mtft_inverse_t(hipStream_t s, const XfStage& st)
     const u32 segT = mtf_seg_tiles((u32)perTiles), nSeg = ((u32)perTiles + segT - 1) / segT;
     u8* segPerm = tilePerm + (size_t)st.nBlocks * perTiles * 256;                  // nBlocks * nSeg * 256 bytes
     { KScope ks_("k_copy_ok"); hipLaunchKernelGGL(k_copy_ok, dim3((st.nBlocks + 255) / 256), dim3(256), 0, s, st.len, st.cap, st.nBlocks, st.ok, st.newLen); }
-    { KScope ks_("k_mtf_i_symbolic"); hipLaunchKernelGGL((k_mtf_i_symbolic<MT>), dim3(perTiles, st.nBlocks), dim3(64), 0, s, v, perTiles, tilePerm); }
+    { KScope ks_("k_mtf_i_symbolic");
+      if (g_mtfChainKnob.load()) hipLaunchKernelGGL((k_mtf_i_symbolic<MT>), dim3(perTiles, st.nBlocks), dim3(64), 0, s, v, perTiles, tilePerm);
+      else hipLaunchKernelGGL((k_mtf_i_symbolic_par<MT>), dim3(perTiles, st.nBlocks), dim3(64), 0, s, v, perTiles, tilePerm); }
     { KScope ks_("k_mtf_i_compose"); hipLaunchKernelGGL((k_mtf_i_compose<MT>), dim3(nSeg, st.nBlocks), dim3(256), 0, s, tilePerm, perTiles, segT, nSeg, st.len, segPerm);
       hipLaunchKernelGGL(k_mtf_i_compose2, dim3(st.nBlocks), dim3(256), 0, s, segPerm, nSeg); }
     { KScope ks_("k_mtf_i_resolve"); hipLaunchKernelGGL((k_mtf_i_resolve<MT>), dim3(perTiles, st.nBlocks), dim3(256), 0, s, v, perTiles, tilePerm, segT, nSeg, segPerm); }
