@@ -349,29 +349,41 @@ __global__ __launch_bounds__(256) void k_bwt_f_r0_counts(BwtView bv, const u32* 
 
 // group-start flags of the sorted keys as a bit map (one ballot per wave): a slot starts a group when its key bytes differ from
 // its left neighbour's, when it is the first slot of a block, or when it or its left neighbour is a short suffix
+constexpr u32 R0F_ROWS = 8;       // rows of 256 slots per workgroup, all loads of a thread in flight at once (one row per workgroup ran at 2.5 TB/s)
 __global__ __launch_bounds__(256) void k_bwt_f_r0_flags(const u64* __restrict__ keys, const u32* __restrict__ base, int nBlocks, u32 total, int P, int pbits,
                                                         unsigned long long* __restrict__ gbits64)
 {
     __shared__ int sBlk;
-    const u32 a0 = blockIdx.x * 256;
+    const u32 a0 = blockIdx.x * (256u * R0F_ROWS);
     if (threadIdx.x == 0) sBlk = find_block(base, nBlocks, a0 < total ? a0 : (total ? total - 1 : 0));
     __syncthreads();
-    const u32 a = a0 + threadIdx.x;
-    bool f = true;
-    // the left neighbour's key comes from the lane next door (lane 0 of a wave loads it)
-    const u64 k = (a < total) ? keys[a] : 0ull;
-    u32 klo = (u32)__shfl_up((int)(u32)k, 1u, 64), khi = (u32)__shfl_up((int)(u32)(k >> 32), 1u, 64);
-    u64 kp = ((u64)khi << 32) | klo;
-    if ((threadIdx.x & 63) == 0 && a > 0 && a < total) kp = keys[a - 1];
-    if (a < total) {
-        int b = sBlk;
-        while (a >= base[b + 1]) b++;
-        const u32 bb = base[b], n = base[b + 1] - bb;
-        const u64 pm = (1ull << pbits) - 1ull;
-        f = (a == bb) || ((k >> pbits) != (kp >> pbits)) || ((u32)(k & pm) + (u32)P > n) || ((u32)(kp & pm) + (u32)P > n);
+    u64 kr[R0F_ROWS], kl[R0F_ROWS];
+#pragma unroll
+    for (u32 r = 0; r < R0F_ROWS; r++) {
+        const u32 a = a0 + r * 256u + threadIdx.x;
+        kr[r] = (a < total) ? keys[a] : 0ull;
+        // the left neighbour's key comes from the lane next door (lane 0 of a wave loads it)
+        kl[r] = ((threadIdx.x & 63) == 0 && a > 0 && a < total) ? keys[a - 1] : 0ull;
     }
-    const unsigned long long m = __ballot(f);
-    if ((threadIdx.x & 63) == 0) gbits64[a >> 6] = m;
+    int b = sBlk;
+    const u64 pm = (1ull << pbits) - 1ull;
+#pragma unroll
+    for (u32 r = 0; r < R0F_ROWS; r++) {
+        const u32 a = a0 + r * 256u + threadIdx.x;
+        if (a0 + r * 256u >= total) break;                  // (uniform)
+        const u64 k = kr[r];
+        const u32 klo = (u32)__shfl_up((int)(u32)k, 1u, 64), khi = (u32)__shfl_up((int)(u32)(k >> 32), 1u, 64);
+        u64 kp = ((u64)khi << 32) | klo;
+        if ((threadIdx.x & 63) == 0) kp = kl[r];
+        bool f = true;
+        if (a < total) {
+            while (a >= base[b + 1]) b++;
+            const u32 bb = base[b], n = base[b + 1] - bb;
+            f = (a == bb) || ((k >> pbits) != (kp >> pbits)) || ((u32)(k & pm) + (u32)P > n) || ((u32)(kp & pm) + (u32)P > n);
+        }
+        const unsigned long long m = __ballot(f);
+        if ((threadIdx.x & 63) == 0) gbits64[a >> 6] = m;
+    }
 }
 
 // per window of 2048 slots: the last group start in it (0 when it has none: slot 0 always starts a group, so 0 is neutral
@@ -2529,7 +2541,7 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
     hipMemsetAsync(w.gbits, 0xFF, 4 * w.gbitsWords, s);
     hipMemsetAsync(w.gnew, 0, 4 * w.gbitsWords, s);
     hipMemsetAsync(w.counters, 0, 64, s);
-    { KScope ks_("k_bwt_f_r0_flags"); hipLaunchKernelGGL(k_bwt_f_r0_flags, dim3((total + 255) / 256), dim3(256), 0, s, sortedKeys, w.base, st.nBlocks, total, nsym, pbits,
+    { KScope ks_("k_bwt_f_r0_flags"); hipLaunchKernelGGL(k_bwt_f_r0_flags, dim3((total + 256 * R0F_ROWS - 1) / (256 * R0F_ROWS)), dim3(256), 0, s, sortedKeys, w.base, st.nBlocks, total, nsym, pbits,
                                                          reinterpret_cast<unsigned long long*>(w.gbits)); }
     // group starts before / after every window of 2048 slots: two scans over ~total/2048 values
     const u32 nWin = (total + SM_WIN - 1) / SM_WIN;
