@@ -291,6 +291,7 @@ __global__ __launch_bounds__(64) void k_mtf_f_rank_par(XfView v, int perTiles, c
     __shared__ u32 posW[64];                 // byte c = place of symbol c in the list
     __shared__ u32 Mw[8], Sx[8];             // places the chunk's symbols held (bit map), set bits in the words above
     __shared__ u32 tileW[MT / 4];            // the tile: symbols in, ranks out
+    __shared__ u32 peerW[512];               // per symbol: the lanes of the chunk that show it (two words)
     const int lane = lane_id();
     const u32* st = tileState + ((size_t)b * perTiles + blockIdx.x) * 256;
     const u32* sg = segMax + ((size_t)b * nSeg + blockIdx.x / segT) * 256;
@@ -362,13 +363,13 @@ __global__ __launch_bounds__(64) void k_mtf_f_rank_par(XfView v, int perTiles, c
     for (u32 k = 0; k < cntR; k += 64) {
         const bool valid = k + (u32)lane < cntR;
         const u32 c = valid ? (u32)tileB[k + (u32)lane] : 0u;
-        u64 peers = __ballot(valid);
-#pragma unroll
-        for (int bit = 0; bit < 8; bit++) {
-            const bool one = (c >> bit) & 1u;
-            const u64 bal = __ballot(valid && one);
-            peers &= one ? bal : ~bal;
-        }
+        // the lanes that show my symbol: every lane sets its bit in the symbol's word pair in LDS (round 6; eight ballots with a 64-bit
+        // select each were 120 of the chunk's 400 instructions)
+        if (valid) { peerW[2 * c] = 0; peerW[2 * c + 1] = 0; }
+        __syncthreads();
+        if (valid) atomicOr(&peerW[2 * c + ((u32)lane >> 5)], 1u << (lane & 31));
+        __syncthreads();
+        const u64 peers = valid ? ((u64)peerW[2 * c] | ((u64)peerW[2 * c + 1] << 32)) : 0ull;
         const u64 pm = peers & below;
         const u32 vv = pm ? 64u - (u32)__clzll((long long)pm) : 0u;            // previous occurrence in the chunk + 1
         u32 rank;
