@@ -32,6 +32,25 @@ __device__ __forceinline__ u32 block_excl_scan256(u32 v, u32* lds4, u32* tot)
     return off + incl - v;
 }
 
+// exclusive prefix maximum over the 256 threads of a workgroup (0 in front of thread 0): inside a wave by shuffles, the waves in front
+// through LDS -- one barrier pair where a log-step scan through LDS takes sixteen
+__device__ __forceinline__ u32 block_excl_max256(u32 v, u32* lds4)
+{
+    const int lane = lane_id(), wv = (int)(threadIdx.x >> 6);
+    u32 val = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 o = (u32)__shfl_up((int)val, (unsigned)d, 64);
+        if (lane >= d) val = o > val ? o : val;
+    }
+    u32 ex = (u32)__shfl_up((int)val, 1u, 64);
+    if (lane == 0) ex = 0;
+    if (lane == 63) lds4[wv] = val;
+    __syncthreads();
+    for (int k = 0; k < wv; k++) { const u32 x = lds4[k]; ex = x > ex ? x : ex; }
+    __syncthreads();
+    return ex;
+}
+
 // ------------------------------------------------------------------------------------------------
 // generic per-block scans over tile arrays (one workgroup per block)
 // ------------------------------------------------------------------------------------------------
@@ -179,7 +198,7 @@ __global__ __launch_bounds__(256) void k_zrlt_f_pass(XfView v, int per, const u3
     if (base >= n) return;
     if (EMIT && !okFlags[b]) return;
     const u8* s = v.src[b];
-    __shared__ u32 tnz[256];
+    __shared__ u32 tnz[4];
     __shared__ u32 l4[4];
     const u32 i0 = base + threadIdx.x * ZPT;
     u8 c[ZPT];
@@ -200,22 +219,21 @@ __global__ __launch_bounds__(256) void k_zrlt_f_pass(XfView v, int per, const u3
             if (myFirst == NOPOS && i < n && c[k] != 0) myFirst = i;
         }
     }
-    tnz[threadIdx.x] = myFirst;
-    __syncthreads();
-    // next non-zero after this thread's bytes: scan following threads, then the next tiles
+    // next non-zero after this thread's bytes: the threads behind it in its wave (shuffles), the waves behind (their minima through LDS),
+    // then the next tiles (round 6: the log-step scan over the 256 threads through LDS cost sixteen barriers per tile and pass)
     u32 after = NOPOS;
     {
-        // suffix min over threads (serial per thread is 256 steps worst case; do a log-step scan instead)
+        const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
         u32 val = myFirst;
-        for (int d = 1; d < 256; d <<= 1) {
-            __syncthreads();
-            const u32 o = (threadIdx.x + d < 256) ? tnz[threadIdx.x + d] : NOPOS;
-            __syncthreads();
-            val = o < val ? o : val;
-            tnz[threadIdx.x] = val;
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 o = (u32)__shfl_down((int)val, (unsigned)d, 64);
+            if (lane + d < 64) val = o < val ? o : val;
         }
+        const u32 nxt = (u32)__shfl_down((int)val, 1u, 64);
+        if (lane == 0) tnz[wave] = val;
         __syncthreads();
-        after = (threadIdx.x + 1 < 256) ? tnz[threadIdx.x + 1] : NOPOS;
+        after = (lane < 63) ? nxt : NOPOS;
+        for (int w = wave + 1; w < 4; w++) { const u32 x = tnz[w]; after = x < after ? x : after; }
         if (after == NOPOS) {
             const u32 cnt = (n + ZT - 1) / ZT;
             after = (t + 1 < cnt) ? nextNZ[(size_t)b * per + t + 1] : n;
@@ -360,7 +378,7 @@ __global__ __launch_bounds__(256) void k_zrlt_i_pass(XfView v, int per, const u3
     if (base >= n) return;
     if (MODE == 2 && !okFlags[b]) return;
     const u8* s = v.src[b];
-    __shared__ u32 scan[256];
+    __shared__ u32 m4[4];
     __shared__ u64 l4[4];
     __shared__ u32 mx;
     const u32 i0 = base + threadIdx.x * ZPT;
@@ -383,20 +401,9 @@ __global__ __launch_bounds__(256) void k_zrlt_i_pass(XfView v, int per, const u3
         }
     }
     // exclusive prefix max over threads of lastNonFF
-    scan[threadIdx.x] = lastNonFF;
-    __syncthreads();
-    u32 val = lastNonFF;
-    for (int d = 1; d < 256; d <<= 1) {
-        const u32 o = ((int)threadIdx.x - d >= 0) ? scan[threadIdx.x - d] : 0;
-        __syncthreads();
-        val = o > val ? o : val;
-        scan[threadIdx.x] = val;
-        __syncthreads();
-    }
-    u32 before = (threadIdx.x > 0) ? scan[threadIdx.x - 1] : 0;
+    u32 before = block_excl_max256(lastNonFF, m4);
     const u32 tp = prevNonFF[(size_t)b * per + t];
     before = before > tp ? before : tp;
-    __syncthreads();
 
     u32 cls[ZPT];
     u32 lastNonR = 0;                // position+1 of last non-run-bit byte within my bytes
@@ -419,20 +426,9 @@ __global__ __launch_bounds__(256) void k_zrlt_i_pass(XfView v, int per, const u3
         return;
     }
     // exclusive prefix max over threads of lastNonR
-    scan[threadIdx.x] = lastNonR;
-    __syncthreads();
-    val = lastNonR;
-    for (int d = 1; d < 256; d <<= 1) {
-        const u32 o = ((int)threadIdx.x - d >= 0) ? scan[threadIdx.x - d] : 0;
-        __syncthreads();
-        val = o > val ? o : val;
-        scan[threadIdx.x] = val;
-        __syncthreads();
-    }
-    u32 nrBefore = (threadIdx.x > 0) ? scan[threadIdx.x - 1] : 0;
+    u32 nrBefore = block_excl_max256(lastNonR, m4);
     const u32 tr = prevNonR[(size_t)b * per + t];
     nrBefore = nrBefore > tr ? nrBefore : tr;
-    __syncthreads();
 
     u32 sizes[ZPT];
     u64 sum = 0;
