@@ -558,7 +558,7 @@ __global__ __launch_bounds__(256) void k_bwt_f_r0_place(FwdView v, const u32* __
 // Round 0 and the text round in one sweep (the default; knob bwt_no_text_round = 2 runs k_bwt_f_r0_place and k_bwt_f_sort_small_text one
 // after the other instead): windows of SM_TS owned slots that look SM_G slots further, as the small-group kernels do. A slot is placed
 // by the window that owns it -- except the members of a SMALL group (2..SM_G members), which are all placed by the window that owns
-// the group's first slot: that window has their keys in LDS anyway, sorts them on the eight text bytes behind the round-0 symbols
+// the group's first slot: that window has their keys in LDS anyway, sorts them on the seven text bytes behind the round-0 symbols
 // before anything is written, and writes position and label ONCE, with the label the text order gives (the separate text round read
 // SA back, and wrote SA and the labels of every member that moved a second time).
 __global__ __launch_bounds__(256) void k_bwt_f_r0_place_text(BwtView bv, FwdView v, const u32* __restrict__ winLastIncl, const u32* __restrict__ winFirstInclRev, u32 nWin,
@@ -633,7 +633,9 @@ __global__ __launch_bounds__(256) void k_bwt_f_r0_place_text(BwtView bv, FwdView
             const u8* t = bv.src[blk];
             const u64 x = text8(t, q, n);
             sSA[i] = gp[k];
-            sK[i] = __builtin_bswap64(x);
+            // (SEVEN text bytes and the member's place in its group below them: the key is unique inside the group, and one compare per
+            // pair gives the stable rank, a second one against the key without the place the smaller keys alone -- see k_bwt_f_small_fused)
+            sK[i] = (__builtin_bswap64(x) & ~0xFFull) | (u64)(i - gs[k]);
         }
     }
     __syncthreads();
@@ -648,20 +650,19 @@ __global__ __launch_bounds__(256) void k_bwt_f_r0_place_text(BwtView bv, FwdView
         if (!inView[k]) continue;
         if (mine[k]) {
             // a member of a small group of this window: its place and label come from the text order inside the group
-            const u64 ki = sK[i];
-            u32 less = 0, eq = 0, eqBefore = 0;
+            const u64 ki = sK[i], lo = ki & ~0xFFull;
+            u32 less = 0, rank = 0;
             for (u32 j = gs[k]; j < ge[k]; j++) {
                 const u64 kj = sK[j];
-                less += (kj < ki) ? 1u : 0u;
-                const u32 same = (kj == ki) ? 1u : 0u;
-                eq += same;
-                eqBefore += (j < i) ? same : 0u;
+                rank += (kj < ki) ? 1u : 0u;
+                less += (kj < lo) ? 1u : 0u;
             }
+            const u32 eqBefore = rank - less;
             const u32 headIdx = gs[k] + less;
             v.SA[slot0 + headIdx + eqBefore] = gp[k];
             lab_set(v, gp[k], v.base[blkOf[k]], slot0 + headIdx, slot0 + headIdx);
             if (less != 0 && eqBefore == 0) atomicOr(&sNew[headIdx >> 5], 1u << (headIdx & 31));
-            if (eq > 1) surv = 1;
+            if (eqBefore != 0) surv = 1;
             continue;
         }
         if (i >= SM_TS) continue;                                  // in view only: the next window owns it
@@ -799,6 +800,12 @@ __global__ __launch_bounds__(256) void k_bwt_f_sort_small(FwdView v, u32* __rest
 // Keys and refinement of the small groups in ONE sweep (versioned labels, see lab_old): k_bwt_f_gather_small + k_bwt_f_sort_small without the
 // key array in between -- a window's bit-map words, positions and keys are read once and stay in LDS (the two kernels read the bit map and
 // SA twice and wrote and read K: 24 of the 40 KiB a dense window moved per round).
+// PACKED (blocks of up to 8 MiB: a key -- a label inside the block + 1 -- has 24 bits): the key in LDS is (key << 8 | place in the group), unique
+// inside the group, so that ONE compare per pair gives a member its stable rank (smaller keys + equal keys in front of it) and a second one
+// against (key << 8) the smaller keys alone; the plain form needs "smaller", "equal" and "equal and in front" -- 9.4 vector instructions
+// per pair against 4, and a member of a group of g compares with all g (round 6: groups of 33..256 members are a third of the small-group
+// visits of the first rounds on real files).
+template <bool PACKED>
 __global__ __launch_bounds__(256) void k_bwt_f_small_fused(FwdView v, u32 h, u32* __restrict__ survTile, int stats)
 {
     __shared__ SmWindow W;
@@ -832,7 +839,8 @@ __global__ __launch_bounds__(256) void k_bwt_f_small_fused(FwdView v, u32 h, u32
         if ((sRt[i >> 5] >> (i & 31)) & 1u) { const u32 r = v.ovr[slot]; off = r > h ? r : h; }
         const u32 gp = v.SA[slot];
         sSA[i] = gp;
-        sK[i] = gather_key(v, gp, off, bb[k], v.base[b + 1]);
+        const u32 key = gather_key(v, gp, off, bb[k], v.base[b + 1]);
+        sK[i] = PACKED ? ((key << 8) | (i - gs[k])) : key;
         if (stats) { atomicAdd(&v.counters[10], 1u); if (i == gs[k]) atomicAdd(&v.counters[11], 1u); }      // (developer statistics, knob bwt_stats)
     }
     __syncthreads();
@@ -842,13 +850,29 @@ __global__ __launch_bounds__(256) void k_bwt_f_small_fused(FwdView v, u32 h, u32
         if (!act[k]) continue;
         const u32 i = threadIdx.x + 256u * k;
         const u32 ki = sK[i];
-        u32 less = 0, eq = 0, eqBefore = 0;
-        for (u32 j = gs[k]; j < ge[k]; j++) {
-            const u32 kj = sK[j];
-            less += (kj < ki) ? 1u : 0u;
-            const u32 same = (kj == ki) ? 1u : 0u;
-            eq += same;
-            eqBefore += (j < i) ? same : 0u;
+        u32 less = 0, eqBefore = 0, tied = 0;
+        if (PACKED) {
+            const u32 lo = ki & ~0xFFu;
+            u32 rank = 0;
+            for (u32 j = gs[k]; j < ge[k]; j++) {
+                const u32 kj = sK[j];
+                rank += (kj < ki) ? 1u : 0u;
+                less += (kj < lo) ? 1u : 0u;
+            }
+            eqBefore = rank - less;
+            // (members that are still tied: in a subgroup of m equal keys m - 1 have an equal key in front of them, and exactly one of
+            // those has exactly one)
+            tied = (eqBefore != 0 ? 1u : 0u) + (eqBefore == 1 ? 1u : 0u);
+        } else {
+            u32 eq = 0;
+            for (u32 j = gs[k]; j < ge[k]; j++) {
+                const u32 kj = sK[j];
+                less += (kj < ki) ? 1u : 0u;
+                const u32 same = (kj == ki) ? 1u : 0u;
+                eq += same;
+                eqBefore += (j < i) ? same : 0u;
+            }
+            tied = (eq > 1) ? 1u : 0u;
         }
         const u32 gp = sSA[i];
         const u32 headIdx = gs[k] + less;
@@ -857,7 +881,7 @@ __global__ __launch_bounds__(256) void k_bwt_f_small_fused(FwdView v, u32 h, u32
             lab_set(v, gp, bb[k], slot0 + headIdx, slot0 + gs[k]);             // (a small group's label is its first slot)
             if (eqBefore == 0) atomicOr(&sNew[headIdx >> 5], 1u << (headIdx & 31));
         }
-        if (eq > 1) surv++;
+        surv += tied;
     }
     {
         const u32 ws = wave_sum(surv);
@@ -2347,14 +2371,15 @@ __global__ __launch_bounds__(256) void k_bwt_f_med_compact(uint2* __restrict__ s
 }
 
 // knobs (tests, tuning): read from the environment once per process, or set through knz_hip_tune()
-struct FwdTuning { int nsym; int noRunRound; int runFallback; int noSuper; int noTextRound; int stats; int noRunOffsets; int noProbe; int link; int gatherWg; int plainLabels; int noFuse; int largeOs; };
+struct FwdTuning { int nsym; int noRunRound; int runFallback; int noSuper; int noTextRound; int stats; int noRunOffsets; int noProbe; int link; int gatherWg; int plainLabels; int noFuse; int largeOs; int noPack; };
 static FwdTuning& fwd_tuning()
 {
     static FwdTuning t = [] {
-        FwdTuning x; x.nsym = 0; x.noRunRound = 0; x.runFallback = 0; x.noSuper = 0; x.noTextRound = 0; x.stats = 0; x.noRunOffsets = 0; x.noProbe = 0; x.link = 1; x.gatherWg = 512; x.plainLabels = 0; x.noFuse = 0; x.largeOs = 1000000;     // link: 0 off, 1 on (from h = 32), n > 1: from h = n
+        FwdTuning x; x.nsym = 0; x.noRunRound = 0; x.runFallback = 0; x.noSuper = 0; x.noTextRound = 0; x.stats = 0; x.noRunOffsets = 0; x.noProbe = 0; x.link = 1; x.gatherWg = 512; x.plainLabels = 0; x.noFuse = 0; x.largeOs = 1000000; x.noPack = 0;     // link: 0 off, 1 on (from h = 32), n > 1: from h = n
         if (getenv("KNZ_BWT_NO_PROBE")) x.noProbe = 1;
         if (getenv("KNZ_BWT_PLAIN_LABELS")) x.plainLabels = 1;
         if (getenv("KNZ_BWT_NO_FUSE")) x.noFuse = 1;
+        if (getenv("KNZ_BWT_NO_PACK")) x.noPack = 1;
         if (const char* e = getenv("KNZ_BWT_LINK")) x.link = atoi(e);
         if (getenv("KNZ_BWT_NO_RUN_OFFSETS")) x.noRunOffsets = 1;
         if (getenv("KNZ_BWT_STATS")) x.stats = 1;
@@ -2383,6 +2408,7 @@ int bwt_forward_tune(const char* key, int value)
     else if (!strcmp(key, "bwt_gather_wg")) t.gatherWg = value;
     else if (!strcmp(key, "bwt_plain_labels")) t.plainLabels = value;
     else if (!strcmp(key, "bwt_no_fuse")) t.noFuse = value;
+    else if (!strcmp(key, "bwt_no_pack")) t.noPack = value;      // small groups ranked on plain keys (three counts per pair) also where the packed keys fit
     else if (!strcmp(key, "bwt_large_os")) t.largeOs = value;
     else return -1;
     return 0;
@@ -2782,7 +2808,8 @@ int launch_bwt_forward(hipStream_t s, const XfStage& st, void* scratch, size_t s
         }
         // -- then the refinements
         if (surv) { KScope ks_("k_bwt_f_sort_small");
-                    if (fused) hipLaunchKernelGGL(k_bwt_f_small_fused, dim3(nTiles), dim3(256), 0, s, v, h, tune.link ? w.survTile : (u32*)nullptr, tune.stats);
+                    if (fused && pbits <= 23 && !tune.noPack) hipLaunchKernelGGL(k_bwt_f_small_fused<true>, dim3(nTiles), dim3(256), 0, s, v, h, tune.link ? w.survTile : (u32*)nullptr, tune.stats);
+                    else if (fused) hipLaunchKernelGGL(k_bwt_f_small_fused<false>, dim3(nTiles), dim3(256), 0, s, v, h, tune.link ? w.survTile : (u32*)nullptr, tune.stats);
                     else hipLaunchKernelGGL(k_bwt_f_sort_small, dim3(nTiles), dim3(256), 0, s, v, tune.link ? w.survTile : (u32*)nullptr);
                     if (linkNow) hipLaunchKernelGGL(k_bwt_f_link_payoff, dim3(1), dim3(256), 0, s, v, w.linkedTile, w.survTile, nTiles, linkStepUsed, w.counters + 14, linkTr);
                     if (tune.link) prims::launch_scan<prims::SCAN_SUM_EXCL>(s, w.survTile, w.survTile, nTiles, nullptr, w.scanTmp, w.counters + 13); }
