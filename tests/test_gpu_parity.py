@@ -475,7 +475,10 @@ def test_decode_in_ranges_side_by_side(hip, oracle):
 def test_suffix_sort_label_paths_give_one_stream(hip):
     """Round 6: the suffix sort keeps its labels as versioned 64-bit entries and refines small groups in one kernel (k_bwt_f_small_fused); blocks
     above 256 MiB use 32-bit labels with separate key kernels (KNZ_BWT_PLAIN_LABELS), and KNZ_BWT_NO_FUSE keeps versioned labels with the
-    two kernels. The three paths must write the same bytes -- the reference's (tests/golden/golden_full.json, hard:repeats and hard:dna)."""
+    two kernels; the fused kernel ranks the members of a group on packed unique keys where a block has at most 8 MiB and on plain keys
+    otherwise (bwt_no_pack forces the plain form). All paths must write the same bytes -- the reference's (tests/golden/golden_full.json,
+    hard:repeats, hard:dna, hard:fibword, all in blocks of 8 MiB: packed keys by default; the 32 MiB and 256 MiB blocks of the config-4 and
+    big-block tests take the plain form by themselves)."""
     import json
     hipapi = importlib.import_module("kanzi_amd.hipapi")
     recs = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_full.json")))
@@ -484,7 +487,7 @@ def test_suffix_sort_label_paths_give_one_stream(hip):
         for config in ("hard:repeats", "hard:dna", "hard:fibword"):
             rec = [r for r in recs if r["config"] == config][0]
             d = vectors.make(tuple(rec["input"]))
-            for knob in (None, "bwt_no_fuse", "bwt_plain_labels"):
+            for knob in (None, "bwt_no_fuse", "bwt_plain_labels", "bwt_no_pack"):
                 if knob:
                     assert L.knz_hip_tune(knob.encode(), 1) == 0
                 try:
@@ -496,6 +499,7 @@ def test_suffix_sort_label_paths_give_one_stream(hip):
     finally:
         L.knz_hip_tune(b"bwt_no_fuse", 0)
         L.knz_hip_tune(b"bwt_plain_labels", 0)
+        L.knz_hip_tune(b"bwt_no_pack", 0)
 
 
 _BIG_INPUT = {}
