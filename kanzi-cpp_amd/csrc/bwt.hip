@@ -135,19 +135,6 @@ constexpr u32 IT = 4096;             // symbols per tile: 4 waves x 16 rows of 6
 #endif
 __device__ __forceinline__ bool hash_split(u32 j) { return (((j >> KNZ_SPLIT_CLUSTER_LOG) * 2654435761u) >> (32 - SPLIT_LOG)) == 0; }
 
-// lanes of the wave whose (valid) symbol equals mine
-__device__ __forceinline__ unsigned long long sym_peers(bool valid, u32 sym)
-{
-    unsigned long long peers = __ballot(valid);
-#pragma unroll
-    for (int bit = 0; bit < 8; bit++) {
-        const bool one = (sym >> bit) & 1u;
-        const unsigned long long bal = __ballot(valid && one);
-        peers &= one ? bal : ~bal;
-    }
-    return peers;
-}
-
 __global__ __launch_bounds__(256) void k_bwt_i_hist(BwtView v, const BwtHdr* __restrict__ hd, int perTiles, u32* __restrict__ tileHist)
 {
     const int b = blockIdx.y;
@@ -244,12 +231,9 @@ __global__ __launch_bounds__(256) void k_bwt_i_links(BwtView v, const BwtHdr* __
         const u32 i = t0 + (u32)wave * 1024u + (u32)r * 64u + (u32)lane;
         const bool valid = i < h.n;
         sym[r] = valid ? s[i] : 0u;
-        const unsigned long long peers = sym_peers(valid, sym[r]);
-        const int leader = __ffsll((long long)peers) - 1;
-        u32 old = 0;
-        if (valid && lane == leader) { old = cntw[wave][sym[r]]; cntw[wave][sym[r]] = old + (u32)__popcll(peers); }
-        old = (u32)__shfl((int)old, leader < 0 ? 0 : leader, 64);
-        pre[r] = old + (u32)__popcll(peers & ltMask);
+        // (prims::rs_row_rank: a row that shows one symbol -- most rows behind a BWT -- costs two ballots, the others the cheap form of the
+        // eight-ballot match)
+        pre[r] = prims::rs_row_rank(valid, sym[r], cntw[wave], lane, ltMask);
     }
     __syncthreads();
     // symbols of earlier waves of the tile come first

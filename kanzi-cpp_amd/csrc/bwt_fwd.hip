@@ -1231,13 +1231,7 @@ __device__ __forceinline__ void med_radix_sort(MedLds<THREADS, ROWS>& L, u32 n, 
                 const u32 idx = waveBase + (u32)r * 64u + (u32)lane;
                 if (idx < n) { key[r] = L.oK[idx]; val[r] = L.oV[idx]; }
                 const u32 dg = (key[r] >> shift) & 255u;
-                unsigned long long peers = ~0ull;
-#pragma unroll
-                for (int bit = 0; bit < 8; bit++) {
-                    const bool one = (dg >> bit) & 1u;
-                    const unsigned long long bal = __ballot(one);
-                    peers &= one ? bal : ~bal;
-                }
+                const unsigned long long peers = prims::digit_peers_fast(true, dg);
                 const u32 pop = (u32)__popcll(peers);
                 const u32 rnk = (u32)__popcll(peers & ltMask);
                 const int leader = __ffsll((long long)peers) - 1;

@@ -186,17 +186,42 @@ constexpr u32 RS_TILE = 1024u * RS_WAVES; // keys per tile
 constexpr u32 RS_GROUP = 64;             // tiles per group of the column scan
 constexpr int RS_MAXPASS = 8;            // passes the one-read variant counts ahead
 
-// lanes of the wave whose (valid) 8-bit digit equals mine
-__device__ __forceinline__ unsigned long long digit_peers(bool valid, u32 dg)
+// One row of 64 keys of a wave: pos = the number of keys of the wave's earlier rows and of the row's lower lanes that show the same digit
+// (cntw: the wave's 256 running counters). A row that shows ONE digit (runs, the constant high bytes of keys) costs two ballots. Else the
+// lanes that share a digit come from eight ballots, accumulated as "lanes that DIFFER from me in some bit": per bit the lane's bit spread
+// over a word (one arithmetic shift), XORed with the two halves of the ballot, two bits ORed in per three-input OR -- about 45 vector
+// instructions per row where the select form (peers &= one ? bal : ~bal on 64-bit values) compiled to about 100, which made a radix pass
+// compute-bound (0.97 ms for 3.4 GB that stream in 0.73). Round 6 also measured a bit set per digit in LDS (every lane ORs its bit in, reads
+// the pair of words, clears its bit): five dependent LDS round trips per row, slower than the ballots (r0 4.08 -> 4.46 ms).
+#define RS_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+__device__ __forceinline__ unsigned long long digit_peers_fast(bool valid, u32 dg)
 {
-    unsigned long long peers = __ballot(valid);
+    const unsigned long long va = __ballot(valid);
+    u32 dlo = 0, dhi = 0;                                   // lanes whose digit differs from mine in some bit
 #pragma unroll
-    for (int bit = 0; bit < 8; bit++) {
-        const bool one = (dg >> bit) & 1u;
-        const unsigned long long bal = __ballot(valid && one);
-        peers &= one ? bal : ~bal;
+    for (int bit = 0; bit < 8; bit += 2) {
+        const int x0 = (int)(dg << (31 - bit)), x1 = (int)(dg << (30 - bit));
+        const unsigned long long b0 = __ballot(x0 < 0), b1 = __ballot(x1 < 0);
+        const u32 m0 = (u32)(x0 >> 31), m1 = (u32)(x1 >> 31);
+        dlo |= ((u32)b0 ^ m0) | ((u32)b1 ^ m1);
+        dhi |= ((u32)(b0 >> 32) ^ m0) | ((u32)(b1 >> 32) ^ m1);
     }
-    return peers;
+    const unsigned long long same = ~(((unsigned long long)dhi << 32) | dlo);
+    return valid ? (same & va) : 0ull;
+}
+__device__ __forceinline__ u32 rs_row_rank(bool valid, u32 dg, u32* cntw, int lane, unsigned long long ltMask)
+{
+    (void)lane;
+    unsigned long long peers;
+    const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)dg);              // (lane 0 is valid when any lane of the row is)
+    if (__ballot(valid && dg != d0) == 0) peers = __ballot(valid);
+    else peers = digit_peers_fast(valid, dg);
+    const u32 rnk = (u32)__popcll(peers & ltMask);
+    const u32 old = valid ? cntw[dg] : 0u;
+    RS_WAVE_FENCE();
+    if (valid && rnk == 0) cntw[dg] = old + (u32)__popcll(peers);              // (the lowest lane of every digit)
+    RS_WAVE_FENCE();
+    return old + rnk;
 }
 
 // Segments: segment g is [base[g], base[g+1]) of the key arrays (dense, base[0] = 0); a tile never straddles segments.
@@ -316,15 +341,7 @@ __device__ __forceinline__ void rs_rank_tile(const u32 (&dg)[16], const bool (&v
     for (int q = tid; q < RS_WAVES * 256; q += RS_THREADS) (&cnt[0][0])[q] = 0;
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const unsigned long long peers = digit_peers(valid[r], dg[r]);
-        const int leader = __ffsll((long long)peers) - 1;
-        u32 old = 0;
-        if (valid[r] && lane == leader) { old = cnt[wave][dg[r]]; cnt[wave][dg[r]] = old + (u32)__popcll(peers); }
-        KNZ_WAVE_ORDER();
-        old = (u32)__shfl((int)old, leader < 0 ? 0 : leader, 64);
-        pos[r] = old + (u32)__popcll(peers & ltMask);
-    }
+    for (int r = 0; r < 16; r++) pos[r] = rs_row_rank(valid[r], dg[r], cnt[wave], lane, ltMask);
     __syncthreads();
     // (digit, wave) order: the first 256 threads own a digit each
     u32 c[RS_WAVES];
@@ -498,15 +515,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_onesweep(SRC src, const u32* 
     for (int q = tid; q < RS_WAVES * 256; q += RS_THREADS) (&cnt[0][0])[q] = 0;
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const unsigned long long peers = digit_peers(valid[r], dg[r]);
-        const int leader = __ffsll((long long)peers) - 1;
-        u32 old = 0;
-        if (valid[r] && lane == leader) { old = cnt[wave][dg[r]]; cnt[wave][dg[r]] = old + (u32)__popcll(peers); }
-        KNZ_WAVE_ORDER();
-        old = (u32)__shfl((int)old, leader < 0 ? 0 : leader, 64);
-        pos[r] = old + (u32)__popcll(peers & ltMask);
-    }
+    for (int r = 0; r < 16; r++) pos[r] = rs_row_rank(valid[r], dg[r], cnt[wave], lane, ltMask);
     __syncthreads();
     u32 c[RS_WAVES];
     u32 mine = 0;
