@@ -109,7 +109,30 @@ __global__ void k_bwt_i_header(BwtView v, BwtHdr* __restrict__ hd, u32* __restri
     }
     base[v.nBlocks] = sum;
     info->total = sum; info->nWords = (sum + 31) / 32; info->count = 0; info->dyn = 0;
+    u32 longest = 0;
+    for (int b = 0; b < v.nBlocks; b++) if (hd[b].okFlag && hd[b].n > longest) longest = hd[b].n;
+    info->pad[2] = longest;                          // (decides the width of the link records: inv_narrow)
 }
+
+// Link records (round 6). A record is the next node, "the next node is a splitter" and the node's symbol. With positions relative to the
+// block's first node a block of up to 8 MiB needs 23 + 1 + 8 bits: the records are 4-byte words then (half the bytes the stable counting
+// sort scatters, half the working set of the walk), 8-byte words otherwise. The stage has no host read-back, so both forms of the two
+// kernels are launched and the one the batch's longest block (InvInfo::pad[2]) does not ask for returns at once.
+constexpr u32 INV_NARROW_MAX = 1u << 23;
+__device__ __forceinline__ bool inv_narrow(const InvInfo* info) { return info->pad[2] <= INV_NARROW_MAX; }
+template <class REC> struct InvRec;
+template <> struct InvRec<u64> {
+    static __device__ __forceinline__ u64 make(u32 nx, u32 bb, bool split, u32 sym) { (void)bb; return (u64)nx | (split ? 0x80000000ull : 0ull) | ((u64)sym << 32); }
+    static __device__ __forceinline__ u32 next(u64 r, u32 bb) { (void)bb; return (u32)r & 0x7FFFFFFFu; }
+    static __device__ __forceinline__ bool split(u64 r) { return (r >> 31) & 1; }
+    static __device__ __forceinline__ u32 sym(u64 r) { return (u32)(r >> 32) & 0xFFu; }
+};
+template <> struct InvRec<u32> {
+    static __device__ __forceinline__ u32 make(u32 nx, u32 bb, bool split, u32 sym) { return (nx - bb) | (split ? 0x800000u : 0u) | (sym << 24); }
+    static __device__ __forceinline__ u32 next(u32 r, u32 bb) { return bb + (r & 0x7FFFFFu); }
+    static __device__ __forceinline__ bool split(u32 r) { return (r >> 23) & 1u; }
+    static __device__ __forceinline__ u32 sym(u32 r) { return r >> 24; }
+};
 
 // ---- list ranking with random splitters (Helman-JaJa style) ------------------------------------
 // Node j = F-position (global slot). rec[j] = next node (31 bits) | "next is a splitter" (bit 31) | symbol << 32.
@@ -206,10 +229,12 @@ __global__ __launch_bounds__(256) void k_bwt_i_scan2(BwtView v, const BwtHdr* __
 
 __device__ __forceinline__ bool is_splitter(u32 node, u32 head, u32 term) { return hash_split(node) || node == head || node == term; }
 
+template <class REC>
 __global__ __launch_bounds__(256) void k_bwt_i_links(BwtView v, const BwtHdr* __restrict__ hd, const u32* __restrict__ base, int perTiles,
                                                      const u32* __restrict__ tileHist, u32 segT, u32 nSeg, const u32* __restrict__ segSum,
-                                                     const u32* __restrict__ Cb, const u32* __restrict__ term, u64* __restrict__ rec)
+                                                     const u32* __restrict__ Cb, const u32* __restrict__ term, REC* __restrict__ rec, const InvInfo* __restrict__ info)
 {
+    if (inv_narrow(info) != (sizeof(REC) == 4)) return;
     const int b = blockIdx.y;
     const BwtHdr h = hd[b];
     if (!h.okFlag || h.n < 2) return;
@@ -253,7 +278,7 @@ __global__ __launch_bounds__(256) void k_bwt_i_links(BwtView v, const BwtHdr* __
         u32 nx;
         if (i == 0) nx = j;                                       // end of text
         else nx = bb + ((i < pIdx) ? i - 1 : i);                  // BWT.cpp:203-215
-        rec[j] = (u64)nx | (is_splitter(nx, head, tm) ? 0x80000000ull : 0ull) | ((u64)sym[r] << 32);
+        rec[j] = InvRec<REC>::make(nx, bb, is_splitter(nx, head, tm), sym[r]);
     }
 }
 
@@ -304,23 +329,26 @@ __device__ __forceinline__ u32 split_rank(const u32* __restrict__ bits, const u3
 constexpr u32 ROW = 128;            // bytes of one row of symbols (sub-lists have 64 nodes on average, 13 % are longer than a row)
 
 // the walk: sub-list length, successor row and the symbols of the sub-list, one thread per splitter
-__global__ __launch_bounds__(256) void k_bwt_i_walk(const u64* __restrict__ rec, const u32* __restrict__ rowNode, const u32* __restrict__ bits,
+template <class REC>
+__global__ __launch_bounds__(256) void k_bwt_i_walk(const REC* __restrict__ rec, const u32* __restrict__ rowNode, const u32* __restrict__ bits,
                                                     const u32* __restrict__ wprefix, InvInfo* __restrict__ info, u32 maxRows, u32* __restrict__ succ,
                                                     u32* __restrict__ dist, u8* __restrict__ rowLen, u8* __restrict__ rows, const u32* __restrict__ base,
                                                     int nBlocks, u32* __restrict__ rowBlk, const u32* __restrict__ wblk)
 {
+    if (inv_narrow(info) != (sizeof(REC) == 4)) return;
     const u32 c = blockIdx.x * 256 + threadIdx.x;
     const u32 count = info->count;
     if (c >= count || c >= maxRows) return;
     u32 node = rowNode[c];
-    u64 r = rec[node];
+    REC r = rec[node];
     // a chain never leaves its block: the block of every row this thread fills, looked up once (the copy kernel needs it per row)
     u32 blk = wblk[node >> 5];
     while (node >= base[blk + 1]) blk++;
     (void)nBlocks;
     rowBlk[c] = blk;
-    if (((u32)r & 0x7FFFFFFFu) == node) {                        // terminal: the last byte of the text
-        succ[c] = c; dist[c] = 0; rowLen[c] = 1; rows[(size_t)c * ROW] = (u8)(r >> 32);
+    const u32 bb = base[blk];
+    if (InvRec<REC>::next(r, bb) == node) {                      // terminal: the last byte of the text
+        succ[c] = c; dist[c] = 0; rowLen[c] = 1; rows[(size_t)c * ROW] = (u8)InvRec<REC>::sym(r);
         return;
     }
     u32 cur = c;
@@ -330,11 +358,11 @@ __global__ __launch_bounds__(256) void k_bwt_i_walk(const u64* __restrict__ rec,
         u64 acc = 0;
         bool done = false;
         for (;;) {
-            acc |= ((r >> 32) & 0xFFull) << (8 * (len & 7));
+            acc |= (u64)InvRec<REC>::sym(r) << (8 * (len & 7));
             len++;
             if ((len & 7) == 0) { row[(len >> 3) - 1] = acc; acc = 0; }
-            nx = (u32)r & 0x7FFFFFFFu;
-            if ((r >> 31) & 1) { done = true; break; }
+            nx = InvRec<REC>::next(r, bb);
+            if (InvRec<REC>::split(r)) { done = true; break; }
             if (len == ROW) break;
             node = nx;
             r = rec[node];
@@ -622,13 +650,17 @@ int launch_bwt_inverse(hipStream_t s, const XfStage& st, void* scratch, size_t s
     { KScope ks_("k_bwt_i_hist"); hipLaunchKernelGGL(k_bwt_i_hist, gridT, dim3(256), 0, s, v, w.hd, perTiles, w.tileHist); }
     { KScope ks_("k_bwt_i_scan"); hipLaunchKernelGGL(k_bwt_i_scan, dim3(nSeg, st.nBlocks), dim3(256), 0, s, w.hd, perTiles, segT, nSeg, w.tileHist, w.segSum);
       hipLaunchKernelGGL(k_bwt_i_scan2, dim3(st.nBlocks), dim3(256), 0, s, v, w.hd, w.base, nSeg, w.segSum, w.Cb, w.term); }
-    { KScope ks_("k_bwt_i_links"); hipLaunchKernelGGL(k_bwt_i_links, gridT, dim3(256), 0, s, v, w.hd, w.base, perTiles, w.tileHist, segT, nSeg, w.segSum, w.Cb, w.term, w.rec); }
+    { KScope ks_("k_bwt_i_links");
+      hipLaunchKernelGGL(k_bwt_i_links<u32>, gridT, dim3(256), 0, s, v, w.hd, w.base, perTiles, w.tileHist, segT, nSeg, w.segSum, w.Cb, w.term, reinterpret_cast<u32*>(w.rec), w.info);
+      hipLaunchKernelGGL(k_bwt_i_links<u64>, gridT, dim3(256), 0, s, v, w.hd, w.base, perTiles, w.tileHist, segT, nSeg, w.segSum, w.Cb, w.term, w.rec, w.info); }
     const u32 nWordsMax = (u32)(maxTotal / 32 + 1);
     { KScope ks_("k_bwt_i_flags"); hipLaunchKernelGGL(k_bwt_i_flags, GRID1(nWordsMax), w.hd, w.base, w.term, st.nBlocks, w.info, w.bits, w.wcount, w.wblk); }
     { KScope ks_("k_bwt_i_scan_words"); prims::launch_scan<prims::SCAN_SUM_EXCL>(s, w.wcount, w.wprefix, nWordsMax, &w.info->nWords, w.scanTmp, &w.info->count); }
     { KScope ks_("k_bwt_i_compact"); hipLaunchKernelGGL(k_bwt_i_compact, GRID1(nWordsMax), w.bits, w.wprefix, w.info, w.maxRows, w.rowNode); }
     const u32 maxCount = (u32)(maxTotal / 48 + 4096 + 3 * (size_t)st.nBlocks);
-    { KScope ks_("k_bwt_i_walk"); hipLaunchKernelGGL(k_bwt_i_walk, GRID1(maxCount), w.rec, w.rowNode, w.bits, w.wprefix, w.info, w.maxRows, w.nA, w.dA, w.rowLen, w.rows, w.base, st.nBlocks, w.rowBlk, w.wblk); }
+    { KScope ks_("k_bwt_i_walk");
+      hipLaunchKernelGGL(k_bwt_i_walk<u32>, GRID1(maxCount), reinterpret_cast<const u32*>(w.rec), w.rowNode, w.bits, w.wprefix, w.info, w.maxRows, w.nA, w.dA, w.rowLen, w.rows, w.base, st.nBlocks, w.rowBlk, w.wblk);
+      hipLaunchKernelGGL(k_bwt_i_walk<u64>, GRID1(maxCount), w.rec, w.rowNode, w.bits, w.wprefix, w.info, w.maxRows, w.nA, w.dA, w.rowLen, w.rows, w.base, st.nBlocks, w.rowBlk, w.wblk); }
     u32* nA = w.nA; u32* nB = w.nB; u32* dA = w.dA; u32* dB = w.dB;
     // chains never leave a block: a chain has at most rows-per-block rows
     const u64 chainRows = (u64)v.VS / 48 + (u64)v.VS / ROW + 4096 + 3;
